@@ -1,0 +1,200 @@
+"""Pin the oracle (oracle/*.py) to golden vectors captured from the imported reference
+(tests/golden/make_golden.py).  CPU only.  Tolerance 1e-5 abs on O(1) activations: the
+reference's own fp32-vs-fp64 noise floor is 6e-6."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fewshot_vit_amd import synthetic
+from oracle import fewshot_oracle as fo
+from oracle import visformer_oracle as vo
+
+TINY_CFG = vo.VisformerCfg(img_size=80, init_channels=8, embed_dim=64, depth=(2, 1, 2), num_heads=6,
+                           mlp_ratio=4.0, group=8)
+FULL_CFG = vo.VisformerCfg()
+
+
+def _nchw(t):
+    return t.detach().numpy()
+
+
+@pytest.fixture(scope='module')
+def tiny(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'tiny_visformer.npz'))
+    shapes = vo.state_dict_shapes(TINY_CFG, prefix='encoder.')
+    sd = synthetic.procedural_state_dict(shapes)
+    return z, sd
+
+
+def test_tiny_bn_calibration_matches_reference(tiny):
+    z, sd = tiny
+    x_cal = synthetic.synthetic_episodes(7, 1, 5, 1, 3)
+    cal = vo.calibrate_bn(sd, x_cal, TINY_CFG, prefix='encoder.')
+    n = 0
+    for k in z.files:
+        if k.startswith('bn.'):
+            ref = z[k]
+            got = cal[k[3:]].numpy()
+            np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-5, err_msg=k)
+            n += 1
+    assert n == 2 * 15        # 15 BatchNorm2d modules in the tiny net
+
+
+def test_tiny_intermediates_match_reference(tiny):
+    z, sd = tiny
+    sd = dict(sd)
+    for k in z.files:
+        if k.startswith('bn.'):
+            sd[k[3:]] = torch.from_numpy(z[k])
+    x = synthetic.synthetic_episodes(21, 1, 2, 1, 0)
+    taps = {}
+    with torch.no_grad():
+        pooled = vo.visformer_forward(sd, x, TINY_CFG, prefix='encoder.', taps=taps)
+    checked = 0
+    for k in z.files:
+        if not k.startswith('tap.'):
+            continue
+        name = k[4:]
+        ref = z[k]
+        got = _nchw(pooled) if name == 'pooled' else _nchw(taps[name])
+        assert got.shape == ref.shape, name
+        err = np.abs(got - ref).max()
+        assert err <= 1e-5 * max(1.0, np.abs(ref).max()), (name, err)
+        checked += 1
+    assert checked >= 12
+
+
+@pytest.fixture(scope='module')
+def full(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'full_visformer_micro_80.npz'))
+    shapes = vo.state_dict_shapes(FULL_CFG, prefix='encoder.')
+    shapes['temp'] = ()
+    sd = synthetic.synthetic_checkpoint_sd(shapes)
+    return z, sd
+
+
+def test_full_state_dict_contract():
+    """Appendix A key/shape table."""
+    sh = vo.state_dict_shapes(FULL_CFG, prefix='encoder.')
+    assert sh['encoder.stem.conv1.weight'] == (64, 3, 3, 3)
+    assert sh['encoder.stage1.0.mlp.conv2.weight'] == (256, 32, 3, 3)
+    assert sh['encoder.stage2.0.attn.qkv.weight'] == (756, 256, 1, 1)
+    assert sh['encoder.stage2.0.attn.proj.weight'] == (256, 252, 1, 1)
+    assert sh['encoder.stage3.0.attn.qkv.weight'] == (1530, 512, 1, 1)
+    assert sh['encoder.stage3.2.attn.proj.weight'] == (512, 510, 1, 1)
+    assert sh['encoder.patch_embed2.proj.weight'] == (256, 128, 2, 2)
+    assert sh['encoder.pos_embed3'] == (1, 512, 5, 5)
+    assert 'encoder.stage1.0.norm1.bn.weight' not in sh
+    n_params = sum(int(np.prod(v)) for k, v in sh.items()
+                   if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked')))
+    assert n_params + 1 == 12531393          # reference parameter count incl. temp
+
+
+def test_full_bn_calibration_matches_shipped_stats(full):
+    z, sd = full
+    shapes = vo.state_dict_shapes(FULL_CFG, prefix='encoder.')
+    raw = synthetic.procedural_state_dict(shapes)
+    x_cal = synthetic.synthetic_episodes(7, 1, 5, 5, 15)
+    cal = vo.calibrate_bn(raw, x_cal, FULL_CFG, prefix='encoder.')
+    stats = synthetic.load_bn_calibration()
+    assert len(stats) == 2 * 21
+    for k, v in stats.items():
+        np.testing.assert_allclose(cal[k].numpy(), v.numpy(), rtol=5e-4, atol=5e-5, err_msg=k)
+
+
+@pytest.mark.parametrize('name,seed,shot', [('5shot', 11, 5), ('1shot', 12, 1)])
+def test_full_logits_match_reference(full, name, seed, shot):
+    z, sd = full
+    x = synthetic.synthetic_episodes(seed, 1, 5, shot, 15)
+    xs, xq = fo.split_shot_query(x.numpy(), 5, shot, 15, 1)
+    logits = vo.meta_baseline_forward(sd, torch.from_numpy(xs), torch.from_numpy(xq), FULL_CFG)
+    ref = z[f'logits_{name}']
+    assert logits.shape == (1, 75, 5)
+    assert np.abs(logits.numpy() - ref).max() <= 2e-5
+
+
+def test_full_taps_and_pooled_match_reference(full):
+    z, sd = full
+    x = synthetic.synthetic_episodes(11, 1, 5, 5, 15)
+    xs, xq = fo.split_shot_query(x.numpy(), 5, 5, 15, 1)
+    xin = torch.from_numpy(np.concatenate([xs.reshape(-1, 3, 80, 80), xq.reshape(-1, 3, 80, 80)]))
+    taps = {}
+    with torch.no_grad():
+        vo.visformer_forward(sd, xin, FULL_CFG, prefix='encoder.', taps=taps)
+        pooled4 = vo.visformer_forward(sd, xin[:4], FULL_CFG, prefix='encoder.')
+    assert np.abs(pooled4.numpy() - z['pooled_first4']).max() <= 1e-5
+    for k in z.files:
+        if k.startswith('tapsample_'):
+            name = k[len('tapsample_'):]
+            got = taps[name][:4].flatten()[::97][:2048].numpy()
+            ref = z[k]
+            assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), name
+            st = z['tapstat_' + name]
+            v = taps[name]
+            np.testing.assert_allclose([float(v.mean()), float(v.std())], st[:2], rtol=1e-4, atol=1e-5)
+
+
+def test_rejects_84x84(full):
+    z, sd = full
+    assert int(z['reject84']) == 1
+    with pytest.raises(AssertionError):
+        vo.visformer_forward(sd, torch.zeros(1, 3, 84, 84), FULL_CFG, prefix='encoder.')
+
+
+# ----------------------------------------------------------------------------- host helpers
+@pytest.fixture(scope='module')
+def ka(golden_dir):
+    with open(os.path.join(golden_dir, 'host_known_answers.json')) as f:
+        return json.load(f)
+
+
+def test_sampler_stream(ka):
+    label = np.repeat(np.arange(20), 600).tolist()
+    np.random.seed(12345)
+    eps = [b.tolist() for b in fo.categories_sampler(label, 3, 5, 16, 1)]
+    assert eps == ka['sampler_seed12345_20x600_3x5x16']
+    # SURVEY.md 8c known answers
+    e0 = np.array(eps[0]).reshape(5, 16)
+    assert e0[:, 0].tolist() == [8274, 5265, 10187, 1959, 9374]
+    assert [int(np.sum(e)) for e in eps] == [551747, 466074, 744432]
+    np.random.seed(0)
+    sums = [int(b.sum()) for b in fo.categories_sampler(label, 2, 5, 20, 4)]
+    assert sums == ka['sampler_seed0_20x600_2x(4ep)x5x20_sum']
+
+
+def test_labels_and_split(ka):
+    assert fo.make_nk_label(5, 3, 2).tolist() == ka['make_nk_label_5_3_2']
+    xs, xq = fo.split_shot_query(np.arange(20), 5, 1, 3, 1)
+    g = ka['split_arange20_5_1_3']
+    assert xs.flatten().tolist() == g['shot'] and xq.flatten().tolist() == g['query']
+    assert list(xs.shape) == g['shot_shape'] and list(xq.shape) == g['query_shape']
+    xs, xq = fo.split_shot_query(np.arange(30), 3, 2, 3, 2)
+    g = ka['split_arange30_3_2_3_ep2']
+    assert xs.flatten().tolist() == g['shot'] and xq.flatten().tolist() == g['query']
+    assert list(xs.shape) == g['shot_shape'] and list(xq.shape) == g['query_shape']
+
+
+def test_ci_acc_ce_averager(ka):
+    assert abs(fo.mean_confidence_interval([.6, .8, .7, .9, .5]) - ka['mci_.6_.8_.7_.9_.5']) < 1e-12
+    assert abs(ka['mci_.6_.8_.7_.9_.5'] - 0.19632431614775608) < 1e-12
+    a = ka['acc_ce']
+    logits, lab = np.array(a['logits'], dtype=np.float32), np.array(a['label'])
+    assert fo.compute_acc(logits, lab) == pytest.approx(a['acc'], abs=1e-7)
+    assert fo.cross_entropy(logits, lab) == pytest.approx(a['ce'], abs=1e-6)
+    av = fo.Averager()
+    for v, n in ((0.5, 80), (0.75, 100), (0.2, 3)):
+        av.add(v, n)
+    assert av.item() == pytest.approx(ka['averager'], abs=1e-12)
+
+
+def test_compute_logits(ka):
+    c = ka['compute_logits']
+    feat, proto = torch.tensor(c['feat']), torch.tensor(c['proto'])
+    for key, metric, temp in (('dot_t2', 'dot', 2.0), ('cos_t10', 'cos', 10.0), ('sqr_t1', 'sqr', 1.0)):
+        got = vo.compute_logits(feat, proto, metric, temp).numpy()
+        assert np.abs(got - np.array(c[key])).max() < 2e-6, key
+    got = vo.compute_logits(feat[0], proto[0], 'dot', 1.0).numpy()
+    assert np.abs(got - np.array(c['dot2d'])).max() < 2e-6
