@@ -1,0 +1,90 @@
+"""ctypes binding of libfsvit.so (C-ABI declared in include/fsvit.h).
+
+There is deliberately NO fallback: if the shared library is missing or fails to load, importing
+the engine raises — the product path never silently runs on anything but the HIP kernels.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libfsvit.so')
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_LRELU = 0, 1, 2
+HEAD_COS, HEAD_SQR, HEAD_DOT = 0, 1, 2
+ERR_ARG, ERR_KEY, ERR_IMG_SIZE, ERR_WORKSPACE = -1, -2, -3, -4
+
+
+class Tensor(C.Structure):
+    _fields_ = [('name', C.c_char_p), ('data', C.POINTER(C.c_float)), ('ndim', C.c_int),
+                ('shape', C.c_int64 * 4)]
+
+
+class VisformerCfg(C.Structure):
+    _fields_ = [('img_size', C.c_int), ('init_channels', C.c_int), ('embed_dim', C.c_int),
+                ('depth', C.c_int * 3), ('num_heads', C.c_int), ('mlp_ratio', C.c_float),
+                ('group', C.c_int), ('bn_eps', C.c_float)]
+
+
+# name -> (restype, argtypes); every symbol include/fsvit.h declares
+_vp, _fp, _i, _f, _sz = C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_size_t
+SIGNATURES = {
+    'fsvit_last_error': (C.c_char_p, []),
+    'fsvit_version': (C.c_char_p, []),
+    'fsvit_visformer_create': (_i, [C.POINTER(VisformerCfg), C.POINTER(Tensor), _i, _i, C.POINTER(_vp)]),
+    'fsvit_visformer_destroy': (None, [_vp]),
+    'fsvit_visformer_out_dim': (_i, [_vp]),
+    'fsvit_visformer_dtype': (_i, [_vp]),
+    'fsvit_visformer_workspace_bytes': (_sz, [_vp, _i]),
+    'fsvit_visformer_forward': (_i, [_vp, _fp, _i, _i, _i, _fp, _vp, _sz, _vp]),
+    'fsvit_visformer_set_tap': (_i, [_vp, C.c_char_p, _vp, _sz]),
+    'fsvit_proto_head': (_i, [_fp, _fp, _i, _i, _i, _i, _i, _f, _i, _fp, _fp, _fp, _vp]),
+    'fsvit_meta_baseline_forward': (_i, [_vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _i, _fp, _fp, _fp, _fp,
+                                         _vp, _sz, _vp]),
+    'fsvit_conv_gemm': (_i, [_vp, _vp, _fp, _vp, _fp, _vp] + [_i] * 15 + [_i, _vp]),
+    'fsvit_attention': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    'fsvit_im2col27': (_i, [_fp, _vp, _i, _i, _i, _i, _vp]),
+    'fsvit_maxpool2_pos': (_i, [_vp, _fp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'fsvit_pool_affine': (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libfsvit.so once; raises ImportError (loudly) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} not found: build the HIP extension first '
+            f'(python -c "import __graft_entry__ as g; g.build()" or make -C few-shot-vit_amd/csrc). '
+            f'There is no CPU/PyTorch fallback for the fsvit hot path.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class FsvitError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f'fsvit error {code}: {msg}')
+        self.code = code
+
+
+def check(rc):
+    """Map the C return code to the exception the reference would raise for the same mistake."""
+    if rc == 0:
+        return
+    msg = load().fsvit_last_error().decode()
+    if rc == ERR_KEY:
+        raise KeyError(msg)                 # load_state_dict / registry lookups
+    if rc == ERR_IMG_SIZE:
+        raise AssertionError(msg)           # PatchEmbed assert (visformer.py:283-284)
+    if rc == ERR_ARG:
+        raise ValueError(msg)
+    raise FsvitError(rc, msg)

@@ -1,0 +1,43 @@
+// Implicit-GEMM convolution / 1x1-conv GEMM on MFMA with a fused epilogue.
+//
+//   y[m, g*N + n] = epi( sum_k x_patch[m, g, k] * w[g, n, k] )      m = (b, oy, ox), k = (ky, kx, c)
+//   epi(v) = v + bias[n];  (+res if res_first);  act;  (+res if !res_first);  + pos[m % (OH*OW), n]
+//
+// Covers every conv of the Visformer eval path with folded BatchNorm (test_phase/models/visformer.py:
+// stem conv2/conv3 :211-213, Mlp conv1/conv2/conv3 :146-150, Attention qkv/proj :175-177,
+// PatchEmbed proj :276) and, after a 27->32 im2col, stem conv1/downsample (:209,:216).
+#pragma once
+#include <stddef.h>
+#include <hip/hip_runtime.h>
+
+namespace fsvit {
+
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_LRELU = 2 };
+
+struct ConvGemmParams {
+  const void* x;       // activations NHWC [B, H, W, x_cstride]
+  const void* w;       // packed weights [groups][N][Kw], K order (ky, kx, c), rows zero-padded to Kw
+  const float* bias;   // [groups*N] or nullptr
+  const void* res;     // residual [M, y_cstride] or nullptr (same dtype as y)
+  const float* pos;    // [OH*OW, y_cstride] fp32 or nullptr
+  void* y;             // [M, y_cstride]
+  int B, H, W;
+  int Cin;             // input channels per group
+  int x_cstride;       // channels per input pixel (all groups)
+  int OH, OW;
+  int KH, KW, stride, pad;
+  int N;               // output channels per group
+  int y_cstride;       // channels per output pixel (all groups)
+  int K;               // KH*KW*Cin
+  int Kw;              // packed weight row length (K rounded up to the 128-byte K slice)
+  int M;               // B*OH*OW
+  int groups;
+  int act;             // enum Act
+  int res_first;       // 1: residual is added before the activation (stem), 0: after (blocks)
+  int log2Cin;         // valid when KH*KW > 1
+};
+
+// dtype: 0 = f32 (exact fp32 MFMA), 1 = bf16.  Returns hipError_t as int.
+int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream);
+
+}  // namespace fsvit

@@ -1,0 +1,194 @@
+// Implicit-GEMM convolution on gfx950 MFMA (see conv_gemm.h for the math and reference lines).
+//
+// Work decomposition: a 256-thread workgroup (4 wave64) owns a BM x BN tile of the
+// [M = B*OH*OW] x [N] output of one group; the K = KH*KW*Cin reduction runs in 128-byte slices
+// (64 bf16 / 32 fp32).  Both operands are K-contiguous in memory (NHWC activations, [N][K] packed
+// weights), are gathered 16 bytes per lane (zero-filled at image borders / tile tails), and are
+// staged through a double-buffered LDS tile whose 16-byte chunks are XOR-swizzled with (row & 7)
+// so that both the ds_write_b128 staging and the ds_read_b128 fragment reads are conflict-free
+// (tools/lds_conflicts.py).  The MFMA computes the TRANSPOSED tile  D^T[n][m] = W[n][:] . X[m][:]
+// so every lane ends up with 4 consecutive output channels of one pixel -> 8/16-byte stores.
+#include "conv_gemm.h"
+#include "fsvit_common.h"
+
+namespace fsvit {
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
+  constexpr int EPC = Elem<T>::kPerChunk;
+  constexpr int BKE = Elem<T>::kBK;
+  constexpr int TM = BM / WAVES_M / 16;
+  constexpr int TN = BN / WAVES_N / 16;
+  constexpr int A_IT = BM / 32;
+  constexpr int B_IT = BN / 32;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows are staged 32 per pass");
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * 128];
+  unsigned char* const ldsA0 = smem;                    // X tile, buffer 0 / 1
+  unsigned char* const ldsB0 = smem + 2 * BM * 128;     // W tile, buffer 0 / 1
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = t >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int c = t & 7;          // 16-byte chunk of the 128-byte K slice this thread stages
+  const int r0 = t >> 3;        // first tile row this thread stages (then +32 per pass)
+
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int g = blockIdx.z;
+
+  const T* __restrict__ X = reinterpret_cast<const T*>(p.x) + (size_t)g * p.Cin;
+  const T* __restrict__ Wt = reinterpret_cast<const T*>(p.w) + (size_t)g * p.N * p.Kw;
+
+  // ---- per-thread row decode for the activation gather
+  const int ohw = p.OH * p.OW;
+  int iy0[A_IT], ix0[A_IT];
+  int pixbase[A_IT];
+  bool rowok[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    int m = m0 + r0 + 32 * i;
+    rowok[i] = m < p.M;
+    int mm = rowok[i] ? m : 0;
+    int b = mm / ohw;
+    int rem = mm - b * ohw;
+    int oy = rem / p.OW;
+    int ox = rem - oy * p.OW;
+    iy0[i] = oy * p.stride - p.pad;
+    ix0[i] = ox * p.stride - p.pad;
+    pixbase[i] = b * p.H * p.W;
+  }
+  bool nok[B_IT];
+  const T* wrow[B_IT];
+#pragma unroll
+  for (int j = 0; j < B_IT; ++j) {
+    int n = n0 + r0 + 32 * j;
+    nok[j] = n < p.N;
+    wrow[j] = Wt + (size_t)(nok[j] ? n : 0) * p.Kw + c * EPC;
+  }
+  const bool multi_tap = (p.KH * p.KW) > 1;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  u32x4 ra[A_IT], rb[B_IT];
+  auto gload = [&](int kt) {
+    const int k = kt * BKE + c * EPC;
+    int ky = 0, kx = 0, cc = k;
+    if (multi_tap) {
+      int tap = k >> p.log2Cin;
+      cc = k & (p.Cin - 1);
+      ky = tap / p.KW;
+      kx = tap - ky * p.KW;
+    }
+    const bool kok = k < p.K;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int iy = iy0[i] + ky, ix = ix0[i] + kx;
+      bool ok = kok && rowok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const T* src = X + (size_t)(pixbase[i] + iy * p.W + ix) * p.x_cstride + cc;
+      ra[i] = ok ? *reinterpret_cast<const u32x4*>(src) : zero4;
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j)
+      rb[j] = nok[j] ? *reinterpret_cast<const u32x4*>(wrow[j] + (size_t)kt * BKE) : zero4;
+  };
+  const int wswz = ((c ^ (r0 & 7)) << 4);
+  auto lstore = [&](int buf) {
+    unsigned char* a = ldsA0 + buf * (BM * 128) + r0 * 128 + wswz;
+    unsigned char* b = ldsB0 + buf * (BN * 128) + r0 * 128 + wswz;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) *reinterpret_cast<u32x4*>(a + i * 32 * 128) = ra[i];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) *reinterpret_cast<u32x4*>(b + j * 32 * 128) = rb[j];
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int lrow = lane & 15;
+  const int lq = lane >> 4;
+  const int rswz = lane & 7;
+  auto compute = [&](int buf) {
+    const unsigned char* a = ldsA0 + buf * (BM * 128) + (wm * TM * 16 + lrow) * 128;
+    const unsigned char* b = ldsB0 + buf * (BN * 128) + (wn * TN * 16 + lrow) * 128;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      const int off = (((kc * 4 + lq) ^ rswz) << 4);
+      u32x4 xf[TM], wf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const u32x4*>(a + i * 16 * 128 + off);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const u32x4*>(b + j * 16 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mma_chunk<T>(wf[j], xf[i], acc[i][j]);
+    }
+  };
+
+  const int nk = p.Kw / BKE;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    compute(cur);
+    if (kt + 1 < nk) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds n = nb + 0..3 (consecutive channels) of pixel m
+  T* __restrict__ Y = reinterpret_cast<T*>(p.y);
+  const T* __restrict__ R = reinterpret_cast<const T*>(p.res);
+  const int cg = g * p.N;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * TM * 16 + i * 16 + lrow;
+    if (m >= p.M) continue;
+    const size_t rowoff = (size_t)m * p.y_cstride + cg;
+    const float* posrow = p.pos ? p.pos + (size_t)(m % ohw) * p.y_cstride + cg : nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * TN * 16 + j * 16 + lq * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + cg + n);
+      f32x4 r = {0.f, 0.f, 0.f, 0.f};
+      if (R) r = load4<T>(R + rowoff + n);
+      if (p.res_first) v += r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+      if (!p.res_first) v += r;
+      if (posrow) v += *reinterpret_cast<const f32x4*>(posrow + n);
+      store4<T>(Y + rowoff + n, v);
+    }
+  }
+}
+
+template <typename T>
+static int launch_t(const ConvGemmParams& p, hipStream_t stream) {
+  dim3 block(256);
+  if (p.N > 64) {
+    dim3 grid((p.M + 127) / 128, (p.N + 127) / 128, p.groups);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 128, 2, 2>), grid, block, 0, stream, p);
+  } else if (p.N > 32) {
+    dim3 grid((p.M + 127) / 128, 1, p.groups);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 64, 2, 2>), grid, block, 0, stream, p);
+  } else {
+    dim3 grid((p.M + 127) / 128, 1, p.groups);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 32, 4, 1>), grid, block, 0, stream, p);
+  }
+  return (int)hipGetLastError();
+}
+
+int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream) {
+  if (p.M <= 0) return 0;
+  return dtype == 0 ? launch_t<float>(p, stream) : launch_t<bf16>(p, stream);
+}
+
+}  // namespace fsvit

@@ -1,0 +1,564 @@
+// fsvit engine: state-dict packing (eval BatchNorm folding, K-major weight layout, head-dim
+// padding), the Visformer eval forward as a fixed chain of kernel launches on one HIP stream, and
+// the extern "C" boundary declared in include/fsvit.h.
+#include "../../include/fsvit.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cstdint>
+#include <initializer_list>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace fsvit;
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+static int hipfail(hipError_t e, const char* what) {
+  return fail((int)e, "%s: %s", what, hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t _e = (expr);                             \
+    if (_e != hipSuccess) return hipfail(_e, #expr);    \
+  } while (0)
+#define RC_TRY(expr)                                                              \
+  do {                                                                            \
+    int _rc = (expr);                                                             \
+    if (_rc != 0) return _rc > 0 ? hipfail((hipError_t)_rc, #expr) : _rc;         \
+  } while (0)
+
+extern "C" const char* fsvit_last_error(void) { return g_err; }
+extern "C" const char* fsvit_version(void) { return "fsvit 0.1.0 gfx950"; }
+
+// ------------------------------------------------------------------------------------ helpers
+static inline uint16_t f32_to_bf16(float f) {   // round to nearest even
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+struct Layer {
+  void* w = nullptr;      // [groups][N][Kw] storage dtype
+  float* bias = nullptr;  // [groups*N] fp32 or null
+  int N = 0, K = 0, Kw = 0, groups = 1;
+};
+struct Block1 { Layer c1, c2, c3; };
+struct BlockA { Layer qkv, proj, fc1, fc2; };
+
+struct Tap { void* dst; size_t bytes; };
+
+struct fsvit_visformer {
+  fsvit_visformer_cfg cfg;
+  int dtype = 0, es = 4;
+  int C0 = 0, C1 = 0, C2 = 0, C3 = 0;
+  int H0 = 0, H1 = 0, H2 = 0, H3 = 0;
+  int hid1 = 0, hid2 = 0, hid3 = 0;
+  int hd2 = 0, hdp2 = 0, hd3 = 0, hdp3 = 0;
+  Layer conv1, down, conv2, conv3, pe2, pe3;
+  float *pos1 = nullptr, *pos2 = nullptr, *pos3 = nullptr;
+  std::vector<Block1> s1;
+  std::vector<BlockA> s2, s3;
+  float *fscale = nullptr, *fshift = nullptr;
+  std::map<std::string, Tap> taps;
+  std::vector<void*> allocs;
+};
+
+namespace {
+
+struct SD {
+  const fsvit_tensor* t;
+  int n;
+  const fsvit_tensor* find(const std::string& name) const {
+    for (int i = 0; i < n; ++i)
+      if (name == t[i].name) return &t[i];
+    return nullptr;
+  }
+  // returns nullptr + sets error when missing / mis-shaped
+  const float* get(const std::string& name, std::initializer_list<int64_t> shape) const {
+    const fsvit_tensor* x = find(name);
+    if (!x) { fail(FSVIT_ERR_KEY, "missing key in state_dict: %s", name.c_str()); return nullptr; }
+    bool ok = x->ndim == (int)shape.size() && x->data != nullptr;
+    int i = 0;
+    for (int64_t s : shape) { if (ok && x->shape[i] != s) ok = false; ++i; }
+    if (!ok) { fail(FSVIT_ERR_KEY, "size mismatch for %s", name.c_str()); return nullptr; }
+    return x->data;
+  }
+};
+
+struct Affine { std::vector<double> s, t; bool ok = false; };
+
+Affine bn_affine(const SD& sd, const std::string& p, int C, double eps) {
+  Affine a;
+  const float* w = sd.get(p + ".weight", {C});
+  const float* b = sd.get(p + ".bias", {C});
+  const float* m = sd.get(p + ".running_mean", {C});
+  const float* v = sd.get(p + ".running_var", {C});
+  if (!w || !b || !m || !v) return a;
+  a.s.resize(C); a.t.resize(C);
+  for (int c = 0; c < C; ++c) {
+    a.s[c] = (double)w[c] / std::sqrt((double)v[c] + eps);
+    a.t[c] = (double)b[c] - (double)m[c] * a.s[c];
+  }
+  a.ok = true;
+  return a;
+}
+
+int upload(fsvit_visformer* h, const std::vector<float>& src, bool as_storage, void** out) {
+  void* d = nullptr;
+  if (as_storage && h->dtype == FSVIT_BF16) {
+    std::vector<uint16_t> tmp(src.size());
+    for (size_t i = 0; i < src.size(); ++i) tmp[i] = f32_to_bf16(src[i]);
+    HIP_TRY(hipMalloc(&d, tmp.size() * 2));
+    h->allocs.push_back(d);
+    HIP_TRY(hipMemcpy(d, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+  } else {
+    HIP_TRY(hipMalloc(&d, src.size() * 4));
+    h->allocs.push_back(d);
+    HIP_TRY(hipMemcpy(d, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+  }
+  *out = d;
+  return 0;
+}
+
+// Pack a conv weight W[O][Ig][KH][KW] (O = groups*N) into [groups][N][Kw], k = (ky*KW+kx)*Ig + c,
+// with optional per-output-channel scale (BN after the conv) and per-input-channel scale (BN before
+// a 1x1 conv).  `rowmap`/`colmap` (optional) scatter rows / K columns (head-dim padding).
+int pack_layer(fsvit_visformer* h, Layer* L, const float* W, int O, int Ig, int KH, int KW, int groups,
+               const std::vector<double>* out_scale, const std::vector<double>* in_scale,
+               const std::vector<double>& bias, bool has_bias,
+               const std::vector<int>* rowmap, int Npad, const std::vector<int>* colmap, int Kpad) {
+  const int bke = 128 / h->es;
+  const int N = (rowmap ? Npad : O) / groups;
+  const int K = colmap ? Kpad : KH * KW * Ig;
+  const int Kw = round_up(K, bke);
+  std::vector<float> pk((size_t)groups * N * Kw, 0.0f);
+  std::vector<float> pb((size_t)groups * N, 0.0f);
+  for (int o = 0; o < O; ++o) {
+    const int row = rowmap ? (*rowmap)[o] : o;
+    const double so = out_scale ? (*out_scale)[o] : 1.0;
+    for (int c = 0; c < Ig; ++c) {
+      const double si = in_scale ? (*in_scale)[c] : 1.0;
+      for (int ky = 0; ky < KH; ++ky)
+        for (int kx = 0; kx < KW; ++kx) {
+          int k = (ky * KW + kx) * Ig + c;
+          if (colmap) k = (*colmap)[k];
+          pk[(size_t)row * Kw + k] = (float)((double)W[(((size_t)o * Ig + c) * KH + ky) * KW + kx] * so * si);
+        }
+    }
+    if (has_bias) pb[row] = (float)bias[o];
+  }
+  L->N = N; L->K = K; L->Kw = Kw; L->groups = groups;
+  RC_TRY(upload(h, pk, true, &L->w));
+  if (has_bias) { void* b; RC_TRY(upload(h, pb, false, &b)); L->bias = (float*)b; }
+  return 0;
+}
+
+// bias[n] = sum_c W[n][c] * t[c]  for a 1x1 conv that follows a BatchNorm
+std::vector<double> prenorm_bias(const float* W, int O, int C, const std::vector<double>& t) {
+  std::vector<double> b(O, 0.0);
+  for (int o = 0; o < O; ++o) {
+    double s = 0.0;
+    for (int c = 0; c < C; ++c) s += (double)W[(size_t)o * C + c] * t[c];
+    b[o] = s;
+  }
+  return b;
+}
+
+// pos_embed [1,C,H,W] -> [H*W][C] fp32 (+ optional per-channel constant)
+int pack_pos(fsvit_visformer* h, const float* pos, int C, int HW, float** out) {
+  std::vector<float> p((size_t)HW * C);
+  for (int c = 0; c < C; ++c)
+    for (int i = 0; i < HW; ++i) p[(size_t)i * C + c] = pos[(size_t)c * HW + i];
+  void* d; RC_TRY(upload(h, p, false, &d));
+  *out = (float*)d;
+  return 0;
+}
+
+int build(fsvit_visformer* h, const SD& sd) {
+  const fsvit_visformer_cfg& cf = h->cfg;
+  const double eps = cf.bn_eps;
+  const int epc = 16 / h->es;
+  const int D = cf.embed_dim;
+  h->C0 = cf.init_channels; h->C1 = D / 2; h->C2 = D; h->C3 = D * 2;
+  if (cf.img_size % 16 != 0) return fail(FSVIT_ERR_ARG, "img_size %d must be a multiple of 16", cf.img_size);
+  h->H0 = cf.img_size / 2; h->H1 = cf.img_size / 4; h->H2 = cf.img_size / 8; h->H3 = cf.img_size / 16;
+  if (cf.group < 2) return fail(FSVIT_ERR_ARG, "group < 2 ('net' setting, visformer.py:137-138) is not supported");
+  h->hid1 = h->C1 * 2;
+  h->hid2 = (int)(h->C2 * cf.mlp_ratio);
+  h->hid3 = (int)(h->C3 * cf.mlp_ratio);
+  const int kch = 64 / h->es;                                  // head dim padded to the 64-byte MFMA K chunk
+  h->hd2 = (int)std::lround((double)(h->C2 / cf.num_heads));  // round(dim // heads * 1.0), visformer.py:172
+  h->hd3 = (int)std::lround((double)(h->C3 / cf.num_heads));
+  h->hdp2 = round_up(h->hd2, kch); h->hdp3 = round_up(h->hd3, kch);
+  const int Cg = h->hid1 / cf.group;
+  if (h->C0 % epc || h->C1 % epc || h->hid1 % cf.group || Cg % epc)
+    return fail(FSVIT_ERR_ARG, "channel counts must be multiples of %d for 16-byte K chunks", epc);
+  if (!is_pow2(h->C0) || !is_pow2(h->C1) || !is_pow2(h->C2) || !is_pow2(Cg))
+    return fail(FSVIT_ERR_ARG, "multi-tap conv input channels must be powers of two");
+  if (h->H2 * h->H2 > 128) return fail(FSVIT_ERR_ARG, "attention supports at most 128 tokens (img_size <= 88)");
+
+  std::vector<double> nob;
+  // ---- stem (visformer.py:202-239): conv -> BN folded as per-output-channel scale + shift
+  {
+    const float* w1 = sd.get("stem.conv1.weight", {h->C0, 3, 3, 3});
+    const float* wd = sd.get("stem.downsample.0.weight", {h->C1, 3, 3, 3});
+    const float* w2 = sd.get("stem.conv2.weight", {h->C1, h->C0, 3, 3});
+    const float* w3 = sd.get("stem.conv3.weight", {h->C1, h->C1, 3, 3});
+    Affine b1 = bn_affine(sd, "stem.bn1", h->C0, eps), b2 = bn_affine(sd, "stem.bn2", h->C1, eps);
+    Affine b3 = bn_affine(sd, "stem.bn3", h->C1, eps), bd = bn_affine(sd, "stem.downsample.1", h->C1, eps);
+    if (!w1 || !wd || !w2 || !w3 || !b1.ok || !b2.ok || !b3.ok || !bd.ok) return FSVIT_ERR_KEY;
+    // conv1 / downsample consume the 32-wide im2col rows: K columns 0..26 = (ky,kx,c), 27..31 = 0
+    std::vector<int> cm(27);
+    for (int k = 0; k < 27; ++k) cm[k] = k;
+    RC_TRY(pack_layer(h, &h->conv1, w1, h->C0, 3, 3, 3, 1, &b1.s, nullptr, b1.t, true, nullptr, 0, &cm, 32));
+    RC_TRY(pack_layer(h, &h->down, wd, h->C1, 3, 3, 3, 1, &bd.s, nullptr, bd.t, true, nullptr, 0, &cm, 32));
+    RC_TRY(pack_layer(h, &h->conv2, w2, h->C1, h->C0, 3, 3, 1, &b2.s, nullptr, b2.t, true, nullptr, 0, nullptr, 0));
+    RC_TRY(pack_layer(h, &h->conv3, w3, h->C1, h->C1, 3, 3, 1, &b3.s, nullptr, b3.t, true, nullptr, 0, nullptr, 0));
+  }
+  {
+    const float* p1 = sd.get("pos_embed1", {1, h->C1, h->H1, h->H1});
+    const float* p2 = sd.get("pos_embed2", {1, h->C2, h->H2, h->H2});
+    const float* p3 = sd.get("pos_embed3", {1, h->C3, h->H3, h->H3});
+    if (!p1 || !p2 || !p3) return FSVIT_ERR_KEY;
+    RC_TRY(pack_pos(h, p1, h->C1, h->H1 * h->H1, &h->pos1));
+    RC_TRY(pack_pos(h, p2, h->C2, h->H2 * h->H2, &h->pos2));
+    RC_TRY(pack_pos(h, p3, h->C3, h->H3 * h->H3, &h->pos3));
+  }
+  // ---- stage 1 (Block with attn_disabled, spatial_conv; visformer.py:241-263, Mlp :127-163)
+  h->s1.resize(cf.depth[0]);
+  for (int i = 0; i < cf.depth[0]; ++i) {
+    const std::string p = "stage1." + std::to_string(i) + ".";
+    Affine n2 = bn_affine(sd, p + "norm2.bn", h->C1, eps);
+    const float* w1 = sd.get(p + "mlp.conv1.weight", {h->hid1, h->C1, 1, 1});
+    const float* w2 = sd.get(p + "mlp.conv2.weight", {h->hid1, Cg, 3, 3});
+    const float* w3 = sd.get(p + "mlp.conv3.weight", {h->C1, h->hid1, 1, 1});
+    if (!n2.ok || !w1 || !w2 || !w3) return FSVIT_ERR_KEY;
+    RC_TRY(pack_layer(h, &h->s1[i].c1, w1, h->hid1, h->C1, 1, 1, 1, nullptr, &n2.s, prenorm_bias(w1, h->hid1, h->C1, n2.t), true, nullptr, 0, nullptr, 0));
+    RC_TRY(pack_layer(h, &h->s1[i].c2, w2, h->hid1, Cg, 3, 3, cf.group, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
+    RC_TRY(pack_layer(h, &h->s1[i].c3, w3, h->C1, h->hid1, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
+  }
+  // ---- patch embeds (visformer.py:266-288): conv k2 s2 + bias -> BN ; pos_embed added in the epilogue
+  for (int s = 2; s <= 3; ++s) {
+    const int Ci = s == 2 ? h->C1 : h->C2, Co = s == 2 ? h->C2 : h->C3;
+    const std::string p = "patch_embed" + std::to_string(s) + ".";
+    const float* w = sd.get(p + "proj.weight", {Co, Ci, 2, 2});
+    const float* b = sd.get(p + "proj.bias", {Co});
+    Affine bn = bn_affine(sd, p + "norm.bn", Co, eps);
+    if (!w || !b || !bn.ok) return FSVIT_ERR_KEY;
+    std::vector<double> bias(Co);
+    for (int o = 0; o < Co; ++o) bias[o] = bn.s[o] * (double)b[o] + bn.t[o];
+    RC_TRY(pack_layer(h, s == 2 ? &h->pe2 : &h->pe3, w, Co, Ci, 2, 2, 1, &bn.s, nullptr, bias, true, nullptr, 0, nullptr, 0));
+  }
+  // ---- stages 2, 3 (attention + MLP blocks; Attention :166-194, Block :259-263)
+  for (int s = 2; s <= 3; ++s) {
+    const int C = s == 2 ? h->C2 : h->C3, hid = s == 2 ? h->hid2 : h->hid3;
+    const int hd = s == 2 ? h->hd2 : h->hd3, hdp = s == 2 ? h->hdp2 : h->hdp3;
+    const int heads = cf.num_heads;
+    if (C % epc || hid % epc) return fail(FSVIT_ERR_ARG, "channel counts must be multiples of %d", epc);
+    std::vector<BlockA>& blocks = s == 2 ? h->s2 : h->s3;
+    blocks.resize(cf.depth[s - 1]);
+    // head-dim padding: qkv rows (x, y, z) -> x*heads*hdp + y*hdp + z ; proj K columns (y, z) -> y*hdp + z
+    std::vector<int> rowmap(3 * heads * hd), colmap(heads * hd);
+    for (int x = 0; x < 3; ++x)
+      for (int y = 0; y < heads; ++y)
+        for (int z = 0; z < hd; ++z) rowmap[(x * heads + y) * hd + z] = (x * heads + y) * hdp + z;
+    for (int y = 0; y < heads; ++y)
+      for (int z = 0; z < hd; ++z) colmap[y * hd + z] = y * hdp + z;
+    for (int i = 0; i < cf.depth[s - 1]; ++i) {
+      const std::string p = "stage" + std::to_string(s) + "." + std::to_string(i) + ".";
+      Affine n1 = bn_affine(sd, p + "norm1.bn", C, eps), n2 = bn_affine(sd, p + "norm2.bn", C, eps);
+      const float* wq = sd.get(p + "attn.qkv.weight", {3 * heads * hd, C, 1, 1});
+      const float* wp = sd.get(p + "attn.proj.weight", {C, heads * hd, 1, 1});
+      const float* w1 = sd.get(p + "mlp.conv1.weight", {hid, C, 1, 1});
+      const float* w3 = sd.get(p + "mlp.conv3.weight", {C, hid, 1, 1});
+      if (!n1.ok || !n2.ok || !wq || !wp || !w1 || !w3) return FSVIT_ERR_KEY;
+      RC_TRY(pack_layer(h, &blocks[i].qkv, wq, 3 * heads * hd, C, 1, 1, 1, nullptr, &n1.s, prenorm_bias(wq, 3 * heads * hd, C, n1.t), true, &rowmap, 3 * heads * hdp, nullptr, 0));
+      RC_TRY(pack_layer(h, &blocks[i].proj, wp, C, heads * hd, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, &colmap, heads * hdp));
+      RC_TRY(pack_layer(h, &blocks[i].fc1, w1, hid, C, 1, 1, 1, nullptr, &n2.s, prenorm_bias(w1, hid, C, n2.t), true, nullptr, 0, nullptr, 0));
+      RC_TRY(pack_layer(h, &blocks[i].fc2, w3, C, hid, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
+    }
+  }
+  // ---- final BN -> pooled feature affine (visformer.py:455-462)
+  {
+    Affine bn = bn_affine(sd, "norm.bn", h->C3, eps);
+    if (!bn.ok) return FSVIT_ERR_KEY;
+    std::vector<float> s(h->C3), t(h->C3);
+    for (int c = 0; c < h->C3; ++c) { s[c] = (float)bn.s[c]; t[c] = (float)bn.t[c]; }
+    void* d; RC_TRY(upload(h, s, false, &d)); h->fscale = (float*)d;
+    RC_TRY(upload(h, t, false, &d)); h->fshift = (float*)d;
+  }
+  return 0;
+}
+
+// ---- workspace plan for a chunk of Bc images
+struct Plan {
+  size_t patches, c1, ident, c2, c3;     // stem scratch
+  size_t ha, hb;                         // stage-1 hidden
+  size_t qkv, ctx, hid;                  // stage-2/3 scratch
+  size_t x1, x2, x3;                     // residual streams
+  size_t total;
+};
+
+size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+Plan make_plan(const fsvit_visformer* h, size_t Bc) {
+  Plan p;
+  const size_t es = h->es, P0 = (size_t)h->H0 * h->H0, P1 = (size_t)h->H1 * h->H1, P2 = (size_t)h->H2 * h->H2, P3 = (size_t)h->H3 * h->H3;
+  const int heads = h->cfg.num_heads;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
+  p.x1 = take(Bc * P1 * h->C1 * es);
+  p.x2 = take(Bc * P2 * h->C2 * es);
+  p.x3 = take(Bc * P3 * h->C3 * es);
+  const size_t scratch0 = off;
+  // stem
+  p.patches = take(Bc * P0 * 32 * es);
+  p.c1 = take(Bc * P0 * h->C0 * es);
+  p.ident = take(Bc * P0 * h->C1 * es);
+  p.c2 = take(Bc * P0 * h->C1 * es);
+  p.c3 = take(Bc * P0 * h->C1 * es);
+  size_t hi = off;
+  // stage 1 (reuses the stem scratch)
+  off = scratch0;
+  p.ha = take(Bc * P1 * h->hid1 * es);
+  p.hb = take(Bc * P1 * h->hid1 * es);
+  if (off > hi) hi = off;
+  // stage 2 / 3 (same offsets, sized for the larger)
+  off = scratch0;
+  size_t q2 = Bc * P2 * 3 * heads * h->hdp2 * es, q3 = Bc * P3 * 3 * heads * h->hdp3 * es;
+  size_t c2 = Bc * P2 * heads * h->hdp2 * es, c3 = Bc * P3 * heads * h->hdp3 * es;
+  size_t h2 = Bc * P2 * h->hid2 * es, h3 = Bc * P3 * h->hid3 * es;
+  p.qkv = take(q2 > q3 ? q2 : q3);
+  p.ctx = take(c2 > c3 ? c2 : c3);
+  p.hid = take(h2 > h3 ? h2 : h3);
+  if (off > hi) hi = off;
+  p.total = hi;
+  return p;
+}
+
+ConvGemmParams conv_params(const Layer& L, const void* x, void* y, int B, int H, int W, int Cin, int x_cstride,
+                           int KH, int KW, int stride, int pad, int y_cstride, int act,
+                           const void* res, int res_first, const float* pos) {
+  ConvGemmParams p;
+  p.x = x; p.w = L.w; p.bias = L.bias; p.res = res; p.pos = pos; p.y = y;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.x_cstride = x_cstride;
+  p.OH = (H + 2 * pad - KH) / stride + 1; p.OW = (W + 2 * pad - KW) / stride + 1;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+  p.N = L.N; p.y_cstride = y_cstride; p.K = L.K; p.Kw = L.Kw; p.M = B * p.OH * p.OW;
+  p.groups = L.groups; p.act = act; p.res_first = res_first; p.log2Cin = ilog2(Cin);
+  return p;
+}
+
+int tap(fsvit_visformer* h, const std::string& name, const void* src, size_t bytes, bool first, hipStream_t st) {
+  if (!first || h->taps.empty()) return 0;
+  auto it = h->taps.find(name);
+  if (it == h->taps.end() || it->second.dst == nullptr) return 0;
+  size_t n = bytes < it->second.bytes ? bytes : it->second.bytes;
+  HIP_TRY(hipMemcpyAsync(it->second.dst, src, n, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsigned char* ws, bool first, hipStream_t st) {
+  const Plan pl = make_plan(h, Bc);
+  const int dt = h->dtype;
+  const size_t es = h->es;
+  const int heads = h->cfg.num_heads;
+  void *patches = ws + pl.patches, *c1 = ws + pl.c1, *ident = ws + pl.ident, *c2 = ws + pl.c2, *c3 = ws + pl.c3;
+  void *x1 = ws + pl.x1, *x2 = ws + pl.x2, *x3 = ws + pl.x3, *ha = ws + pl.ha, *hb = ws + pl.hb;
+  void *qkv = ws + pl.qkv, *ctx = ws + pl.ctx, *hid = ws + pl.hid;
+  const int img = h->cfg.img_size;
+
+  // stem: conv1 / downsample as K=32 GEMMs over the im2col rows, conv2, conv3 (+identity, LeakyReLU), max-pool + pos1
+  RC_TRY(launch_im2col27(x, patches, Bc, img, img, h->H0, h->H0, dt, st));
+  RC_TRY(launch_conv_gemm(conv_params(h->conv1, patches, c1, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C0, ACT_LRELU, nullptr, 0, nullptr), dt, st));
+  RC_TRY(launch_conv_gemm(conv_params(h->down, patches, ident, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C1, ACT_NONE, nullptr, 0, nullptr), dt, st));
+  RC_TRY(launch_conv_gemm(conv_params(h->conv2, c1, c2, Bc, h->H0, h->H0, h->C0, h->C0, 3, 3, 1, 1, h->C1, ACT_LRELU, nullptr, 0, nullptr), dt, st));
+  RC_TRY(launch_conv_gemm(conv_params(h->conv3, c2, c3, Bc, h->H0, h->H0, h->C1, h->C1, 3, 3, 1, 1, h->C1, ACT_LRELU, ident, 1, nullptr), dt, st));
+  RC_TRY(launch_maxpool2_pos(c3, h->pos1, x1, Bc, h->H1, h->H1, h->C1, dt, st));
+  RC_TRY(tap(h, "stem", x1, (size_t)Bc * h->H1 * h->H1 * h->C1 * es, first, st));
+
+  // stage 1: x += conv3(GELU(conv2_g(GELU(conv1(BN(x))))))
+  const int Cg = h->hid1 / h->cfg.group;
+  for (size_t i = 0; i < h->s1.size(); ++i) {
+    const Block1& b = h->s1[i];
+    RC_TRY(launch_conv_gemm(conv_params(b.c1, x1, ha, Bc, h->H1, h->H1, h->C1, h->C1, 1, 1, 1, 0, h->hid1, ACT_GELU, nullptr, 0, nullptr), dt, st));
+    RC_TRY(launch_conv_gemm(conv_params(b.c2, ha, hb, Bc, h->H1, h->H1, Cg, h->hid1, 3, 3, 1, 1, h->hid1, ACT_GELU, nullptr, 0, nullptr), dt, st));
+    RC_TRY(launch_conv_gemm(conv_params(b.c3, hb, x1, Bc, h->H1, h->H1, h->hid1, h->hid1, 1, 1, 1, 0, h->C1, ACT_NONE, x1, 0, nullptr), dt, st));
+    RC_TRY(tap(h, "stage1." + std::to_string(i), x1, (size_t)Bc * h->H1 * h->H1 * h->C1 * es, first, st));
+  }
+
+  // stages 2 and 3
+  for (int s = 2; s <= 3; ++s) {
+    const int Ci = s == 2 ? h->C1 : h->C2, C = s == 2 ? h->C2 : h->C3;
+    const int Hi = s == 2 ? h->H1 : h->H2, Ho = s == 2 ? h->H2 : h->H3;
+    const int hidc = s == 2 ? h->hid2 : h->hid3, hd = s == 2 ? h->hd2 : h->hd3, hdp = s == 2 ? h->hdp2 : h->hdp3;
+    void* xin = s == 2 ? x1 : x2;
+    void* xs = s == 2 ? x2 : x3;
+    const Layer& pe = s == 2 ? h->pe2 : h->pe3;
+    const float* pos = s == 2 ? h->pos2 : h->pos3;
+    const size_t xbytes = (size_t)Bc * Ho * Ho * C * es;
+    RC_TRY(launch_conv_gemm(conv_params(pe, xin, xs, Bc, Hi, Hi, Ci, Ci, 2, 2, 2, 0, C, ACT_NONE, nullptr, 0, pos), dt, st));
+    RC_TRY(tap(h, "patch_embed" + std::to_string(s), xs, xbytes, first, st));
+    const std::vector<BlockA>& blocks = s == 2 ? h->s2 : h->s3;
+    const float scale = 1.0f / std::sqrt((float)hd);                       // head_dim ** -0.5 (visformer.py:174)
+    for (size_t i = 0; i < blocks.size(); ++i) {
+      const BlockA& b = blocks[i];
+      RC_TRY(launch_conv_gemm(conv_params(b.qkv, xs, qkv, Bc, Ho, Ho, C, C, 1, 1, 1, 0, 3 * heads * hdp, ACT_NONE, nullptr, 0, nullptr), dt, st));
+      RC_TRY(launch_attention(qkv, ctx, Bc, Ho * Ho, heads, hdp, scale, dt, st));
+      RC_TRY(launch_conv_gemm(conv_params(b.proj, ctx, xs, Bc, Ho, Ho, heads * hdp, heads * hdp, 1, 1, 1, 0, C, ACT_NONE, xs, 0, nullptr), dt, st));
+      RC_TRY(launch_conv_gemm(conv_params(b.fc1, xs, hid, Bc, Ho, Ho, C, C, 1, 1, 1, 0, hidc, ACT_GELU, nullptr, 0, nullptr), dt, st));
+      RC_TRY(launch_conv_gemm(conv_params(b.fc2, hid, xs, Bc, Ho, Ho, hidc, hidc, 1, 1, 1, 0, C, ACT_NONE, xs, 0, nullptr), dt, st));
+      RC_TRY(tap(h, "stage" + std::to_string(s) + "." + std::to_string(i), xs, xbytes, first, st));
+    }
+  }
+  RC_TRY(launch_pool_affine(x3, h->fscale, h->fshift, feat, Bc, h->H3 * h->H3, h->C3, dt, st));
+  return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ C ABI
+extern "C" int fsvit_visformer_create(const fsvit_visformer_cfg* cfg, const fsvit_tensor* state_dict, int n_tensors,
+                                      int dtype, fsvit_visformer** out) {
+  if (!cfg || !state_dict || !out || n_tensors <= 0) return fail(FSVIT_ERR_ARG, "null argument");
+  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  if (cfg->num_heads < 1 || cfg->embed_dim < 2 || cfg->init_channels < 1 || cfg->depth[0] < 0 || cfg->depth[1] < 0 || cfg->depth[2] < 0)
+    return fail(FSVIT_ERR_ARG, "bad Visformer configuration");
+  fsvit_visformer* h = new fsvit_visformer();
+  h->cfg = *cfg;
+  h->dtype = dtype;
+  h->es = dtype == FSVIT_F32 ? 4 : 2;
+  SD sd{state_dict, n_tensors};
+  int rc = build(h, sd);
+  if (rc != 0) { fsvit_visformer_destroy(h); return rc; }
+  *out = h;
+  return 0;
+}
+
+extern "C" void fsvit_visformer_destroy(fsvit_visformer* h) {
+  if (!h) return;
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+}
+
+extern "C" int fsvit_visformer_out_dim(const fsvit_visformer* h) { return h ? h->C3 : 0; }
+extern "C" int fsvit_visformer_dtype(const fsvit_visformer* h) { return h ? h->dtype : -1; }
+
+extern "C" size_t fsvit_visformer_workspace_bytes(const fsvit_visformer* h, int chunk_images) {
+  if (!h || chunk_images <= 0) return 0;
+  return make_plan(h, (size_t)chunk_images).total;
+}
+
+extern "C" int fsvit_visformer_set_tap(fsvit_visformer* h, const char* name, void* dst_dev, size_t bytes) {
+  if (!h || !name) return fail(FSVIT_ERR_ARG, "null argument");
+  if (!dst_dev) h->taps.erase(name);
+  else h->taps[name] = Tap{dst_dev, bytes};
+  return 0;
+}
+
+extern "C" int fsvit_visformer_forward(fsvit_visformer* h, const float* x, int n_img, int img_h, int img_w,
+                                       float* feat, void* ws, size_t ws_bytes, void* stream) {
+  if (!h || !x || !feat || !ws) return fail(FSVIT_ERR_ARG, "null argument");
+  if (img_h != h->cfg.img_size || img_w != h->cfg.img_size)   // PatchEmbed assert / pos_embed mismatch (visformer.py:283-284,431)
+    return fail(FSVIT_ERR_IMG_SIZE, "Input image size (%d*%d) does not match model (%d*%d).", img_h, img_w, h->cfg.img_size, h->cfg.img_size);
+  if (n_img <= 0) return 0;
+  if (((uintptr_t)ws & 255) != 0) return fail(FSVIT_ERR_ARG, "workspace must be 256-byte aligned");
+  // largest chunk that fits the workspace (plan size is monotone in the chunk)
+  int lo = 0, hi = n_img;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) / 2;
+    if (make_plan(h, (size_t)mid).total <= ws_bytes) lo = mid; else hi = mid - 1;
+  }
+  if (lo < 1) return fail(FSVIT_ERR_WORKSPACE, "workspace of %zu bytes cannot hold one image (need %zu)", ws_bytes, make_plan(h, 1).total);
+  const int chunk = lo;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t img_elems = (size_t)3 * img_h * img_w;
+  for (int off = 0; off < n_img; off += chunk) {
+    const int bc = n_img - off < chunk ? n_img - off : chunk;
+    int rc = forward_chunk(h, x + (size_t)off * img_elems, bc, feat + (size_t)off * h->C3, (unsigned char*)ws, off == 0, st);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
+extern "C" int fsvit_proto_head(const float* fs, const float* fq, int E, int way, int shot, int Q, int D, float temp,
+                                int method, float* logits, float* acc, float* loss, void* stream) {
+  if (!fs || !fq || !logits) return fail(FSVIT_ERR_ARG, "null argument");
+  if (method != FSVIT_HEAD_COS && method != FSVIT_HEAD_SQR && method != FSVIT_HEAD_DOT) return fail(FSVIT_ERR_ARG, "unknown head method %d", method);
+  RC_TRY(launch_proto_head(fs, fq, E, way, shot, Q, D, temp, method, logits, acc, loss, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int fsvit_meta_baseline_forward(fsvit_visformer* h, const float* x_shot, const float* x_query, int E, int way,
+                                           int shot, int Q, int img_h, int img_w, float temp, int method, float* logits,
+                                           float* acc, float* loss, float* feat, void* ws, size_t ws_bytes, void* stream) {
+  if (!h || !feat) return fail(FSVIT_ERR_ARG, "null argument");
+  const int ns = E * way * shot, nq = E * Q;
+  // the reference encodes cat([shots, queries]) in one call (meta_baseline.py:29-32); eval mode is
+  // per-image independent, so two passes into one feature buffer are equivalent
+  int rc = fsvit_visformer_forward(h, x_shot, ns, img_h, img_w, feat, ws, ws_bytes, stream);
+  if (rc != 0) return rc;
+  rc = fsvit_visformer_forward(h, x_query, nq, img_h, img_w, feat + (size_t)ns * h->C3, ws, ws_bytes, stream);
+  if (rc != 0) return rc;
+  return fsvit_proto_head(feat, feat + (size_t)ns * h->C3, E, way, shot, Q, h->C3, temp, method, logits, acc, loss, stream);
+}
+
+extern "C" int fsvit_conv_gemm(const void* x, const void* w, const float* bias, const void* res, const float* pos, void* y,
+                               int B, int H, int W, int Cin, int x_cstride, int KH, int KW, int stride, int pad, int N,
+                               int y_cstride, int Kw, int groups, int act, int res_first, int dtype, void* stream) {
+  if (!x || !w || !y) return fail(FSVIT_ERR_ARG, "null argument");
+  const int es = dtype == FSVIT_F32 ? 4 : 2, epc = 16 / es, bke = 128 / es;
+  if (Cin % epc || x_cstride % epc || N % 4 || y_cstride % 4 || Kw % bke || Kw < KH * KW * Cin)
+    return fail(FSVIT_ERR_ARG, "conv_gemm alignment: Cin/x_cstride %% %d, N/y_cstride %% 4, Kw %% %d", epc, bke);
+  if (KH * KW > 1 && !is_pow2(Cin)) return fail(FSVIT_ERR_ARG, "multi-tap conv needs power-of-two Cin");
+  Layer L; L.w = const_cast<void*>(w); L.bias = const_cast<float*>(bias); L.N = N; L.K = KH * KW * Cin; L.Kw = Kw; L.groups = groups;
+  ConvGemmParams p = conv_params(L, x, y, B, H, W, Cin, x_cstride, KH, KW, stride, pad, y_cstride, act, res, res_first, pos);
+  RC_TRY(launch_conv_gemm(p, dtype, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int fsvit_attention(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, void* stream) {
+  if (!qkv || !ctx) return fail(FSVIT_ERR_ARG, "null argument");
+  int rc = launch_attention(qkv, ctx, B, S, heads, hdp, scale, dtype, (hipStream_t)stream);
+  if (rc != 0) return hipfail((hipError_t)rc, "attention");
+  return 0;
+}
+
+extern "C" int fsvit_im2col27(const float* x, void* out, int B, int H, int W, int dtype, void* stream) {
+  if (!x || !out || (H & 1) || (W & 1)) return fail(FSVIT_ERR_ARG, "bad argument");
+  RC_TRY(launch_im2col27(x, out, B, H, W, H / 2, W / 2, dtype, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int fsvit_maxpool2_pos(const void* in, const float* pos, void* out, int B, int OH, int OW, int C, int dtype, void* stream) {
+  if (!in || !out || C % 4) return fail(FSVIT_ERR_ARG, "bad argument");
+  RC_TRY(launch_maxpool2_pos(in, pos, out, B, OH, OW, C, dtype, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float* shift, float* feat, int B, int HW, int C,
+                                 int dtype, void* stream) {
+  if (!x || !scale || !shift || !feat || C % 4) return fail(FSVIT_ERR_ARG, "bad argument");
+  RC_TRY(launch_pool_affine(x, scale, shift, feat, B, HW, C, dtype, (hipStream_t)stream));
+  return 0;
+}

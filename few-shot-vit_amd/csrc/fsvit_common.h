@@ -1,0 +1,87 @@
+// Shared device/host helpers for the fsvit gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "conv_gemm.h"
+
+namespace fsvit {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+typedef __bf16 bf16;
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kPerChunk = 4;      // elements per 16-byte chunk
+  static constexpr int kBK = 32;           // elements per 128-byte K slice
+};
+template <> struct Elem<bf16> {
+  static constexpr int kPerChunk = 8;
+  static constexpr int kBK = 64;
+};
+
+// One 64-byte K chunk of a 16x16 output tile: `a` and `b` are the 16 bytes this lane read from
+// row (lane&15) at K offset (lane>>4)*16 bytes of the two K-contiguous operands.
+// bf16: one v_mfma_f32_16x16x32_bf16.  f32: four v_mfma_f32_16x16x4_f32 (exact fp32 fma chain);
+// MFMA j consumes element j of every lane's chunk, i.e. a fixed permutation of k shared by
+// both operands, so the dot product covers each k exactly once.
+template <typename T> __device__ __forceinline__ f32x4 mma_chunk(u32x4 a, u32x4 b, f32x4 acc);
+template <> __device__ __forceinline__ f32x4 mma_chunk<bf16>(u32x4 a, u32x4 b, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mma_chunk<float>(u32x4 a, u32x4 b, f32x4 acc) {
+  f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[0], fb[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[1], fb[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[2], fb[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[3], fb[3], acc, 0, 0, 0);
+  return acc;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == ACT_GELU) return gelu_erf(v);
+  if (act == ACT_LRELU) return v > 0.0f ? v : 0.1f * v;
+  return v;
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// 4 consecutive elements <-> 4 floats
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load4<bf16>(const bf16* p) {
+  bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+  f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  return r;
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
+  bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+  *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace fsvit

@@ -1,0 +1,124 @@
+// Episode head kernels.
+//  * pool_affine: final BatchNorm (eval, folded to scale/shift) + AdaptiveAvgPool2d(1) + flatten
+//    (test_phase/models/visformer.py:455-462): feat[b][c] = scale[c] * mean_hw x[b][hw][c] + shift[c].
+//  * proto_head: MetaBaseline head (test_phase/models/meta_baseline.py:33-47) with
+//    utils.compute_logits 'dot' after F.normalize / 'sqr' (utils/__init__.py:78-101), plus the
+//    per-episode accuracy and mean cross-entropy of the eval loop (test_few_shot.py:89-90,
+//    utils/__init__.py:104-109) so the host needs no per-episode device sync.
+//    One workgroup per episode; wavefront reductions (DPP/shuffle) for norms and dots.
+#include "fsvit_common.h"
+#include "kernels.h"
+
+namespace fsvit {
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_affine_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, float* __restrict__ feat,
+                                                          int HW, int C) {
+  const int b = blockIdx.x;
+  const T* xb = x + (size_t)b * HW * C;
+  const float inv = 1.0f / (float)HW;
+  for (int c4 = threadIdx.x; c4 < C / 4; c4 += 256) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < HW; ++p) acc += load4<T>(xb + (size_t)p * C + c4 * 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+    *reinterpret_cast<f32x4*>(feat + (size_t)b * C + c4 * 4) = acc * inv * sc + sh;
+  }
+}
+
+int launch_pool_affine(const void* x, const float* scale, const float* shift, float* feat, int B, int HW, int C, int dtype, hipStream_t s) {
+  if (B <= 0) return 0;
+  dim3 grid(B), block(256);
+  if (dtype == 0) hipLaunchKernelGGL(pool_affine_kernel<float>, grid, block, 0, s, (const float*)x, scale, shift, feat, HW, C);
+  else hipLaunchKernelGGL(pool_affine_kernel<bf16>, grid, block, 0, s, (const bf16*)x, scale, shift, feat, HW, C);
+  return (int)hipGetLastError();
+}
+
+// method: 0 = 'cos' (normalise both, dot), 1 = 'sqr' (negative squared distance to the mean prototype),
+//         2 = 'dot' (plain dot product with the mean prototype)
+__global__ __launch_bounds__(256) void proto_head_kernel(const float* __restrict__ feat_shot, const float* __restrict__ feat_query,
+                                                         int way, int shot, int Q, int D, float temp, int method,
+                                                         float* __restrict__ logits, float* __restrict__ acc, float* __restrict__ loss) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* proto = reinterpret_cast<float*>(smem);              // [way][D]
+  float* qstat = proto + (size_t)way * D;                     // [Q][2]: correct flag, nll
+  const int e = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* fs = feat_shot + (size_t)e * way * shot * D;
+  const float* fq = feat_query + (size_t)e * Q * D;
+
+  // prototypes: mean over shots (meta_baseline.py:37 / :42)
+  for (int i = t; i < way * D; i += 256) {
+    const int c = i / D, d = i - c * D;
+    float s = 0.f;
+    for (int k = 0; k < shot; ++k) s += fs[((size_t)c * shot + k) * D + d];
+    proto[i] = s / (float)shot;
+  }
+  __syncthreads();
+  if (method == 0) {                                          // F.normalize(proto), eps 1e-12 (:38)
+    for (int c = wave; c < way; c += 4) {
+      float ss = 0.f;
+      for (int d = lane; d < D; d += 64) ss += proto[c * D + d] * proto[c * D + d];
+      const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+      for (int d = lane; d < D; d += 64) proto[c * D + d] *= inv;
+    }
+    __syncthreads();
+  }
+  const int per = Q / way;                                    // queries per class (make_nk_label, few_shot.py:13-16)
+  for (int q = wave; q < Q; q += 4) {
+    const float* x = fq + (size_t)q * D;
+    float inv = 1.0f;
+    if (method == 0) {
+      float ss = 0.f;
+      for (int d = lane; d < D; d += 64) ss += x[d] * x[d];
+      inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);        // F.normalize(query) (:39)
+    }
+    float best = -INFINITY, mx = -INFINITY;
+    int arg = 0;
+    float* lrow = logits + ((size_t)e * Q + q) * way;
+    float lab_logit = 0.f;
+    const int label = per > 0 ? q / per : 0;
+    for (int c = 0; c < way; ++c) {
+      float s = 0.f;
+      if (method != 1) {
+        for (int d = lane; d < D; d += 64) s += (x[d] * inv) * proto[c * D + d];
+      } else {
+        for (int d = lane; d < D; d += 64) { const float df = x[d] - proto[c * D + d]; s -= df * df; }
+      }
+      const float l = wave_sum(s) * temp;
+      if (lane == 0) lrow[c] = l;
+      if (l > best) { best = l; arg = c; }                    // first maximum, as torch.argmax
+      mx = fmaxf(mx, l);
+      if (c == label) lab_logit = l;
+    }
+    // cross entropy of this query: logsumexp - logit[label]; logits recomputed from global (L1-hot)
+    if (lane == 0) {
+      float se = 0.f;
+      for (int c = 0; c < way; ++c) se += expf(lrow[c] - mx);
+      qstat[q * 2 + 0] = (arg == label) ? 1.0f : 0.0f;
+      qstat[q * 2 + 1] = mx + logf(se) - lab_logit;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    float a = 0.f, l = 0.f;
+    for (int q = 0; q < Q; ++q) { a += qstat[q * 2]; l += qstat[q * 2 + 1]; }
+    if (acc) acc[e] = a / (float)Q;
+    if (loss) loss[e] = l / (float)Q;
+  }
+}
+
+int launch_proto_head(const float* feat_shot, const float* feat_query, int E, int way, int shot, int Q, int D,
+                      float temp, int method, float* logits, float* acc, float* loss, hipStream_t s) {
+  if (E <= 0) return 0;
+  const size_t lds = ((size_t)way * D + (size_t)Q * 2) * sizeof(float);
+  if (lds > 160 * 1024 || way < 1 || shot < 1 || Q < 1) return (int)hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute((const void*)proto_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(proto_head_kernel, dim3(E), dim3(256), lds, s, feat_shot, feat_query, way, shot, Q, D, temp, method,
+                     logits, acc, loss);
+  return (int)hipGetLastError();
+}
+
+}  // namespace fsvit

@@ -1,0 +1,22 @@
+// Internal launchers of the fsvit gfx950 kernels (dtype: 0 = f32, 1 = bf16 storage).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "conv_gemm.h"
+
+namespace fsvit {
+
+int launch_im2col27(const float* x_nchw, void* out, int B, int H, int W, int OH, int OW, int dtype, hipStream_t s);
+int launch_maxpool2_pos(const void* in, const float* pos, void* out, int B, int OH, int OW, int C, int dtype, hipStream_t s);
+
+// qkv [B*S][3*heads*hdp] (channel = x*heads*hdp + y*hdp + z) -> ctx [B*S][heads*hdp]
+int launch_attention(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, hipStream_t s);
+size_t attention_lds_bytes(int S, int hdp, int dtype);
+
+// x [B][HW][C] -> feat [B][C] fp32 = scale[c] * mean_hw(x) + shift[c]
+int launch_pool_affine(const void* x, const float* scale, const float* shift, float* feat, int B, int HW, int C, int dtype, hipStream_t s);
+
+// cosine / squared-distance prototype head (meta_baseline.py:33-47, utils/__init__.py:78-109)
+int launch_proto_head(const float* feat_shot, const float* feat_query, int E, int way, int shot, int Q, int D,
+                      float temp, int method, float* logits, float* acc, float* loss, hipStream_t s);
+
+}  // namespace fsvit

@@ -1,0 +1,223 @@
+"""Python face of the C-ABI: device-pointer plumbing only (torch owns memory and streams).
+
+`VisformerEngine` wraps one packed `fsvit_visformer` handle; `ops` exposes the operator-level
+entry points used by the parity tests.  Every call goes through libfsvit.so — see `_lib.py`.
+"""
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+DTYPES = {'f32': _lib.F32, 'parity': _lib.F32, 'fp32': _lib.F32, 'bf16': _lib.BF16}
+TORCH_DTYPE = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16}
+
+
+def default_numerics() -> str:
+    """'bf16' (throughput mode) unless FSVIT_NUMERICS=parity|f32 selects exact-fp32 MFMA."""
+    return os.environ.get('FSVIT_NUMERICS', 'bf16')
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('fsvit kernels run on an MI355X only: tensor is on %s (no CPU fallback)' % t.device)
+
+
+class VisformerEngine:
+    """Packed eval-mode Visformer on one GPU.
+
+    cfg: dict(img_size, init_channels, embed_dim, depth, num_heads, mlp_ratio, group[, bn_eps])
+    state_dict: encoder-relative keys -> tensors (any device); reference layout.
+    """
+
+    def __init__(self, cfg: dict, state_dict: Dict[str, torch.Tensor], numerics: str = None, device=None,
+                 chunk_images: int = None):
+        self.lib = _lib.load()
+        numerics = numerics or default_numerics()
+        if numerics not in DTYPES:
+            raise ValueError(f'unknown numerics mode {numerics!r} (bf16 | parity)')
+        self.dtype = DTYPES[numerics]
+        self.device = torch.device(device if device is not None else 'cuda')
+        if self.device.type != 'cuda':
+            raise RuntimeError('VisformerEngine needs a GPU device (no CPU fallback)')
+        self.chunk_images = int(chunk_images or os.environ.get('FSVIT_CHUNK', 400))
+        c = _lib.VisformerCfg()
+        c.img_size, c.init_channels, c.embed_dim = cfg['img_size'], cfg['init_channels'], cfg['embed_dim']
+        for i in range(3):
+            c.depth[i] = cfg['depth'][i]
+        c.num_heads, c.mlp_ratio, c.group = cfg['num_heads'], cfg.get('mlp_ratio', 4.0), cfg.get('group', 8)
+        c.bn_eps = cfg.get('bn_eps', 1e-5)
+        self.img_size = cfg['img_size']
+        keep, arr = [], (_lib.Tensor * len(state_dict))()
+        n = 0
+        for k, v in state_dict.items():
+            if k.endswith('num_batches_tracked'):
+                continue
+            a = np.ascontiguousarray(v.detach().to('cpu', torch.float32).numpy())
+            keep.append(a)
+            arr[n].name = k.encode()
+            arr[n].data = a.ctypes.data_as(C.POINTER(C.c_float))
+            arr[n].ndim = a.ndim
+            for i, s in enumerate(a.shape):
+                arr[n].shape[i] = s
+            n += 1
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fsvit_visformer_create(C.byref(c), arr, n, self.dtype, C.byref(h)))
+        self.h = h
+        self.out_dim = self.lib.fsvit_visformer_out_dim(h)
+        self._ws = None
+        self._taps = {}
+
+    def __del__(self):
+        h, self.h = getattr(self, 'h', None), None
+        if h:
+            try:
+                self.lib.fsvit_visformer_destroy(h)
+            except Exception:       # interpreter shutdown
+                pass
+
+    def workspace(self, n_img: int) -> torch.Tensor:
+        chunk = max(1, min(n_img, self.chunk_images))
+        need = self.lib.fsvit_visformer_workspace_bytes(self.h, chunk)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def set_tap(self, name: str, shape) -> torch.Tensor:
+        t = torch.zeros(shape, dtype=TORCH_DTYPE[self.dtype], device=self.device)
+        _lib.check(self.lib.fsvit_visformer_set_tap(self.h, name.encode(), _ptr(t), t.numel() * t.element_size()))
+        self._taps[name] = t
+        return t
+
+    def forward(self, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        """x [B,3,H,W] fp32 cuda -> pooled features [B,out_dim] fp32."""
+        _require_cuda(x)
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError('expected [B,3,H,W] input')
+        x = x.contiguous().float()
+        B = x.shape[0]
+        if out is None:
+            out = torch.empty(B, self.out_dim, dtype=torch.float32, device=x.device)
+        ws = self.workspace(B)
+        with torch.cuda.device(x.device):
+            _lib.check(self.lib.fsvit_visformer_forward(self.h, _ptr(x), B, x.shape[2], x.shape[3], _ptr(out), _ptr(ws),
+                                                        ws.numel(), _stream_ptr(x.device)))
+        return out
+
+    def meta_baseline_forward(self, x_shot, x_query, temp: float, method: str = 'cos', want_stats=False):
+        """x_shot [E,way,shot,3,H,W], x_query [E,Q,3,H,W] -> logits [E,Q,way] (+ per-episode acc, loss)."""
+        _require_cuda(x_shot, x_query)
+        E, way, shot = x_shot.shape[:3]
+        Q = x_query.shape[1]
+        x_shot = x_shot.contiguous().float()
+        x_query = x_query.contiguous().float()
+        dev = x_shot.device
+        feat = torch.empty(E * way * shot + E * Q, self.out_dim, dtype=torch.float32, device=dev)
+        logits = torch.empty(E, Q, way, dtype=torch.float32, device=dev)
+        acc = torch.empty(E, dtype=torch.float32, device=dev)
+        loss = torch.empty(E, dtype=torch.float32, device=dev)
+        ws = self.workspace(max(E * way * shot, E * Q))
+        m = {'cos': _lib.HEAD_COS, 'sqr': _lib.HEAD_SQR, 'dot': _lib.HEAD_DOT}[method]
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.fsvit_meta_baseline_forward(
+                self.h, _ptr(x_shot), _ptr(x_query), E, way, shot, Q, x_shot.shape[-2], x_shot.shape[-1], float(temp), m,
+                _ptr(logits), _ptr(acc), _ptr(loss), _ptr(feat), _ptr(ws), ws.numel(), _stream_ptr(dev)))
+        if want_stats:
+            return logits, acc, loss
+        return logits
+
+
+class ops:
+    """Operator-level entry points (storage dtype follows the input tensors: fp32 or bf16)."""
+
+    @staticmethod
+    def _dt(t):
+        if t.dtype == torch.float32:
+            return _lib.F32
+        if t.dtype == torch.bfloat16:
+            return _lib.BF16
+        raise TypeError(t.dtype)
+
+    @staticmethod
+    def conv_gemm(x, w, bias, res, pos, B, H, W, Cin, KH, KW, stride, pad, N, groups, act, res_first, x_cstride=None):
+        """x NHWC [B,H,W,x_cstride]; w [groups][N][Kw] packed; returns y NHWC [B,OH,OW,groups*N]."""
+        _require_cuda(x, w)
+        lib = _lib.load()
+        OH = (H + 2 * pad - KH) // stride + 1
+        OW = (W + 2 * pad - KW) // stride + 1
+        x_cstride = x_cstride or x.shape[-1]
+        y = torch.empty(B, OH, OW, groups * N, dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.fsvit_conv_gemm(_ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(pos), _ptr(y), B, H, W, Cin, x_cstride,
+                                           KH, KW, stride, pad, N, groups * N, w.shape[-1], groups, act, int(res_first),
+                                           ops._dt(x), _stream_ptr(x.device)))
+        return y
+
+    @staticmethod
+    def attention(qkv, B, S, heads, hdp, scale):
+        _require_cuda(qkv)
+        lib = _lib.load()
+        ctx = torch.empty(B * S, heads * hdp, dtype=qkv.dtype, device=qkv.device)
+        with torch.cuda.device(qkv.device):
+            _lib.check(lib.fsvit_attention(_ptr(qkv), _ptr(ctx), B, S, heads, hdp, float(scale), ops._dt(qkv), _stream_ptr(qkv.device)))
+        return ctx
+
+    @staticmethod
+    def im2col27(x, dtype):
+        _require_cuda(x)
+        lib = _lib.load()
+        B, _, H, W = x.shape
+        out = torch.empty(B * (H // 2) * (W // 2), 32, dtype=dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.fsvit_im2col27(_ptr(x.contiguous()), _ptr(out), B, H, W, ops._dt(out), _stream_ptr(x.device)))
+        return out
+
+    @staticmethod
+    def maxpool2_pos(x, pos):
+        _require_cuda(x)
+        lib = _lib.load()
+        B, H, W, Cc = x.shape
+        out = torch.empty(B, H // 2, W // 2, Cc, dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.fsvit_maxpool2_pos(_ptr(x), _ptr(pos), _ptr(out), B, H // 2, W // 2, Cc, ops._dt(x), _stream_ptr(x.device)))
+        return out
+
+    @staticmethod
+    def pool_affine(x, scale, shift):
+        _require_cuda(x)
+        lib = _lib.load()
+        B, HW, Cc = x.shape
+        out = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.fsvit_pool_affine(_ptr(x), _ptr(scale), _ptr(shift), _ptr(out), B, HW, Cc, ops._dt(x), _stream_ptr(x.device)))
+        return out
+
+    @staticmethod
+    def proto_head(feat_shot, feat_query, temp, method='cos'):
+        """feat_shot [E,way,shot,D], feat_query [E,Q,D] fp32 -> logits [E,Q,way], acc [E], loss [E]."""
+        _require_cuda(feat_shot, feat_query)
+        lib = _lib.load()
+        E, way, shot, D = feat_shot.shape
+        Q = feat_query.shape[1]
+        dev = feat_shot.device
+        logits = torch.empty(E, Q, way, dtype=torch.float32, device=dev)
+        acc = torch.empty(E, dtype=torch.float32, device=dev)
+        loss = torch.empty(E, dtype=torch.float32, device=dev)
+        m = {'cos': _lib.HEAD_COS, 'sqr': _lib.HEAD_SQR, 'dot': _lib.HEAD_DOT}[method]
+        with torch.cuda.device(dev):
+            _lib.check(lib.fsvit_proto_head(_ptr(feat_shot.contiguous().float()), _ptr(feat_query.contiguous().float()), E, way,
+                                            shot, Q, D, float(temp), m, _ptr(logits), _ptr(acc), _ptr(loss), _stream_ptr(dev)))
+        return logits, acc, loss

@@ -1,0 +1,117 @@
+"""Host glue with the reference's names (test_phase/utils/__init__.py:15-153)."""
+import os
+import shutil
+import time
+
+import numpy as np
+import scipy.stats
+import torch
+import torch.nn.functional as F
+
+from . import few_shot  # noqa: F401
+
+_log_path = None
+
+
+def set_log_path(path):
+    global _log_path
+    _log_path = path
+
+
+def log(obj, filename='log.txt'):
+    print(obj)
+    if _log_path is not None:
+        with open(os.path.join(_log_path, filename), 'a') as f:
+            print(obj, file=f)
+
+
+class Averager:
+    """Weighted running mean (utils/__init__.py:28-39)."""
+
+    def __init__(self):
+        self.n = 0.0
+        self.v = 0.0
+
+    def add(self, v, n=1.0):
+        self.v = (self.v * self.n + v * n) / (self.n + n)
+        self.n += n
+
+    def item(self):
+        return self.v
+
+
+class Timer:
+    def __init__(self):
+        self.v = time.time()
+
+    def s(self):
+        self.v = time.time()
+
+    def t(self):
+        return time.time() - self.v
+
+
+def set_gpu(gpu):
+    print('set gpu:', gpu)
+    os.environ['CUDA_VISIBLE_DEVICES'] = gpu      # ROCm honours CUDA_VISIBLE_DEVICES as well
+
+
+def ensure_path(path, remove=True, interactive=False):
+    """Non-interactive by default (the reference prompts on stdin, utils/__init__.py:59-67)."""
+    basename = os.path.basename(path.rstrip('/'))
+    if os.path.exists(path):
+        if remove and (basename.startswith('_') or not interactive
+                       or input('{} exists, remove? ([y]/n): '.format(path)) != 'n'):
+            shutil.rmtree(path)
+            os.makedirs(path)
+    else:
+        os.makedirs(path)
+
+
+def time_str(t):
+    if t >= 3600:
+        return '{:.1f}h'.format(t / 3600)
+    if t >= 60:
+        return '{:.1f}m'.format(t / 60)
+    return '{:.1f}s'.format(t)
+
+
+def compute_logits(feat, proto, metric='dot', temp=1.0):
+    """utils/__init__.py:78-101.  On GPU tensors of the episodic form [E,Q,D] x [E,way,D] the
+    'dot' / 'cos' / 'sqr' metrics run in the fsvit head kernel; small host-side (CPU) calls keep
+    torch semantics for config plumbing."""
+    assert feat.dim() == proto.dim()
+    if feat.is_cuda and feat.dim() == 3 and metric in ('cos', 'sqr', 'dot'):
+        from ..engine import ops
+        return ops.proto_head(proto.unsqueeze(2), feat, temp, metric)[0]
+    if metric == 'cos':
+        feat, proto, metric = F.normalize(feat, dim=-1), F.normalize(proto, dim=-1), 'dot'
+    if metric == 'dot':
+        logits = feat @ proto.transpose(-1, -2)
+    elif metric == 'sqr':
+        logits = -(feat.unsqueeze(-2) - proto.unsqueeze(-3)).pow(2).sum(dim=-1)
+    else:
+        raise ValueError(metric)
+    return logits * temp
+
+
+def compute_acc(logits, label, reduction='mean'):
+    ret = (torch.argmax(logits, dim=1) == label).float()
+    if reduction == 'none':
+        return ret.detach()
+    return ret.mean().item()
+
+
+def compute_n_params(model, return_str=True):
+    tot = sum(int(np.prod(p.shape)) for p in model.parameters())
+    if return_str:
+        return '{:.1f}M'.format(tot / 1e6) if tot >= 1e6 else '{:.1f}K'.format(tot / 1e3)
+    return tot
+
+
+def mean_confidence_interval(data, confidence=0.95):
+    """95 % CI half-width over per-batch accuracies (test_few_shot.py:20-25)."""
+    a = 1.0 * np.array(data)
+    n = len(a)
+    se = scipy.stats.sem(a)
+    return se * scipy.stats.t.ppf((1 + confidence) / 2., n - 1)

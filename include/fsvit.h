@@ -1,0 +1,120 @@
+/* fsvit — C-ABI of the MI355X-native few-shot ViT hot path (libfsvit.so).
+ *
+ * The reference (DongSky/few-shot-vit) is 100 % Python: its boundary for this path is the
+ * `models.make / nn.Module.forward` contract, not an FFI.  These entry points are
+ * what a ctypes binding of that contract calls; each one names the reference
+ * interface it replaces.  Plain pointers and sizes only — no torch types.
+ *
+ * Conventions
+ *   - every `*_dev` / activation / output pointer is a DEVICE pointer owned by the caller;
+ *     `fsvit_tensor.data` pointers are HOST pointers (state-dict tensors, fp32, contiguous);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue work;
+ *   - return 0 on success; > 0 is a hipError_t, < 0 an fsvit error; `fsvit_last_error()` (thread
+ *     local) describes the last failure;
+ *   - `dtype` selects storage + MFMA arithmetic of activations/weights: FSVIT_F32 = exact fp32
+ *     MFMA (v_mfma_f32_16x16x4_f32, the parity mode), FSVIT_BF16 = bf16 MFMA with fp32 accumulate.
+ */
+#ifndef FSVIT_H
+#define FSVIT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { FSVIT_F32 = 0, FSVIT_BF16 = 1 };
+enum { FSVIT_ACT_NONE = 0, FSVIT_ACT_GELU = 1, FSVIT_ACT_LRELU = 2 };
+enum { FSVIT_HEAD_COS = 0, FSVIT_HEAD_SQR = 1, FSVIT_HEAD_DOT = 2 };
+enum {
+  FSVIT_ERR_ARG = -1,        /* bad argument / unsupported configuration        */
+  FSVIT_ERR_KEY = -2,        /* state-dict key missing or wrong shape (KeyError) */
+  FSVIT_ERR_IMG_SIZE = -3,   /* input image size does not match the model (AssertionError) */
+  FSVIT_ERR_WORKSPACE = -4   /* workspace too small                              */
+};
+
+const char* fsvit_last_error(void);
+/* Build identification: "fsvit <version> gfx950". */
+const char* fsvit_version(void);
+
+/* ---------------------------------------------------------------- Visformer encoder
+ * Replaces `Visformer.__init__` + `load_state_dict` + `Visformer.forward` in eval mode
+ * (test_phase/models/visformer.py:291-462; factory visformer_small_80 :482-487). */
+typedef struct fsvit_visformer fsvit_visformer;
+
+typedef struct fsvit_tensor {
+  const char* name;       /* state-dict key relative to the encoder, e.g. "stem.conv1.weight" */
+  const float* data;      /* HOST pointer, fp32, contiguous, PyTorch layout ([O,I,kh,kw], [C], [1,C,H,W]) */
+  int ndim;
+  int64_t shape[4];
+} fsvit_tensor;
+
+typedef struct fsvit_visformer_cfg {   /* visformer.py:292-295 arguments that shape the eval path */
+  int img_size;
+  int init_channels;
+  int embed_dim;
+  int depth[3];
+  int num_heads;
+  float mlp_ratio;
+  int group;
+  float bn_eps;
+} fsvit_visformer_cfg;
+
+/* Folds every eval-mode BatchNorm into the adjacent conv (visformer.py:118-124), reorders conv
+ * weights to K-major (ky,kx,c), pads head dims for MFMA, converts to `dtype` and uploads.
+ * Fails with FSVIT_ERR_KEY when a key of SURVEY.md Appendix A is absent or mis-shaped
+ * (load_state_dict(strict=True) behaviour, models/models.py:21-26). */
+int fsvit_visformer_create(const fsvit_visformer_cfg* cfg, const fsvit_tensor* state_dict, int n_tensors,
+                           int dtype, fsvit_visformer** out);
+void fsvit_visformer_destroy(fsvit_visformer* h);
+int fsvit_visformer_out_dim(const fsvit_visformer* h);            /* `.out_dim` (visformer.py:298) */
+int fsvit_visformer_dtype(const fsvit_visformer* h);
+/* Bytes of scratch needed to push `chunk_images` images through the encoder at once. */
+size_t fsvit_visformer_workspace_bytes(const fsvit_visformer* h, int chunk_images);
+/* x_nchw_dev: [n_img,3,img,img] fp32 (what `data.cuda()` hands the model, test_few_shot.py:81).
+ * feat_dev:   [n_img,out_dim] fp32 pooled features (visformer.py:462).
+ * Images are processed in chunks sized to `ws_bytes` (at least one image must fit). */
+int fsvit_visformer_forward(fsvit_visformer* h, const float* x_nchw_dev, int n_img, int img_h, int img_w,
+                            float* feat_dev, void* ws_dev, size_t ws_bytes, void* stream);
+/* Test hook: copy the named residual-stream activation of the FIRST chunk (NHWC, storage dtype) to
+ * dst_dev during the next forwards.  Names: "stem" (after max-pool + pos_embed1), "stage1.N",
+ * "patch_embed2"/"patch_embed3" (incl. pos_embed), "stage2.N", "stage3.N".  dst_dev NULL clears. */
+int fsvit_visformer_set_tap(fsvit_visformer* h, const char* name, void* dst_dev, size_t bytes);
+
+/* ---------------------------------------------------------------- episode head
+ * Replaces MetaBaseline.forward after the encoder call (test_phase/models/meta_baseline.py:33-47),
+ * utils.compute_logits (utils/__init__.py:78-101) and, per episode, F.cross_entropy +
+ * utils.compute_acc with fs.make_nk_label labels (test_few_shot.py:87-90).
+ * feat_shot_dev [E,way,shot,D], feat_query_dev [E,Q,D] fp32 -> logits_dev [E,Q,way];
+ * acc_dev / loss_dev [E] may be NULL. */
+int fsvit_proto_head(const float* feat_shot_dev, const float* feat_query_dev, int E, int way, int shot, int Q, int D,
+                     float temp, int method, float* logits_dev, float* acc_dev, float* loss_dev, void* stream);
+
+/* Whole `MetaBaseline.forward(x_shot, x_query)` (meta_baseline.py:24-47) in eval mode:
+ * x_shot_dev [E,way,shot,3,H,W], x_query_dev [E,Q,3,H,W] fp32 -> logits_dev [E,Q,way].
+ * feat_dev: scratch [(E*way*shot + E*Q), out_dim] fp32. */
+int fsvit_meta_baseline_forward(fsvit_visformer* h, const float* x_shot_dev, const float* x_query_dev,
+                                int E, int way, int shot, int Q, int img_h, int img_w, float temp, int method,
+                                float* logits_dev, float* acc_dev, float* loss_dev, float* feat_dev,
+                                void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- operator level (tests, reuse)
+ * Implicit-GEMM conv with fused epilogue; see few-shot-vit_amd/csrc/conv_gemm.h for the layout.
+ * x NHWC [B,H,W,x_cstride]; w [groups][N][Kw] K-major (ky,kx,c); y NHWC [B,OH,OW,y_cstride]. */
+int fsvit_conv_gemm(const void* x_dev, const void* w_dev, const float* bias_dev, const void* res_dev,
+                    const float* pos_dev, void* y_dev, int B, int H, int W, int Cin, int x_cstride,
+                    int KH, int KW, int stride, int pad, int N, int y_cstride, int Kw, int groups,
+                    int act, int res_first, int dtype, void* stream);
+/* qkv [B*S][3*heads*hdp] -> ctx [B*S][heads*hdp] (visformer.py:183-190) */
+int fsvit_attention(const void* qkv_dev, void* ctx_dev, int B, int S, int heads, int hdp, float scale,
+                    int dtype, void* stream);
+int fsvit_im2col27(const float* x_nchw_dev, void* out_dev, int B, int H, int W, int dtype, void* stream);
+int fsvit_maxpool2_pos(const void* in_dev, const float* pos_dev, void* out_dev, int B, int OH, int OW, int C,
+                       int dtype, void* stream);
+int fsvit_pool_affine(const void* x_dev, const float* scale_dev, const float* shift_dev, float* feat_dev,
+                      int B, int HW, int C, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSVIT_H */

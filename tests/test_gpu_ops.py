@@ -1,0 +1,169 @@
+"""Operator-level parity of the HIP kernels (through the C-ABI) against plain fp32 torch on CPU.
+
+Tolerances: f32 storage uses exact-fp32 MFMA -> 2e-4 abs on O(1..10) outputs (accumulation
+order only).  bf16 storage: inputs/weights are pre-rounded to bf16 on the reference side, so the
+remaining error is the bf16 rounding of the OUTPUT (rel 2^-8) plus fp32 accumulation order.
+"""
+import math
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {'f32': torch.float32, 'bf16': torch.bfloat16}
+
+
+def _tol(dt, ref):
+    scale = float(ref.abs().max())
+    return 2e-4 * max(1.0, scale) if dt == 'f32' else 1.2e-2 * max(1.0, scale)
+
+
+def pack_w(w, groups, dtype):
+    """[O, Ig, KH, KW] -> [groups][N][Kw] with k = (ky*KW+kx)*Ig + c, zero-padded to the K slice."""
+    O, Ig, KH, KW = w.shape
+    N = O // groups
+    K = KH * KW * Ig
+    bke = 32 if dtype == torch.float32 else 64
+    Kw = (K + bke - 1) // bke * bke
+    p = torch.zeros(groups, N, Kw)
+    p[:, :, :K] = w.permute(0, 2, 3, 1).reshape(groups, N, K)
+    return p.to(dtype)
+
+
+def q(t, dtype):
+    """round-trip through the storage dtype (identity for fp32)."""
+    return t.to(dtype).float()
+
+
+CASES = [
+    # name,            B, H,  W,  Cin_tot, O,   KH, s, p, groups, act, res, res_first, bias, pos
+    ('1x1_gelu',        2, 20, 20, 128,    256, 1, 1, 0, 1, 1, False, 0, True, False),
+    ('3x3_lrelu_res',   2, 40, 40, 64,     128, 3, 1, 1, 1, 2, True, 1, True, False),
+    ('3x3_grouped',     3, 20, 20, 256,    256, 3, 1, 1, 8, 1, False, 0, False, False),
+    ('k2s2_pos',        2, 20, 20, 128,    256, 2, 2, 0, 1, 0, False, 0, True, True),
+    ('1x1_tails',       1, 5,  5,  288,    96,  1, 1, 0, 1, 0, True, 0, False, False),
+    ('1x1_qkv_like',    3, 10, 10, 256,    864, 1, 1, 0, 1, 0, False, 0, True, False),
+    ('k32_im2col',      2, 40, 40, 32,     64,  1, 1, 0, 1, 2, False, 0, True, False),
+    ('1x1_bigK',        5, 5,  5,  2048,   512, 1, 1, 0, 1, 0, True, 0, False, False),
+    ('3x3_small_n32',   1, 12, 12, 32,     32,  3, 1, 1, 1, 1, False, 0, True, False),
+]
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_conv_gemm(case, dt):
+    from fewshot_vit_amd.engine import ops
+    name, B, H, W, Cin, O, KH, s, p, groups, act, use_res, res_first, use_bias, use_pos = case
+    dtype = DT[dt]
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000)
+    Ig = Cin // groups
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    w = q(torch.randn(O, Ig, KH, KH, generator=g) / math.sqrt(Ig * KH * KH), dtype)
+    bias = torch.randn(O, generator=g) * 0.3 if use_bias else None
+    OH = (H + 2 * p - KH) // s + 1
+    res = q(torch.randn(B, O, OH, OH, generator=g), dtype) if use_res else None
+    pos = torch.randn(OH * OH, O, generator=g) * 0.2 if use_pos else None
+
+    ref = F.conv2d(x, w, bias, stride=s, padding=p, groups=groups)
+    if use_res and res_first:
+        ref = ref + res
+    ref = {0: lambda t: t, 1: F.gelu, 2: lambda t: F.leaky_relu(t, 0.1)}[act](ref)
+    if use_res and not res_first:
+        ref = ref + res
+    if use_pos:
+        ref = ref + pos.t().reshape(1, O, OH, OH)
+
+    dev = 'cuda'
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev, dtype)
+    wd = pack_w(w, groups, dtype).to(dev)
+    y = ops.conv_gemm(xd, wd, bias.to(dev) if use_bias else None,
+                      res.permute(0, 2, 3, 1).contiguous().to(dev, dtype) if use_res else None,
+                      pos.to(dev) if use_pos else None,
+                      B, H, W, Ig, KH, KH, s, p, O // groups, groups, act, res_first)
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    assert err <= _tol(dt, ref), (name, dt, err)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('S,heads,hd', [(100, 6, 42), (25, 6, 85), (100, 2, 10), (25, 3, 21)])
+def test_attention(S, heads, hd, dt):
+    from fewshot_vit_amd.engine import ops
+    dtype = DT[dt]
+    kch = 16 if dt == 'f32' else 32
+    hdp = (hd + kch - 1) // kch * kch
+    B = 3
+    g = torch.Generator().manual_seed(S * 7 + hd)
+    qkv = q(torch.randn(B, S, 3, heads, hd, generator=g), dtype)
+    scale = hd ** -0.5
+    qq, kk, vv = [qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3)]        # [B,heads,S,hd]
+    ref = ((qq @ kk.transpose(-1, -2)) * scale).softmax(-1) @ vv
+    ref = ref.permute(0, 2, 1, 3)                                            # [B,S,heads,hd]
+    padded = torch.zeros(B, S, 3, heads, hdp)
+    padded[..., :hd] = qkv
+    ctx = ops.attention(padded.reshape(B * S, 3 * heads * hdp).to('cuda', dtype), B, S, heads, hdp, scale)
+    torch.cuda.synchronize()
+    got = ctx.float().cpu().reshape(B, S, heads, hdp)
+    assert got[..., hd:].abs().max().item() == 0.0                           # padded head dims stay exactly 0
+    err = (got[..., :hd] - ref).abs().max().item()
+    assert err <= (2e-5 if dt == 'f32' else 2e-2), (dt, err)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_im2col_maxpool_pool(dt):
+    from fewshot_vit_amd.engine import ops
+    dtype = DT[dt]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 3, 80, 80, generator=g)
+    cols = ops.im2col27(x.cuda(), dtype).float().cpu()                        # [B*1600, 32]
+    ref = F.unfold(x, 3, padding=1, stride=2)                                 # [B, 27 (c,ky,kx), 1600]
+    ref = ref.reshape(3, 3, 9, 1600).permute(0, 3, 2, 1).reshape(3 * 1600, 27)   # k = (ky*3+kx)*3 + c
+    assert (cols[:, 27:] == 0).all()
+    assert (cols[:, :27] - q(ref, dtype)).abs().max().item() == 0.0
+
+    a = q(torch.randn(2, 16, 40, 40, generator=g), dtype)
+    pos = torch.randn(400, 16, generator=g)
+    mp = ops.maxpool2_pos(a.permute(0, 2, 3, 1).contiguous().to('cuda', dtype), pos.cuda()).float().cpu()
+    refmp = F.max_pool2d(a, 2) + pos.t().reshape(1, 16, 20, 20)
+    assert (mp.permute(0, 3, 1, 2) - refmp).abs().max().item() <= (1e-6 if dt == 'f32' else 4e-2)
+
+    xx = q(torch.randn(4, 25, 512, generator=g), dtype)
+    sc, sh = torch.rand(512, generator=g) + 0.5, torch.randn(512, generator=g)
+    pooled = ops.pool_affine(xx.to('cuda', dtype), sc.cuda(), sh.cuda()).cpu()
+    assert (pooled - (xx.mean(1) * sc + sh)).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize('method', ['cos', 'sqr'])
+@pytest.mark.parametrize('E,way,shot,Qper,D', [(3, 5, 5, 15, 512), (2, 5, 1, 15, 512), (1, 10, 5, 5, 128)])
+def test_proto_head(E, way, shot, Qper, D, method):
+    from fewshot_vit_amd.engine import ops
+    from oracle import fewshot_oracle as fo
+    from oracle import visformer_oracle as vo
+    g = torch.Generator().manual_seed(E * 100 + way)
+    fs = torch.randn(E, way, shot, D, generator=g)
+    fq = torch.randn(E, way * Qper, D, generator=g) + fs.mean(2).repeat_interleave(Qper, dim=1) * 0.7
+    temp = 10.0 if method == 'cos' else 0.05
+    ref = vo.meta_baseline_head(fs, fq, method=method, temp=temp)
+    logits, acc, loss = ops.proto_head(fs.cuda(), fq.cuda(), temp, method)
+    torch.cuda.synchronize()
+    assert (logits.cpu() - ref).abs().max().item() <= 1e-4 * max(1.0, float(ref.abs().max()))
+    label = fo.make_nk_label(way, Qper, 1)
+    for e in range(E):
+        assert acc[e].item() == pytest.approx(fo.compute_acc(ref[e].numpy(), label), abs=1e-6)
+        assert loss[e].item() == pytest.approx(fo.cross_entropy(ref[e].numpy(), label), rel=1e-4, abs=1e-4)
+
+
+def test_compute_logits_gpu_matches_reference_semantics():
+    from fewshot_vit_amd import utils
+    from oracle import visformer_oracle as vo
+    g = torch.Generator().manual_seed(9)
+    feat, proto = torch.randn(2, 7, 64, generator=g), torch.randn(2, 3, 64, generator=g)
+    for metric, temp in (('cos', 10.0), ('sqr', 1.0), ('dot', 2.0)):
+        got = utils.compute_logits(feat.cuda(), proto.cuda(), metric, temp).cpu()
+        ref = vo.compute_logits(feat, proto, metric, temp)
+        assert (got - ref).abs().max().item() <= 1e-4 * max(1.0, float(ref.abs().max())), metric

@@ -1,0 +1,153 @@
+"""End-to-end parity of the HIP Visformer + MetaBaseline path (through the C-ABI) against the
+oracle on the same seeded inputs, and against the committed golden vectors of the reference.
+
+north_star tolerance: logits within 1e-3 of the reference CPU path -> enforced for the `parity`
+numerics mode (exact fp32 MFMA).  The `bf16` mode is the throughput mode; its measured deviation
+is bounded loosely here (SURVEY.md 7 measured 1.6e-2..3.2e-2 for bf16 operands) and arg-max
+agreement is required."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL_PARITY = 1e-3        # BASELINE.json north_star
+LOGIT_TOL_BF16 = 0.25          # loose guard; the measured value is printed and recorded in DESIGN.md
+
+
+@pytest.fixture(scope='module')
+def full_sd():
+    from fewshot_vit_amd import synthetic
+    from oracle import visformer_oracle as vo
+    shapes = vo.state_dict_shapes(vo.VisformerCfg(), prefix='encoder.')
+    shapes['temp'] = ()
+    return synthetic.synthetic_checkpoint_sd(shapes)
+
+
+def _model(sd, numerics):
+    from fewshot_vit_amd import models
+    m = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={'numerics': numerics})
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval()
+
+
+def _episode(seed, shot):
+    from fewshot_vit_amd import synthetic
+    from fewshot_vit_amd.utils import few_shot as fs
+    x = synthetic.synthetic_episodes(seed, 1, 5, shot, 15)
+    return fs.split_shot_query(x, 5, shot, 15, 1)
+
+
+@pytest.mark.parametrize('name,seed,shot', [('5shot', 11, 5), ('1shot', 12, 1)])
+def test_logits_parity_mode_vs_reference_golden(full_sd, golden_dir, name, seed, shot):
+    z = np.load(os.path.join(golden_dir, 'full_visformer_micro_80.npz'))
+    m = _model(full_sd, 'parity')
+    xs, xq = _episode(seed, shot)
+    with torch.no_grad():
+        logits = m(xs.cuda(), xq.cuda())
+    torch.cuda.synchronize()
+    err = np.abs(logits.cpu().numpy() - z[f'logits_{name}']).max()
+    print(f'[parity] {name} max|dlogit| vs reference golden = {err:.3e}')
+    assert logits.shape == (1, 75, 5)
+    assert err <= LOGIT_TOL_PARITY
+
+
+@pytest.mark.parametrize('name,seed,shot', [('5shot', 11, 5), ('1shot', 12, 1)])
+def test_logits_bf16_mode_vs_reference_golden(full_sd, golden_dir, name, seed, shot):
+    z = np.load(os.path.join(golden_dir, 'full_visformer_micro_80.npz'))
+    ref = z[f'logits_{name}']
+    m = _model(full_sd, 'bf16')
+    xs, xq = _episode(seed, shot)
+    with torch.no_grad():
+        logits = m(xs.cuda(), xq.cuda()).cpu().numpy()
+    err = np.abs(logits - ref).max()
+    agree = (logits.argmax(-1) == ref.argmax(-1)).mean()
+    print(f'[bf16] {name} max|dlogit| vs reference golden = {err:.3e}, argmax agreement = {agree:.4f}')
+    assert err <= LOGIT_TOL_BF16
+    assert agree == 1.0
+
+
+@pytest.mark.parametrize('numerics,tol', [('parity', 2e-4), ('bf16', 0.3)])
+def test_residual_stream_taps_vs_oracle(full_sd, numerics, tol):
+    """Every residual-stream checkpoint of the encoder against the oracle's NCHW taps."""
+    from fewshot_vit_amd import synthetic
+    from oracle import visformer_oracle as vo
+    cfg = vo.VisformerCfg()
+    m = _model(full_sd, numerics)
+    eng = m.encoder.engine()
+    x = synthetic.synthetic_episodes(31, 1, 3, 1, 1)            # 6 images
+    B = x.shape[0]
+    shapes = {'stem': (B, 20, 20, 128), 'patch_embed2': (B, 10, 10, 256), 'patch_embed3': (B, 5, 5, 512)}
+    for i in range(4):
+        shapes[f'stage1.{i}'] = (B, 20, 20, 128)
+    for i in range(2):
+        shapes[f'stage2.{i}'] = (B, 10, 10, 256)
+    for i in range(3):
+        shapes[f'stage3.{i}'] = (B, 5, 5, 512)
+    bufs = {k: eng.set_tap(k, s) for k, s in shapes.items()}
+    with torch.no_grad():
+        feat = m.encoder(x.cuda())
+    torch.cuda.synchronize()
+    taps = {}
+    enc_sd = {k[len('encoder.'):]: v for k, v in full_sd.items() if k.startswith('encoder.')}
+    with torch.no_grad():
+        pooled = vo.visformer_forward(enc_sd, x, cfg, taps=taps)
+    worst = {}
+    for k, buf in bufs.items():
+        ref = taps[k]
+        if k == 'stem':
+            ref = ref + enc_sd['pos_embed1']
+        elif k.startswith('patch_embed'):
+            ref = ref + enc_sd['pos_embed' + k[-1]]
+        got = buf.float().cpu().permute(0, 3, 1, 2)
+        worst[k] = ((got - ref).abs().max() / max(1.0, float(ref.abs().max()))).item()
+    print(f'[{numerics}] tap rel errors:', {k: f'{v:.2e}' for k, v in worst.items()})
+    perr = (feat.cpu() - pooled).abs().max().item()
+    print(f'[{numerics}] pooled feature max abs err = {perr:.3e}')
+    for k, v in worst.items():
+        assert v <= tol, (k, v)
+    assert perr <= tol * max(1.0, float(pooled.abs().max()))
+
+
+def test_batched_episodes_equal_single_episodes(full_sd):
+    """Batching episodes per launch must not change any episode's logits (eval BN = running stats)."""
+    from fewshot_vit_amd import synthetic
+    from fewshot_vit_amd.utils import few_shot as fs
+    m = _model(full_sd, 'bf16')
+    x = synthetic.synthetic_episodes(77, 3, 5, 1, 15)
+    xs, xq = fs.split_shot_query(x, 5, 1, 15, 3)
+    with torch.no_grad():
+        all_logits = m(xs.cuda(), xq.cuda()).cpu()
+        singles = torch.cat([m(xs[e:e + 1].cuda(), xq[e:e + 1].cuda()).cpu() for e in range(3)])
+    assert torch.equal(all_logits, singles)
+
+
+def test_rejects_wrong_image_size_and_cpu_tensors(full_sd):
+    m = _model(full_sd, 'bf16')
+    with pytest.raises(AssertionError):
+        m.encoder(torch.zeros(1, 3, 84, 84, device='cuda'))
+    with pytest.raises(RuntimeError):
+        m.encoder.engine().forward(torch.zeros(1, 3, 80, 80))     # CPU tensor: no fallback
+    with pytest.raises(KeyError):
+        from fewshot_vit_amd import models
+        models.make('no-such-model')
+
+
+def test_strict_state_dict_and_repacking(full_sd):
+    from fewshot_vit_amd import models
+    m = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={})
+    bad = dict(full_sd)
+    bad.pop('encoder.stage2.0.attn.qkv.weight')
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad, strict=True)
+    m.load_state_dict(full_sd)
+    m.cuda().eval()
+    xs, xq = _episode(11, 1)
+    with torch.no_grad():
+        a = m(xs.cuda(), xq.cuda()).cpu()
+        with torch.no_grad():
+            m.encoder.norm.bn.weight.mul_(1.5)       # in-place edit bumps the version -> engine re-packs
+        b = m(xs.cuda(), xq.cuda()).cpu()
+    assert not torch.equal(a, b)
