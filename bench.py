@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the fsvit hot path: BASELINE.json configs[1] — Visformer-S (`visformer_micro_80`)
+5-way 5-shot episodic eval (15 queries/class), bf16 MFMA, synthetic 80x80 episodes resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" = one pass of `MetaBaseline.forward` (encoder + cosine head, one C-ABI call) over a batch of
+`--episodes` episodes per GPU.  Episodes are independent, so ranks shard them with no data-path
+collective (weak scaling); the only exchange is ONE all-reduce of the accuracy statistics at the end
+of the timed region (RCCL over xGMI), as in the north star.  Rank 0 prints one JSON line.
+
+Extra legs (rank 0, N=1 only unless disabled):
+  roofline      per-launch HIP-event timing inside the timed region (engine profile mode) -> the
+                dominant kernel's algorithmic TFLOP/s against the 2.5 PFLOP/s dense bf16 MFMA peak.
+  cpu_baseline  the oracle (oracle/visformer_oracle.py, a port of the reference's CPU path) timed on
+                the host cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOP_PER_IMAGE = 2.0306e9            # algorithmic forward FLOPs, visformer_micro_80 @80x80
+HEAD_FLOP_PER_EPISODE = 0.38e6
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}    # dense peaks, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--episodes', type=int, default=16, help='episodes per GPU per step (ep_per_batch)')
+    ap.add_argument('--shot', type=int, default=5)
+    ap.add_argument('--numerics', default='bf16', choices=['bf16', 'parity'])
+    ap.add_argument('--chunk', type=int, default=int(os.environ.get('FSVIT_CHUNK', 400)), help='images per encoder chunk')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-episodes', type=int, default=16)
+    ap.add_argument('--layers', action='store_true', help='print the per-layer timing table to stderr')
+    return ap.parse_args()
+
+
+def device_episodes(seed, n_ep, way, shot, query, dev):
+    """Class-structured synthetic episodes generated directly in HBM (x = mu_c + 1.5*eps, so accuracy
+    is neither chance nor saturated); layout = what fs.split_shot_query returns."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    per = shot + query
+    mu = torch.randn(n_ep, way, 1, 3, 80, 80, device=dev, generator=g)
+    x = mu + 1.5 * torch.randn(n_ep, way, per, 3, 80, 80, device=dev, generator=g)
+    x_shot = x[:, :, :shot].contiguous()
+    x_query = x[:, :, shot:].contiguous().view(n_ep, way * query, 3, 80, 80)
+    return x_shot, x_query
+
+
+def cpu_baseline(sd, shot, n_ep):
+    """Oracle timed at ep_per_batch=1 (the reference's test setting, test_few_shot.py:47-48)."""
+    from fewshot_vit_amd import synthetic
+    from fewshot_vit_amd.utils import few_shot as fs
+    from oracle import visformer_oracle as vo
+    cfg = vo.VisformerCfg()
+    cores = torch.get_num_threads()
+    x = synthetic.synthetic_episodes(12345, 1, 5, shot, 15)
+    xs, xq = fs.split_shot_query(x, 5, shot, 15, 1)
+    for _ in range(2):
+        vo.meta_baseline_forward(sd, xs, xq, cfg)
+    t0 = time.perf_counter()
+    for _ in range(n_ep):
+        vo.meta_baseline_forward(sd, xs, xq, cfg)
+    dt = time.perf_counter() - t0
+    return {'value': n_ep / dt, 'unit': 'episodes/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n_ep} episodes 5-way {shot}-shot (100 images each at 5-shot), ep_per_batch=1, fp32 torch CPU '
+                      f'oracle, 2 warm-up episodes, {dt:.1f} s'}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs an MI355X: the fsvit hot path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+
+    from fewshot_vit_amd import models, synthetic
+    os.environ['FSVIT_CHUNK'] = str(args.chunk)
+    model = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={'numerics': args.numerics})
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synthetic.synthetic_checkpoint_sd(shapes)          # procedural weights by key name + shipped BN calibration
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    engine = model.encoder.engine()
+
+    way, query, E = 5, 15, args.episodes
+    x_shot, x_query = device_episodes(12345 + rank, E, way, args.shot, query, dev)
+    temp = float(model.temp.detach())
+
+    def step():
+        return engine.meta_baseline_forward(x_shot, x_query, temp, 'cos', want_stats=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    profile = (not args.no_roofline) and rank == 0
+    accs = []
+    barrier()
+    if profile:
+        engine.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, acc, _ = step()
+        accs.append(acc)
+    # the one exchange of the path: all-reduce of (sum acc, sum acc^2, n) -> mean accuracy +- CI
+    acc_all = torch.stack(accs).double().flatten()
+    stats = torch.stack([acc_all.sum(), (acc_all * acc_all).sum(), torch.tensor(float(acc_all.numel()), device=dev, dtype=torch.float64)])
+    if world > 1:
+        dist.all_reduce(stats)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    recs = engine.profile_end() if profile else None
+
+    n = float(stats[2].item())
+    mean = float(stats[0].item()) / n
+    var = max(0.0, (float(stats[1].item()) - n * mean * mean) / max(1.0, n - 1.0))
+    import scipy.stats
+    ci = (var / n) ** 0.5 * float(scipy.stats.t.ppf(0.975, max(1.0, n - 1.0)))
+
+    if rank == 0:
+        total_eps = world * E * args.steps
+        eps = total_eps / elapsed
+        imgs = way * (args.shot + query)
+        flops_ep = FLOP_PER_IMAGE * imgs + HEAD_FLOP_PER_EPISODE
+        out = {
+            'metric': 'episodes_per_sec_5way_%dshot_visformer_s' % args.shot, 'value': eps, 'unit': 'episodes/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16' if args.numerics == 'bf16' else 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: Visformer-S (visformer_micro_80) miniImageNet-shaped 5-way %d-shot '
+                                   'episodic eval, 15 query/class, 80x80 fp32 NCHW episodes resident in HBM, procedural weights + '
+                                   'calibrated BN' % args.shot,
+                       'episodes_per_step_per_gpu': E, 'images_per_episode': imgs, 'encoder_chunk_images': args.chunk,
+                       'parallelism': 'episode-parallel x%d, one all-reduce of accuracy stats' % world},
+            'whole_path_tflops': eps * flops_ep / 1e12,
+            'whole_path_mfma_frac': eps * flops_ep / 1e12 / MFMA_PEAK_TFLOPS['bf16' if args.numerics == 'bf16' else 'f32'],
+            'accuracy': {'mean': mean, 'ci95': ci, 'episodes': int(n)},
+        }
+        if recs:
+            bykern = {}
+            for r in recs:
+                k = bykern.setdefault(r['kernel'], {'ms': 0.0, 'flops': 0.0, 'launches': 0})
+                k['ms'] += r['ms']
+                k['flops'] += r['flops']
+                k['launches'] += r['launches']
+            dom = max(bykern, key=lambda k: bykern[k]['ms'])
+            d = bykern[dom]
+            peak = MFMA_PEAK_TFLOPS['bf16' if args.numerics == 'bf16' else 'f32']
+            achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                               'traffic': None, 'kernel': dom, 'launches': d['launches'],
+                               'avg_launch_us': 1e3 * d['ms'] / d['launches'],
+                               'avg_launch_gflop': d['flops'] / d['launches'] / 1e9,
+                               'share_of_gpu_time': d['ms'] / sum(k['ms'] for k in bykern.values())}
+            out['kernels'] = {k: {'ms_per_step': v['ms'] / args.steps, 'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0,
+                                  'launches_per_step': v['launches'] / args.steps} for k, v in bykern.items()}
+            if args.layers:
+                tot = sum(r['ms'] for r in recs)
+                for r in sorted(recs, key=lambda r: -r['ms']):
+                    tf = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
+                    print(f"  {r['layer']:<22} {r['kernel']:<40} {r['ms'] / args.steps:8.3f} ms/step {100 * r['ms'] / tot:5.1f}%  {tf:7.1f} TF/s",
+                          file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(sd, args.shot, args.cpu_episodes)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -26,6 +26,11 @@ class VisformerCfg(C.Structure):
                 ('group', C.c_int), ('bn_eps', C.c_float)]
 
 
+class ProfRec(C.Structure):
+    _fields_ = [('layer', C.c_char * 48), ('kernel_id', C.c_int), ('launches', C.c_int), ('flops', C.c_double),
+                ('ms', C.c_double)]
+
+
 # name -> (restype, argtypes); every symbol include/fsvit.h declares
 _vp, _fp, _i, _f, _sz = C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -38,6 +43,9 @@ SIGNATURES = {
     'fsvit_visformer_workspace_bytes': (_sz, [_vp, _i]),
     'fsvit_visformer_forward': (_i, [_vp, _fp, _i, _i, _i, _fp, _vp, _sz, _vp]),
     'fsvit_visformer_set_tap': (_i, [_vp, C.c_char_p, _vp, _sz]),
+    'fsvit_visformer_profile_begin': (_i, [_vp]),
+    'fsvit_visformer_profile_end': (_i, [_vp, C.POINTER(ProfRec), _i, C.POINTER(_i)]),
+    'fsvit_kernel_name': (C.c_char_p, [_i, _i]),
     'fsvit_proto_head': (_i, [_fp, _fp, _i, _i, _i, _i, _i, _f, _i, _fp, _fp, _fp, _vp]),
     'fsvit_meta_baseline_forward': (_i, [_vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _i, _fp, _fp, _fp, _fp,
                                          _vp, _sz, _vp]),

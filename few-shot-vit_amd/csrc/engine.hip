@@ -67,6 +67,9 @@ struct BlockA { Layer qkv, proj, fc1, fc2; };
 
 struct Tap { void* dst; size_t bytes; };
 
+// One timed launch: events bracket the kernel on the stream it was launched on.
+struct ProfEntry { std::string layer; int kernel; double flops; hipEvent_t e0, e1; };
+
 struct fsvit_visformer {
   fsvit_visformer_cfg cfg;
   int dtype = 0, es = 4;
@@ -81,6 +84,9 @@ struct fsvit_visformer {
   float *fscale = nullptr, *fshift = nullptr;
   std::map<std::string, Tap> taps;
   std::vector<void*> allocs;
+  bool profiling = false;
+  std::vector<ProfEntry> prof;
+  hipEvent_t prof_last = nullptr;      // end event of the previous launch = start of the next
 };
 
 namespace {
@@ -378,6 +384,31 @@ int tap(fsvit_visformer* h, const std::string& name, const void* src, size_t byt
   return 0;
 }
 
+// kernel ids reported by the profiler (names in fsvit_kernel_name)
+enum { KID_GEMM128 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7 };
+
+int gemm_kid(const Layer& L) { return L.N > 64 ? KID_GEMM128 : (L.N > 32 ? KID_GEMM64 : KID_GEMM32); }
+
+// Runs one launch; in profiling mode brackets it with HIP events on the same stream.
+template <typename F>
+int timed(fsvit_visformer* h, hipStream_t st, const char* layer, int kernel, double flops, F&& launch) {
+  if (!h->profiling) return launch();
+  hipEvent_t e0 = h->prof_last, e1;
+  if (!e0) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventRecord(e0, st)); }
+  int rc = launch();
+  if (rc != 0) return rc;
+  HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipEventRecord(e1, st));
+  h->prof.push_back(ProfEntry{layer, kernel, flops, e0, e1});
+  h->prof_last = e1;
+  return 0;
+}
+
+int run_gemm(fsvit_visformer* h, hipStream_t st, const char* layer, const Layer& L, const ConvGemmParams& p, double n_true, double k_true) {
+  const double flops = 2.0 * (double)p.M * n_true * k_true * (double)p.groups;     // algorithmic: unpadded N and K
+  return timed(h, st, layer, gemm_kid(L), flops, [&]() { return launch_conv_gemm(p, h->dtype, st); });
+}
+
 int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsigned char* ws, bool first, hipStream_t st) {
   const Plan pl = make_plan(h, Bc);
   const int dt = h->dtype;
@@ -389,21 +420,22 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
   const int img = h->cfg.img_size;
 
   // stem: conv1 / downsample as K=32 GEMMs over the im2col rows, conv2, conv3 (+identity, LeakyReLU), max-pool + pos1
-  RC_TRY(launch_im2col27(x, patches, Bc, img, img, h->H0, h->H0, dt, st));
-  RC_TRY(launch_conv_gemm(conv_params(h->conv1, patches, c1, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C0, ACT_LRELU, nullptr, 0, nullptr), dt, st));
-  RC_TRY(launch_conv_gemm(conv_params(h->down, patches, ident, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C1, ACT_NONE, nullptr, 0, nullptr), dt, st));
-  RC_TRY(launch_conv_gemm(conv_params(h->conv2, c1, c2, Bc, h->H0, h->H0, h->C0, h->C0, 3, 3, 1, 1, h->C1, ACT_LRELU, nullptr, 0, nullptr), dt, st));
-  RC_TRY(launch_conv_gemm(conv_params(h->conv3, c2, c3, Bc, h->H0, h->H0, h->C1, h->C1, 3, 3, 1, 1, h->C1, ACT_LRELU, ident, 1, nullptr), dt, st));
-  RC_TRY(launch_maxpool2_pos(c3, h->pos1, x1, Bc, h->H1, h->H1, h->C1, dt, st));
+  h->prof_last = nullptr;
+  RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() { return launch_im2col27(x, patches, Bc, img, img, h->H0, h->H0, dt, st); }));
+  RC_TRY(run_gemm(h, st, "stem.conv1", h->conv1, conv_params(h->conv1, patches, c1, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C0, ACT_LRELU, nullptr, 0, nullptr), h->C0, 27));
+  RC_TRY(run_gemm(h, st, "stem.downsample", h->down, conv_params(h->down, patches, ident, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C1, ACT_NONE, nullptr, 0, nullptr), h->C1, 27));
+  RC_TRY(run_gemm(h, st, "stem.conv2", h->conv2, conv_params(h->conv2, c1, c2, Bc, h->H0, h->H0, h->C0, h->C0, 3, 3, 1, 1, h->C1, ACT_LRELU, nullptr, 0, nullptr), h->C1, 9.0 * h->C0));
+  RC_TRY(run_gemm(h, st, "stem.conv3", h->conv3, conv_params(h->conv3, c2, c3, Bc, h->H0, h->H0, h->C1, h->C1, 3, 3, 1, 1, h->C1, ACT_LRELU, ident, 1, nullptr), h->C1, 9.0 * h->C1));
+  RC_TRY(timed(h, st, "stem.maxpool", KID_MAXPOOL, 0.0, [&]() { return launch_maxpool2_pos(c3, h->pos1, x1, Bc, h->H1, h->H1, h->C1, dt, st); }));
   RC_TRY(tap(h, "stem", x1, (size_t)Bc * h->H1 * h->H1 * h->C1 * es, first, st));
 
   // stage 1: x += conv3(GELU(conv2_g(GELU(conv1(BN(x))))))
   const int Cg = h->hid1 / h->cfg.group;
   for (size_t i = 0; i < h->s1.size(); ++i) {
     const Block1& b = h->s1[i];
-    RC_TRY(launch_conv_gemm(conv_params(b.c1, x1, ha, Bc, h->H1, h->H1, h->C1, h->C1, 1, 1, 1, 0, h->hid1, ACT_GELU, nullptr, 0, nullptr), dt, st));
-    RC_TRY(launch_conv_gemm(conv_params(b.c2, ha, hb, Bc, h->H1, h->H1, Cg, h->hid1, 3, 3, 1, 1, h->hid1, ACT_GELU, nullptr, 0, nullptr), dt, st));
-    RC_TRY(launch_conv_gemm(conv_params(b.c3, hb, x1, Bc, h->H1, h->H1, h->hid1, h->hid1, 1, 1, 1, 0, h->C1, ACT_NONE, x1, 0, nullptr), dt, st));
+    RC_TRY(run_gemm(h, st, "stage1.mlp.conv1", b.c1, conv_params(b.c1, x1, ha, Bc, h->H1, h->H1, h->C1, h->C1, 1, 1, 1, 0, h->hid1, ACT_GELU, nullptr, 0, nullptr), h->hid1, h->C1));
+    RC_TRY(run_gemm(h, st, "stage1.mlp.conv2", b.c2, conv_params(b.c2, ha, hb, Bc, h->H1, h->H1, Cg, h->hid1, 3, 3, 1, 1, h->hid1, ACT_GELU, nullptr, 0, nullptr), Cg, 9.0 * Cg));
+    RC_TRY(run_gemm(h, st, "stage1.mlp.conv3", b.c3, conv_params(b.c3, hb, x1, Bc, h->H1, h->H1, h->hid1, h->hid1, 1, 1, 1, 0, h->C1, ACT_NONE, x1, 0, nullptr), h->C1, h->hid1));
     RC_TRY(tap(h, "stage1." + std::to_string(i), x1, (size_t)Bc * h->H1 * h->H1 * h->C1 * es, first, st));
   }
 
@@ -417,21 +449,24 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
     const Layer& pe = s == 2 ? h->pe2 : h->pe3;
     const float* pos = s == 2 ? h->pos2 : h->pos3;
     const size_t xbytes = (size_t)Bc * Ho * Ho * C * es;
-    RC_TRY(launch_conv_gemm(conv_params(pe, xin, xs, Bc, Hi, Hi, Ci, Ci, 2, 2, 2, 0, C, ACT_NONE, nullptr, 0, pos), dt, st));
+    const std::string sp = "stage" + std::to_string(s);
+    RC_TRY(run_gemm(h, st, s == 2 ? "patch_embed2" : "patch_embed3", pe, conv_params(pe, xin, xs, Bc, Hi, Hi, Ci, Ci, 2, 2, 2, 0, C, ACT_NONE, nullptr, 0, pos), C, 4.0 * Ci));
     RC_TRY(tap(h, "patch_embed" + std::to_string(s), xs, xbytes, first, st));
     const std::vector<BlockA>& blocks = s == 2 ? h->s2 : h->s3;
     const float scale = 1.0f / std::sqrt((float)hd);                       // head_dim ** -0.5 (visformer.py:174)
+    const int S = Ho * Ho;
     for (size_t i = 0; i < blocks.size(); ++i) {
       const BlockA& b = blocks[i];
-      RC_TRY(launch_conv_gemm(conv_params(b.qkv, xs, qkv, Bc, Ho, Ho, C, C, 1, 1, 1, 0, 3 * heads * hdp, ACT_NONE, nullptr, 0, nullptr), dt, st));
-      RC_TRY(launch_attention(qkv, ctx, Bc, Ho * Ho, heads, hdp, scale, dt, st));
-      RC_TRY(launch_conv_gemm(conv_params(b.proj, ctx, xs, Bc, Ho, Ho, heads * hdp, heads * hdp, 1, 1, 1, 0, C, ACT_NONE, xs, 0, nullptr), dt, st));
-      RC_TRY(launch_conv_gemm(conv_params(b.fc1, xs, hid, Bc, Ho, Ho, C, C, 1, 1, 1, 0, hidc, ACT_GELU, nullptr, 0, nullptr), dt, st));
-      RC_TRY(launch_conv_gemm(conv_params(b.fc2, hid, xs, Bc, Ho, Ho, hidc, hidc, 1, 1, 1, 0, C, ACT_NONE, xs, 0, nullptr), dt, st));
-      RC_TRY(tap(h, "stage" + std::to_string(s) + "." + std::to_string(i), xs, xbytes, first, st));
+      RC_TRY(run_gemm(h, st, (sp + ".attn.qkv").c_str(), b.qkv, conv_params(b.qkv, xs, qkv, Bc, Ho, Ho, C, C, 1, 1, 1, 0, 3 * heads * hdp, ACT_NONE, nullptr, 0, nullptr), 3.0 * heads * hd, C));
+      RC_TRY(timed(h, st, (sp + ".attn.core").c_str(), KID_ATTN, 4.0 * Bc * heads * (double)S * S * hd,
+                   [&]() { return launch_attention(qkv, ctx, Bc, S, heads, hdp, scale, dt, st); }));
+      RC_TRY(run_gemm(h, st, (sp + ".attn.proj").c_str(), b.proj, conv_params(b.proj, ctx, xs, Bc, Ho, Ho, heads * hdp, heads * hdp, 1, 1, 1, 0, C, ACT_NONE, xs, 0, nullptr), C, (double)heads * hd));
+      RC_TRY(run_gemm(h, st, (sp + ".mlp.conv1").c_str(), b.fc1, conv_params(b.fc1, xs, hid, Bc, Ho, Ho, C, C, 1, 1, 1, 0, hidc, ACT_GELU, nullptr, 0, nullptr), hidc, C));
+      RC_TRY(run_gemm(h, st, (sp + ".mlp.conv3").c_str(), b.fc2, conv_params(b.fc2, hid, xs, Bc, Ho, Ho, hidc, hidc, 1, 1, 1, 0, C, ACT_NONE, xs, 0, nullptr), C, hidc));
+      RC_TRY(tap(h, sp + "." + std::to_string(i), xs, xbytes, first, st));
     }
   }
-  RC_TRY(launch_pool_affine(x3, h->fscale, h->fshift, feat, Bc, h->H3 * h->H3, h->C3, dt, st));
+  RC_TRY(timed(h, st, "norm.pool", KID_POOL, 0.0, [&]() { return launch_pool_affine(x3, h->fscale, h->fshift, feat, Bc, h->H3 * h->H3, h->C3, dt, st); }));
   return 0;
 }
 
@@ -560,5 +595,60 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
                                  int dtype, void* stream) {
   if (!x || !scale || !shift || !feat || C % 4) return fail(FSVIT_ERR_ARG, "bad argument");
   RC_TRY(launch_pool_affine(x, scale, shift, feat, B, HW, C, dtype, (hipStream_t)stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------ profiling
+extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
+  static const char* f32n[] = {"conv_gemm_kernel<float,128,128,2,2>", "conv_gemm_kernel<float,128,64,2,2>", "conv_gemm_kernel<float,128,32,4,1>",
+                               "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_kernel<float>", "pool_affine_kernel<float>", "proto_head_kernel"};
+  static const char* bf16n[] = {"conv_gemm_kernel<__bf16,128,128,2,2>", "conv_gemm_kernel<__bf16,128,64,2,2>", "conv_gemm_kernel<__bf16,128,32,4,1>",
+                                "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_kernel<__bf16>", "pool_affine_kernel<__bf16>", "proto_head_kernel"};
+  if (kernel_id < 0 || kernel_id > 7) return "?";
+  return dtype == FSVIT_F32 ? f32n[kernel_id] : bf16n[kernel_id];
+}
+
+extern "C" int fsvit_visformer_profile_begin(fsvit_visformer* h) {
+  if (!h) return fail(FSVIT_ERR_ARG, "null argument");
+  h->prof.clear();
+  h->prof_last = nullptr;
+  h->profiling = true;
+  return 0;
+}
+
+extern "C" int fsvit_visformer_profile_end(fsvit_visformer* h, fsvit_prof_rec* out, int max_recs, int* n_out) {
+  if (!h || !out || !n_out) return fail(FSVIT_ERR_ARG, "null argument");
+  h->profiling = false;
+  std::vector<fsvit_prof_rec> agg;
+  hipEvent_t freed = nullptr;
+  for (ProfEntry& e : h->prof) {
+    HIP_TRY(hipEventSynchronize(e.e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e.e0, e.e1));
+    size_t k = 0;
+    for (; k < agg.size(); ++k)
+      if (e.layer == agg[k].layer && e.kernel == agg[k].kernel_id) break;
+    if (k == agg.size()) {
+      fsvit_prof_rec r;
+      memset(&r, 0, sizeof(r));
+      snprintf(r.layer, sizeof(r.layer), "%s", e.layer.c_str());
+      r.kernel_id = e.kernel;
+      agg.push_back(r);
+    }
+    agg[k].flops += e.flops;
+    agg[k].ms += ms;
+    agg[k].launches += 1;
+  }
+  // events are shared between neighbours (e1 of launch i is e0 of launch i+1 inside a chunk)
+  for (ProfEntry& e : h->prof) {
+    if (e.e0 != freed) (void)hipEventDestroy(e.e0);
+    (void)hipEventDestroy(e.e1);
+    freed = e.e1;
+  }
+  h->prof.clear();
+  h->prof_last = nullptr;
+  *n_out = (int)agg.size();
+  if ((int)agg.size() > max_recs) return fail(FSVIT_ERR_ARG, "profile has %zu records, buffer holds %d", agg.size(), max_recs);
+  for (size_t i = 0; i < agg.size(); ++i) out[i] = agg[i];
   return 0;
 }

@@ -102,6 +102,18 @@ class VisformerEngine:
         self._taps[name] = t
         return t
 
+    def profile_begin(self):
+        _lib.check(self.lib.fsvit_visformer_profile_begin(self.h))
+
+    def profile_end(self):
+        """-> list of dict(layer, kernel, launches, flops, ms): HIP-event time of every launch since
+        profile_begin, summed per (layer, kernel template instantiation)."""
+        recs = (_lib.ProfRec * 256)()
+        n = C.c_int(0)
+        _lib.check(self.lib.fsvit_visformer_profile_end(self.h, recs, 256, C.byref(n)))
+        return [dict(layer=recs[i].layer.decode(), kernel=self.lib.fsvit_kernel_name(recs[i].kernel_id, self.dtype).decode(),
+                     launches=recs[i].launches, flops=recs[i].flops, ms=recs[i].ms) for i in range(n.value)]
+
     def forward(self, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         """x [B,3,H,W] fp32 cuda -> pooled features [B,out_dim] fp32."""
         _require_cuda(x)

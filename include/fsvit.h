@@ -81,6 +81,22 @@ int fsvit_visformer_forward(fsvit_visformer* h, const float* x_nchw_dev, int n_i
  * "patch_embed2"/"patch_embed3" (incl. pos_embed), "stage2.N", "stage3.N".  dst_dev NULL clears. */
 int fsvit_visformer_set_tap(fsvit_visformer* h, const char* name, void* dst_dev, size_t bytes);
 
+/* Live per-launch timing (bench.py roofline leg): between begin and end every kernel launch of
+ * fsvit_visformer_forward is bracketed by HIP events ON THE STREAM IT IS LAUNCHED ON.  `end`
+ * synchronises and returns one record per (layer, kernel) with summed algorithmic FLOPs (2*MAC,
+ * unpadded dims), summed milliseconds and the launch count. */
+typedef struct fsvit_prof_rec {
+  char layer[48];     /* e.g. "stem.conv3", "stage2.attn.qkv" */
+  int kernel_id;      /* see fsvit_kernel_name */
+  int launches;
+  double flops;
+  double ms;
+} fsvit_prof_rec;
+int fsvit_visformer_profile_begin(fsvit_visformer* h);
+int fsvit_visformer_profile_end(fsvit_visformer* h, fsvit_prof_rec* out, int max_recs, int* n_out);
+/* Device kernel (template instantiation) behind a kernel_id, as rocprofv3 --kernel-trace names it. */
+const char* fsvit_kernel_name(int kernel_id, int dtype);
+
 /* ---------------------------------------------------------------- episode head
  * Replaces MetaBaseline.forward after the encoder call (test_phase/models/meta_baseline.py:33-47),
  * utils.compute_logits (utils/__init__.py:78-101) and, per episode, F.cross_entropy +
