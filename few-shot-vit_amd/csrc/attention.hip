@@ -130,10 +130,170 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// v2: register-resident softmax.  One workgroup per (image, head), NW waves; K (row-major) and V^T
+// are staged once in LDS, each wave then owns whole 16-query tiles with no further barrier:
+//   S^T tile = K . Q^T on MFMA (operands swapped) puts all keys of query (lane&15) into the 4 lanes
+//   {lane&15 + 16*j}: the row max / sum are an in-lane reduction plus two cross-lane steps;
+//   P stays in registers: the C-layout of S^T (4 consecutive keys per lane) is fed straight back as
+//   the MFMA B operand of ctx^T = V^T . P^T -- the k-permutation it implies is applied to the V^T
+//   fragment read instead (two 8-byte LDS reads per 32-key chunk for bf16; the natural 16-byte read
+//   for fp32), so no LDS round trip or lane shuffle is needed for P.
+// NKT = key tiles of 16 (keys padded to the 64-byte chunk, masked), NDT = head-dim tiles of 16.
+template <typename T, int NKT, int NDT, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_v2_kernel(const T* __restrict__ qkv, T* __restrict__ ctx,
+                                                               int S, int heads, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ES = sizeof(T);
+  constexpr int EPC = Elem<T>::kPerChunk;
+  constexpr int HDP = NDT * 16;
+  constexpr int SKP = NKT * 16;
+  constexpr int QS = HDP * ES + 16;            // K row stride (bytes): odd multiple of 16 -> conflict-free b128 reads
+  constexpr int VS = SKP * ES + 16;            // V^T row stride
+  constexpr int NKC = HDP * ES / 64;           // 64-byte chunks along the head dim
+  unsigned char* const Ks = smem;
+  unsigned char* const Vt = smem + SKP * QS;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lrow = lane & 15, lq = lane >> 4;
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const int rowlen = 3 * heads * HDP;
+  const T* base = qkv + (size_t)b * S * rowlen + h * HDP;
+  constexpr int CPR = HDP / EPC;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  for (int idx = t; idx < SKP * CPR; idx += NW * 64) {
+    const int row = idx / CPR, ch = idx - row * CPR;
+    u32x4 k = zero4, v = zero4;
+    if (row < S) {
+      const T* src = base + (size_t)row * rowlen + heads * HDP + ch * EPC;
+      k = *reinterpret_cast<const u32x4*>(src);
+      v = *reinterpret_cast<const u32x4*>(src + heads * HDP);
+    }
+    *reinterpret_cast<u32x4*>(Ks + row * QS + ch * 16) = k;
+    const T* ve = reinterpret_cast<const T*>(&v);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) *reinterpret_cast<T*>(Vt + (ch * EPC + e) * VS + row * ES) = ve[e];
+  }
+  __syncthreads();
+
+  const int nqt = (S + 15) / 16;
+  T* obase = ctx + (size_t)b * S * heads * HDP + h * HDP;
+  for (int qt = wave; qt < nqt; qt += NW) {
+    const int q = qt * 16 + lrow;
+    // Q fragments straight from global: row q, 16-byte chunk (kc*4 + lq)
+    u32x4 qf[NKC];
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc)
+      qf[kc] = q < S ? *reinterpret_cast<const u32x4*>(base + (size_t)q * rowlen + (kc * 4 + lq) * EPC) : zero4;
+    f32x4 sc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const unsigned char* ka = Ks + (kt * 16 + lrow) * QS + lq * 16;
+#pragma unroll
+      for (int kc = 0; kc < NKC; ++kc) acc = mma_chunk<T>(*reinterpret_cast<const u32x4*>(ka + kc * 64), qf[kc], acc);
+      sc[kt] = acc;                      // keys kt*16 + lq*4 + r  x  query lrow
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = kt * 16 + lq * 4 + r < S;
+        sc[kt][r] = ok ? sc[kt][r] * scale : -INFINITY;
+        m = fmaxf(m, sc[kt][r]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = kt * 16 + lq * 4 + r < S ? expf(sc[kt][r] - m) : 0.f;
+        sc[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    // ctx^T[d][q] = sum_key V^T[d][key] * P[q][key]
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const unsigned char* va = Vt + (dt * 16 + lrow) * VS;
+      if constexpr (ES == 4) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          const u32x4 vf = *reinterpret_cast<const u32x4*>(va + kt * 64 + lq * 16);
+          acc = mma_chunk<T>(vf, __builtin_bit_cast(u32x4, sc[kt]), acc);
+        }
+      } else {
+#pragma unroll
+        for (int kc = 0; kc < NKT / 2; ++kc) {
+          const u32x2 v0 = *reinterpret_cast<const u32x2*>(va + (32 * kc + lq * 4) * 2);
+          const u32x2 v1 = *reinterpret_cast<const u32x2*>(va + (32 * kc + 16 + lq * 4) * 2);
+          const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+          const bf16x8 pb = {(bf16)sc[2 * kc][0], (bf16)sc[2 * kc][1], (bf16)sc[2 * kc][2], (bf16)sc[2 * kc][3],
+                             (bf16)sc[2 * kc + 1][0], (bf16)sc[2 * kc + 1][1], (bf16)sc[2 * kc + 1][2], (bf16)sc[2 * kc + 1][3]};
+          acc = mma_chunk<T>(vf, __builtin_bit_cast(u32x4, pb), acc);
+        }
+      }
+      if (q < S) store4<T>(obase + (size_t)q * heads * HDP + dt * 16 + lq * 4, acc * inv);
+    }
+  }
+}
+
+template <typename T, int NKT, int NDT, int NW>
+static int launch_v2(const void* qkv, void* ctx, int B, int S, int heads, float scale, hipStream_t s) {
+  constexpr int ES = sizeof(T);
+  const size_t lds = (size_t)NKT * 16 * (NDT * 16 * ES + 16) + (size_t)NDT * 16 * (NKT * 16 * ES + 16);
+  auto kern = attention_v2_kernel<T, NKT, NDT, NW>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3(B * heads), dim3(NW * 64), lds, s, (const T*)qkv, (T*)ctx, S, heads, scale);
+  return (int)hipGetLastError();
+}
+
+// returns -1 when no v2 instantiation covers the shape (caller falls back to the generic v1 kernel)
+template <typename T, int NKT, int NW>
+static int dispatch_ndt(int ndt, const void* qkv, void* ctx, int B, int S, int heads, float scale, hipStream_t s) {
+  switch (ndt) {
+    case 1: if constexpr (sizeof(T) == 4) return launch_v2<T, NKT, 1, NW>(qkv, ctx, B, S, heads, scale, s); else return -1;
+    case 2: return launch_v2<T, NKT, 2, NW>(qkv, ctx, B, S, heads, scale, s);
+    case 3: if constexpr (sizeof(T) == 4) return launch_v2<T, NKT, 3, NW>(qkv, ctx, B, S, heads, scale, s); else return -1;
+    case 4: return launch_v2<T, NKT, 4, NW>(qkv, ctx, B, S, heads, scale, s);
+    case 6: return launch_v2<T, NKT, 6, NW>(qkv, ctx, B, S, heads, scale, s);
+    case 8: return launch_v2<T, NKT, 8, NW>(qkv, ctx, B, S, heads, scale, s);
+    default: return -1;
+  }
+}
+
+static int launch_attention_v2(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, hipStream_t s) {
+  const int ndt = hdp / 16;
+  if (dtype == 0) {
+    if (S <= 32) return dispatch_ndt<float, 2, 2>(ndt, qkv, ctx, B, S, heads, scale, s);
+    if (S <= 112) return dispatch_ndt<float, 7, 4>(ndt, qkv, ctx, B, S, heads, scale, s);
+  } else {
+    if (S <= 32) return dispatch_ndt<bf16, 2, 2>(ndt, qkv, ctx, B, S, heads, scale, s);
+    if (S <= 128) return dispatch_ndt<bf16, 8, 4>(ndt, qkv, ctx, B, S, heads, scale, s);
+  }
+  return -1;
+}
+
 int launch_attention(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, hipStream_t s) {
   if (B <= 0) return 0;
   const int es = dtype == 0 ? 4 : 2;
   if (S < 1 || S > 128 || hdp % (64 / es) != 0) return (int)hipErrorInvalidValue;
+  {
+    const int rc = launch_attention_v2(qkv, ctx, B, S, heads, hdp, scale, dtype, s);
+    if (rc != -1) return rc;
+  }
   const size_t lds = attention_lds_bytes(S, hdp, dtype);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   dim3 grid(B * heads), block(256);
