@@ -39,5 +39,7 @@ struct ConvGemmParams {
 
 // dtype: 0 = f32 (exact fp32 MFMA), 1 = bf16.  Returns hipError_t as int.
 int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream);
+int launch_conv_gemm_v1(const ConvGemmParams& p, int dtype, hipStream_t stream);
+int launch_conv_gemm_v2(const ConvGemmParams& p, int dtype, hipStream_t stream);
 
 }  // namespace fsvit

@@ -8,6 +8,8 @@
 // so that both the ds_write_b128 staging and the ds_read_b128 fragment reads are conflict-free
 // (tools/lds_conflicts.py).  The MFMA computes the TRANSPOSED tile  D^T[n][m] = W[n][:] . X[m][:]
 // so every lane ends up with 4 consecutive output channels of one pixel -> 8/16-byte stores.
+#include <stdlib.h>
+
 #include "conv_gemm.h"
 #include "fsvit_common.h"
 
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
       if (R) r = load4<T>(R + rowoff + n);
       if (p.res_first) v += r;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act);
+      for (int e = 0; e < 4; ++e) v[e] = apply_act<sizeof(T) == 2>(v[e], p.act);
       if (!p.res_first) v += r;
       if (posrow) v += *reinterpret_cast<const f32x4*>(posrow + n);
       store4<T>(Y + rowoff + n, v);
@@ -186,9 +188,16 @@ static int launch_t(const ConvGemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream) {
+int launch_conv_gemm_v1(const ConvGemmParams& p, int dtype, hipStream_t stream) {
   if (p.M <= 0) return 0;
   return dtype == 0 ? launch_t<float>(p, stream) : launch_t<bf16>(p, stream);
+}
+
+// v2 (persistent + LDS-DMA, conv_gemm_v2.hip) is the product path; FSVIT_GEMM=v1 keeps the first
+// register-staged kernel reachable for A/B measurements.
+int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream) {
+  static const bool use_v1 = [] { const char* e = getenv("FSVIT_GEMM"); return e && e[0] == 'v' && e[1] == '1'; }();
+  return use_v1 ? launch_conv_gemm_v1(p, dtype, stream) : launch_conv_gemm_v2(p, dtype, stream);
 }
 
 }  // namespace fsvit

@@ -1,0 +1,304 @@
+// Implicit-GEMM convolution, v2: persistent workgroups + direct-to-LDS (LDS-DMA) staging.
+//
+// Same math, operand layouts, fragment mapping and epilogue as conv_gemm.hip (v1); what changes is
+// the data movement, which is what bounded v1 (rocprof r01_v1: 515 TF/s at K=N=2048, 100-260 TF/s on
+// the K<=256 layers):
+//   * both operand tiles are staged with `global_load_lds_dwordx4` (16 B per lane, 1 KiB per wave
+//     instruction, no VGPR round trip, no ds_write pass).  The LDS image is lane-linear, so the
+//     (row & 7) XOR swizzle that keeps ds_read_b128 conflict-free is applied to the per-lane SOURCE
+//     chunk instead: lane l of a wave fills chunk slot (l & 7) of row (l >> 3) with global chunk
+//     (l & 7) ^ (l >> 3).  Out-of-image taps / tile tails read a 16-byte zero page.
+//   * workgroups are persistent: each walks a list of (m-tile, n-tile) items and runs ONE software
+//     pipeline over the flattened (item, k-slice) sequence, so the first K slice of the next tile
+//     streams in under the last MFMAs and the epilogue of the current one — the prologue/epilogue
+//     bubbles that dominated the small-K layers disappear.
+//   * the item list is XCD-aware: workgroup b runs on XCD b % 8 (observed placement, used for speed
+//     only), and each XCD owns whole m-tiles and visits all their n-tiles back to back, so an
+//     activation tile is fetched from HBM once and re-read by its other n-tiles from that XCD's L2.
+#include "conv_gemm.h"
+#include "fsvit_common.h"
+
+namespace fsvit {
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS-DMA issued through inline asm so hipcc's waitcnt pass does not see it: with the builtin, any
+// ordinary global load in the loop (the epilogue's bias fetch was enough) made the pass put
+// `s_waitcnt vmcnt(0)` in front of the first ds_read of EVERY k-step, i.e. drain the DMA right after
+// issuing it (cdna_hip_programming.md 5 "three .s-level traps" (b)).  Hidden from the pass, the DMA
+// is ordered by hand: dma_wait_all() before the barrier that publishes a buffer.  The compiler's own
+// counted waits for its ordinary loads stay safe: extra in-flight operations only make vmcnt(N)
+// stricter.  M0 (the LDS destination base) is written in the same statement that consumes it.
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_byte_addr)
+      : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lptr_t)p; }
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int MINB>
+__global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmParams p, const int tiles_m, const int tiles_n) {
+  constexpr int EPC = Elem<T>::kPerChunk;
+  constexpr int BKE = Elem<T>::kBK;
+  constexpr int TM = BM / WAVES_M / 16;
+  constexpr int TN = BN / WAVES_N / 16;
+  constexpr int A_IT = BM / 32;
+  constexpr int B_IT = BN / 32;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * 128];
+  unsigned char* const ldsA0 = smem;
+  unsigned char* const ldsB0 = smem + 2 * BM * 128;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int lrow = lane & 15, lq = lane >> 4, rswz = lane & 7;
+  const int srow = lane >> 3;                  // staging: row inside the wave's 8-row group
+  const int sc = (lane & 7) ^ srow;            // staging: global 16-byte chunk this lane fetches (pre-swizzled)
+
+  // ---- work list of this workgroup
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, P = gridDim.x >> 3;
+  const int MG = p.groups * tiles_m;                            // (group, m-tile) pairs, dealt round-robin to XCDs
+  const int cnt = MG > xcd ? ((MG - xcd + 7) / 8) * tiles_n : 0;   // items owned by this XCD
+  if (slot >= cnt) return;
+
+  const int ohw = p.OH * p.OW;
+  const int nk = p.Kw / BKE;
+  const bool multi_tap = (p.KH * p.KW) > 1;
+  const T* const zero = reinterpret_cast<const T*>(g_zero_page);
+
+  // ---- load cursor state (one pipeline step ahead of the compute cursor)
+  int iy0[A_IT], ix0[A_IT], pixbase[A_IT];
+  bool rowok[A_IT];
+  const T* wrow[B_IT];
+  bool nok[B_IT];
+  const T* Xg = nullptr;
+  auto setup = [&](int j) {
+    const int mg = xcd + 8 * (j / tiles_n), nt = j % tiles_n;
+    const int g = mg / tiles_m, mt = mg - g * tiles_m;
+    Xg = reinterpret_cast<const T*>(p.x) + (size_t)g * p.Cin;
+    const T* Wg = reinterpret_cast<const T*>(p.w) + (size_t)g * p.N * p.Kw;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int m = mt * BM + 32 * i + 8 * wave + srow;
+      rowok[i] = m < p.M;
+      const int mm = rowok[i] ? m : 0;
+      const int b = mm / ohw;
+      const int rem = mm - b * ohw;
+      const int oy = rem / p.OW;
+      const int ox = rem - oy * p.OW;
+      iy0[i] = oy * p.stride - p.pad;
+      ix0[i] = ox * p.stride - p.pad;
+      pixbase[i] = b * p.H * p.W;
+    }
+#pragma unroll
+    for (int jj = 0; jj < B_IT; ++jj) {
+      const int n = nt * BN + 32 * jj + 8 * wave + srow;
+      nok[jj] = n < p.N;
+      wrow[jj] = Wg + (size_t)(nok[jj] ? n : 0) * p.Kw + sc * EPC;
+    }
+  };
+  auto issue = [&](int kt, int buf) {
+    const int k = kt * BKE + sc * EPC;
+    int ky = 0, kx = 0, cc = k;
+    if (multi_tap) {
+      const int tap = k >> p.log2Cin;
+      cc = k & (p.Cin - 1);
+      ky = tap / p.KW;
+      kx = tap - ky * p.KW;
+    }
+    const bool kok = k < p.K;
+    const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr(ldsA0) + buf * (BM * 128) + wave * (8 * 128));
+    const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(ldsB0) + buf * (BN * 128) + wave * (8 * 128));
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+      const bool ok = kok && rowok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const T* src = ok ? Xg + (size_t)(pixbase[i] + iy * p.W + ix) * p.x_cstride + cc : zero;
+      dma16(src, la + i * (32 * 128));
+    }
+#pragma unroll
+    for (int jj = 0; jj < B_IT; ++jj) {
+      const T* src = nok[jj] ? wrow[jj] + (size_t)kt * BKE : zero;
+      dma16(src, lb + jj * (32 * 128));
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int buf) {
+    const unsigned char* a = ldsA0 + buf * (BM * 128) + (wm * TM * 16 + lrow) * 128;
+    const unsigned char* b = ldsB0 + buf * (BN * 128) + (wn * TN * 16 + lrow) * 128;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      const int off = (((kc * 4 + lq) ^ rswz) << 4);
+      u32x4 xf[TM], wf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const u32x4*>(a + i * 16 * 128 + off);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const u32x4*>(b + j * 16 * 128 + off);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = mma_chunk<T>(wf[j], xf[i], acc[i][j]);
+    }
+  };
+
+  T* __restrict__ Y = reinterpret_cast<T*>(p.y);
+  const T* __restrict__ R = reinterpret_cast<const T*>(p.res);
+  // Epilogue in two passes so no load sits behind a dependent wait: (1) issue every bias / residual /
+  // pos-embed load of the tile back to back, (2) arithmetic + stores.  The activation is selected by
+  // ONE wave-uniform branch around the whole pass (a per-element switch compiles to a branch tree).
+  auto epilogue = [&](int j) {
+    const int mg = xcd + 8 * (j / tiles_n), nt = j % tiles_n;
+    const int g = mg / tiles_m, mt = mg - g * tiles_m;
+    const int cg = g * p.N;
+    const int nb = nt * BN + wn * TN * 16 + lq * 4;
+    const int mb = mt * BM + wm * TM * 16 + lrow;
+    // Loads are UNCONDITIONAL on clamped (always in-bounds) coordinates so they issue back to back
+    // with a single wait; a per-lane `ok ? load : 0` becomes an exec-masked branch + vmcnt(0) per
+    // load.  Only the stores are predicated.
+    int ncl[TN];
+    bool nk_[TN];
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+      const int n = nb + jn * 16;
+      nk_[jn] = n < p.N;
+      ncl[jn] = cg + (nk_[jn] ? n : p.N - 4);
+    }
+    f32x4 bv[TN];
+    if (p.bias) {
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) bv[jn] = *reinterpret_cast<const f32x4*>(p.bias + ncl[jn]);
+    } else {
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) bv[jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    constexpr int HB = TM > 2 ? 2 : TM;
+    auto batch = [&](int i0, auto actf) {
+      f32x4 rv[HB][TN];
+      size_t rowoff[HB];
+      bool mk_[HB];
+#pragma unroll
+      for (int i = 0; i < HB; ++i) {
+        const int m = mb + (i0 + i) * 16;
+        mk_[i] = m < p.M;
+        rowoff[i] = (size_t)(mk_[i] ? m : p.M - 1) * p.y_cstride;
+      }
+      if (R) {
+#pragma unroll
+        for (int i = 0; i < HB; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn) rv[i][jn] = load4<T>(R + rowoff[i] + ncl[jn]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < HB; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn) rv[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (p.res_first) {
+#pragma unroll
+        for (int i = 0; i < HB; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn) { acc[i0 + i][jn] += rv[i][jn]; rv[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      }
+      if (p.pos) {
+#pragma unroll
+        for (int i = 0; i < HB; ++i) {
+          const int m = mk_[i] ? mb + (i0 + i) * 16 : p.M - 1;
+          const float* posrow = p.pos + (size_t)(m % ohw) * p.y_cstride;
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn) rv[i][jn] += *reinterpret_cast<const f32x4*>(posrow + ncl[jn]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < HB; ++i) {
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+          f32x4 v = acc[i0 + i][jn] + bv[jn];
+          acc[i0 + i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = actf(v[e]);
+          v += rv[i][jn];
+          if (mk_[i] && nk_[jn]) store4<T>(Y + rowoff[i] + ncl[jn], v);
+        }
+      }
+    };
+    auto finish = [&](auto actf) {
+#pragma unroll
+      for (int i0 = 0; i0 < TM; i0 += HB) batch(i0, actf);
+    };
+    if (p.act == ACT_GELU) finish([](float x) { return sizeof(T) == 2 ? gelu_fast(x) : gelu_erf(x); });
+    else if (p.act == ACT_LRELU) finish([](float x) { return x > 0.0f ? x : 0.1f * x; });
+    else finish([](float x) { return x; });
+  };
+
+  // ---- one software pipeline over the flattened (item, k-slice) sequence.  The inner k-loop holds
+  // only DMA issue + LDS reads + MFMA (no ordinary VMEM access may sit in it, or hipcc drains vmcnt
+  // at its header every step); the first slice of the NEXT item is issued before the last MFMAs and
+  // the epilogue of the current one.
+  int buf = 0;
+  setup(slot);
+  issue(0, 0);
+  dma_wait_all();
+  __syncthreads();                       // buffer 0 landed in every wave's view
+  for (int j = slot; j < cnt; j += P) {
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      issue(kt + 1, buf ^ 1);
+      compute(buf);
+      dma_wait_all();                    // this wave's share of the next buffer has landed ...
+      __syncthreads();                   // ... so has everyone's, and everyone is done reading `buf`
+      buf ^= 1;
+    }
+    const int jn = j + P;
+    if (jn < cnt) {
+      setup(jn);
+      issue(0, buf ^ 1);
+    }
+    compute(buf);
+    epilogue(j);
+    dma_wait_all();
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int MINB>
+static int launch_cfg(const ConvGemmParams& p, hipStream_t stream) {
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const long items = (long)p.groups * tiles_m * tiles_n;
+  long grid = 256L * MINB;                       // persistent: MINB workgroups per CU
+  if (items < grid) grid = (items + 7) / 8 * 8;
+  hipLaunchKernelGGL((conv_gemm_v2_kernel<T, BM, BN, WAVES_M, WAVES_N, MINB>), dim3((unsigned)grid), dim3(256), 0, stream, p, tiles_m, tiles_n);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+static int launch_v2_t(const ConvGemmParams& p, hipStream_t stream) {
+  if (p.N > 64) return launch_cfg<T, 128, 128, 2, 2, 2>(p, stream);
+  if (p.N > 32) return launch_cfg<T, 128, 64, 2, 2, 3>(p, stream);
+  return launch_cfg<T, 128, 32, 4, 1, 3>(p, stream);
+}
+
+int launch_conv_gemm_v2(const ConvGemmParams& p, int dtype, hipStream_t stream) {
+  if (p.M <= 0) return 0;
+  return dtype == 0 ? launch_v2_t<float>(p, stream) : launch_v2_t<bf16>(p, stream);
+}
+
+}  // namespace fsvit

@@ -600,9 +600,9 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 
 // ------------------------------------------------------------------------------------ profiling
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
-  static const char* f32n[] = {"conv_gemm_kernel<float,128,128,2,2>", "conv_gemm_kernel<float,128,64,2,2>", "conv_gemm_kernel<float,128,32,4,1>",
+  static const char* f32n[] = {"conv_gemm_v2_kernel<float,128,128,2,2,2>", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
                                "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel"};
-  static const char* bf16n[] = {"conv_gemm_kernel<__bf16,128,128,2,2>", "conv_gemm_kernel<__bf16,128,64,2,2>", "conv_gemm_kernel<__bf16,128,32,4,1>",
+  static const char* bf16n[] = {"conv_gemm_v2_kernel<__bf16,128,128,2,2,2>", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
                                 "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel"};
   if (kernel_id < 0 || kernel_id > 7) return "?";
   return dtype == FSVIT_F32 ? f32n[kernel_id] : bf16n[kernel_id];
