@@ -38,10 +38,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--episodes', type=int, default=16, help='episodes per GPU per step (ep_per_batch)')
+    ap.add_argument('--episodes', type=int, default=32, help='episodes per GPU per step (ep_per_batch)')
     ap.add_argument('--shot', type=int, default=5)
     ap.add_argument('--numerics', default='bf16', choices=['bf16', 'parity'])
-    ap.add_argument('--chunk', type=int, default=int(os.environ.get('FSVIT_CHUNK', 400)), help='images per encoder chunk')
+    ap.add_argument('--chunk', type=int, default=int(os.environ.get('FSVIT_CHUNK', 1600)), help='images per encoder chunk')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-episodes', type=int, default=16)

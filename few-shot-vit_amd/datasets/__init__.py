@@ -1,1 +1,3 @@
+from .datasets import make, register, datasets  # noqa: F401
 from .samplers import CategoriesSampler  # noqa: F401
+from . import synthetic  # noqa: F401  registers 'synthetic-episodes'

@@ -52,7 +52,7 @@ class VisformerEngine:
         self.device = torch.device(device if device is not None else 'cuda')
         if self.device.type != 'cuda':
             raise RuntimeError('VisformerEngine needs a GPU device (no CPU fallback)')
-        self.chunk_images = int(chunk_images or os.environ.get('FSVIT_CHUNK', 400))
+        self.chunk_images = int(chunk_images or os.environ.get("FSVIT_CHUNK", 1600))
         c = _lib.VisformerCfg()
         c.img_size, c.init_channels, c.embed_dim = cfg['img_size'], cfg['init_channels'], cfg['embed_dim']
         for i in range(3):

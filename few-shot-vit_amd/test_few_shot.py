@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Episodic few-shot evaluation driver with the reference's CLI / YAML surface
+(test_phase/test_few_shot.py:36-134): 5-way `--shot`-shot, 15 queries per class, 2000 batches of
+`ep_per_batch`=1 episode, seeds 12345, `acc +- 95 % CI` over per-batch accuracies.
+
+MI355X-native differences (results are unchanged by them):
+  * many batches are pushed through the HIP engine per launch (`--launch-batches`), because one
+    80-100 image episode cannot fill the GPU; accuracies stay per batch, so the CI is the same;
+  * multi-GPU = one process per GPU (torchrun), episodes sharded rank::world from the SAME sampler
+    stream, one all-gather of the per-batch statistics at the end (parallel.py) instead of
+    nn.DataParallel;
+  * `--episodes` limits the number of batches (BASELINE config 1 uses 100) without changing the stream.
+
+  python -m fewshot_vit_amd.test_few_shot --config few-shot-vit_amd/configs/test_synthetic.yaml --shot 5
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m fewshot_vit_amd.test_few_shot ...
+"""
+import argparse
+
+import numpy as np
+import torch
+import yaml
+
+from . import datasets, models, parallel, utils
+from .datasets.samplers import CategoriesSampler
+from .utils import few_shot as fs
+
+
+def fix_random_seeds(seed=12345):
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+
+
+def build_model(config, numerics=None):
+    """`load` / `load_encoder` handling of test_few_shot.py:56-63."""
+    if config.get('load') is None:
+        model = models.make('meta-baseline', encoder=None)
+    else:
+        model = models.load(torch.load(config['load'], map_location='cpu'))
+    if config.get('load_encoder') is not None:
+        model.encoder = models.load(torch.load(config['load_encoder'], map_location='cpu')).encoder
+    if config.get('synthetic_checkpoint'):            # offline stand-in: procedural weights + calibrated BN
+        from . import synthetic
+        model = models.make('meta-baseline', encoder=config['synthetic_checkpoint'], encoder_args={})
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict(synthetic.synthetic_checkpoint_sd(shapes, calib=config['synthetic_checkpoint']))
+    if model.encoder is None:
+        raise ValueError('config must provide load, load_encoder or synthetic_checkpoint')
+    if numerics is not None:
+        model.encoder.numerics = numerics
+    return model
+
+
+def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch_batches=16, numerics=None,
+             rank=0, world=1, device=None, log=print):
+    fix_random_seeds(12345)
+    dataset = datasets.make(config['dataset'], **config['dataset_args'])
+    n_way, n_query = 5, 15
+    sampler = CategoriesSampler(dataset.label, n_batch, n_way, shot + n_query, ep_per_batch=ep_per_batch,
+                                rank=rank, world_size=world)
+    device = device or torch.device('cuda', torch.cuda.current_device())
+    model = build_model(config, numerics).to(device).eval()
+    if rank == 0:
+        log('num params: {}'.format(utils.compute_n_params(model)))
+    engine = model.encoder.engine()
+    temp = float(model.temp.detach()) if isinstance(model.temp, torch.Tensor) else float(model.temp)
+
+    np.random.seed(12345)                                  # fixes the episode stream (test_few_shot.py:76)
+    out = None
+    for epoch in range(1, test_epochs + 1):
+        accs, losses, last_label = [], [], None
+        pending = []
+
+        def flush():
+            if not pending:
+                return
+            data = torch.stack([torch.stack([dataset[int(i)][0] for i in idx]) for idx in pending])   # [G, E*way*(S+Q), 3,H,W]
+            G = data.shape[0]
+            data = data.view(G * ep_per_batch * n_way * (shot + n_query), *data.shape[2:]).to(device, non_blocking=True)
+            x_shot, x_query = fs.split_shot_query(data, n_way, shot, n_query, ep_per_batch=G * ep_per_batch)
+            _, acc, loss = engine.meta_baseline_forward(x_shot, x_query, temp, model.method, want_stats=True)
+            accs.append(acc.view(G, ep_per_batch).mean(dim=1))       # per reference batch
+            losses.append(loss.view(G, ep_per_batch).mean(dim=1))
+            pending.clear()
+
+        for idx in sampler:
+            pending.append(idx)
+            last_label = dataset.label[int(idx[-1])]
+            if len(pending) == launch_batches:
+                flush()
+        flush()
+        mine = torch.stack([torch.cat(accs), torch.cat(losses)], dim=1).double() if accs else torch.zeros(0, 2, dtype=torch.float64, device=device)
+        allv = parallel.gather_in_stream_order(mine, n_batch, rank, world).cpu().numpy()     # the one exchange
+        va_lst = allv[:, 0].tolist()
+        aves_va, aves_vl = utils.Averager(), utils.Averager()
+        per_batch_items = ep_per_batch * n_way * (shot + n_query)
+        for a, l in allv:
+            aves_va.add(a, per_batch_items)
+            aves_vl.add(l, per_batch_items)
+        out = dict(acc=aves_va.item(), ci=float(utils.mean_confidence_interval(va_lst)) if len(va_lst) > 1 else float('nan'),
+                   loss=aves_vl.item(), n=len(va_lst), last_label=last_label, va_lst=va_lst)
+        if rank == 0:
+            log('test epoch {}: acc={:.2f} +- {:.2f} (%), loss={:.4f} (@{})'.format(
+                epoch, out['acc'] * 100, out['ci'] * 100, out['loss'], last_label))
+    return out
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--config', default='./configs/test_few_shot.yaml')
+    parser.add_argument('--shot', type=int, default=1)
+    parser.add_argument('--test-epochs', type=int, default=1)
+    parser.add_argument('--gpu', default=None, help='kept for CLI compatibility; use torchrun for multi-GPU')
+    parser.add_argument('--episodes', type=int, default=2000, help='number of batches (reference: 2000)')
+    parser.add_argument('--ep-per-batch', type=int, default=1)
+    parser.add_argument('--launch-batches', type=int, default=16)
+    parser.add_argument('--numerics', default=None, choices=[None, 'bf16', 'parity'])
+    args = parser.parse_args()
+    config = yaml.load(open(args.config, 'r'), Loader=yaml.FullLoader)
+    if args.gpu is not None and ',' not in args.gpu:
+        utils.set_gpu(args.gpu)
+    rank, world, local = parallel.init_from_env()
+    torch.cuda.set_device(local)
+    evaluate(config, shot=args.shot, test_epochs=args.test_epochs, n_batch=args.episodes, ep_per_batch=args.ep_per_batch,
+             launch_batches=args.launch_batches, numerics=args.numerics, rank=rank, world=world,
+             device=torch.device('cuda', local), log=utils.log)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
