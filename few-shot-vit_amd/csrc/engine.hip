@@ -9,6 +9,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <utility>
 #include <cstdint>
 #include <initializer_list>
 #include <map>
@@ -321,7 +323,7 @@ struct Plan {
   size_t patches, c1, ident, c2, c3;     // stem scratch
   size_t ha, hb;                         // stage-1 hidden
   size_t qkv, ctx, hid;                  // stage-2/3 scratch
-  size_t x1, x2, x3;                     // residual streams
+  size_t x1, x1b, x2, x3;                // residual streams (x1b: ping-pong partner for the fused stage-1 block)
   size_t total;
 };
 
@@ -334,6 +336,7 @@ Plan make_plan(const fsvit_visformer* h, size_t Bc) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
   p.x1 = take(Bc * P1 * h->C1 * es);
+  p.x1b = take(Bc * P1 * h->C1 * es);
   p.x2 = take(Bc * P2 * h->C2 * es);
   p.x3 = take(Bc * P3 * h->C3 * es);
   const size_t scratch0 = off;
@@ -385,7 +388,7 @@ int tap(fsvit_visformer* h, const std::string& name, const void* src, size_t byt
 }
 
 // kernel ids reported by the profiler (names in fsvit_kernel_name)
-enum { KID_GEMM128 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7 };
+enum { KID_GEMM128 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8 };
 
 int gemm_kid(const Layer& L) { return L.N > 64 ? KID_GEMM128 : (L.N > 32 ? KID_GEMM64 : KID_GEMM32); }
 
@@ -415,7 +418,7 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
   const size_t es = h->es;
   const int heads = h->cfg.num_heads;
   void *patches = ws + pl.patches, *c1 = ws + pl.c1, *ident = ws + pl.ident, *c2 = ws + pl.c2, *c3 = ws + pl.c3;
-  void *x1 = ws + pl.x1, *x2 = ws + pl.x2, *x3 = ws + pl.x3, *ha = ws + pl.ha, *hb = ws + pl.hb;
+  void *x1 = ws + pl.x1, *x1b = ws + pl.x1b, *x2 = ws + pl.x2, *x3 = ws + pl.x3, *ha = ws + pl.ha, *hb = ws + pl.hb;
   void *qkv = ws + pl.qkv, *ctx = ws + pl.ctx, *hid = ws + pl.hid;
   const int img = h->cfg.img_size;
 
@@ -431,11 +434,20 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
 
   // stage 1: x += conv3(GELU(conv2_g(GELU(conv1(BN(x))))))
   const int Cg = h->hid1 / h->cfg.group;
+  static const bool no_fuse = [] { const char* e = getenv("FSVIT_NO_FUSE"); return e && e[0] == '1'; }();
+  const bool fuse1 = !no_fuse && stage1_fused_supported(dt, h->C1, h->hid1, h->cfg.group, h->H1);
   for (size_t i = 0; i < h->s1.size(); ++i) {
     const Block1& b = h->s1[i];
-    RC_TRY(run_gemm(h, st, "stage1.mlp.conv1", b.c1, conv_params(b.c1, x1, ha, Bc, h->H1, h->H1, h->C1, h->C1, 1, 1, 1, 0, h->hid1, ACT_GELU, nullptr, 0, nullptr), h->hid1, h->C1));
-    RC_TRY(run_gemm(h, st, "stage1.mlp.conv2", b.c2, conv_params(b.c2, ha, hb, Bc, h->H1, h->H1, Cg, h->hid1, 3, 3, 1, 1, h->hid1, ACT_GELU, nullptr, 0, nullptr), Cg, 9.0 * Cg));
-    RC_TRY(run_gemm(h, st, "stage1.mlp.conv3", b.c3, conv_params(b.c3, hb, x1, Bc, h->H1, h->H1, h->hid1, h->hid1, 1, 1, 1, 0, h->C1, ACT_NONE, x1, 0, nullptr), h->C1, h->hid1));
+    if (fuse1) {   // one LDS-resident kernel per block, ping-pong between x1 and x1b
+      const double fl = 2.0 * Bc * h->H1 * h->H1 * ((double)h->hid1 * h->C1 + (double)h->hid1 * 9 * Cg + (double)h->C1 * h->hid1);
+      RC_TRY(timed(h, st, "stage1.block", KID_STAGE1, fl,
+                   [&]() { return launch_stage1_block(x1, x1b, b.c1.w, b.c1.bias, b.c2.w, b.c3.w, Bc, st); }));
+      std::swap(x1, x1b);
+    } else {
+      RC_TRY(run_gemm(h, st, "stage1.mlp.conv1", b.c1, conv_params(b.c1, x1, ha, Bc, h->H1, h->H1, h->C1, h->C1, 1, 1, 1, 0, h->hid1, ACT_GELU, nullptr, 0, nullptr), h->hid1, h->C1));
+      RC_TRY(run_gemm(h, st, "stage1.mlp.conv2", b.c2, conv_params(b.c2, ha, hb, Bc, h->H1, h->H1, Cg, h->hid1, 3, 3, 1, 1, h->hid1, ACT_GELU, nullptr, 0, nullptr), Cg, 9.0 * Cg));
+      RC_TRY(run_gemm(h, st, "stage1.mlp.conv3", b.c3, conv_params(b.c3, hb, x1, Bc, h->H1, h->H1, h->hid1, h->hid1, 1, 1, 1, 0, h->C1, ACT_NONE, x1, 0, nullptr), h->C1, h->hid1));
+    }
     RC_TRY(tap(h, "stage1." + std::to_string(i), x1, (size_t)Bc * h->H1 * h->H1 * h->C1 * es, first, st));
   }
 
@@ -572,6 +584,12 @@ extern "C" int fsvit_conv_gemm(const void* x, const void* w, const float* bias, 
   return 0;
 }
 
+extern "C" int fsvit_stage1_block(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, void* stream) {
+  if (!x || !y || !w1 || !b1 || !w2 || !w3 || x == y) return fail(FSVIT_ERR_ARG, "bad argument");
+  RC_TRY(launch_stage1_block(x, y, w1, b1, w2, w3, B, (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int fsvit_attention(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, void* stream) {
   if (!qkv || !ctx) return fail(FSVIT_ERR_ARG, "null argument");
   int rc = launch_attention(qkv, ctx, B, S, heads, hdp, scale, dtype, (hipStream_t)stream);
@@ -601,10 +619,10 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 // ------------------------------------------------------------------------------------ profiling
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
   static const char* f32n[] = {"conv_gemm_v2_kernel<float,128,128,2,2,2>", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
-                               "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel"};
+                               "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel"};
   static const char* bf16n[] = {"conv_gemm_v2_kernel<__bf16,128,128,2,2,2>", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
-                                "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel"};
-  if (kernel_id < 0 || kernel_id > 7) return "?";
+                                "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel"};
+  if (kernel_id < 0 || kernel_id > 8) return "?";
   return dtype == FSVIT_F32 ? f32n[kernel_id] : bf16n[kernel_id];
 }
 

@@ -19,4 +19,8 @@ int launch_pool_affine(const void* x, const float* scale, const float* shift, fl
 int launch_proto_head(const float* feat_shot, const float* feat_query, int E, int way, int shot, int Q, int D,
                       float temp, int method, float* logits, float* acc, float* loss, hipStream_t s);
 
+// fused stage-1 block (bf16, Visformer-S geometry only); x and y must be different buffers
+bool stage1_fused_supported(int dtype, int C1, int hid, int group, int H1);
+int launch_stage1_block(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, hipStream_t s);
+
 }  // namespace fsvit

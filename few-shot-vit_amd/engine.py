@@ -179,6 +179,16 @@ class ops:
         return y
 
     @staticmethod
+    def stage1_block(x, w1, b1, w2, w3):
+        """x NHWC [B,20,20,128] bf16; packed w1 [256][128], w2 [8][32][320], w3 [128][256] bf16; b1 [256] fp32."""
+        _require_cuda(x, w1, w2, w3, b1)
+        lib = _lib.load()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.fsvit_stage1_block(_ptr(x), _ptr(y), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(w3), x.shape[0], _stream_ptr(x.device)))
+        return y
+
+    @staticmethod
     def attention(qkv, B, S, heads, hdp, scale):
         _require_cuda(qkv)
         lib = _lib.load()

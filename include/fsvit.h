@@ -124,6 +124,11 @@ int fsvit_conv_gemm(const void* x_dev, const void* w_dev, const float* bias_dev,
 /* qkv [B*S][3*heads*hdp] -> ctx [B*S][heads*hdp] (visformer.py:183-190) */
 int fsvit_attention(const void* qkv_dev, void* ctx_dev, int B, int S, int heads, int hdp, float scale,
                     int dtype, void* stream);
+/* One fused Visformer stage-1 block (visformer.py:259-263 with attn_disabled + spatial_conv Mlp :152-163), bf16,
+ * Visformer-S geometry only (20x20 tokens, 128 channels, 256 hidden, 8 groups): y = x + conv3(GELU(conv2_g(GELU(conv1(x)+b1)))).
+ * x, y NHWC [B,20,20,128] bf16 (distinct buffers); w1 [256][128], w2 [8][32][320], w3 [128][256] packed K-major bf16. */
+int fsvit_stage1_block(const void* x_dev, void* y_dev, const void* w1_dev, const float* b1_dev, const void* w2_dev,
+                       const void* w3_dev, int B, void* stream);
 int fsvit_im2col27(const float* x_nchw_dev, void* out_dev, int B, int H, int W, int dtype, void* stream);
 int fsvit_maxpool2_pos(const void* in_dev, const float* pos_dev, void* out_dev, int B, int OH, int OW, int C,
                        int dtype, void* stream);

@@ -167,3 +167,31 @@ def test_compute_logits_gpu_matches_reference_semantics():
         got = utils.compute_logits(feat.cuda(), proto.cuda(), metric, temp).cpu()
         ref = vo.compute_logits(feat, proto, metric, temp)
         assert (got - ref).abs().max().item() <= 1e-4 * max(1.0, float(ref.abs().max())), metric
+
+
+def test_stage1_fused_block_matches_unfused_math():
+    """Fused stage-1 block vs fp32 torch with the same bf16 roundings of x, weights and the two hidden maps."""
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(123)
+    B = 5
+    x = q(torch.randn(B, 128, 20, 20, generator=g), bf)
+    w1 = q(torch.randn(256, 128, 1, 1, generator=g) / math.sqrt(128), bf)
+    b1 = torch.randn(256, generator=g) * 0.2
+    w2 = q(torch.randn(256, 32, 3, 3, generator=g) / math.sqrt(288), bf)
+    w3 = q(torch.randn(128, 256, 1, 1, generator=g) / math.sqrt(256), bf)
+    h1 = q(F.gelu(F.conv2d(x, w1, b1)), bf)
+    h2 = q(F.gelu(F.conv2d(h1, w2, padding=1, groups=8)), bf)
+    ref = x + F.conv2d(h2, w3)
+    y = ops.stage1_block(x.permute(0, 2, 3, 1).contiguous().to('cuda', bf), pack_w(w1, 1, bf)[0].cuda(), b1.cuda(),
+                         pack_w(w2, 8, bf).cuda(), pack_w(w3, 1, bf)[0].cuda())
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs()
+    # hidden maps are rounded to bf16 at slightly different fp32 values on the two sides: allow a few bf16 ulps of the output
+    assert err.max().item() <= 3e-2 * max(1.0, float(ref.abs().max())), err.max().item()
+    assert err.mean().item() <= 2e-3
+    # halo / border structure: the error must not concentrate on the half-image seam (rows 9/10) or the image border
+    assert err[:, :, 8:12].mean().item() <= 3 * err.mean().item() + 1e-6
+    border = torch.cat([err[:, :, 0].flatten(), err[:, :, -1].flatten(), err[:, :, :, 0].flatten(), err[:, :, :, -1].flatten()])
+    assert border.mean().item() <= 3 * err.mean().item() + 1e-6
