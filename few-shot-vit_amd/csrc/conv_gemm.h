@@ -35,6 +35,17 @@ struct ConvGemmParams {
   int act;             // enum Act
   int res_first;       // 1: residual is added before the activation (stem), 0: after (blocks)
   int log2Cin;         // valid when KH*KW > 1
+  // v2 only -------------------------------------------------------------------------------------
+  // Tail operand: ONE extra 128-byte K slice whose activation rows come from x2[m][0..K2) (rows in
+  // natural (b, oy, ox) order, aligned with the output pixels) and whose weights are columns
+  // [Kw - BKE, Kw) of the packed rows.  Used to fold the stem's downsample/identity conv (K = 27 im2col
+  // taps) into conv3 (visformer.py:232-235: out = bn3(conv3(.)) + bn_d(conv_d(x))).
+  const void* x2;
+  int x2_cstride;
+  int K2;              // 0 = no tail operand
+  // pool2: rows are enumerated 2x2-window-major and the epilogue max-pools each window after the
+  // activation (MaxPool2d(2), visformer.py:237); y / pos rows are then the pooled pixels.
+  int pool2;
 };
 
 // dtype: 0 = f32 (exact fp32 MFMA), 1 = bf16.  Returns hipError_t as int.

@@ -75,12 +75,13 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
   if (slot >= cnt) return;
 
   const int ohw = p.OH * p.OW;
-  const int nk = p.Kw / BKE;
+  const int nk_main = p.Kw / BKE - (p.K2 > 0 ? 1 : 0);   // K slices of the main operand
+  const int nk = p.Kw / BKE;                             // + the optional tail slice
   const bool multi_tap = (p.KH * p.KW) > 1;
   const T* const zero = reinterpret_cast<const T*>(g_zero_page);
 
   // ---- load cursor state (one pipeline step ahead of the compute cursor)
-  int iy0[A_IT], ix0[A_IT], pixbase[A_IT];
+  int iy0[A_IT], ix0[A_IT], pixbase[A_IT], pixnat[A_IT];
   bool rowok[A_IT];
   const T* wrow[B_IT];
   bool nok[B_IT];
@@ -97,8 +98,17 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
       const int mm = rowok[i] ? m : 0;
       const int b = mm / ohw;
       const int rem = mm - b * ohw;
-      const int oy = rem / p.OW;
-      const int ox = rem - oy * p.OW;
+      int oy, ox;
+      if (p.pool2) {                       // rem = (py * PW + px) * 4 + dy * 2 + dx
+        const int win = rem >> 2, pw2 = p.OW >> 1;
+        const int py = win / pw2;
+        oy = 2 * py + ((rem >> 1) & 1);
+        ox = 2 * (win - py * pw2) + (rem & 1);
+      } else {
+        oy = rem / p.OW;
+        ox = rem - oy * p.OW;
+      }
+      pixnat[i] = b * ohw + oy * p.OW + ox;
       iy0[i] = oy * p.stride - p.pad;
       ix0[i] = ox * p.stride - p.pad;
       pixbase[i] = b * p.H * p.W;
@@ -119,15 +129,25 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
       ky = tap / p.KW;
       kx = tap - ky * p.KW;
     }
-    const bool kok = k < p.K;
+    const bool kok = k < p.K;            // (main operand only; the tail slice has its own bound)
     const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr(ldsA0) + buf * (BM * 128) + wave * (8 * 128));
     const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(ldsB0) + buf * (BN * 128) + wave * (8 * 128));
+    if (kt < nk_main) {
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const int iy = iy0[i] + ky, ix = ix0[i] + kx;
-      const bool ok = kok && rowok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const T* src = ok ? Xg + (size_t)(pixbase[i] + iy * p.W + ix) * p.x_cstride + cc : zero;
-      dma16(src, la + i * (32 * 128));
+      for (int i = 0; i < A_IT; ++i) {
+        const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+        const bool ok = kok && rowok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const T* src = ok ? Xg + (size_t)(pixbase[i] + iy * p.W + ix) * p.x_cstride + cc : zero;
+        dma16(src, la + i * (32 * 128));
+      }
+    } else {                               // tail operand: row m of x2, columns sc*EPC .. (no spatial gather)
+      const T* X2 = reinterpret_cast<const T*>(p.x2);
+      const bool cok = sc * EPC < p.K2;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const T* src = (cok && rowok[i]) ? X2 + (size_t)pixnat[i] * p.x2_cstride + sc * EPC : zero;
+        dma16(src, la + i * (32 * 128));
+      }
     }
 #pragma unroll
     for (int jj = 0; jj < B_IT; ++jj) {
@@ -199,7 +219,8 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
       for (int i = 0; i < HB; ++i) {
         const int m = mb + (i0 + i) * 16;
         mk_[i] = m < p.M;
-        rowoff[i] = (size_t)(mk_[i] ? m : p.M - 1) * p.y_cstride;
+        const int mc = mk_[i] ? m : p.M - 1;
+        rowoff[i] = (size_t)(p.pool2 ? (mc >> 2) : mc) * p.y_cstride;   // pool2: 4 consecutive rows = one 2x2 window
       }
       if (R) {
 #pragma unroll
@@ -222,7 +243,7 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
 #pragma unroll
         for (int i = 0; i < HB; ++i) {
           const int m = mk_[i] ? mb + (i0 + i) * 16 : p.M - 1;
-          const float* posrow = p.pos + (size_t)(m % ohw) * p.y_cstride;
+          const float* posrow = p.pos + (size_t)(p.pool2 ? (m >> 2) % (ohw >> 2) : m % ohw) * p.y_cstride;
 #pragma unroll
           for (int jn = 0; jn < TN; ++jn) rv[i][jn] += *reinterpret_cast<const f32x4*>(posrow + ncl[jn]);
         }
@@ -235,8 +256,15 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
           acc[i0 + i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = actf(v[e]);
+          if (p.pool2) {                   // the window's 4 pixels sit in lanes lrow = 4j .. 4j+3 of the same lq
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = fmaxf(v[e], __shfl_xor(v[e], 1, 64));
+              v[e] = fmaxf(v[e], __shfl_xor(v[e], 2, 64));
+            }
+          }
           v += rv[i][jn];
-          if (mk_[i] && nk_[jn]) store4<T>(Y + rowoff[i] + ncl[jn], v);
+          if (mk_[i] && nk_[jn] && (!p.pool2 || (lrow & 3) == 0)) store4<T>(Y + rowoff[i] + ncl[jn], v);
         }
       }
     };
@@ -298,6 +326,7 @@ static int launch_v2_t(const ConvGemmParams& p, hipStream_t stream) {
 
 int launch_conv_gemm_v2(const ConvGemmParams& p, int dtype, hipStream_t stream) {
   if (p.M <= 0) return 0;
+  if (p.pool2 && (p.res || (p.OH & 1) || (p.OW & 1) || p.stride != 1)) return (int)hipErrorInvalidValue;
   return dtype == 0 ? launch_v2_t<float>(p, stream) : launch_v2_t<bf16>(p, stream);
 }
 

@@ -79,7 +79,7 @@ struct fsvit_visformer {
   int H0 = 0, H1 = 0, H2 = 0, H3 = 0;
   int hid1 = 0, hid2 = 0, hid3 = 0;
   int hd2 = 0, hdp2 = 0, hd3 = 0, hdp3 = 0;
-  Layer conv1, down, conv2, conv3, pe2, pe3;
+  Layer conv1, down, conv2, conv3, conv3f, pe2, pe3;   // conv3f: conv3 + downsample folded in as a tail K slice
   float *pos1 = nullptr, *pos2 = nullptr, *pos3 = nullptr;
   std::vector<Block1> s1;
   std::vector<BlockA> s2, s3;
@@ -242,6 +242,22 @@ int build(fsvit_visformer* h, const SD& sd) {
     RC_TRY(pack_layer(h, &h->down, wd, h->C1, 3, 3, 3, 1, &bd.s, nullptr, bd.t, true, nullptr, 0, &cm, 32));
     RC_TRY(pack_layer(h, &h->conv2, w2, h->C1, h->C0, 3, 3, 1, &b2.s, nullptr, b2.t, true, nullptr, 0, nullptr, 0));
     RC_TRY(pack_layer(h, &h->conv3, w3, h->C1, h->C1, 3, 3, 1, &b3.s, nullptr, b3.t, true, nullptr, 0, nullptr, 0));
+    {  // conv3f rows = [ bn3-scaled conv3 (K = 9*C1, padded to the K slice) | one tail slice: bn_d-scaled downsample taps ]
+      const int bke = 128 / h->es, K = 9 * h->C1, Kmain = round_up(K, bke), Kw = Kmain + bke;
+      std::vector<float> pk((size_t)h->C1 * Kw, 0.0f), pb(h->C1);
+      for (int o = 0; o < h->C1; ++o) {
+        for (int c = 0; c < h->C1; ++c)
+          for (int t9 = 0; t9 < 9; ++t9)
+            pk[(size_t)o * Kw + t9 * h->C1 + c] = (float)((double)w3[((size_t)o * h->C1 + c) * 9 + t9] * b3.s[o]);
+        for (int c = 0; c < 3; ++c)
+          for (int t9 = 0; t9 < 9; ++t9)
+            pk[(size_t)o * Kw + Kmain + t9 * 3 + c] = (float)((double)wd[((size_t)o * 3 + c) * 9 + t9] * bd.s[o]);
+        pb[o] = (float)(b3.t[o] + bd.t[o]);
+      }
+      h->conv3f.N = h->C1; h->conv3f.K = K; h->conv3f.Kw = Kw; h->conv3f.groups = 1;
+      RC_TRY(upload(h, pk, true, &h->conv3f.w));
+      void* bdev; RC_TRY(upload(h, pb, false, &bdev)); h->conv3f.bias = (float*)bdev;
+    }
   }
   {
     const float* p1 = sd.get("pos_embed1", {1, h->C1, h->H1, h->H1});
@@ -375,6 +391,7 @@ ConvGemmParams conv_params(const Layer& L, const void* x, void* y, int B, int H,
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
   p.N = L.N; p.y_cstride = y_cstride; p.K = L.K; p.Kw = L.Kw; p.M = B * p.OH * p.OW;
   p.groups = L.groups; p.act = act; p.res_first = res_first; p.log2Cin = ilog2(Cin);
+  p.x2 = nullptr; p.x2_cstride = 0; p.K2 = 0; p.pool2 = 0;
   return p;
 }
 
@@ -426,10 +443,18 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
   h->prof_last = nullptr;
   RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() { return launch_im2col27(x, patches, Bc, img, img, h->H0, h->H0, dt, st); }));
   RC_TRY(run_gemm(h, st, "stem.conv1", h->conv1, conv_params(h->conv1, patches, c1, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C0, ACT_LRELU, nullptr, 0, nullptr), h->C0, 27));
-  RC_TRY(run_gemm(h, st, "stem.downsample", h->down, conv_params(h->down, patches, ident, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C1, ACT_NONE, nullptr, 0, nullptr), h->C1, 27));
   RC_TRY(run_gemm(h, st, "stem.conv2", h->conv2, conv_params(h->conv2, c1, c2, Bc, h->H0, h->H0, h->C0, h->C0, 3, 3, 1, 1, h->C1, ACT_LRELU, nullptr, 0, nullptr), h->C1, 9.0 * h->C0));
-  RC_TRY(run_gemm(h, st, "stem.conv3", h->conv3, conv_params(h->conv3, c2, c3, Bc, h->H0, h->H0, h->C1, h->C1, 3, 3, 1, 1, h->C1, ACT_LRELU, ident, 1, nullptr), h->C1, 9.0 * h->C1));
-  RC_TRY(timed(h, st, "stem.maxpool", KID_MAXPOOL, 0.0, [&]() { return launch_maxpool2_pos(c3, h->pos1, x1, Bc, h->H1, h->H1, h->C1, dt, st); }));
+  static const bool split_stem = [] { const char* e = getenv("FSVIT_NO_FUSE"); return e && e[0] == '1'; }();
+  if (!split_stem) {
+    // conv3 + bn3 + (downsample conv + bn_d as a tail K slice over the im2col rows) + LeakyReLU + MaxPool2d(2) + pos_embed1
+    ConvGemmParams p3 = conv_params(h->conv3f, c2, x1, Bc, h->H0, h->H0, h->C1, h->C1, 3, 3, 1, 1, h->C1, ACT_LRELU, nullptr, 0, h->pos1);
+    p3.x2 = patches; p3.x2_cstride = 32; p3.K2 = 32; p3.pool2 = 1;
+    RC_TRY(run_gemm(h, st, "stem.conv3+down+pool", h->conv3f, p3, h->C1, 9.0 * h->C1 + 27.0));
+  } else {
+    RC_TRY(run_gemm(h, st, "stem.downsample", h->down, conv_params(h->down, patches, ident, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C1, ACT_NONE, nullptr, 0, nullptr), h->C1, 27));
+    RC_TRY(run_gemm(h, st, "stem.conv3", h->conv3, conv_params(h->conv3, c2, c3, Bc, h->H0, h->H0, h->C1, h->C1, 3, 3, 1, 1, h->C1, ACT_LRELU, ident, 1, nullptr), h->C1, 9.0 * h->C1));
+    RC_TRY(timed(h, st, "stem.maxpool", KID_MAXPOOL, 0.0, [&]() { return launch_maxpool2_pos(c3, h->pos1, x1, Bc, h->H1, h->H1, h->C1, dt, st); }));
+  }
   RC_TRY(tap(h, "stem", x1, (size_t)Bc * h->H1 * h->H1 * h->C1 * es, first, st));
 
   // stage 1: x += conv3(GELU(conv2_g(GELU(conv1(BN(x))))))
