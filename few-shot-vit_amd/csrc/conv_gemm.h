@@ -52,5 +52,6 @@ struct ConvGemmParams {
 int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream);
 int launch_conv_gemm_v1(const ConvGemmParams& p, int dtype, hipStream_t stream);
 int launch_conv_gemm_v2(const ConvGemmParams& p, int dtype, hipStream_t stream);
+int conv_gemm_v2_config(const ConvGemmParams& p);   // which tile configuration launch_conv_gemm_v2 picks
 
 }  // namespace fsvit

@@ -15,6 +15,8 @@
 //   * the item list is XCD-aware: workgroup b runs on XCD b % 8 (observed placement, used for speed
 //     only), and each XCD owns whole m-tiles and visits all their n-tiles back to back, so an
 //     activation tile is fetched from HBM once and re-read by its other n-tiles from that XCD's L2.
+#include <stdlib.h>
+
 #include "conv_gemm.h"
 #include "fsvit_common.h"
 
@@ -319,10 +321,15 @@ static int launch_cfg(const ConvGemmParams& p, hipStream_t stream) {
 
 template <typename T>
 static int launch_v2_t(const ConvGemmParams& p, hipStream_t stream) {
-  if (p.N > 64) return launch_cfg<T, 128, 128, 2, 2, 2>(p, stream);
+  static const int force = [] { const char* e = getenv("FSVIT_GEMM_TILE"); return e ? atoi(e) : 0; }();   // experiments only
+  if (p.N > 64 && force != 64) return launch_cfg<T, 128, 128, 2, 2, 2>(p, stream);
   if (p.N > 32) return launch_cfg<T, 128, 64, 2, 2, 3>(p, stream);
   return launch_cfg<T, 128, 32, 4, 1, 3>(p, stream);
 }
+
+// 1: 128x64, 2: 128x32, 3: 128x128 (0 is reserved for a 256x128 / 8-wave / 3-stage-ring variant that was
+// measured and dropped in round 1: +6 % at K = N = 2048 but -10..-25 % on the conv / small-K layers) -- mirrors launch_v2_t
+int conv_gemm_v2_config(const ConvGemmParams& p) { return p.N > 64 ? 3 : (p.N > 32 ? 1 : 2); }
 
 int launch_conv_gemm_v2(const ConvGemmParams& p, int dtype, hipStream_t stream) {
   if (p.M <= 0) return 0;

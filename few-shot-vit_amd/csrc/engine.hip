@@ -405,9 +405,8 @@ int tap(fsvit_visformer* h, const std::string& name, const void* src, size_t byt
 }
 
 // kernel ids reported by the profiler (names in fsvit_kernel_name)
-enum { KID_GEMM128 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8 };
+enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9 };
 
-int gemm_kid(const Layer& L) { return L.N > 64 ? KID_GEMM128 : (L.N > 32 ? KID_GEMM64 : KID_GEMM32); }
 
 // Runs one launch; in profiling mode brackets it with HIP events on the same stream.
 template <typename F>
@@ -426,7 +425,8 @@ int timed(fsvit_visformer* h, hipStream_t st, const char* layer, int kernel, dou
 
 int run_gemm(fsvit_visformer* h, hipStream_t st, const char* layer, const Layer& L, const ConvGemmParams& p, double n_true, double k_true) {
   const double flops = 2.0 * (double)p.M * n_true * k_true * (double)p.groups;     // algorithmic: unpadded N and K
-  return timed(h, st, layer, gemm_kid(L), flops, [&]() { return launch_conv_gemm(p, h->dtype, st); });
+  static const int kid_of_cfg[4] = {KID_GEMM256, KID_GEMM64, KID_GEMM32, KID_GEMM128};
+  return timed(h, st, layer, kid_of_cfg[conv_gemm_v2_config(p)], flops, [&]() { return launch_conv_gemm(p, h->dtype, st); });
 }
 
 int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsigned char* ws, bool first, hipStream_t st) {
@@ -643,11 +643,11 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 
 // ------------------------------------------------------------------------------------ profiling
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
-  static const char* f32n[] = {"conv_gemm_v2_kernel<float,128,128,2,2,2>", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
-                               "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel"};
-  static const char* bf16n[] = {"conv_gemm_v2_kernel<__bf16,128,128,2,2,2>", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
-                                "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel"};
-  if (kernel_id < 0 || kernel_id > 8) return "?";
+  static const char* f32n[] = {"conv_gemm_v2_kernel<float,256,128,4,2,3>", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
+                               "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<float,128,128,2,2,2>"};
+  static const char* bf16n[] = {"conv_gemm_v2_kernel<__bf16,256,128,4,2,3>", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
+                                "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<__bf16,128,128,2,2,2>"};
+  if (kernel_id < 0 || kernel_id > 9) return "?";
   return dtype == FSVIT_F32 ? f32n[kernel_id] : bf16n[kernel_id];
 }
 
