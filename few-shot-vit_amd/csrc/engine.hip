@@ -550,6 +550,7 @@ extern "C" int fsvit_visformer_set_tap(fsvit_visformer* h, const char* name, voi
 
 extern "C" int fsvit_visformer_forward(fsvit_visformer* h, const float* x, int n_img, int img_h, int img_w,
                                        float* feat, void* ws, size_t ws_bytes, void* stream) {
+  if (h && n_img <= 0) return 0;
   if (!h || !x || !feat || !ws) return fail(FSVIT_ERR_ARG, "null argument");
   if (img_h != h->cfg.img_size || img_w != h->cfg.img_size)   // PatchEmbed assert / pos_embed mismatch (visformer.py:283-284,431)
     return fail(FSVIT_ERR_IMG_SIZE, "Input image size (%d*%d) does not match model (%d*%d).", img_h, img_w, h->cfg.img_size, h->cfg.img_size);

@@ -123,6 +123,8 @@ class VisformerEngine:
         B = x.shape[0]
         if out is None:
             out = torch.empty(B, self.out_dim, dtype=torch.float32, device=x.device)
+        if B == 0:
+            return out
         ws = self.workspace(B)
         with torch.cuda.device(x.device):
             _lib.check(self.lib.fsvit_visformer_forward(self.h, _ptr(x), B, x.shape[2], x.shape[3], _ptr(out), _ptr(ws),

@@ -151,3 +151,26 @@ def test_strict_state_dict_and_repacking(full_sd):
             m.encoder.norm.bn.weight.mul_(1.5)       # in-place edit bumps the version -> engine re-packs
         b = m(xs.cuda(), xq.cuda()).cpu()
     assert not torch.equal(a, b)
+
+
+def test_ragged_batches_and_chunking(full_sd):
+    """Image counts that are not multiples of the tile / chunk sizes, chunked vs unchunked, 10-way episodes."""
+    from fewshot_vit_amd import synthetic
+    from fewshot_vit_amd.engine import VisformerEngine
+    enc_sd = {k[len('encoder.'):]: v for k, v in full_sd.items() if k.startswith('encoder.')}
+    cfg = dict(img_size=80, init_channels=64, embed_dim=256, depth=(4, 2, 3), num_heads=6, mlp_ratio=4.0, group=8)
+    x = synthetic.synthetic_episodes(3, 1, 1, 7, 0).cuda()              # 7 images
+    big = VisformerEngine(cfg, enc_sd, numerics='bf16', chunk_images=1600)
+    small = VisformerEngine(cfg, enc_sd, numerics='bf16', chunk_images=3)   # 3 + 3 + 1
+    a, b = big.forward(x), small.forward(x)
+    one = torch.cat([big.forward(x[i:i + 1]) for i in range(7)])
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, one)
+    assert big.forward(x[:0]).shape == (0, 512)                          # empty input
+    m = _model(full_sd, 'bf16')
+    x10 = synthetic.synthetic_episodes(4, 2, 10, 5, 5).cuda()           # SUN-M train geometry: 10-way 5-shot 5-query
+    from fewshot_vit_amd.utils import few_shot as fs
+    xs, xq = fs.split_shot_query(x10, 10, 5, 5, 2)
+    with torch.no_grad():
+        logits = m(xs, xq)
+    assert logits.shape == (2, 50, 10) and torch.isfinite(logits).all()
