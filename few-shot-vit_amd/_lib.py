@@ -26,6 +26,11 @@ class VisformerCfg(C.Structure):
                 ('group', C.c_int), ('bn_eps', C.c_float)]
 
 
+class VitCfg(C.Structure):
+    _fields_ = [('img_size', C.c_int), ('patch_size', C.c_int), ('embed_dim', C.c_int), ('depth', C.c_int),
+                ('num_heads', C.c_int), ('mlp_ratio', C.c_float), ('ln_eps', C.c_float)]
+
+
 class ProfRec(C.Structure):
     _fields_ = [('layer', C.c_char * 48), ('kernel_id', C.c_int), ('launches', C.c_int), ('flops', C.c_double),
                 ('ms', C.c_double)]
@@ -42,9 +47,14 @@ SIGNATURES = {
     'fsvit_visformer_dtype': (_i, [_vp]),
     'fsvit_visformer_workspace_bytes': (_sz, [_vp, _i]),
     'fsvit_visformer_forward': (_i, [_vp, _fp, _i, _i, _i, _fp, _vp, _sz, _vp]),
-    'fsvit_visformer_set_tap': (_i, [_vp, C.c_char_p, _vp, _sz]),
-    'fsvit_visformer_profile_begin': (_i, [_vp]),
-    'fsvit_visformer_profile_end': (_i, [_vp, C.POINTER(ProfRec), _i, C.POINTER(_i)]),
+    'fsvit_vit_create': (_i, [C.POINTER(VitCfg), C.POINTER(Tensor), _i, _i, C.POINTER(_vp)]),
+    'fsvit_vit_destroy': (None, [_vp]),
+    'fsvit_vit_out_dim': (_i, [_vp]),
+    'fsvit_vit_workspace_bytes': (_sz, [_vp, _i]),
+    'fsvit_vit_forward': (_i, [_vp, _fp, _i, _i, _i, _fp, _vp, _sz, _vp]),
+    'fsvit_encoder_set_tap': (_i, [_vp, C.c_char_p, _vp, _sz]),
+    'fsvit_encoder_profile_begin': (_i, [_vp]),
+    'fsvit_encoder_profile_end': (_i, [_vp, C.POINTER(ProfRec), _i, C.POINTER(_i)]),
     'fsvit_kernel_name': (C.c_char_p, [_i, _i]),
     'fsvit_proto_head': (_i, [_fp, _fp, _i, _i, _i, _i, _i, _f, _i, _fp, _fp, _fp, _vp]),
     'fsvit_meta_baseline_forward': (_i, [_vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _i, _fp, _fp, _fp, _fp,

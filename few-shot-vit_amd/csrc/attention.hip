@@ -268,6 +268,7 @@ static int dispatch_ndt(int ndt, const void* qkv, void* ctx, int B, int S, int h
     case 2: return launch_v2<T, NKT, 2, NW>(qkv, ctx, B, S, heads, scale, s);
     case 3: if constexpr (sizeof(T) == 4) return launch_v2<T, NKT, 3, NW>(qkv, ctx, B, S, heads, scale, s); else return -1;
     case 4: return launch_v2<T, NKT, 4, NW>(qkv, ctx, B, S, heads, scale, s);
+    case 5: if constexpr (sizeof(T) == 4) return launch_v2<T, NKT, 5, NW>(qkv, ctx, B, S, heads, scale, s); else return -1;
     case 6: return launch_v2<T, NKT, 6, NW>(qkv, ctx, B, S, heads, scale, s);
     case 8: return launch_v2<T, NKT, 8, NW>(qkv, ctx, B, S, heads, scale, s);
     default: return -1;
@@ -279,9 +280,11 @@ static int launch_attention_v2(const void* qkv, void* ctx, int B, int S, int hea
   if (dtype == 0) {
     if (S <= 32) return dispatch_ndt<float, 2, 2>(ndt, qkv, ctx, B, S, heads, scale, s);
     if (S <= 112) return dispatch_ndt<float, 7, 4>(ndt, qkv, ctx, B, S, heads, scale, s);
+    if (S <= 208) return dispatch_ndt<float, 13, 4>(ndt, qkv, ctx, B, S, heads, scale, s);   // ViT: 196 patches + cls
   } else {
     if (S <= 32) return dispatch_ndt<bf16, 2, 2>(ndt, qkv, ctx, B, S, heads, scale, s);
     if (S <= 128) return dispatch_ndt<bf16, 8, 4>(ndt, qkv, ctx, B, S, heads, scale, s);
+    if (S <= 224) return dispatch_ndt<bf16, 14, 4>(ndt, qkv, ctx, B, S, heads, scale, s);
   }
   return -1;
 }
@@ -289,11 +292,12 @@ static int launch_attention_v2(const void* qkv, void* ctx, int B, int S, int hea
 int launch_attention(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, hipStream_t s) {
   if (B <= 0) return 0;
   const int es = dtype == 0 ? 4 : 2;
-  if (S < 1 || S > 128 || hdp % (64 / es) != 0) return (int)hipErrorInvalidValue;
+  if (S < 1 || hdp % (64 / es) != 0) return (int)hipErrorInvalidValue;
   {
     const int rc = launch_attention_v2(qkv, ctx, B, S, heads, hdp, scale, dtype, s);
     if (rc != -1) return rc;
   }
+  if (S > 128) return (int)hipErrorInvalidValue;      // the generic v1 kernel holds at most 128 tokens
   const size_t lds = attention_lds_bytes(S, hdp, dtype);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   dim3 grid(B * heads), block(256);

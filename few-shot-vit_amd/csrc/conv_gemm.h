@@ -46,6 +46,9 @@ struct ConvGemmParams {
   // pool2: rows are enumerated 2x2-window-major and the epilogue max-pools each window after the
   // activation (MaxPool2d(2), visformer.py:237); y / pos rows are then the pooled pixels.
   int pool2;
+  // Row remap of the OUTPUT (and residual): row m of image b = m / (OH*OW) goes to row b * y_rpi + y_row0 + m % (OH*OW).
+  // y_rpi == 0: dense rows.  Used to write the ViT patch tokens behind each image's cls token (deit.py:200-201).
+  int y_rpi, y_row0;
 };
 
 // dtype: 0 = f32 (exact fp32 MFMA), 1 = bf16.  Returns hipError_t as int.

@@ -222,7 +222,9 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
         const int m = mb + (i0 + i) * 16;
         mk_[i] = m < p.M;
         const int mc = mk_[i] ? m : p.M - 1;
-        rowoff[i] = (size_t)(p.pool2 ? (mc >> 2) : mc) * p.y_cstride;   // pool2: 4 consecutive rows = one 2x2 window
+        int orow = p.pool2 ? (mc >> 2) : mc;                            // pool2: 4 consecutive rows = one 2x2 window
+        if (p.y_rpi) orow = (orow / ohw) * p.y_rpi + p.y_row0 + orow % ohw;
+        rowoff[i] = (size_t)orow * p.y_cstride;
       }
       if (R) {
 #pragma unroll
@@ -333,7 +335,7 @@ int conv_gemm_v2_config(const ConvGemmParams& p) { return p.N > 64 ? 3 : (p.N > 
 
 int launch_conv_gemm_v2(const ConvGemmParams& p, int dtype, hipStream_t stream) {
   if (p.M <= 0) return 0;
-  if (p.pool2 && (p.res || (p.OH & 1) || (p.OW & 1) || p.stride != 1)) return (int)hipErrorInvalidValue;
+  if (p.pool2 && (p.res || p.y_rpi || (p.OH & 1) || (p.OW & 1) || p.stride != 1)) return (int)hipErrorInvalidValue;
   return dtype == 0 ? launch_v2_t<float>(p, stream) : launch_v2_t<bf16>(p, stream);
 }
 

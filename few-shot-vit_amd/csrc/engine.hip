@@ -72,9 +72,21 @@ struct Tap { void* dst; size_t bytes; };
 // One timed launch: events bracket the kernel on the stream it was launched on.
 struct ProfEntry { std::string layer; int kernel; double flops; hipEvent_t e0, e1; };
 
-struct fsvit_visformer {
-  fsvit_visformer_cfg cfg;
+// State shared by every encoder handle (the C-ABI functions that take "any encoder" rely on it being
+// the first base sub-object).
+enum { KIND_VISFORMER = 1, KIND_VIT = 2 };
+struct EngineBase {
+  int kind = 0;
   int dtype = 0, es = 4;
+  std::map<std::string, Tap> taps;
+  std::vector<void*> allocs;
+  bool profiling = false;
+  std::vector<ProfEntry> prof;
+  hipEvent_t prof_last = nullptr;      // end event of the previous launch = start of the next
+};
+
+struct fsvit_visformer : EngineBase {
+  fsvit_visformer_cfg cfg;
   int C0 = 0, C1 = 0, C2 = 0, C3 = 0;
   int H0 = 0, H1 = 0, H2 = 0, H3 = 0;
   int hid1 = 0, hid2 = 0, hid3 = 0;
@@ -84,11 +96,6 @@ struct fsvit_visformer {
   std::vector<Block1> s1;
   std::vector<BlockA> s2, s3;
   float *fscale = nullptr, *fshift = nullptr;
-  std::map<std::string, Tap> taps;
-  std::vector<void*> allocs;
-  bool profiling = false;
-  std::vector<ProfEntry> prof;
-  hipEvent_t prof_last = nullptr;      // end event of the previous launch = start of the next
 };
 
 namespace {
@@ -131,7 +138,7 @@ Affine bn_affine(const SD& sd, const std::string& p, int C, double eps) {
   return a;
 }
 
-int upload(fsvit_visformer* h, const std::vector<float>& src, bool as_storage, void** out) {
+int upload(EngineBase* h, const std::vector<float>& src, bool as_storage, void** out) {
   void* d = nullptr;
   if (as_storage && h->dtype == FSVIT_BF16) {
     std::vector<uint16_t> tmp(src.size());
@@ -151,7 +158,7 @@ int upload(fsvit_visformer* h, const std::vector<float>& src, bool as_storage, v
 // Pack a conv weight W[O][Ig][KH][KW] (O = groups*N) into [groups][N][Kw], k = (ky*KW+kx)*Ig + c,
 // with optional per-output-channel scale (BN after the conv) and per-input-channel scale (BN before
 // a 1x1 conv).  `rowmap`/`colmap` (optional) scatter rows / K columns (head-dim padding).
-int pack_layer(fsvit_visformer* h, Layer* L, const float* W, int O, int Ig, int KH, int KW, int groups,
+int pack_layer(EngineBase* h, Layer* L, const float* W, int O, int Ig, int KH, int KW, int groups,
                const std::vector<double>* out_scale, const std::vector<double>* in_scale,
                const std::vector<double>& bias, bool has_bias,
                const std::vector<int>* rowmap, int Npad, const std::vector<int>* colmap, int Kpad) {
@@ -193,7 +200,7 @@ std::vector<double> prenorm_bias(const float* W, int O, int C, const std::vector
 }
 
 // pos_embed [1,C,H,W] -> [H*W][C] fp32 (+ optional per-channel constant)
-int pack_pos(fsvit_visformer* h, const float* pos, int C, int HW, float** out) {
+int pack_pos(EngineBase* h, const float* pos, int C, int HW, float** out) {
   std::vector<float> p((size_t)HW * C);
   for (int c = 0; c < C; ++c)
     for (int i = 0; i < HW; ++i) p[(size_t)i * C + c] = pos[(size_t)c * HW + i];
@@ -391,11 +398,11 @@ ConvGemmParams conv_params(const Layer& L, const void* x, void* y, int B, int H,
   p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
   p.N = L.N; p.y_cstride = y_cstride; p.K = L.K; p.Kw = L.Kw; p.M = B * p.OH * p.OW;
   p.groups = L.groups; p.act = act; p.res_first = res_first; p.log2Cin = ilog2(Cin);
-  p.x2 = nullptr; p.x2_cstride = 0; p.K2 = 0; p.pool2 = 0;
+  p.x2 = nullptr; p.x2_cstride = 0; p.K2 = 0; p.pool2 = 0; p.y_rpi = 0; p.y_row0 = 0;
   return p;
 }
 
-int tap(fsvit_visformer* h, const std::string& name, const void* src, size_t bytes, bool first, hipStream_t st) {
+int tap(EngineBase* h, const std::string& name, const void* src, size_t bytes, bool first, hipStream_t st) {
   if (!first || h->taps.empty()) return 0;
   auto it = h->taps.find(name);
   if (it == h->taps.end() || it->second.dst == nullptr) return 0;
@@ -410,7 +417,7 @@ enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXP
 
 // Runs one launch; in profiling mode brackets it with HIP events on the same stream.
 template <typename F>
-int timed(fsvit_visformer* h, hipStream_t st, const char* layer, int kernel, double flops, F&& launch) {
+int timed(EngineBase* h, hipStream_t st, const char* layer, int kernel, double flops, F&& launch) {
   if (!h->profiling) return launch();
   hipEvent_t e0 = h->prof_last, e1;
   if (!e0) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventRecord(e0, st)); }
@@ -423,7 +430,7 @@ int timed(fsvit_visformer* h, hipStream_t st, const char* layer, int kernel, dou
   return 0;
 }
 
-int run_gemm(fsvit_visformer* h, hipStream_t st, const char* layer, const Layer& L, const ConvGemmParams& p, double n_true, double k_true) {
+int run_gemm(EngineBase* h, hipStream_t st, const char* layer, const Layer& L, const ConvGemmParams& p, double n_true, double k_true) {
   const double flops = 2.0 * (double)p.M * n_true * k_true * (double)p.groups;     // algorithmic: unpadded N and K
   static const int kid_of_cfg[4] = {KID_GEMM256, KID_GEMM64, KID_GEMM32, KID_GEMM128};
   return timed(h, st, layer, kid_of_cfg[conv_gemm_v2_config(p)], flops, [&]() { return launch_conv_gemm(p, h->dtype, st); });
@@ -517,6 +524,7 @@ extern "C" int fsvit_visformer_create(const fsvit_visformer_cfg* cfg, const fsvi
   if (cfg->num_heads < 1 || cfg->embed_dim < 2 || cfg->init_channels < 1 || cfg->depth[0] < 0 || cfg->depth[1] < 0 || cfg->depth[2] < 0)
     return fail(FSVIT_ERR_ARG, "bad Visformer configuration");
   fsvit_visformer* h = new fsvit_visformer();
+  h->kind = KIND_VISFORMER;
   h->cfg = *cfg;
   h->dtype = dtype;
   h->es = dtype == FSVIT_F32 ? 4 : 2;
@@ -541,7 +549,8 @@ extern "C" size_t fsvit_visformer_workspace_bytes(const fsvit_visformer* h, int 
   return make_plan(h, (size_t)chunk_images).total;
 }
 
-extern "C" int fsvit_visformer_set_tap(fsvit_visformer* h, const char* name, void* dst_dev, size_t bytes) {
+extern "C" int fsvit_encoder_set_tap(void* hv, const char* name, void* dst_dev, size_t bytes) {
+  EngineBase* h = static_cast<EngineBase*>(hv);
   if (!h || !name) return fail(FSVIT_ERR_ARG, "null argument");
   if (!dst_dev) h->taps.erase(name);
   else h->taps[name] = Tap{dst_dev, bytes};
@@ -582,18 +591,21 @@ extern "C" int fsvit_proto_head(const float* fs, const float* fq, int E, int way
   return 0;
 }
 
-extern "C" int fsvit_meta_baseline_forward(fsvit_visformer* h, const float* x_shot, const float* x_query, int E, int way,
+static int encoder_forward_any(void* hv, const float* x, int n, int img_h, int img_w, float* feat, void* ws, size_t ws_bytes, void* stream);
+static int encoder_out_dim_any(void* hv);
+
+extern "C" int fsvit_meta_baseline_forward(void* hv, const float* x_shot, const float* x_query, int E, int way,
                                            int shot, int Q, int img_h, int img_w, float temp, int method, float* logits,
                                            float* acc, float* loss, float* feat, void* ws, size_t ws_bytes, void* stream) {
-  if (!h || !feat) return fail(FSVIT_ERR_ARG, "null argument");
-  const int ns = E * way * shot, nq = E * Q;
+  if (!hv || !feat) return fail(FSVIT_ERR_ARG, "null argument");
+  const int ns = E * way * shot, nq = E * Q, D = encoder_out_dim_any(hv);
   // the reference encodes cat([shots, queries]) in one call (meta_baseline.py:29-32); eval mode is
   // per-image independent, so two passes into one feature buffer are equivalent
-  int rc = fsvit_visformer_forward(h, x_shot, ns, img_h, img_w, feat, ws, ws_bytes, stream);
+  int rc = encoder_forward_any(hv, x_shot, ns, img_h, img_w, feat, ws, ws_bytes, stream);
   if (rc != 0) return rc;
-  rc = fsvit_visformer_forward(h, x_query, nq, img_h, img_w, feat + (size_t)ns * h->C3, ws, ws_bytes, stream);
+  rc = encoder_forward_any(hv, x_query, nq, img_h, img_w, feat + (size_t)ns * D, ws, ws_bytes, stream);
   if (rc != 0) return rc;
-  return fsvit_proto_head(feat, feat + (size_t)ns * h->C3, E, way, shot, Q, h->C3, temp, method, logits, acc, loss, stream);
+  return fsvit_proto_head(feat, feat + (size_t)ns * D, E, way, shot, Q, D, temp, method, logits, acc, loss, stream);
 }
 
 extern "C" int fsvit_conv_gemm(const void* x, const void* w, const float* bias, const void* res, const float* pos, void* y,
@@ -645,14 +657,17 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 // ------------------------------------------------------------------------------------ profiling
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
   static const char* f32n[] = {"conv_gemm_v2_kernel<float,256,128,4,2,3>", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
-                               "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<float,128,128,2,2,2>"};
+                               "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<float,128,128,2,2,2>",
+                               "patchify_kernel<float>", "layernorm_kernel<float>"};
   static const char* bf16n[] = {"conv_gemm_v2_kernel<__bf16,256,128,4,2,3>", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
-                                "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<__bf16,128,128,2,2,2>"};
-  if (kernel_id < 0 || kernel_id > 9) return "?";
+                                "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<__bf16,128,128,2,2,2>",
+                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>"};
+  if (kernel_id < 0 || kernel_id > 11) return "?";
   return dtype == FSVIT_F32 ? f32n[kernel_id] : bf16n[kernel_id];
 }
 
-extern "C" int fsvit_visformer_profile_begin(fsvit_visformer* h) {
+extern "C" int fsvit_encoder_profile_begin(void* hv) {
+  EngineBase* h = static_cast<EngineBase*>(hv);
   if (!h) return fail(FSVIT_ERR_ARG, "null argument");
   h->prof.clear();
   h->prof_last = nullptr;
@@ -660,7 +675,8 @@ extern "C" int fsvit_visformer_profile_begin(fsvit_visformer* h) {
   return 0;
 }
 
-extern "C" int fsvit_visformer_profile_end(fsvit_visformer* h, fsvit_prof_rec* out, int max_recs, int* n_out) {
+extern "C" int fsvit_encoder_profile_end(void* hv, fsvit_prof_rec* out, int max_recs, int* n_out) {
+  EngineBase* h = static_cast<EngineBase*>(hv);
   if (!h || !out || !n_out) return fail(FSVIT_ERR_ARG, "null argument");
   h->profiling = false;
   std::vector<fsvit_prof_rec> agg;
@@ -695,4 +711,211 @@ extern "C" int fsvit_visformer_profile_end(fsvit_visformer* h, fsvit_prof_rec* o
   if ((int)agg.size() > max_recs) return fail(FSVIT_ERR_ARG, "profile has %zu records, buffer holds %d", agg.size(), max_recs);
   for (size_t i = 0; i < agg.size(); ++i) out[i] = agg[i];
   return 0;
+}
+
+// ==================================================================================== ViT / DeiT encoder
+// test_phase/models/deit.py:139-218.  LayerNorm gains/shifts are folded into the following Linear
+// (W' = W diag(gamma), b' = b + W beta); the normalisation itself is a one-wave-per-token kernel.
+struct VitBlock { Layer qkv, proj, fc1, fc2; };
+
+struct fsvit_vit : EngineBase {
+  fsvit_vit_cfg cfg;
+  int D = 0, S = 0, np = 0, npw = 0, Kp = 0, hd = 0, hdp = 0, hid = 0;
+  Layer pe;
+  float *pos_patch = nullptr;      // pos_embed[1:]  [np][D]
+  float *cls_pos0 = nullptr;       // cls_token + pos_embed[0]  [D]
+  float *ng = nullptr, *nb = nullptr;
+  std::vector<VitBlock> blocks;
+};
+
+namespace {
+
+std::vector<double> add_vec(const std::vector<double>& a, const float* b, int n) {
+  std::vector<double> r(n);
+  for (int i = 0; i < n; ++i) r[i] = a[i] + (double)b[i];
+  return r;
+}
+
+int build_vit(fsvit_vit* h, const SD& sd) {
+  const fsvit_vit_cfg& cf = h->cfg;
+  const int epc = 16 / h->es, kch = 64 / h->es;
+  const int D = cf.embed_dim, p = cf.patch_size, heads = cf.num_heads;
+  if (cf.img_size % p || D % heads || D % 8) return fail(FSVIT_ERR_ARG, "unsupported ViT geometry");
+  h->D = D; h->npw = cf.img_size / p; h->np = h->npw * h->npw; h->S = h->np + 1;
+  h->hd = D / heads; h->hdp = round_up(h->hd, kch); h->hid = (int)(D * cf.mlp_ratio);
+  if (h->hid % 8) return fail(FSVIT_ERR_ARG, "hidden width must be a multiple of 8");
+  if (h->S > (h->es == 4 ? 208 : 224)) return fail(FSVIT_ERR_ARG, "attention supports at most %d tokens", h->es == 4 ? 208 : 224);
+  const int K = 3 * p * p;
+  h->Kp = round_up(K, 8);
+  (void)epc;
+  {
+    const float* w = sd.get("patch_embed.proj.weight", {D, 3, p, p});
+    const float* b = sd.get("patch_embed.proj.bias", {D});
+    const float* cls = sd.get("cls_token", {1, 1, D});
+    const float* pos = sd.get("pos_embed", {1, h->S, D});
+    const float* g = sd.get("norm.weight", {D});
+    const float* bt = sd.get("norm.bias", {D});
+    if (!w || !b || !cls || !pos || !g || !bt) return FSVIT_ERR_KEY;
+    std::vector<int> cm(K);
+    for (int k = 0; k < K; ++k) cm[k] = k;                       // conv weight [D][3][p][p] is already (c, py, px)-major
+    std::vector<double> bias(D);
+    for (int i = 0; i < D; ++i) bias[i] = b[i];
+    RC_TRY(pack_layer(h, &h->pe, w, D, K, 1, 1, 1, nullptr, nullptr, bias, true, nullptr, 0, &cm, h->Kp));
+    std::vector<float> pp((size_t)h->np * D), c0(D), gg(g, g + D), bb(bt, bt + D);
+    for (int i = 0; i < h->np; ++i)
+      for (int d = 0; d < D; ++d) pp[(size_t)i * D + d] = pos[(size_t)(i + 1) * D + d];
+    for (int d = 0; d < D; ++d) c0[d] = cls[d] + pos[d];
+    void* dv;
+    RC_TRY(upload(h, pp, false, &dv)); h->pos_patch = (float*)dv;
+    RC_TRY(upload(h, c0, false, &dv)); h->cls_pos0 = (float*)dv;
+    RC_TRY(upload(h, gg, false, &dv)); h->ng = (float*)dv;
+    RC_TRY(upload(h, bb, false, &dv)); h->nb = (float*)dv;
+  }
+  const int hd = h->hd, hdp = h->hdp;
+  std::vector<int> rowmap(3 * heads * hd), colmap(heads * hd);
+  for (int x = 0; x < 3; ++x)
+    for (int y = 0; y < heads; ++y)
+      for (int z = 0; z < hd; ++z) rowmap[(x * heads + y) * hd + z] = (x * heads + y) * hdp + z;
+  for (int y = 0; y < heads; ++y)
+    for (int z = 0; z < hd; ++z) colmap[y * hd + z] = y * hdp + z;
+  std::vector<double> nob;
+  h->blocks.resize(cf.depth);
+  for (int i = 0; i < cf.depth; ++i) {
+    const std::string bp = "blocks." + std::to_string(i) + ".";
+    const float* g1 = sd.get(bp + "norm1.weight", {D});
+    const float* b1 = sd.get(bp + "norm1.bias", {D});
+    const float* g2 = sd.get(bp + "norm2.weight", {D});
+    const float* b2 = sd.get(bp + "norm2.bias", {D});
+    const float* wq = sd.get(bp + "attn.qkv.weight", {3 * D, D});
+    const float* bq = sd.get(bp + "attn.qkv.bias", {3 * D});
+    const float* wp = sd.get(bp + "attn.proj.weight", {D, D});
+    const float* bpj = sd.get(bp + "attn.proj.bias", {D});
+    const float* w1 = sd.get(bp + "mlp.fc1.weight", {h->hid, D});
+    const float* bf1 = sd.get(bp + "mlp.fc1.bias", {h->hid});
+    const float* w2 = sd.get(bp + "mlp.fc2.weight", {D, h->hid});
+    const float* bf2 = sd.get(bp + "mlp.fc2.bias", {D});
+    if (!g1 || !b1 || !g2 || !b2 || !wq || !bq || !wp || !bpj || !w1 || !bf1 || !w2 || !bf2) return FSVIT_ERR_KEY;
+    std::vector<double> s1(g1, g1 + D), t1(b1, b1 + D), s2(g2, g2 + D), t2(b2, b2 + D);
+    std::vector<double> vbp(bpj, bpj + D), vb2(bf2, bf2 + D);
+    RC_TRY(pack_layer(h, &h->blocks[i].qkv, wq, 3 * D, D, 1, 1, 1, nullptr, &s1, add_vec(prenorm_bias(wq, 3 * D, D, t1), bq, 3 * D), true, &rowmap, 3 * heads * hdp, nullptr, 0));
+    RC_TRY(pack_layer(h, &h->blocks[i].proj, wp, D, heads * hd, 1, 1, 1, nullptr, nullptr, vbp, true, nullptr, 0, &colmap, heads * hdp));
+    RC_TRY(pack_layer(h, &h->blocks[i].fc1, w1, h->hid, D, 1, 1, 1, nullptr, &s2, add_vec(prenorm_bias(w1, h->hid, D, t2), bf1, h->hid), true, nullptr, 0, nullptr, 0));
+    RC_TRY(pack_layer(h, &h->blocks[i].fc2, w2, D, h->hid, 1, 1, 1, nullptr, nullptr, vb2, true, nullptr, 0, nullptr, 0));
+  }
+  return 0;
+}
+
+struct VitPlan { size_t patches, tokens, xn, qkv, ctx, hid, total; };
+
+VitPlan make_vit_plan(const fsvit_vit* h, size_t Bc) {
+  VitPlan p;
+  const size_t es = h->es;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align256(bytes); return o; };
+  p.tokens = take(Bc * h->S * h->D * es);
+  p.xn = take(Bc * h->S * h->D * es);
+  p.qkv = take(Bc * h->S * 3 * h->cfg.num_heads * h->hdp * es);
+  p.ctx = take(Bc * h->S * h->cfg.num_heads * h->hdp * es);
+  const size_t pb = Bc * h->np * h->Kp * es, hb = Bc * h->S * h->hid * es;      // patches are dead once the tokens exist
+  p.patches = p.hid = take(pb > hb ? pb : hb);
+  p.total = off;
+  return p;
+}
+
+enum { KID_PATCHIFY = 10, KID_LN = 11 };
+
+int vit_forward_chunk(fsvit_vit* h, const float* x, int Bc, float* feat, unsigned char* ws, bool first, hipStream_t st) {
+  const VitPlan pl = make_vit_plan(h, Bc);
+  const int dt = h->dtype, D = h->D, S = h->S, heads = h->cfg.num_heads, hdp = h->hdp;
+  const size_t es = h->es;
+  void *patches = ws + pl.patches, *tokens = ws + pl.tokens, *xn = ws + pl.xn, *qkv = ws + pl.qkv, *ctx = ws + pl.ctx, *hid = ws + pl.hid;
+  const int M = Bc * S;
+  h->prof_last = nullptr;
+  RC_TRY(timed(h, st, "patch_embed.patchify", KID_PATCHIFY, 0.0, [&]() { return launch_patchify(x, patches, Bc, h->cfg.img_size, h->cfg.patch_size, h->Kp, dt, st); }));
+  {
+    ConvGemmParams p = conv_params(h->pe, patches, tokens, Bc, h->npw, h->npw, h->Kp, h->Kp, 1, 1, 1, 0, D, ACT_NONE, nullptr, 0, h->pos_patch);
+    p.y_rpi = S; p.y_row0 = 1;                                   // patch token i of image b -> row b*S + 1 + i
+    RC_TRY(run_gemm(h, st, "patch_embed.proj", h->pe, p, D, 3.0 * h->cfg.patch_size * h->cfg.patch_size));
+  }
+  RC_TRY(timed(h, st, "cls_token", KID_PATCHIFY, 0.0, [&]() { return launch_cls_pos(h->cls_pos0, tokens, Bc, S, D, dt, st); }));
+  RC_TRY(tap(h, "embed", tokens, (size_t)M * D * es, first, st));
+  const float scale = 1.0f / std::sqrt((float)h->hd);
+  for (size_t i = 0; i < h->blocks.size(); ++i) {
+    const VitBlock& b = h->blocks[i];
+    RC_TRY(timed(h, st, "blocks.norm1", KID_LN, 0.0, [&]() { return launch_layernorm(tokens, xn, M, D, h->cfg.ln_eps, dt, st); }));
+    RC_TRY(run_gemm(h, st, "blocks.attn.qkv", b.qkv, conv_params(b.qkv, xn, qkv, Bc, S, 1, D, D, 1, 1, 1, 0, 3 * heads * hdp, ACT_NONE, nullptr, 0, nullptr), 3.0 * D, D));
+    RC_TRY(timed(h, st, "blocks.attn.core", KID_ATTN, 4.0 * Bc * heads * (double)S * S * h->hd,
+                 [&]() { return launch_attention(qkv, ctx, Bc, S, heads, hdp, scale, dt, st); }));
+    RC_TRY(run_gemm(h, st, "blocks.attn.proj", b.proj, conv_params(b.proj, ctx, tokens, Bc, S, 1, heads * hdp, heads * hdp, 1, 1, 1, 0, D, ACT_NONE, tokens, 0, nullptr), D, D));
+    RC_TRY(timed(h, st, "blocks.norm2", KID_LN, 0.0, [&]() { return launch_layernorm(tokens, xn, M, D, h->cfg.ln_eps, dt, st); }));
+    RC_TRY(run_gemm(h, st, "blocks.mlp.fc1", b.fc1, conv_params(b.fc1, xn, hid, Bc, S, 1, D, D, 1, 1, 1, 0, h->hid, ACT_GELU, nullptr, 0, nullptr), h->hid, D));
+    RC_TRY(run_gemm(h, st, "blocks.mlp.fc2", b.fc2, conv_params(b.fc2, hid, tokens, Bc, S, 1, h->hid, h->hid, 1, 1, 1, 0, D, ACT_NONE, tokens, 0, nullptr), D, h->hid));
+    RC_TRY(tap(h, "blocks." + std::to_string(i), tokens, (size_t)M * D * es, first, st));
+  }
+  RC_TRY(timed(h, st, "norm.cls", KID_LN, 0.0, [&]() { return launch_final_ln_cls(tokens, h->ng, h->nb, feat, Bc, S, D, h->cfg.ln_eps, dt, st); }));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int fsvit_vit_create(const fsvit_vit_cfg* cfg, const fsvit_tensor* state_dict, int n_tensors, int dtype, fsvit_vit** out) {
+  if (!cfg || !state_dict || !out || n_tensors <= 0) return fail(FSVIT_ERR_ARG, "null argument");
+  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  if (cfg->num_heads < 1 || cfg->embed_dim < 8 || cfg->depth < 0 || cfg->patch_size < 1) return fail(FSVIT_ERR_ARG, "bad ViT configuration");
+  fsvit_vit* h = new fsvit_vit();
+  h->kind = KIND_VIT;
+  h->cfg = *cfg;
+  h->dtype = dtype;
+  h->es = dtype == FSVIT_F32 ? 4 : 2;
+  SD sd{state_dict, n_tensors};
+  int rc = build_vit(h, sd);
+  if (rc != 0) { fsvit_vit_destroy(h); return rc; }
+  *out = h;
+  return 0;
+}
+
+extern "C" void fsvit_vit_destroy(fsvit_vit* h) {
+  if (!h) return;
+  for (void* p : h->allocs) (void)hipFree(p);
+  delete h;
+}
+
+extern "C" int fsvit_vit_out_dim(const fsvit_vit* h) { return h ? h->D : 0; }
+
+extern "C" size_t fsvit_vit_workspace_bytes(const fsvit_vit* h, int chunk_images) {
+  if (!h || chunk_images <= 0) return 0;
+  return make_vit_plan(h, (size_t)chunk_images).total;
+}
+
+extern "C" int fsvit_vit_forward(fsvit_vit* h, const float* x, int n_img, int img_h, int img_w, float* feat, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  if (h && n_img <= 0) return 0;
+  if (!h || !x || !feat || !ws) return fail(FSVIT_ERR_ARG, "null argument");
+  if (img_h != h->cfg.img_size || img_w != h->cfg.img_size)      // PatchEmbed assert (deit.py:96-97)
+    return fail(FSVIT_ERR_IMG_SIZE, "Input image size (%d*%d) doesn't match model (%d*%d).", img_h, img_w, h->cfg.img_size, h->cfg.img_size);
+  if (((uintptr_t)ws & 255) != 0) return fail(FSVIT_ERR_ARG, "workspace must be 256-byte aligned");
+  int lo = 0, hi = n_img;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) / 2;
+    if (make_vit_plan(h, (size_t)mid).total <= ws_bytes) lo = mid; else hi = mid - 1;
+  }
+  if (lo < 1) return fail(FSVIT_ERR_WORKSPACE, "workspace of %zu bytes cannot hold one image (need %zu)", ws_bytes, make_vit_plan(h, 1).total);
+  const size_t img_elems = (size_t)3 * img_h * img_w;
+  for (int off = 0; off < n_img; off += lo) {
+    const int bc = n_img - off < lo ? n_img - off : lo;
+    int rc = vit_forward_chunk(h, x + (size_t)off * img_elems, bc, feat + (size_t)off * h->D, (unsigned char*)ws, off == 0, (hipStream_t)stream);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
+static int encoder_forward_any(void* hv, const float* x, int n, int img_h, int img_w, float* feat, void* ws, size_t ws_bytes, void* stream) {
+  EngineBase* b = static_cast<EngineBase*>(hv);
+  if (b->kind == KIND_VISFORMER) return fsvit_visformer_forward(static_cast<fsvit_visformer*>(b), x, n, img_h, img_w, feat, ws, ws_bytes, stream);
+  if (b->kind == KIND_VIT) return fsvit_vit_forward(static_cast<fsvit_vit*>(b), x, n, img_h, img_w, feat, ws, ws_bytes, stream);
+  return fail(FSVIT_ERR_ARG, "not an fsvit encoder handle");
+}
+static int encoder_out_dim_any(void* hv) {
+  EngineBase* b = static_cast<EngineBase*>(hv);
+  return b->kind == KIND_VISFORMER ? static_cast<fsvit_visformer*>(b)->C3 : (b->kind == KIND_VIT ? static_cast<fsvit_vit*>(b)->D : 0);
 }

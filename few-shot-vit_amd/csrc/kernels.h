@@ -23,4 +23,10 @@ int launch_proto_head(const float* feat_shot, const float* feat_query, int E, in
 bool stage1_fused_supported(int dtype, int C1, int hid, int group, int H1);
 int launch_stage1_block(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, hipStream_t s);
 
+// ViT / DeiT helpers (vit.hip)
+int launch_patchify(const float* x_nchw, void* out, int B, int img, int p, int Kp, int dtype, hipStream_t s);
+int launch_cls_pos(const float* cls_plus_pos0, void* tokens, int B, int S, int D, int dtype, hipStream_t s);
+int launch_layernorm(const void* x, void* y, int M, int D, float eps, int dtype, hipStream_t s);
+int launch_final_ln_cls(const void* tokens, const float* gamma, const float* beta, float* feat, int B, int S, int D, float eps, int dtype, hipStream_t s);
+
 }  // namespace fsvit

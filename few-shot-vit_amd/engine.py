@@ -35,12 +35,13 @@ def _require_cuda(*ts):
             raise RuntimeError('fsvit kernels run on an MI355X only: tensor is on %s (no CPU fallback)' % t.device)
 
 
-class VisformerEngine:
-    """Packed eval-mode Visformer on one GPU.
+class _EncoderEngine:
+    """One packed eval-mode encoder on one GPU (shared plumbing of the Visformer and ViT handles)."""
 
-    cfg: dict(img_size, init_channels, embed_dim, depth, num_heads, mlp_ratio, group[, bn_eps])
-    state_dict: encoder-relative keys -> tensors (any device); reference layout.
-    """
+    _fn = {}          # C entry points: create / destroy / out_dim / workspace_bytes / forward
+
+    def _make_cfg(self, cfg: dict):
+        raise NotImplementedError
 
     def __init__(self, cfg: dict, state_dict: Dict[str, torch.Tensor], numerics: str = None, device=None,
                  chunk_images: int = None):
@@ -51,14 +52,9 @@ class VisformerEngine:
         self.dtype = DTYPES[numerics]
         self.device = torch.device(device if device is not None else 'cuda')
         if self.device.type != 'cuda':
-            raise RuntimeError('VisformerEngine needs a GPU device (no CPU fallback)')
-        self.chunk_images = int(chunk_images or os.environ.get("FSVIT_CHUNK", 1600))
-        c = _lib.VisformerCfg()
-        c.img_size, c.init_channels, c.embed_dim = cfg['img_size'], cfg['init_channels'], cfg['embed_dim']
-        for i in range(3):
-            c.depth[i] = cfg['depth'][i]
-        c.num_heads, c.mlp_ratio, c.group = cfg['num_heads'], cfg.get('mlp_ratio', 4.0), cfg.get('group', 8)
-        c.bn_eps = cfg.get('bn_eps', 1e-5)
+            raise RuntimeError(f'{type(self).__name__} needs a GPU device (no CPU fallback)')
+        self.chunk_images = int(chunk_images or os.environ.get('FSVIT_CHUNK', self._default_chunk))
+        c = self._make_cfg(cfg)
         self.img_size = cfg['img_size']
         keep, arr = [], (_lib.Tensor * len(state_dict))()
         n = 0
@@ -70,14 +66,14 @@ class VisformerEngine:
             arr[n].name = k.encode()
             arr[n].data = a.ctypes.data_as(C.POINTER(C.c_float))
             arr[n].ndim = a.ndim
-            for i, s in enumerate(a.shape):
-                arr[n].shape[i] = s
+            for i, sdim in enumerate(a.shape):
+                arr[n].shape[i] = sdim
             n += 1
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.fsvit_visformer_create(C.byref(c), arr, n, self.dtype, C.byref(h)))
+            _lib.check(getattr(self.lib, self._fn['create'])(C.byref(c), arr, n, self.dtype, C.byref(h)))
         self.h = h
-        self.out_dim = self.lib.fsvit_visformer_out_dim(h)
+        self.out_dim = getattr(self.lib, self._fn['out_dim'])(h)
         self._ws = None
         self._taps = {}
 
@@ -85,37 +81,37 @@ class VisformerEngine:
         h, self.h = getattr(self, 'h', None), None
         if h:
             try:
-                self.lib.fsvit_visformer_destroy(h)
+                getattr(self.lib, self._fn['destroy'])(h)
             except Exception:       # interpreter shutdown
                 pass
 
     def workspace(self, n_img: int) -> torch.Tensor:
         chunk = max(1, min(n_img, self.chunk_images))
-        need = self.lib.fsvit_visformer_workspace_bytes(self.h, chunk)
+        need = getattr(self.lib, self._fn['workspace_bytes'])(self.h, chunk)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
     def set_tap(self, name: str, shape) -> torch.Tensor:
         t = torch.zeros(shape, dtype=TORCH_DTYPE[self.dtype], device=self.device)
-        _lib.check(self.lib.fsvit_visformer_set_tap(self.h, name.encode(), _ptr(t), t.numel() * t.element_size()))
+        _lib.check(self.lib.fsvit_encoder_set_tap(self.h, name.encode(), _ptr(t), t.numel() * t.element_size()))
         self._taps[name] = t
         return t
 
     def profile_begin(self):
-        _lib.check(self.lib.fsvit_visformer_profile_begin(self.h))
+        _lib.check(self.lib.fsvit_encoder_profile_begin(self.h))
 
     def profile_end(self):
         """-> list of dict(layer, kernel, launches, flops, ms): HIP-event time of every launch since
         profile_begin, summed per (layer, kernel template instantiation)."""
         recs = (_lib.ProfRec * 256)()
         n = C.c_int(0)
-        _lib.check(self.lib.fsvit_visformer_profile_end(self.h, recs, 256, C.byref(n)))
+        _lib.check(self.lib.fsvit_encoder_profile_end(self.h, recs, 256, C.byref(n)))
         return [dict(layer=recs[i].layer.decode(), kernel=self.lib.fsvit_kernel_name(recs[i].kernel_id, self.dtype).decode(),
                      launches=recs[i].launches, flops=recs[i].flops, ms=recs[i].ms) for i in range(n.value)]
 
     def forward(self, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
-        """x [B,3,H,W] fp32 cuda -> pooled features [B,out_dim] fp32."""
+        """x [B,3,H,W] fp32 cuda -> features [B,out_dim] fp32."""
         _require_cuda(x)
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError('expected [B,3,H,W] input')
@@ -127,8 +123,8 @@ class VisformerEngine:
             return out
         ws = self.workspace(B)
         with torch.cuda.device(x.device):
-            _lib.check(self.lib.fsvit_visformer_forward(self.h, _ptr(x), B, x.shape[2], x.shape[3], _ptr(out), _ptr(ws),
-                                                        ws.numel(), _stream_ptr(x.device)))
+            _lib.check(getattr(self.lib, self._fn['forward'])(self.h, _ptr(x), B, x.shape[2], x.shape[3], _ptr(out), _ptr(ws),
+                                                             ws.numel(), _stream_ptr(x.device)))
         return out
 
     def meta_baseline_forward(self, x_shot, x_query, temp: float, method: str = 'cos', want_stats=False):
@@ -152,6 +148,36 @@ class VisformerEngine:
         if want_stats:
             return logits, acc, loss
         return logits
+
+
+class VisformerEngine(_EncoderEngine):
+    """cfg: dict(img_size, init_channels, embed_dim, depth, num_heads, mlp_ratio, group[, bn_eps]);
+    state_dict: encoder-relative reference keys."""
+    _fn = dict(create='fsvit_visformer_create', destroy='fsvit_visformer_destroy', out_dim='fsvit_visformer_out_dim',
+               workspace_bytes='fsvit_visformer_workspace_bytes', forward='fsvit_visformer_forward')
+    _default_chunk = 1600
+
+    def _make_cfg(self, cfg):
+        c = _lib.VisformerCfg()
+        c.img_size, c.init_channels, c.embed_dim = cfg['img_size'], cfg['init_channels'], cfg['embed_dim']
+        for i in range(3):
+            c.depth[i] = cfg['depth'][i]
+        c.num_heads, c.mlp_ratio, c.group = cfg['num_heads'], cfg.get('mlp_ratio', 4.0), cfg.get('group', 8)
+        c.bn_eps = cfg.get('bn_eps', 1e-5)
+        return c
+
+
+class VitEngine(_EncoderEngine):
+    """cfg: dict(img_size, patch_size, embed_dim, depth, num_heads[, mlp_ratio, ln_eps]) (deit.py:142-144)."""
+    _fn = dict(create='fsvit_vit_create', destroy='fsvit_vit_destroy', out_dim='fsvit_vit_out_dim',
+               workspace_bytes='fsvit_vit_workspace_bytes', forward='fsvit_vit_forward')
+    _default_chunk = 400
+
+    def _make_cfg(self, cfg):
+        c = _lib.VitCfg()
+        c.img_size, c.patch_size, c.embed_dim, c.depth = cfg['img_size'], cfg['patch_size'], cfg['embed_dim'], cfg['depth']
+        c.num_heads, c.mlp_ratio, c.ln_eps = cfg['num_heads'], cfg.get('mlp_ratio', 4.0), cfg.get('ln_eps', 1e-6)
+        return c
 
 
 class ops:

@@ -79,10 +79,10 @@ int fsvit_visformer_forward(fsvit_visformer* h, const float* x_nchw_dev, int n_i
 /* Test hook: copy the named residual-stream activation of the FIRST chunk (NHWC, storage dtype) to
  * dst_dev during the next forwards.  Names: "stem" (after max-pool + pos_embed1), "stage1.N",
  * "patch_embed2"/"patch_embed3" (incl. pos_embed), "stage2.N", "stage3.N".  dst_dev NULL clears. */
-int fsvit_visformer_set_tap(fsvit_visformer* h, const char* name, void* dst_dev, size_t bytes);
+int fsvit_encoder_set_tap(void* encoder, const char* name, void* dst_dev, size_t bytes);   /* ViT names: "embed", "blocks.N" */
 
 /* Live per-launch timing (bench.py roofline leg): between begin and end every kernel launch of
- * fsvit_visformer_forward is bracketed by HIP events ON THE STREAM IT IS LAUNCHED ON.  `end`
+ * fsvit_visformer_forward / fsvit_vit_forward is bracketed by HIP events ON THE STREAM IT IS LAUNCHED ON.  `end`
  * synchronises and returns one record per (layer, kernel) with summed algorithmic FLOPs (2*MAC,
  * unpadded dims), summed milliseconds and the launch count. */
 typedef struct fsvit_prof_rec {
@@ -92,10 +92,32 @@ typedef struct fsvit_prof_rec {
   double flops;
   double ms;
 } fsvit_prof_rec;
-int fsvit_visformer_profile_begin(fsvit_visformer* h);
-int fsvit_visformer_profile_end(fsvit_visformer* h, fsvit_prof_rec* out, int max_recs, int* n_out);
+int fsvit_encoder_profile_begin(void* encoder);
+int fsvit_encoder_profile_end(void* encoder, fsvit_prof_rec* out, int max_recs, int* n_out);
 /* Device kernel (template instantiation) behind a kernel_id, as rocprofv3 --kernel-trace names it. */
 const char* fsvit_kernel_name(int kernel_id, int dtype);
+
+/* ---------------------------------------------------------------- ViT / DeiT encoder
+ * Replaces `VisionTransformer.__init__` + `load_state_dict` + `forward` in eval mode (test_phase/models/deit.py:139-218;
+ * factories deit_{tiny,small,base,nano}_patch16_224, deit_{nano,micro}_patch6_84, :220-357).  LayerNorm eps 1e-6,
+ * Linear layers with bias, qkv_bias=True, cls token at index 0, features = norm(x)[:, 0].  Same conventions as the
+ * Visformer handle; state-dict keys of SURVEY.md Appendix A (DeiT part). */
+typedef struct fsvit_vit fsvit_vit;
+typedef struct fsvit_vit_cfg {          /* deit.py:142-144 */
+  int img_size;
+  int patch_size;
+  int embed_dim;
+  int depth;
+  int num_heads;
+  float mlp_ratio;
+  float ln_eps;
+} fsvit_vit_cfg;
+int fsvit_vit_create(const fsvit_vit_cfg* cfg, const fsvit_tensor* state_dict, int n_tensors, int dtype, fsvit_vit** out);
+void fsvit_vit_destroy(fsvit_vit* h);
+int fsvit_vit_out_dim(const fsvit_vit* h);                           /* `.out_dim` (deit.py:147) */
+size_t fsvit_vit_workspace_bytes(const fsvit_vit* h, int chunk_images);
+int fsvit_vit_forward(fsvit_vit* h, const float* x_nchw_dev, int n_img, int img_h, int img_w, float* feat_dev,
+                      void* ws_dev, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- episode head
  * Replaces MetaBaseline.forward after the encoder call (test_phase/models/meta_baseline.py:33-47),
@@ -109,7 +131,7 @@ int fsvit_proto_head(const float* feat_shot_dev, const float* feat_query_dev, in
 /* Whole `MetaBaseline.forward(x_shot, x_query)` (meta_baseline.py:24-47) in eval mode:
  * x_shot_dev [E,way,shot,3,H,W], x_query_dev [E,Q,3,H,W] fp32 -> logits_dev [E,Q,way].
  * feat_dev: scratch [(E*way*shot + E*Q), out_dim] fp32. */
-int fsvit_meta_baseline_forward(fsvit_visformer* h, const float* x_shot_dev, const float* x_query_dev,
+int fsvit_meta_baseline_forward(void* encoder /* fsvit_visformer* or fsvit_vit* */, const float* x_shot_dev, const float* x_query_dev,
                                 int E, int way, int shot, int Q, int img_h, int img_w, float temp, int method,
                                 float* logits_dev, float* acc_dev, float* loss_dev, float* feat_dev,
                                 void* ws_dev, size_t ws_bytes, void* stream);

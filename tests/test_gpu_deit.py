@@ -1,0 +1,87 @@
+"""DeiT / ViT encoders through the C-ABI vs the pinned oracle and the reference goldens.
+Tolerance: 1e-3 on features / logits in `parity` mode (north star); bf16 deviation is printed and bounded loosely."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(name, numerics):
+    from fewshot_vit_amd import models, synthetic
+    m = models.make(name, numerics=numerics)
+    shapes = {'encoder.' + k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = synthetic.procedural_state_dict(shapes)
+    m.load_state_dict({k[len('encoder.'):]: v for k, v in sd.items()}, strict=True)
+    return m.cuda().eval(), sd
+
+
+@pytest.mark.parametrize('name,B', [('deit_small_patch16_224', 3), ('deit_micro_patch6_84', 4)])
+@pytest.mark.parametrize('numerics,tol', [('parity', 1e-3), ('bf16', 0.15)])
+def test_deit_features_vs_reference_golden_and_oracle(golden_dir, name, B, numerics, tol):
+    from oracle import deit_oracle as do
+    z = np.load(os.path.join(golden_dir, 'deit.npz'))
+    cfg = do.FACTORIES[name]
+    m, sd = _model(name, numerics)
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, 3, cfg.img_size, cfg.img_size, generator=g)
+    eng = m.engine()
+    S, D = cfg.num_patches + 1, cfg.embed_dim
+    bufs = {k: eng.set_tap(k, (B, S, D)) for k in ('embed', 'blocks.0', 'blocks.5', 'blocks.11')}
+    with torch.no_grad():
+        feat = m(x.cuda()).cpu()
+    err = np.abs(feat.numpy() - z[f'{name}.feat']).max()
+    taps = {}
+    with torch.no_grad():
+        ref = do.deit_forward(sd, x, cfg, prefix='encoder.', taps=taps)
+    worst = {k: ((b.float().cpu() - taps[k]).abs().max() / max(1.0, float(taps[k].abs().max()))).item() for k, b in bufs.items()}
+    print(f'[{numerics}] {name}: max|dfeat| vs reference golden = {err:.3e}; token-stream rel errors {worst}')
+    assert err <= tol
+    assert (feat - ref).abs().max().item() <= tol
+    for k, v in worst.items():
+        assert v <= (2e-4 if numerics == 'parity' else 0.1), (k, v)
+    assert m.out_dim == D and feat.shape == (B, D)
+
+
+def test_meta_baseline_with_deit_encoder_and_errors():
+    from fewshot_vit_amd import models, synthetic
+    from fewshot_vit_amd.utils import few_shot as fs
+    from oracle import deit_oracle as do
+    from oracle import visformer_oracle as vo
+    cfg = do.FACTORIES['deit_micro_patch6_84']
+    m = models.make('meta-baseline', encoder='deit_micro_patch6_84', encoder_args={'numerics': 'parity'})
+    sd = synthetic.procedural_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    x = synthetic.synthetic_episodes(9, 2, 5, 1, 2, img=84)             # 2 episodes x 15 images
+    xs, xq = fs.split_shot_query(x, 5, 1, 2, 2)
+    with torch.no_grad():
+        logits = m(xs.cuda(), xq.cuda()).cpu()
+        f = do.deit_forward(sd, torch.cat([xs.reshape(-1, 3, 84, 84), xq.reshape(-1, 3, 84, 84)]), cfg, prefix='encoder.')
+    ref = vo.meta_baseline_head(f[:10].reshape(2, 5, 1, -1), f[10:].reshape(2, 10, -1), temp=10.0)
+    assert (logits - ref).abs().max().item() <= 1e-3
+    with pytest.raises(AssertionError):
+        m.encoder(torch.zeros(1, 3, 80, 80, device='cuda'))
+    bad = dict(sd)
+    bad.pop('encoder.blocks.3.attn.qkv.bias')
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad, strict=True)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_vit_ops_layernorm_rows(dt):
+    """LayerNorm normalisation is exercised through the encoder; here the remapped patch-token rows + cls row."""
+    from fewshot_vit_amd import models, synthetic
+    m, sd = _model('deit_nano_patch6_84', 'parity' if dt == 'f32' else 'bf16')
+    x = torch.randn(2, 3, 84, 84, generator=torch.Generator().manual_seed(1))
+    eng = m.engine()
+    buf = eng.set_tap('embed', (2, 197, 224))
+    with torch.no_grad():
+        m(x.cuda())
+    got = buf.float().cpu()
+    w, b = sd['encoder.patch_embed.proj.weight'], sd['encoder.patch_embed.proj.bias']
+    tok = torch.nn.functional.conv2d(x, w, b, stride=6).flatten(2).transpose(1, 2)
+    ref = torch.cat([sd['encoder.cls_token'].expand(2, -1, -1), tok], 1) + sd['encoder.pos_embed']
+    assert (got - ref).abs().max().item() <= (2e-5 if dt == 'f32' else 3e-2)

@@ -198,3 +198,25 @@ def test_compute_logits(ka):
         assert np.abs(got - np.array(c[key])).max() < 2e-6, key
     got = vo.compute_logits(feat[0], proto[0], 'dot', 1.0).numpy()
     assert np.abs(got - np.array(c['dot2d'])).max() < 2e-6
+
+
+# ----------------------------------------------------------------------------- DeiT (deit.py)
+@pytest.mark.parametrize('name,B', [('deit_small_patch16_224', 3), ('deit_micro_patch6_84', 4)])
+def test_deit_oracle_matches_reference(golden_dir, name, B):
+    from oracle import deit_oracle as do
+    z = np.load(os.path.join(golden_dir, 'deit.npz'))
+    cfg = do.FACTORIES[name]
+    sd = synthetic.procedural_state_dict(do.state_dict_shapes(cfg, prefix='encoder.'))
+    assert sum(int(np.prod(v.shape)) for v in sd.values()) == {'deit_small_patch16_224': 21665664, 'deit_micro_patch6_84': 10780176}[name]
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, 3, cfg.img_size, cfg.img_size, generator=g)
+    taps = {}
+    with torch.no_grad():
+        feat = do.deit_forward(sd, x, cfg, prefix='encoder.', taps=taps)
+    assert np.abs(feat.numpy() - z[f'{name}.feat']).max() <= 2e-5
+    for i in (0, 5, 11):
+        ref = z[f'{name}.blocks.{i}']
+        got = taps[f'blocks.{i}'][:, ::13, ::7].numpy()
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    with pytest.raises(AssertionError):
+        do.deit_forward(sd, torch.zeros(1, 3, cfg.img_size + 4, cfg.img_size + 4), cfg, prefix='encoder.')
