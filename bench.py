@@ -28,7 +28,8 @@ if REPO not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-FLOP_PER_IMAGE = 2.0306e9            # algorithmic forward FLOPs, visformer_micro_80 @80x80
+# algorithmic forward FLOPs per image (2*MAC, SURVEY.md 8d / BASELINE.md 2) and input size per encoder
+MODELS = {'visformer_micro_80': (2.0306e9, 80), 'deit_small_patch16_224': (9.197e9, 224), 'deit_micro_patch6_84': (4.716e9, 84)}
 HEAD_FLOP_PER_EPISODE = 0.38e6
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}    # dense peaks, MI355X_MICROARCH.md
 
@@ -40,6 +41,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--episodes', type=int, default=32, help='episodes per GPU per step (ep_per_batch)')
     ap.add_argument('--shot', type=int, default=5)
+    ap.add_argument('--model', default='visformer_micro_80', choices=sorted(MODELS), help='encoder (default = BASELINE configs[1])')
     ap.add_argument('--numerics', default='bf16', choices=['bf16', 'parity'])
     ap.add_argument('--chunk', type=int, default=int(os.environ.get('FSVIT_CHUNK', 1600)), help='images per encoder chunk')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -49,32 +51,44 @@ def parse():
     return ap.parse_args()
 
 
-def device_episodes(seed, n_ep, way, shot, query, dev):
+def device_episodes(seed, n_ep, way, shot, query, dev, img=80):
     """Class-structured synthetic episodes generated directly in HBM (x = mu_c + 1.5*eps, so accuracy
     is neither chance nor saturated); layout = what fs.split_shot_query returns."""
     g = torch.Generator(device=dev).manual_seed(seed)
     per = shot + query
-    mu = torch.randn(n_ep, way, 1, 3, 80, 80, device=dev, generator=g)
-    x = mu + 1.5 * torch.randn(n_ep, way, per, 3, 80, 80, device=dev, generator=g)
+    mu = torch.randn(n_ep, way, 1, 3, img, img, device=dev, generator=g)
+    x = mu + 1.5 * torch.randn(n_ep, way, per, 3, img, img, device=dev, generator=g)
     x_shot = x[:, :, :shot].contiguous()
-    x_query = x[:, :, shot:].contiguous().view(n_ep, way * query, 3, 80, 80)
+    x_query = x[:, :, shot:].contiguous().view(n_ep, way * query, 3, img, img)
     return x_shot, x_query
 
 
-def cpu_baseline(sd, shot, n_ep):
+def cpu_baseline(sd, shot, n_ep, model='visformer_micro_80'):
     """Oracle timed at ep_per_batch=1 (the reference's test setting, test_few_shot.py:47-48)."""
     from fewshot_vit_amd import synthetic
     from fewshot_vit_amd.utils import few_shot as fs
     from oracle import visformer_oracle as vo
-    cfg = vo.VisformerCfg()
     cores = torch.get_num_threads()
-    x = synthetic.synthetic_episodes(12345, 1, 5, shot, 15)
+    img = MODELS[model][1]
+    x = synthetic.synthetic_episodes(12345, 1, 5, shot, 15, img=img)
     xs, xq = fs.split_shot_query(x, 5, shot, 15, 1)
+    if model == 'visformer_micro_80':
+        cfg = vo.VisformerCfg()
+        run = lambda: vo.meta_baseline_forward(sd, xs, xq, cfg)
+    else:
+        from oracle import deit_oracle as do
+        cfg = do.FACTORIES[model]
+
+        def run():
+            with torch.no_grad():
+                f = do.deit_forward(sd, torch.cat([xs.reshape(-1, 3, img, img), xq.reshape(-1, 3, img, img)]), cfg, prefix='encoder.')
+            n = xs.shape[1] * xs.shape[2]
+            return vo.meta_baseline_head(f[:n].reshape(1, 5, shot, -1), f[n:].reshape(1, 75, -1), temp=10.0)
     for _ in range(2):
-        vo.meta_baseline_forward(sd, xs, xq, cfg)
+        run()
     t0 = time.perf_counter()
     for _ in range(n_ep):
-        vo.meta_baseline_forward(sd, xs, xq, cfg)
+        run()
     dt = time.perf_counter() - t0
     return {'value': n_ep / dt, 'unit': 'episodes/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n_ep} episodes 5-way {shot}-shot (100 images each at 5-shot), ep_per_batch=1, fp32 torch CPU '
@@ -100,15 +114,17 @@ def main():
 
     from fewshot_vit_amd import models, synthetic
     os.environ['FSVIT_CHUNK'] = str(args.chunk)
-    model = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={'numerics': args.numerics})
+    flop_per_image, img = MODELS[args.model]
+    model = models.make('meta-baseline', encoder=args.model, encoder_args={'numerics': args.numerics})
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = synthetic.synthetic_checkpoint_sd(shapes)          # procedural weights by key name + shipped BN calibration
+    # procedural weights by key name (+ the shipped BN calibration for the Visformer)
+    sd = synthetic.synthetic_checkpoint_sd(shapes, calib=args.model if args.model == 'visformer_micro_80' else None)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
     engine = model.encoder.engine()
 
     way, query, E = 5, 15, args.episodes
-    x_shot, x_query = device_episodes(12345 + rank, E, way, args.shot, query, dev)
+    x_shot, x_query = device_episodes(12345 + rank, E, way, args.shot, query, dev, img)
     temp = float(model.temp.detach())
 
     def step():
@@ -153,15 +169,17 @@ def main():
         total_eps = world * E * args.steps
         eps = total_eps / elapsed
         imgs = way * (args.shot + query)
-        flops_ep = FLOP_PER_IMAGE * imgs + HEAD_FLOP_PER_EPISODE
+        flops_ep = flop_per_image * imgs + HEAD_FLOP_PER_EPISODE
         out = {
-            'metric': 'episodes_per_sec_5way_%dshot_visformer_s' % args.shot, 'value': eps, 'unit': 'episodes/s',
+            'metric': 'episodes_per_sec_5way_%dshot_%s' % (args.shot, 'visformer_s' if args.model == 'visformer_micro_80' else args.model), 'value': eps, 'unit': 'episodes/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if args.numerics == 'bf16' else 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: Visformer-S (visformer_micro_80) miniImageNet-shaped 5-way %d-shot '
-                                   'episodic eval, 15 query/class, 80x80 fp32 NCHW episodes resident in HBM, procedural weights + '
-                                   'calibrated BN' % args.shot,
+            'config': {'workload': ('BASELINE configs[1]: Visformer-S (visformer_micro_80) miniImageNet-shaped 5-way %d-shot '
+                                    'episodic eval, 15 query/class, 80x80 fp32 NCHW episodes resident in HBM, procedural weights + '
+                                    'calibrated BN' % args.shot) if args.model == 'visformer_micro_80' else
+                                   ('BASELINE configs[4] shape: %s, %dx%d, 5-way %d-shot episodic eval, 15 query/class, synthetic episodes '
+                                    'resident in HBM, procedural weights' % (args.model, img, img, args.shot)),
                        'episodes_per_step_per_gpu': E, 'images_per_episode': imgs, 'encoder_chunk_images': args.chunk,
                        'parallelism': 'episode-parallel x%d, one all-reduce of accuracy stats' % world},
             'whole_path_tflops': eps * flops_ep / 1e12,
@@ -193,7 +211,7 @@ def main():
                     print(f"  {r['layer']:<22} {r['kernel']:<40} {r['ms'] / args.steps:8.3f} ms/step {100 * r['ms'] / tot:5.1f}%  {tf:7.1f} TF/s",
                           file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(sd, args.shot, args.cpu_episodes)
+            out['cpu_baseline'] = cpu_baseline(sd, args.shot, args.cpu_episodes, args.model)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
