@@ -196,13 +196,17 @@ __global__ __launch_bounds__(NW * 64) void attention_v2_kernel(const T* __restri
       for (int kc = 0; kc < NKC; ++kc) acc = mma_chunk<T>(*reinterpret_cast<const u32x4*>(ka + kc * 64), qf[kc], acc);
       sc[kt] = acc;                      // keys kt*16 + lq*4 + r  x  query lrow
     }
+    // bf16 storage: P is rounded to bf16 anyway, so exp runs on the hardware exp2 (v_exp_f32) with log2(e) folded
+    // into the score scale; the fp32 parity path keeps expf.
+    constexpr bool FAST_EXP = ES == 2;
+    const float sscale = FAST_EXP ? scale * 1.44269504088896340736f : scale;
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool ok = kt * 16 + lq * 4 + r < S;
-        sc[kt][r] = ok ? sc[kt][r] * scale : -INFINITY;
+        sc[kt][r] = ok ? sc[kt][r] * sscale : -INFINITY;
         m = fmaxf(m, sc[kt][r]);
       }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
@@ -212,7 +216,8 @@ __global__ __launch_bounds__(NW * 64) void attention_v2_kernel(const T* __restri
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = kt * 16 + lq * 4 + r < S ? expf(sc[kt][r] - m) : 0.f;
+        const float d = sc[kt][r] - m;                 // -inf for masked keys -> exp = 0
+        const float e = FAST_EXP ? __builtin_amdgcn_exp2f(d) : expf(d);
         sc[kt][r] = e;
         sum += e;
       }
