@@ -197,8 +197,13 @@ def main():
             d = bykern[dom]
             peak = MFMA_PEAK_TFLOPS['bf16' if args.numerics == 'bf16' else 'f32']
             achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            traffic = None          # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
+            tf = os.path.join(REPO, 'profiles', 'r01_v5_hbm_traffic.json')
+            if os.path.exists(tf) and args.model == 'visformer_micro_80' and args.numerics == 'bf16' and E == 32:
+                with open(tf) as f:
+                    traffic = json.load(f).get(dom.replace('conv_gemm_v2_kernel<__bf16,128,128,2,2,2>', 'conv_gemm_v2_kernel<__bf16,128,128,2,2,2>'), {}).get('hbm_bytes_per_launch')
             out['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                               'traffic': None, 'kernel': dom, 'launches': d['launches'],
+                               'traffic': traffic, 'kernel': dom, 'launches': d['launches'],
                                'avg_launch_us': 1e3 * d['ms'] / d['launches'],
                                'avg_launch_gflop': d['flops'] / d['launches'] / 1e9,
                                'share_of_gpu_time': d['ms'] / sum(k['ms'] for k in bykern.values())}
