@@ -34,7 +34,8 @@ constexpr int OFF_H2 = OFF_H1 + 4 * H1_PLANE;      //  74752
 constexpr int OFF_W1 = OFF_H2 + 4 * H2_PLANE;      //  88064  [16 k-chunks][32 n][16 B]
 constexpr int OFF_W2 = OFF_W1 + 16 * 32 * 16;      //  96256  [9 taps * 4 k-chunks][32 n][16 B]
 constexpr int OFF_W3 = OFF_W2 + 36 * 32 * 16;      // 114688  [4 k-chunks][128 n][16 B]
-constexpr int LDS_BYTES = OFF_W3 + 4 * 128 * 16;   // 122880
+constexpr int OFF_B1 = OFF_W3 + 4 * 128 * 16;      // 122880  conv1 folded bias, 256 fp32
+constexpr int LDS_BYTES = OFF_B1 + HID * 4;        // 123904
 constexpr int KW2 = 320;                  // packed conv2 row length (9*32 = 288 rounded up to the 64-element K slice)
 }  // namespace s1
 
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(1024) void stage1_block_kernel(const bf16* __restri
   unsigned char* const W1b = smem + OFF_W1;
   unsigned char* const W2b = smem + OFF_W2;
   unsigned char* const W3b = smem + OFF_W3;
+  float* const B1s = reinterpret_cast<float*>(smem + OFF_B1);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
 
   const int t = threadIdx.x, lane = t & 63;
@@ -109,85 +111,122 @@ __global__ __launch_bounds__(1024) void stage1_block_kernel(const bf16* __restri
     const u32x4 z = {0u, 0u, 0u, 0u};
     for (int i = t; i < (4 * H1_PLANE) / 16; i += NW * 64) *reinterpret_cast<u32x4*>(H1 + i * 16) = z;
     if (t < (XTP - XT) * 16) *reinterpret_cast<u32x4*>(Xs + XT * 256 + t * 16) = z;
+    if (t < HID) B1s[t] = b1[t];        // bias table: an in-loop global load would cost a full round trip + vmcnt(0) per tile
   }
   s1_dma_wait();
   __syncthreads();
 
-  // P3 ownership: output channels 16 (w & 7) .. +15, m-tiles (w >> 3), +2, ...  (7 or 6 tiles)
+  // P3 ownership: output channels 16 (w & 7) .. +15, m-tiles (w >> 3), +2, ...  (7 tiles for the even half, 6 for the odd)
   const int n3 = w & 7, m3 = w >> 3;
   f32x4 acc[7];
 #pragma unroll
   for (int i = 0; i < 7; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto p3 = [&]() {
     const u32x4 wf = *reinterpret_cast<const u32x4*>(W3b + (lq * 128 + n3 * 16 + lrow) * 16);
+    const unsigned char* hb = H2 + lq * H2_PLANE + (m3 * 16 + lrow) * 16;
+    u32x4 af[7];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int mt = m3 + 2 * i;
-      if (mt < 13) {
-        const u32x4 af = *reinterpret_cast<const u32x4*>(H2 + lq * H2_PLANE + (mt * 16 + lrow) * 16);
-        acc[i] = mma_chunk<bf16>(wf, af, acc[i]);
-      }
+    for (int i = 0; i < 6; ++i) af[i] = *reinterpret_cast<const u32x4*>(hb + i * 512);
+    af[6] = m3 == 0 ? *reinterpret_cast<const u32x4*>(hb + 6 * 512) : u32x4{0u, 0u, 0u, 0u};     // m-tile 12 exists only for the even half
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc[i] = mma_chunk<bf16>(wf, af[i], acc[i]);
+  };
+
+  // P1 / P2 work split: (m-tile, n-tile) pairs p and p + 16; both pairs of a wave have the same n-tile (w & 1), so
+  // they share the weight fragment and run as two independent MFMA chains
+  const int nt = w & 1;
+  const int mtA = w >> 1, mtB = (w + NW) >> 1;
+  const bool p1B = w + NW < 2 * (XTP / 16);            // second conv1 pair exists  (28 pairs)
+  const bool p2B = w + NW < 2 * (OTP / 16);            // second conv2 pair exists  (26 pairs)
+  int hpA, hpB;                                        // H1 pixel (top-left tap) of this lane's output token, pairs A / B
+  {
+    int tk = mtA * 16 + lrow; tk = tk < OT ? tk : OT - 1;
+    hpA = (tk / W) * PW + tk % W;
+    tk = mtB * 16 + lrow; tk = tk < OT ? tk : OT - 1;  // padded output rows recompute token 199 (ignored later)
+    hpB = (tk / W) * PW + tk % W;
+  }
+  auto h1_store = [&](int mt, f32x4 a, f32x4 bias) {
+    const int tk = mt * 16 + lrow;
+    if (tk < XT) {
+      const int pr = tk / W, pc = tk - pr * W;
+      const int pix = (pr + (hsel ? 0 : 1)) * PW + pc + 1;
+      a += bias;
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)gelu_fast(a[e]);
+      *reinterpret_cast<bf16x4*>(H1 + (nt * 2 + (lq >> 1)) * H1_PLANE + pix * 16 + (lq & 1) * 8) = o;
     }
+  };
+  auto h2_store = [&](int mt, f32x4 a) {
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (bf16)gelu_fast(a[e]);
+    *reinterpret_cast<bf16x4*>(H2 + (nt * 2 + (lq >> 1)) * H2_PLANE + (mt * 16 + lrow) * 16 + (lq & 1) * 8) = o;
   };
 
 #pragma unroll 1
   for (int g = 0; g < G; ++g) {
-    // ---- interval A: DMA W2(g); P3(g-1); P1: H1g = GELU(conv1) for (m-tile, n-tile) pairs w, w + 16
+    // ---- interval A: DMA W2(g); P3(g-1); P1: H1g = GELU(conv1)
     dma_w2(g);
     if (g > 0) p3();
-#pragma unroll
-    for (int pi = 0; pi < 2; ++pi) {
-      const int pr_ = w + NW * pi;
-      if (pr_ < 2 * (XTP / 16)) {
-        const int mt = pr_ >> 1, nt = pr_ & 1;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        const unsigned char* xr = Xs + (mt * 16 + lrow) * 256;
-        const unsigned char* wr = W1b + (nt * 16 + lrow) * 16;
+    {
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(B1s + g * CG + nt * 16 + lq * 4);
+      const unsigned char* wr = W1b + (nt * 16 + lrow) * 16;
+      const unsigned char* xa = Xs + (mtA * 16 + lrow) * 256;
+      const unsigned char* xb = Xs + (mtB * 16 + lrow) * 256;
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+      if (p1B) {
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
-          const u32x4 xf = *reinterpret_cast<const u32x4*>(xr + (((kc * 4 + lq) ^ lrow) << 4));
+          const int sw = (((kc * 4 + lq) ^ lrow) << 4);
           const u32x4 wf = *reinterpret_cast<const u32x4*>(wr + (kc * 4 + lq) * 512);
-          a = mma_chunk<bf16>(wf, xf, a);
+          const u32x4 x0 = *reinterpret_cast<const u32x4*>(xa + sw);
+          const u32x4 x1 = *reinterpret_cast<const u32x4*>(xb + sw);
+          a0 = mma_chunk<bf16>(wf, x0, a0);
+          a1 = mma_chunk<bf16>(wf, x1, a1);
         }
-        const int tk = mt * 16 + lrow;
-        if (tk < XT) {
-          const int pr = tk / W, pc = tk - pr * W;
-          const int pix = (pr + (hsel ? 0 : 1)) * PW + pc + 1;
-          a += *reinterpret_cast<const f32x4*>(b1 + g * CG + nt * 16 + lq * 4);
-          bf16x4 o;
+        h1_store(mtA, a0, bias);
+        h1_store(mtB, a1, bias);
+      } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (bf16)gelu_fast(a[e]);
-          *reinterpret_cast<bf16x4*>(H1 + (nt * 2 + (lq >> 1)) * H1_PLANE + pix * 16 + (lq & 1) * 8) = o;
+        for (int kc = 0; kc < 4; ++kc) {
+          const u32x4 wf = *reinterpret_cast<const u32x4*>(wr + (kc * 4 + lq) * 512);
+          const u32x4 x0 = *reinterpret_cast<const u32x4*>(xa + (((kc * 4 + lq) ^ lrow) << 4));
+          a0 = mma_chunk<bf16>(wf, x0, a0);
         }
+        h1_store(mtA, a0, bias);
       }
     }
     s1_dma_wait();
     __syncthreads();
-    // ---- interval B: DMA W1(g+1), W3(g); P2: H2g = GELU(grouped 3x3 conv of H1g) for pairs w, w + 16
+    // ---- interval B: DMA W1(g+1), W3(g); P2: H2g = GELU(grouped 3x3 conv of H1g)
     if (g + 1 < G) dma_w1(g + 1);
     dma_w3(g);
-#pragma unroll
-    for (int pi = 0; pi < 2; ++pi) {
-      const int pr_ = w + NW * pi;
-      if (pr_ < 2 * (OTP / 16)) {
-        const int mt = pr_ >> 1, nt = pr_ & 1;
-        int tk = mt * 16 + lrow;
-        tk = tk < OT ? tk : OT - 1;                    // padded output rows recompute token 199 (ignored later)
-        const int r = tk / W, c = tk - r * W;
-        const unsigned char* hp = H1 + lq * H1_PLANE + (r * PW + c) * 16;
-        const unsigned char* wr = W2b + (lq * 32 + nt * 16 + lrow) * 16;
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    {
+      const unsigned char* wr = W2b + (lq * 32 + nt * 16 + lrow) * 16;
+      const unsigned char* ha = H1 + lq * H1_PLANE + hpA * 16;
+      const unsigned char* hb = H1 + lq * H1_PLANE + hpB * 16;
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+      if (p2B) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-          const int ky = tap / 3, kx = tap - ky * 3;
-          const u32x4 af = *reinterpret_cast<const u32x4*>(hp + (ky * PW + kx) * 16);
+          const int toff = ((tap / 3) * PW + tap % 3) * 16;
           const u32x4 wf = *reinterpret_cast<const u32x4*>(wr + tap * 2048);
-          a = mma_chunk<bf16>(wf, af, a);
+          const u32x4 f0 = *reinterpret_cast<const u32x4*>(ha + toff);
+          const u32x4 f1 = *reinterpret_cast<const u32x4*>(hb + toff);
+          a0 = mma_chunk<bf16>(wf, f0, a0);
+          a1 = mma_chunk<bf16>(wf, f1, a1);
         }
-        bf16x4 o;
+        h2_store(mtA, a0);
+        h2_store(mtB, a1);
+      } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16)gelu_fast(a[e]);
-        *reinterpret_cast<bf16x4*>(H2 + (nt * 2 + (lq >> 1)) * H2_PLANE + (mt * 16 + lrow) * 16 + (lq & 1) * 8) = o;
+        for (int tap = 0; tap < 9; ++tap) {
+          const u32x4 wf = *reinterpret_cast<const u32x4*>(wr + tap * 2048);
+          const u32x4 f0 = *reinterpret_cast<const u32x4*>(ha + ((tap / 3) * PW + tap % 3) * 16);
+          a0 = mma_chunk<bf16>(wf, f0, a0);
+        }
+        h2_store(mtA, a0);
       }
     }
     s1_dma_wait();
