@@ -45,6 +45,44 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_byte_addr) 
       : "v"(gsrc), "s"(lds_byte_addr)
       : "memory");
 }
+// N LDS-DMAs to destinations lds_byte_addr + i * 4096 in ONE statement: M0 is saved / restored once and
+// advanced with s_add (the per-DMA form spends 5 scalar instructions on M0 for every load).
+__device__ __forceinline__ void dma16x4(const void* s0, const void* s1, const void* s2, const void* s3, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %5\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_add_u32 m0, m0, 0x1000\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, off\n\t"
+      "s_add_u32 m0, m0, 0x1000\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %3, off\n\t"
+      "s_add_u32 m0, m0, 0x1000\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %4, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "s"(lds_byte_addr)
+      : "memory", "scc");
+}
+__device__ __forceinline__ void dma16x2(const void* s0, const void* s1, unsigned lds_byte_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_add_u32 m0, m0, 0x1000\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(s0), "v"(s1), "s"(lds_byte_addr)
+      : "memory", "scc");
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lptr_t)p; }
 
@@ -135,13 +173,15 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
     const unsigned la = __builtin_amdgcn_readfirstlane(lds_addr(ldsA0) + buf * (BM * 128) + wave * (8 * 128));
     const unsigned lb = __builtin_amdgcn_readfirstlane(lds_addr(ldsB0) + buf * (BN * 128) + wave * (8 * 128));
     if (kt < nk_main) {
+      const T* srcs[A_IT];
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
         const int iy = iy0[i] + ky, ix = ix0[i] + kx;
         const bool ok = kok && rowok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const T* src = ok ? Xg + (size_t)(pixbase[i] + iy * p.W + ix) * p.x_cstride + cc : zero;
-        dma16(src, la + i * (32 * 128));
+        srcs[i] = ok ? Xg + (size_t)(pixbase[i] + iy * p.W + ix) * p.x_cstride + cc : zero;
       }
+      static_assert(A_IT == 4, "A tile = 128 rows = 4 row groups per wave");
+      dma16x4(srcs[0], srcs[1], srcs[2], srcs[3], la);
     } else {                               // tail operand: row m of x2, columns sc*EPC .. (no spatial gather)
       const T* X2 = reinterpret_cast<const T*>(p.x2);
       const bool cok = sc * EPC < p.K2;
@@ -151,10 +191,14 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
         dma16(src, la + i * (32 * 128));
       }
     }
+    const T* bs[B_IT];
 #pragma unroll
-    for (int jj = 0; jj < B_IT; ++jj) {
-      const T* src = nok[jj] ? wrow[jj] + (size_t)kt * BKE : zero;
-      dma16(src, lb + jj * (32 * 128));
+    for (int jj = 0; jj < B_IT; ++jj) bs[jj] = nok[jj] ? wrow[jj] + (size_t)kt * BKE : zero;
+    if constexpr (B_IT == 4) dma16x4(bs[0], bs[1], bs[2], bs[3], lb);
+    else if constexpr (B_IT == 2) dma16x2(bs[0], bs[1], lb);
+    else {
+#pragma unroll
+      for (int jj = 0; jj < B_IT; ++jj) dma16(bs[jj], lb + jj * (32 * 128));
     }
   };
 

@@ -37,7 +37,8 @@ int launch_pool_affine(const void* x, const float* scale, const float* shift, fl
 
 // method: 0 = 'cos' (normalise both, dot), 1 = 'sqr' (negative squared distance to the mean prototype),
 //         2 = 'dot' (plain dot product with the mean prototype)
-__global__ __launch_bounds__(256) void proto_head_kernel(const float* __restrict__ feat_shot, const float* __restrict__ feat_query,
+template <int NT>
+__global__ __launch_bounds__(NT) void proto_head_kernel(const float* __restrict__ feat_shot, const float* __restrict__ feat_query,
                                                          int way, int shot, int Q, int D, float temp, int method,
                                                          float* __restrict__ logits, float* __restrict__ acc, float* __restrict__ loss) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(256) void proto_head_kernel(const float* __restrict
   const float* fq = feat_query + (size_t)e * Q * D;
 
   // prototypes: mean over shots (meta_baseline.py:37 / :42)
-  for (int i = t; i < way * D; i += 256) {
+  constexpr int NWV = NT / 64;
+  for (int i = t; i < way * D; i += NT) {
     const int c = i / D, d = i - c * D;
     float s = 0.f;
     for (int k = 0; k < shot; ++k) s += fs[((size_t)c * shot + k) * D + d];
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void proto_head_kernel(const float* __restrict
   }
   __syncthreads();
   if (method == 0) {                                          // F.normalize(proto), eps 1e-12 (:38)
-    for (int c = wave; c < way; c += 4) {
+    for (int c = wave; c < way; c += NWV) {
       float ss = 0.f;
       for (int d = lane; d < D; d += 64) ss += proto[c * D + d] * proto[c * D + d];
       const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void proto_head_kernel(const float* __restrict
     __syncthreads();
   }
   const int per = Q / way;                                    // queries per class (make_nk_label, few_shot.py:13-16)
-  for (int q = wave; q < Q; q += 4) {
+  for (int q = wave; q < Q; q += NWV) {
     const float* x = fq + (size_t)q * D;
     float inv = 1.0f;
     if (method == 0) {
@@ -114,9 +116,10 @@ int launch_proto_head(const float* feat_shot, const float* feat_query, int E, in
   if (E <= 0) return 0;
   const size_t lds = ((size_t)way * D + (size_t)Q * 2) * sizeof(float);
   if (lds > 160 * 1024 || way < 1 || shot < 1 || Q < 1) return (int)hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute((const void*)proto_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // few episodes per launch -> latency bound: 16 waves per episode (one wave per query at a time)
+  hipError_t e = hipFuncSetAttribute((const void*)proto_head_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(proto_head_kernel, dim3(E), dim3(256), lds, s, feat_shot, feat_query, way, shot, Q, D, temp, method,
+  hipLaunchKernelGGL(proto_head_kernel<1024>, dim3(E), dim3(1024), lds, s, feat_shot, feat_query, way, shot, Q, D, temp, method,
                      logits, acc, loss);
   return (int)hipGetLastError();
 }
