@@ -111,8 +111,13 @@ class _BN:
         var_b = x.var(dim=(0, 2, 3), unbiased=False)
         if self.stats_out is not None:
             n = x.numel() // x.shape[1]
-            self.stats_out[name + '.running_mean'] = mean.clone()
-            self.stats_out[name + '.running_var'] = var_b * (n / (n - 1))
+            if self.mode == 'train':      # nn.BatchNorm2d(momentum=0.1) running-stat update (visformer.py:121)
+                m = 0.1
+                self.stats_out[name + '.running_mean'] = ((1 - m) * self.sd[name + '.running_mean'] + m * mean).detach()
+                self.stats_out[name + '.running_var'] = ((1 - m) * self.sd[name + '.running_var'] + m * var_b * (n / (n - 1))).detach()
+            else:
+                self.stats_out[name + '.running_mean'] = mean.detach().clone()
+                self.stats_out[name + '.running_var'] = (var_b * (n / (n - 1))).detach()
         return F.batch_norm(x, None, None, w, b, True, 0.0, self.eps)
 
 
@@ -155,33 +160,56 @@ def stem(sd, x, bn, p='stem.'):
     return F.max_pool2d(out, 2)
 
 
+def drop_path(x, rate, mode, masks_in=None, masks_out=None):
+    """visformer.py:89-96."""
+    if rate == 0.0 or mode != 'train':
+        return x
+    keep = 1.0 - rate
+    if masks_in is not None:
+        m = masks_in.pop(0).to(x.dtype).reshape(-1, 1, 1, 1)
+    else:
+        m = (keep + torch.rand((x.shape[0], 1, 1, 1), dtype=x.dtype)).floor_()
+    if masks_out is not None:
+        masks_out.append(m.reshape(-1).clone())
+    return x.div(keep) * m
+
+
 def visformer_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, cfg: VisformerCfg,
                       prefix: str = '', mode: str = 'eval',
                       stats_out: Optional[dict] = None, taps: Optional[dict] = None,
-                      return_map: bool = False):
+                      return_map: bool = False, drop_path_rate: float = 0.0,
+                      droppath_masks: Optional[list] = None, masks_out: Optional[list] = None):
     """Visformer.forward, visformer.py:424-462 (eval: DropPath is identity, all Dropout p=0).
 
     sd      state dict (reference key names, optionally under `prefix`)
     x       [B,3,img,img] float32
-    mode    'eval' (running stats) or 'calibrate' (batch stats; fills stats_out)
+    mode    'eval' (running stats), 'calibrate' (batch stats; fills stats_out with the batch statistics) or
+            'train' (batch stats, stats_out receives the momentum-0.1 running-stat update, DropPath active)
     taps    optional dict receiving named intermediates (NCHW) for golden checks
+    drop_path_rate / droppath_masks   train mode only: per-block rates linspace(0, rate, depth) (visformer.py:312);
+            masks are drawn from the global torch RNG in the reference's call order (floor(keep + U[0,1)), :92-96)
+            unless a list of [B] 0/1 tensors is supplied (one per DropPath call, in forward order).
     """
     if prefix:
         sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
     assert x.shape[-1] == cfg.img_size and x.shape[-2] == cfg.img_size, \
         f"Input image size ({x.shape[-2]}*{x.shape[-1]}) does not match model ({cfg.img_size}*{cfg.img_size})."
-    bn = _BN(sd, cfg.bn_eps, mode, stats_out)
+    bn = _BN(sd, cfg.bn_eps, 'eval' if mode == 'eval' else mode, stats_out)
 
     def tap(name, t):
         if taps is not None:
             taps[name] = t
 
+    dpr = torch.linspace(0, drop_path_rate, sum(cfg.depth)).tolist()  # :312
+    masks_in = list(droppath_masks) if droppath_masks is not None else None
+    blk = 0
     x = stem(sd, x, bn)                                              # :425-426
     tap('stem', x)
     x = x + sd['pos_embed1']                                         # :431
     for i in range(cfg.depth[0]):                                    # :433-434 ; Block.forward :259-263
         p = f'stage1.{i}.'
-        x = x + mlp(sd, bn(x, p + 'norm2.bn'), p + 'mlp.', cfg.group)
+        x = x + drop_path(mlp(sd, bn(x, p + 'norm2.bn'), p + 'mlp.', cfg.group), dpr[blk], mode, masks_in, masks_out)
+        blk += 1
         tap(p[:-1], x)
     for s in (2, 3):
         pe = f'patch_embed{s}.'
@@ -193,8 +221,9 @@ def visformer_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, cfg: Visform
             p = f'stage{s}.{i}.'
             a = attention(sd, bn(x, p + 'norm1.bn'), p + 'attn.', cfg.num_heads, taps)
             tap(p + 'attn', a)
-            x = x + a                                                # :261
-            x = x + mlp(sd, bn(x, p + 'norm2.bn'), p + 'mlp.', cfg.group)   # :262
+            x = x + drop_path(a, dpr[blk], mode, masks_in, masks_out)                                  # :261
+            x = x + drop_path(mlp(sd, bn(x, p + 'norm2.bn'), p + 'mlp.', cfg.group), dpr[blk], mode, masks_in, masks_out)   # :262
+            blk += 1
             tap(p[:-1], x)
     x = bn(x, 'norm.bn')                                             # :455
     tap('norm', x)
@@ -246,16 +275,19 @@ def meta_baseline_head(feat_shot, feat_query, method='cos', temp=10.0):
     return compute_logits(feat_query, proto, metric=metric, temp=temp)
 
 
-def meta_baseline_forward(sd, x_shot, x_query, cfg: VisformerCfg, method='cos'):
-    """MetaBaseline.forward, meta_baseline.py:24-47.  `sd` holds 'temp' and 'encoder.*'."""
+def meta_baseline_forward(sd, x_shot, x_query, cfg: VisformerCfg, method='cos', mode='eval', **fwd_kwargs):
+    """MetaBaseline.forward, meta_baseline.py:24-47.  `sd` holds 'temp' and 'encoder.*'.
+    mode='train' keeps the autograd graph (reference gradients = torch.autograd of this restatement)."""
     shot_shape, query_shape = x_shot.shape[:-3], x_query.shape[:-3]
     img_shape = x_shot.shape[-3:]
     xs = x_shot.reshape(-1, *img_shape)
     xq = x_query.reshape(-1, *img_shape)
-    with torch.no_grad():
-        tot = visformer_forward(sd, torch.cat([xs, xq], dim=0), cfg, prefix='encoder.')
-    fs, fq = tot[:len(xs)], tot[-len(xq):]
-    fs = fs.reshape(*shot_shape, -1)
-    fq = fq.reshape(*query_shape, -1)
-    temp = float(sd['temp']) if 'temp' in sd else 10.0
-    return meta_baseline_head(fs, fq, method=method, temp=temp)
+    with torch.set_grad_enabled(mode == 'train'):
+        tot = visformer_forward(sd, torch.cat([xs, xq], dim=0), cfg, prefix='encoder.', mode=mode, **fwd_kwargs)
+        fs, fq = tot[:len(xs)], tot[-len(xq):]
+        fs = fs.reshape(*shot_shape, -1)
+        fq = fq.reshape(*query_shape, -1)
+        temp = sd['temp'] if 'temp' in sd else 10.0
+        if mode != 'train':
+            temp = float(temp)
+        return meta_baseline_head(fs, fq, method=method, temp=temp)

@@ -220,3 +220,42 @@ def test_deit_oracle_matches_reference(golden_dir, name, B):
         assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
     with pytest.raises(AssertionError):
         do.deit_forward(sd, torch.zeros(1, 3, cfg.img_size + 4, cfg.img_size + 4), cfg, prefix='encoder.')
+
+
+# ----------------------------------------------------------------------------- train mode (SUN-M step)
+def test_oracle_train_step_matches_reference(golden_dir):
+    """Train-mode forward (batch-stat BN, DropPath 0.5 from the torch RNG stream) + autograd of the oracle vs the
+    reference's own loss.backward() on the tiny Visformer (meta_tuning_sun_m/train_meta.py:161-174)."""
+    z = np.load(os.path.join(golden_dir, 'tiny_train_step.npz'))
+    shapes = vo.state_dict_shapes(TINY_CFG, prefix='encoder.')
+    shapes['temp'] = ()
+    sd = synthetic.procedural_state_dict(shapes)
+    cal = vo.calibrate_bn(sd, synthetic.synthetic_episodes(7, 1, 5, 1, 3), TINY_CFG, prefix='encoder.')
+    params = {k: v.clone().requires_grad_(True) for k, v in cal.items()
+              if v.dtype.is_floating_point and not k.endswith(('running_mean', 'running_var'))}
+    full = dict(cal)
+    full.update(params)
+    x = synthetic.synthetic_episodes(33, 2, 3, 2, 2)
+    xs, xq = fo.split_shot_query(x.numpy(), 3, 2, 2, 2)
+    label = torch.arange(3).repeat_interleave(2).repeat(2)
+    stats = {}
+    torch.manual_seed(77)
+    logits = vo.meta_baseline_forward(full, torch.from_numpy(xs), torch.from_numpy(xq), TINY_CFG, mode='train',
+                                      drop_path_rate=0.5, stats_out=stats).view(-1, 3)
+    loss = torch.nn.functional.cross_entropy(logits, label)
+    loss.backward()
+    assert abs(float(loss) - float(z['loss'])) <= 1e-5
+    assert np.abs(logits.detach().numpy() - z['logits']).max() <= 2e-5
+    n = 0
+    for k in z.files:
+        if k.startswith('grad.'):
+            name = k[5:]
+            g = params[name].grad.flatten()
+            got = g[::max(1, g.numel() // 256)][:256].numpy()
+            scale = float(z['gradnorm.' + name])      # (a conv bias in front of a train-mode BN has zero gradient: pure noise)
+            assert np.abs(got - z[k]).max() <= 2e-4 * scale + 1e-6, name
+            assert abs(float(g.norm()) - scale) <= 2e-4 * scale + 1e-6, name
+            n += 1
+        elif k.startswith('bn.'):
+            np.testing.assert_allclose(stats[k[3:]].numpy(), z[k], rtol=2e-4, atol=2e-5, err_msg=k)
+    assert n == 60
