@@ -257,5 +257,5 @@ def test_oracle_train_step_matches_reference(golden_dir):
             assert abs(float(g.norm()) - scale) <= 2e-4 * scale + 1e-6, name
             n += 1
         elif k.startswith('bn.'):
-            np.testing.assert_allclose(stats[k[3:]].numpy(), z[k], rtol=2e-4, atol=2e-5, err_msg=k)
+            np.testing.assert_allclose(stats[k[len('bn.encoder.'):]].numpy(), z[k], rtol=2e-4, atol=2e-5, err_msg=k)
     assert n == 60
