@@ -36,6 +36,10 @@ class ProfRec(C.Structure):
                 ('ms', C.c_double)]
 
 
+class Param(C.Structure):
+    _fields_ = [('name', C.c_char_p), ('data', C.c_void_p), ('grad', C.c_void_p), ('numel', C.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/fsvit.h declares
 _vp, _fp, _i, _f, _sz = C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -65,6 +69,14 @@ SIGNATURES = {
     'fsvit_im2col27': (_i, [_fp, _vp, _i, _i, _i, _i, _vp]),
     'fsvit_maxpool2_pos': (_i, [_vp, _fp, _vp, _i, _i, _i, _i, _i, _vp]),
     'fsvit_pool_affine': (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    'fsvit_visformer_trainer_create': (_i, [C.POINTER(VisformerCfg), _i, C.POINTER(_vp)]),
+    'fsvit_visformer_trainer_destroy': (None, [_vp]),
+    'fsvit_visformer_trainer_workspace_bytes': (_sz, [_vp, C.POINTER(Param), _i, _i, _f]),
+    'fsvit_visformer_train_forward': (_i, [_vp, C.POINTER(Param), _i, _fp, _i, _i, _i, _f, _fp, _fp, _vp, _sz, _vp]),
+    'fsvit_visformer_train_backward': (_i, [_vp, C.POINTER(Param), _i, _fp, _vp]),
+    'fsvit_proto_head_backward': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _fp, _fp, _vp]),
+    'fsvit_sgd_step': (_i, [_fp, _fp, _fp, _sz, _f, _f, _f, _i, _vp]),
+    'fsvit_attention_backward': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
 }
 
 _lib = None

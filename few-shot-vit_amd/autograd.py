@@ -1,0 +1,49 @@
+"""torch.autograd bridges of the meta-tuning step (meta_tuning_sun_m/train_meta.py:161-177).
+
+`loss.backward()` reaches the HIP trainer through two Functions: the train-mode encoder
+(fsvit_visformer_train_forward / _backward) and the cosine prototype head
+(fsvit_proto_head / fsvit_proto_head_backward).  Cross-entropy stays in the caller, as in the
+reference loop.  Both Functions only move device pointers; there is no torch arithmetic fallback.
+"""
+import torch
+
+from .engine import ops
+
+
+class VisformerTrainFn(torch.autograd.Function):
+    """feat = encoder(x) in train mode.  `params` are passed as inputs so autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, x, trainer, names, buffers, drop_path_rate, masks, *params):
+        tensors = dict(zip(names, params))
+        tensors.update(buffers)
+        feat = trainer.forward(tensors, x, drop_path_rate, masks)
+        ctx.trainer, ctx.names, ctx.buffers = trainer, names, buffers
+        ctx.save_for_backward(*params)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        params = ctx.saved_tensors
+        tensors = dict(zip(ctx.names, params))
+        grads = {k: torch.empty_like(v) for k, v in tensors.items()}
+        tensors.update(ctx.buffers)
+        ctx.trainer.backward(tensors, grads, dfeat)
+        return (None, None, None, None, None, None) + tuple(grads[k] for k in ctx.names)
+
+
+class ProtoHeadFn(torch.autograd.Function):
+    """logits = temp * cos(query, mean_shot(prototypes)) (meta_baseline.py:33-47, method 'cos')."""
+
+    @staticmethod
+    def forward(ctx, feat_shot, feat_query, temp):
+        feat_shot, feat_query = feat_shot.contiguous(), feat_query.contiguous()
+        logits, _, _ = ops.proto_head(feat_shot, feat_query, float(temp), 'cos')
+        ctx.save_for_backward(feat_shot, feat_query, temp)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        feat_shot, feat_query, temp = ctx.saved_tensors
+        ds, dq, dt = ops.proto_head_backward(feat_shot, feat_query, dlogits, float(temp))
+        return ds, dq, dt.reshape(temp.shape)

@@ -49,6 +49,10 @@ struct ConvGemmParams {
   // Row remap of the OUTPUT (and residual): row m of image b = m / (OH*OW) goes to row b * y_rpi + y_row0 + m % (OH*OW).
   // y_rpi == 0: dense rows.  Used to write the ViT patch tokens behind each image's cls token (deit.py:200-201).
   int y_rpi, y_row0;
+  // Split-K wgrad (training): weight row n of group g starts at w + g*w_gstride + n*w_rstride elements (both 0:
+  // the packed default g*N*Kw + n*Kw), and the output can be stored as fp32 whatever the storage dtype.
+  long w_gstride, w_rstride;
+  int out_f32;
 };
 
 // dtype: 0 = f32 (exact fp32 MFMA), 1 = bf16.  Returns hipError_t as int.

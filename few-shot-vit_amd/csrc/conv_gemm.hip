@@ -190,7 +190,7 @@ static int launch_t(const ConvGemmParams& p, hipStream_t stream) {
 
 int launch_conv_gemm_v1(const ConvGemmParams& p, int dtype, hipStream_t stream) {
   if (p.M <= 0) return 0;
-  if (p.K2 > 0 || p.pool2 || p.y_rpi) return (int)hipErrorInvalidValue;   // tail operand / pooled epilogue exist in v2 only
+  if (p.K2 > 0 || p.pool2 || p.y_rpi || p.w_rstride || p.out_f32) return (int)hipErrorInvalidValue;   // tail operand / pooled epilogue exist in v2 only
   return dtype == 0 ? launch_t<float>(p, stream) : launch_t<bf16>(p, stream);
 }
 

@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
     const int mg = xcd + 8 * (j / tiles_n), nt = j % tiles_n;
     const int g = mg / tiles_m, mt = mg - g * tiles_m;
     Xg = reinterpret_cast<const T*>(p.x) + (size_t)g * p.Cin;
-    const T* Wg = reinterpret_cast<const T*>(p.w) + (size_t)g * p.N * p.Kw;
+    const long wrs = p.w_rstride ? p.w_rstride : (long)p.Kw;
+    const T* Wg = reinterpret_cast<const T*>(p.w) + (p.w_rstride ? (long)g * p.w_gstride : (long)g * p.N * p.Kw);
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       const int m = mt * BM + 32 * i + 8 * wave + srow;
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
     for (int jj = 0; jj < B_IT; ++jj) {
       const int n = nt * BN + 32 * jj + 8 * wave + srow;
       nok[jj] = n < p.N;
-      wrow[jj] = Wg + (size_t)(nok[jj] ? n : 0) * p.Kw + sc * EPC;
+      wrow[jj] = Wg + (long)(nok[jj] ? n : 0) * wrs + sc * EPC;
     }
   };
   auto issue = [&](int kt, int buf) {
@@ -312,7 +313,10 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
             }
           }
           v += rv[i][jn];
-          if (mk_[i] && nk_[jn] && (!p.pool2 || (lrow & 3) == 0)) store4<T>(Y + rowoff[i] + ncl[jn], v);
+          if (mk_[i] && nk_[jn] && (!p.pool2 || (lrow & 3) == 0)) {
+            if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + rowoff[i] + ncl[jn]) = v;
+            else store4<T>(Y + rowoff[i] + ncl[jn], v);
+          }
         }
       }
     };

@@ -30,6 +30,13 @@ static int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+int fsvit_set_error(int code, const char* fmt, ...) {      // shared with train_engine.hip
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
 static int hipfail(hipError_t e, const char* what) {
   return fail((int)e, "%s: %s", what, hipGetErrorString(e));
 }
@@ -399,6 +406,7 @@ ConvGemmParams conv_params(const Layer& L, const void* x, void* y, int B, int H,
   p.N = L.N; p.y_cstride = y_cstride; p.K = L.K; p.Kw = L.Kw; p.M = B * p.OH * p.OW;
   p.groups = L.groups; p.act = act; p.res_first = res_first; p.log2Cin = ilog2(Cin);
   p.x2 = nullptr; p.x2_cstride = 0; p.K2 = 0; p.pool2 = 0; p.y_rpi = 0; p.y_row0 = 0;
+  p.w_gstride = 0; p.w_rstride = 0; p.out_f32 = 0;
   return p;
 }
 

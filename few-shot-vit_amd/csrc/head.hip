@@ -8,6 +8,7 @@
 //    One workgroup per episode; wavefront reductions (DPP/shuffle) for norms and dots.
 #include "fsvit_common.h"
 #include "kernels.h"
+#include "train_kernels.h"
 
 namespace fsvit {
 
@@ -121,6 +122,91 @@ int launch_proto_head(const float* feat_shot, const float* feat_query, int E, in
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(proto_head_kernel<1024>, dim3(E), dim3(1024), lds, s, feat_shot, feat_query, way, shot, Q, D, temp, method,
                      logits, acc, loss);
+  return (int)hipGetLastError();
+}
+
+// Backward of the cosine head (meta_baseline.py:33-47 with method 'cos'): logits = temp * <q^, p^_c>, p_c = mean_s f_shot[c][s].
+// One workgroup per episode.  x^ = x / max(|x|, 1e-12):  dx = (dx^ - x^ <x^, dx^>) / |x|.
+__global__ __launch_bounds__(256) void proto_head_bwd_kernel(const float* __restrict__ feat_shot, const float* __restrict__ feat_query,
+                                                             const float* __restrict__ dlogits, int way, int shot, int Q, int D, float temp,
+                                                             float* __restrict__ dfeat_shot, float* __restrict__ dfeat_query, float* __restrict__ dtemp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* proto = reinterpret_cast<float*>(smem);            // [way][D] normalised prototypes
+  float* dproto = proto + (size_t)way * D;                    // [way][D] gradient w.r.t. the normalised prototypes
+  float* pinv = dproto + (size_t)way * D;                     // [way] 1 / |p_c|
+  float* qinv = pinv + way;                                   // [Q]   1 / |q|
+  float* red = qinv + Q;                                      // [4] per-wave partial of dtemp
+  const int e = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* fs = feat_shot + (size_t)e * way * shot * D;
+  const float* fq = feat_query + (size_t)e * Q * D;
+  const float* dl = dlogits + (size_t)e * Q * way;
+  for (int i = t; i < way * D; i += 256) {
+    const int c = i / D, d = i - c * D;
+    float s = 0.f;
+    for (int k = 0; k < shot; ++k) s += fs[((size_t)c * shot + k) * D + d];
+    proto[i] = s / (float)shot;
+  }
+  __syncthreads();
+  for (int c = wave; c < way; c += 4) {
+    float ss = 0.f;
+    for (int d = lane; d < D; d += 64) ss += proto[c * D + d] * proto[c * D + d];
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+    for (int d = lane; d < D; d += 64) proto[c * D + d] *= inv;
+    if (lane == 0) pinv[c] = inv;
+  }
+  __syncthreads();
+  // queries: dq^ = temp * sum_c dl[q][c] p^_c ; dq = (dq^ - q^ <q^, dq^>) / |q| ; dtemp += sum_c dl[q][c] <q^, p^_c>
+  float dt_acc = 0.f;
+  for (int q = wave; q < Q; q += 4) {
+    const float* x = fq + (size_t)q * D;
+    float ss = 0.f;
+    for (int d = lane; d < D; d += 64) ss += x[d] * x[d];
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+    if (lane == 0) qinv[q] = inv;
+    float dotqg = 0.f;
+    for (int c = 0; c < way; ++c) {
+      float s = 0.f;
+      for (int d = lane; d < D; d += 64) s += x[d] * inv * proto[c * D + d];
+      s = wave_sum(s);
+      dt_acc += dl[q * way + c] * s;
+      dotqg += temp * dl[q * way + c] * s;                    // <q^, dq^>
+    }
+    for (int d = lane; d < D; d += 64) {
+      float g = 0.f;
+      for (int c = 0; c < way; ++c) g += temp * dl[q * way + c] * proto[c * D + d];
+      dfeat_query[((size_t)e * Q + q) * D + d] = (g - x[d] * inv * dotqg) * inv;
+    }
+  }
+  if (lane == 0) red[wave] = dt_acc;
+  __syncthreads();
+  if (t == 0 && dtemp) dtemp[e] = red[0] + red[1] + red[2] + red[3];
+  // prototypes: dp^_c[d] = temp * sum_q dl[q][c] q^[d]
+  for (int i = t; i < way * D; i += 256) {
+    const int c = i / D, d = i - c * D;
+    float g = 0.f;
+    for (int q = 0; q < Q; ++q) g += dl[q * way + c] * fq[(size_t)q * D + d] * qinv[q];
+    dproto[i] = temp * g;
+  }
+  __syncthreads();
+  for (int c = wave; c < way; c += 4) {
+    float dot = 0.f;
+    for (int d = lane; d < D; d += 64) dot += proto[c * D + d] * dproto[c * D + d];
+    dot = wave_sum(dot);
+    for (int d = lane; d < D; d += 64) {
+      const float g = (dproto[c * D + d] - proto[c * D + d] * dot) * pinv[c] / (float)shot;
+      for (int k = 0; k < shot; ++k) dfeat_shot[(((size_t)e * way + c) * shot + k) * D + d] = g;
+    }
+  }
+}
+
+int launch_proto_head_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
+                          float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s) {
+  if (E <= 0) return 0;
+  const size_t lds = ((size_t)2 * way * D + way + Q + 4) * sizeof(float);
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute((const void*)proto_head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(proto_head_bwd_kernel, dim3(E), dim3(256), lds, s, feat_shot, feat_query, dlogits, way, shot, Q, D, temp, dfeat_shot, dfeat_query, dtemp);
   return (int)hipGetLastError();
 }
 

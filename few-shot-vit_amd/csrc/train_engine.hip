@@ -1,0 +1,657 @@
+// Visformer meta-tuning step (meta_tuning_sun_m/train_meta.py:161-177): train-mode forward
+// (batch-statistics BatchNorm with running-stat update, DropPath) with saved activations, and the full backward
+// to every parameter gradient.  GEMM-shaped work (forward convs, data gradients, split-K weight gradients) runs on
+// conv_gemm_v2; everything else is train_kernels.hip / attention_bwd.hip / head.hip.  This first version is
+// correctness-first: nothing is fused and BatchNorm is never folded (its statistics depend on the batch).
+#include "../../include/fsvit.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "train_kernels.h"
+
+using namespace fsvit;
+
+extern "C" const char* fsvit_last_error(void);
+int fsvit_set_error(int code, const char* fmt, ...);      // engine.hip
+
+#define T_TRY(expr)                                                                     \
+  do {                                                                                  \
+    int _rc = (expr);                                                                   \
+    if (_rc != 0) return _rc > 0 ? fsvit_set_error(_rc, "%s: %s", #expr, hipGetErrorString((hipError_t)_rc)) : _rc; \
+  } while (0)
+
+// launches are skipped in the sizing pass (dry arenas hand out fake addresses)
+#define T_RUN(expr)                                                                     \
+  do {                                                                                  \
+    if (!t->save.dry) {                                                                 \
+      int _rc = (expr);                                                                 \
+      if (_rc != 0) return _rc > 0 ? fsvit_set_error(_rc, "%s: %s", #expr, hipGetErrorString((hipError_t)_rc)) : _rc; \
+    }                                                                                   \
+  } while (0)
+
+namespace {
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct Arena {
+  unsigned char* base = nullptr;
+  size_t size = 0, off = 0, peak = 0;
+  bool dry = false;                       // dry run: only measure
+  void* take(size_t bytes) {
+    size_t o = off;
+    off += align256(bytes);
+    if (off > peak) peak = off;
+    if (dry) return (void*)(uintptr_t)(o + 256);
+    return off <= size ? base + o : nullptr;
+  }
+};
+
+struct ConvSpec {                         // one nn.Conv2d of the model (PyTorch layout weight [O][Ig][KH][KW])
+  std::string wname;
+  int O = 0, Ig = 0, KH = 1, KW = 1, stride = 1, pad = 0, groups = 1;
+  int hd_rows = 1, hdp_rows = 1, hd_cols = 1, hdp_cols = 1;      // head-dim padding (qkv rows / proj columns)
+  bool via_patches = false;               // stem conv1 / downsample: input is the 32-wide im2col row
+  int rows_fwd() const { return (O / groups) / hd_rows * hdp_rows; }                         // padded N per group
+  int kreal() const { return KH * KW * Ig; }
+  int kpad_cols() const { return via_patches ? 32 : kreal() / hd_cols * hdp_cols; }         // padded K (elements)
+};
+
+struct BnSave { void* z; float *mean, *invstd, *sa, *sb; int M, C; };
+
+}  // namespace
+
+struct fsvit_visformer_trainer {
+  fsvit_visformer_cfg cfg;
+  int dtype = 0, es = 4;
+  int C0, C1, C2, C3, H0, H1, H2, H3, hid1, hid2, hid3, hd2, hdp2, hd3, hdp3, Cg;
+  // ---- per-call state
+  std::map<std::string, const fsvit_param*> P;
+  hipStream_t st = nullptr;
+  Arena save, tmp;
+  int B = 0;
+  float dp_rate = 0.f;
+  const float* masks = nullptr;           // [n_droppath_calls][B] 0/1
+  // saved forward state (pointers into `save`)
+  struct Stem { void *patches, *z1, *a1, *zd, *ad, *z2, *a2, *z3, *a3; unsigned char* arg; BnSave b1, bd, b2, b3; void* x1; } stem;
+  struct S1 { void *x, *xn, *z1, *h1, *z2, *h2; BnSave bn; const float* scale; void* out; };
+  struct SA { void *x, *xn1, *qkv, *ctx, *xa, *xn2, *z1, *h; BnSave bn1, bn2; const float *s1, *s2; void* out; };
+  struct PE { void *xin, *z; BnSave bn; void* out; };
+  std::vector<S1> s1;
+  std::vector<SA> s2, s3;
+  PE pe2, pe3;
+  BnSave bnf;
+  void* xnf = nullptr;
+  float* scales = nullptr;                // [n_calls][B] = mask / keep
+};
+
+namespace {
+
+typedef fsvit_visformer_trainer TR;
+
+const fsvit_param* getp(TR* t, const std::string& name) {
+  auto it = t->P.find(name);
+  if (it == t->P.end()) { fsvit_set_error(FSVIT_ERR_KEY, "missing parameter: %s", name.c_str()); return nullptr; }
+  return it->second;
+}
+
+ConvGemmParams gemm_params(const void* x, const void* w, void* y, int B, int H, int W, int Cin, int x_cstride, int KH, int KW, int stride, int pad,
+                           int N, int y_cstride, int K, int Kw, int groups) {
+  ConvGemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.w = w; p.y = y;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.x_cstride = x_cstride;
+  p.OH = (H + 2 * pad - KH) / stride + 1; p.OW = (W + 2 * pad - KW) / stride + 1;
+  p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+  p.N = N; p.y_cstride = y_cstride; p.K = K; p.Kw = Kw; p.M = B * p.OH * p.OW;
+  p.groups = groups; p.act = ACT_NONE; p.log2Cin = ilog2(Cin);
+  return p;
+}
+
+// ---------------------------------------------------------------- conv forward: z = conv(x) (+ bias)
+int conv_fwd(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, void* z, const float* bias) {
+  const fsvit_param* w = getp(t, c.wname);
+  if (!w) return FSVIT_ERR_KEY;
+  const int bke = 128 / t->es, Ng = c.rows_fwd(), K = c.kpad_cols(), Kw = round_up(K, bke);
+  void* pk = t->tmp.take((size_t)c.groups * Ng * Kw * t->es);
+  if (!pk) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (weights)");
+  T_RUN(launch_pack_weight(w->data, pk, c.O, c.Ig, c.KH, c.KW, c.groups, 0, Ng, Kw, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols, t->dtype, t->st));
+  ConvGemmParams p;
+  if (c.via_patches) p = gemm_params(x, pk, z, B, H, W, 32, 32, 1, 1, 1, 0, Ng, Ng, 32, Kw, 1);
+  else p = gemm_params(x, pk, z, B, H, W, K / (c.KH * c.KW), c.groups * (K / (c.KH * c.KW)), c.KH, c.KW, c.stride, c.pad, Ng, c.groups * Ng, K, Kw, c.groups);
+  p.bias = bias;
+  T_RUN(launch_conv_gemm(p, t->dtype, t->st));
+  return 0;
+}
+
+// ---------------------------------------------------------------- data gradient: dx = conv^T(dz)   (stride-1 convs and 1x1)
+int conv_bwd_data(TR* t, const ConvSpec& c, const void* dz, int B, int OH, int OW, void* dx) {
+  const fsvit_param* w = getp(t, c.wname);
+  if (!w) return FSVIT_ERR_KEY;
+  const int bke = 128 / t->es;
+  const int Ng_pad = c.rows_fwd();                        // dz channels per group (padded)
+  const int Ig_pad = c.Ig / c.hd_cols * c.hdp_cols;       // dx channels per group (padded for proj's ctx input)
+  const int K = c.KH * c.KW * Ng_pad, Kw = round_up(K, bke);
+  void* pk = t->tmp.take((size_t)c.groups * Ig_pad * Kw * t->es);
+  if (!pk) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (dgrad weights)");
+  // rows = input channels (padded like the forward K columns), K = output channels (padded like the forward rows)
+  T_RUN(launch_pack_weight(w->data, pk, c.O, c.Ig, c.KH, c.KW, c.groups, 1, Ig_pad, Kw, c.hd_cols, c.hdp_cols, c.hd_rows, c.hdp_rows, t->dtype, t->st));
+  ConvGemmParams p = gemm_params(dz, pk, dx, B, OH, OW, Ng_pad, c.groups * Ng_pad, c.KH, c.KW, 1, c.pad, Ig_pad, c.groups * Ig_pad, K, Kw, c.groups);
+  T_RUN(launch_conv_gemm(p, t->dtype, t->st));
+  return 0;
+}
+
+// ---------------------------------------------------------------- weight gradient: dW = sum_m dz[m] (x) xcol[m]   (split-K GEMM over transposed operands)
+int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, const void* dz) {
+  const fsvit_param* w = getp(t, c.wname);
+  if (!w) return FSVIT_ERR_KEY;
+  if (!w->grad) return 0;
+  const int OH = c.via_patches ? H : (H + 2 * c.pad - c.KH) / c.stride + 1, OW = c.via_patches ? W : (W + 2 * c.pad - c.KW) / c.stride + 1;
+  const int M = B * OH * OW;
+  int splits = (M + 16383) / 16384;
+  if (splits > 64) splits = 64;
+  const int Ks = round_up((M + splits - 1) / splits, 64), Mpad = splits * Ks;
+  const int Ng_pad = c.rows_fwd(), Kc_pad = round_up(c.kpad_cols(), 4);
+  const int ldz = c.groups * Ng_pad;
+  const int Cin_tot = c.via_patches ? 32 : c.groups * (c.kpad_cols() / (c.KH * c.KW));
+  const size_t tmp_mark = t->tmp.off;
+  void* dzt = t->tmp.take((size_t)Ng_pad * Mpad * t->es);
+  void* xct = t->tmp.take((size_t)Kc_pad * Mpad * t->es);
+  float* ysp = (float*)t->tmp.take((size_t)round_up(Ng_pad, 4) * splits * Kc_pad * 4);
+  if (!dzt || !xct || !ysp) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (wgrad)");
+  for (int g = 0; g < c.groups; ++g) {
+    T_RUN(launch_transpose_cols(dz, dzt, M, ldz, g * Ng_pad, Ng_pad, Mpad, t->dtype, t->st));
+    if (c.via_patches) T_RUN(launch_transpose_cols(x, xct, M, 32, 0, 32, Mpad, t->dtype, t->st));
+    else {
+      const int Cg = c.kpad_cols() / (c.KH * c.KW);
+      T_RUN(launch_im2col_t(x, xct, B, H, W, Cin_tot, g * Cg, Cg, c.KH, c.KW, c.stride, c.pad, OH, OW, Mpad, t->dtype, t->st));
+    }
+    // Y[n][s*Kc_pad + k] = sum_{m in split s} dzt[n][m] * xct[k][m]
+    ConvGemmParams p = gemm_params(dzt, xct, ysp, 1, Ng_pad, 1, Ks, Mpad, 1, 1, 1, 0, Kc_pad, splits * Kc_pad, Ks, Ks, splits);
+    p.w_gstride = Ks; p.w_rstride = Mpad; p.out_f32 = 1;
+    T_RUN(launch_conv_gemm(p, t->dtype, t->st));
+    const int KHf = c.via_patches ? 3 : c.KH, KWf = c.via_patches ? 3 : c.KW;
+    T_RUN(launch_wgrad_finalize(ysp, w->grad, c.O / c.groups, c.Ig, KHf, KWf, g, splits, Kc_pad, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols, t->st));
+  }
+  t->tmp.off = tmp_mark;
+  return 0;
+}
+
+// ---------------------------------------------------------------- BatchNorm (train)
+int bn_fwd(TR* t, const std::string& name, const void* z, int M, int C, int act, const void* res, void* y, BnSave* sv) {
+  const fsvit_param *g = getp(t, name + ".weight"), *b = getp(t, name + ".bias"), *rm = getp(t, name + ".running_mean"), *rv = getp(t, name + ".running_var");
+  if (!g || !b || !rm || !rv) return FSVIT_ERR_KEY;
+  float* stats = (float*)t->save.take((size_t)4 * C * 4);
+  float* partial = (float*)t->tmp.take((size_t)bn_reduce_blocks(M) * 2 * C * 4);
+  if (!stats || !partial) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (bn)");
+  sv->z = const_cast<void*>(z); sv->M = M; sv->C = C;
+  sv->mean = stats; sv->invstd = stats + C; sv->sa = stats + 2 * C; sv->sb = stats + 3 * C;
+  T_RUN(launch_bn_reduce(z, nullptr, nullptr, nullptr, partial, M, C, 0, t->dtype, t->st));
+  T_RUN(launch_bn_fwd_finalize(partial, M, C, t->cfg.bn_eps, 0.1f, g->data, b->data, rm->data, rv->data, sv->mean, sv->invstd, sv->sa, sv->sb, t->st));
+  T_RUN(launch_bn_apply(z, sv->sa, sv->sb, res, y, (size_t)M, C, act, t->dtype, t->st));
+  return 0;
+}
+
+// dy: gradient w.r.t. the BN output (after undoing the activation) -> dz; writes dgamma / dbeta
+int bn_bwd(TR* t, const std::string& name, const BnSave& sv, const void* dy, void* dz) {
+  const fsvit_param *g = getp(t, name + ".weight"), *b = getp(t, name + ".bias");
+  if (!g || !b) return FSVIT_ERR_KEY;
+  const size_t mark = t->tmp.off;
+  float* partial = (float*)t->tmp.take((size_t)bn_reduce_blocks(sv.M) * 2 * sv.C * 4);
+  float* coef = (float*)t->tmp.take((size_t)5 * sv.C * 4);
+  if (!partial || !coef) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (bn bwd)");
+  float* dgamma = g->grad ? g->grad : coef + 3 * sv.C;
+  float* dbeta = b->grad ? b->grad : coef + 4 * sv.C;
+  T_RUN(launch_bn_reduce(dy, sv.z, sv.mean, sv.invstd, partial, sv.M, sv.C, 1, t->dtype, t->st));
+  T_RUN(launch_bn_bwd_finalize(partial, sv.M, sv.C, g->data, sv.invstd, dgamma, dbeta, coef, coef + sv.C, coef + 2 * sv.C, t->st));
+  T_RUN(launch_bn_bwd_apply(dy, sv.z, sv.mean, sv.invstd, coef, coef + sv.C, coef + 2 * sv.C, dz, (size_t)sv.M, sv.C, t->dtype, t->st));
+  t->tmp.off = mark;
+  return 0;
+}
+
+void* take_act(TR* t, size_t elems) { return t->save.take(elems * t->es); }
+void* take_tmp(TR* t, size_t elems) { return t->tmp.take(elems * t->es); }
+#define NEED(ptr) do { if (!(ptr)) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small"); } while (0)
+
+const float* dp_scale(TR* t, int call, int block_index, int nblocks) {
+  // per-block rates linspace(0, rate, depth) (visformer.py:312); rate 0 -> plain residual
+  const float r = nblocks > 1 ? t->dp_rate * (float)block_index / (float)(nblocks - 1) : 0.f;
+  if (r == 0.f || !t->scales) return nullptr;
+  return t->scales + (size_t)call * t->B;
+}
+
+// ================================================================ specs
+struct Specs {
+  ConvSpec conv1, down, conv2, conv3, pe2, pe3;
+  std::vector<ConvSpec> s1c1, s1c2, s1c3;
+  struct A { ConvSpec qkv, proj, fc1, fc2; };
+  std::vector<A> s2, s3;
+};
+
+Specs make_specs(const TR* t) {
+  Specs s;
+  auto mk = [](std::string n, int O, int Ig, int k, int stride, int pad, int groups) { ConvSpec c; c.wname = n; c.O = O; c.Ig = Ig; c.KH = c.KW = k; c.stride = stride; c.pad = pad; c.groups = groups; return c; };
+  s.conv1 = mk("stem.conv1.weight", t->C0, 3, 3, 2, 1, 1); s.conv1.via_patches = true;
+  s.down = mk("stem.downsample.0.weight", t->C1, 3, 3, 2, 1, 1); s.down.via_patches = true;
+  s.conv2 = mk("stem.conv2.weight", t->C1, t->C0, 3, 1, 1, 1);
+  s.conv3 = mk("stem.conv3.weight", t->C1, t->C1, 3, 1, 1, 1);
+  for (int i = 0; i < t->cfg.depth[0]; ++i) {
+    const std::string p = "stage1." + std::to_string(i) + ".mlp.";
+    s.s1c1.push_back(mk(p + "conv1.weight", t->hid1, t->C1, 1, 1, 0, 1));
+    s.s1c2.push_back(mk(p + "conv2.weight", t->hid1, t->Cg, 3, 1, 1, t->cfg.group));
+    s.s1c3.push_back(mk(p + "conv3.weight", t->C1, t->hid1, 1, 1, 0, 1));
+  }
+  s.pe2 = mk("patch_embed2.proj.weight", t->C2, t->C1, 2, 2, 0, 1);
+  s.pe3 = mk("patch_embed3.proj.weight", t->C3, t->C2, 2, 2, 0, 1);
+  for (int st = 2; st <= 3; ++st) {
+    const int C = st == 2 ? t->C2 : t->C3, hid = st == 2 ? t->hid2 : t->hid3, hd = st == 2 ? t->hd2 : t->hd3, hdp = st == 2 ? t->hdp2 : t->hdp3;
+    const int heads = t->cfg.num_heads;
+    for (int i = 0; i < t->cfg.depth[st - 1]; ++i) {
+      const std::string p = "stage" + std::to_string(st) + "." + std::to_string(i) + ".";
+      Specs::A a;
+      a.qkv = mk(p + "attn.qkv.weight", 3 * heads * hd, C, 1, 1, 0, 1); a.qkv.hd_rows = hd; a.qkv.hdp_rows = hdp;
+      a.proj = mk(p + "attn.proj.weight", C, heads * hd, 1, 1, 0, 1); a.proj.hd_cols = hd; a.proj.hdp_cols = hdp;
+      a.fc1 = mk(p + "mlp.conv1.weight", hid, C, 1, 1, 0, 1);
+      a.fc2 = mk(p + "mlp.conv3.weight", C, hid, 1, 1, 0, 1);
+      (st == 2 ? s.s2 : s.s3).push_back(a);
+    }
+  }
+  return s;
+}
+
+// ================================================================ forward
+int train_forward_impl(TR* t, const float* x, float* feat) {
+  const Specs sp = make_specs(t);
+  const int B = t->B, dt = t->dtype;
+  hipStream_t st = t->st;
+  const int img = t->cfg.img_size, H0 = t->H0, H1 = t->H1;
+  const size_t M0 = (size_t)B * H0 * H0, M1 = (size_t)B * H1 * H1;
+  const int nblk = t->cfg.depth[0] + t->cfg.depth[1] + t->cfg.depth[2];
+  int dp_call = 0, blk = 0;
+
+  // ---- stem (visformer.py:219-239)
+  auto& S = t->stem;
+  NEED(S.patches = take_act(t, M0 * 32)); NEED(S.z1 = take_act(t, M0 * t->C0)); NEED(S.a1 = take_act(t, M0 * t->C0));
+  NEED(S.zd = take_act(t, M0 * t->C1)); NEED(S.ad = take_act(t, M0 * t->C1)); NEED(S.z2 = take_act(t, M0 * t->C1)); NEED(S.a2 = take_act(t, M0 * t->C1));
+  NEED(S.z3 = take_act(t, M0 * t->C1)); NEED(S.a3 = take_act(t, M0 * t->C1)); NEED(S.arg = (unsigned char*)t->save.take(M1 * t->C1)); NEED(S.x1 = take_act(t, M1 * t->C1));
+  T_RUN(launch_im2col27(x, S.patches, B, img, img, H0, H0, dt, st));
+  T_TRY(conv_fwd(t, sp.conv1, S.patches, B, H0, H0, S.z1, nullptr));
+  T_TRY(bn_fwd(t, "stem.bn1", S.z1, (int)M0, t->C0, ACT_LRELU, nullptr, S.a1, &S.b1));
+  T_TRY(conv_fwd(t, sp.down, S.patches, B, H0, H0, S.zd, nullptr));
+  T_TRY(bn_fwd(t, "stem.downsample.1", S.zd, (int)M0, t->C1, ACT_NONE, nullptr, S.ad, &S.bd));
+  T_TRY(conv_fwd(t, sp.conv2, S.a1, B, H0, H0, S.z2, nullptr));
+  T_TRY(bn_fwd(t, "stem.bn2", S.z2, (int)M0, t->C1, ACT_LRELU, nullptr, S.a2, &S.b2));
+  T_TRY(conv_fwd(t, sp.conv3, S.a2, B, H0, H0, S.z3, nullptr));
+  T_TRY(bn_fwd(t, "stem.bn3", S.z3, (int)M0, t->C1, ACT_LRELU, S.ad, S.a3, &S.b3));
+  {
+    const fsvit_param* pos = getp(t, "pos_embed1");
+    if (!pos) return FSVIT_ERR_KEY;
+    // pos_embed is [1,C,H,W] in the checkpoint; transpose to [HW][C] in tmp
+    float* pt = (float*)t->tmp.take((size_t)H1 * H1 * t->C1 * 4);
+    NEED(pt);
+    T_RUN(launch_transpose_cols(pos->data, pt, t->C1, H1 * H1, 0, H1 * H1, t->C1, 0, st));   // in [C][HW] -> out [HW][C]
+    T_RUN(launch_maxpool2_idx(S.a3, pt, S.x1, S.arg, B, H1, H1, t->C1, dt, st));
+  }
+  void* xcur = S.x1;
+
+  // ---- stage 1 (Block with attn_disabled: x + DropPath(mlp(norm2(x))), visformer.py:259-263)
+  t->s1.resize(t->cfg.depth[0]);
+  for (int i = 0; i < t->cfg.depth[0]; ++i, ++blk) {
+    auto& b = t->s1[i];
+    const std::string p = "stage1." + std::to_string(i) + ".";
+    b.x = xcur;
+    NEED(b.xn = take_act(t, M1 * t->C1)); NEED(b.z1 = take_act(t, M1 * t->hid1)); NEED(b.h1 = take_act(t, M1 * t->hid1));
+    NEED(b.z2 = take_act(t, M1 * t->hid1)); NEED(b.h2 = take_act(t, M1 * t->hid1)); NEED(b.out = take_act(t, M1 * t->C1));
+    const size_t mark = t->tmp.off;
+    void* z3 = take_tmp(t, M1 * t->C1); NEED(z3);
+    T_TRY(bn_fwd(t, p + "norm2.bn", b.x, (int)M1, t->C1, ACT_NONE, nullptr, b.xn, &b.bn));
+    T_TRY(conv_fwd(t, sp.s1c1[i], b.xn, B, H1, H1, b.z1, nullptr));
+    T_RUN(launch_gelu_fwd(b.z1, b.h1, M1 * t->hid1, dt, st));
+    T_TRY(conv_fwd(t, sp.s1c2[i], b.h1, B, H1, H1, b.z2, nullptr));
+    T_RUN(launch_gelu_fwd(b.z2, b.h2, M1 * t->hid1, dt, st));
+    T_TRY(conv_fwd(t, sp.s1c3[i], b.h2, B, H1, H1, z3, nullptr));
+    b.scale = dp_scale(t, dp_call, blk, nblk);
+    if (t->dp_rate * blk > 0.f) ++dp_call;
+    T_RUN(launch_add_scaled(b.x, z3, b.scale, b.out, M1 * t->C1, (size_t)H1 * H1 * t->C1, dt, st));
+    t->tmp.off = mark;
+    xcur = b.out;
+  }
+
+  // ---- stages 2, 3
+  for (int sg = 2; sg <= 3; ++sg) {
+    const int Ci = sg == 2 ? t->C1 : t->C2, C = sg == 2 ? t->C2 : t->C3, Hi = sg == 2 ? t->H1 : t->H2, Ho = sg == 2 ? t->H2 : t->H3;
+    const int hid = sg == 2 ? t->hid2 : t->hid3, hd = sg == 2 ? t->hd2 : t->hd3, hdp = sg == 2 ? t->hdp2 : t->hdp3, heads = t->cfg.num_heads;
+    const size_t M = (size_t)B * Ho * Ho;
+    auto& pe = sg == 2 ? t->pe2 : t->pe3;
+    const std::string pn = "patch_embed" + std::to_string(sg) + ".";
+    pe.xin = xcur;
+    NEED(pe.z = take_act(t, M * C)); NEED(pe.out = take_act(t, M * C));
+    {
+      const fsvit_param *bias = getp(t, pn + "proj.bias"), *pos = getp(t, "pos_embed" + std::to_string(sg));
+      if (!bias || !pos) return FSVIT_ERR_KEY;
+      const size_t mark = t->tmp.off;
+      T_TRY(conv_fwd(t, sg == 2 ? sp.pe2 : sp.pe3, pe.xin, B, Hi, Hi, pe.z, bias->data));
+      void* y = take_tmp(t, M * C); NEED(y);
+      T_TRY(bn_fwd(t, pn + "norm.bn", pe.z, (int)M, C, ACT_NONE, nullptr, y, &pe.bn));
+      float* pt = (float*)t->tmp.take((size_t)Ho * Ho * C * 4); NEED(pt);
+      T_RUN(launch_transpose_cols(pos->data, pt, C, Ho * Ho, 0, Ho * Ho, C, 0, st));
+      T_RUN(launch_bcast_add(y, pt, pe.out, B, (size_t)Ho * Ho * C, dt, st));
+      t->tmp.off = mark;
+    }
+    xcur = pe.out;
+    auto& blocks = sg == 2 ? t->s2 : t->s3;
+    blocks.resize(t->cfg.depth[sg - 1]);
+    const float scale = 1.0f / std::sqrt((float)hd);
+    for (int i = 0; i < t->cfg.depth[sg - 1]; ++i, ++blk) {
+      auto& b = blocks[i];
+      const auto& cs = (sg == 2 ? sp.s2 : sp.s3)[i];
+      const std::string p = "stage" + std::to_string(sg) + "." + std::to_string(i) + ".";
+      b.x = xcur;
+      NEED(b.xn1 = take_act(t, M * C)); NEED(b.qkv = take_act(t, M * 3 * heads * hdp)); NEED(b.ctx = take_act(t, M * heads * hdp));
+      NEED(b.xa = take_act(t, M * C)); NEED(b.xn2 = take_act(t, M * C)); NEED(b.z1 = take_act(t, M * hid)); NEED(b.h = take_act(t, M * hid));
+      NEED(b.out = take_act(t, M * C));
+      const size_t mark = t->tmp.off;
+      void* zp = take_tmp(t, M * C); NEED(zp);
+      T_TRY(bn_fwd(t, p + "norm1.bn", b.x, (int)M, C, ACT_NONE, nullptr, b.xn1, &b.bn1));
+      T_TRY(conv_fwd(t, cs.qkv, b.xn1, B, Ho, Ho, b.qkv, nullptr));
+      T_RUN(launch_attention(b.qkv, b.ctx, B, Ho * Ho, heads, hdp, scale, dt, st));
+      T_TRY(conv_fwd(t, cs.proj, b.ctx, B, Ho, Ho, zp, nullptr));
+      b.s1 = dp_scale(t, dp_call, blk, nblk);
+      if (t->dp_rate * blk > 0.f) ++dp_call;
+      T_RUN(launch_add_scaled(b.x, zp, b.s1, b.xa, M * C, (size_t)Ho * Ho * C, dt, st));
+      T_TRY(bn_fwd(t, p + "norm2.bn", b.xa, (int)M, C, ACT_NONE, nullptr, b.xn2, &b.bn2));
+      T_TRY(conv_fwd(t, cs.fc1, b.xn2, B, Ho, Ho, b.z1, nullptr));
+      T_RUN(launch_gelu_fwd(b.z1, b.h, M * hid, dt, st));
+      T_TRY(conv_fwd(t, cs.fc2, b.h, B, Ho, Ho, zp, nullptr));
+      b.s2 = dp_scale(t, dp_call, blk, nblk);
+      if (t->dp_rate * blk > 0.f) ++dp_call;
+      T_RUN(launch_add_scaled(b.xa, zp, b.s2, b.out, M * C, (size_t)Ho * Ho * C, dt, st));
+      t->tmp.off = mark;
+      xcur = b.out;
+    }
+  }
+  // ---- final norm + pool (visformer.py:455-462)
+  const size_t M3 = (size_t)B * t->H3 * t->H3;
+  NEED(t->xnf = take_act(t, M3 * t->C3));
+  T_TRY(bn_fwd(t, "norm.bn", xcur, (int)M3, t->C3, ACT_NONE, nullptr, t->xnf, &t->bnf));
+  {
+    float* ones = (float*)t->tmp.take((size_t)2 * t->C3 * 4); NEED(ones);
+    T_RUN(launch_fill_f32(ones, 1.0f, t->C3, st));
+    T_RUN(launch_fill_f32(ones + t->C3, 0.0f, t->C3, st));
+    T_RUN(launch_pool_affine(t->xnf, ones, ones + t->C3, feat, B, t->H3 * t->H3, t->C3, dt, st));
+  }
+  return 0;
+}
+
+// ================================================================ backward
+int train_backward_impl(TR* t, const float* dfeat) {
+  const Specs sp = make_specs(t);
+  const int B = t->B, dt = t->dtype;
+  hipStream_t st = t->st;
+  const int H0 = t->H0, H1 = t->H1;
+  const size_t M0 = (size_t)B * H0 * H0, M1 = (size_t)B * H1 * H1, M3 = (size_t)B * t->H3 * t->H3;
+  // gradient of the residual stream, ping-pong in tmp
+  void* dx = take_tmp(t, M3 * t->C3); NEED(dx);
+  {
+    void* dxn = take_tmp(t, M3 * t->C3); NEED(dxn);
+    T_RUN(launch_avgpool_bwd(dfeat, dxn, B, t->H3 * t->H3, t->C3, dt, st));
+    T_TRY(bn_bwd(t, "norm.bn", t->bnf, dxn, dx));
+  }
+  for (int sg = 3; sg >= 2; --sg) {
+    const int Ci = sg == 2 ? t->C1 : t->C2, C = sg == 2 ? t->C2 : t->C3, Hi = sg == 2 ? t->H1 : t->H2, Ho = sg == 2 ? t->H2 : t->H3;
+    const int hid = sg == 2 ? t->hid2 : t->hid3, hd = sg == 2 ? t->hd2 : t->hd3, hdp = sg == 2 ? t->hdp2 : t->hdp3, heads = t->cfg.num_heads;
+    const size_t M = (size_t)B * Ho * Ho;
+    auto& blocks = sg == 2 ? t->s2 : t->s3;
+    const float scale = 1.0f / std::sqrt((float)hd);
+    for (int i = (int)blocks.size() - 1; i >= 0; --i) {
+      auto& b = blocks[i];
+      const auto& cs = (sg == 2 ? sp.s2 : sp.s3)[i];
+      const std::string p = "stage" + std::to_string(sg) + "." + std::to_string(i) + ".";
+      const size_t mark = t->tmp.off;
+      // mlp branch:  out = xa + s2 * fc2(gelu(fc1(bn2(xa))))
+      void* dz2 = take_tmp(t, M * C); NEED(dz2);
+      T_RUN(launch_add_scaled(nullptr, dx, b.s2, dz2, M * C, (size_t)Ho * Ho * C, dt, st));
+      T_TRY(conv_bwd_weight(t, cs.fc2, b.h, B, Ho, Ho, dz2));
+      void* dh = take_tmp(t, M * hid); NEED(dh);
+      T_TRY(conv_bwd_data(t, cs.fc2, dz2, B, Ho, Ho, dh));
+      T_RUN(launch_gelu_bwd(dh, b.z1, dh, M * hid, dt, st));                                   // dh := dz1 (in place)
+      T_TRY(conv_bwd_weight(t, cs.fc1, b.xn2, B, Ho, Ho, dh));
+      void* dxn2 = take_tmp(t, M * C); NEED(dxn2);
+      T_TRY(conv_bwd_data(t, cs.fc1, dh, B, Ho, Ho, dxn2));
+      T_TRY(bn_bwd(t, p + "norm2.bn", b.bn2, dxn2, dz2));                                      // dz2 := d(xa) through norm2
+      T_RUN(launch_add_scaled(dx, dz2, nullptr, dx, M * C, (size_t)Ho * Ho * C, dt, st));     // dx := d(xa) total
+      // attention branch:  xa = x + s1 * proj(attn(qkv(bn1(x))))
+      T_RUN(launch_add_scaled(nullptr, dx, b.s1, dz2, M * C, (size_t)Ho * Ho * C, dt, st));   // dz2 := dzp
+      T_TRY(conv_bwd_weight(t, cs.proj, b.ctx, B, Ho, Ho, dz2));
+      void* dctx = take_tmp(t, M * heads * hdp); NEED(dctx);
+      T_TRY(conv_bwd_data(t, cs.proj, dz2, B, Ho, Ho, dctx));
+      void* dqkv = take_tmp(t, M * 3 * heads * hdp); NEED(dqkv);
+      T_RUN(launch_attention_bwd(b.qkv, dctx, dqkv, B, Ho * Ho, heads, hd, hdp, scale, dt, st));
+      T_TRY(conv_bwd_weight(t, cs.qkv, b.xn1, B, Ho, Ho, dqkv));
+      T_TRY(conv_bwd_data(t, cs.qkv, dqkv, B, Ho, Ho, dxn2));                                 // dxn2 := d(xn1)
+      T_TRY(bn_bwd(t, p + "norm1.bn", b.bn1, dxn2, dz2));
+      T_RUN(launch_add_scaled(dx, dz2, nullptr, dx, M * C, (size_t)Ho * Ho * C, dt, st));
+      t->tmp.off = mark;
+    }
+    // patch embed:  out = bn(conv_k2s2(xin) + bias) + pos
+    auto& pe = sg == 2 ? t->pe2 : t->pe3;
+    const std::string pn = "patch_embed" + std::to_string(sg) + ".";
+    const ConvSpec& pc = sg == 2 ? sp.pe2 : sp.pe3;
+    const size_t Mi = (size_t)B * Hi * Hi;
+    {
+      const fsvit_param *bias = getp(t, pn + "proj.bias"), *pos = getp(t, "pos_embed" + std::to_string(sg));
+      if (!bias || !pos) return FSVIT_ERR_KEY;
+      if (pos->grad) {
+        float* ps = (float*)t->tmp.take((size_t)Ho * Ho * C * 4); NEED(ps);
+        T_RUN(launch_batch_sum(dx, ps, B, (size_t)Ho * Ho * C, dt, st));
+        T_RUN(launch_transpose_cols(ps, pos->grad, Ho * Ho, C, 0, C, Ho * Ho, 0, st));         // [HW][C] -> [C][HW]
+      }
+      void* dz = take_tmp(t, M * C); NEED(dz);
+      T_TRY(bn_bwd(t, pn + "norm.bn", pe.bn, dx, dz));
+      if (bias->grad) {
+        float* partial = (float*)t->tmp.take((size_t)bn_reduce_blocks((int)M) * 2 * C * 4); NEED(partial);
+        T_RUN(launch_colsum(dz, partial, bias->grad, (int)M, C, dt, st));
+      }
+      T_TRY(conv_bwd_weight(t, pc, pe.xin, B, Hi, Hi, dz));
+      // data gradient of the non-overlapping k2s2 conv: G[m][(ky,kx,c)] = dz[m] . W[:, c, ky, kx], scattered to the input grid
+      const fsvit_param* w = getp(t, pc.wname);
+      const int bke = 128 / t->es, Kw = round_up(C, bke);
+      void* pk = t->tmp.take((size_t)4 * Ci * Kw * t->es); NEED(pk);
+      T_RUN(launch_pack_weight(w->data, pk, C, Ci, 2, 2, 1, 2, 4 * Ci, Kw, 1, 1, 1, 1, dt, st));
+      void* G = take_tmp(t, M * 4 * Ci); NEED(G);
+      ConvGemmParams p = gemm_params(dz, pk, G, B, Ho, Ho, C, C, 1, 1, 1, 0, 4 * Ci, 4 * Ci, C, Kw, 1);
+      T_RUN(launch_conv_gemm(p, dt, st));
+      void* dxi = take_tmp(t, Mi * Ci); NEED(dxi);
+      T_RUN(launch_unpatch2(G, dxi, B, Ho, Ho, Ci, dt, st));
+      // the new residual-stream gradient lives at the start of tmp: move it there
+      t->tmp.off = 0;
+      dx = take_tmp(t, Mi * Ci);
+      T_RUN((int)hipMemcpyAsync(dx, dxi, Mi * Ci * t->es, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  // ---- stage 1
+  for (int i = (int)t->s1.size() - 1; i >= 0; --i) {
+    auto& b = t->s1[i];
+    const std::string p = "stage1." + std::to_string(i) + ".";
+    const size_t mark = t->tmp.off;
+    void* dz3 = take_tmp(t, M1 * t->C1); NEED(dz3);
+    T_RUN(launch_add_scaled(nullptr, dx, b.scale, dz3, M1 * t->C1, (size_t)H1 * H1 * t->C1, dt, st));
+    T_TRY(conv_bwd_weight(t, sp.s1c3[i], b.h2, B, H1, H1, dz3));
+    void* dh2 = take_tmp(t, M1 * t->hid1); NEED(dh2);
+    T_TRY(conv_bwd_data(t, sp.s1c3[i], dz3, B, H1, H1, dh2));
+    T_RUN(launch_gelu_bwd(dh2, b.z2, dh2, M1 * t->hid1, dt, st));
+    T_TRY(conv_bwd_weight(t, sp.s1c2[i], b.h1, B, H1, H1, dh2));
+    void* dh1 = take_tmp(t, M1 * t->hid1); NEED(dh1);
+    T_TRY(conv_bwd_data(t, sp.s1c2[i], dh2, B, H1, H1, dh1));
+    T_RUN(launch_gelu_bwd(dh1, b.z1, dh1, M1 * t->hid1, dt, st));
+    T_TRY(conv_bwd_weight(t, sp.s1c1[i], b.xn, B, H1, H1, dh1));
+    T_TRY(conv_bwd_data(t, sp.s1c1[i], dh1, B, H1, H1, dz3));                                  // dz3 := d(xn)
+    void* dxb = take_tmp(t, M1 * t->C1); NEED(dxb);
+    T_TRY(bn_bwd(t, p + "norm2.bn", b.bn, dz3, dxb));
+    T_RUN(launch_add_scaled(dx, dxb, nullptr, dx, M1 * t->C1, (size_t)H1 * H1 * t->C1, dt, st));
+    t->tmp.off = mark;
+  }
+  // ---- stem
+  {
+    auto& S = t->stem;
+    const fsvit_param* pos = getp(t, "pos_embed1");
+    if (!pos) return FSVIT_ERR_KEY;
+    if (pos->grad) {
+      float* ps = (float*)t->tmp.take((size_t)H1 * H1 * t->C1 * 4); NEED(ps);
+      T_RUN(launch_batch_sum(dx, ps, B, (size_t)H1 * H1 * t->C1, dt, st));
+      T_RUN(launch_transpose_cols(ps, pos->grad, H1 * H1, t->C1, 0, t->C1, H1 * H1, 0, st));
+    }
+    void* da3 = take_tmp(t, M0 * t->C1); NEED(da3);
+    T_RUN(launch_maxpool2_bwd(dx, S.arg, da3, B, H1, H1, t->C1, dt, st));
+    void* g3 = take_tmp(t, M0 * t->C1); NEED(g3);
+    T_RUN(launch_bn_act_bwd(da3, S.z3, S.b3.sa, S.b3.sb, S.ad, g3, M0, t->C1, dt, st));       // gradient at (bn3(z3) + identity)
+    T_TRY(bn_bwd(t, "stem.bn3", S.b3, g3, da3));                                              // da3 := dz3
+    T_TRY(conv_bwd_weight(t, sp.conv3, S.a2, B, H0, H0, da3));
+    void* da2 = take_tmp(t, M0 * t->C1); NEED(da2);
+    T_TRY(conv_bwd_data(t, sp.conv3, da3, B, H0, H0, da2));
+    // identity path: ad = bn_d(zd)
+    T_TRY(bn_bwd(t, "stem.downsample.1", S.bd, g3, da3));                                     // da3 := dzd
+    T_TRY(conv_bwd_weight(t, sp.down, S.patches, B, H0, H0, da3));
+    T_RUN(launch_bn_act_bwd(da2, S.z2, S.b2.sa, S.b2.sb, nullptr, g3, M0, t->C1, dt, st));
+    T_TRY(bn_bwd(t, "stem.bn2", S.b2, g3, da2));                                              // da2 := dz2
+    T_TRY(conv_bwd_weight(t, sp.conv2, S.a1, B, H0, H0, da2));
+    void* da1 = take_tmp(t, M0 * t->C0); NEED(da1);
+    T_TRY(conv_bwd_data(t, sp.conv2, da2, B, H0, H0, da1));
+    void* g1 = take_tmp(t, M0 * t->C0); NEED(g1);
+    T_RUN(launch_bn_act_bwd(da1, S.z1, S.b1.sa, S.b1.sb, nullptr, g1, M0, t->C0, dt, st));
+    T_TRY(bn_bwd(t, "stem.bn1", S.b1, g1, da1));                                              // da1 := dz1
+    T_TRY(conv_bwd_weight(t, sp.conv1, S.patches, B, H0, H0, da1));
+  }
+  return 0;
+}
+
+}  // namespace
+
+// ================================================================ C ABI
+extern "C" int fsvit_visformer_trainer_create(const fsvit_visformer_cfg* cfg, int dtype, fsvit_visformer_trainer** out) {
+  if (!cfg || !out) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
+  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16) return fsvit_set_error(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  TR* t = new TR();
+  t->cfg = *cfg; t->dtype = dtype; t->es = dtype == FSVIT_F32 ? 4 : 2;
+  const int D = cfg->embed_dim, kch = 64 / t->es;
+  t->C0 = cfg->init_channels; t->C1 = D / 2; t->C2 = D; t->C3 = D * 2;
+  t->H0 = cfg->img_size / 2; t->H1 = cfg->img_size / 4; t->H2 = cfg->img_size / 8; t->H3 = cfg->img_size / 16;
+  t->hid1 = t->C1 * 2; t->hid2 = (int)(t->C2 * cfg->mlp_ratio); t->hid3 = (int)(t->C3 * cfg->mlp_ratio);
+  t->hd2 = t->C2 / cfg->num_heads; t->hd3 = t->C3 / cfg->num_heads;
+  t->hdp2 = round_up(t->hd2, kch); t->hdp3 = round_up(t->hd3, kch);
+  t->Cg = t->hid1 / cfg->group;
+  *out = t;
+  return 0;
+}
+
+extern "C" void fsvit_visformer_trainer_destroy(fsvit_visformer_trainer* t) { delete t; }
+
+static void bind_params(TR* t, const fsvit_param* params, int n) {
+  t->P.clear();
+  for (int i = 0; i < n; ++i) t->P[params[i].name] = &params[i];
+}
+
+static int droppath_calls(const TR* t, float rate, std::vector<float>* keep) {
+  const int depth = t->cfg.depth[0] + t->cfg.depth[1] + t->cfg.depth[2];
+  int ncalls = 0;
+  for (int b = 0; b < depth; ++b) {
+    const float r = depth > 1 ? rate * (float)b / (float)(depth - 1) : 0.f;
+    if (r == 0.f) continue;
+    const int calls = b < t->cfg.depth[0] ? 1 : 2;
+    for (int k = 0; k < calls; ++k) if (keep) keep->push_back(1.0f - r);
+    ncalls += calls;
+  }
+  return ncalls;
+}
+
+// Sizing pass: walk forward + backward with dry arenas (no launches) and record both peaks.
+static int size_workspace(TR* t, int n_img, float rate, size_t* save_bytes, size_t* tmp_bytes) {
+  t->B = n_img; t->dp_rate = rate; t->scales = nullptr;
+  t->save = Arena(); t->tmp = Arena();
+  t->save.dry = t->tmp.dry = true;
+  int rc = train_forward_impl(t, nullptr, nullptr);
+  if (rc) return rc;
+  size_t tp = t->tmp.peak;
+  t->tmp.off = 0;
+  rc = train_backward_impl(t, nullptr);
+  if (rc) return rc;
+  if (t->tmp.peak > tp) tp = t->tmp.peak;
+  *save_bytes = align256(t->save.peak + (size_t)droppath_calls(t, rate, nullptr) * n_img * 4 + 256);
+  *tmp_bytes = align256(tp);
+  return 0;
+}
+
+extern "C" size_t fsvit_visformer_trainer_workspace_bytes(fsvit_visformer_trainer* t, const fsvit_param* params, int n_params, int n_img, float drop_path_rate) {
+  if (!t || !params || n_img <= 0) return 0;
+  bind_params(t, params, n_params);
+  size_t sb = 0, tb = 0;
+  if (size_workspace(t, n_img, drop_path_rate, &sb, &tb)) return 0;
+  return sb + tb;
+}
+
+extern "C" int fsvit_visformer_train_forward(fsvit_visformer_trainer* t, const fsvit_param* params, int n_params, const float* x_nchw_dev, int n_img,
+                                             int img_h, int img_w, float drop_path_rate, const float* masks_dev, float* feat_dev, void* ws_dev,
+                                             size_t ws_bytes, void* stream) {
+  if (!t || !params || !x_nchw_dev || !feat_dev || !ws_dev || n_img <= 0) return fsvit_set_error(FSVIT_ERR_ARG, "bad argument");
+  if (img_h != t->cfg.img_size || img_w != t->cfg.img_size)
+    return fsvit_set_error(FSVIT_ERR_IMG_SIZE, "Input image size (%d*%d) does not match model (%d*%d).", img_h, img_w, t->cfg.img_size, t->cfg.img_size);
+  if (n_img < 2) return fsvit_set_error(FSVIT_ERR_ARG, "train-mode BatchNorm needs more than one image");
+  if (drop_path_rate > 0.f && !masks_dev) return fsvit_set_error(FSVIT_ERR_ARG, "DropPath masks required when drop_path_rate > 0");
+  bind_params(t, params, n_params);
+  size_t sb = 0, tb = 0;
+  T_TRY(size_workspace(t, n_img, drop_path_rate, &sb, &tb));
+  if (ws_bytes < sb + tb) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace of %zu bytes is too small (need %zu)", ws_bytes, sb + tb);
+  t->st = (hipStream_t)stream;
+  t->save = Arena(); t->save.base = (unsigned char*)ws_dev; t->save.size = sb;
+  t->tmp = Arena(); t->tmp.base = (unsigned char*)ws_dev + sb; t->tmp.size = ws_bytes - sb;
+  t->scales = nullptr;
+  if (drop_path_rate > 0.f) {                       // DropPath scale = mask / keep_prob per call (visformer.py:92-96)
+    std::vector<float> keep;
+    const int ncalls = droppath_calls(t, drop_path_rate, &keep);
+    t->scales = (float*)t->save.take((size_t)ncalls * n_img * 4);
+    if (!t->scales) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small");
+    for (int k = 0; k < ncalls; ++k)
+      T_RUN(launch_scale_copy(masks_dev + (size_t)k * n_img, t->scales + (size_t)k * n_img, n_img, 1.0f / keep[k], t->st));
+  }
+  return train_forward_impl(t, x_nchw_dev, feat_dev);
+}
+
+extern "C" int fsvit_visformer_train_backward(fsvit_visformer_trainer* t, const fsvit_param* params, int n_params, const float* dfeat_dev, void* stream) {
+  if (!t || !params || !dfeat_dev) return fsvit_set_error(FSVIT_ERR_ARG, "bad argument");
+  if (!t->save.base || t->save.dry) return fsvit_set_error(FSVIT_ERR_ARG, "train_backward called without a preceding train_forward");
+  bind_params(t, params, n_params);
+  t->st = (hipStream_t)stream;
+  t->tmp.off = 0;
+  return train_backward_impl(t, dfeat_dev);
+}
+
+extern "C" int fsvit_proto_head_backward(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D,
+                                         float temp, float* dfeat_shot, float* dfeat_query, float* dtemp_per_episode, void* stream) {
+  if (!feat_shot || !feat_query || !dlogits || !dfeat_shot || !dfeat_query) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
+  int rc = launch_proto_head_bwd(feat_shot, feat_query, dlogits, E, way, shot, Q, D, temp, dfeat_shot, dfeat_query, dtemp_per_episode, (hipStream_t)stream);
+  return rc ? fsvit_set_error(rc, "proto_head_bwd") : 0;
+}
+
+extern "C" int fsvit_attention_backward(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, int hd, int hdp, float scale, int dtype,
+                                        void* stream) {
+  if (!qkv || !dctx || !dqkv) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
+  int rc = launch_attention_bwd(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, dtype, (hipStream_t)stream);
+  return rc ? fsvit_set_error(rc, "attention_bwd") : 0;
+}
+
+extern "C" int fsvit_sgd_step(float* param, const float* grad, float* momentum_buf, size_t n, float lr, float momentum, float weight_decay, int first_step,
+                              void* stream) {
+  if (!param || !grad || !momentum_buf) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
+  int rc = launch_sgd(param, grad, momentum_buf, n, lr, momentum, weight_decay, first_step, (hipStream_t)stream);
+  return rc ? fsvit_set_error(rc, "sgd") : 0;
+}

@@ -1,0 +1,45 @@
+// Launchers of the training-path kernels (train_kernels.hip, attention_bwd.hip, head_bwd in head.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace fsvit {
+
+int launch_pack_weight(const float* w, void* out, int O, int Ig, int KH, int KW, int groups, int mode, int rows_pad, int Kw, int hd_rows, int hdp_rows,
+                       int hd_cols, int hdp_cols, int dtype, hipStream_t s);
+int launch_wgrad_finalize(const float* y, float* dw, int Ng, int Ig, int KH, int KW, int g, int splits, int Kc_pad, int hd_rows, int hdp_rows, int hd_cols,
+                          int hdp_cols, hipStream_t s);
+int launch_transpose_cols(const void* in, void* out, int M, int ld, int c0, int ncols, int Mpad, int dtype, hipStream_t s);
+int launch_im2col_t(const void* x, void* out, int B, int H, int W, int ld, int c0, int C, int KH, int KW, int stride, int pad, int OH, int OW, int Mpad,
+                    int dtype, hipStream_t s);
+int launch_unpatch2(const void* g, void* dx, int B, int OH, int OW, int C, int dtype, hipStream_t s);
+int bn_reduce_blocks(int M);
+int launch_bn_reduce(const void* a, const void* z, const float* mean, const float* invstd, float* partial, int M, int C, int bwd, int dtype, hipStream_t s);
+int launch_bn_fwd_finalize(const float* partial, int M, int C, float eps, float momentum, const float* gamma, const float* beta, float* rmean, float* rvar,
+                           float* mean, float* invstd, float* sa, float* sb, hipStream_t s);
+int launch_bn_bwd_finalize(const float* partial, int M, int C, const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* ca, float* cb,
+                           float* cc, hipStream_t s);
+int launch_bn_apply(const void* z, const float* sa, const float* sb, const void* res, void* y, size_t M, int C, int act, int dtype, hipStream_t s);
+int launch_bn_act_bwd(const void* dout, const void* z, const float* sa, const float* sb, const void* res, void* g, size_t M, int C, int dtype, hipStream_t s);
+int launch_bn_bwd_apply(const void* dy, const void* z, const float* mean, const float* invstd, const float* ca, const float* cb, const float* cc, void* dz,
+                        size_t M, int C, int dtype, hipStream_t s);
+int launch_gelu_fwd(const void* z, void* h, size_t n, int dtype, hipStream_t s);
+int launch_gelu_bwd(const void* dh, const void* z, void* dz, size_t n, int dtype, hipStream_t s);
+int launch_add_scaled(const void* a, const void* br, const float* scale, void* out, size_t n, size_t per_img, int dtype, hipStream_t s);
+int launch_maxpool2_idx(const void* in, const float* pos, void* out, unsigned char* arg, int B, int OH, int OW, int C, int dtype, hipStream_t s);
+int launch_maxpool2_bwd(const void* dout, const unsigned char* arg, void* din, int B, int OH, int OW, int C, int dtype, hipStream_t s);
+int launch_avgpool_bwd(const float* dfeat, void* dx, int B, int HW, int C, int dtype, hipStream_t s);
+int launch_batch_sum(const void* g, float* out, int B, size_t per_img, int dtype, hipStream_t s);
+int launch_bcast_add(const void* x, const float* p, void* y, int B, size_t per_img, int dtype, hipStream_t s);
+int launch_fill_f32(float* p, float v, size_t n, hipStream_t s);
+int launch_scale_copy(const float* in, float* out, size_t n, float sc, hipStream_t s);
+// out[c] = sum_m a[m][c]; partial: bn_reduce_blocks(M) * 2 * C floats of scratch
+int launch_colsum(const void* a, float* partial, float* out, int M, int C, int dtype, hipStream_t s);
+int launch_sgd(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, int first, hipStream_t s);
+// attention backward (attention_bwd.hip): qkv [B*S][3*heads*hdp], dctx [B*S][heads*hdp] -> dqkv [B*S][3*heads*hdp]
+int launch_attention_bwd(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, int hd, int hdp, float scale, int dtype, hipStream_t s);
+// prototype head backward (head.hip): dlogits [E,Q,way] -> dfeat_shot [E,way,shot,D], dfeat_query [E,Q,D], dtemp[E] (cos method)
+int launch_proto_head_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
+                          float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s);
+
+}  // namespace fsvit

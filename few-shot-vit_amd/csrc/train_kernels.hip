@@ -1,0 +1,532 @@
+// Training-path kernels of the Visformer meta-tuning step (meta_tuning_sun_m/train_meta.py:161-177):
+// everything the eval path folds away or never needs.  All are HBM-bound elementwise / reduction /
+// layout kernels except attention backward; the GEMM-shaped work (forward convs, dgrad, split-K wgrad)
+// reuses conv_gemm_v2.  T = storage dtype of activations and activation gradients (fp32 or bf16);
+// parameters, parameter gradients, BN statistics and reductions are fp32.
+#include "fsvit_common.h"
+#include "train_kernels.h"
+
+namespace fsvit {
+
+static inline unsigned gs_grid(size_t total, int per_block = 256) {
+  size_t nb = (total + per_block - 1) / per_block;
+  return (unsigned)(nb > 32768 ? 32768 : (nb < 1 ? 1 : nb));
+}
+#define GS_LOOP(idx, total) for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (total); idx += (size_t)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------------------------------------ weights
+// PyTorch conv weight W[O][Ig][KH][KW] (O = groups * Ng) -> packed [groups][Npad][Kw] (see conv_gemm.h).
+//  mode 0 (forward): row n = output channel, k = (ky*KW + kx) * Ig + i
+//  mode 1 (dgrad):   row c = input channel of the group, k = (ky*KW + kx) * Ng + n with the taps FLIPPED, so a
+//                    stride-1 conv of dY with it is the transposed convolution
+//  mode 2 (k2s2 dgrad): row r = (ky*KW + kx) * Ig + i, k = n (no flip): dY[m] . W[:, i, ky, kx] for the non-overlapping patch conv
+// Head-dim padding (qkv rows / proj columns, visformer.py:172-177): logical index j < real maps to
+// (j / hd) * hdp + j % hd in the padded dimension (hd == hdp: identity).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int O, int Ig, int KH, int KW,
+                                                          int groups, int mode, int rows_pad, int Kw, int hd_rows, int hdp_rows,
+                                                          int hd_cols, int hdp_cols) {
+  const int Ng = O / groups;
+  const size_t total = (size_t)groups * rows_pad * Kw;
+  GS_LOOP(idx, total) {
+    const int k = (int)(idx % Kw);
+    const size_t t2 = idx / Kw;
+    const int r = (int)(t2 % rows_pad), g = (int)(t2 / rows_pad);
+    float v = 0.0f;
+    if (mode == 2) {
+      if (r < KH * KW * Ig && k < Ng) {
+        const int tap = r / Ig, ch = r % Ig;
+        v = w[(((size_t)(g * Ng + k) * Ig + ch) * KH + tap / KW) * KW + tap % KW];
+      }
+      out[idx] = from_f32<T>(v);
+      continue;
+    }
+    const int nin = mode == 0 ? Ig : Ng;            // channels per tap in the K dimension
+    // undo the head padding of the K (column) dimension: only for 1x1 layers
+    int kk = k;
+    bool ok = true;
+    if (hdp_cols != hd_cols) { const int y = k / hdp_cols, zz = k % hdp_cols; ok = zz < hd_cols; kk = y * hd_cols + zz; }
+    int rr = r;
+    if (hdp_rows != hd_rows) { const int y = r / hdp_rows, zz = r % hdp_rows; ok = ok && zz < hd_rows; rr = y * hd_rows + zz; }
+    const int nrows = mode == 0 ? Ng : Ig;
+    if (ok && rr < nrows && kk < KH * KW * nin) {
+      const int tap = kk / nin, ch = kk % nin;
+      const int ky = tap / KW, kx = tap % KW;
+      if (mode == 0) v = w[(((size_t)(g * Ng + rr) * Ig + ch) * KH + ky) * KW + kx];
+      else v = w[(((size_t)(g * Ng + ch) * Ig + rr) * KH + (KH - 1 - ky)) * KW + (KW - 1 - kx)];
+    }
+    out[idx] = from_f32<T>(v);
+  }
+}
+
+// split-K wgrad result Y[Ng][splits * Kc] (fp32, Kc = KH*KW*Ig padded to Kc_pad) of ONE group -> dW[O][Ig][KH][KW] (overwrite)
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ y, float* __restrict__ dw, int Ng, int Ig, int KH, int KW,
+                                                             int g, int splits, int Kc_pad, int hd_rows, int hdp_rows, int hd_cols, int hdp_cols) {
+  const size_t total = (size_t)Ng * Ig * KH * KW;
+  GS_LOOP(idx, total) {
+    const int kx = (int)(idx % KW);
+    size_t t2 = idx / KW;
+    const int ky = (int)(t2 % KH); t2 /= KH;
+    const int i = (int)(t2 % Ig);
+    const int n = (int)(t2 / Ig);
+    int k = (ky * KW + kx) * Ig + i;
+    if (hdp_cols != hd_cols) k = (k / hd_cols) * hdp_cols + k % hd_cols;
+    int r = n;
+    if (hdp_rows != hd_rows) r = (n / hd_rows) * hdp_rows + n % hd_rows;
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += y[(size_t)r * splits * Kc_pad + (size_t)sp * Kc_pad + k];
+    dw[(((size_t)(g * Ng + n) * Ig + i) * KH + ky) * KW + kx] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ transposes for wgrad
+// in [M][ld] (columns c0 .. c0+ncols) -> out [ncols][Mpad], zero for m >= M.  32x32 LDS tile transpose.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_cols_kernel(const T* __restrict__ in, T* __restrict__ out, int M, int ld, int c0, int ncols, int Mpad) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+  const int mt = blockIdx.x * 32, ct = blockIdx.y * 32;
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) {
+    const int m = mt + ty + r, c = ct + tx;
+    tile[ty + r][tx] = (m < M && c < ncols) ? to_f32<T>(in[(size_t)m * ld + c0 + c]) : 0.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) {
+    const int c = ct + ty + r, m = mt + tx;
+    if (c < ncols && m < Mpad) out[(size_t)c * Mpad + m] = from_f32<T>(tile[tx][ty + r]);
+  }
+}
+
+// x NHWC [B,H,W,ld] (channels c0 .. c0+C) -> out [(ky*KW+kx)*C + c][Mpad], m = (b, oy, ox); zero outside the image / m >= M
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_t_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int ld, int c0, int C,
+                                                       int KH, int KW, int stride, int pad, int OH, int OW, int Mpad) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int mt = blockIdx.x * 32, ct = blockIdx.y * 32, tap = blockIdx.z;
+  const int ky = tap / KW, kx = tap % KW;
+  const int M = B * OH * OW;
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) {
+    const int m = mt + ty + r, c = ct + tx;
+    float v = 0.0f;
+    if (m < M && c < C) {
+      const int b = m / (OH * OW), rem = m % (OH * OW), oy = rem / OW, ox = rem % OW;
+      const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = to_f32<T>(x[((size_t)(b * H + iy) * W + ix) * ld + c0 + c]);
+    }
+    tile[ty + r][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 32; r += 8) {
+    const int c = ct + ty + r, m = mt + tx;
+    if (c < C && m < Mpad) out[(size_t)(tap * C + c) * Mpad + m] = from_f32<T>(tile[tx][ty + r]);
+  }
+}
+
+// k2s2 dgrad scatter: g [B*OH*OW][4*C] with k = (ky*2+kx)*C + c  ->  dx [B, 2*OH, 2*OW, C]
+template <typename T>
+__global__ __launch_bounds__(256) void unpatch2_kernel(const T* __restrict__ g, T* __restrict__ dx, int B, int OH, int OW, int C) {
+  const size_t total = (size_t)B * OH * OW * 4 * C;
+  GS_LOOP(idx, total) {
+    const int c = (int)(idx % C);
+    size_t t2 = idx / C;
+    const int tap = (int)(t2 % 4); t2 /= 4;
+    const int ox = (int)(t2 % OW); t2 /= OW;
+    const int oy = (int)(t2 % OH);
+    const size_t b = t2 / OH;
+    dx[((b * 2 * OH + 2 * oy + (tap >> 1)) * 2 * OW + 2 * ox + (tap & 1)) * C + c] = g[idx];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm (train)
+// partial[blk][2][C]: per-block sums of z and z^2 (or of dy and dy*xhat in the backward form) over a row range
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ a, const T* __restrict__ z, const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd, float* __restrict__ partial, int M, int C, int rows_per_block) {
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s0 = 0.f, s1 = 0.f;
+    const float mu = BWD ? mean[c] : 0.f, is = BWD ? invstd[c] : 0.f;
+    for (int m = r0; m < r1; ++m) {
+      const float v = to_f32<T>(a[(size_t)m * C + c]);
+      if (BWD) { s0 += v; s1 += v * (to_f32<T>(z[(size_t)m * C + c]) - mu) * is; }
+      else { s0 += v; s1 += v * v; }
+    }
+    partial[((size_t)blockIdx.x * 2 + 0) * C + c] = s0;
+    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = s1;
+  }
+}
+
+// forward finalize: mean / invstd (biased variance), scale/shift for the apply pass, running-stat update (momentum, unbiased var)
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __restrict__ partial, int nblk, int M, int C, float eps, float momentum,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                              float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ sa, float* __restrict__ sb) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = 0; b < nblk; ++b) { s0 += partial[((size_t)b * 2 + 0) * C + c]; s1 += partial[((size_t)b * 2 + 1) * C + c]; }
+  const double mu = s0 / M;
+  double var = s1 / M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)mu;
+  invstd[c] = is;
+  sa[c] = gamma[c] * is;
+  sb[c] = beta[c] - (float)mu * gamma[c] * is;
+  if (running_mean) {
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mu;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)(var * ((double)M / (double)(M - 1)));
+  }
+}
+
+// backward finalize: dgamma = sum(dy * xhat), dbeta = sum(dy); coefficients of dz = ca * dy + cb + cc * xhat
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int M, int C, const float* __restrict__ gamma,
+                                                              const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = 0; b < nblk; ++b) { s0 += partial[((size_t)b * 2 + 0) * C + c]; s1 += partial[((size_t)b * 2 + 1) * C + c]; }
+  dbeta[c] = (float)s0;
+  dgamma[c] = (float)s1;
+  const float gi = gamma[c] * invstd[c];
+  ca[c] = gi;
+  cb[c] = (float)(-gi * s0 / M);
+  cc[c] = (float)(-gi * s1 / M);
+}
+
+// y = act(sa[c] * z + sb[c] (+ res))      act: 0 none, 2 LeakyReLU(0.1)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ z, const float* __restrict__ sa, const float* __restrict__ sb,
+                                                       const T* __restrict__ res, T* __restrict__ y, size_t M, int C, int act) {
+  const int c4n = C / 4;
+  const size_t total = M * c4n;
+  GS_LOOP(idx, total) {
+    const int c = (int)(idx % c4n) * 4;
+    const size_t off = (idx / c4n) * C + c;
+    f32x4 v = load4<T>(z + off) * *reinterpret_cast<const f32x4*>(sa + c) + *reinterpret_cast<const f32x4*>(sb + c);
+    if (res) v += load4<T>(res + off);
+    if (act == ACT_LRELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.1f * v[e];
+    }
+    store4<T>(y + off, v);
+  }
+}
+
+// dyin = dout * act'(y)  with y = sa*z + sb (+res) recomputed;  writes g (gradient w.r.t. the BN output, also the residual's gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ z, const float* __restrict__ sa,
+                                                         const float* __restrict__ sb, const T* __restrict__ res, T* __restrict__ g, size_t M, int C) {
+  const int c4n = C / 4;
+  const size_t total = M * c4n;
+  GS_LOOP(idx, total) {
+    const int c = (int)(idx % c4n) * 4;
+    const size_t off = (idx / c4n) * C + c;
+    f32x4 y = load4<T>(z + off) * *reinterpret_cast<const f32x4*>(sa + c) + *reinterpret_cast<const f32x4*>(sb + c);
+    if (res) y += load4<T>(res + off);
+    f32x4 d = load4<T>(dout + off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = y[e] > 0.f ? d[e] : 0.1f * d[e];
+    store4<T>(g + off, d);
+  }
+}
+
+// dz = ca[c] * dy + cb[c] + cc[c] * xhat,  xhat = (z - mean) * invstd
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ z, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ ca, const float* __restrict__ cb,
+                                                           const float* __restrict__ cc, T* __restrict__ dz, size_t M, int C) {
+  const int c4n = C / 4;
+  const size_t total = M * c4n;
+  GS_LOOP(idx, total) {
+    const int c = (int)(idx % c4n) * 4;
+    const size_t off = (idx / c4n) * C + c;
+    const f32x4 xh = (load4<T>(z + off) - *reinterpret_cast<const f32x4*>(mean + c)) * *reinterpret_cast<const f32x4*>(invstd + c);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(ca + c) * load4<T>(dy + off) + *reinterpret_cast<const f32x4*>(cb + c) +
+                    *reinterpret_cast<const f32x4*>(cc + c) * xh;
+    store4<T>(dz + off, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ z, T* __restrict__ h, size_t n4) {
+  GS_LOOP(idx, n4) {
+    f32x4 v = load4<T>(z + idx * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = sizeof(T) == 2 ? gelu_fast(v[e]) : gelu_erf(v[e]);
+    store4<T>(h + idx * 4, v);
+  }
+}
+// dz = dh * (Phi(z) + z * phi(z))
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ z, T* __restrict__ dz, size_t n4) {
+  GS_LOOP(idx, n4) {
+    const f32x4 x = load4<T>(z + idx * 4), d = load4<T>(dh + idx * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float cdf = 0.5f * (1.0f + erff(x[e] * 0.70710678118654752440f));
+      const float pdf = 0.39894228040143267794f * expf(-0.5f * x[e] * x[e]);
+      o[e] = d[e] * (cdf + x[e] * pdf);
+    }
+    store4<T>(dz + idx * 4, o);
+  }
+}
+// out = a + scale[b] * br   (scale == nullptr: 1);  rows_per_img rows of C per image
+template <typename T>
+__global__ __launch_bounds__(256) void add_scaled_kernel(const T* __restrict__ a, const T* __restrict__ br, const float* __restrict__ scale,
+                                                         T* __restrict__ out, size_t n4, size_t per_img4) {
+  GS_LOOP(idx, n4) {
+    const float s = scale ? scale[idx / per_img4] : 1.0f;
+    f32x4 v = load4<T>(br + idx * 4) * s;
+    if (a) v += load4<T>(a + idx * 4);
+    store4<T>(out + idx * 4, v);
+  }
+}
+
+// MaxPool2d(2) with argmax (0..3) + pos add (forward), and its scatter backward
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_idx_kernel(const T* __restrict__ in, const float* __restrict__ pos, T* __restrict__ out,
+                                                           unsigned char* __restrict__ arg, int B, int OH, int OW, int C) {
+  const size_t total = (size_t)B * OH * OW * C;
+  GS_LOOP(idx, total) {
+    const int c = (int)(idx % C);
+    const size_t pix = idx / C;
+    const int ox = (int)(pix % OW);
+    const size_t t2 = pix / OW;
+    const int oy = (int)(t2 % OH);
+    const size_t b = t2 / OH;
+    const int W = OW * 2;
+    const T* p = in + ((b * OH * 2 + oy * 2) * W + ox * 2) * C + c;
+    float best = to_f32<T>(p[0]);
+    int bi = 0;
+    const float v1 = to_f32<T>(p[C]), v2 = to_f32<T>(p[(size_t)W * C]), v3 = to_f32<T>(p[(size_t)W * C + C]);
+    if (v1 > best) { best = v1; bi = 1; }
+    if (v2 > best) { best = v2; bi = 2; }
+    if (v3 > best) { best = v3; bi = 3; }
+    arg[idx] = (unsigned char)bi;
+    out[idx] = from_f32<T>(best + (pos ? pos[(size_t)(oy * OW + ox) * C + c] : 0.f));
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__ dout, const unsigned char* __restrict__ arg, T* __restrict__ din,
+                                                           int B, int OH, int OW, int C) {
+  const size_t total = (size_t)B * OH * OW * C;
+  GS_LOOP(idx, total) {
+    const int c = (int)(idx % C);
+    const size_t pix = idx / C;
+    const int ox = (int)(pix % OW);
+    const size_t t2 = pix / OW;
+    const int oy = (int)(t2 % OH);
+    const size_t b = t2 / OH;
+    const int W = OW * 2;
+    T* p = din + ((b * OH * 2 + oy * 2) * W + ox * 2) * C + c;
+    const int a = arg[idx];
+    const T d = dout[idx], z = from_f32<T>(0.f);
+    p[0] = a == 0 ? d : z;
+    p[C] = a == 1 ? d : z;
+    p[(size_t)W * C] = a == 2 ? d : z;
+    p[(size_t)W * C + C] = a == 3 ? d : z;
+  }
+}
+
+// dx[b][hw][c] = dfeat[b][c] / HW   (AdaptiveAvgPool2d(1) backward)
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dfeat, T* __restrict__ dx, int B, int HW, int C) {
+  const size_t total = (size_t)B * HW * C;
+  GS_LOOP(idx, total) {
+    const int c = (int)(idx % C);
+    const size_t b = idx / ((size_t)HW * C);
+    dx[idx] = from_f32<T>(dfeat[b * C + c] / (float)HW);
+  }
+}
+
+// out[r][c] = sum_b g[b][r][c]  (pos_embed gradient: r over HW) ; rows = HW, reduces over B images
+template <typename T>
+__global__ __launch_bounds__(256) void batch_sum_kernel(const T* __restrict__ g, float* __restrict__ out, int B, size_t per_img) {
+  GS_LOOP(idx, per_img) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += to_f32<T>(g[(size_t)b * per_img + idx]);
+    out[idx] = s;
+  }
+}
+
+// y[b][i] = x[b][i] + p[i]   (pos_embed add after the PatchEmbed norm, visformer.py:437-438)
+template <typename T>
+__global__ __launch_bounds__(256) void bcast_add_kernel(const T* __restrict__ x, const float* __restrict__ p, T* __restrict__ y, size_t n4, size_t per_img4) {
+  GS_LOOP(idx, n4) {
+    const f32x4 v = load4<T>(x + idx * 4) + *reinterpret_cast<const f32x4*>(p + (idx % per_img4) * 4);
+    store4<T>(y + idx * 4, v);
+  }
+}
+__global__ __launch_bounds__(256) void fill_f32_kernel(float* __restrict__ p, float v, size_t n) { GS_LOOP(idx, n) p[idx] = v; }
+__global__ __launch_bounds__(256) void scale_copy_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, float s) { GS_LOOP(idx, n) out[idx] = in[idx] * s; }
+// column sums from bn_reduce partials (conv bias gradient)
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0;
+  for (int b = 0; b < nblk; ++b) s0 += partial[((size_t)b * 2 + 0) * C + c];
+  out[c] = (float)s0;
+}
+
+// SGD with momentum and weight decay, torch.optim.SGD semantics (utils/__init__.py:131-132): d = g + wd*p; buf = mom*buf + d (buf = d on the
+// first step); p -= lr * buf
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, size_t n, float lr,
+                                                  float momentum, float wd, int first) {
+  GS_LOOP(idx, n) {
+    const float d = g[idx] + wd * p[idx];
+    const float b = first ? d : momentum * buf[idx] + d;
+    buf[idx] = b;
+    p[idx] -= lr * b;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == 0) { CALL_F32; } else { CALL_BF16; } } while (0)
+
+int launch_pack_weight(const float* w, void* out, int O, int Ig, int KH, int KW, int groups, int mode, int rows_pad, int Kw, int hd_rows, int hdp_rows,
+                       int hd_cols, int hdp_cols, int dtype, hipStream_t s) {
+  const size_t total = (size_t)groups * rows_pad * Kw;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, w, (float*)out, O, Ig, KH, KW, groups, mode, rows_pad, Kw, hd_rows, hdp_rows, hd_cols, hdp_cols),
+             hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, w, (bf16*)out, O, Ig, KH, KW, groups, mode, rows_pad, Kw, hd_rows, hdp_rows, hd_cols, hdp_cols));
+  return (int)hipGetLastError();
+}
+int launch_wgrad_finalize(const float* y, float* dw, int Ng, int Ig, int KH, int KW, int g, int splits, int Kc_pad, int hd_rows, int hdp_rows, int hd_cols,
+                          int hdp_cols, hipStream_t s) {
+  const size_t total = (size_t)Ng * Ig * KH * KW;
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(gs_grid(total)), dim3(256), 0, s, y, dw, Ng, Ig, KH, KW, g, splits, Kc_pad, hd_rows, hdp_rows, hd_cols, hdp_cols);
+  return (int)hipGetLastError();
+}
+int launch_transpose_cols(const void* in, void* out, int M, int ld, int c0, int ncols, int Mpad, int dtype, hipStream_t s) {
+  dim3 grid((Mpad + 31) / 32, (ncols + 31) / 32);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(transpose_cols_kernel<float>, grid, dim3(256), 0, s, (const float*)in, (float*)out, M, ld, c0, ncols, Mpad),
+             hipLaunchKernelGGL(transpose_cols_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, M, ld, c0, ncols, Mpad));
+  return (int)hipGetLastError();
+}
+int launch_im2col_t(const void* x, void* out, int B, int H, int W, int ld, int c0, int C, int KH, int KW, int stride, int pad, int OH, int OW, int Mpad,
+                    int dtype, hipStream_t s) {
+  dim3 grid((Mpad + 31) / 32, (C + 31) / 32, KH * KW);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(im2col_t_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)out, B, H, W, ld, c0, C, KH, KW, stride, pad, OH, OW, Mpad),
+             hipLaunchKernelGGL(im2col_t_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, (bf16*)out, B, H, W, ld, c0, C, KH, KW, stride, pad, OH, OW, Mpad));
+  return (int)hipGetLastError();
+}
+int launch_unpatch2(const void* g, void* dx, int B, int OH, int OW, int C, int dtype, hipStream_t s) {
+  const size_t total = (size_t)B * OH * OW * 4 * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(unpatch2_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, (const float*)g, (float*)dx, B, OH, OW, C),
+             hipLaunchKernelGGL(unpatch2_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, (const bf16*)g, (bf16*)dx, B, OH, OW, C));
+  return (int)hipGetLastError();
+}
+int bn_reduce_blocks(int M) { int nb = (M + 255) / 256; return nb > 1024 ? 1024 : nb; }
+int launch_bn_reduce(const void* a, const void* z, const float* mean, const float* invstd, float* partial, int M, int C, int bwd, int dtype, hipStream_t s) {
+  const int nb = bn_reduce_blocks(M), rpb = (M + nb - 1) / nb;
+  if (dtype == 0) {
+    if (bwd) hipLaunchKernelGGL((bn_reduce_kernel<float, true>), dim3(nb), dim3(256), 0, s, (const float*)a, (const float*)z, mean, invstd, partial, M, C, rpb);
+    else hipLaunchKernelGGL((bn_reduce_kernel<float, false>), dim3(nb), dim3(256), 0, s, (const float*)a, (const float*)z, mean, invstd, partial, M, C, rpb);
+  } else {
+    if (bwd) hipLaunchKernelGGL((bn_reduce_kernel<bf16, true>), dim3(nb), dim3(256), 0, s, (const bf16*)a, (const bf16*)z, mean, invstd, partial, M, C, rpb);
+    else hipLaunchKernelGGL((bn_reduce_kernel<bf16, false>), dim3(nb), dim3(256), 0, s, (const bf16*)a, (const bf16*)z, mean, invstd, partial, M, C, rpb);
+  }
+  return (int)hipGetLastError();
+}
+int launch_bn_fwd_finalize(const float* partial, int M, int C, float eps, float momentum, const float* gamma, const float* beta, float* rmean, float* rvar,
+                           float* mean, float* invstd, float* sa, float* sb, hipStream_t s) {
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, bn_reduce_blocks(M), M, C, eps, momentum, gamma, beta, rmean, rvar, mean, invstd, sa, sb);
+  return (int)hipGetLastError();
+}
+int launch_bn_bwd_finalize(const float* partial, int M, int C, const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* ca, float* cb,
+                           float* cc, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, bn_reduce_blocks(M), M, C, gamma, invstd, dgamma, dbeta, ca, cb, cc);
+  return (int)hipGetLastError();
+}
+int launch_bn_apply(const void* z, const float* sa, const float* sb, const void* res, void* y, size_t M, int C, int act, int dtype, hipStream_t s) {
+  const size_t total = M * (C / 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, (const float*)z, sa, sb, (const float*)res, (float*)y, M, C, act),
+             hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, (const bf16*)z, sa, sb, (const bf16*)res, (bf16*)y, M, C, act));
+  return (int)hipGetLastError();
+}
+int launch_bn_act_bwd(const void* dout, const void* z, const float* sa, const float* sb, const void* res, void* g, size_t M, int C, int dtype, hipStream_t s) {
+  const size_t total = M * (C / 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_act_bwd_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, (const float*)dout, (const float*)z, sa, sb, (const float*)res, (float*)g, M, C),
+             hipLaunchKernelGGL(bn_act_bwd_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, (const bf16*)dout, (const bf16*)z, sa, sb, (const bf16*)res, (bf16*)g, M, C));
+  return (int)hipGetLastError();
+}
+int launch_bn_bwd_apply(const void* dy, const void* z, const float* mean, const float* invstd, const float* ca, const float* cb, const float* cc, void* dz,
+                        size_t M, int C, int dtype, hipStream_t s) {
+  const size_t total = M * (C / 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, (const float*)dy, (const float*)z, mean, invstd, ca, cb, cc, (float*)dz, M, C),
+             hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, (const bf16*)dy, (const bf16*)z, mean, invstd, ca, cb, cc, (bf16*)dz, M, C));
+  return (int)hipGetLastError();
+}
+int launch_gelu_fwd(const void* z, void* h, size_t n, int dtype, hipStream_t s) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gelu_fwd_kernel<float>, dim3(gs_grid(n / 4)), dim3(256), 0, s, (const float*)z, (float*)h, n / 4),
+             hipLaunchKernelGGL(gelu_fwd_kernel<bf16>, dim3(gs_grid(n / 4)), dim3(256), 0, s, (const bf16*)z, (bf16*)h, n / 4));
+  return (int)hipGetLastError();
+}
+int launch_gelu_bwd(const void* dh, const void* z, void* dz, size_t n, int dtype, hipStream_t s) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(gs_grid(n / 4)), dim3(256), 0, s, (const float*)dh, (const float*)z, (float*)dz, n / 4),
+             hipLaunchKernelGGL(gelu_bwd_kernel<bf16>, dim3(gs_grid(n / 4)), dim3(256), 0, s, (const bf16*)dh, (const bf16*)z, (bf16*)dz, n / 4));
+  return (int)hipGetLastError();
+}
+int launch_add_scaled(const void* a, const void* br, const float* scale, void* out, size_t n, size_t per_img, int dtype, hipStream_t s) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL(add_scaled_kernel<float>, dim3(gs_grid(n / 4)), dim3(256), 0, s, (const float*)a, (const float*)br, scale, (float*)out, n / 4, per_img / 4),
+             hipLaunchKernelGGL(add_scaled_kernel<bf16>, dim3(gs_grid(n / 4)), dim3(256), 0, s, (const bf16*)a, (const bf16*)br, scale, (bf16*)out, n / 4, per_img / 4));
+  return (int)hipGetLastError();
+}
+int launch_maxpool2_idx(const void* in, const float* pos, void* out, unsigned char* arg, int B, int OH, int OW, int C, int dtype, hipStream_t s) {
+  const size_t total = (size_t)B * OH * OW * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_idx_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, (const float*)in, pos, (float*)out, arg, B, OH, OW, C),
+             hipLaunchKernelGGL(maxpool2_idx_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, (const bf16*)in, pos, (bf16*)out, arg, B, OH, OW, C));
+  return (int)hipGetLastError();
+}
+int launch_maxpool2_bwd(const void* dout, const unsigned char* arg, void* din, int B, int OH, int OW, int C, int dtype, hipStream_t s) {
+  const size_t total = (size_t)B * OH * OW * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(maxpool2_bwd_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, (const float*)dout, arg, (float*)din, B, OH, OW, C),
+             hipLaunchKernelGGL(maxpool2_bwd_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, (const bf16*)dout, arg, (bf16*)din, B, OH, OW, C));
+  return (int)hipGetLastError();
+}
+int launch_avgpool_bwd(const float* dfeat, void* dx, int B, int HW, int C, int dtype, hipStream_t s) {
+  const size_t total = (size_t)B * HW * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, dfeat, (float*)dx, B, HW, C),
+             hipLaunchKernelGGL(avgpool_bwd_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, dfeat, (bf16*)dx, B, HW, C));
+  return (int)hipGetLastError();
+}
+int launch_batch_sum(const void* g, float* out, int B, size_t per_img, int dtype, hipStream_t s) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL(batch_sum_kernel<float>, dim3(gs_grid(per_img)), dim3(256), 0, s, (const float*)g, out, B, per_img),
+             hipLaunchKernelGGL(batch_sum_kernel<bf16>, dim3(gs_grid(per_img)), dim3(256), 0, s, (const bf16*)g, out, B, per_img));
+  return (int)hipGetLastError();
+}
+int launch_bcast_add(const void* x, const float* p, void* y, int B, size_t per_img, int dtype, hipStream_t s) {
+  const size_t n4 = (size_t)B * per_img / 4;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bcast_add_kernel<float>, dim3(gs_grid(n4)), dim3(256), 0, s, (const float*)x, p, (float*)y, n4, per_img / 4),
+             hipLaunchKernelGGL(bcast_add_kernel<bf16>, dim3(gs_grid(n4)), dim3(256), 0, s, (const bf16*)x, p, (bf16*)y, n4, per_img / 4));
+  return (int)hipGetLastError();
+}
+int launch_fill_f32(float* p, float v, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(gs_grid(n)), dim3(256), 0, s, p, v, n);
+  return (int)hipGetLastError();
+}
+int launch_scale_copy(const float* in, float* out, size_t n, float sc, hipStream_t s) {
+  hipLaunchKernelGGL(scale_copy_kernel, dim3(gs_grid(n)), dim3(256), 0, s, in, out, n, sc);
+  return (int)hipGetLastError();
+}
+int launch_colsum(const void* a, float* partial, float* out, int M, int C, int dtype, hipStream_t s) {
+  int rc = launch_bn_reduce(a, nullptr, nullptr, nullptr, partial, M, C, 0, dtype, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, bn_reduce_blocks(M), C, out);
+  return (int)hipGetLastError();
+}
+int launch_sgd(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, int first, hipStream_t s) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sgd_kernel, dim3(gs_grid(n)), dim3(256), 0, s, p, g, buf, n, lr, momentum, wd, first);
+  return (int)hipGetLastError();
+}
+
+}  // namespace fsvit

@@ -167,6 +167,96 @@ class VisformerEngine(_EncoderEngine):
         return c
 
 
+class VisformerTrainer:
+    """Train-mode Visformer (meta-tuning step, train_meta.py:161-177): forward with batch-statistics BN + DropPath
+    and saved activations, backward to all parameter gradients.  Parameters are read from (and running stats are
+    updated in) the caller's own fp32 cuda tensors every call - nothing is packed ahead of time."""
+
+    def __init__(self, cfg: dict, numerics: str = None, device=None):
+        self.lib = _lib.load()
+        numerics = numerics or default_numerics()
+        if numerics not in DTYPES:
+            raise ValueError(f'unknown numerics mode {numerics!r} (bf16 | parity)')
+        self.dtype = DTYPES[numerics]
+        self.device = torch.device(device if device is not None else 'cuda')
+        if self.device.type != 'cuda':
+            raise RuntimeError('VisformerTrainer needs a GPU device (no CPU fallback)')
+        self.cfg = dict(cfg)
+        self.out_dim = cfg['embed_dim'] * 2
+        c = VisformerEngine._make_cfg(None, cfg)
+        h = C.c_void_p()
+        _lib.check(self.lib.fsvit_visformer_trainer_create(C.byref(c), self.dtype, C.byref(h)))
+        self.h = h
+        self._ws = None
+        self._keep = None
+
+    def __del__(self):
+        h, self.h = getattr(self, 'h', None), None
+        if h:
+            try:
+                self.lib.fsvit_visformer_trainer_destroy(h)
+            except Exception:
+                pass
+
+    def n_droppath_calls(self, rate: float) -> int:
+        d = self.cfg['depth']
+        depth = sum(d)
+        n = 0
+        for b in range(depth):
+            if depth > 1 and rate * b / (depth - 1) > 0:
+                n += 1 if b < d[0] else 2
+        return n
+
+    @staticmethod
+    def _table(tensors: Dict[str, torch.Tensor], grads: Optional[Dict[str, torch.Tensor]]):
+        arr = (_lib.Param * len(tensors))()
+        keep = []
+        for i, (k, v) in enumerate(tensors.items()):
+            if v.dtype != torch.float32 or not v.is_contiguous() or not v.is_cuda:
+                raise ValueError(f'{k}: training tensors must be contiguous fp32 cuda tensors')
+            kb = k.encode()
+            keep.append(kb)
+            arr[i].name = kb
+            arr[i].data = v.data_ptr()
+            g = None if grads is None else grads.get(k)
+            arr[i].grad = g.data_ptr() if g is not None else None
+            arr[i].numel = v.numel()
+        return arr, keep
+
+    def forward(self, tensors: Dict[str, torch.Tensor], x: torch.Tensor, drop_path_rate: float = 0.0,
+                masks: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """tensors: encoder-relative name -> fp32 cuda tensor (parameters AND running stats);
+        x [B,3,H,W]; masks [n_droppath_calls, B] of 0/1.  Returns feat [B,out_dim]; activations stay in the workspace."""
+        _require_cuda(x)
+        x = x.contiguous().float()
+        B = x.shape[0]
+        arr, keep = self._table(tensors, None)
+        need = self.lib.fsvit_visformer_trainer_workspace_bytes(self.h, arr, len(tensors), B, float(drop_path_rate))
+        if need == 0:
+            _lib.check(_lib.ERR_KEY if 'missing' in self.lib.fsvit_last_error().decode() else _lib.ERR_ARG)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        feat = torch.empty(B, self.out_dim, dtype=torch.float32, device=x.device)
+        if masks is not None:
+            masks = masks.contiguous().float()
+        with torch.cuda.device(x.device):
+            _lib.check(self.lib.fsvit_visformer_train_forward(self.h, arr, len(tensors), _ptr(x), B, x.shape[2], x.shape[3],
+                                                              float(drop_path_rate), _ptr(masks), _ptr(feat), _ptr(self._ws),
+                                                              self._ws.numel(), _stream_ptr(x.device)))
+        self._keep = (x, masks)
+        return feat
+
+    def backward(self, tensors: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor], dfeat: torch.Tensor):
+        """Overwrites grads[name] (same shapes as tensors[name]) from dfeat [B,out_dim]."""
+        _require_cuda(dfeat)
+        dfeat = dfeat.contiguous().float()
+        arr, keep = self._table(tensors, grads)
+        with torch.cuda.device(dfeat.device):
+            _lib.check(self.lib.fsvit_visformer_train_backward(self.h, arr, len(tensors), _ptr(dfeat), _stream_ptr(dfeat.device)))
+        self._keep = None
+
+
 class VitEngine(_EncoderEngine):
     """cfg: dict(img_size, patch_size, embed_dim, depth, num_heads[, mlp_ratio, ln_eps]) (deit.py:142-144)."""
     _fn = dict(create='fsvit_vit_create', destroy='fsvit_vit_destroy', out_dim='fsvit_vit_out_dim',
@@ -254,6 +344,39 @@ class ops:
         with torch.cuda.device(x.device):
             _lib.check(lib.fsvit_pool_affine(_ptr(x), _ptr(scale), _ptr(shift), _ptr(out), B, HW, Cc, ops._dt(x), _stream_ptr(x.device)))
         return out
+
+    @staticmethod
+    def attention_backward(qkv, dctx, B, S, heads, hd, hdp, scale):
+        _require_cuda(qkv, dctx)
+        lib = _lib.load()
+        dqkv = torch.empty_like(qkv)
+        with torch.cuda.device(qkv.device):
+            _lib.check(lib.fsvit_attention_backward(_ptr(qkv), _ptr(dctx), _ptr(dqkv), B, S, heads, hd, hdp, float(scale),
+                                                    ops._dt(qkv), _stream_ptr(qkv.device)))
+        return dqkv
+
+    @staticmethod
+    def proto_head_backward(feat_shot, feat_query, dlogits, temp):
+        """-> dfeat_shot [E,way,shot,D], dfeat_query [E,Q,D], dtemp (scalar tensor); method 'cos'."""
+        _require_cuda(feat_shot, feat_query, dlogits)
+        lib = _lib.load()
+        E, way, shot, D = feat_shot.shape
+        Q = feat_query.shape[1]
+        dev = feat_shot.device
+        ds, dq = torch.empty_like(feat_shot), torch.empty_like(feat_query)
+        dt = torch.empty(E, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.fsvit_proto_head_backward(_ptr(feat_shot), _ptr(feat_query), _ptr(dlogits.contiguous().float()), E, way,
+                                                     shot, Q, D, float(temp), _ptr(ds), _ptr(dq), _ptr(dt), _stream_ptr(dev)))
+        return ds, dq, dt.sum()
+
+    @staticmethod
+    def sgd_step(param, grad, buf, lr, momentum, weight_decay, first_step):
+        _require_cuda(param, grad, buf)
+        lib = _lib.load()
+        with torch.cuda.device(param.device):
+            _lib.check(lib.fsvit_sgd_step(_ptr(param), _ptr(grad), _ptr(buf), param.numel(), float(lr), float(momentum),
+                                          float(weight_decay), int(bool(first_step)), _stream_ptr(param.device)))
 
     @staticmethod
     def proto_head(feat_shot, feat_query, temp, method='cos'):

@@ -25,12 +25,31 @@ class MetaBaseline(nn.Module):
         C-ABI call (fsvit_meta_baseline_forward)."""
         if self.method not in ('cos', 'sqr'):
             raise ValueError(self.method)
-        if self.training:
-            raise NotImplementedError(
-                'fsvit: the meta-training (backward) path is not built yet; call model.eval() '
-                '(train-mode BatchNorm statistics and gradients are scheduled after the eval path)')
         if x_shot.dim() != 6 or x_query.dim() != 5:
             raise ValueError('expected x_shot [E,way,shot,C,H,W] and x_query [E,Q,C,H,W]')
+        if self.training:
+            return self._forward_train(x_shot, x_query)
+        return self._forward_eval(x_shot, x_query)
+
+    def _forward_train(self, x_shot, x_query):
+        """The meta-tuning step's forward (train_meta.py:167): one encoder pass over shot + query images of all
+        episodes (so BatchNorm sees the whole batch, meta_baseline.py:31), then the differentiable cosine head."""
+        if self.method != 'cos':
+            raise NotImplementedError("fsvit: the training head is built for method 'cos' (every shipped config)")
+        if not hasattr(self.encoder, 'trainer'):
+            raise NotImplementedError('fsvit: the training path is built for the Visformer encoders')
+        from ..autograd import ProtoHeadFn
+        E, way, shot = x_shot.shape[:3]
+        Q = x_query.shape[1]
+        img = x_shot.shape[-3:]
+        x_tot = self.encoder(torch.cat([x_shot.reshape(-1, *img), x_query.reshape(-1, *img)], dim=0))
+        n_shot = E * way * shot
+        f_shot = x_tot[:n_shot].view(E, way, shot, -1)
+        f_query = x_tot[n_shot:].view(E, Q, -1)
+        temp = self.temp if isinstance(self.temp, torch.Tensor) else torch.tensor(float(self.temp), device=x_tot.device)
+        return ProtoHeadFn.apply(f_shot, f_query, temp)
+
+    def _forward_eval(self, x_shot, x_query):
         engine = self.encoder.engine()
         temp = float(self.temp.detach()) if isinstance(self.temp, torch.Tensor) else float(self.temp)
         return engine.meta_baseline_forward(x_shot, x_query, temp, self.method)

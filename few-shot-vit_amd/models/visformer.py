@@ -113,8 +113,10 @@ class Visformer(nn.Module):
                                             dpr[depth[0] + depth[1] + i]) for i in range(depth[2])])
         self.norm = _BatchNorm(embed_dim * 2)
         self._init_weights()
+        self.drop_path_rate = float(drop_path_rate)
         self._engine = None
         self._engine_key = None
+        self._trainer = None
 
     def _init_weights(self):
         """conv_init=True initialisation of the shipped factories (visformer.py:395-422)."""
@@ -145,14 +147,51 @@ class Visformer(nn.Module):
             self._engine_key = key
         return self._engine
 
-    def forward(self, x):
-        """[B,3,img,img] fp32 -> [B,out_dim] pooled features (visformer.py:424-462), eval mode."""
-        if self.training:
-            raise NotImplementedError('fsvit: train-mode Visformer (batch-stat BN, DropPath, backward) is not built yet; '
-                                      'call .eval()')
+    def trainer(self):
+        from ..engine import VisformerTrainer
+        dev = self.pos_embed1.device
+        if dev.type != 'cuda':
+            raise RuntimeError('fsvit: the encoder lives on %s; the HIP trainer needs an MI355X (no CPU fallback)' % dev)
+        if self._trainer is None or self._trainer.device != dev:
+            self._trainer = VisformerTrainer(self.cfg, numerics=self.numerics, device=dev)
+        return self._trainer
+
+    def draw_droppath_masks(self, n_img, device):
+        """The Bernoulli draws of every DropPath call with a non-zero rate, in call order:
+        floor(keep_prob + rand(B)) (visformer.py:93-95)."""
+        n = self.trainer().n_droppath_calls(self.drop_path_rate)
+        if n == 0:
+            return None
+        depth = self.cfg['depth']
+        rates = torch.linspace(0, self.drop_path_rate, sum(depth)).tolist()
+        rows = []
+        for b, r in enumerate(rates):
+            if r > 0:
+                for _ in range(1 if b < depth[0] else 2):
+                    rows.append((1.0 - r + torch.rand(n_img, device=device)).floor_())
+        return torch.stack(rows)
+
+    def forward(self, x, droppath_masks=None):
+        """[B,3,img,img] fp32 -> [B,out_dim] pooled features (visformer.py:424-462).
+        eval: packed engine (BN folded).  train: batch-statistics BN (running stats updated in place), DropPath, and a
+        backward through the HIP trainer; `droppath_masks` overrides the random draws (tests)."""
         assert x.shape[-2] == self.img_size and x.shape[-1] == self.img_size, \
             f"Input image size ({x.shape[-2]}*{x.shape[-1]}) does not match model ({self.img_size}*{self.img_size})."
-        return self.engine().forward(x)
+        if not self.training:
+            return self.engine().forward(x)
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d) and not m.training:
+                raise NotImplementedError('fsvit: freeze_bn (BatchNorm in eval mode inside a training step) is not built')
+        from ..autograd import VisformerTrainFn
+        named = [(k, p) for k, p in self.named_parameters()]
+        names = tuple(k for k, _ in named)
+        buffers = {k: b for k, b in self.named_buffers() if not k.endswith('num_batches_tracked')}
+        masks = droppath_masks if droppath_masks is not None else self.draw_droppath_masks(x.shape[0], x.device)
+        feat = VisformerTrainFn.apply(x, self.trainer(), names, buffers, self.drop_path_rate, masks, *[p for _, p in named])
+        for k, b in self.named_buffers():
+            if k.endswith('num_batches_tracked'):
+                b += 1
+        return feat
 
 
 @register('visformer_micro_80')

@@ -115,3 +115,49 @@ def mean_confidence_interval(data, confidence=0.95):
     n = len(a)
     se = scipy.stats.sem(a)
     return se * scipy.stats.t.ppf((1 + confidence) / 2., n - 1)
+
+
+class FsvitSGD(torch.optim.Optimizer):
+    """torch.optim.SGD(params, lr, momentum, weight_decay) semantics (no dampening / nesterov) with the update done by
+    the HIP kernel behind fsvit_sgd_step; exposes param_groups so MultiStepLR drives `lr` as in the reference."""
+
+    def __init__(self, params, lr, momentum=0.9, weight_decay=0.):
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from ..engine import ops
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                first = 'momentum_buffer' not in st
+                if first:
+                    st['momentum_buffer'] = torch.empty_like(p, memory_format=torch.contiguous_format)
+                data = p.data
+                if data.dim() == 0:
+                    data = data.view(1)
+                ops.sgd_step(data, p.grad.contiguous().view(-1), st['momentum_buffer'].view(-1), group['lr'], group['momentum'],
+                             group['weight_decay'], first)
+
+
+def make_optimizer(params, name, lr, weight_decay=None, milestones=None, gamma=0.1):
+    """utils/__init__.py:128-139 of the reference's meta_tuning_sun_m: SGD(momentum 0.9) or Adam, optional MultiStepLR."""
+    if weight_decay is None:
+        weight_decay = 0.
+    if name == 'sgd':
+        optimizer = FsvitSGD(params, lr, momentum=0.9, weight_decay=weight_decay)
+    elif name == 'adam':
+        optimizer = torch.optim.Adam(params, lr, weight_decay=weight_decay)
+    else:
+        raise ValueError(name)
+    lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(optimizer, milestones, gamma=gamma) if milestones else None
+    return optimizer, lr_scheduler
+
+
+def freeze_bn(model):
+    """utils/__init__.py:150-153; the HIP trainer does not implement frozen-BN training and says so at forward time."""
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()

@@ -157,6 +157,49 @@ int fsvit_maxpool2_pos(const void* in_dev, const float* pos_dev, void* out_dev, 
 int fsvit_pool_affine(const void* x_dev, const float* scale_dev, const float* shift_dev, float* feat_dev,
                       int B, int HW, int C, int dtype, void* stream);
 
+/* ---------------------------------------------------------------- meta-tuning step
+ * Replaces the encoder part of `model.train(); logits = model(x_shot, x_query); loss.backward(); optimizer.step()`
+ * (meta_tuning_sun_m/train_meta.py:161-177): train-mode Visformer forward (batch-statistics BatchNorm that also
+ * updates running_mean / running_var in place, momentum 0.1, visformer.py:53-64; DropPath visformer.py:89-96)
+ * with saved activations, and the backward to every parameter gradient.
+ * Parameters stay in the framework's own fp32 tensors ON THE DEVICE (they change every step):
+ *   name  reference state-dict key of the encoder ("stem.conv1.weight", "stage2.0.attn.qkv.weight", "norm.bn.running_var", ...)
+ *   data  device pointer, fp32, PyTorch layout;  grad  device pointer of the same shape that train_backward OVERWRITES
+ *         (NULL: not wanted; buffers such as running stats never get one). */
+typedef struct fsvit_param {
+  const char* name;
+  float* data;
+  float* grad;
+  int64_t numel;
+} fsvit_param;
+typedef struct fsvit_visformer_trainer fsvit_visformer_trainer;
+int fsvit_visformer_trainer_create(const fsvit_visformer_cfg* cfg, int dtype, fsvit_visformer_trainer** out);
+void fsvit_visformer_trainer_destroy(fsvit_visformer_trainer* t);
+/* bytes of workspace one forward+backward over n_img images needs (saved activations + temporaries) */
+size_t fsvit_visformer_trainer_workspace_bytes(fsvit_visformer_trainer* t, const fsvit_param* params, int n_params, int n_img,
+                                               float drop_path_rate);
+/* x_nchw_dev [n_img,3,H,W] fp32 -> feat_dev [n_img,out_dim] fp32.  masks_dev: the DropPath Bernoulli draws, one row of
+ * n_img 0/1 floats per DropPath call with a non-zero rate, in call order (stage-1 blocks: one call; stage-2/3 blocks: attn
+ * then mlp) - the caller draws them (floor(keep + rand), visformer.py:93-95) so the random stream stays the framework's.
+ * The workspace must stay untouched until train_backward returns. */
+int fsvit_visformer_train_forward(fsvit_visformer_trainer* t, const fsvit_param* params, int n_params, const float* x_nchw_dev,
+                                  int n_img, int img_h, int img_w, float drop_path_rate, const float* masks_dev, float* feat_dev,
+                                  void* ws_dev, size_t ws_bytes, void* stream);
+/* dfeat_dev [n_img,out_dim] fp32 -> every params[i].grad */
+int fsvit_visformer_train_backward(fsvit_visformer_trainer* t, const fsvit_param* params, int n_params, const float* dfeat_dev,
+                                   void* stream);
+/* Backward of fsvit_proto_head, method 'cos' (meta_baseline.py:33-47): dlogits [E,Q,way] -> dfeat_shot [E,way,shot,D],
+ * dfeat_query [E,Q,D], dtemp_per_episode [E] (sum it for the learnable temperature, meta_baseline.py:20-21). */
+int fsvit_proto_head_backward(const float* feat_shot_dev, const float* feat_query_dev, const float* dlogits_dev, int E, int way,
+                              int shot, int Q, int D, float temp, float* dfeat_shot_dev, float* dfeat_query_dev,
+                              float* dtemp_per_episode_dev, void* stream);
+/* torch.optim.SGD(momentum, weight_decay) update of one fp32 tensor (utils/__init__.py:127-139) */
+int fsvit_sgd_step(float* param_dev, const float* grad_dev, float* momentum_buf_dev, size_t n, float lr, float momentum,
+                   float weight_decay, int first_step, void* stream);
+/* Operator level of the training path: attention backward (qkv, dctx -> dqkv; hd real / hdp padded head dim). */
+int fsvit_attention_backward(const void* qkv_dev, const void* dctx_dev, void* dqkv_dev, int B, int S, int heads, int hd, int hdp,
+                             float scale, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,7 +56,11 @@ def test_no_cpu_fallback():
     m = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={}).eval()
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         m(torch.zeros(1, 5, 1, 3, 80, 80), torch.zeros(1, 75, 3, 80, 80))
-    m.train()
+    m.train()                      # the training step has no CPU path either
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(torch.zeros(1, 5, 1, 3, 80, 80), torch.zeros(1, 75, 3, 80, 80))
+    from fewshot_vit_amd import utils
+    utils.freeze_bn(m)             # frozen-BN training is not built: say so rather than train with the wrong statistics
     with pytest.raises(NotImplementedError):
         m(torch.zeros(1, 5, 1, 3, 80, 80), torch.zeros(1, 75, 3, 80, 80))
 

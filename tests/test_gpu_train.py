@@ -1,0 +1,245 @@
+"""Parity of the HIP meta-tuning step (meta_tuning_sun_m/train_meta.py:161-177): train-mode
+forward (batch-statistics BN, DropPath), loss.backward() and the SGD update, all through the C-ABI, against
+
+  * the reference's own training step on the tiny Visformer (tests/golden/tiny_train_step.npz), and
+  * torch.autograd of the oracle on visformer_micro_80 with the same seeded inputs and DropPath draws.
+
+Tolerances: `parity` numerics (fp32 storage + exact fp32 MFMA) must reproduce every parameter gradient to 1e-3 of
+its norm and the logits to the north_star 1e-3; the `bf16` throughput mode is bounded loosely and its measured
+deviation printed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(img_size=80, init_channels=8, embed_dim=64, depth=[2, 1, 2], num_heads=6, mlp_ratio=4., group=8)
+
+
+def _cpu_masks(seed, rates, depth0, n_img):
+    """The reference's DropPath draws from the CPU generator (visformer.py:93-95), in call order."""
+    torch.manual_seed(seed)
+    rows = []
+    for b, r in enumerate(rates):
+        if r > 0:
+            for _ in range(1 if b < depth0 else 2):
+                rows.append((1.0 - r + torch.rand((n_img, 1, 1, 1))).floor_().reshape(-1))
+    return torch.stack(rows) if rows else None
+
+
+def _make(encoder_kwargs, sd, numerics, drop_path_rate):
+    from fewshot_vit_amd.models.meta_baseline import MetaBaseline
+    from fewshot_vit_amd.models import register
+    from fewshot_vit_amd.models.visformer import Visformer
+    register('_test_visformer')(lambda **kw: Visformer(**encoder_kwargs, **kw))
+    m = MetaBaseline('_test_visformer', encoder_args={'numerics': numerics, 'drop_path_rate': drop_path_rate})
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().train()
+
+
+def _grad_check(named_grads, ref, rel_tol, what):
+    worst = 0.0
+    for k, g in named_grads.items():
+        r = ref[k]
+        scale = float(r.norm())
+        err = float((g.cpu() - r).norm())
+        rel = err / (scale + 1e-12)
+        if scale > 1e-7:
+            worst = max(worst, rel)
+            assert rel <= rel_tol, f'{what}: grad of {k}: rel err {rel:.3e} (norm {scale:.3e})'
+        else:
+            assert err <= 1e-5, f'{what}: grad of {k} should vanish, |g| = {err:.3e}'
+    return worst
+
+
+@pytest.mark.parametrize('numerics', ['parity', 'bf16'])
+def test_tiny_train_step_vs_reference_golden(golden_dir, numerics):
+    from fewshot_vit_amd import synthetic
+    from fewshot_vit_amd.utils import few_shot as fs
+    from oracle import visformer_oracle as vo
+    z = np.load(os.path.join(golden_dir, 'tiny_train_step.npz'))
+    cfg = vo.VisformerCfg(img_size=80, init_channels=8, embed_dim=64, depth=(2, 1, 2), num_heads=6, mlp_ratio=4.0, group=8)
+    shapes = vo.state_dict_shapes(cfg, prefix='encoder.')
+    shapes['temp'] = ()
+    sd = synthetic.procedural_state_dict(shapes)
+    for k in z.files:
+        if k.startswith('bnpre.'):
+            sd[k[len('bnpre.'):]] = torch.from_numpy(z[k])
+    m = _make(TINY, sd, numerics, 0.5)
+    x = synthetic.synthetic_episodes(33, 2, 3, 2, 2)
+    xs, xq = fs.split_shot_query(x, 3, 2, 2, 2)
+    label = torch.arange(3).repeat_interleave(2).repeat(2).cuda()
+    rates = torch.linspace(0, 0.5, 5).tolist()
+    masks = _cpu_masks(77, rates, 2, 24).cuda()
+    m.encoder.draw_droppath_masks = lambda n, dev: masks
+    logits = m(xs.cuda(), xq.cuda()).view(-1, 3)
+    loss = torch.nn.functional.cross_entropy(logits, label)
+    loss.backward()
+    torch.cuda.synchronize()
+    par = numerics == 'parity'
+    dl = np.abs(logits.detach().cpu().numpy() - z['logits']).max()
+    print(f'[{numerics}] tiny train step: |dloss| = {abs(float(loss) - float(z["loss"])):.3e}, max|dlogit| = {dl:.3e}')
+    assert dl <= (1e-3 if par else 0.3)
+    assert abs(float(loss) - float(z['loss'])) <= (1e-4 if par else 0.05)
+    n, worst = 0, 0.0
+    for k in z.files:
+        if k.startswith('grad.'):
+            name = k[5:]
+            g = dict(m.named_parameters())[name].grad.flatten().cpu()
+            got = g[::max(1, g.numel() // 256)][:256].numpy()
+            scale = float(z['gradnorm.' + name])
+            tol = (1e-3 if par else 0.12) * scale + 1e-6
+            e = np.abs(got - z[k]).max()
+            worst = max(worst, e / (scale + 1e-12)) if scale > 1e-6 else worst
+            assert e <= tol, (name, e, scale)
+            assert abs(float(g.norm()) - scale) <= tol, name
+            n += 1
+        elif k.startswith('bn.'):
+            got = m.state_dict()[k[3:]].cpu().numpy()
+            np.testing.assert_allclose(got, z[k], rtol=1e-3 if par else 5e-2, atol=1e-4 if par else 2e-2, err_msg=k)
+    assert n == 60
+    print(f'[{numerics}] tiny train step: worst sampled grad error / grad norm = {worst:.3e}')
+
+
+@pytest.mark.parametrize('numerics,drop', [('parity', 0.0), ('parity', 0.5), ('bf16', 0.5)])
+def test_micro_train_step_vs_oracle_autograd(numerics, drop):
+    """visformer_micro_80, 2 episodes x (5-way 1-shot + 10 queries) = 30 images: every gradient vs torch.autograd of the oracle."""
+    from fewshot_vit_amd import synthetic
+    from fewshot_vit_amd.utils import few_shot as fs
+    from oracle import visformer_oracle as vo
+    cfg = vo.VisformerCfg()
+    shapes = vo.state_dict_shapes(cfg, prefix='encoder.')
+    shapes['temp'] = ()
+    sd = synthetic.synthetic_checkpoint_sd(shapes)
+    x = synthetic.synthetic_episodes(5, 2, 5, 1, 2)
+    xs, xq = fs.split_shot_query(x, 5, 1, 2, 2)
+    n_img = 30
+    label = torch.arange(5).repeat_interleave(2).repeat(2)
+    rates = torch.linspace(0, drop, 9).tolist()
+    masks = _cpu_masks(123, rates, 4, n_img)
+    # oracle (CPU fp32 autograd)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))}
+    full = {k: v.clone() for k, v in sd.items()}
+    full.update(params)
+    stats = {}
+    ref_logits = vo.meta_baseline_forward(full, xs, xq, cfg, mode='train', drop_path_rate=drop,
+                                          droppath_masks=list(masks) if masks is not None else None, stats_out=stats).view(-1, 5)
+    ref_loss = torch.nn.functional.cross_entropy(ref_logits, label)
+    ref_loss.backward()
+    ref_grads = {k: p.grad.detach() for k, p in params.items()}
+    # HIP
+    m = _make(dict(img_size=80, init_channels=64, embed_dim=256, depth=[4, 2, 3], num_heads=6, mlp_ratio=4., group=8), sd, numerics, drop)
+    if masks is not None:
+        mc = masks.cuda()
+        m.encoder.draw_droppath_masks = lambda n, dev: mc
+    logits = m(xs.cuda(), xq.cuda()).view(-1, 5)
+    loss = torch.nn.functional.cross_entropy(logits, label.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    par = numerics == 'parity'
+    dl = float((logits.detach().cpu() - ref_logits.detach()).abs().max())
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    assert set(grads) == set(ref_grads)
+    worst = _grad_check(grads, ref_grads, 1e-3 if par else 0.15, numerics)
+    print(f'[{numerics} drop={drop}] micro train step: max|dlogit| = {dl:.3e}, |dloss| = {abs(float(loss) - float(ref_loss)):.3e}, '
+          f'worst grad rel err = {worst:.3e}')
+    assert dl <= (1e-3 if par else 0.3)
+    for k, v in stats.items():          # updated running statistics
+        got = m.state_dict()['encoder.' + k].cpu()
+        torch.testing.assert_close(got, v, rtol=1e-3 if par else 5e-2, atol=1e-4 if par else 2e-2, msg=k)
+    assert int(m.encoder.norm.bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('S,hd,hdp', [(100, 42, 48), (25, 85, 96), (25, 21, 32)])
+def test_attention_backward_vs_torch(dtype, S, hd, hdp):
+    from fewshot_vit_amd.engine import ops
+    if dtype == torch.bfloat16 and hdp % 32:
+        hdp = (hdp + 31) // 32 * 32
+    B, heads = 3, 6
+    g = torch.Generator().manual_seed(S * hd)
+    qkv = torch.zeros(B, S, 3, heads, hdp)
+    qkv[..., :hd] = torch.randn(B, S, 3, heads, hd, generator=g)
+    dctx = torch.zeros(B, S, heads, hdp)
+    dctx[..., :hd] = torch.randn(B, S, heads, hd, generator=g)
+    qkv_d = qkv.to(dtype).cuda()
+    dctx_d = dctx.to(dtype).cuda()
+    scale = hd ** -0.5
+    out = ops.attention_backward(qkv_d.view(B * S, -1), dctx_d.view(B * S, -1), B, S, heads, hd, hdp, scale)
+    torch.cuda.synchronize()
+    ref_in = qkv_d.float().cpu().requires_grad_(True)
+    q, k, v = ref_in[:, :, 0].transpose(1, 2), ref_in[:, :, 1].transpose(1, 2), ref_in[:, :, 2].transpose(1, 2)   # [B,heads,S,hdp]
+    p = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)
+    ctx = (p @ v).transpose(1, 2)                                                                              # [B,S,heads,hdp]
+    ctx.backward(dctx_d.float().cpu())
+    err = float((out.float().cpu().view_as(ref_in) - ref_in.grad).abs().max())
+    ref_max = float(ref_in.grad.abs().max())
+    print(f'attention_backward {dtype} S={S} hd={hd}: max err {err:.3e} (max |grad| {ref_max:.2f})')
+    assert err <= (2e-4 if dtype == torch.float32 else 2e-2) * max(1.0, ref_max)
+    assert float(out.float().view(B, S, 3, heads, hdp)[..., hd:].abs().max()) == 0.0     # padded head dims stay exact zeros
+
+
+def test_proto_head_backward_vs_torch():
+    from fewshot_vit_amd.engine import ops
+    E, way, shot, Q, D = 3, 5, 5, 15, 512
+    g = torch.Generator().manual_seed(9)
+    fs_ = torch.randn(E, way, shot, D, generator=g)
+    fq = torch.randn(E, Q, D, generator=g)
+    dl = torch.randn(E, Q, way, generator=g)
+    a, b = fs_.clone().requires_grad_(True), fq.clone().requires_grad_(True)
+    t = torch.tensor(10.0, requires_grad=True)
+    proto = torch.nn.functional.normalize(a.mean(dim=-2), dim=-1)
+    logits = torch.bmm(torch.nn.functional.normalize(b, dim=-1), proto.transpose(1, 2)) * t
+    logits.backward(dl)
+    ds, dq, dt = ops.proto_head_backward(fs_.cuda(), fq.cuda(), dl.cuda(), 10.0)
+    torch.cuda.synchronize()
+    assert float((ds.cpu() - a.grad).abs().max()) <= 1e-5 * float(a.grad.abs().max()) + 1e-7
+    assert float((dq.cpu() - b.grad).abs().max()) <= 1e-5 * float(b.grad.abs().max()) + 1e-7
+    assert abs(float(dt) - float(t.grad)) <= 1e-4 * abs(float(t.grad)) + 1e-6
+
+
+def test_sgd_step_matches_torch_optim():
+    """torch.optim.SGD(momentum=0.9, weight_decay) semantics of utils.make_optimizer (utils/__init__.py:128-132)."""
+    from fewshot_vit_amd.engine import ops
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(10007, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([ref], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    p, buf = p0.clone().cuda(), torch.zeros(10007).cuda()
+    for step in range(3):
+        gr = torch.randn(10007, generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        ops.sgd_step(p, gr.cuda(), buf, 0.01, 0.9, 5e-4, step == 0)
+    torch.cuda.synchronize()
+    assert float((p.cpu() - ref.detach()).abs().max()) <= 1e-6
+
+
+def test_training_loop_reduces_loss_and_eval_follows():
+    """train_meta.py:155-177 shape: model.train(); loss.backward(); optimizer.step() repeated on one batch of episodes
+    drives the loss down; the eval engine then repacks from the updated weights."""
+    from fewshot_vit_amd import models, synthetic, utils
+    from fewshot_vit_amd.utils import few_shot as fs
+    m = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={'drop_path_rate': 0.1, 'numerics': 'bf16'}).cuda()
+    opt, _ = utils.make_optimizer(m.parameters(), 'sgd', lr=0.01, weight_decay=5e-4)
+    x = synthetic.synthetic_episodes(3, 2, 5, 1, 3).cuda()
+    xs, xq = fs.split_shot_query(x, 5, 1, 3, 2)
+    label = fs.make_nk_label(5, 3, 2).cuda()
+    losses = []
+    m.train()
+    for it in range(6):
+        logits = m(xs, xq).view(-1, 5)
+        loss = torch.nn.functional.cross_entropy(logits, label)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    print('losses', ['%.4f' % v for v in losses])
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0]
+    m.eval()
+    with torch.no_grad():
+        lg = m(xs, xq)
+    assert torch.isfinite(lg).all()
