@@ -155,7 +155,7 @@ int conv_bwd_data(TR* t, const ConvSpec& c, const void* dz, int B, int OH, int O
 int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, const void* dz) {
   const fsvit_param* w = getp(t, c.wname);
   if (!w) return FSVIT_ERR_KEY;
-  if (!w->grad) return 0;
+  if (!w->grad && !t->save.dry) return 0;      // (the sizing pass always counts the weight-gradient scratch)
   const int OH = c.via_patches ? H : (H + 2 * c.pad - c.KH) / c.stride + 1, OW = c.via_patches ? W : (W + 2 * c.pad - c.KW) / c.stride + 1;
   const int M = B * OH * OW;
   int splits = (M + 16383) / 16384;
@@ -451,14 +451,14 @@ int train_backward_impl(TR* t, const float* dfeat) {
     {
       const fsvit_param *bias = getp(t, pn + "proj.bias"), *pos = getp(t, "pos_embed" + std::to_string(sg));
       if (!bias || !pos) return FSVIT_ERR_KEY;
-      if (pos->grad) {
+      if (pos->grad || t->save.dry) {
         float* ps = (float*)t->tmp.take((size_t)Ho * Ho * C * 4); NEED(ps);
         T_RUN(launch_batch_sum(dx, ps, B, (size_t)Ho * Ho * C, dt, st));
         T_RUN(launch_transpose_cols(ps, pos->grad, Ho * Ho, C, 0, C, Ho * Ho, 0, st));         // [HW][C] -> [C][HW]
       }
       void* dz = take_tmp(t, M * C); NEED(dz);
       T_TRY(bn_bwd(t, pn + "norm.bn", pe.bn, dx, dz));
-      if (bias->grad) {
+      if (bias->grad || t->save.dry) {
         float* partial = (float*)t->tmp.take((size_t)bn_reduce_blocks((int)M) * 2 * C * 4); NEED(partial);
         T_RUN(launch_colsum(dz, partial, bias->grad, (int)M, C, dt, st));
       }
@@ -506,7 +506,7 @@ int train_backward_impl(TR* t, const float* dfeat) {
     auto& S = t->stem;
     const fsvit_param* pos = getp(t, "pos_embed1");
     if (!pos) return FSVIT_ERR_KEY;
-    if (pos->grad) {
+    if (pos->grad || t->save.dry) {
       float* ps = (float*)t->tmp.take((size_t)H1 * H1 * t->C1 * 4); NEED(ps);
       T_RUN(launch_batch_sum(dx, ps, B, (size_t)H1 * H1 * t->C1, dt, st));
       T_RUN(launch_transpose_cols(ps, pos->grad, H1 * H1, t->C1, 0, t->C1, H1 * H1, 0, st));
