@@ -48,6 +48,10 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-episodes', type=int, default=16)
     ap.add_argument('--layers', action='store_true', help='print the per-layer timing table to stderr')
+    ap.add_argument('--mode', default='eval', choices=['eval', 'train'],
+                    help="eval = BASELINE configs[1] (the headline metric); train = configs[2], one SUN-M meta-tuning step "
+                         "(train_meta_mini_visformer_5shot.yaml geometry: 8 episodes x 10-way (5 shot + 5 query) = 800 images)")
+    ap.add_argument('--train-episodes', type=int, default=8, help='train mode: episodes per GPU per step (ep_per_batch)')
     return ap.parse_args()
 
 
@@ -95,6 +99,96 @@ def cpu_baseline(sd, shot, n_ep, model='visformer_micro_80'):
                       f'oracle, 2 warm-up episodes, {dt:.1f} s'}
 
 
+def cpu_train_baseline(sd, n_ep=1):
+    """Oracle training step (train-mode forward + torch.autograd backward) on the host cores: 1 episode of the step's 8."""
+    from fewshot_vit_amd import synthetic
+    from fewshot_vit_amd.utils import few_shot as fs
+    from oracle import visformer_oracle as vo
+    cfg = vo.VisformerCfg()
+    x = synthetic.synthetic_episodes(12345, n_ep, 10, 5, 5)
+    xs, xq = fs.split_shot_query(x, 10, 5, 5, n_ep)
+    label = fs.make_nk_label(10, 5, n_ep)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))}
+    full = {k: v.clone() for k, v in sd.items()}
+    full.update(params)
+
+    def run():
+        for p in params.values():
+            p.grad = None
+        logits = vo.meta_baseline_forward(full, xs, xq, cfg, mode='train', drop_path_rate=0.5).view(-1, 10)
+        torch.nn.functional.cross_entropy(logits, label).backward()
+    run()
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        run()
+    dt = time.perf_counter() - t0
+    return {'value': reps * n_ep / dt, 'unit': 'episodes/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{reps} x forward+backward of {n_ep} episode(s) 10-way 5-shot 5-query (100 images each), fp32 torch CPU oracle '
+                      f'with autograd, no optimizer step, 1 warm-up, {dt:.1f} s'}
+
+
+def train_main(args, rank, world, dev):
+    """BASELINE configs[2]: one meta-tuning step = model.train() forward, CE, backward, (grad all-reduce), SGD step."""
+    from fewshot_vit_amd import models, synthetic, utils, parallel
+    from fewshot_vit_amd.utils import few_shot as fs
+    model = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={'numerics': args.numerics, 'drop_path_rate': 0.5})
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = synthetic.synthetic_checkpoint_sd(shapes, calib='visformer_micro_80')
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).train()
+    opt, _ = utils.make_optimizer(model.parameters(), 'sgd', lr=0.001, weight_decay=5e-4)
+    way, shot, query, E = 10, 5, 5, args.train_episodes
+    x_shot, x_query = device_episodes(999 + rank, E, way, shot, query, dev, 80)
+    label = fs.make_nk_label(way, query, E).to(dev)
+
+    def step():
+        logits = model(x_shot, x_query).view(-1, way)
+        loss = torch.nn.functional.cross_entropy(logits, label)
+        opt.zero_grad()
+        loss.backward()
+        if world > 1:
+            parallel.allreduce_mean_grads(model.parameters())
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        imgs = way * (shot + query)
+        eps = world * E * args.steps / elapsed
+        flops_ep = 3.0 * MODELS['visformer_micro_80'][0] * imgs          # forward + dgrad + wgrad
+        peak = MFMA_PEAK_TFLOPS['bf16' if args.numerics == 'bf16' else 'f32']
+        out = {'metric': 'train_episodes_per_sec_10way_5shot_visformer_s', 'value': eps, 'unit': 'episodes/s', 'n_gpus': world,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.numerics == 'bf16' else 'f32', 'data': 'synthetic',
+               'config': {'workload': 'BASELINE configs[2]: SUN-M train_meta.py meta-tuning step, Visformer-S (visformer_micro_80, '
+                                      'drop_path 0.5), ep_per_batch episodes of 10-way 5-shot 5-query 80x80 (train_meta_mini_visformer_5shot.yaml), '
+                                      'forward + CE + backward + SGD(0.9, wd 5e-4), episodes resident in HBM',
+                          'episodes_per_step_per_gpu': E, 'images_per_episode': imgs,
+                          'parallelism': 'episode axis sharded x%d, one all-reduce of the flattened gradients per step' % world},
+               'whole_path_tflops': eps * flops_ep / 1e12, 'whole_path_mfma_frac': eps * flops_ep / 1e12 / peak,
+               'final_loss': float(loss)}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_train_baseline(sd)
+        print(json.dumps(out))
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', 0))
@@ -111,6 +205,12 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+
+    if args.mode == 'train':
+        train_main(args, rank, world, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from fewshot_vit_amd import models, synthetic
     os.environ['FSVIT_CHUNK'] = str(args.chunk)

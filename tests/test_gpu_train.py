@@ -250,3 +250,27 @@ def test_training_loop_reduces_loss_and_eval_follows():
     with torch.no_grad():
         lg = m(xs, xq)
     assert torch.isfinite(lg).all()
+
+
+def test_train_meta_driver_one_epoch(tmp_path):
+    """The train_meta.py surface end to end on a small schedule: train batches, tval/val episodes in eval mode, the
+    reference's checkpoint schema (train_meta.py:241-257) readable by models.load, MultiStepLR stepping."""
+    from fewshot_vit_amd import models, train_meta
+    config = dict(train_dataset='synthetic-episodes', train_dataset_args=dict(split='train', n_classes=12, n_per_class=30, noise=1.0, seed=1),
+                  tval_dataset='synthetic-episodes', tval_dataset_args=dict(split='test', n_classes=6, n_per_class=30, noise=1.0, seed=0),
+                  val_dataset='synthetic-episodes', val_dataset_args=dict(split='val', n_classes=6, n_per_class=30, noise=1.0, seed=2),
+                  model='meta-baseline', model_args=dict(encoder='visformer_micro_80', encoder_args=dict(drop_path_rate=0.5)),
+                  synthetic_checkpoint='visformer_micro_80', n_train_way=5, n_train_shot=1, n_train_query=3, n_way=5, n_shot=1, n_query=15,
+                  train_batches=3, eval_batches=2, ep_per_batch=2, max_epoch=2, optimizer='sgd',
+                  optimizer_args=dict(lr=0.001, weight_decay=5e-4, gamma=0.5, milestones=[1]), save_epoch=1)
+    lines = []
+    trlog = train_meta.main(config, name='t', device=torch.device('cuda', 0), log=lines.append, save_root=str(tmp_path))
+    assert len(trlog['tl']) == 2 and all(np.isfinite(trlog[k]).all() for k in trlog)
+    assert any(l.startswith('epoch 2, train') for l in lines)
+    for f in ('epoch-last.pth', 'epoch-1.pth', 'epoch-2.pth', 'max-va.pth', 'trlog.pth', 'config.yaml'):
+        assert os.path.exists(os.path.join(str(tmp_path), 't', f)), f
+    ck = torch.load(os.path.join(str(tmp_path), 't', 'epoch-last.pth'), map_location='cpu')
+    assert ck['training']['epoch'] == 2 and ck['model'] == 'meta-baseline'
+    assert ck['training']['optimizer_sd']['param_groups'][0]['lr'] == pytest.approx(0.0005)      # one milestone passed
+    m = models.load(ck)
+    assert m.encoder.out_dim == 512

@@ -61,3 +61,59 @@ def test_two_rank_gather_matches_single_process(n_batch):
         assert mean == pytest.approx(ref[:, 0].mean(), abs=1e-12)
         assert var == pytest.approx(ref[:, 0].var(ddof=1), abs=1e-12)
         assert ci == pytest.approx(float(utils.mean_confidence_interval(ref[:, 0].tolist())), abs=1e-12)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from fewshot_vit_amd import parallel
+    from fewshot_vit_amd.datasets.samplers import CategoriesSampler
+    parallel.init_from_env(backend='gloo')
+    params, data, loss_fn = _toy_problem()
+    label = np.repeat(np.arange(20), 600).tolist()
+    np.random.seed(1)
+    idx = next(iter(CategoriesSampler(label, 1, 5, 4, ep_per_batch=4)))              # same stream on every rank
+    mine = parallel.shard_episode_axis(idx, 4, rank, world)
+    loss_fn(params, data[mine % len(data)].view(4 // world, -1, data.shape[1])).backward()
+    parallel.allreduce_mean_grads(params)
+    q.put((rank, [p.grad.numpy().copy() for p in params], mine.tolist()))
+    dist.destroy_process_group()
+
+
+def _toy_problem():
+    g = torch.Generator().manual_seed(0)
+    params = [torch.randn(6, 3, generator=g).requires_grad_(True), torch.randn(3, generator=g).requires_grad_(True)]
+    data = torch.randn(64, 6, generator=g)
+
+    def loss_fn(ps, x):                 # x [episodes, items, 6]: per-episode mean loss, averaged over the episodes
+        return ((x @ ps[0] + ps[1]).tanh() ** 2).mean(dim=(1, 2)).mean()
+    return params, data, loss_fn
+
+
+def test_two_rank_gradient_allreduce_matches_single_process_step():
+    """train_meta.py data parallelism: ranks keep slices of the batch's episode axis; the all-reduced mean of their
+    gradients equals the gradient of the whole batch's mean loss."""
+    from fewshot_vit_amd import parallel
+    from fewshot_vit_amd.datasets.samplers import CategoriesSampler
+    params, data, loss_fn = _toy_problem()
+    label = np.repeat(np.arange(20), 600).tolist()
+    np.random.seed(1)
+    idx = next(iter(CategoriesSampler(label, 1, 5, 4, ep_per_batch=4)))
+    assert torch.equal(torch.cat([parallel.shard_episode_axis(idx, 4, r, 2) for r in range(2)]), idx)
+    with pytest.raises(ValueError):
+        parallel.shard_episode_axis(idx, 4, 0, 3)
+    loss_fn(params, data[idx % len(data)].view(4, -1, data.shape[1])).backward()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, grads, mine in results:
+        for g, p in zip(grads, params):
+            np.testing.assert_allclose(g, p.grad.numpy(), rtol=1e-6, atol=1e-7)
