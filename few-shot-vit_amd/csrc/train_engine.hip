@@ -152,36 +152,40 @@ int conv_bwd_data(TR* t, const ConvSpec& c, const void* dz, int B, int OH, int O
 }
 
 // ---------------------------------------------------------------- weight gradient: dW = sum_m dz[m] (x) xcol[m]   (split-K GEMM over transposed operands)
+// A grouped conv is computed as ONE dense GEMM over all channels (the cross-group blocks are discarded by the finalize
+// pass): 8 x the useful FLOPs of the stage-1 3x3 conv, but one full-width launch instead of 8 quarter-empty ones.
 int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, const void* dz) {
   const fsvit_param* w = getp(t, c.wname);
   if (!w) return FSVIT_ERR_KEY;
   if (!w->grad && !t->save.dry) return 0;      // (the sizing pass always counts the weight-gradient scratch)
   const int OH = c.via_patches ? H : (H + 2 * c.pad - c.KH) / c.stride + 1, OW = c.via_patches ? W : (W + 2 * c.pad - c.KW) / c.stride + 1;
   const int M = B * OH * OW;
-  int splits = (M + 16383) / 16384;
-  if (splits > 64) splits = 64;
-  const int Ks = round_up((M + splits - 1) / splits, 64), Mpad = splits * Ks;
-  const int Ng_pad = c.rows_fwd(), Kc_pad = round_up(c.kpad_cols(), 4);
-  const int ldz = c.groups * Ng_pad;
+  const int rows = c.groups * c.rows_fwd();                                     // all output channels (padded)
   const int Cin_tot = c.via_patches ? 32 : c.groups * (c.kpad_cols() / (c.KH * c.KW));
+  const int Kc_pad = c.via_patches ? 32 : round_up(c.KH * c.KW * Cin_tot, 4);
+  const int tiles = ((rows + 127) / 128) * ((Kc_pad + 127) / 128);
+  int splits = (1024 + tiles - 1) / tiles;
+  if (splits > 64) splits = 64;
+  if (splits > M / 512) splits = M / 512;
+  if (splits < 1) splits = 1;
+  const int Ks = round_up((M + splits - 1) / splits, 64), Mpad = splits * Ks;
   const size_t tmp_mark = t->tmp.off;
-  void* dzt = t->tmp.take((size_t)Ng_pad * Mpad * t->es);
+  void* dzt = t->tmp.take((size_t)rows * Mpad * t->es);
   void* xct = t->tmp.take((size_t)Kc_pad * Mpad * t->es);
-  float* ysp = (float*)t->tmp.take((size_t)round_up(Ng_pad, 4) * splits * Kc_pad * 4);
+  float* ysp = (float*)t->tmp.take((size_t)round_up(rows, 4) * splits * Kc_pad * 4);
   if (!dzt || !xct || !ysp) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (wgrad)");
-  for (int g = 0; g < c.groups; ++g) {
-    T_RUN(launch_transpose_cols(dz, dzt, M, ldz, g * Ng_pad, Ng_pad, Mpad, t->dtype, t->st));
-    if (c.via_patches) T_RUN(launch_transpose_cols(x, xct, M, 32, 0, 32, Mpad, t->dtype, t->st));
-    else {
-      const int Cg = c.kpad_cols() / (c.KH * c.KW);
-      T_RUN(launch_im2col_t(x, xct, B, H, W, Cin_tot, g * Cg, Cg, c.KH, c.KW, c.stride, c.pad, OH, OW, Mpad, t->dtype, t->st));
-    }
-    // Y[n][s*Kc_pad + k] = sum_{m in split s} dzt[n][m] * xct[k][m]
-    ConvGemmParams p = gemm_params(dzt, xct, ysp, 1, Ng_pad, 1, Ks, Mpad, 1, 1, 1, 0, Kc_pad, splits * Kc_pad, Ks, Ks, splits);
-    p.w_gstride = Ks; p.w_rstride = Mpad; p.out_f32 = 1;
-    T_RUN(launch_conv_gemm(p, t->dtype, t->st));
+  T_RUN(launch_transpose_cols(dz, dzt, M, rows, 0, rows, Mpad, t->dtype, t->st));
+  if (c.via_patches) T_RUN(launch_transpose_cols(x, xct, M, 32, 0, 32, Mpad, t->dtype, t->st));
+  else T_RUN(launch_im2col_t(x, xct, B, H, W, Cin_tot, 0, Cin_tot, c.KH, c.KW, c.stride, c.pad, OH, OW, Mpad, t->dtype, t->st));
+  // Y[n][s*Kc_pad + k] = sum_{m in split s} dzt[n][m] * xct[k][m]
+  ConvGemmParams p = gemm_params(dzt, xct, ysp, 1, rows, 1, Ks, Mpad, 1, 1, 1, 0, Kc_pad, splits * Kc_pad, Ks, Ks, splits);
+  p.w_gstride = Ks; p.w_rstride = Mpad; p.out_f32 = 1;
+  T_RUN(launch_conv_gemm(p, t->dtype, t->st));
+  if (c.groups > 1)
+    T_RUN(launch_wgrad_finalize_dense(ysp, w->grad, c.O / c.groups, c.Ig, c.KH, c.KW, c.groups, splits, Kc_pad, t->st));
+  else {
     const int KHf = c.via_patches ? 3 : c.KH, KWf = c.via_patches ? 3 : c.KW;
-    T_RUN(launch_wgrad_finalize(ysp, w->grad, c.O / c.groups, c.Ig, KHf, KWf, g, splits, Kc_pad, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols, t->st));
+    T_RUN(launch_wgrad_finalize(ysp, w->grad, c.O, c.Ig, KHf, KWf, 0, splits, Kc_pad, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols, t->st));
   }
   t->tmp.off = tmp_mark;
   return 0;

@@ -9,6 +9,8 @@ int launch_pack_weight(const float* w, void* out, int O, int Ig, int KH, int KW,
                        int hd_cols, int hdp_cols, int dtype, hipStream_t s);
 int launch_wgrad_finalize(const float* y, float* dw, int Ng, int Ig, int KH, int KW, int g, int splits, int Kc_pad, int hd_rows, int hdp_rows, int hd_cols,
                           int hdp_cols, hipStream_t s);
+// grouped conv via one dense GEMM: keeps the diagonal (same-group) blocks
+int launch_wgrad_finalize_dense(const float* y, float* dw, int Ng, int Ig, int KH, int KW, int groups, int splits, int Kc_pad, hipStream_t s);
 int launch_transpose_cols(const void* in, void* out, int M, int ld, int c0, int ncols, int Mpad, int dtype, hipStream_t s);
 int launch_im2col_t(const void* x, void* out, int B, int H, int W, int ld, int c0, int C, int KH, int KW, int stride, int pad, int OH, int OW, int Mpad,
                     int dtype, hipStream_t s);

@@ -79,6 +79,24 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
   }
 }
 
+// Grouped conv computed as ONE dense split-K GEMM (all cross-group products included, only the diagonal blocks are kept):
+// y[groups*Ng][splits * Kc_pad] with k = (ky*KW + kx) * (groups*Ig) + g*Ig + i  ->  dW[groups*Ng][Ig][KH][KW]
+__global__ __launch_bounds__(256) void wgrad_finalize_dense_kernel(const float* __restrict__ y, float* __restrict__ dw, int Ng, int Ig, int KH, int KW,
+                                                                   int groups, int splits, int Kc_pad) {
+  const size_t total = (size_t)groups * Ng * Ig * KH * KW;
+  GS_LOOP(idx, total) {
+    const int kx = (int)(idx % KW);
+    size_t t2 = idx / KW;
+    const int ky = (int)(t2 % KH); t2 /= KH;
+    const int i = (int)(t2 % Ig);
+    const int o = (int)(t2 / Ig), g = o / Ng;
+    const int k = (ky * KW + kx) * (groups * Ig) + g * Ig + i;
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += y[(size_t)o * splits * Kc_pad + (size_t)sp * Kc_pad + k];
+    dw[idx] = s;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ transposes for wgrad
 // in [M][ld] (columns c0 .. c0+ncols) -> out [ncols][Mpad], zero for m >= M.  32x32 LDS tile transpose.
 template <typename T>
@@ -127,6 +145,53 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const T* __restrict__ x, 
   }
 }
 
+// Vectorised 64 x 64 tile transposes (8/16-byte accesses on both sides): require ld, c0, ncols, Mpad % 4 == 0.
+// `row_src(m)` gives the source row of output column m (or -1 for zero fill).
+template <typename T, typename RowFn>
+__device__ __forceinline__ void transpose_tile64(const T* __restrict__ in, T* __restrict__ out, int ld, int c0, int ncols, int Mpad, size_t out_row0,
+                                                 int mt, int ct, RowFn row_src) {
+  __shared__ float tile[64][65];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // 16 channel quads x 16 rows
+#pragma unroll
+  for (int r = 0; r < 64; r += 16) {
+    const int m = mt + ty + r, c = ct + tx * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < ncols) {
+      const long src = row_src(m);
+      if (src >= 0) v = load4<T>(in + (size_t)src * ld + c0 + c);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[tx * 4 + e][ty + r] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 64; r += 16) {
+    const int c = ct + ty + r, m = mt + tx * 4;
+    if (c < ncols && m < Mpad) {
+      const f32x4 v = {tile[ty + r][tx * 4], tile[ty + r][tx * 4 + 1], tile[ty + r][tx * 4 + 2], tile[ty + r][tx * 4 + 3]};
+      store4<T>(out + (out_row0 + c) * (size_t)Mpad + m, v);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_cols_v4_kernel(const T* __restrict__ in, T* __restrict__ out, int M, int ld, int c0, int ncols, int Mpad) {
+  transpose_tile64<T>(in, out, ld, c0, ncols, Mpad, 0, blockIdx.x * 64, blockIdx.y * 64, [&](int m) -> long { return m < M ? m : -1; });
+}
+
+// x NHWC [B,H,W,ld] (channels c0 .. c0+C) -> out [(ky*KW+kx)*C + c][Mpad], m = (b, oy, ox); zero outside the image / m >= M
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_t_v4_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int ld, int c0, int C,
+                                                          int KH, int KW, int stride, int pad, int OH, int OW, int Mpad) {
+  const int tap = blockIdx.z, ky = tap / KW, kx = tap % KW, M = B * OH * OW;
+  transpose_tile64<T>(x, out, ld, c0, C, Mpad, (size_t)tap * C, blockIdx.x * 64, blockIdx.y * 64, [&](int m) -> long {
+    if (m >= M) return -1;
+    const int b = m / (OH * OW), rem = m % (OH * OW), oy = rem / OW, ox = rem % OW;
+    const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+    return ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? ((long)(b * H + iy) * W + ix) : -1;
+  });
+}
+
 // k2s2 dgrad scatter: g [B*OH*OW][4*C] with k = (ky*2+kx)*C + c  ->  dx [B, 2*OH, 2*OW, C]
 template <typename T>
 __global__ __launch_bounds__(256) void unpatch2_kernel(const T* __restrict__ g, T* __restrict__ dx, int B, int OH, int OW, int C) {
@@ -143,22 +208,47 @@ __global__ __launch_bounds__(256) void unpatch2_kernel(const T* __restrict__ g, 
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm (train)
-// partial[blk][2][C]: per-block sums of z and z^2 (or of dy and dy*xhat in the backward form) over a row range
+// partial[blk][2][C]: per-block sums of z and z^2 (or of dy and dy*xhat in the backward form) over an interleaved row set.
+// 256 threads = LC channel lanes (4 channels each, 8/16-byte loads) x R row lanes; rows r = blk*R + rl, += gridDim*R.
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ a, const T* __restrict__ z, const float* __restrict__ mean,
-                                                        const float* __restrict__ invstd, float* __restrict__ partial, int M, int C, int rows_per_block) {
-  const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s0 = 0.f, s1 = 0.f;
-    const float mu = BWD ? mean[c] : 0.f, is = BWD ? invstd[c] : 0.f;
-    for (int m = r0; m < r1; ++m) {
-      const float v = to_f32<T>(a[(size_t)m * C + c]);
-      if (BWD) { s0 += v; s1 += v * (to_f32<T>(z[(size_t)m * C + c]) - mu) * is; }
-      else { s0 += v; s1 += v * v; }
+                                                        const float* __restrict__ invstd, float* __restrict__ partial, int M, int C) {
+  __shared__ f32x4 red[2][256];
+  const int lanesC = C >> 2;
+  const int LC = lanesC < 256 ? lanesC : 256, R = 256 / LC;
+  const int cl = threadIdx.x % LC, rl = threadIdx.x / LC;
+  const bool live = rl < R;
+  for (int cv = cl; cv < lanesC; cv += LC) {            // (one pass for C <= 1024)
+    const int c = cv * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, mu = s0, is = s0;
+    if (BWD) { mu = *reinterpret_cast<const f32x4*>(mean + c); is = *reinterpret_cast<const f32x4*>(invstd + c); }
+    if (live) {
+      for (size_t m = (size_t)blockIdx.x * R + rl; m < (size_t)M; m += (size_t)gridDim.x * R) {
+        const f32x4 v = load4<T>(a + m * C + c);
+        s0 += v;
+        if (BWD) s1 += v * (load4<T>(z + m * C + c) - mu) * is;
+        else s1 += v * v;
+      }
     }
-    partial[((size_t)blockIdx.x * 2 + 0) * C + c] = s0;
-    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = s1;
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (rl == 0) {
+      for (int r = 1; r < R; ++r) { s0 += red[0][r * LC + cl]; s1 += red[1][r * LC + cl]; }
+      *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 0) * C + c) = s0;
+      *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 1) * C + c) = s1;
+    }
+    __syncthreads();
   }
+}
+
+// sum of the per-block partials of one channel: 8 threads per channel (32 channels per block), fp64 accumulation
+__device__ __forceinline__ void bn_partial_sums(const float* __restrict__ partial, int nblk, int C, int c, int sub, double& s0, double& s1) {
+  s0 = 0.0; s1 = 0.0;
+  if (c < C)
+    for (int b = sub; b < nblk; b += 8) { s0 += partial[((size_t)b * 2 + 0) * C + c]; s1 += partial[((size_t)b * 2 + 1) * C + c]; }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
 }
 
 // forward finalize: mean / invstd (biased variance), scale/shift for the apply pass, running-stat update (momentum, unbiased var)
@@ -166,10 +256,10 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
                                                               float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ sa, float* __restrict__ sb) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int b = 0; b < nblk; ++b) { s0 += partial[((size_t)b * 2 + 0) * C + c]; s1 += partial[((size_t)b * 2 + 1) * C + c]; }
+  const int c = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+  double s0, s1;
+  bn_partial_sums(partial, nblk, C, c, sub, s0, s1);
+  if (c >= C || sub) return;
   const double mu = s0 / M;
   double var = s1 / M - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -188,10 +278,10 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __res
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int M, int C, const float* __restrict__ gamma,
                                                               const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int b = 0; b < nblk; ++b) { s0 += partial[((size_t)b * 2 + 0) * C + c]; s1 += partial[((size_t)b * 2 + 1) * C + c]; }
+  const int c = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+  double s0, s1;
+  bn_partial_sums(partial, nblk, C, c, sub, s0, s1);
+  if (c >= C || sub) return;
   dbeta[c] = (float)s0;
   dgamma[c] = (float)s1;
   const float gi = gamma[c] * invstd[c];
@@ -370,10 +460,10 @@ __global__ __launch_bounds__(256) void fill_f32_kernel(float* __restrict__ p, fl
 __global__ __launch_bounds__(256) void scale_copy_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, float s) { GS_LOOP(idx, n) out[idx] = in[idx] * s; }
 // column sums from bn_reduce partials (conv bias gradient)
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0;
-  for (int b = 0; b < nblk; ++b) s0 += partial[((size_t)b * 2 + 0) * C + c];
+  const int c = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+  double s0, s1;
+  bn_partial_sums(partial, nblk, C, c, sub, s0, s1);
+  if (c >= C || sub) return;
   out[c] = (float)s0;
 }
 
@@ -405,7 +495,18 @@ int launch_wgrad_finalize(const float* y, float* dw, int Ng, int Ig, int KH, int
   hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(gs_grid(total)), dim3(256), 0, s, y, dw, Ng, Ig, KH, KW, g, splits, Kc_pad, hd_rows, hdp_rows, hd_cols, hdp_cols);
   return (int)hipGetLastError();
 }
+int launch_wgrad_finalize_dense(const float* y, float* dw, int Ng, int Ig, int KH, int KW, int groups, int splits, int Kc_pad, hipStream_t s) {
+  const size_t total = (size_t)groups * Ng * Ig * KH * KW;
+  hipLaunchKernelGGL(wgrad_finalize_dense_kernel, dim3(gs_grid(total)), dim3(256), 0, s, y, dw, Ng, Ig, KH, KW, groups, splits, Kc_pad);
+  return (int)hipGetLastError();
+}
 int launch_transpose_cols(const void* in, void* out, int M, int ld, int c0, int ncols, int Mpad, int dtype, hipStream_t s) {
+  if (((ld | c0 | ncols | Mpad) & 3) == 0) {
+    dim3 g4((Mpad + 63) / 64, (ncols + 63) / 64);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(transpose_cols_v4_kernel<float>, g4, dim3(256), 0, s, (const float*)in, (float*)out, M, ld, c0, ncols, Mpad),
+               hipLaunchKernelGGL(transpose_cols_v4_kernel<bf16>, g4, dim3(256), 0, s, (const bf16*)in, (bf16*)out, M, ld, c0, ncols, Mpad));
+    return (int)hipGetLastError();
+  }
   dim3 grid((Mpad + 31) / 32, (ncols + 31) / 32);
   DISPATCH_T(dtype, hipLaunchKernelGGL(transpose_cols_kernel<float>, grid, dim3(256), 0, s, (const float*)in, (float*)out, M, ld, c0, ncols, Mpad),
              hipLaunchKernelGGL(transpose_cols_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)in, (bf16*)out, M, ld, c0, ncols, Mpad));
@@ -413,6 +514,12 @@ int launch_transpose_cols(const void* in, void* out, int M, int ld, int c0, int 
 }
 int launch_im2col_t(const void* x, void* out, int B, int H, int W, int ld, int c0, int C, int KH, int KW, int stride, int pad, int OH, int OW, int Mpad,
                     int dtype, hipStream_t s) {
+  if (((ld | c0 | C | Mpad) & 3) == 0) {
+    dim3 g4((Mpad + 63) / 64, (C + 63) / 64, KH * KW);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(im2col_t_v4_kernel<float>, g4, dim3(256), 0, s, (const float*)x, (float*)out, B, H, W, ld, c0, C, KH, KW, stride, pad, OH, OW, Mpad),
+               hipLaunchKernelGGL(im2col_t_v4_kernel<bf16>, g4, dim3(256), 0, s, (const bf16*)x, (bf16*)out, B, H, W, ld, c0, C, KH, KW, stride, pad, OH, OW, Mpad));
+    return (int)hipGetLastError();
+  }
   dim3 grid((Mpad + 31) / 32, (C + 31) / 32, KH * KW);
   DISPATCH_T(dtype, hipLaunchKernelGGL(im2col_t_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (float*)out, B, H, W, ld, c0, C, KH, KW, stride, pad, OH, OW, Mpad),
              hipLaunchKernelGGL(im2col_t_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)x, (bf16*)out, B, H, W, ld, c0, C, KH, KW, stride, pad, OH, OW, Mpad));
@@ -424,26 +531,26 @@ int launch_unpatch2(const void* g, void* dx, int B, int OH, int OW, int C, int d
              hipLaunchKernelGGL(unpatch2_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, (const bf16*)g, (bf16*)dx, B, OH, OW, C));
   return (int)hipGetLastError();
 }
-int bn_reduce_blocks(int M) { int nb = (M + 255) / 256; return nb > 1024 ? 1024 : nb; }
+int bn_reduce_blocks(int M) { int nb = (M + 63) / 64; return nb > 512 ? 512 : nb; }
 int launch_bn_reduce(const void* a, const void* z, const float* mean, const float* invstd, float* partial, int M, int C, int bwd, int dtype, hipStream_t s) {
-  const int nb = bn_reduce_blocks(M), rpb = (M + nb - 1) / nb;
+  const int nb = bn_reduce_blocks(M);
   if (dtype == 0) {
-    if (bwd) hipLaunchKernelGGL((bn_reduce_kernel<float, true>), dim3(nb), dim3(256), 0, s, (const float*)a, (const float*)z, mean, invstd, partial, M, C, rpb);
-    else hipLaunchKernelGGL((bn_reduce_kernel<float, false>), dim3(nb), dim3(256), 0, s, (const float*)a, (const float*)z, mean, invstd, partial, M, C, rpb);
+    if (bwd) hipLaunchKernelGGL((bn_reduce_kernel<float, true>), dim3(nb), dim3(256), 0, s, (const float*)a, (const float*)z, mean, invstd, partial, M, C);
+    else hipLaunchKernelGGL((bn_reduce_kernel<float, false>), dim3(nb), dim3(256), 0, s, (const float*)a, (const float*)z, mean, invstd, partial, M, C);
   } else {
-    if (bwd) hipLaunchKernelGGL((bn_reduce_kernel<bf16, true>), dim3(nb), dim3(256), 0, s, (const bf16*)a, (const bf16*)z, mean, invstd, partial, M, C, rpb);
-    else hipLaunchKernelGGL((bn_reduce_kernel<bf16, false>), dim3(nb), dim3(256), 0, s, (const bf16*)a, (const bf16*)z, mean, invstd, partial, M, C, rpb);
+    if (bwd) hipLaunchKernelGGL((bn_reduce_kernel<bf16, true>), dim3(nb), dim3(256), 0, s, (const bf16*)a, (const bf16*)z, mean, invstd, partial, M, C);
+    else hipLaunchKernelGGL((bn_reduce_kernel<bf16, false>), dim3(nb), dim3(256), 0, s, (const bf16*)a, (const bf16*)z, mean, invstd, partial, M, C);
   }
   return (int)hipGetLastError();
 }
 int launch_bn_fwd_finalize(const float* partial, int M, int C, float eps, float momentum, const float* gamma, const float* beta, float* rmean, float* rvar,
                            float* mean, float* invstd, float* sa, float* sb, hipStream_t s) {
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, bn_reduce_blocks(M), M, C, eps, momentum, gamma, beta, rmean, rvar, mean, invstd, sa, sb);
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, partial, bn_reduce_blocks(M), M, C, eps, momentum, gamma, beta, rmean, rvar, mean, invstd, sa, sb);
   return (int)hipGetLastError();
 }
 int launch_bn_bwd_finalize(const float* partial, int M, int C, const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* ca, float* cb,
                            float* cc, hipStream_t s) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, bn_reduce_blocks(M), M, C, gamma, invstd, dgamma, dbeta, ca, cb, cc);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, partial, bn_reduce_blocks(M), M, C, gamma, invstd, dgamma, dbeta, ca, cb, cc);
   return (int)hipGetLastError();
 }
 int launch_bn_apply(const void* z, const float* sa, const float* sb, const void* res, void* y, size_t M, int C, int act, int dtype, hipStream_t s) {
@@ -520,7 +627,7 @@ int launch_scale_copy(const float* in, float* out, size_t n, float sc, hipStream
 int launch_colsum(const void* a, float* partial, float* out, int M, int C, int dtype, hipStream_t s) {
   int rc = launch_bn_reduce(a, nullptr, nullptr, nullptr, partial, M, C, 0, dtype, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, partial, bn_reduce_blocks(M), C, out);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, partial, bn_reduce_blocks(M), C, out);
   return (int)hipGetLastError();
 }
 int launch_sgd(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, int first, hipStream_t s) {
