@@ -6,6 +6,8 @@
 #include "fsvit_common.h"
 #include "train_kernels.h"
 
+#include <cstdlib>
+
 namespace fsvit {
 
 template <typename T>
@@ -74,8 +76,246 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 MFMA version.  One workgroup per (image, head); S <= 128 keys, everything of the head lives in LDS:
+//   row-major   Q, K, V, dO  [SKP][HDP]   (score-type products: both operands read 16-byte k-chunks of a row)
+//   transposed  K^T, Q^T, dO^T [HDP][SKP] (the A operand of the three products that contract over keys / queries)
+// pass 1 (per 16-query tile, one wave): S^T = K Q^T and dP^T = V dO^T in the [key x query] orientation, in-register
+//   softmax (2 shuffles), D = rowsum(P o dP), dS = scale P o (dP - D); dQ^T = K^T dS^T with dS fed back as the MFMA B
+//   operand straight from registers (keys permuted consistently in both operands, as attention_v2 does for P V).
+//   The per-query statistics (max, 1/sum, D) go to LDS.
+// pass 2 (per 16-key tile, one wave): S and dP recomputed in the [query x key] orientation from the statistics, so
+//   P and dS are again B operands from registers: dV^T = dO^T P, dK^T = Q^T dS.
+template <int NKT, int NDT, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dctx,
+                                                                     bf16* __restrict__ dqkv, int S, int heads, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int HDP = NDT * 16, SKP = NKT * 16;
+  constexpr int RS = HDP * 2 + 16;             // row-major row stride (bytes): odd multiple of 16 -> conflict-free b128 reads
+  constexpr int TS = SKP * 2 + 16;             // transposed row stride
+  constexpr int NKC = HDP / 32;                // 32-element MFMA chunks along the head dim
+  constexpr int CPR = HDP / 8;                 // 16-byte chunks per row
+  unsigned char* const Qr = smem;
+  unsigned char* const Kr = Qr + SKP * RS;
+  unsigned char* const Vr = Kr + SKP * RS;
+  unsigned char* const Or = Vr + SKP * RS;
+  unsigned char* const Kt = Or + SKP * RS;
+  unsigned char* const Qt = Kt + HDP * TS;
+  unsigned char* const Ot = Qt + HDP * TS;
+  float* const st_m = reinterpret_cast<float*>(Ot + HDP * TS);
+  float* const st_inv = st_m + SKP;
+  float* const st_D = st_inv + SKP;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lrow = lane & 15, lq = lane >> 4;
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const int rowlen = 3 * heads * HDP;
+  const bf16* base = qkv + (size_t)b * S * rowlen + h * HDP;
+  const bf16* dob = dctx + (size_t)b * S * heads * HDP + h * HDP;
+  bf16* dbase = dqkv + (size_t)b * S * rowlen + h * HDP;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+  for (int idx = t; idx < SKP * CPR; idx += NW * 64) {
+    const int row = idx / CPR, ch = idx - row * CPR;
+    u32x4 q = zero4, k = zero4, v = zero4, o = zero4;
+    if (row < S) {
+      const bf16* src = base + (size_t)row * rowlen + ch * 8;
+      q = *reinterpret_cast<const u32x4*>(src);
+      k = *reinterpret_cast<const u32x4*>(src + heads * HDP);
+      v = *reinterpret_cast<const u32x4*>(src + 2 * heads * HDP);
+      o = *reinterpret_cast<const u32x4*>(dob + (size_t)row * heads * HDP + ch * 8);
+    }
+    *reinterpret_cast<u32x4*>(Qr + row * RS + ch * 16) = q;
+    *reinterpret_cast<u32x4*>(Kr + row * RS + ch * 16) = k;
+    *reinterpret_cast<u32x4*>(Vr + row * RS + ch * 16) = v;
+    *reinterpret_cast<u32x4*>(Or + row * RS + ch * 16) = o;
+    const bf16* qe = reinterpret_cast<const bf16*>(&q);
+    const bf16* ke = reinterpret_cast<const bf16*>(&k);
+    const bf16* oe = reinterpret_cast<const bf16*>(&o);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      *reinterpret_cast<bf16*>(Qt + (ch * 8 + e) * TS + row * 2) = qe[e];
+      *reinterpret_cast<bf16*>(Kt + (ch * 8 + e) * TS + row * 2) = ke[e];
+      *reinterpret_cast<bf16*>(Ot + (ch * 8 + e) * TS + row * 2) = oe[e];
+    }
+  }
+  __syncthreads();
+
+  const float sscale = scale * 1.44269504088896340736f;        // exp2 domain, exactly as the forward kernel
+  const int nt = (S + 15) / 16;
+
+  // ------------------------------------------------------------------ pass 1: dQ + per-query statistics
+  for (int qt = wave; qt < NKT; qt += NW) {
+    const int q = qt * 16 + lrow;
+    if (qt >= nt) {                                               // padded query tile: P = 0 in pass 2
+      if (lq == 0) { st_m[q] = 0.f; st_inv[q] = 0.f; st_D[q] = 0.f; }
+      continue;
+    }
+    u32x4 qf[NKC], of[NKC];
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+      qf[kc] = *reinterpret_cast<const u32x4*>(Qr + q * RS + (kc * 4 + lq) * 16);
+      of[kc] = *reinterpret_cast<const u32x4*>(Or + q * RS + (kc * 4 + lq) * 16);
+    }
+    f32x4 sc[NKT], dp[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+      const int krow = (kt * 16 + lrow) * RS + lq * 16;
+#pragma unroll
+      for (int kc = 0; kc < NKC; ++kc) {
+        a0 = mma_chunk<bf16>(*reinterpret_cast<const u32x4*>(Kr + krow + kc * 64), qf[kc], a0);
+        a1 = mma_chunk<bf16>(*reinterpret_cast<const u32x4*>(Vr + krow + kc * 64), of[kc], a1);
+      }
+      sc[kt] = a0;                       // keys kt*16 + lq*4 + r  x  query lrow
+      dp[kt] = a1;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = kt * 16 + lq * 4 + r < S;
+        sc[kt][r] = ok ? sc[kt][r] * sscale : -INFINITY;
+        m = fmaxf(m, sc[kt][r]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sc[kt][r] - m);
+        sc[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    float D = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sc[kt][r] *= inv; D += sc[kt][r] * dp[kt][r]; }
+    D += __shfl_xor(D, 16, 64);
+    D += __shfl_xor(D, 32, 64);
+    const bool qok = q < S;
+    if (lq == 0) { st_m[q] = m; st_inv[q] = qok ? inv : 0.f; st_D[q] = D; }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[kt][r] = scale * sc[kt][r] * (dp[kt][r] - D);       // dS
+    // dQ^T[d][q] = sum_key K^T[d][key] * dS[q][key]
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const unsigned char* ka = Kt + (dt * 16 + lrow) * TS;
+#pragma unroll
+      for (int kc = 0; kc < NKT / 2; ++kc) {
+        const u32x2 v0 = *reinterpret_cast<const u32x2*>(ka + (32 * kc + lq * 4) * 2);
+        const u32x2 v1 = *reinterpret_cast<const u32x2*>(ka + (32 * kc + 16 + lq * 4) * 2);
+        const u32x4 kf = {v0[0], v0[1], v1[0], v1[1]};
+        const bf16x8 sb = {(bf16)sc[2 * kc][0], (bf16)sc[2 * kc][1], (bf16)sc[2 * kc][2], (bf16)sc[2 * kc][3],
+                           (bf16)sc[2 * kc + 1][0], (bf16)sc[2 * kc + 1][1], (bf16)sc[2 * kc + 1][2], (bf16)sc[2 * kc + 1][3]};
+        acc = mma_chunk<bf16>(kf, __builtin_bit_cast(u32x4, sb), acc);
+      }
+      if (qok) store4<bf16>(dbase + (size_t)q * rowlen + dt * 16 + lq * 4, acc);
+    }
+  }
+  __syncthreads();
+
+  // ------------------------------------------------------------------ pass 2: dK, dV
+  for (int jt = wave; jt < nt; jt += NW) {
+    const int key = jt * 16 + lrow;
+    const bool kok = key < S;
+    u32x4 kf[NKC], vf[NKC];
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+      kf[kc] = *reinterpret_cast<const u32x4*>(Kr + key * RS + (kc * 4 + lq) * 16);
+      vf[kc] = *reinterpret_cast<const u32x4*>(Vr + key * RS + (kc * 4 + lq) * 16);
+    }
+    f32x4 accK[NDT], accV[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) { accK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; accV[dt] = accK[dt]; }
+#pragma unroll
+    for (int qc = 0; qc < NKT / 2; ++qc) {
+      bf16x8 pb, sb;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int it = 2 * qc + half;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        const int qrow = (it * 16 + lrow) * RS + lq * 16;
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+          a0 = mma_chunk<bf16>(*reinterpret_cast<const u32x4*>(Qr + qrow + kc * 64), kf[kc], a0);    // queries it*16 + lq*4 + r  x  key lrow
+          a1 = mma_chunk<bf16>(*reinterpret_cast<const u32x4*>(Or + qrow + kc * 64), vf[kc], a1);
+        }
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(st_m + it * 16 + lq * 4);
+        const f32x4 i4 = *reinterpret_cast<const f32x4*>(st_inv + it * 16 + lq * 4);
+        const f32x4 D4 = *reinterpret_cast<const f32x4*>(st_D + it * 16 + lq * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = kok ? __builtin_amdgcn_exp2f(a0[r] * sscale - m4[r]) * i4[r] : 0.f;
+          pb[half * 4 + r] = (bf16)pr;
+          sb[half * 4 + r] = (bf16)(scale * pr * (a1[r] - D4[r]));
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const unsigned char* oa = Ot + (dt * 16 + lrow) * TS;
+        const unsigned char* qa = Qt + (dt * 16 + lrow) * TS;
+        const u32x2 o0 = *reinterpret_cast<const u32x2*>(oa + (32 * qc + lq * 4) * 2);
+        const u32x2 o1 = *reinterpret_cast<const u32x2*>(oa + (32 * qc + 16 + lq * 4) * 2);
+        const u32x2 q0 = *reinterpret_cast<const u32x2*>(qa + (32 * qc + lq * 4) * 2);
+        const u32x2 q1 = *reinterpret_cast<const u32x2*>(qa + (32 * qc + 16 + lq * 4) * 2);
+        accV[dt] = mma_chunk<bf16>(u32x4{o0[0], o0[1], o1[0], o1[1]}, __builtin_bit_cast(u32x4, pb), accV[dt]);
+        accK[dt] = mma_chunk<bf16>(u32x4{q0[0], q0[1], q1[0], q1[1]}, __builtin_bit_cast(u32x4, sb), accK[dt]);
+      }
+    }
+    if (kok) {
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        bf16* r = dbase + (size_t)key * rowlen + heads * HDP + dt * 16 + lq * 4;
+        store4<bf16>(r, accK[dt]);
+        store4<bf16>(r + heads * HDP, accV[dt]);
+      }
+    }
+  }
+}
+
+template <int NKT, int NDT, int NW>
+static int launch_bwd_mfma(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, float scale, hipStream_t s, bool* ran) {
+  constexpr int HDP = NDT * 16, SKP = NKT * 16;
+  const size_t lds = (size_t)4 * SKP * (HDP * 2 + 16) + (size_t)3 * HDP * (SKP * 2 + 16) + (size_t)3 * SKP * sizeof(float);
+  *ran = false;
+  if (lds > 160 * 1024) return 0;
+  auto kern = attention_bwd_mfma_kernel<NKT, NDT, NW>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3(B * heads), dim3(NW * 64), lds, s, (const bf16*)qkv, (const bf16*)dctx, (bf16*)dqkv, S, heads, scale);
+  *ran = true;
+  return (int)hipGetLastError();
+}
+
 int launch_attention_bwd(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, int hd, int hdp, float scale, int dtype, hipStream_t s) {
   if (B <= 0) return 0;
+  if (dtype == 1 && hdp % 32 == 0 && S <= 128 && getenv("FSVIT_ATTN_BWD_VALU") == nullptr) {      // bf16: MFMA kernel
+    bool ran = false;
+    int rc = 0;
+    const int ndt = hdp / 16;
+    if (S <= 32) {
+      if (ndt == 2) rc = launch_bwd_mfma<2, 2, 2>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
+      else if (ndt == 4) rc = launch_bwd_mfma<2, 4, 2>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
+      else if (ndt == 6) rc = launch_bwd_mfma<2, 6, 2>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
+      else if (ndt == 8) rc = launch_bwd_mfma<2, 8, 2>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
+    } else {
+      if (ndt == 2) rc = launch_bwd_mfma<8, 2, 8>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
+      else if (ndt == 4) rc = launch_bwd_mfma<8, 4, 8>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
+      else if (ndt == 6) rc = launch_bwd_mfma<8, 6, 8>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
+    }
+    if (rc || ran) return rc;
+  }
   const size_t lds = ((size_t)4 * S * (hd + 1) + (size_t)2 * S * (S + 1)) * sizeof(float);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   hipError_t e;
