@@ -76,6 +76,8 @@ SIGNATURES = {
     'fsvit_visformer_train_backward': (_i, [_vp, C.POINTER(Param), _i, _fp, _vp]),
     'fsvit_proto_head_backward': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _fp, _fp, _vp]),
     'fsvit_sgd_step': (_i, [_fp, _fp, _fp, _sz, _f, _f, _f, _i, _vp]),
+    'fsvit_image_transform_gather': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i,
+                                          C.POINTER(C.c_float), C.POINTER(C.c_float), _fp, _vp]),
     'fsvit_attention_backward': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
 }
 

@@ -37,6 +37,7 @@ int fsvit_set_error(int code, const char* fmt, ...) {      // shared with train_
   va_end(ap);
   return code;
 }
+extern "C" int fsvit_set_error_public(int code, const char* msg) { return fsvit_set_error(code, "%s", msg); }   // transform.hip
 static int hipfail(hipError_t e, const char* what) {
   return fail((int)e, "%s: %s", what, hipGetErrorString(e));
 }

@@ -333,7 +333,7 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
 
   // ---- stages 2, 3
   for (int sg = 2; sg <= 3; ++sg) {
-    const int Ci = sg == 2 ? t->C1 : t->C2, C = sg == 2 ? t->C2 : t->C3, Hi = sg == 2 ? t->H1 : t->H2, Ho = sg == 2 ? t->H2 : t->H3;
+    const int C = sg == 2 ? t->C2 : t->C3, Hi = sg == 2 ? t->H1 : t->H2, Ho = sg == 2 ? t->H2 : t->H3;
     const int hid = sg == 2 ? t->hid2 : t->hid3, hd = sg == 2 ? t->hd2 : t->hd3, hdp = sg == 2 ? t->hdp2 : t->hdp3, heads = t->cfg.num_heads;
     const size_t M = (size_t)B * Ho * Ho;
     auto& pe = sg == 2 ? t->pe2 : t->pe3;

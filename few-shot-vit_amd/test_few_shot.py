@@ -75,7 +75,11 @@ def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch
         def flush():
             if not pending:
                 return
-            data = torch.stack([torch.stack([dataset[int(i)][0] for i in idx]) for idx in pending])   # [G, E*way*(S+Q), 3,H,W]
+            if hasattr(dataset, 'gather'):                  # device-resident dataset: gather + transform on the GPU
+                data = dataset.gather(torch.cat(list(pending)))
+                data = data.view(len(pending), -1, *data.shape[1:])
+            else:
+                data = torch.stack([torch.stack([dataset[int(i)][0] for i in idx]) for idx in pending])   # [G, E*way*(S+Q), 3,H,W]
             G = data.shape[0]
             data = data.view(G * ep_per_batch * n_way * (shot + n_query), *data.shape[2:]).to(device, non_blocking=True)
             x_shot, x_query = fs.split_shot_query(data, n_way, shot, n_query, ep_per_batch=G * ep_per_batch)

@@ -38,6 +38,8 @@ def fix_random_seeds(seed=12345):
 
 
 def _batch(dataset, idx, device):
+    if hasattr(dataset, 'gather'):                       # device-resident dataset: gather + transform on the GPU
+        return dataset.gather(idx)
     return torch.stack([dataset[int(i)][0] for i in idx]).to(device, non_blocking=True)
 
 

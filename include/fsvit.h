@@ -196,6 +196,19 @@ int fsvit_proto_head_backward(const float* feat_shot_dev, const float* feat_quer
 /* torch.optim.SGD(momentum, weight_decay) update of one fp32 tensor (utils/__init__.py:127-139) */
 int fsvit_sgd_step(float* param_dev, const float* grad_dev, float* momentum_buf_dev, size_t n, float lr, float momentum,
                    float weight_decay, int first_step, void* stream);
+/* ---------------------------------------------------------------- device-resident dataset transform
+ * Replaces, for a gathered batch of dataset indices, the per-image CPU pipeline of the reference's datasets
+ * (test_phase/datasets/mini_imagenet.py:47-56: Resize((88,88)) -> CenterCrop(80) -> ToTensor -> Normalize;
+ * tiered_imagenet.py:53-57: Resize(80) -> ToTensor -> Normalize): images_dev uint8 [N,H,W,3] resident in HBM,
+ * index_dev int64 [B] -> out_dev fp32 [B,3,OH,OW].  The resize is Pillow's BILINEAR (two 8-bit passes, 22-bit fixed point),
+ * bit-exact: the caller passes Pillow's coefficient tables (xmin / count / coef[ksize] per resized column and row, device
+ * int32; few-shot-vit_amd/datasets/transforms.py computes them as Resample.c does).  crop_*0 = offset of the OHxOW crop in
+ * the resized image; mean3 / std3 are HOST pointers to 3 floats. */
+int fsvit_image_transform_gather(const uint8_t* images_dev, int H, int W, const int64_t* index_dev, int B, const int32_t* xmin_h_dev,
+                                 const int32_t* cnt_h_dev, const int32_t* coef_h_dev, int ksize_h, const int32_t* xmin_v_dev,
+                                 const int32_t* cnt_v_dev, const int32_t* coef_v_dev, int ksize_v, int crop_y0, int crop_x0, int OH, int OW,
+                                 const float* mean3_host, const float* std3_host, float* out_dev, void* stream);
+
 /* Operator level of the training path: attention backward (qkv, dctx -> dqkv; hd real / hdp padded head dim). */
 int fsvit_attention_backward(const void* qkv_dev, const void* dctx_dev, void* dqkv_dev, int B, int S, int heads, int hd, int hdp,
                              float scale, int dtype, void* stream);
