@@ -198,7 +198,9 @@ int launch_conv_gemm_v1(const ConvGemmParams& p, int dtype, hipStream_t stream) 
 // register-staged kernel reachable for A/B measurements.
 int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream) {
   static const bool use_v1 = [] { const char* e = getenv("FSVIT_GEMM"); return e && e[0] == 'v' && e[1] == '1'; }();
-  return use_v1 ? launch_conv_gemm_v1(p, dtype, stream) : launch_conv_gemm_v2(p, dtype, stream);
+  if (use_v1) return launch_conv_gemm_v1(p, dtype, stream);
+  if (gemm256_eligible(p, dtype)) return launch_gemm256(p, stream);      // dense 1x1 layers of the attention + MLP blocks
+  return launch_conv_gemm_v2(p, dtype, stream);
 }
 
 }  // namespace fsvit

@@ -442,7 +442,8 @@ int timed(EngineBase* h, hipStream_t st, const char* layer, int kernel, double f
 int run_gemm(EngineBase* h, hipStream_t st, const char* layer, const Layer& L, const ConvGemmParams& p, double n_true, double k_true) {
   const double flops = 2.0 * (double)p.M * n_true * k_true * (double)p.groups;     // algorithmic: unpadded N and K
   static const int kid_of_cfg[4] = {KID_GEMM256, KID_GEMM64, KID_GEMM32, KID_GEMM128};
-  return timed(h, st, layer, kid_of_cfg[conv_gemm_v2_config(p)], flops, [&]() { return launch_conv_gemm(p, h->dtype, st); });
+  const int kid = gemm256_eligible(p, h->dtype) ? KID_GEMM256 : kid_of_cfg[conv_gemm_v2_config(p)];
+  return timed(h, st, layer, kid, flops, [&]() { return launch_conv_gemm(p, h->dtype, st); });
 }
 
 int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsigned char* ws, bool first, hipStream_t st) {
@@ -665,10 +666,10 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 
 // ------------------------------------------------------------------------------------ profiling
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
-  static const char* f32n[] = {"conv_gemm_v2_kernel<float,256,128,4,2,3>", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
+  static const char* f32n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
                                "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<float,128,128,2,2,2>",
                                "patchify_kernel<float>", "layernorm_kernel<float>"};
-  static const char* bf16n[] = {"conv_gemm_v2_kernel<__bf16,256,128,4,2,3>", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
+  static const char* bf16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
                                 "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<__bf16,128,128,2,2,2>",
                                 "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>"};
   if (kernel_id < 0 || kernel_id > 11) return "?";

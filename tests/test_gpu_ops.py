@@ -50,6 +50,13 @@ CASES = [
     ('k32_im2col',      2, 40, 40, 32,     64,  1, 1, 0, 1, 2, False, 0, True, False),
     ('1x1_bigK',        5, 5,  5,  2048,   512, 1, 1, 0, 1, 0, True, 0, False, False),
     ('3x3_small_n32',   1, 12, 12, 32,     32,  3, 1, 1, 1, 1, False, 0, True, False),
+    # dense bf16 layers large enough for gemm256.hip (M >= 1024, N >= 192, K % 64 == 0): M / N tails, every epilogue
+    ('g256_fc1_gelu',   13, 10, 10, 256,   1024, 1, 1, 0, 1, 1, False, 0, True, False),
+    ('g256_fc2_res',    11, 10, 10, 1024,  256, 1, 1, 0, 1, 0, True, 0, True, False),
+    ('g256_qkv_tailN',  12, 10, 10, 256,   1152, 1, 1, 0, 1, 0, False, 0, True, False),
+    ('g256_proj_k384',  41, 5,  5,  384,   704, 1, 1, 0, 1, 2, True, 1, False, False),
+    ('g256_k128',       3, 20, 20, 128,    320, 1, 1, 0, 1, 0, False, 0, False, False),
+    ('g256_bigK',       45, 5,  5,  2048,  512, 1, 1, 0, 1, 0, True, 0, True, False),
 ]
 
 
@@ -195,3 +202,26 @@ def test_stage1_fused_block_matches_unfused_math():
     assert err[:, :, 8:12].mean().item() <= 3 * err.mean().item() + 1e-6
     border = torch.cat([err[:, :, 0].flatten(), err[:, :, -1].flatten(), err[:, :, :, 0].flatten(), err[:, :, :, -1].flatten()])
     assert border.mean().item() <= 3 * err.mean().item() + 1e-6
+
+
+def test_gemm256_large_shapes_repeatable_and_correct():
+    """Race screen of the pipelined 256x256 kernel (counted-vmcnt LDS-DMA ring, cdna_hip_programming.md: a misplaced wait shows up as
+    rare wrong tiles): several persistent items per workgroup, tails in M and N, 25 repeats must be bit-identical and match fp32."""
+    from fewshot_vit_amd.engine import ops
+    g = torch.Generator().manual_seed(11)
+    for (M, N, K) in ((70000, 1152, 256), (20000, 2048, 512), (9000, 512, 2048)):
+        x = torch.randn(M, K, generator=g).bfloat16()
+        w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+        xd, wd = x.cuda().view(1, M, 1, K), w.cuda().view(1, N, K)
+        first = None
+        for rep in range(25):
+            y = ops.conv_gemm(xd, wd, None, None, None, 1, M, 1, K, 1, 1, 1, 0, N, 1, 0, False).view(M, N)
+            if first is None:
+                first = y.clone()
+            else:
+                assert torch.equal(y, first), f'run {rep} differs from run 0 at {(M, N, K)}'
+        torch.cuda.synchronize()
+        rows = torch.randint(0, M, (512,), generator=g)
+        ref = x[rows].float() @ w.float().t()
+        err = (first[rows.cuda()].float().cpu() - ref).abs().max().item()
+        assert err <= 2e-2 * max(1.0, ref.abs().max().item()), (M, N, K, err)
