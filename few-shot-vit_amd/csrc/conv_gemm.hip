@@ -199,6 +199,7 @@ int launch_conv_gemm_v1(const ConvGemmParams& p, int dtype, hipStream_t stream) 
 int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream) {
   static const bool use_v1 = [] { const char* e = getenv("FSVIT_GEMM"); return e && e[0] == 'v' && e[1] == '1'; }();
   if (use_v1) return launch_conv_gemm_v1(p, dtype, stream);
+  if (conv3x3_halo_eligible(p, dtype)) return launch_conv3x3_halo(p, stream);   // stem 3x3 convs: halo tile resident in LDS
   if (gemm256_eligible(p, dtype)) return launch_gemm256(p, stream);      // dense 1x1 layers of the attention + MLP blocks
   return launch_conv_gemm_v2(p, dtype, stream);
 }

@@ -421,7 +421,7 @@ int tap(EngineBase* h, const std::string& name, const void* src, size_t bytes, b
 }
 
 // kernel ids reported by the profiler (names in fsvit_kernel_name)
-enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9 };
+enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12 };
 
 
 // Runs one launch; in profiling mode brackets it with HIP events on the same stream.
@@ -442,7 +442,7 @@ int timed(EngineBase* h, hipStream_t st, const char* layer, int kernel, double f
 int run_gemm(EngineBase* h, hipStream_t st, const char* layer, const Layer& L, const ConvGemmParams& p, double n_true, double k_true) {
   const double flops = 2.0 * (double)p.M * n_true * k_true * (double)p.groups;     // algorithmic: unpadded N and K
   static const int kid_of_cfg[4] = {KID_GEMM256, KID_GEMM64, KID_GEMM32, KID_GEMM128};
-  const int kid = gemm256_eligible(p, h->dtype) ? KID_GEMM256 : kid_of_cfg[conv_gemm_v2_config(p)];
+  const int kid = conv3x3_halo_eligible(p, h->dtype) ? KID_HALO : gemm256_eligible(p, h->dtype) ? KID_GEMM256 : kid_of_cfg[conv_gemm_v2_config(p)];
   return timed(h, st, layer, kid, flops, [&]() { return launch_conv_gemm(p, h->dtype, st); });
 }
 
@@ -668,11 +668,11 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
   static const char* f32n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
                                "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<float,128,128,2,2,2>",
-                               "patchify_kernel<float>", "layernorm_kernel<float>"};
+                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel"};
   static const char* bf16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
                                 "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<__bf16,128,128,2,2,2>",
-                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>"};
-  if (kernel_id < 0 || kernel_id > 11) return "?";
+                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel"};
+  if (kernel_id < 0 || kernel_id > 12) return "?";
   return dtype == FSVIT_F32 ? f32n[kernel_id] : bf16n[kernel_id];
 }
 

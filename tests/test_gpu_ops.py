@@ -50,6 +50,9 @@ CASES = [
     ('k32_im2col',      2, 40, 40, 32,     64,  1, 1, 0, 1, 2, False, 0, True, False),
     ('1x1_bigK',        5, 5,  5,  2048,   512, 1, 1, 0, 1, 0, True, 0, False, False),
     ('3x3_small_n32',   1, 12, 12, 32,     32,  3, 1, 1, 1, 1, False, 0, True, False),
+    # stem geometry (40x40, 128 output channels): conv3x3_halo.hip in bf16 (several 8-row tiles per image, image borders)
+    ('halo_conv2_c64',  5, 40, 40, 64,     128, 3, 1, 1, 1, 2, False, 0, True, False),
+    ('halo_c128_gelu',  3, 40, 40, 128,    128, 3, 1, 1, 1, 1, False, 0, True, False),
     # dense bf16 layers large enough for gemm256.hip (M >= 1024, N >= 192, K % 64 == 0): M / N tails, every epilogue
     ('g256_fc1_gelu',   13, 10, 10, 256,   1024, 1, 1, 0, 1, 1, False, 0, True, False),
     ('g256_fc2_res',    11, 10, 10, 1024,  256, 1, 1, 0, 1, 0, True, 0, True, False),
