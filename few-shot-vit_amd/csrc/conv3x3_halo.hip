@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const ConvGemmPara
           }
         }
       };
-      if (p.act == ACT_GELU) finish([](float x) { return gelu_fast(x); });
+      if (p.act == ACT_GELU) finish([](float x) { return gelu_sig(x); });
       else if (p.act == ACT_LRELU) finish([](float x) { return x > 0.0f ? x : 0.1f * x; });
       else finish([](float x) { return x; });
     }

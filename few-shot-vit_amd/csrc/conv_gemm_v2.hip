@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
 #pragma unroll
       for (int i0 = 0; i0 < TM; i0 += HB) batch(i0, actf);
     };
-    if (p.act == ACT_GELU) finish([](float x) { return sizeof(T) == 2 ? gelu_fast(x) : gelu_erf(x); });
+    if (p.act == ACT_GELU) finish([](float x) { return sizeof(T) == 2 ? gelu_sig(x) : gelu_erf(x); });
     else if (p.act == ACT_LRELU) finish([](float x) { return x > 0.0f ? x : 0.1f * x; });
     else finish([](float x) { return x; });
   };

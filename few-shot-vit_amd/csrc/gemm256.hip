@@ -99,7 +99,11 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvGemmParams p,
       for (int j = 0; j < 2; ++j) {
         int m = mt * G_BM + rbA[h][j] + srow;
         m = m < p.M ? m : p.M - 1;
-        int n = nt * G_BN + rbB[h][j] + srow;
+        // LDS weight row R holds output channel (R & ~31) + perm(R & 31): row r of the even / odd 16-row MFMA tile of a
+        // 32-channel block is channel 8 (r / 4) + 4 (tile & 1) + (r & 3), so that the 4 + 4 accumulators a lane holds of
+        // the tile pair are 8 CONSECUTIVE channels of one output row -> one 16-byte store (and bias / residual load)
+        const int R = rbB[h][j] + srow, r32 = R & 31;
+        int n = nt * G_BN + (R & ~31) + 8 * ((r32 & 15) >> 2) + 4 * (r32 >> 4) + (r32 & 3);
         n = n < p.N ? n : p.N - 1;
         oa[h][j] = (unsigned)m * (unsigned)(p.x_cstride * 2) + schunk;
         ob[h][j] = (unsigned)n * (unsigned)(p.Kw * 2) + schunk;
@@ -188,20 +192,22 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvGemmParams p,
       mma(1, 0);
     }
 
-    // ---- epilogue of output tile `it` (the next tile's first K tile is landing meanwhile): lane holds, per 16x16 tile,
-    // 4 consecutive n of row m = lrow
+    // ---- epilogue of output tile `it` (the next tile's first K tile is landing meanwhile): per 16x16 tile PAIR a lane holds
+    // 8 consecutive n (see `setup`) of row m = lrow: 16-byte bias / residual loads and stores (the store tail of this
+    // kernel is issue-bound - 32 dwordx2 stores per lane cost more than the whole K = 256 main loop)
     {
       const int mt = xcd + 8 * (it / tiles_n), nt = it % tiles_n;
-      const int mb = mt * G_BM + wm * 128 + lrow, nb = nt * G_BN + wn * 64 + lq * 4;
-      int ncl[4];
-      bool nok[4];
-      f32x4 bv[4];
+      const int mb = mt * G_BM + wm * 128 + lrow, nb = nt * G_BN + wn * 64 + lq * 8;
+      int ncl[2];
+      bool nok[2];
+      f32x4 bv[2][2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = nb + j * 16;
-        nok[j] = n < p.N;
-        ncl[j] = nok[j] ? n : p.N - 4;
-        bv[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncl[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int jp = 0; jp < 2; ++jp) {
+        const int n = nb + jp * 32;
+        nok[jp] = n < p.N;                         // N % 8 == 0: a group of 8 is valid or not as a whole
+        ncl[jp] = nok[jp] ? n : 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) bv[jp][q] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncl[jp] + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       auto finish = [&](auto actf) {
 #pragma unroll
@@ -209,22 +215,31 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvGemmParams p,
           const int m = mb + i * 16;
           const bool mok = m < p.M;
           const size_t rowoff = (size_t)(mok ? m : p.M - 1) * p.y_cstride;
-          f32x4 rv[4];
+          u32x4 rv[2];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) rv[j] = R ? load4<bf16>(R + rowoff + ncl[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int jp = 0; jp < 2; ++jp) rv[jp] = R ? *reinterpret_cast<const u32x4*>(R + rowoff + ncl[jp]) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            f32x4 v = acc[i][j] + bv[j];
-            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p.res_first) v += rv[j];
+          for (int jp = 0; jp < 2; ++jp) {
+            const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[jp]);
+            bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = actf(v[e]);
-            if (!p.res_first) v += rv[j];
-            if (mok && nok[j]) store4<bf16>(Y + rowoff + ncl[j], v);
+            for (int q = 0; q < 2; ++q) {
+              f32x4 v = acc[i][2 * jp + q] + bv[jp][q];
+              acc[i][2 * jp + q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float r = (float)r8[4 * q + e];
+                float x = p.res_first ? v[e] + r : v[e];
+                x = actf(x);
+                if (!p.res_first) x += r;
+                o[4 * q + e] = (bf16)x;
+              }
+            }
+            if (mok && nok[jp]) *reinterpret_cast<bf16x8*>(Y + rowoff + ncl[jp]) = o;
           }
         }
       };
-      if (p.act == ACT_GELU) finish([](float x) { return gelu_fast(x); });
+      if (p.act == ACT_GELU) finish([](float x) { return gelu_sig(x); });
       else if (p.act == ACT_LRELU) finish([](float x) { return x > 0.0f ? x : 0.1f * x; });
       else finish([](float x) { return x; });
     }
@@ -242,7 +257,7 @@ bool gemm256_eligible(const ConvGemmParams& p, int dtype) {
   if (off || dtype != 1) return false;
   if (p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.groups != 1) return false;
   if (p.x2 || p.K2 || p.pool2 || p.y_rpi || p.pos || p.out_f32 || p.w_rstride || p.w_gstride) return false;
-  if (p.N < 192 || p.M < 1024 || (p.N & 3)) return false;
+  if (p.N < 192 || p.M < 1024 || (p.N & 7) || (p.y_cstride & 7)) return false;   // 16-byte epilogue accesses
   if (p.K != p.Kw || (p.Kw & 63) || p.Kw < 128) return false;                 // whole 64-element K tiles on both operands
   if ((size_t)p.M * p.x_cstride * 2 >= (1ull << 32) || (size_t)p.N * p.Kw * 2 >= (1ull << 32)) return false;   // 32-bit DMA offsets
   // One 8-wave workgroup per CU cannot hide its epilogue behind another workgroup's MFMAs, so the HBM-bound layers

@@ -153,14 +153,14 @@ __global__ __launch_bounds__(1024) void stage1_block_kernel(const bf16* __restri
       a += bias;
       bf16x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16)gelu_fast(a[e]);
+      for (int e = 0; e < 4; ++e) o[e] = (bf16)gelu_sig(a[e]);
       *reinterpret_cast<bf16x4*>(H1 + (nt * 2 + (lq >> 1)) * H1_PLANE + pix * 16 + (lq & 1) * 8) = o;
     }
   };
   auto h2_store = [&](int mt, f32x4 a) {
     bf16x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (bf16)gelu_fast(a[e]);
+    for (int e = 0; e < 4; ++e) o[e] = (bf16)gelu_sig(a[e]);
     *reinterpret_cast<bf16x4*>(H2 + (nt * 2 + (lq >> 1)) * H2_PLANE + (mt * 16 + lrow) * 16 + (lq & 1) * 8) = o;
   };
 

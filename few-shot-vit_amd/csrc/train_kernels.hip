@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ z, 
   GS_LOOP(idx, n4) {
     f32x4 v = load4<T>(z + idx * 4);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = sizeof(T) == 2 ? gelu_fast(v[e]) : gelu_erf(v[e]);
+    for (int e = 0; e < 4; ++e) v[e] = sizeof(T) == 2 ? gelu_sig(v[e]) : gelu_erf(v[e]);
     store4<T>(h + idx * 4, v);
   }
 }
