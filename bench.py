@@ -298,10 +298,14 @@ def main():
             peak = MFMA_PEAK_TFLOPS['bf16' if args.numerics == 'bf16' else 'f32']
             achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
             traffic = None          # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
-            tf = os.path.join(REPO, 'profiles', 'r01_v5_hbm_traffic.json')
-            if os.path.exists(tf) and args.model == 'visformer_micro_80' and args.numerics == 'bf16' and E == 32:
-                with open(tf) as f:
-                    traffic = json.load(f).get(dom.replace('conv_gemm_v2_kernel<__bf16,128,128,2,2,2>', 'conv_gemm_v2_kernel<__bf16,128,128,2,2,2>'), {}).get('hbm_bytes_per_launch')
+            import glob
+            tfs = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_hbm_traffic.json')))      # newest committed PMC passes
+            if tfs and args.model == 'visformer_micro_80' and args.numerics == 'bf16' and E == 32 and args.mode == 'eval':
+                with open(tfs[-1]) as f:
+                    tj = json.load(f)
+                cand = [k for k in tj if k == dom] or [k for k in tj if k.split('<')[0] == dom.split('<')[0]]
+                if len(cand) == 1:
+                    traffic = tj[cand[0]].get('hbm_bytes_per_launch')
             out['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                                'traffic': traffic, 'kernel': dom, 'launches': d['launches'],
                                'avg_launch_us': 1e3 * d['ms'] / d['launches'],

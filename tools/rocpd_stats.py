@@ -7,10 +7,16 @@ import sys
 
 
 def short(name):
+    if name.startswith('_Z'):
+        import subprocess
+        try:
+            name = subprocess.run(['c++filt', name.replace('DF16b', 'u6__bf16')], capture_output=True, text=True, timeout=10).stdout.strip() or name
+        except Exception:
+            pass
     name = re.sub(r'\[clone[^\]]*\]', '', name)
     name = re.sub(r'^void ', '', name)
     m = re.match(r'(?:fsvit::)?(?:\(anonymous namespace\)::)?([A-Za-z0-9_:]+(?:<[^(]*>)?)', name)
-    return (m.group(1) if m else name)[:110]
+    return (m.group(1) if m else name).replace(', ', ',')[:110]
 
 
 def main():
