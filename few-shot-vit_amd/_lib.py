@@ -65,6 +65,7 @@ SIGNATURES = {
                                          _vp, _sz, _vp]),
     'fsvit_conv_gemm': (_i, [_vp, _vp, _fp, _vp, _fp, _vp] + [_i] * 15 + [_i, _vp]),
     'fsvit_stage1_block': (_i, [_vp, _vp, _vp, _fp, _vp, _vp, _i, _vp]),
+    'fsvit_mlp_rows': (_i, [_vp, _vp, _vp, _i, _fp, _vp, _i, _fp, _i, _i, _i, _vp]),
     'fsvit_attention': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     'fsvit_im2col27': (_i, [_fp, _vp, _i, _i, _i, _i, _vp]),
     'fsvit_maxpool2_pos': (_i, [_vp, _fp, _vp, _i, _i, _i, _i, _i, _vp]),

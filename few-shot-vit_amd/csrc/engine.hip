@@ -73,7 +73,11 @@ struct Layer {
   int N = 0, K = 0, Kw = 0, groups = 1;
 };
 struct Block1 { Layer c1, c2, c3; };
-struct BlockA { Layer qkv, proj, fc1, fc2; };
+struct BlockA {
+  Layer qkv, proj, fc1, fc2;
+  void* mlp_img = nullptr;     // mlp_rows.hip: fragment-major image of fc1 + fc2 (null: the two GEMM launches are used)
+  float* mlp_b1 = nullptr;
+};
 
 struct Tap { void* dst; size_t bytes; };
 
@@ -335,6 +339,17 @@ int build(fsvit_visformer* h, const SD& sd) {
       RC_TRY(pack_layer(h, &blocks[i].proj, wp, C, heads * hd, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, &colmap, heads * hdp));
       RC_TRY(pack_layer(h, &blocks[i].fc1, w1, hid, C, 1, 1, 1, nullptr, &n2.s, prenorm_bias(w1, hid, C, n2.t), true, nullptr, 0, nullptr, 0));
       RC_TRY(pack_layer(h, &blocks[i].fc2, w3, C, hid, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
+      if (mlp_rows_supported(h->dtype, C, hid)) {                // fused row-wise Mlp: re-pack fc1 / fc2 as the MFMA fragment stream
+        void *img = nullptr, *b1i = nullptr;
+        HIP_TRY(hipMalloc(&img, mlp_rows_image_bytes(C, hid)));
+        h->allocs.push_back(img);
+        HIP_TRY(hipMalloc(&b1i, (size_t)hid * 4));
+        h->allocs.push_back(b1i);
+        RC_TRY(launch_mlp_pack(blocks[i].fc1.w, blocks[i].fc1.Kw, blocks[i].fc1.bias, blocks[i].fc2.w, blocks[i].fc2.Kw, img, (float*)b1i, C, hid, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        blocks[i].mlp_img = img;
+        blocks[i].mlp_b1 = (float*)b1i;
+      }
     }
   }
   // ---- final BN -> pooled feature affine (visformer.py:455-462)
@@ -421,7 +436,7 @@ int tap(EngineBase* h, const std::string& name, const void* src, size_t bytes, b
 }
 
 // kernel ids reported by the profiler (names in fsvit_kernel_name)
-enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12 };
+enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13 };
 
 
 // Runs one launch; in profiling mode brackets it with HIP events on the same stream.
@@ -515,8 +530,13 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
       RC_TRY(timed(h, st, (sp + ".attn.core").c_str(), KID_ATTN, 4.0 * Bc * heads * (double)S * S * hd,
                    [&]() { return launch_attention(qkv, ctx, Bc, S, heads, hdp, scale, dt, st); }));
       RC_TRY(run_gemm(h, st, (sp + ".attn.proj").c_str(), b.proj, conv_params(b.proj, ctx, xs, Bc, Ho, Ho, heads * hdp, heads * hdp, 1, 1, 1, 0, C, ACT_NONE, xs, 0, nullptr), C, (double)heads * hd));
-      RC_TRY(run_gemm(h, st, (sp + ".mlp.conv1").c_str(), b.fc1, conv_params(b.fc1, xs, hid, Bc, Ho, Ho, C, C, 1, 1, 1, 0, hidc, ACT_GELU, nullptr, 0, nullptr), hidc, C));
-      RC_TRY(run_gemm(h, st, (sp + ".mlp.conv3").c_str(), b.fc2, conv_params(b.fc2, hid, xs, Bc, Ho, Ho, hidc, hidc, 1, 1, 1, 0, C, ACT_NONE, xs, 0, nullptr), C, hidc));
+      if (b.mlp_img) {     // conv1 + GELU + conv3 + residual in one launch, the hidden map stays in registers
+        RC_TRY(timed(h, st, (sp + ".mlp").c_str(), KID_MLPROWS, 4.0 * Bc * S * (double)hidc * C,
+                     [&]() { return launch_mlp_rows(xs, xs, b.mlp_img, b.mlp_b1, b.fc2.bias, Bc * S, C, hidc, st); }));
+      } else {
+        RC_TRY(run_gemm(h, st, (sp + ".mlp.conv1").c_str(), b.fc1, conv_params(b.fc1, xs, hid, Bc, Ho, Ho, C, C, 1, 1, 1, 0, hidc, ACT_GELU, nullptr, 0, nullptr), hidc, C));
+        RC_TRY(run_gemm(h, st, (sp + ".mlp.conv3").c_str(), b.fc2, conv_params(b.fc2, hid, xs, Bc, Ho, Ho, hidc, hidc, 1, 1, 1, 0, C, ACT_NONE, xs, 0, nullptr), C, hidc));
+      }
       RC_TRY(tap(h, sp + "." + std::to_string(i), xs, xbytes, first, st));
     }
   }
@@ -638,6 +658,25 @@ extern "C" int fsvit_stage1_block(const void* x, void* y, const void* w1, const 
   return 0;
 }
 
+extern "C" int fsvit_mlp_rows(const void* x, void* y, const void* w1, int k1w, const float* b1, const void* w2, int k2w, const float* b2,
+                              int M, int C, int hid, void* stream) {
+  if (!x || !y || !w1 || !w2) return fail(FSVIT_ERR_ARG, "null argument");
+  if (!mlp_rows_supported(FSVIT_BF16, C, hid)) return fail(FSVIT_ERR_ARG, "fsvit_mlp_rows: only C = 256, hidden = 1024 (bf16) is built");
+  if (k1w < C || k2w < hid) return fail(FSVIT_ERR_ARG, "weight rows shorter than K");
+  hipStream_t st = (hipStream_t)stream;
+  void *img = nullptr, *b1i = nullptr;
+  HIP_TRY(hipMalloc(&img, mlp_rows_image_bytes(C, hid)));
+  hipError_t e = hipMalloc(&b1i, (size_t)hid * 4);
+  if (e != hipSuccess) { (void)hipFree(img); return hipfail(e, "hipMalloc"); }
+  int rc = launch_mlp_pack(w1, k1w, b1, w2, k2w, img, (float*)b1i, C, hid, st);
+  if (rc == 0) rc = launch_mlp_rows(x, y, img, (const float*)b1i, b2, M, C, hid, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(img);
+  (void)hipFree(b1i);
+  if (rc != 0) return hipfail((hipError_t)rc, "fsvit_mlp_rows");
+  return 0;
+}
+
 extern "C" int fsvit_attention(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, void* stream) {
   if (!qkv || !ctx) return fail(FSVIT_ERR_ARG, "null argument");
   int rc = launch_attention(qkv, ctx, B, S, heads, hdp, scale, dtype, (hipStream_t)stream);
@@ -668,11 +707,11 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
   static const char* f32n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
                                "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<float,128,128,2,2,2>",
-                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel"};
+                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel"};
   static const char* bf16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
                                 "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<__bf16,128,128,2,2,2>",
-                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel"};
-  if (kernel_id < 0 || kernel_id > 12) return "?";
+                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel"};
+  if (kernel_id < 0 || kernel_id > 13) return "?";
   return dtype == FSVIT_F32 ? f32n[kernel_id] : bf16n[kernel_id];
 }
 

@@ -23,6 +23,13 @@ int launch_proto_head(const float* feat_shot, const float* feat_query, int E, in
 bool stage1_fused_supported(int dtype, int C1, int hid, int group, int H1);
 int launch_stage1_block(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, hipStream_t s);
 
+// fused row-wise Mlp of the attention blocks (mlp_rows.hip; bf16, C = 256, hidden = 1024): y = x + W2 GELU(W1 x + b1) (+ b2), in place allowed.
+// wimg / b1img are built once by launch_mlp_pack from the standard packed layers (w1 [hid][k1w], w2 [C][k2w]).
+bool mlp_rows_supported(int dtype, int C, int hid);
+size_t mlp_rows_image_bytes(int C, int hid);
+int launch_mlp_pack(const void* w1, int k1w, const float* b1, const void* w2, int k2w, void* wimg, float* b1img, int C, int hid, hipStream_t s);
+int launch_mlp_rows(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, int M, int C, int hid, hipStream_t s);
+
 // ViT / DeiT helpers (vit.hip)
 int launch_patchify(const float* x_nchw, void* out, int B, int img, int p, int Kp, int dtype, hipStream_t s);
 int launch_cls_pos(const float* cls_plus_pos0, void* tokens, int B, int S, int D, int dtype, hipStream_t s);

@@ -307,6 +307,17 @@ class ops:
         return y
 
     @staticmethod
+    def mlp_rows(x, w1, b1, w2, b2=None):
+        """x [M][256] bf16; w1 [1024][K1w], w2 [256][K2w] packed K-major bf16; b1 [1024], b2 [256] fp32 or None.  y = x + W2 GELU(W1 x + b1) + b2."""
+        _require_cuda(x, w1, w2)
+        lib = _lib.load()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.fsvit_mlp_rows(_ptr(x), _ptr(y), _ptr(w1), w1.shape[-1], _ptr(b1), _ptr(w2), w2.shape[-1], _ptr(b2),
+                                          x.shape[0], x.shape[1], w1.shape[0], _stream_ptr(x.device)))
+        return y
+
+    @staticmethod
     def attention(qkv, B, S, heads, hdp, scale):
         _require_cuda(qkv)
         lib = _lib.load()

@@ -151,6 +151,12 @@ int fsvit_attention(const void* qkv_dev, void* ctx_dev, int B, int S, int heads,
  * x, y NHWC [B,20,20,128] bf16 (distinct buffers); w1 [256][128], w2 [8][32][320], w3 [128][256] packed K-major bf16. */
 int fsvit_stage1_block(const void* x_dev, void* y_dev, const void* w1_dev, const float* b1_dev, const void* w2_dev,
                        const void* w3_dev, int B, void* stream);
+/* Fused Mlp of a Visformer attention block (visformer.py:146-150 with spatial_conv=False, + the residual of :262):
+ * y = x + W2 GELU(W1 x + b1) (+ b2), rows = tokens.  bf16, C = 256, hidden = 1024 only (stage 2 of Visformer-S).  x, y [M][C]
+ * (y may alias x); w1 [hid][k1w], w2 [C][k2w] K-contiguous bf16 rows (BatchNorm already folded into w1 / b1); b1 [hid], b2 [C]
+ * fp32 or NULL.  The operator form packs the weights on every call (the engine packs once per checkpoint). */
+int fsvit_mlp_rows(const void* x_dev, void* y_dev, const void* w1_dev, int k1w, const float* b1_dev, const void* w2_dev, int k2w,
+                   const float* b2_dev, int M, int C, int hid, void* stream);
 int fsvit_im2col27(const float* x_nchw_dev, void* out_dev, int B, int H, int W, int dtype, void* stream);
 int fsvit_maxpool2_pos(const void* in_dev, const float* pos_dev, void* out_dev, int B, int OH, int OW, int C,
                        int dtype, void* stream);

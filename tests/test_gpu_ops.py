@@ -207,6 +207,39 @@ def test_stage1_fused_block_matches_unfused_math():
     assert border.mean().item() <= 3 * err.mean().item() + 1e-6
 
 
+@pytest.mark.parametrize('M', [256, 1000, 70000 + 37])
+def test_mlp_rows_fused_matches_unfused_math(M):
+    """Fused row Mlp (mlp_rows.hip: hidden map kept in registers) vs fp32 torch with the same bf16 roundings of x, the weights
+    and the hidden map; M tails, several tiles per persistent workgroup, 10 repeats bit-identical (race screen of the LDS-DMA ring)."""
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(M)
+    C, HID = 256, 1024
+    x = q(torch.randn(M, C, generator=g), bf)
+    w1 = q(torch.randn(HID, C, generator=g) / math.sqrt(C), bf)
+    b1 = torch.randn(HID, generator=g) * 0.3
+    w2 = q(torch.randn(C, HID, generator=g) / math.sqrt(HID), bf)
+    b2 = torch.randn(C, generator=g) * 0.3
+    hdn = q(F.gelu(x @ w1.t() + b1), bf)
+    xd, w1d, w2d = x.to('cuda', bf), w1.to('cuda', bf), w2.to('cuda', bf)
+    for use_b2 in (False, True):
+        ref = x + hdn @ w2.t() + (b2 if use_b2 else 0.0)
+        y0 = ops.mlp_rows(xd, w1d, b1.cuda(), w2d, b2.cuda() if use_b2 else None)
+        torch.cuda.synchronize()
+        err = (y0.float().cpu() - ref).abs()
+        assert err.max().item() <= 3e-2 * max(1.0, float(ref.abs().max())), (M, use_b2, err.max().item())
+        assert err.mean().item() <= 3e-3, (M, use_b2, err.mean().item())
+        for _ in range(10):
+            assert torch.equal(ops.mlp_rows(xd, w1d, b1.cuda(), w2d, b2.cuda() if use_b2 else None), y0)
+    # in place (the engine's use): y aliases x
+    lib_y = xd.clone()
+    from fewshot_vit_amd import _lib
+    from fewshot_vit_amd.engine import _ptr, _stream_ptr
+    _lib.check(_lib.load().fsvit_mlp_rows(_ptr(lib_y), _ptr(lib_y), _ptr(w1d), C, _ptr(b1.cuda()), _ptr(w2d), HID, None, M, C, HID, _stream_ptr(xd.device)))
+    torch.cuda.synchronize()
+    assert torch.equal(lib_y, ops.mlp_rows(xd, w1d, b1.cuda(), w2d, None))
+
+
 def test_gemm256_large_shapes_repeatable_and_correct():
     """Race screen of the pipelined 256x256 kernel (counted-vmcnt LDS-DMA ring, cdna_hip_programming.md: a misplaced wait shows up as
     rare wrong tiles): several persistent items per workgroup, tails in M and N, 25 repeats must be bit-identical and match fp32."""
