@@ -40,6 +40,12 @@ typedef __attribute__((address_space(3))) void* lptrm_t;
 namespace {
 
 constexpr int MR_NST = 4;                       // ring stages
+#ifndef MR_FD1
+#define MR_FD1 4
+#endif
+#ifndef MR_FD2
+#define MR_FD2 4
+#endif
 
 // NP consecutive 1 KiB LDS-DMAs: source = sbase + voff + i * 1024, destination = lds + i * 1024.  The immediate offset of
 // global_load_lds moves the LDS destination together with the global source (tools/probes/ldsdma_offset.hip, measured on
@@ -79,7 +85,9 @@ __device__ __forceinline__ void mr_bar() {
   __builtin_amdgcn_sched_barrier(0);
 }
 template <int N> __device__ __forceinline__ void mr_wait_vm() {
+  static_assert(N == 0 || N == 2 || N == 4 || N == 8, "add the literal");
   if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -104,29 +112,25 @@ __device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
 
 }  // namespace
 
+// Measured and dropped: waves 4-7 - the SIMD partners of waves 0-3 - running GEMM1 one barrier interval early so that
+// one partner is in its GELU while the other issues MFMAs (-3 %); read-ahead depths 6 / 8 instead of 4 (+-0 %: LDS latency is not
+// the limiter); (s2 outer, ct inner) MFMA order in GEMM2 (+-0 %).
 template <int C, int HID>
-__global__ __launch_bounds__(512, 2) void mlp_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
-                                                          const float* __restrict__ b1img, const float* __restrict__ b2, const int M, const int n_tiles) {
+__device__ __forceinline__ void mlp_rows_body(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
+                                              const float* __restrict__ b2, const int M, const int n_tiles, unsigned char* smem, const int wave, const int lane) {
   constexpr int NCT = C / 32, NKS = C / 16, NCH = HID / 32;
   constexpr int STAGE = (NKS + 2 * NCT) * 1024;          // W1 fragments then W2 fragments of one hidden chunk
   constexpr int NP = STAGE / 1024 / 8;                   // 1 KiB DMA pieces per wave and stage
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* const b1tab = reinterpret_cast<float*>(smem + MR_NST * STAGE);
-
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  constexpr int FD = 4;                                  // weight fragments read ahead of the MFMA that consumes them (GELU span)
+  constexpr int FD1 = MR_FD1, FD2 = MR_FD2;              // ... inside GEMM1 / GEMM2, where the other phase's registers are free
+  const float* const b1tab = reinterpret_cast<const float*>(smem + MR_NST * STAGE);
   const int r = lane & 31, kh = lane >> 5;
   const unsigned lds0 = (unsigned)(size_t)(lptrm_t)smem;
   const unsigned voff = (unsigned)(wave * NP * 1024 + lane * 16);      // this lane's 16 bytes inside a stage image
 
-  int tile = blockIdx.x;
-  if (tile >= n_tiles) return;
-
-  // bias table of conv1 (already in accumulator order) -> LDS
-  for (int i = t; i < HID; i += 512) b1tab[i] = b1img[i];
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // table written before the first ring barrier publishes it
-
-  // ring prologue: stages of steps 0 .. NST-2 (chunk = step % NCH; the image repeats every NCH steps)
+  // ring: stage n (hidden chunk n % NCH; the image repeats every NCH stages) is issued right after barrier n-3, waited for
+  // (counted vmcnt) before barrier n, which publishes it; its slot is refilled after barrier n+1, when every wave has
+  // finished GEMM2(n).
   int issue_chunk = 0, issue_slot = 0;
   auto issue = [&]() {
     mr_dma<NP>(voff, wimg + (size_t)issue_chunk * STAGE, lds0 + issue_slot * STAGE + wave * NP * 1024);
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void mlp_rows_kernel(const bf16* __restrict
   for (int i = 0; i < MR_NST - 1; ++i) issue();
   int slot = 0;
 
-  while (true) {
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     // ---- this wave's 32 token rows -> registers (tail rows re-read the last valid row; their results are never stored)
     const int m = tile * 256 + wave * 32 + r;
     const bool mok = m < M;
@@ -158,55 +162,65 @@ __global__ __launch_bounds__(512, 2) void mlp_rows_kernel(const bf16* __restrict
 #pragma unroll
       for (int i = 0; i < 16; ++i) yacc[ct][i] = 0.0f;
 
-#pragma unroll 1
-    for (int j = 0; j < NCH; ++j) {
-      // ring: everything but the NST-2 newest stages of this wave has landed; the barrier publishes stage `slot` of every wave
-      // and certifies that all waves finished reading the slot refilled next
-      mr_wait_vm<(MR_NST - 2) * NP>();
-      mr_bar();
-      issue();
-      const unsigned char* sp = smem + slot * STAGE + lane * 16;
-      // The 32 weight fragments of the step are ONE stream read FD fragments ahead of the MFMA that consumes them (a rotating set
-      // of FD registers; left alone hipcc reads every fragment into the same 4 VGPRs right before its MFMA and eats the full LDS
-      // latency 32 times per step).  The reads for GEMM2's first fragments are in flight during the GELU.
-      constexpr int FD = 4, NF = NKS + 2 * NCT;
-      u32x4 fr[FD];
+    f32x16 hacc;
+    u32x4 fr[FD2 > FD1 ? FD2 : FD1];
+    // GEMM1 of hidden chunk j from ring slot sl: the 16 W1 fragments are read FD ahead of their MFMA through a rotating register set
+    // (left alone hipcc reads every fragment into the same VGPRs right before its MFMA and eats the LDS latency 32 times per step)
+    auto gemm1 = [&](int j, int sl) {
+      const unsigned char* sp = smem + sl * STAGE + lane * 16;
 #pragma unroll
-      for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + i * 1024);
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- GEMM1: hidden chunk j of this wave's 32 tokens
-      f32x16 hacc;
-      {
-        const float* bp = b1tab + j * 32 + kh * 16;
+      for (int i = 0; i < FD1; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + i * 1024);
+      const float* bp = b1tab + j * 32 + kh * 16;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 4 * g);
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 4 * g);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) hacc[4 * g + e] = b[e];
-        }
+        for (int e = 0; e < 4; ++e) hacc[4 * g + e] = b[e];
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < NKS; ++s) {
-        hacc = mfma32(fr[s % FD], xr[s], hacc);
-        if (s + FD < NF) fr[s % FD] = *reinterpret_cast<const u32x4*>(sp + (s + FD) * 1024);
-        __builtin_amdgcn_sched_barrier(0);                     // pin: MFMA s, then the read FD ahead (waitcnt pass then emits lgkmcnt(FD-1))
+        hacc = mfma32(fr[s % FD1], xr[s], hacc);
+        if (s + FD1 < NKS) fr[s % FD1] = *reinterpret_cast<const u32x4*>(sp + (s + FD1) * 1024);
+        __builtin_amdgcn_sched_barrier(0);               // pin: MFMA s, then the read FD ahead (the waitcnt pass then emits lgkmcnt(FD-1))
       }
-      // ---- GELU, pack: the accumulator becomes GEMM2's B operand
+    };
+    // GELU + GEMM2 of the chunk in slot sl: GEMM2's first fragments are in flight during the GELU; the GELU'd accumulator, packed to
+    // bf16, is GEMM2's B operand
+    auto gelu_gemm2 = [&](int sl) {
+      const unsigned char* sp = smem + sl * STAGE + NKS * 1024 + lane * 16;
+#pragma unroll
+      for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + (2 * (i % NCT) + i / NCT) * 1024);
+      __builtin_amdgcn_sched_barrier(0);
       u32x4 hp[2];
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int e = 0; e < 4; ++e) hp[s2][e] = mr_pk2(gelu_sig(hacc[8 * s2 + 2 * e]), gelu_sig(hacc[8 * s2 + 2 * e + 1]));
-      // ---- GEMM2: all C output channels, K = this chunk's 32 hidden units
+      __builtin_amdgcn_sched_barrier(0);
+      // fragment order (s2 outer, ct inner): consecutive MFMAs hit different accumulators (image order is [ct][s2])
+      auto foff = [](int f) { return (2 * (f % NCT) + f / NCT) * 1024; };
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct)
+      for (int f = 0; f < 2 * NCT; ++f) {
+        // the first FD fragments were read before the GELU; top the read-ahead up to FD2 once the GELU's registers are free
+        if (f == 0) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const int f = NKS + 2 * ct + s2;
-          yacc[ct] = mfma32(fr[f % FD], hp[s2], yacc[ct]);
-          if (f + FD < NF) fr[f % FD] = *reinterpret_cast<const u32x4*>(sp + (f + FD) * 1024);
+          for (int i = FD; i < FD2; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + foff(i));
           __builtin_amdgcn_sched_barrier(0);
         }
+        yacc[f % NCT] = mfma32(fr[f % FD2], hp[f / NCT], yacc[f % NCT]);
+        if (f + FD2 < 2 * NCT) fr[f % FD2] = *reinterpret_cast<const u32x4*>(sp + foff(f + FD2));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+#pragma unroll 1
+    for (int j = 0; j < NCH; ++j) {
+      mr_wait_vm<(MR_NST - 2) * NP>();  // this wave's pieces of stage j have landed (the NST-2 newest stages may be in flight)
+      mr_bar();
+      issue();
+      gemm1(j, slot);
+      gelu_gemm2(slot);
       slot = slot == MR_NST - 1 ? 0 : slot + 1;
     }
 
@@ -226,10 +240,23 @@ __global__ __launch_bounds__(512, 2) void mlp_rows_kernel(const bf16* __restrict
         if (mok) *reinterpret_cast<bf16x8*>(Y + rowoff + 32 * ct + 8 * q) = o;
       }
     }
-    tile += gridDim.x;
-    if (tile >= n_tiles) break;
   }
   mr_wait_vm<0>();     // no DMA may be in flight into the LDS of a finished workgroup
+}
+
+template <int C, int HID>
+__global__ __launch_bounds__(512, 2) void mlp_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
+                                                          const float* __restrict__ b1img, const float* __restrict__ b2, const int M, const int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int STAGE = (C / 16 + 2 * (C / 32)) * 1024;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  if ((int)blockIdx.x >= n_tiles) return;
+  // bias table of conv1 (already in accumulator order) -> LDS
+  float* const b1tab = reinterpret_cast<float*>(smem + MR_NST * STAGE);
+  for (int i = t; i < HID; i += 512) b1tab[i] = b1img[i];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // table written before the first barrier publishes it
+  mlp_rows_body<C, HID>(X, Y, wimg, b2, M, n_tiles, smem, wave, lane);
 }
 
 // Builds the fragment-major weight image + bias table from the engine's standard packed layers (w1 [HID][k1w], w2 [C][k2w],
