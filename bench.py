@@ -39,11 +39,11 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--episodes', type=int, default=32, help='episodes per GPU per step (ep_per_batch)')
+    ap.add_argument('--episodes', type=int, default=64, help='episodes per GPU per step (ep_per_batch)')
     ap.add_argument('--shot', type=int, default=5)
     ap.add_argument('--model', default='visformer_micro_80', choices=sorted(MODELS), help='encoder (default = BASELINE configs[1])')
     ap.add_argument('--numerics', default='bf16', choices=['bf16', 'parity'])
-    ap.add_argument('--chunk', type=int, default=int(os.environ.get('FSVIT_CHUNK', 1600)), help='images per encoder chunk')
+    ap.add_argument('--chunk', type=int, default=int(os.environ.get('FSVIT_CHUNK', 6400)), help='images per encoder chunk')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-episodes', type=int, default=16)
@@ -300,7 +300,7 @@ def main():
             traffic = None          # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
             import glob
             tfs = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_hbm_traffic.json')))      # newest committed PMC passes
-            if tfs and args.model == 'visformer_micro_80' and args.numerics == 'bf16' and E == 32 and args.mode == 'eval':
+            if tfs and args.model == 'visformer_micro_80' and args.numerics == 'bf16' and E == 64 and args.chunk == 6400 and args.mode == 'eval':
                 with open(tfs[-1]) as f:
                     tj = json.load(f)
                 cand = [k for k in tj if k == dom] or [k for k in tj if k.split('<')[0] == dom.split('<')[0]]

@@ -661,7 +661,7 @@ extern "C" int fsvit_stage1_block(const void* x, void* y, const void* w1, const 
 extern "C" int fsvit_mlp_rows(const void* x, void* y, const void* w1, int k1w, const float* b1, const void* w2, int k2w, const float* b2,
                               int M, int C, int hid, void* stream) {
   if (!x || !y || !w1 || !w2) return fail(FSVIT_ERR_ARG, "null argument");
-  if (!mlp_rows_supported(FSVIT_BF16, C, hid)) return fail(FSVIT_ERR_ARG, "fsvit_mlp_rows: only C = 256, hidden = 1024 (bf16) is built");
+  if (!mlp_rows_supported(FSVIT_BF16, C, hid)) return fail(FSVIT_ERR_ARG, "fsvit_mlp_rows: only C = 256 / hidden = 1024 and C = 512 / hidden = 2048 (bf16) are built");
   if (k1w < C || k2w < hid) return fail(FSVIT_ERR_ARG, "weight rows shorter than K");
   hipStream_t st = (hipStream_t)stream;
   void *img = nullptr, *b1i = nullptr;

@@ -1,15 +1,16 @@
-// Fused Mlp of the Visformer attention blocks (stage 2: C = 256, hidden = 1024), bf16:
+// Fused Mlp of the Visformer attention blocks (stage 2: C = 256, hidden = 1024; stage 3: C = 512, hidden = 2048), bf16:
 //   y = x + conv3( GELU( conv1( BN(x) ) ) )     test_phase/models/visformer.py:146-150 (spatial_conv=False) + :262 (residual)
 // with the eval BatchNorm folded into conv1 (column scale + bias, engine.hip build()).  Both convs are 1x1 = row-wise
 // GEMMs, so the hidden activation (4C per token - 655 MB per 3200-image step and block) never has to leave the chip.
 //
-// Why the two gemm256 launches were slow: at K = 256 / N = 256 a 256x256 output tile has only four K tiles between
-// epilogues, and the hidden tensor is written and re-read through HBM.  Here:
-//   * a workgroup owns 256 token rows, a WAVE owns 32 of them for the whole Mlp; the wave's x rows live in registers as
-//     MFMA B operands (64 VGPRs), the output accumulator (32 rows x 256 channels fp32) in 128 more;
+// Why the two gemm256 launches were slow: at K = 256 / 512 a 256x256 output tile has only 4 / 8 K tiles between epilogues whose
+// GELU + store tail costs as much as the main loop, and the hidden tensor is written and re-read through HBM.  Here:
+//   * a WAVE owns 32 RB token rows for the whole Mlp (RB = 2 at C = 256, 1 at C = 512); its x rows live in registers as MFMA
+//     B operands (128 VGPRs), the output accumulator (32 RB rows x C channels fp32) in 256 more: one wave per SIMD with the
+//     whole 512-entry register file (4 waves per workgroup, one workgroup per CU);
 //   * only weights move: the hidden dimension is walked in chunks of 32 units; chunk j needs W1[32j..32j+32][0..C) and
-//     W2[0..C)[32j..32j+32) = 32 KB, which every wave reads from LDS as MFMA A operands (v_mfma_f32_32x32x16_bf16:
-//     D^T[n][m] = sum_k W[n][k] X[m][k], 32 flop per LDS byte) - 256 flop per staged byte, twice gemm256's;
+//     W2[0..C)[32j..32j+32) = C/8 KB, which every wave reads from LDS as MFMA A operands (v_mfma_f32_32x32x16_bf16:
+//     D^T[n][m] = sum_k W[n][k] X[m][k]); at RB = 2 a fragment feeds two MFMAs.  128 RB flop per staged byte, 32 RB per LDS byte;
 //   * GEMM1's accumulator IS GEMM2's B operand: a lane of the 32x32 result holds 16 hidden units of one token; after
 //     bias + GELU they are packed to bf16 and fed straight back (the k order this implies is baked into the packed W2);
 //   * every permutation is paid at PACK time (mlp_pack_kernel): the weight image in HBM is already the sequence of
@@ -17,9 +18,9 @@
 //     LDS-DMA copy (no swizzle, no address arithmetic) and every ds_read_b128 is lane-linear = conflict-free; the channel
 //     order of the x registers / output accumulators is chosen so that a lane holds 16 CONSECUTIVE channels of its token
 //     per 32-channel tile: 16-byte loads and stores, and the residual comes from the very registers that fed GEMM1;
-//   * the weight stream is periodic (1 MB per 256 rows, L2-resident), so one 4-stage LDS ring with counted vmcnt runs
-//     across tiles of the persistent workgroup; the only workgroup-wide synchronisation is the ring's barrier (one per
-//     32 MFMAs per wave); waves never exchange data.
+//   * the weight stream is periodic (1 / 4 MB per tile), so one ring of four 32 KB LDS slots (32 fragments each: a whole chunk
+//     at C = 256, its W1 / W2 half at C = 512) with counted vmcnt runs across the tiles of the persistent workgroup; the
+//     only workgroup-wide synchronisation is the ring's barrier (one per slot); waves never exchange data.
 // Layout contract with the pack kernel (lane = 32 * kh + r):
 //   x regs   xr[s], s < C/16     : token r, channels 32 (s/2) + 16 kh + 8 (s&1) + 0..7
 //   W1 frag  (chunk j, step s)   : hidden unit 32 j + r, the same 8 channels
@@ -27,6 +28,9 @@
 //   hp[s2]                       : hacc[8 s2 .. 8 s2 + 8) packed to bf16
 //   W2 frag  (j, ct, s2)         : output channel 32 ct + 16 (r>>2 & 1) + 4 (r>>3) + (r&3), hidden units as hp[s2] of lane kh
 //   yacc[ct][i]                  : channel 32 ct + 16 kh + i of token r
+// History: the first version ran 8 waves x 32 rows (two waves per SIMD, 256 registers each) at C = 256 only:
+// 757 TFLOP/s; PMC showed MFMA 34 % and VALU 32 % busy with no overlap, and neither a phase shift between SIMD partners, deeper
+// fragment read-ahead nor MFMA reordering moved it.
 #include <stdlib.h>
 
 #include "fsvit_common.h"
@@ -39,57 +43,38 @@ typedef __attribute__((address_space(3))) void* lptrm_t;
 
 namespace {
 
-constexpr int MR_NST = 4;                       // ring stages
-#ifndef MR_FD1
-#define MR_FD1 4
-#endif
-#ifndef MR_FD2
-#define MR_FD2 4
-#endif
+constexpr int MR_NST = 4;                       // ring slots
+constexpr int MR_SLOT = 32768;                  // 32 fragments of 1 KiB
+constexpr int MR_NW = 4;                        // waves per workgroup (one per SIMD)
+constexpr int MR_FD = 6;                        // weight fragments read ahead of the MFMAs that consume them
 
-// NP consecutive 1 KiB LDS-DMAs: source = sbase + voff + i * 1024, destination = lds + i * 1024.  The immediate offset of
-// global_load_lds moves the LDS destination together with the global source (tools/probes/ldsdma_offset.hip, measured on
-// gfx950), so a linear copy needs one M0 write and no address arithmetic.
-template <int NP>
-__device__ __forceinline__ void mr_dma(unsigned voff, const void* sbase, unsigned lds) {
+// This wave's share of one ring slot: 8 consecutive 1 KiB LDS-DMAs, source = sbase + voff + i * 1024, destination = lds + i * 1024.
+// The immediate offset of global_load_lds moves the LDS destination together with the global source (tools/probes/
+// ldsdma_offset.hip, measured on gfx950), so a linear copy needs no address arithmetic; the 13-bit offset field covers 4 pieces.
+__device__ __forceinline__ void mr_dma8(unsigned voff, const void* sbase, unsigned lds) {
   unsigned keep;
-  static_assert(NP == 2 || NP == 4, "pieces per wave");
-  if constexpr (NP == 4) {
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds)
-        : "memory");
-  } else {
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds)
-        : "memory");
-  }
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %4\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %3\n\t"
+      "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+      "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
+      "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
+      "s_mov_b32 m0, %5\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %2, %3\n\t"
+      "global_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+      "global_load_lds_dwordx4 %2, %3 offset:2048\n\t"
+      "global_load_lds_dwordx4 %2, %3 offset:3072\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "v"(voff + 4096u), "s"(sbase), "s"(lds), "s"(lds + 4096u)
+      : "memory");
 }
 __device__ __forceinline__ void mr_bar() {
   asm volatile("s_barrier" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
-}
-template <int N> __device__ __forceinline__ void mr_wait_vm() {
-  static_assert(N == 0 || N == 2 || N == 4 || N == 8, "add the literal");
-  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // x rows are loaded through inline asm: a compiler-visible global_load inside the tile loop makes hipcc's waitcnt pass carry
@@ -106,157 +91,208 @@ __device__ __forceinline__ unsigned mr_pk2(float a, float b) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-__device__ __forceinline__ f32x16 mfma32(u32x4 a, u32x4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+// MFMAs are issued from inline asm with the register FILE of the accumulator spelled out: the 256 output accumulators must
+// live in AGPRs and everything else (x rows, GEMM1 accumulators, fragments) in arch VGPRs.  Left to hipcc's allocator the
+// kernel kept the outputs in VGPRs, spilled the x rows to scratch and reloaded one before every MFMA behind s_waitcnt vmcnt(0).
+// What the compiler no longer does for these instructions and the kernel does by hand: wait states between the last MFMA that
+// writes an accumulator and the first VALU / v_accvgpr_read that reads it (s_nop blocks below), and between the VALU that packs hp
+// and the first MFMA that reads it.  Dependent MFMAs on one accumulator issue back to back (same opcode, same vDst).
+__device__ __forceinline__ void mfma32_v(u32x4 a, u32x4 b, f32x16& c) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma32_a(u32x4 a, u32x4 b, f32x16& c) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// accumulator := 0 without ever being a VGPR value (a C++ `= 0` makes the loop-carried accumulators VGPR-class and every asm use
+// a 16-register round trip through v_accvgpr_write / read)
+__device__ __forceinline__ void mfma32_a_zero(f32x16& c) {
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  asm volatile("s_nop 7\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(c) : "v"(z));      // s_nop: VALU-written z -> MFMA SrcA/B
 }
 
 }  // namespace
 
-// Measured and dropped: waves 4-7 - the SIMD partners of waves 0-3 - running GEMM1 one barrier interval early so that
-// one partner is in its GELU while the other issues MFMAs (-3 %); read-ahead depths 6 / 8 instead of 4 (+-0 %: LDS latency is not
-// the limiter); (s2 outer, ct inner) MFMA order in GEMM2 (+-0 %).
-template <int C, int HID>
-__device__ __forceinline__ void mlp_rows_body(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
-                                              const float* __restrict__ b2, const int M, const int n_tiles, unsigned char* smem, const int wave, const int lane) {
+template <int C, int HID, int RB>
+__global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
+                                                          const float* __restrict__ b1img, const float* __restrict__ b2, const int M, const int n_tiles) {
   constexpr int NCT = C / 32, NKS = C / 16, NCH = HID / 32;
-  constexpr int STAGE = (NKS + 2 * NCT) * 1024;          // W1 fragments then W2 fragments of one hidden chunk
-  constexpr int NP = STAGE / 1024 / 8;                   // 1 KiB DMA pieces per wave and stage
-  constexpr int FD = 4;                                  // weight fragments read ahead of the MFMA that consumes them (GELU span)
-  constexpr int FD1 = MR_FD1, FD2 = MR_FD2;              // ... inside GEMM1 / GEMM2, where the other phase's registers are free
-  const float* const b1tab = reinterpret_cast<const float*>(smem + MR_NST * STAGE);
+  constexpr int PPC = 2 * NKS / 32;                      // ring slots per hidden chunk: 1 (W1 | W2) or 2 (W1, W2)
+  constexpr int BM = MR_NW * 32 * RB;                    // token rows per workgroup tile
+  constexpr int NACC = RB == 1 ? 2 : 1;                  // GEMM1 accumulators per row block (two independent MFMA chains per wave)
+  constexpr int FD = MR_FD;
+  static_assert(RB * NKS == 32 && (PPC == 1 || PPC == 2), "register budget: 128 x + 256 y VGPRs");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const b1tab = reinterpret_cast<float*>(smem + MR_NST * MR_SLOT);
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = lane & 31, kh = lane >> 5;
   const unsigned lds0 = (unsigned)(size_t)(lptrm_t)smem;
-  const unsigned voff = (unsigned)(wave * NP * 1024 + lane * 16);      // this lane's 16 bytes inside a stage image
+  const unsigned voff = (unsigned)(wave * 8192 + lane * 16);           // this lane's 16 bytes inside a slot image
+  if ((int)blockIdx.x >= n_tiles) return;
 
-  // ring: stage n (hidden chunk n % NCH; the image repeats every NCH stages) is issued right after barrier n-3, waited for
-  // (counted vmcnt) before barrier n, which publishes it; its slot is refilled after barrier n+1, when every wave has
-  // finished GEMM2(n).
-  int issue_chunk = 0, issue_slot = 0;
+  // bias table of conv1 (already in accumulator order) -> LDS
+  for (int i = t; i < HID; i += MR_NW * 64) b1tab[i] = b1img[i];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // table written before the first ring barrier publishes it
+
+  // ring: slot image n (the weight image is a sequence of NCH * PPC slot images, repeated for every tile) is issued right after
+  // barrier n-3, waited for (counted vmcnt: 8 DMAs per wave and slot) before barrier n-1 and first read after barrier n: LDS-DMA
+  // data is ordered for a ds_read only by the issuing wave's counted vmcnt followed by a barrier the reader passes, and the read
+  // must sit one barrier interval AFTER that wait (cdna_hip_programming.md, 8-phase template).  A build that waited for image n
+  // right before barrier n and read it right after produced rare inf tiles in the first 2 KB of a slot, coming and going with
+  // code placement.  Barrier n also certifies that every wave has finished reading the slot refilled next.
+  int issue_img = 0, issue_slot = 0;
   auto issue = [&]() {
-    mr_dma<NP>(voff, wimg + (size_t)issue_chunk * STAGE, lds0 + issue_slot * STAGE + wave * NP * 1024);
-    issue_chunk = issue_chunk == NCH - 1 ? 0 : issue_chunk + 1;
+    mr_dma8(voff, wimg + (size_t)issue_img * MR_SLOT, lds0 + issue_slot * MR_SLOT + wave * 8192);
+    issue_img = issue_img == NCH * PPC - 1 ? 0 : issue_img + 1;
     issue_slot = issue_slot == MR_NST - 1 ? 0 : issue_slot + 1;
   };
 #pragma unroll
   for (int i = 0; i < MR_NST - 1; ++i) issue();
   int slot = 0;
+  bool first = true;
+  auto ring_sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // all but the newest slot image of this wave have landed: the image read after the NEXT barrier
+    mr_bar();
+    issue();
+  };
+  auto next_slot = [&]() { slot = slot == MR_NST - 1 ? 0 : slot + 1; };
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    // ---- this wave's 32 token rows -> registers (tail rows re-read the last valid row; their results are never stored)
-    const int m = tile * 256 + wave * 32 + r;
-    const bool mok = m < M;
-    const size_t rowoff = (size_t)(mok ? m : M - 1) * C + 16 * kh;
-    u32x4 xr[NKS];
+    // ---- this wave's 32 RB token rows -> registers (tail rows re-read the last valid row; their results are never stored)
+    bool mok[RB];
+    size_t rowoff[RB];
+    u32x4 xr[RB][NKS];
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) xr[s] = mr_gload16(X + rowoff + 32 * (s >> 1) + 8 * (s & 1));
+    for (int rb = 0; rb < RB; ++rb) {
+      const int m = tile * BM + (wave * RB + rb) * 32 + r;
+      mok[rb] = m < M;
+      rowoff[rb] = (size_t)(mok[rb] ? m : M - 1) * C + 16 * kh;
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) xr[rb][s] = mr_gload16(X + rowoff[rb] + 32 * (s >> 1) + 8 * (s & 1));
+    }
     // The x loads and the previous tile's stores share the vmcnt queue with the ring's DMAs: drain once per tile (every DMA older
     // than these loads landed long ago).  The registers are threaded through the wait so no use can be scheduled above it.
-    static_assert(NKS == 16, "operand list of the wait below");
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]),
-                   "+v"(xr[8]), "+v"(xr[9]), "+v"(xr[10]), "+v"(xr[11]), "+v"(xr[12]), "+v"(xr[13]), "+v"(xr[14]), "+v"(xr[15])
-                 :: "memory");
-    f32x16 yacc[NCT];
+    {
+      u32x4* xf = &xr[0][0];
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(xf[4]), "+v"(xf[5]), "+v"(xf[6]), "+v"(xf[7]),
+                     "+v"(xf[8]), "+v"(xf[9]), "+v"(xf[10]), "+v"(xf[11]), "+v"(xf[12]), "+v"(xf[13]), "+v"(xf[14]), "+v"(xf[15])
+                   :: "memory");
+      asm volatile(""
+                   : "+v"(xf[16]), "+v"(xf[17]), "+v"(xf[18]), "+v"(xf[19]), "+v"(xf[20]), "+v"(xf[21]), "+v"(xf[22]), "+v"(xf[23]),
+                     "+v"(xf[24]), "+v"(xf[25]), "+v"(xf[26]), "+v"(xf[27]), "+v"(xf[28]), "+v"(xf[29]), "+v"(xf[30]), "+v"(xf[31])
+                   :: "memory");
+    }
+    if (first) { mr_bar(); first = false; }             // one barrier between the drain above and the first reads of image 0
+    f32x16 yacc[RB][NCT];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) yacc[ct][i] = 0.0f;
-
-    f32x16 hacc;
-    u32x4 fr[FD2 > FD1 ? FD2 : FD1];
-    // GEMM1 of hidden chunk j from ring slot sl: the 16 W1 fragments are read FD ahead of their MFMA through a rotating register set
-    // (left alone hipcc reads every fragment into the same VGPRs right before its MFMA and eats the LDS latency 32 times per step)
-    auto gemm1 = [&](int j, int sl) {
-      const unsigned char* sp = smem + sl * STAGE + lane * 16;
-#pragma unroll
-      for (int i = 0; i < FD1; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + i * 1024);
-      const float* bp = b1tab + j * 32 + kh * 16;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 4 * g);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hacc[4 * g + e] = b[e];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) {
-        hacc = mfma32(fr[s % FD1], xr[s], hacc);
-        if (s + FD1 < NKS) fr[s % FD1] = *reinterpret_cast<const u32x4*>(sp + (s + FD1) * 1024);
-        __builtin_amdgcn_sched_barrier(0);               // pin: MFMA s, then the read FD ahead (the waitcnt pass then emits lgkmcnt(FD-1))
-      }
-    };
-    // GELU + GEMM2 of the chunk in slot sl: GEMM2's first fragments are in flight during the GELU; the GELU'd accumulator, packed to
-    // bf16, is GEMM2's B operand
-    auto gelu_gemm2 = [&](int sl) {
-      const unsigned char* sp = smem + sl * STAGE + NKS * 1024 + lane * 16;
-#pragma unroll
-      for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + (2 * (i % NCT) + i / NCT) * 1024);
-      __builtin_amdgcn_sched_barrier(0);
-      u32x4 hp[2];
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hp[s2][e] = mr_pk2(gelu_sig(hacc[8 * s2 + 2 * e]), gelu_sig(hacc[8 * s2 + 2 * e + 1]));
-      __builtin_amdgcn_sched_barrier(0);
-      // fragment order (s2 outer, ct inner): consecutive MFMAs hit different accumulators (image order is [ct][s2])
-      auto foff = [](int f) { return (2 * (f % NCT) + f / NCT) * 1024; };
-#pragma unroll
-      for (int f = 0; f < 2 * NCT; ++f) {
-        // the first FD fragments were read before the GELU; top the read-ahead up to FD2 once the GELU's registers are free
-        if (f == 0) {
-#pragma unroll
-          for (int i = FD; i < FD2; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + foff(i));
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        yacc[f % NCT] = mfma32(fr[f % FD2], hp[f / NCT], yacc[f % NCT]);
-        if (f + FD2 < 2 * NCT) fr[f % FD2] = *reinterpret_cast<const u32x4*>(sp + foff(f + FD2));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
+      for (int ct = 0; ct < NCT; ++ct) mfma32_a_zero(yacc[rb][ct]);
 
 #pragma unroll 1
     for (int j = 0; j < NCH; ++j) {
-      mr_wait_vm<(MR_NST - 2) * NP>();  // this wave's pieces of stage j have landed (the NST-2 newest stages may be in flight)
-      mr_bar();
-      issue();
-      gemm1(j, slot);
-      gelu_gemm2(slot);
-      slot = slot == MR_NST - 1 ? 0 : slot + 1;
+      ring_sync();
+      u32x4 fr[FD];
+      f32x16 hacc[RB][NACC];
+      // ---- GEMM1: hidden chunk j of this wave's tokens.  The NKS W1 fragments are read FD ahead of their MFMAs through a rotating
+      // register set (left alone hipcc reads every fragment into the same VGPRs right before its MFMA: full LDS latency each time).
+      {
+        const unsigned char* sp = smem + slot * MR_SLOT + lane * 16;
+#pragma unroll
+        for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + i * 1024);
+        const float* bp = b1tab + j * 32 + kh * 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 4 * g);
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              hacc[rb][0][4 * g + e] = b[e];
+              if (NACC == 2) hacc[rb][1][4 * g + e] = 0.0f;
+            }
+        }
+        // the bias reaches the accumulators through ds_read / v_mov: wait states VALU -> MFMA SrcC (hipcc's hazard recognizer does not
+        // look inside inline asm), accumulators threaded through so the moves cannot sink below
+        asm volatile("s_nop 7" : "+v"(hacc[0][0]), "+v"(hacc[RB - 1][NACC - 1]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) mfma32_v(fr[s % FD], xr[rb][s], hacc[rb][s % NACC]);
+          if (s + FD < NKS) fr[s % FD] = *reinterpret_cast<const u32x4*>(sp + (s + FD) * 1024);
+          __builtin_amdgcn_sched_barrier(0);             // pin: MFMAs of step s, then the read FD ahead (the waitcnt pass then emits lgkmcnt(FD-1))
+        }
+      }
+      // wait states MFMA -> VALU; the accumulators are threaded through so that no GELU instruction can be scheduled above them
+      if constexpr (RB * NACC == 2)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(hacc[0][0]), "+v"(hacc[RB - 1][NACC - 1]));
+      __builtin_amdgcn_sched_barrier(0);
+      if (PPC == 2) next_slot();
+      // ---- GELU, pack: the accumulator becomes GEMM2's B operand
+      u32x4 hp[RB][2];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a0 = hacc[rb][0][8 * s2 + 2 * e], a1 = hacc[rb][0][8 * s2 + 2 * e + 1];
+            if (NACC == 2) { a0 += hacc[rb][1][8 * s2 + 2 * e]; a1 += hacc[rb][1][8 * s2 + 2 * e + 1]; }
+            hp[rb][s2][e] = mr_pk2(gelu_sig(a0), gelu_sig(a1));
+          }
+      if (PPC == 2) ring_sync();
+      // ---- GEMM2: all C output channels, K = this chunk's 32 hidden units; fragment order (s2 outer, ct inner) so that consecutive
+      // MFMAs hit different accumulators (the image order is [ct][s2])
+      {
+        const unsigned char* sp = smem + slot * MR_SLOT + (PPC == 2 ? 0 : NKS) * 1024 + lane * 16;
+        auto foff = [](int f) { return (2 * (f % NCT) + f / NCT) * 1024; };
+#pragma unroll
+        for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + foff(i));
+        if constexpr (RB == 2) asm volatile("s_nop 7" : "+v"(hp[0][0]), "+v"(hp[0][1]), "+v"(hp[1][0]), "+v"(hp[1][1]));   // VALU-written hp -> MFMA SrcB
+        else asm volatile("s_nop 7" : "+v"(hp[0][0]), "+v"(hp[0][1]));
+
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 2 * NCT; ++f) {
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) mfma32_a(fr[f % FD], hp[rb][f / NCT], yacc[rb][f % NCT]);
+          if (f + FD < 2 * NCT) fr[f % FD] = *reinterpret_cast<const u32x4*>(sp + foff(f + FD));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      next_slot();
     }
 
+    {   // wait states MFMA -> v_accvgpr_read, accumulators threaded through
+      f32x16* yf = &yacc[0][0];
+      static_assert(RB * NCT == 16, "operand list");
+      asm volatile("s_nop 15\n\ts_nop 3"
+                   : "+a"(yf[0]), "+a"(yf[1]), "+a"(yf[2]), "+a"(yf[3]), "+a"(yf[4]), "+a"(yf[5]), "+a"(yf[6]), "+a"(yf[7]),
+                     "+a"(yf[8]), "+a"(yf[9]), "+a"(yf[10]), "+a"(yf[11]), "+a"(yf[12]), "+a"(yf[13]), "+a"(yf[14]), "+a"(yf[15]));
+    }
     // ---- epilogue: + residual (the x registers), + optional bias of conv3, 2 x 16-byte stores per 32-channel tile
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const bf16x8 xv = __builtin_bit_cast(bf16x8, xr[2 * ct + q]);
-        bf16x8 o;
+      for (int ct = 0; ct < NCT; ++ct) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float v = yacc[ct][8 * q + e] + (float)xv[e];
-          if (b2) v += b2[32 * ct + 16 * kh + 8 * q + e];
-          o[e] = (bf16)v;
+        for (int q = 0; q < 2; ++q) {
+          const bf16x8 xv = __builtin_bit_cast(bf16x8, xr[rb][2 * ct + q]);
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float v = yacc[rb][ct][8 * q + e] + (float)xv[e];
+            if (b2) v += b2[32 * ct + 16 * kh + 8 * q + e];
+            o[e] = (bf16)v;
+          }
+          if (mok[rb]) *reinterpret_cast<bf16x8*>(Y + rowoff[rb] + 32 * ct + 8 * q) = o;
         }
-        if (mok) *reinterpret_cast<bf16x8*>(Y + rowoff + 32 * ct + 8 * q) = o;
       }
-    }
   }
-  mr_wait_vm<0>();     // no DMA may be in flight into the LDS of a finished workgroup
-}
-
-template <int C, int HID>
-__global__ __launch_bounds__(512, 2) void mlp_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
-                                                          const float* __restrict__ b1img, const float* __restrict__ b2, const int M, const int n_tiles) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int STAGE = (C / 16 + 2 * (C / 32)) * 1024;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  if ((int)blockIdx.x >= n_tiles) return;
-  // bias table of conv1 (already in accumulator order) -> LDS
-  float* const b1tab = reinterpret_cast<float*>(smem + MR_NST * STAGE);
-  for (int i = t; i < HID; i += 512) b1tab[i] = b1img[i];
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // table written before the first barrier publishes it
-  mlp_rows_body<C, HID>(X, Y, wimg, b2, M, n_tiles, smem, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may be in flight into the LDS of a finished workgroup
 }
 
 // Builds the fragment-major weight image + bias table from the engine's standard packed layers (w1 [HID][k1w], w2 [C][k2w],
@@ -288,8 +324,9 @@ __global__ void mlp_pack_kernel(const bf16* __restrict__ w1, int k1w, const floa
 }
 
 bool mlp_rows_supported(int dtype, int C, int hid) {
-  static const bool off = [] { const char* e = getenv("FSVIT_MLP_ROWS"); return e && e[0] == '0'; }();
-  return !off && dtype == 1 && C == 256 && hid == 1024;
+  static const int mode = [] { const char* e = getenv("FSVIT_MLP_ROWS"); return e ? atoi(e) : 3; }();      // bit 0: C = 256, bit 1: C = 512
+  if (dtype != 1) return false;
+  return (C == 256 && hid == 1024 && (mode & 1)) || (C == 512 && hid == 2048 && (mode & 2));
 }
 size_t mlp_rows_image_bytes(int C, int hid) { return (size_t)(hid / 32) * (C / 16 + 2 * (C / 32)) * 1024; }
 
@@ -300,21 +337,28 @@ int launch_mlp_pack(const void* w1, int k1w, const float* b1, const void* w2, in
   return (int)hipGetLastError();
 }
 
-int launch_mlp_rows(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, int M, int C, int hid, hipStream_t s) {
-  if (C != 256 || hid != 1024) return (int)hipErrorInvalidValue;
-  if (M <= 0) return 0;
-  auto kern = mlp_rows_kernel<256, 1024>;
-  const int lds = MR_NST * (256 / 16 + 2 * (256 / 32)) * 1024 + 1024 * 4;
+template <int C, int HID, int RB>
+static int launch_mlp_rows_t(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, int M, hipStream_t s) {
+  auto kern = mlp_rows_kernel<C, HID, RB>;
+  const int lds = MR_NST * MR_SLOT + HID * 4;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  const int n_tiles = (M + 255) / 256;
+  constexpr int BM = MR_NW * 32 * RB;
+  const int n_tiles = (M + BM - 1) / BM;
   const int grid = n_tiles < 256 ? n_tiles : 256;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, (const bf16*)x, (bf16*)y, (const unsigned char*)wimg, b1img, b2, M, n_tiles);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(MR_NW * 64), lds, s, (const bf16*)x, (bf16*)y, (const unsigned char*)wimg, b1img, b2, M, n_tiles);
   return (int)hipGetLastError();
+}
+
+int launch_mlp_rows(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, int M, int C, int hid, hipStream_t s) {
+  if (M <= 0) return 0;
+  if (C == 256 && hid == 1024) return launch_mlp_rows_t<256, 1024, 2>(x, y, wimg, b1img, b2, M, s);
+  if (C == 512 && hid == 2048) return launch_mlp_rows_t<512, 2048, 1>(x, y, wimg, b1img, b2, M, s);
+  return (int)hipErrorInvalidValue;
 }
 
 }  // namespace fsvit

@@ -155,7 +155,7 @@ class VisformerEngine(_EncoderEngine):
     state_dict: encoder-relative reference keys."""
     _fn = dict(create='fsvit_visformer_create', destroy='fsvit_visformer_destroy', out_dim='fsvit_visformer_out_dim',
                workspace_bytes='fsvit_visformer_workspace_bytes', forward='fsvit_visformer_forward')
-    _default_chunk = 1600
+    _default_chunk = 3200
 
     def _make_cfg(self, cfg):
         c = _lib.VisformerCfg()
@@ -308,7 +308,7 @@ class ops:
 
     @staticmethod
     def mlp_rows(x, w1, b1, w2, b2=None):
-        """x [M][256] bf16; w1 [1024][K1w], w2 [256][K2w] packed K-major bf16; b1 [1024], b2 [256] fp32 or None.  y = x + W2 GELU(W1 x + b1) + b2."""
+        """x [M][C] bf16, C = 256 or 512; w1 [4C][K1w], w2 [C][K2w] packed K-major bf16; b1 [4C], b2 [C] fp32 or None.  y = x + W2 GELU(W1 x + b1) + b2."""
         _require_cuda(x, w1, w2)
         lib = _lib.load()
         y = torch.empty_like(x)

@@ -152,7 +152,8 @@ int fsvit_attention(const void* qkv_dev, void* ctx_dev, int B, int S, int heads,
 int fsvit_stage1_block(const void* x_dev, void* y_dev, const void* w1_dev, const float* b1_dev, const void* w2_dev,
                        const void* w3_dev, int B, void* stream);
 /* Fused Mlp of a Visformer attention block (visformer.py:146-150 with spatial_conv=False, + the residual of :262):
- * y = x + W2 GELU(W1 x + b1) (+ b2), rows = tokens.  bf16, C = 256, hidden = 1024 only (stage 2 of Visformer-S).  x, y [M][C]
+ * y = x + W2 GELU(W1 x + b1) (+ b2), rows = tokens.  bf16; C = 256 / hidden = 1024 and C = 512 / hidden = 2048 (stages 2, 3 of
+ * Visformer-S).  x, y [M][C]
  * (y may alias x); w1 [hid][k1w], w2 [C][k2w] K-contiguous bf16 rows (BatchNorm already folded into w1 / b1); b1 [hid], b2 [C]
  * fp32 or NULL.  The operator form packs the weights on every call (the engine packs once per checkpoint). */
 int fsvit_mlp_rows(const void* x_dev, void* y_dev, const void* w1_dev, int k1w, const float* b1_dev, const void* w2_dev, int k2w,
