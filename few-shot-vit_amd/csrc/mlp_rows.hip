@@ -130,6 +130,9 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
   const unsigned lds0 = (unsigned)(size_t)(lptrm_t)smem;
   const unsigned voff = (unsigned)(wave * 8192 + lane * 16);           // this lane's 16 bytes inside a slot image
   if ((int)blockIdx.x >= n_tiles) return;
+#ifdef MR_PAD     // code-placement screen (tools/screen_mlp_rows.sh): shifts every later instruction by 4 * MR_PAD bytes
+  asm volatile(".rept %0\n\ts_nop 0\n\t.endr" :: "n"(MR_PAD));
+#endif
 
   // bias table of conv1 (already in accumulator order) -> LDS
   for (int i = t; i < HID; i += MR_NW * 64) b1tab[i] = b1img[i];
