@@ -71,7 +71,7 @@ def train_step(model, optimizer, x_shot, x_query, label, n_way, world=1):
     return loss.item(), acc
 
 
-def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, save_root='./save'):
+def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, save_root='./save', warmup=False):
     log = log or utils.log
     fix_random_seeds(12345)
     svname = name
@@ -103,7 +103,7 @@ def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, sa
     for nm, key in (('tval', 'tval_dataset'), ('val', 'val_dataset')):
         if config.get(key):
             ds = datasets.make(config[key], **config[key + '_args'])
-            evals.append((nm, ds, CategoriesSampler(ds.label, config.get('eval_batches', 200), n_way, n_shot + n_query, ep_per_batch=4,
+            evals.append((nm, ds, CategoriesSampler(ds.label, config.get('eval_batches', 500 if warmup else 200), n_way, n_shot + n_query, ep_per_batch=4,
                                                     rank=rank, world_size=world)))
     if rank == 0:
         log('train dataset: {} (x{}), {}'.format(tuple(train_dataset[0][0].shape), len(train_dataset), train_dataset.n_classes))
@@ -113,7 +113,13 @@ def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, sa
         raise NotImplementedError('fsvit: freeze_bn training is not built')
     if rank == 0:
         log('num params: {}'.format(utils.compute_n_params(model)))
-    optimizer, lr_scheduler = utils.make_optimizer(model.parameters(), config['optimizer'], **config['optimizer_args'])
+    if warmup:    # train_meta_warmup.py:140-141: SGD(momentum 0.9) + epoch-indexed multi-step schedule with a 3-epoch linear warm-up
+        from .utils.schedulers import MultiStepLRScheduler
+        oa = config['optimizer_args']
+        optimizer = utils.FsvitSGD(model.parameters(), float(oa['lr']), momentum=0.9, weight_decay=float(oa['weight_decay']))
+        lr_scheduler = MultiStepLRScheduler(optimizer, oa['milestones'], decay_rate=0.5, warmup_lr_init=1e-5, warmup_t=3)
+    else:
+        optimizer, lr_scheduler = utils.make_optimizer(model.parameters(), config['optimizer'], **config['optimizer_args'])
 
     max_epoch, save_epoch = config['max_epoch'], config.get('save_epoch')
     max_va = 0.
@@ -164,7 +170,10 @@ def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, sa
             aves['tl'].add(float(t[0]))
             aves['ta'].add(float(t[1]))
         if lr_scheduler is not None:
-            lr_scheduler.step()
+            if warmup:
+                lr_scheduler.step(epoch - 1)                    # train_meta_warmup.py:217
+            else:
+                lr_scheduler.step()
         for k, v in aves.items():
             aves[k] = v.item()
             trlog[k].append(aves[k])
@@ -188,7 +197,7 @@ def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, sa
     return trlog
 
 
-def cli():
+def cli(warmup=False):
     parser = argparse.ArgumentParser()
     parser.add_argument('--config')
     parser.add_argument('--name', default=None)
@@ -201,7 +210,7 @@ def cli():
         utils.set_gpu(args.gpu)
     rank, world, local = parallel.init_from_env()
     torch.cuda.set_device(local)
-    main(config, args.name, args.tag, rank, world, torch.device('cuda', local), save_root=args.save_root)
+    main(config, args.name, args.tag, rank, world, torch.device('cuda', local), save_root=args.save_root, warmup=warmup)
     if world > 1:
         torch.distributed.destroy_process_group()
 
