@@ -461,7 +461,10 @@ int run_gemm(EngineBase* h, hipStream_t st, const char* layer, const Layer& L, c
   return timed(h, st, layer, kid, flops, [&]() { return launch_conv_gemm(p, h->dtype, st); });
 }
 
-int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsigned char* ws, bool first, hipStream_t st) {
+// xsrc2 != nullptr: images [0, B1) come from x, images [B1, Bc) from xsrc2 (the shot and query tensors of one MetaBaseline call: one
+// pass over cat([shot, query]) as the reference does, meta_baseline.py:29-32, without materialising the concatenation)
+int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsigned char* ws, bool first, hipStream_t st,
+                  const float* xsrc2 = nullptr, int B1 = 0) {
   const Plan pl = make_plan(h, Bc);
   const int dt = h->dtype;
   const size_t es = h->es;
@@ -473,7 +476,11 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
 
   // stem: conv1 / downsample as K=32 GEMMs over the im2col rows, conv2, conv3 (+identity, LeakyReLU), max-pool + pos1
   h->prof_last = nullptr;
-  RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() { return launch_im2col27(x, patches, Bc, img, img, h->H0, h->H0, dt, st); }));
+  if (!xsrc2) B1 = Bc;
+  RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() { return launch_im2col27(x, patches, B1, img, img, h->H0, h->H0, dt, st); }));
+  if (Bc > B1)
+    RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() {
+      return launch_im2col27(xsrc2, (unsigned char*)patches + (size_t)B1 * h->H0 * h->H0 * 32 * es, Bc - B1, img, img, h->H0, h->H0, dt, st); }));
   RC_TRY(run_gemm(h, st, "stem.conv1", h->conv1, conv_params(h->conv1, patches, c1, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C0, ACT_LRELU, nullptr, 0, nullptr), h->C0, 27));
   RC_TRY(run_gemm(h, st, "stem.conv2", h->conv2, conv_params(h->conv2, c1, c2, Bc, h->H0, h->H0, h->C0, h->C0, 3, 3, 1, 1, h->C1, ACT_LRELU, nullptr, 0, nullptr), h->C1, 9.0 * h->C0));
   static const bool split_stem = [] { const char* e = getenv("FSVIT_NO_FUSE"); return e && e[0] == '1'; }();
@@ -631,6 +638,19 @@ extern "C" int fsvit_meta_baseline_forward(void* hv, const float* x_shot, const 
   const int ns = E * way * shot, nq = E * Q, D = encoder_out_dim_any(hv);
   // the reference encodes cat([shots, queries]) in one call (meta_baseline.py:29-32); eval mode is
   // per-image independent, so two passes into one feature buffer are equivalent
+  {   // Visformer: ONE pass over shots + queries when the workspace holds them all (larger launches, fewer tile tails)
+    EngineBase* eb = static_cast<EngineBase*>(hv);
+    if (eb->kind == KIND_VISFORMER && x_shot && x_query && ns > 0 && nq > 0) {
+      fsvit_visformer* h = static_cast<fsvit_visformer*>(eb);
+      if (img_h != h->cfg.img_size || img_w != h->cfg.img_size)
+        return fail(FSVIT_ERR_IMG_SIZE, "Input image size (%d*%d) does not match model (%d*%d).", img_h, img_w, h->cfg.img_size, h->cfg.img_size);
+      if (ws && ((uintptr_t)ws & 255) == 0 && make_plan(h, (size_t)ns + nq).total <= ws_bytes) {
+        int rc1 = forward_chunk(h, x_shot, ns + nq, feat, (unsigned char*)ws, true, (hipStream_t)stream, x_query, ns);
+        if (rc1 != 0) return rc1;
+        return fsvit_proto_head(feat, feat + (size_t)ns * D, E, way, shot, Q, D, temp, method, logits, acc, loss, stream);
+      }
+    }
+  }
   int rc = encoder_forward_any(hv, x_shot, ns, img_h, img_w, feat, ws, ws_bytes, stream);
   if (rc != 0) return rc;
   rc = encoder_forward_any(hv, x_query, nq, img_h, img_w, feat + (size_t)ns * D, ws, ws_bytes, stream);

@@ -139,7 +139,7 @@ class _EncoderEngine:
         logits = torch.empty(E, Q, way, dtype=torch.float32, device=dev)
         acc = torch.empty(E, dtype=torch.float32, device=dev)
         loss = torch.empty(E, dtype=torch.float32, device=dev)
-        ws = self.workspace(max(E * way * shot, E * Q))
+        ws = self.workspace(E * way * shot + E * Q)      # shots + queries go through the encoder in one pass when they fit one chunk
         m = {'cos': _lib.HEAD_COS, 'sqr': _lib.HEAD_SQR, 'dot': _lib.HEAD_DOT}[method]
         with torch.cuda.device(dev):
             _lib.check(self.lib.fsvit_meta_baseline_forward(
