@@ -72,7 +72,10 @@ struct Layer {
   float* bias = nullptr;  // [groups*N] fp32 or null
   int N = 0, K = 0, Kw = 0, groups = 1;
 };
-struct Block1 { Layer c1, c2, c3; };
+struct Block1 {
+  Layer c1, c2, c3;
+  void* rows_img = nullptr;    // stage1_rows.hip: fragment-major image of the three convs (null: stage1_fused / unfused path)
+};
 struct BlockA {
   Layer qkv, proj, fc1, fc2;
   void* mlp_img = nullptr;     // mlp_rows.hip: fragment-major image of fc1 + fc2 (null: the two GEMM launches are used)
@@ -299,6 +302,14 @@ int build(fsvit_visformer* h, const SD& sd) {
     RC_TRY(pack_layer(h, &h->s1[i].c1, w1, h->hid1, h->C1, 1, 1, 1, nullptr, &n2.s, prenorm_bias(w1, h->hid1, h->C1, n2.t), true, nullptr, 0, nullptr, 0));
     RC_TRY(pack_layer(h, &h->s1[i].c2, w2, h->hid1, Cg, 3, 3, cf.group, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
     RC_TRY(pack_layer(h, &h->s1[i].c3, w3, h->C1, h->hid1, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
+    if (stage1_rows_supported(h->dtype, h->C1, h->hid1, cf.group, h->H1)) {
+      void* img = nullptr;
+      HIP_TRY(hipMalloc(&img, stage1_rows_image_bytes()));
+      h->allocs.push_back(img);
+      RC_TRY(launch_stage1_pack(h->s1[i].c1.w, h->s1[i].c2.w, h->s1[i].c3.w, img, nullptr));
+      HIP_TRY(hipDeviceSynchronize());
+      h->s1[i].rows_img = img;
+    }
   }
   // ---- patch embeds (visformer.py:266-288): conv k2 s2 + bias -> BN ; pos_embed added in the epilogue
   for (int s = 2; s <= 3; ++s) {
@@ -436,7 +447,7 @@ int tap(EngineBase* h, const std::string& name, const void* src, size_t bytes, b
 }
 
 // kernel ids reported by the profiler (names in fsvit_kernel_name)
-enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13 };
+enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_STAGE1R = 14 };
 
 
 // Runs one launch; in profiling mode brackets it with HIP events on the same stream.
@@ -502,7 +513,11 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
   const bool fuse1 = !no_fuse && stage1_fused_supported(dt, h->C1, h->hid1, h->cfg.group, h->H1);
   for (size_t i = 0; i < h->s1.size(); ++i) {
     const Block1& b = h->s1[i];
-    if (fuse1) {   // one LDS-resident kernel per block, ping-pong between x1 and x1b
+    if (fuse1 && b.rows_img) {   // band-per-wave kernel: activations in registers, only weights through LDS; ping-pong x1 / x1b
+      const double fl = 2.0 * Bc * h->H1 * h->H1 * ((double)h->hid1 * h->C1 + (double)h->hid1 * 9 * Cg + (double)h->C1 * h->hid1);
+      RC_TRY(timed(h, st, "stage1.block", KID_STAGE1R, fl, [&]() { return launch_stage1_rows(x1, x1b, b.rows_img, b.c1.bias, Bc, st); }));
+      std::swap(x1, x1b);
+    } else if (fuse1) {   // one LDS-resident kernel per block, ping-pong between x1 and x1b
       const double fl = 2.0 * Bc * h->H1 * h->H1 * ((double)h->hid1 * h->C1 + (double)h->hid1 * 9 * Cg + (double)h->C1 * h->hid1);
       RC_TRY(timed(h, st, "stage1.block", KID_STAGE1, fl,
                    [&]() { return launch_stage1_block(x1, x1b, b.c1.w, b.c1.bias, b.c2.w, b.c3.w, Bc, st); }));
@@ -674,7 +689,18 @@ extern "C" int fsvit_conv_gemm(const void* x, const void* w, const float* bias, 
 
 extern "C" int fsvit_stage1_block(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, void* stream) {
   if (!x || !y || !w1 || !b1 || !w2 || !w3 || x == y) return fail(FSVIT_ERR_ARG, "bad argument");
-  RC_TRY(launch_stage1_block(x, y, w1, b1, w2, w3, B, (hipStream_t)stream));
+  hipStream_t st = (hipStream_t)stream;
+  if (stage1_rows_supported(FSVIT_BF16, 128, 256, 8, 20)) {      // operator form: packs the fragment image on every call
+    void* img = nullptr;
+    HIP_TRY(hipMalloc(&img, stage1_rows_image_bytes()));
+    int rc = launch_stage1_pack(w1, w2, w3, img, st);
+    if (rc == 0) rc = launch_stage1_rows(x, y, img, b1, B, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(img);
+    if (rc != 0) return hipfail((hipError_t)rc, "fsvit_stage1_block");
+    return 0;
+  }
+  RC_TRY(launch_stage1_block(x, y, w1, b1, w2, w3, B, st));
   return 0;
 }
 
@@ -727,11 +753,11 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
   static const char* f32n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
                                "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<float,128,128,2,2,2>",
-                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel"};
+                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel", "stage1_rows_kernel"};
   static const char* bf16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
                                 "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<__bf16,128,128,2,2,2>",
-                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel"};
-  if (kernel_id < 0 || kernel_id > 13) return "?";
+                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "stage1_rows_kernel"};
+  if (kernel_id < 0 || kernel_id > 14) return "?";
   return dtype == FSVIT_F32 ? f32n[kernel_id] : bf16n[kernel_id];
 }
 

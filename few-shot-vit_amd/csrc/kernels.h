@@ -23,6 +23,13 @@ int launch_proto_head(const float* feat_shot, const float* feat_query, int E, in
 bool stage1_fused_supported(int dtype, int C1, int hid, int group, int H1);
 int launch_stage1_block(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, hipStream_t s);
 
+// stage-1 block, band-per-wave design (stage1_rows.hip; same contract as launch_stage1_block); wimg is built once by launch_stage1_pack
+// from the standard packed layers w1 [256][128], w2 [8][32][320], w3 [128][256]
+bool stage1_rows_supported(int dtype, int C1, int hid, int group, int H1);
+size_t stage1_rows_image_bytes();
+int launch_stage1_pack(const void* w1, const void* w2, const void* w3, void* wimg, hipStream_t s);
+int launch_stage1_rows(const void* x, void* y, const void* wimg, const float* b1, int B, hipStream_t s);
+
 // fused row-wise Mlp of the attention blocks (mlp_rows.hip; bf16, C = 256, hidden = 1024): y = x + W2 GELU(W1 x + b1) (+ b2), in place allowed.
 // wimg / b1img are built once by launch_mlp_pack from the standard packed layers (w1 [hid][k1w], w2 [C][k2w]).
 bool mlp_rows_supported(int dtype, int C, int hid);

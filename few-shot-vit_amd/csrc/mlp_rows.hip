@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
           for (int e = 0; e < 4; ++e) {
             float a0 = hacc[rb][0][8 * s2 + 2 * e], a1 = hacc[rb][0][8 * s2 + 2 * e + 1];
             if (NACC == 2) { a0 += hacc[rb][1][8 * s2 + 2 * e]; a1 += hacc[rb][1][8 * s2 + 2 * e + 1]; }
-            hp[rb][s2][e] = mr_pk2(gelu_sig(a0), gelu_sig(a1));
+            const f32x2 gg = gelu_sig2(f32x2{a0, a1});
+            hp[rb][s2][e] = mr_pk2(gg[0], gg[1]);
           }
       if (PPC == 2) ring_sync();
       // ---- GEMM2: all C output channels, K = this chunk's 32 hidden units; fragment order (s2 outer, ct inner) so that consecutive

@@ -151,16 +151,14 @@ __global__ __launch_bounds__(1024) void stage1_block_kernel(const bf16* __restri
       const int pr = tk / W, pc = tk - pr * W;
       const int pix = (pr + (hsel ? 0 : 1)) * PW + pc + 1;
       a += bias;
-      bf16x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (bf16)gelu_sig(a[e]);
+      const f32x2 g0 = gelu_sig2(f32x2{a[0], a[1]}), g1 = gelu_sig2(f32x2{a[2], a[3]});
+      const bf16x4 o = {(bf16)g0[0], (bf16)g0[1], (bf16)g1[0], (bf16)g1[1]};
       *reinterpret_cast<bf16x4*>(H1 + (nt * 2 + (lq >> 1)) * H1_PLANE + pix * 16 + (lq & 1) * 8) = o;
     }
   };
   auto h2_store = [&](int mt, f32x4 a) {
-    bf16x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (bf16)gelu_sig(a[e]);
+    const f32x2 g0 = gelu_sig2(f32x2{a[0], a[1]}), g1 = gelu_sig2(f32x2{a[2], a[3]});
+    const bf16x4 o = {(bf16)g0[0], (bf16)g0[1], (bf16)g1[0], (bf16)g1[1]};
     *reinterpret_cast<bf16x4*>(H2 + (nt * 2 + (lq >> 1)) * H2_PLANE + (mt * 16 + lrow) * 16 + (lq & 1) * 8) = o;
   };
 

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
+"""Runs the stage-1 block operator (stage1_rows.hip, or stage1_fused.hip with FSVIT_STAGE1_ROWS=0) a few times for rocprofv3 --pmc passes."""
 import sys, os, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fewshot_vit_amd.engine import ops
 from bench_ops import pack_w
 bf = torch.bfloat16
-B = 1600
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 3200
 x = torch.randn(B, 20, 20, 128, device='cuda').to(bf)
 w1 = pack_w(256, 128, 1, 1, bf)[0]; w2 = pack_w(256, 32, 3, 8, bf); w3 = pack_w(128, 256, 1, 1, bf)[0]
 b1 = torch.randn(256, device='cuda')
