@@ -244,68 +244,112 @@ __global__ __launch_bounds__(s1r::NW * 64, s1r::NW / 4) void stage1_rows_kernel(
       const unsigned char* sp = smem + slot * SLOT + lane * 16;
       u32x4 fr[FD];
 
-      // ---- conv1 + GELU -> H1 patch, one 16-channel n-tile at a time (fragments 4 nt + kc)
+      // One wave per SIMD overlaps nothing by itself: the VALU work of the block (2 x 256 GELUs per token, ~6 VALU issues per MFMA)
+      // is interleaved BY HAND with the MFMAs that do not depend on it - GELU + store of conv1's n-tile 0 under the MFMAs of
+      // n-tile 1, GELU of conv2's n-tile 0 under the MFMAs of n-tile 1 - and every LDS operand is requested one use ahead of the
+      // MFMA that consumes it (in-place rotation: the read for the next tap / fragment is issued right behind the MFMA that
+      // read the register).  sched_barrier(0) pins each (MFMAs, VALU slice, reads) group in source order.
+      auto h1_store = [&](int nt, int t8, const f32x4& a) {
+        // lane holds channels 16 nt + 4 q .. +3 of token (t8, m): plane 2 nt + q / 2, bytes (q & 1) * 8 of the pixel's 16-byte slot
+        const f32x2 g0 = gelu_sig2(f32x2{a[0], a[1]}), g1 = gelu_sig2(f32x2{a[2], a[3]});
+        u32x2 o;
+        o[0] = s1r_pk2(g0[0], g0[1]);
+        o[1] = s1r_pk2(g1[0], g1[1]);
+        if (!((rowok >> t8) & 1u)) o = u32x2{0u, 0u};
+        if (pixw[t8] >= 0) *reinterpret_cast<u32x2*>(H1 + (2 * nt + (q >> 1)) * PLANE + (q & 1) * 8 + pixw[t8] * 16) = o;
+      };
+      // ---- conv1 (fragments 4 nt + kc) + GELU -> H1 patch
+      {
+        f32x4 acc0[MT1], acc1[MT1];
+        const f32x4 bias0 = *reinterpret_cast<const f32x4*>(b1tab + g * 32 + q * 4);
+        const f32x4 bias1 = *reinterpret_cast<const f32x4*>(b1tab + g * 32 + 16 + q * 4);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        f32x4 acc[MT1];
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(b1tab + g * 32 + nt * 16 + q * 4);
+        for (int i = 0; i < 4; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + i * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + (4 * nt + i) * 1024);
-#pragma unroll
-        for (int t8 = 0; t8 < MT1; ++t8) acc[t8] = bias;
-        s1r_nop_v<MT1>(acc, 0);
+        for (int t8 = 0; t8 < MT1; ++t8) { acc0[t8] = bias0; acc1[t8] = bias1; }
+        s1r_nop_v<MT1>(acc0, 0);
+        s1r_nop_v<MT1>(acc1, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
 #pragma unroll
-          for (int t8 = 0; t8 < MT1; ++t8) mma16_v(fr[kc], xr[t8][kc], acc[t8]);
+          for (int t8 = 0; t8 < MT1; ++t8) mma16_v(fr[kc], xr[t8][kc], acc0[t8]);
+          fr[kc] = *reinterpret_cast<const u32x4*>(sp + (4 + kc) * 1024);          // n-tile 1's fragment, one k-chunk ... four uses ahead
           __builtin_amdgcn_sched_barrier(0);
         }
-        s1r_nop_v<MT1>(acc, 1);
+        s1r_nop_v<MT1>(acc0, 1);
         __builtin_amdgcn_sched_barrier(0);
-        // lane holds channels 16 nt + 4 q .. +3 of token (t8, m): plane 2 nt + q / 2, bytes (q & 1) * 8 of the pixel's 16-byte slot
-        unsigned char* const hp1 = H1 + (2 * nt + (q >> 1)) * PLANE + (q & 1) * 8;
+        constexpr int TPK = (MT1 + 3) / 4;                                         // n-tile 0 tiles GELU'd per k-chunk of n-tile 1
 #pragma unroll
-        for (int t8 = 0; t8 < MT1; ++t8) {
-          u32x2 o;
-          const f32x2 g0 = gelu_sig2(f32x2{acc[t8][0], acc[t8][1]}), g1 = gelu_sig2(f32x2{acc[t8][2], acc[t8][3]});
-          o[0] = s1r_pk2(g0[0], g0[1]);
-          o[1] = s1r_pk2(g1[0], g1[1]);
-          if (!((rowok >> t8) & 1u)) o = u32x2{0u, 0u};
-          if (pixw[t8] >= 0) *reinterpret_cast<u32x2*>(hp1 + pixw[t8] * 16) = o;
+        for (int kc = 0; kc < 4; ++kc) {
+#pragma unroll
+          for (int t8 = 0; t8 < MT1; ++t8) mma16_v(fr[kc], xr[t8][kc], acc1[t8]);
+#pragma unroll
+          for (int j = 0; j < TPK; ++j)
+            if (kc * TPK + j < MT1) h1_store(0, kc * TPK + j, acc0[kc * TPK + j]);
+          __builtin_amdgcn_sched_barrier(0);
         }
+        s1r_nop_v<MT1>(acc1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t8 = 0; t8 < MT1; ++t8) h1_store(1, t8, acc1[t8]);
       }
 
       // ---- conv2 (9 taps = 9 k-chunks of the 32 group channels) + GELU; fragments 8 + 2 tap + nt.  The packed results of the two
       // n-tiles form conv3's B operand: lane (m, q) holds hidden channels {4 q .. 4 q + 3} (n-tile 0) and {16 + 4 q ..} (n-tile 1)
       u32x4 hp[MT2];
+      {
+        f32x4 acc0[MT2], acc1[MT2];
+        u32x4 hb[MT2];
+        const unsigned char* const hrd = H1 + q * PLANE;
+        auto tapoff = [](int tap) { return ((tap / 3) * PW + tap % 3) * 16; };
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        f32x4 acc[MT2];
+        for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + (8 + 2 * i) * 1024);
 #pragma unroll
-        for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + (8 + 2 * i + nt) * 1024);
+        for (int t5 = 0; t5 < MT2; ++t5) hb[t5] = *reinterpret_cast<const u32x4*>(hrd + pix0[t5] * 16 + tapoff(0));
 #pragma unroll
-        for (int t5 = 0; t5 < MT2; ++t5) acc[t5] = f32x4{0.f, 0.f, 0.f, 0.f};
-        s1r_nop_v<MT2>(acc, 0);
+        for (int t5 = 0; t5 < MT2; ++t5) { acc0[t5] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[t5] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        s1r_nop_v<MT2>(acc0, 0);
+        s1r_nop_v<MT2>(acc1, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int toff = ((tap / 3) * PW + tap % 3) * 16;
-          u32x4 hb[MT2];
+        for (int tap = 0; tap < 9; ++tap) {                    // n-tile 0
 #pragma unroll
-          for (int t5 = 0; t5 < MT2; ++t5) hb[t5] = *reinterpret_cast<const u32x4*>(H1 + q * PLANE + pix0[t5] * 16 + toff);
-#pragma unroll
-          for (int t5 = 0; t5 < MT2; ++t5) mma16_v(fr[tap % FD], hb[t5], acc[t5]);
-          if (tap + FD < 9) fr[tap % FD] = *reinterpret_cast<const u32x4*>(sp + (8 + 2 * (tap + FD) + nt) * 1024);
+          for (int t5 = 0; t5 < MT2; ++t5) {
+            mma16_v(fr[tap % FD], hb[t5], acc0[t5]);
+            hb[t5] = *reinterpret_cast<const u32x4*>(hrd + pix0[t5] * 16 + tapoff(tap < 8 ? tap + 1 : 0));     // next tap (after tap 8: tap 0 again, for n-tile 1)
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          fr[tap % FD] = *reinterpret_cast<const u32x4*>(sp + (tap + FD < 9 ? 8 + 2 * (tap + FD) : 8 + 2 * (tap + FD - 9) + 1) * 1024);   // ... then n-tile 1's
           __builtin_amdgcn_sched_barrier(0);
         }
-        s1r_nop_v<MT2>(acc, 1);
+        s1r_nop_v<MT2>(acc0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {                    // n-tile 1, GELU of n-tile 0 underneath (tile tap / 2 at even taps)
+          const int fi = (tap + 9) % FD;
+#pragma unroll
+          for (int t5 = 0; t5 < MT2; ++t5) {
+            mma16_v(fr[fi], hb[t5], acc1[t5]);
+            if (tap < 8) hb[t5] = *reinterpret_cast<const u32x4*>(hrd + pix0[t5] * 16 + tapoff(tap + 1));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (tap + FD < 9) fr[fi] = *reinterpret_cast<const u32x4*>(sp + (8 + 2 * (tap + FD) + 1) * 1024);
+          if ((tap & 1) == 0 && tap / 2 < MT2) {
+            const int t5 = tap / 2;
+            const f32x2 g0 = gelu_sig2(f32x2{acc0[t5][0], acc0[t5][1]}), g1 = gelu_sig2(f32x2{acc0[t5][2], acc0[t5][3]});
+            hp[t5][0] = s1r_pk2(g0[0], g0[1]);
+            hp[t5][1] = s1r_pk2(g1[0], g1[1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        s1r_nop_v<MT2>(acc1, 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t5 = 0; t5 < MT2; ++t5) {
-          const f32x2 g0 = gelu_sig2(f32x2{acc[t5][0], acc[t5][1]}), g1 = gelu_sig2(f32x2{acc[t5][2], acc[t5][3]});
-          hp[t5][2 * nt] = s1r_pk2(g0[0], g0[1]);
-          hp[t5][2 * nt + 1] = s1r_pk2(g1[0], g1[1]);
+          const f32x2 g0 = gelu_sig2(f32x2{acc1[t5][0], acc1[t5][1]}), g1 = gelu_sig2(f32x2{acc1[t5][2], acc1[t5][3]});
+          hp[t5][2] = s1r_pk2(g0[0], g0[1]);
+          hp[t5][3] = s1r_pk2(g1[0], g1[1]);
         }
       }
 
@@ -382,13 +426,15 @@ __global__ void stage1_pack_kernel(const bf16* __restrict__ w1, const bf16* __re
 }
 
 // Opt-in (FSVIT_STAGE1_ROWS=1).  Measured on MI355X (profiles/r01_v9_stage1_rows_pmc.txt, 3200 images): correct (same operator
-// test as stage1_fused), 5.8 ms per 64-episode step against 5.35 ms for stage1_fused - the design removed the LDS / barrier
+// test as stage1_fused), 5.66 ms per 64-episode step (5.8 before the hand interleave below) against 5.39 ms for stage1_fused - the design removed the LDS / barrier
 // bottleneck (0.4 instead of 1.4 ds_read_b128 per MFMA, no activation barriers) but exposed the next one: the block needs
 // 2 x 256 GELUs per token, ~1150 VALU issues per group and wave against 194 MFMAs; with ONE wave per SIMD nothing overlaps them
 // (PMC: VALU 44 %, MFMA 23 %, waits 33 % of the wave's cycles), whereas stage1_fused's four waves per SIMD do.  The 2-row-band /
 // two-waves-per-SIMD variant (S1R_BAND=2) needs 170 VGPRs + 96 AGPRs of its 256 registers, and hipcc splits the file 128 / 128
-// as soon as an "a" constraint appears (83 spills).  Next: hand-interleave GELU(conv1 n-tile 0) under conv3 of the previous group
-// and GELU(conv2 n-tile 0) under conv2 n-tile 1, or keep the outputs in VGPRs with a 2-row band.
+// as soon as an "a" constraint appears (83 spills).  Interleaving GELU(conv1 n-tile 0) under conv1 n-tile 1 and GELU(conv2 n-tile 0)
+// under conv2 n-tile 1 and requesting every LDS operand one use ahead bought 2.5 %: with a single wave per SIMD every remaining
+// latency (first fragments of a phase, x / residual loads per task, barrier skew) is exposed.  Next: a 2-row band with the outputs
+// in VGPRs (two waves per SIMD), which trades 25 % more MFMA / GELU work for hardware overlap.
 bool stage1_rows_supported(int dtype, int C1, int hid, int group, int H1) {
   static const bool on = [] { const char* e = getenv("FSVIT_STAGE1_ROWS"); return e && e[0] == '1'; }();
   return on && dtype == 1 && C1 == s1r::C1 && hid == s1r::HID && group == s1r::G && H1 == s1r::W;
