@@ -65,6 +65,11 @@ SIGNATURES = {
                                          _vp, _sz, _vp]),
     'fsvit_conv_gemm': (_i, [_vp, _vp, _fp, _vp, _fp, _vp] + [_i] * 15 + [_i, _vp]),
     'fsvit_stage1_block': (_i, [_vp, _vp, _vp, _fp, _vp, _vp, _i, _vp]),
+    'fsvit_linear_forward': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
+    'fsvit_linear_backward': (_i, [_fp, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _vp]),
+    'fsvit_token_softlabel': (_i, [_fp, _fp, _i, _i, _i, _i, _i, C.c_double, _vp]),
+    'fsvit_soft_target_ce': (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _vp]),
+    'fsvit_adamw_step': (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _i, _vp]),
     'fsvit_mlp_rows': (_i, [_vp, _vp, _vp, _i, _fp, _vp, _i, _fp, _i, _i, _i, _vp]),
     'fsvit_attention': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     'fsvit_im2col27': (_i, [_fp, _vp, _i, _i, _i, _i, _vp]),

@@ -47,3 +47,40 @@ class ProtoHeadFn(torch.autograd.Function):
         feat_shot, feat_query, temp = ctx.saved_tensors
         ds, dq, dt = ops.proto_head_backward(feat_shot, feat_query, dlogits, float(temp))
         return ds, dq, dt.reshape(temp.shape)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the HIP linear kernels (classifier.py:27-34); x [..., K] fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
+        ctx.save_for_backward(x2, w)
+        ctx.xshape, ctx.has_b = x.shape, b is not None
+        return ops.linear(x2, w, b).view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous().float()
+        dx, dw, db = ops.linear_backward(dy2, x2, w, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_b)
+        return (dx.view(ctx.xshape) if dx is not None else None), dw, (db if ctx.has_b else None)
+
+
+class SoftTargetCEFn(torch.autograd.Function):
+    """SoftTargetCrossEntropy (offline.py:34-45): mean over rows of sum(-target * log_softmax(logits)); the gradient comes out of
+    the same kernel launch as the loss."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        R = logits.shape[0]
+        if target.shape[0] != R:                                   # offline.py:41-43
+            target = target.repeat(R // target.shape[0], 1)
+        row, dz = ops.soft_target_ce(logits, target, grad_scale=1.0 / R)
+        ctx.save_for_backward(dz)
+        return row.mean()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dz,) = ctx.saved_tensors
+        return dz * dloss, None

@@ -723,6 +723,37 @@ extern "C" int fsvit_mlp_rows(const void* x, void* y, const void* w1, int k1w, c
   return 0;
 }
 
+// ---- distillation head (sun_meta_training/offline.py, models/token_label.py, models/classifier.py)
+extern "C" int fsvit_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int N, int K, void* stream) {
+  if (!x || !w || !y || (K & 3) || N <= 0 || K <= 0) return fail(FSVIT_ERR_ARG, "fsvit_linear_forward: null argument or K %% 4 != 0");
+  RC_TRY(launch_linear_fwd(x, w, b, y, M, N, K, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int fsvit_linear_backward(const float* dy, const float* x, const float* w, float* dx, int accumulate_dx, float* dw, float* db,
+                                     int M, int N, int K, void* stream) {
+  if (!dy || (dx && !w) || (dw && !x) || N > 256 || N <= 0 || K <= 0) return fail(FSVIT_ERR_ARG, "fsvit_linear_backward: bad argument (N <= 256)");
+  RC_TRY(launch_linear_bwd(dy, x, w, dx, accumulate_dx, dw, db, M, N, K, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int fsvit_token_softlabel(const float* teacher_logits, float* soft, int B, int T, int C, int k, int bp, double smoothing, void* stream) {
+  if (!teacher_logits || !soft || T > 64 || T <= 0 || C < 2 || k < 1 || k > C || bp < 0 || bp > T)
+    return fail(FSVIT_ERR_ARG, "fsvit_token_softlabel: bad argument (T <= 64, 1 <= k <= C, 0 <= bp <= T)");
+  RC_TRY(launch_token_softlabel(teacher_logits, soft, B, T, C, k, bp, smoothing, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int fsvit_soft_target_ce(const float* logits, const float* target, float* row_loss, float* dlogits, int R, int C, float grad_scale,
+                                    void* stream) {
+  if (!logits || !target || !row_loss || C > 128 || C <= 0) return fail(FSVIT_ERR_ARG, "fsvit_soft_target_ce: bad argument (C <= 128)");
+  RC_TRY(launch_soft_target_ce(logits, target, row_loss, dlogits, R, C, grad_scale, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int fsvit_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, int step, void* stream) {
+  if (!p || !g || !m || !v || step < 1) return fail(FSVIT_ERR_ARG, "fsvit_adamw_step: bad argument");
+  RC_TRY(launch_adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int fsvit_attention(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, void* stream) {
   if (!qkv || !ctx) return fail(FSVIT_ERR_ARG, "null argument");
   int rc = launch_attention(qkv, ctx, B, S, heads, hdp, scale, dtype, (hipStream_t)stream);

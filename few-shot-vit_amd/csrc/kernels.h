@@ -37,6 +37,13 @@ size_t mlp_rows_image_bytes(int C, int hid);
 int launch_mlp_pack(const void* w1, int k1w, const float* b1, const void* w2, int k2w, void* wimg, float* b1img, int C, int hid, hipStream_t s);
 int launch_mlp_rows(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, int M, int C, int hid, hipStream_t s);
 
+// distillation head (token_label.hip; fp32): LinearClassifier forward / backward, generate_softlabel, SoftTargetCrossEntropy, AdamW
+int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, hipStream_t s);
+int launch_linear_bwd(const float* dy, const float* x, const float* w, float* dx, int accumulate_dx, float* dw, float* db, int M, int N, int K, hipStream_t s);
+int launch_token_softlabel(const float* lt, float* soft, int B, int T, int C, int k, int bp, double smoothing, hipStream_t s);
+int launch_soft_target_ce(const float* z, const float* tgt, float* rowloss, float* dz, int R, int C, float gscale, hipStream_t s);
+int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t s);
+
 // ViT / DeiT helpers (vit.hip)
 int launch_patchify(const float* x_nchw, void* out, int B, int img, int p, int Kp, int dtype, hipStream_t s);
 int launch_cls_pos(const float* cls_plus_pos0, void* tokens, int B, int S, int D, int dtype, hipStream_t s);

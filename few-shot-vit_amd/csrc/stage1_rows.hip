@@ -92,15 +92,24 @@ __device__ __forceinline__ u32x4 s1r_gload16(const void* p) {       // asm: invi
 }
 // MFMAs from inline asm with the accumulator's register file spelled out (outputs in AGPRs, everything else in VGPRs); the
 // wait states hipcc would insert around them are placed by hand below (mlp_rows.hip has the full account)
+// S1R_ASM (band 4, one wave per SIMD, outputs in AGPRs) / compiler builtins (band 2, two waves per SIMD, everything in VGPRs: hipcc
+// splits a 256-register budget 128 / 128 as soon as an "a" constraint appears)
+constexpr bool S1R_ASM = s1r::BAND == 4;
 __device__ __forceinline__ void mma16_v(u32x4 a, u32x4 b, f32x4& c) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  if constexpr (S1R_ASM) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  else c = mma_chunk<bf16>(a, b, c);
 }
 __device__ __forceinline__ void mma16_a(u32x4 a, u32x4 b, f32x4& c) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  if constexpr (S1R_ASM) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else c = mma_chunk<bf16>(a, b, c);
 }
 __device__ __forceinline__ void mma16_a_zero(f32x4& c) {
-  const u32x4 z = {0u, 0u, 0u, 0u};
-  asm volatile("s_nop 7\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "=a"(c) : "v"(z));
+  if constexpr (S1R_ASM) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    asm volatile("s_nop 7\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %1, 0" : "=a"(c) : "v"(z));
+  } else {
+    c = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 }
 // `INSN` with N registers threaded through as in/out operands (constraint "+v" or "+a"): everything that produces them is
 // scheduled before, everything that consumes them after - how hand-placed wait states are pinned between compiler-scheduled code
@@ -110,6 +119,7 @@ __device__ __forceinline__ void mma16_a_zero(f32x4& c) {
 #define S1R_TIE8(insn, c, a) asm volatile(insn : S1R_T1(c, a, 0), S1R_T1(c, a, 1), S1R_T1(c, a, 2), S1R_T1(c, a, 3), S1R_T1(c, a, 4), S1R_T1(c, a, 5), S1R_T1(c, a, 6), S1R_T1(c, a, 7))
 #define S1R_TIE4_AT(insn, c, a, o) asm volatile(insn : S1R_T1(c, a, o), S1R_T1(c, a, o + 1), S1R_T1(c, a, o + 2), S1R_T1(c, a, o + 3) :: "memory")
 template <int N> __device__ __forceinline__ void s1r_nop_v(f32x4* a, const int kind) {       // kind 0: s_nop 7, 1: s_nop 15 + s_nop 3
+  if constexpr (s1r::BAND != 4) return;     // builtin MFMAs: hipcc's hazard recognizer places the wait states
   if (kind == 0) {
     if constexpr (N == 3) S1R_TIE3("s_nop 7", "+v", a);
     else if constexpr (N == 5) S1R_TIE5("s_nop 7", "+v", a);
@@ -121,6 +131,7 @@ template <int N> __device__ __forceinline__ void s1r_nop_v(f32x4* a, const int k
   }
 }
 template <int N> __device__ __forceinline__ void s1r_nop_u(u32x4* a) {
+  if constexpr (s1r::BAND != 4) return;
   if constexpr (N == 3) S1R_TIE3("s_nop 7", "+v", a);
   else S1R_TIE5("s_nop 7", "+v", a);
 }
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(s1r::NW * 64, s1r::NW / 4) void stage1_rows_kernel(
 #pragma unroll
     for (int t5 = 0; t5 < MT2; ++t5) {
       // wait states MFMA -> v_accvgpr_read for this m-tile's accumulators
-      S1R_TIE8("s_nop 15\n\ts_nop 3", "+a", yacc[t5]);
+      if constexpr (BAND == 4) S1R_TIE8("s_nop 15\n\ts_nop 3", "+a", yacc[t5]);
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const bf16x8 r8 = __builtin_bit_cast(bf16x8, res[t5][p]);

@@ -1,0 +1,179 @@
+// Distillation head of the SUN meta-training phase (sun_meta_training/offline.py, models/token_label.py), fp32:
+//   * LinearClassifier forward / backward (classifier.py:27-34) for the per-token head (512 -> n_classes + 1 on every one of the
+//     25 tokens) and the global head (512 -> n_classes on the pooled feature) of TokenLabelOffline (token_label.py:36-60);
+//   * generate_softlabel (offline.py:57-76): per-token top-k scatter + background-token mask of the teacher's token logits;
+//   * SoftTargetCrossEntropy (offline.py:34-45) forward + gradient in one pass;
+//   * the AdamW update the phase trains with (offline.py:233).
+// Sizes are tiny next to the encoder (B*25 x 512 x 65 per step): these kernels are written for exactness and determinism
+// (fixed reduction orders, no atomics), not for the MFMA roofline - one wave per dot product / row.
+#include "fsvit_common.h"
+#include "kernels.h"
+
+namespace fsvit {
+
+// y[m][n] = x[m][:] . w[n][:] + b[n];  one workgroup per row m, wave w takes n = w, w + 4, ...; K % 4 == 0
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                         float* __restrict__ y, int M, int N, int K) {
+  const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* xr = x + (size_t)m * K;
+  for (int n = wave; n < N; n += 4) {
+    const float* wr = w + (size_t)n * K;
+    float s = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xr + k), c = *reinterpret_cast<const f32x4*>(wr + k);
+      s = fmaf(a[0], c[0], s); s = fmaf(a[1], c[1], s); s = fmaf(a[2], c[2], s); s = fmaf(a[3], c[3], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) y[(size_t)m * N + n] = s + (b ? b[n] : 0.f);
+  }
+}
+
+// dx[m][k] = sum_n dy[m][n] w[n][k]   (one workgroup per row, thread per k)
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                           int M, int N, int K, int accumulate) {
+  __shared__ float dys[256];
+  const int m = blockIdx.x;
+  for (int n = threadIdx.x; n < N; n += 256) dys[n] = dy[(size_t)m * N + n];
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s = fmaf(dys[n], w[(size_t)n * K + k], s);
+    float* o = dx + (size_t)m * K + k;
+    *o = accumulate ? *o + s : s;
+  }
+}
+
+// dw[n][k] = sum_m dy[m][n] x[m][k],  db[n] = sum_m dy[m][n]   (one workgroup per n, thread per k, fixed order over m)
+__global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
+                                                           float* __restrict__ db, int M, int N, int K) {
+  const int n = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s = fmaf(dy[(size_t)m * N + n], x[(size_t)m * K + k], s);
+    dw[(size_t)n * K + k] = s;
+  }
+  if (db && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += dy[(size_t)m * N + n];
+    db[n] = s;
+  }
+}
+
+// generate_softlabel: teacher token logits lt [B][T][C] -> soft [B*T][C+1].  One workgroup (64 threads) per image.
+//   positive tokens = the T - bp tokens with the largest per-token max (ties: lower token index first);
+//   positive row: on_value at its top-k classes (ties: lower class index first), off_value elsewhere;
+//   background row: on_value at column BG (= 1: offline.py:61 rebinds `c` to logits_max.size(1) before :71 uses it), off elsewhere.
+__global__ __launch_bounds__(64) void token_softlabel_kernel(const float* __restrict__ lt, float* __restrict__ soft, int T, int C, int k, int bp,
+                                                             float on_value, float off_value) {
+  __shared__ float tmax[64];
+  __shared__ int ispos[64];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* base = lt + (size_t)b * T * C;
+  if (t < T) {
+    float mx = base[(size_t)t * C];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, base[(size_t)t * C + c]);
+    tmax[t] = mx;
+  }
+  __syncthreads();
+  if (t < T) {
+    int rank = 0;
+    for (int u = 0; u < T; ++u) rank += (tmax[u] > tmax[t] || (tmax[u] == tmax[t] && u < t)) ? 1 : 0;
+    ispos[t] = rank < T - bp;
+  }
+  __syncthreads();
+  if (t < T) {
+    float* row = soft + ((size_t)b * T + t) * (C + 1);
+    for (int c = 0; c <= C; ++c) row[c] = off_value;
+    if (ispos[t]) {
+      const float* z = base + (size_t)t * C;
+      float prev = 3.4e38f;
+      int prev_idx = -1;
+      for (int j = 0; j < k; ++j) {            // j-th largest: the largest value strictly below (prev, prev_idx) in (value desc, index asc) order
+        float best = -3.4e38f;
+        int bi = -1;
+        for (int c = 0; c < C; ++c) {
+          const float v = z[c];
+          const bool below = v < prev || (v == prev && c > prev_idx);
+          if (below && (bi < 0 || v > best)) { best = v; bi = c; }
+        }
+        if (bi < 0) break;
+        row[bi] = on_value;
+        prev = best;
+        prev_idx = bi;
+      }
+    } else {
+      row[1] = on_value;
+    }
+  }
+}
+
+// SoftTargetCrossEntropy: rowloss[r] = -sum_c t[r][c] log_softmax(z[r])[c];  dz[r][c] = gscale (softmax(z[r])[c] sum_c t[r][c] - t[r][c]).
+// One wave per row (C <= 128 columns: two per lane).
+__global__ __launch_bounds__(256) void soft_target_ce_kernel(const float* __restrict__ z, const float* __restrict__ tgt, float* __restrict__ rowloss,
+                                                             float* __restrict__ dz, int R, int C, float gscale) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float* zr = z + (size_t)r * C;
+  const float* tr = tgt + (size_t)r * C;
+  const float z0 = lane < C ? zr[lane] : -3.4e38f, z1 = lane + 64 < C ? zr[lane + 64] : -3.4e38f;
+  const float t0 = lane < C ? tr[lane] : 0.f, t1 = lane + 64 < C ? tr[lane + 64] : 0.f;
+  const float mx = wave_max(fmaxf(z0, z1));
+  const float e0 = lane < C ? expf(z0 - mx) : 0.f, e1 = lane + 64 < C ? expf(z1 - mx) : 0.f;
+  const float se = wave_sum(e0 + e1);
+  const float lse = mx + logf(se);
+  const float st = wave_sum(t0 + t1);
+  const float tz = wave_sum(t0 * (lane < C ? z0 : 0.f) + t1 * (lane + 64 < C ? z1 : 0.f));
+  if (lane == 0) rowloss[r] = lse * st - tz;
+  if (dz) {
+    if (lane < C) dz[(size_t)r * C + lane] = gscale * (e0 / se * st - t0);
+    if (lane + 64 < C) dz[(size_t)r * C + lane + 64] = gscale * (e1 / se * st - t1);
+  }
+}
+
+// torch.optim.AdamW / timm AdamW (decoupled weight decay), update number `step` (1-based)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
+                             float beta1, float beta2, float eps, float wd, float bc1, float rsqrt_bc2) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  float pi = p[i] * (1.0f - lr * wd);
+  const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+  const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+  p[i] = pi - (lr / bc1) * (mi / denom);
+}
+
+int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, hipStream_t s) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(M), dim3(256), 0, s, x, w, b, y, M, N, K);
+  return (int)hipGetLastError();
+}
+int launch_linear_bwd(const float* dy, const float* x, const float* w, float* dx, int accumulate_dx, float* dw, float* db, int M, int N, int K, hipStream_t s) {
+  if (M <= 0) return 0;
+  if (dx) hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(M), dim3(256), 0, s, dy, w, dx, M, N, K, accumulate_dx);
+  if (dw) hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(N), dim3(256), 0, s, dy, x, dw, db, M, N, K);
+  return (int)hipGetLastError();
+}
+int launch_token_softlabel(const float* lt, float* soft, int B, int T, int C, int k, int bp, double smoothing, hipStream_t s) {
+  if (B <= 0) return 0;
+  const double offd = smoothing / (double)C;                 // python-float arithmetic of offline.py:58-59, rounded once to fp32 by torch.full
+  const float off = (float)offd, on = (float)(1.0 - smoothing + offd);
+  hipLaunchKernelGGL(token_softlabel_kernel, dim3(B), dim3(64), 0, s, lt, soft, T, C, k, bp, on, off);
+  return (int)hipGetLastError();
+}
+int launch_soft_target_ce(const float* z, const float* tgt, float* rowloss, float* dz, int R, int C, float gscale, hipStream_t s) {
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL(soft_target_ce_kernel, dim3((R + 3) / 4), dim3(256), 0, s, z, tgt, rowloss, dz, R, C, gscale);
+  return (int)hipGetLastError();
+}
+int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t s) {
+  if (n == 0) return 0;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, wd, (float)bc1,
+                     (float)(1.0 / sqrt(bc2)));
+  return (int)hipGetLastError();
+}
+
+}  // namespace fsvit

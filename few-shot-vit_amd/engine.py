@@ -306,6 +306,60 @@ class ops:
             _lib.check(lib.fsvit_stage1_block(_ptr(x), _ptr(y), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(w3), x.shape[0], _stream_ptr(x.device)))
         return y
 
+    # ---- distillation head (sun_meta_training/offline.py): fp32, token-major rows
+    @staticmethod
+    def linear(x, w, b=None):
+        """x [M, K] fp32, w [N, K], b [N] or None -> x w^T + b (classifier.py:27-34)."""
+        _require_cuda(x, w)
+        x, w = x.contiguous().float(), w.contiguous().float()
+        y = torch.empty(x.shape[0], w.shape[0], dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().fsvit_linear_forward(_ptr(x), _ptr(w), _ptr(None if b is None else b.contiguous().float()), _ptr(y),
+                                                        x.shape[0], w.shape[0], x.shape[1], _stream_ptr(x.device)))
+        return y
+
+    @staticmethod
+    def linear_backward(dy, x, w, need_dx=True, need_dw=True, need_db=True):
+        _require_cuda(dy, x, w)
+        dy, x, w = dy.contiguous().float(), x.contiguous().float(), w.contiguous().float()
+        dx = torch.empty_like(x) if need_dx else None
+        dw = torch.empty_like(w) if need_dw else None
+        db = torch.empty(w.shape[0], dtype=torch.float32, device=x.device) if (need_db and need_dw) else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().fsvit_linear_backward(_ptr(dy), _ptr(x), _ptr(w), _ptr(dx), 0, _ptr(dw), _ptr(db), x.shape[0], w.shape[0], x.shape[1],
+                                                         _stream_ptr(x.device)))
+        return dx, dw, db
+
+    @staticmethod
+    def token_softlabel(teacher_logits, k=3, bp=10, smoothing=0.1):
+        """teacher token logits [B, T, C] -> soft labels [B*T, C+1] (offline.py:57-76)."""
+        _require_cuda(teacher_logits)
+        lt = teacher_logits.contiguous().float()
+        B, T, Cc = lt.shape
+        soft = torch.empty(B * T, Cc + 1, dtype=torch.float32, device=lt.device)
+        with torch.cuda.device(lt.device):
+            _lib.check(_lib.load().fsvit_token_softlabel(_ptr(lt), _ptr(soft), B, T, Cc, int(k), int(bp), float(smoothing), _stream_ptr(lt.device)))
+        return soft
+
+    @staticmethod
+    def soft_target_ce(logits, target, grad_scale=None):
+        """-> (row_loss [R], dlogits [R, C] = grad_scale * d(sum of row losses)/dlogits, or None)."""
+        _require_cuda(logits, target)
+        z, t = logits.contiguous().float(), target.contiguous().float()
+        R, Cc = z.shape
+        row = torch.empty(R, dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z) if grad_scale is not None else None
+        with torch.cuda.device(z.device):
+            _lib.check(_lib.load().fsvit_soft_target_ce(_ptr(z), _ptr(t), _ptr(row), _ptr(dz), R, Cc, float(grad_scale or 0.0), _stream_ptr(z.device)))
+        return row, dz
+
+    @staticmethod
+    def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+        _require_cuda(p, g, m, v)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.load().fsvit_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                                                    float(weight_decay), int(step), _stream_ptr(p.device)))
+
     @staticmethod
     def mlp_rows(x, w1, b1, w2, b2=None):
         """x [M][C] bf16, C = 256 or 512; w1 [4C][K1w], w2 [C][K2w] packed K-major bf16; b1 [4C], b2 [C] fp32 or None.  y = x + W2 GELU(W1 x + b1) + b2."""

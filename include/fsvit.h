@@ -158,6 +158,27 @@ int fsvit_stage1_block(const void* x_dev, void* y_dev, const void* w1_dev, const
  * fp32 or NULL.  The operator form packs the weights on every call (the engine packs once per checkpoint). */
 int fsvit_mlp_rows(const void* x_dev, void* y_dev, const void* w1_dev, int k1w, const float* b1_dev, const void* w2_dev, int k2w,
                    const float* b2_dev, int M, int C, int hid, void* stream);
+/* ---------------------------------------------------------------- distillation head
+ * Replaces, for sun_meta_training/offline.py: `LinearClassifier.forward` / its autograd (models/classifier.py:27-34) as used by
+ * `TokenLabelOffline` (models/token_label.py:36-60) on the 25 tokens and on the pooled feature, `generate_softlabel`
+ * (offline.py:57-76), `SoftTargetCrossEntropy` (offline.py:34-45) and the AdamW update (offline.py:233).  fp32, token-major rows. */
+/* y [M][N] = x [M][K] w[N][K]^T + b[N] (b may be NULL); K % 4 == 0. */
+int fsvit_linear_forward(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev, int M, int N, int K, void* stream);
+/* dx [M][K] (+)= dy w (NULL: skipped), dw [N][K] = dy^T x and db [N] = column sums of dy (NULL: skipped); N <= 256. */
+int fsvit_linear_backward(const float* dy_dev, const float* x_dev, const float* w_dev, float* dx_dev, int accumulate_dx, float* dw_dev,
+                          float* db_dev, int M, int N, int K, void* stream);
+/* teacher token logits [B][T][C] (T = 25 tokens in (h, w) order = the reference's [B, C, 5, 5].permute(0, 2, 3, 1)) -> soft labels
+ * [B*T][C+1]: top-k scatter for the T - bp tokens with the largest max logit, the reference's background row (on_value at column 1,
+ * offline.py:61,71) for the other bp. */
+int fsvit_token_softlabel(const float* teacher_logits_dev, float* soft_dev, int B, int T, int C, int k, int bp, double smoothing, void* stream);
+/* row_loss [R] = -sum_c target log_softmax(logits) (the caller's mean is over R), dlogits [R][C] = grad_scale (softmax * sum(target) -
+ * target) or NULL; C <= 128. */
+int fsvit_soft_target_ce(const float* logits_dev, const float* target_dev, float* row_loss_dev, float* dlogits_dev, int R, int C,
+                         float grad_scale, void* stream);
+/* AdamW (decoupled weight decay), update number `step` >= 1: p, exp_avg m, exp_avg_sq v updated in place. */
+int fsvit_adamw_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, size_t n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, void* stream);
+
 int fsvit_im2col27(const float* x_nchw_dev, void* out_dev, int B, int H, int W, int dtype, void* stream);
 int fsvit_maxpool2_pos(const void* in_dev, const float* pos_dev, void* out_dev, int B, int OH, int OW, int C,
                        int dtype, void* stream);

@@ -1,0 +1,116 @@
+"""Distillation head on the GPU (C-ABI kernels behind the `token-label` / `linear-classifier` models, generate_softlabel,
+SoftTargetCrossEntropy, AdamW) against the reference-pinned oracle and the reference's golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'token_label.npz'))
+
+
+@pytest.mark.parametrize('k,bp', [(3, 10), (5, 7), (1, 0)])
+def test_generate_softlabel_bit_exact_vs_reference_golden(k, bp):
+    from fewshot_vit_amd.models.classifier import generate_softlabel
+    lt = torch.from_numpy(G['teacher_logits_token']).cuda()
+    soft = generate_softlabel(lt, k=k, bp=bp).cpu().numpy()
+    assert np.array_equal(soft, G[f'soft_k{k}_bp{bp}'])
+
+
+def test_soft_target_ce_loss_and_gradient():
+    from fewshot_vit_amd.models.classifier import SoftTargetCrossEntropy
+    z = torch.from_numpy(G['student_logits_token']).cuda().requires_grad_(True)
+    t = torch.from_numpy(G['soft_k3_bp10']).cuda()
+    loss = SoftTargetCrossEntropy()(z, t)
+    (2.0 * loss).backward()
+    assert float(loss) == pytest.approx(float(G['soft_ce_loss']), rel=2e-6)
+    assert (z.grad.cpu().numpy() - 2.0 * G['soft_ce_dlogits']).__abs__().max() <= 2e-7
+
+
+def test_token_label_model_matches_reference_and_oracle_gradients():
+    from fewshot_vit_amd import models
+    from oracle import token_label_oracle as tlo
+    fmap, pooled = torch.from_numpy(G['tl_map']).cuda(), torch.from_numpy(G['tl_pooled']).cuda()
+
+    class Enc(nn.Module):
+        out_dim = 32
+
+        def forward(self, x):
+            return fmap_req, pooled_req
+
+    fmap_req, pooled_req = fmap.clone().requires_grad_(True), pooled.clone().requires_grad_(True)
+    m = models.make('token-label', encoder=Enc(), encoder_args={}, classifier='linear-classifier', classifier_args={'n_classes': 10})
+    sd = {k[len('tl_sd.'):]: torch.from_numpy(G[k]) for k in G.files if k.startswith('tl_sd.')}
+    m.load_state_dict(sd, strict=True)                                            # reference key names / shapes
+    for tag, teacher in (('student', False), ('teacher', True)):
+        y_token, y, x1 = m(torch.zeros(4, 3, 8, 8, device='cuda'), teacher)
+        assert (y_token.detach().cpu().numpy() - G[f'tl_{tag}_y_token']).__abs__().max() <= 1e-5
+        assert (y.detach().cpu().numpy() - G[f'tl_{tag}_y']).__abs__().max() <= 1e-5
+    # backward of the student pass: every gradient against torch autograd of the same math on the CPU
+    y_token, y, _ = m(torch.zeros(4, 3, 8, 8, device='cuda'), False)
+    gt = torch.Generator().manual_seed(5)
+    wt, wy = torch.randn(y_token.shape, generator=gt), torch.randn(y.shape, generator=gt)
+    ((y_token * wt.cuda()).sum() + (y * wy.cuda()).sum()).backward()
+    fm_c, po_c = fmap.cpu().clone().requires_grad_(True), pooled.cpu().clone().requires_grad_(True)
+    ps = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yt_c = torch.nn.functional.linear(fm_c.permute(0, 2, 3, 1), ps['classifier_local.linear.weight'], ps['classifier_local.linear.bias']).permute(0, 3, 1, 2)
+    y_c = torch.nn.functional.linear(po_c, ps['classifier.linear.weight'], ps['classifier.linear.bias'])
+    ((yt_c * wt).sum() + (y_c * wy).sum()).backward()
+    assert (fmap_req.grad.cpu() - fm_c.grad).abs().max() <= 1e-5
+    assert (pooled_req.grad.cpu() - po_c.grad).abs().max() <= 1e-5
+    for k, p in m.named_parameters():
+        assert (p.grad.cpu() - ps[k].grad).abs().max() <= 2e-5 * max(1.0, float(ps[k].grad.abs().max())), k
+
+
+def test_adamw_kernel_matches_torch():
+    from fewshot_vit_amd.models.classifier import FsvitAdamW
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(1000, generator=g)
+    pa, pb = nn.Parameter(p0.clone().cuda()), nn.Parameter(p0.clone())
+    oa = FsvitAdamW([pa], lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    ob = torch.optim.AdamW([pb], lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    for _ in range(7):
+        grad = torch.randn(1000, generator=g)
+        pa.grad, pb.grad = grad.cuda(), grad.clone()
+        oa.step()
+        ob.step()
+    assert (pa.detach().cpu() - pb.detach()).abs().max() <= 2e-6
+
+
+def test_distillation_step_reduces_loss():
+    """offline.py:283-303 on a stub encoder: cls_loss + 0.5 * token_loss, AdamW, a few steps on one batch."""
+    from fewshot_vit_amd import models
+    from fewshot_vit_amd.models.classifier import FsvitAdamW, SoftTargetCrossEntropy, generate_softlabel
+    torch.manual_seed(0)
+
+    class Enc(nn.Module):
+        out_dim = 64
+
+        def __init__(self):
+            super().__init__()
+            self.scale = nn.Parameter(torch.ones(64, 1, 1))
+
+        def forward(self, x):
+            fm = x * self.scale
+            return fm, fm.mean(dim=(2, 3))
+
+    x = torch.randn(16, 64, 5, 5, device='cuda')
+    label = torch.randint(0, 12, (16,), device='cuda')
+    model = models.make('token-label', encoder=Enc(), encoder_args={}, classifier='linear-classifier', classifier_args={'n_classes': 12})
+    teacher = models.make('token-label', encoder=Enc(), encoder_args={}, classifier='linear-classifier', classifier_args={'n_classes': 12}).eval()
+    opt = FsvitAdamW(model.parameters(), lr=5e-3, weight_decay=0.05)
+    crit = SoftTargetCrossEntropy()
+    losses = []
+    for _ in range(8):
+        logits_token, logits, _ = model(x)
+        with torch.no_grad():
+            lt_t, _, _ = teacher(x, True)
+            soft = generate_softlabel(lt_t, k=3, bp=10)
+        loss = torch.nn.functional.cross_entropy(logits, label) + 0.5 * crit(logits_token.permute(0, 2, 3, 1).reshape(-1, 13), soft)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
