@@ -65,6 +65,9 @@ SIGNATURES = {
                                          _vp, _sz, _vp]),
     'fsvit_conv_gemm': (_i, [_vp, _vp, _fp, _vp, _fp, _vp] + [_i] * 15 + [_i, _vp]),
     'fsvit_stage1_block': (_i, [_vp, _vp, _vp, _fp, _vp, _vp, _i, _vp]),
+    'fsvit_visformer_last_tokens': (_i, [_vp, _vp, _sz, _i, _fp, _vp]),
+    'fsvit_visformer_train_tokens': (_i, [_vp, _fp, _vp]),
+    'fsvit_visformer_train_set_token_grad': (_i, [_vp, _fp]),
     'fsvit_linear_forward': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _vp]),
     'fsvit_linear_backward': (_i, [_fp, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _vp]),
     'fsvit_token_softlabel': (_i, [_fp, _fp, _i, _i, _i, _i, _i, C.c_double, _vp]),

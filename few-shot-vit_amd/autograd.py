@@ -32,6 +32,32 @@ class VisformerTrainFn(torch.autograd.Function):
         return (None, None, None, None, None, None) + tuple(grads[k] for k in ctx.names)
 
 
+class VisformerTrainMapFn(torch.autograd.Function):
+    """(tokens, feat) = encoder(x) in train mode for the distillation phase, whose encoder returns the post-norm map next to the
+    pooled feature (sun_meta_training/models/visformer.py:464); tokens [B, T, D] token-major."""
+
+    @staticmethod
+    def forward(ctx, x, trainer, names, buffers, drop_path_rate, masks, n_tok, *params):
+        tensors = dict(zip(names, params))
+        tensors.update(buffers)
+        feat = trainer.forward(tensors, x, drop_path_rate, masks)
+        tokens = trainer.tokens(x.shape[0], n_tok)
+        ctx.trainer, ctx.names, ctx.buffers = trainer, names, buffers
+        ctx.save_for_backward(*params)
+        return tokens, feat
+
+    @staticmethod
+    def backward(ctx, dtokens, dfeat):
+        params = ctx.saved_tensors
+        tensors = dict(zip(ctx.names, params))
+        grads = {k: torch.empty_like(v) for k, v in tensors.items()}
+        tensors.update(ctx.buffers)
+        if dfeat is None:
+            dfeat = torch.zeros(dtokens.shape[0], dtokens.shape[2], device=dtokens.device)
+        ctx.trainer.backward(tensors, grads, dfeat, dtokens)
+        return (None,) * 7 + tuple(grads[k] for k in ctx.names)
+
+
 class ProtoHeadFn(torch.autograd.Function):
     """logits = temp * cos(query, mean_shot(prototypes)) (meta_baseline.py:33-47, method 'cos')."""
 

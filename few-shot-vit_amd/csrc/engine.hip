@@ -635,6 +635,18 @@ extern "C" int fsvit_visformer_forward(fsvit_visformer* h, const float* x, int n
   return 0;
 }
 
+/* Post-norm token map [n_img][H3*H3][C3] fp32 of the images of the LAST fsvit_visformer_forward call on this handle (same workspace,
+ * untouched since; the call must have fitted one chunk): the `x` of `return x, pooled` in the distillation phase's encoder
+ * (sun_meta_training/models/visformer.py:464) for the eval-mode teacher. */
+extern "C" int fsvit_visformer_last_tokens(fsvit_visformer* h, const void* ws, size_t ws_bytes, int n_img, float* tokens, void* stream) {
+  if (!h || !ws || !tokens || n_img <= 0) return fail(FSVIT_ERR_ARG, "bad argument");
+  const Plan pl = make_plan(h, (size_t)n_img);
+  if (pl.total > ws_bytes) return fail(FSVIT_ERR_WORKSPACE, "last_tokens: the forward of %d images did not fit one chunk of this workspace", n_img);
+  RC_TRY(launch_tokens_to_f32((const unsigned char*)ws + pl.x3, h->fscale, h->fshift, tokens, (size_t)n_img * h->H3 * h->H3 * h->C3, h->C3, h->dtype,
+                              (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int fsvit_proto_head(const float* fs, const float* fq, int E, int way, int shot, int Q, int D, float temp,
                                 int method, float* logits, float* acc, float* loss, void* stream) {
   if (!fs || !fq || !logits) return fail(FSVIT_ERR_ARG, "null argument");

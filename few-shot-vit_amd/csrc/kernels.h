@@ -42,6 +42,8 @@ int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, 
 int launch_linear_bwd(const float* dy, const float* x, const float* w, float* dx, int accumulate_dx, float* dw, float* db, int M, int N, int K, hipStream_t s);
 int launch_token_softlabel(const float* lt, float* soft, int B, int T, int C, int k, int bp, double smoothing, hipStream_t s);
 int launch_soft_target_ce(const float* z, const float* tgt, float* rowloss, float* dz, int R, int C, float gscale, hipStream_t s);
+int launch_tokens_to_f32(const void* in, const float* scale, const float* shift, float* out, size_t n, int C, int dtype, hipStream_t s);
+int launch_add_f32_into(void* inout, const float* add, size_t n, int dtype, hipStream_t s);
 int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t s);
 
 // ViT / DeiT helpers (vit.hip)

@@ -145,6 +145,36 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   p[i] = pi - (lr / bc1) * (mi / denom);
 }
 
+// token map plumbing: storage dtype <-> fp32
+template <typename T>
+__global__ void tokens_to_f32_kernel(const T* __restrict__ in, const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out, size_t n, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const float v = to_f32<T>(in[i]);
+  out[i] = scale ? v * scale[c] + shift[c] : v;
+}
+template <typename T>
+__global__ void add_f32_into_kernel(T* __restrict__ inout, const float* __restrict__ add, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) inout[i] = from_f32<T>(to_f32<T>(inout[i]) + add[i]);
+}
+// out[i] = in[i] (* scale[c] + shift[c] when scale != NULL): the post-norm token map in fp32
+int launch_tokens_to_f32(const void* in, const float* scale, const float* shift, float* out, size_t n, int C, int dtype, hipStream_t s) {
+  if (n == 0) return 0;
+  const unsigned g = (unsigned)((n + 255) / 256);
+  if (dtype == 0) hipLaunchKernelGGL(tokens_to_f32_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)in, scale, shift, out, n, C);
+  else hipLaunchKernelGGL(tokens_to_f32_kernel<bf16>, dim3(g), dim3(256), 0, s, (const bf16*)in, scale, shift, out, n, C);
+  return (int)hipGetLastError();
+}
+int launch_add_f32_into(void* inout, const float* add, size_t n, int dtype, hipStream_t s) {
+  if (n == 0) return 0;
+  const unsigned g = (unsigned)((n + 255) / 256);
+  if (dtype == 0) hipLaunchKernelGGL(add_f32_into_kernel<float>, dim3(g), dim3(256), 0, s, (float*)inout, add, n);
+  else hipLaunchKernelGGL(add_f32_into_kernel<bf16>, dim3(g), dim3(256), 0, s, (bf16*)inout, add, n);
+  return (int)hipGetLastError();
+}
+
 int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, hipStream_t s) {
   if (M <= 0) return 0;
   hipLaunchKernelGGL(linear_fwd_kernel, dim3(M), dim3(256), 0, s, x, w, b, y, M, N, K);

@@ -93,6 +93,7 @@ struct fsvit_visformer_trainer {
   BnSave bnf;
   void* xnf = nullptr;
   float* scales = nullptr;                // [n_calls][B] = mask / keep
+  const float* dtokens = nullptr;         // optional gradient of the post-norm token map for the next backward (distillation head)
 };
 
 namespace {
@@ -409,6 +410,10 @@ int train_backward_impl(TR* t, const float* dfeat) {
   {
     void* dxn = take_tmp(t, M3 * t->C3); NEED(dxn);
     T_RUN(launch_avgpool_bwd(dfeat, dxn, B, t->H3 * t->H3, t->C3, dt, st));
+    if (t->dtokens) {                      // the token map also feeds the per-token classifier (token_label.py:49-53)
+      T_RUN(launch_add_f32_into(dxn, t->dtokens, M3 * t->C3, dt, st));
+      t->dtokens = nullptr;
+    }
     T_TRY(bn_bwd(t, "norm.bn", t->bnf, dxn, dx));
   }
   for (int sg = 3; sg >= 2; --sg) {
@@ -658,4 +663,19 @@ extern "C" int fsvit_sgd_step(float* param, const float* grad, float* momentum_b
   if (!param || !grad || !momentum_buf) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
   int rc = launch_sgd(param, grad, momentum_buf, n, lr, momentum, weight_decay, first_step, (hipStream_t)stream);
   return rc ? fsvit_set_error(rc, "sgd") : 0;
+}
+
+// ---- post-norm token map of the last train_forward (the `x` of `return x, pooled`, sun_meta_training/models/visformer.py:464) and its gradient
+extern "C" int fsvit_visformer_train_tokens(fsvit_visformer_trainer* t, float* tokens_dev, void* stream) {
+  if (!t || !tokens_dev) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
+  if (!t->xnf || !t->save.base || t->save.dry) return fsvit_set_error(FSVIT_ERR_ARG, "train_tokens called without a preceding train_forward");
+  const size_t n = (size_t)t->B * t->H3 * t->H3 * t->C3;
+  int rc = fsvit::launch_tokens_to_f32(t->xnf, nullptr, nullptr, tokens_dev, n, t->C3, t->dtype, (hipStream_t)stream);
+  if (rc != 0) return fsvit_set_error(FSVIT_ERR_ARG, "launch failed: %d", rc);
+  return 0;
+}
+extern "C" int fsvit_visformer_train_set_token_grad(fsvit_visformer_trainer* t, const float* dtokens_dev) {
+  if (!t) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
+  t->dtokens = dtokens_dev;               // consumed (and cleared) by the next fsvit_visformer_train_backward; NULL: none
+  return 0;
 }

@@ -127,6 +127,14 @@ class _EncoderEngine:
                                                              ws.numel(), _stream_ptr(x.device)))
         return out
 
+    def last_tokens(self, n_img: int, tokens_per_image: int) -> torch.Tensor:
+        """Post-norm token map [n_img, T, out_dim] fp32 of the images of the immediately preceding `forward` call (Visformer only; the
+        call must have fitted one chunk) - the `x` of the distillation encoder's `return x, pooled`."""
+        out = torch.empty(n_img, tokens_per_image, self.out_dim, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fsvit_visformer_last_tokens(self.h, _ptr(self._ws), self._ws.numel(), n_img, _ptr(out), _stream_ptr(self.device)))
+        return out
+
     def meta_baseline_forward(self, x_shot, x_query, temp: float, method: str = 'cos', want_stats=False):
         """x_shot [E,way,shot,3,H,W], x_query [E,Q,3,H,W] -> logits [E,Q,way] (+ per-episode acc, loss)."""
         _require_cuda(x_shot, x_query)
@@ -247,11 +255,22 @@ class VisformerTrainer:
         self._keep = (x, masks)
         return feat
 
-    def backward(self, tensors: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor], dfeat: torch.Tensor):
-        """Overwrites grads[name] (same shapes as tensors[name]) from dfeat [B,out_dim]."""
+    def tokens(self, B: int, tokens_per_image: int) -> torch.Tensor:
+        """Post-norm token map [B, T, out_dim] fp32 of the last forward (sun_meta_training/models/visformer.py:464)."""
+        out = torch.empty(B, tokens_per_image, self.out_dim, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fsvit_visformer_train_tokens(self.h, _ptr(out), _stream_ptr(self.device)))
+        return out
+
+    def backward(self, tensors: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor], dfeat: torch.Tensor, dtokens: torch.Tensor = None):
+        """Overwrites grads[name] (same shapes as tensors[name]) from dfeat [B,out_dim] (+ dtokens [B,T,out_dim], the gradient of the
+        token map handed out by `tokens`)."""
         _require_cuda(dfeat)
         dfeat = dfeat.contiguous().float()
         arr, keep = self._table(tensors, grads)
+        if dtokens is not None:
+            dtokens = dtokens.contiguous().float()
+            _lib.check(self.lib.fsvit_visformer_train_set_token_grad(self.h, _ptr(dtokens)))
         with torch.cuda.device(dfeat.device):
             _lib.check(self.lib.fsvit_visformer_train_backward(self.h, arr, len(tensors), _ptr(dfeat), _stream_ptr(dfeat.device)))
         self._keep = None

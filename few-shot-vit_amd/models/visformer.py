@@ -84,7 +84,7 @@ class Visformer(nn.Module):
     Visformer factory; visformer.py:466-487).  Other combinations raise at construction."""
 
     def __init__(self, img_size=80, init_channels=64, embed_dim=256, depth=(4, 2, 3), num_heads=6, mlp_ratio=4.,
-                 group=8, drop_path_rate=0., attn_stage='011', spatial_conv='100', numerics=None, **unused):
+                 group=8, drop_path_rate=0., attn_stage='011', spatial_conv='100', numerics=None, return_map=False, **unused):
         super().__init__()
         if attn_stage != '011' or spatial_conv != '100' or init_channels is None:
             raise NotImplementedError('fsvit builds the stem + attn_stage=011 + spatial_conv=100 Visformer family')
@@ -94,6 +94,7 @@ class Visformer(nn.Module):
         self.cfg = dict(img_size=img_size, init_channels=init_channels, embed_dim=embed_dim, depth=tuple(depth),
                         num_heads=num_heads, mlp_ratio=mlp_ratio, group=group)
         self.numerics = numerics
+        self.return_map = bool(return_map)           # distillation phase: forward returns (map [B,C,h,w], pooled) (sun_meta_training/models/visformer.py:464)
         self.img_size = img_size
         self.embed_dim = self.num_features = embed_dim
         self.out_dim = embed_dim * 2                   # visformer.py:298
@@ -177,8 +178,13 @@ class Visformer(nn.Module):
         backward through the HIP trainer; `droppath_masks` overrides the random draws (tests)."""
         assert x.shape[-2] == self.img_size and x.shape[-1] == self.img_size, \
             f"Input image size ({x.shape[-2]}*{x.shape[-1]}) does not match model ({self.img_size}*{self.img_size})."
+        hw = self.img_size // 16
         if not self.training:
-            return self.engine().forward(x)
+            feat = self.engine().forward(x)
+            if not self.return_map:
+                return feat
+            tok = self.engine().last_tokens(x.shape[0], hw * hw)
+            return tok.permute(0, 2, 1).reshape(x.shape[0], self.out_dim, hw, hw), feat
         for m in self.modules():
             if isinstance(m, nn.BatchNorm2d) and not m.training:
                 raise NotImplementedError('fsvit: freeze_bn (BatchNorm in eval mode inside a training step) is not built')
@@ -187,10 +193,16 @@ class Visformer(nn.Module):
         names = tuple(k for k, _ in named)
         buffers = {k: b for k, b in self.named_buffers() if not k.endswith('num_batches_tracked')}
         masks = droppath_masks if droppath_masks is not None else self.draw_droppath_masks(x.shape[0], x.device)
-        feat = VisformerTrainFn.apply(x, self.trainer(), names, buffers, self.drop_path_rate, masks, *[p for _, p in named])
+        if self.return_map:
+            from ..autograd import VisformerTrainMapFn
+            tok, feat = VisformerTrainMapFn.apply(x, self.trainer(), names, buffers, self.drop_path_rate, masks, hw * hw, *[p for _, p in named])
+        else:
+            feat = VisformerTrainFn.apply(x, self.trainer(), names, buffers, self.drop_path_rate, masks, *[p for _, p in named])
         for k, b in self.named_buffers():
             if k.endswith('num_batches_tracked'):
                 b += 1
+        if self.return_map:
+            return tok.permute(0, 2, 1).reshape(x.shape[0], self.out_dim, hw, hw), feat
         return feat
 
 

@@ -162,6 +162,11 @@ int fsvit_mlp_rows(const void* x_dev, void* y_dev, const void* w1_dev, int k1w, 
  * Replaces, for sun_meta_training/offline.py: `LinearClassifier.forward` / its autograd (models/classifier.py:27-34) as used by
  * `TokenLabelOffline` (models/token_label.py:36-60) on the 25 tokens and on the pooled feature, `generate_softlabel`
  * (offline.py:57-76), `SoftTargetCrossEntropy` (offline.py:34-45) and the AdamW update (offline.py:233).  fp32, token-major rows. */
+/* The distillation phase's encoder returns `(x, pooled)` (sun_meta_training/models/visformer.py:464): the post-norm token map
+ * [n_img][25][512] fp32 (token-major; the reference's [B, 512, 5, 5] permuted by (0, 2, 3, 1)) of the last eval forward / train forward,
+ * and the gradient hand-over for the train backward (added to the pooled feature's gradient path; consumed by the next backward). */
+int fsvit_visformer_last_tokens(fsvit_visformer* h, const void* ws_dev, size_t ws_bytes, int n_img, float* tokens_dev, void* stream);
+/* (train-mode counterparts: fsvit_visformer_train_tokens / fsvit_visformer_train_set_token_grad, declared with the trainer below) */
 /* y [M][N] = x [M][K] w[N][K]^T + b[N] (b may be NULL); K % 4 == 0. */
 int fsvit_linear_forward(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev, int M, int N, int K, void* stream);
 /* dx [M][K] (+)= dy w (NULL: skipped), dw [N][K] = dy^T x and db [N] = column sums of dy (NULL: skipped); N <= 256. */
@@ -201,6 +206,9 @@ typedef struct fsvit_param {
   int64_t numel;
 } fsvit_param;
 typedef struct fsvit_visformer_trainer fsvit_visformer_trainer;
+/* post-norm token map of the last train_forward / gradient hand-over for the next train_backward (distillation head, see above) */
+int fsvit_visformer_train_tokens(fsvit_visformer_trainer* t, float* tokens_dev, void* stream);
+int fsvit_visformer_train_set_token_grad(fsvit_visformer_trainer* t, const float* dtokens_dev);
 int fsvit_visformer_trainer_create(const fsvit_visformer_cfg* cfg, int dtype, fsvit_visformer_trainer** out);
 void fsvit_visformer_trainer_destroy(fsvit_visformer_trainer* t);
 /* bytes of workspace one forward+backward over n_img images needs (saved activations + temporaries) */

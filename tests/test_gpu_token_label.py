@@ -114,3 +114,41 @@ def test_distillation_step_reduces_loss():
         opt.step()
         losses.append(float(loss))
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+def test_encoder_map_and_token_gradient_vs_oracle():
+    """visformer_micro_80(return_map=True) = the distillation phase's encoder contract `return x, pooled`
+    (sun_meta_training/models/visformer.py:464): eval map / pooled against the oracle, and in train mode the gradient that reaches the
+    parameters through BOTH outputs against torch.autograd of the oracle (parity numerics)."""
+    from fewshot_vit_amd import models, synthetic
+    from oracle import visformer_oracle as vo
+    cfg = vo.VisformerCfg()
+    shapes = vo.state_dict_shapes(cfg, prefix='')
+    sd = synthetic.synthetic_checkpoint_sd({'encoder.' + k: v for k, v in shapes.items()})
+    sd = {k[len('encoder.'):]: v for k, v in sd.items()}
+    x = synthetic.synthetic_episodes(5, 1, 5, 1, 1)                             # 10 images [10, 3, 80, 80]
+    enc = models.make('visformer_micro_80', numerics='parity', return_map=True)
+    enc.load_state_dict(sd, strict=True)
+    enc = enc.cuda().eval()
+    with torch.no_grad():
+        fmap, pooled = enc(x.cuda())
+    ref_map, ref_pooled = vo.visformer_forward(sd, x, cfg, return_map=True)
+    assert fmap.shape == (10, 512, 5, 5)
+    assert (fmap.cpu() - ref_map).abs().max() <= 1e-3 and (pooled.cpu() - ref_pooled).abs().max() <= 1e-4
+    assert (fmap.mean(dim=(2, 3)) - pooled).abs().max() <= 1e-4
+    # train mode: loss through the map AND the pooled feature
+    g = torch.Generator().manual_seed(9)
+    wm, wp = torch.randn(10, 512, 5, 5, generator=g), torch.randn(10, 512, generator=g)
+    enc.train()
+    fmap, pooled = enc(x.cuda())
+    ((fmap * wm.cuda()).sum() + (pooled * wp.cuda()).sum()).backward()
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))}
+    full = {k: v.clone() for k, v in sd.items()}
+    full.update(params)
+    rm, rp = vo.visformer_forward(full, x, cfg, mode='train', return_map=True)
+    ((rm * wm).sum() + (rp * wp).sum()).backward()
+    assert (fmap.detach().cpu() - rm.detach()).abs().max() <= 2e-3
+    got = dict(enc.named_parameters())
+    for k in ('stage3.2.mlp.conv3.weight', 'norm.bn.weight', 'stage2.0.attn.qkv.weight', 'stem.conv1.weight'):
+        r = params[k].grad
+        assert ((got[k].grad.cpu() - r).norm() / r.norm()).item() <= 5e-3, k
