@@ -152,3 +152,25 @@ def test_encoder_map_and_token_gradient_vs_oracle():
     for k in ('stage3.2.mlp.conv3.weight', 'norm.bn.weight', 'stage2.0.attn.qkv.weight', 'stem.conv1.weight'):
         r = params[k].grad
         assert ((got[k].grad.cpu() - r).norm() / r.norm()).item() <= 5e-3, k
+
+
+def test_offline_driver_two_epochs(tmp_path):
+    """sun_meta_training/offline.py surface end to end on a small schedule: student / teacher `token-label` over visformer_micro_80,
+    distillation steps on the HIP trainer, few-shot val episodes, cosine schedule with warm-up stepped with (epoch - 1), checkpoint
+    schema readable by models.load."""
+    from fewshot_vit_amd import models, offline
+    config = dict(train_dataset='synthetic-episodes', train_dataset_args=dict(split='train', n_classes=8, n_per_class=20, noise=1.0, seed=1),
+                  val_dataset='synthetic-episodes', val_dataset_args=dict(split='val', n_classes=6, n_per_class=30, noise=1.0, seed=2),
+                  model='token-label', model_args=dict(encoder='visformer_micro_80', encoder_args=dict(drop_path_rate=0.1),
+                                                       classifier='linear-classifier', classifier_args=dict(n_classes=8)),
+                  synthetic_checkpoint='visformer_micro_80', batch_size=16, train_batches=3, eval_batches=2, max_epoch=2,
+                  n_way=5, n_shot=1, n_query=3, ep_per_batch=2, tl_soft_k=3, bg_token_num=10, optimizer='adamw',
+                  optimizer_args=dict(lr=5e-4, weight_decay=0.05, warmup_lr=1e-6, warmup=1), save_epoch=1)
+    lines = []
+    trlog = offline.main(config, name='o', device=torch.device('cuda', 0), log=lines.append, save_root=str(tmp_path))
+    assert len(trlog['tl']) == 2 and all(np.isfinite(trlog[k]).all() for k in trlog)
+    assert any(l.startswith('epoch 2, train') for l in lines)
+    ck = torch.load(os.path.join(str(tmp_path), 'o', 'epoch-last.pth'), map_location='cpu')
+    assert ck['model'] == 'token-label' and 'classifier_local.linear.weight' in ck['model_sd'] and ck['model_sd']['classifier_local.linear.weight'].shape == (9, 512)
+    lr_expected = 0.5 * (5e-4 * 16 / 512) * (1 + np.cos(np.pi * 1 / 2))          # after epoch 2: cosine at t = 1 of t_initial = 2 (warm-up 1 epoch)
+    assert ck['training']['optimizer_sd']['param_groups'][0]['lr'] == pytest.approx(lr_expected, rel=1e-6)
