@@ -31,6 +31,25 @@ class LinearClassifier(nn.Module):
         return LinearFn.apply(x, self.linear.weight, self.linear.bias)
 
 
+@register('classifier')
+class Classifier(nn.Module):
+    """sun_meta_training/models/classifier.py:11-24: encoder (returning `(map, pooled)`) + classifier on the pooled feature."""
+
+    def __init__(self, encoder, encoder_args, classifier, classifier_args):
+        super().__init__()
+        if isinstance(encoder, nn.Module):
+            self.encoder = encoder
+        else:
+            self.encoder = make(encoder, **dict(encoder_args or {}, return_map=True))
+        classifier_args = dict(classifier_args)
+        classifier_args['in_dim'] = self.encoder.out_dim
+        self.classifier = make(classifier, **classifier_args)
+
+    def forward(self, x):
+        _, x1 = self.encoder(x)
+        return self.classifier(x1)
+
+
 @register('token-label')
 class TokenLabelOffline(nn.Module):
     """token_label.py:36-60: a global classifier on the pooled feature and on the teacher's tokens, a local classifier with one

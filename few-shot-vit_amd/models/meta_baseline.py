@@ -43,6 +43,8 @@ class MetaBaseline(nn.Module):
         Q = x_query.shape[1]
         img = x_shot.shape[-3:]
         x_tot = self.encoder(torch.cat([x_shot.reshape(-1, *img), x_query.reshape(-1, *img)], dim=0))
+        if isinstance(x_tot, tuple):                       # distillation-phase encoder: `_, x_tot = self.encoder(...)` (sun_meta_training/models/meta_baseline.py:31)
+            x_tot = x_tot[1]
         n_shot = E * way * shot
         f_shot = x_tot[:n_shot].view(E, way, shot, -1)
         f_query = x_tot[n_shot:].view(E, Q, -1)

@@ -174,3 +174,25 @@ def test_offline_driver_two_epochs(tmp_path):
     assert ck['model'] == 'token-label' and 'classifier_local.linear.weight' in ck['model_sd'] and ck['model_sd']['classifier_local.linear.weight'].shape == (9, 512)
     lr_expected = 0.5 * (5e-4 * 16 / 512) * (1 + np.cos(np.pi * 1 / 2))          # after epoch 2: cosine at t = 1 of t_initial = 2 (warm-up 1 epoch)
     assert ck['training']['optimizer_sd']['param_groups'][0]['lr'] == pytest.approx(lr_expected, rel=1e-6)
+
+
+def test_train_classifier_driver(tmp_path):
+    """sun_meta_training/train_classifier.py surface: `classifier` (encoder + linear head) trained with CE / AdamW / cosine schedule,
+    supervised val pass, few-shot episodes through a meta-baseline that shares the encoder, checkpoint usable as offline.py's teacher."""
+    from fewshot_vit_amd import models, train_classifier
+    config = dict(train_dataset='synthetic-episodes', train_dataset_args=dict(split='train', n_classes=8, n_per_class=20, noise=1.0, seed=1),
+                  val_dataset='synthetic-episodes', val_dataset_args=dict(split='train', n_classes=8, n_per_class=4, noise=1.0, seed=1),
+                  fs_dataset='synthetic-episodes', fs_dataset_args=dict(split='test', n_classes=6, n_per_class=30, noise=1.0, seed=0),
+                  eval_fs_epoch=2, fs_batches=1,
+                  model='classifier', model_args=dict(encoder='visformer_micro_80', encoder_args=dict(drop_path_rate=0.1),
+                                                      classifier='linear-classifier', classifier_args=dict(n_classes=8)),
+                  synthetic_checkpoint='visformer_micro_80', batch_size=16, train_batches=3, max_epoch=2, optimizer='adamw',
+                  optimizer_args=dict(lr=5e-4, weight_decay=0.05, warmup_lr=1e-6, warmup=1), save_epoch=1)
+    lines = []
+    trlog = train_classifier.main(config, name='c', device=torch.device('cuda', 0), log=lines.append, save_root=str(tmp_path))
+    assert len(trlog['tl']) == 2 and np.isfinite(trlog['tl']).all() and np.isfinite(trlog['vl']).all()
+    assert 0.0 <= trlog['fsa-1'][-1] <= 1.0 and 0.0 <= trlog['fsa-5'][-1] <= 1.0
+    assert any('fs 1:' in l for l in lines)
+    ck = torch.load(os.path.join(str(tmp_path), 'c', 'epoch-last.pth'), map_location='cpu')
+    m = models.load(ck)
+    assert ck['model'] == 'classifier' and m.classifier.linear.weight.shape == (8, 512)
