@@ -78,8 +78,9 @@ struct Block1 {
 };
 struct BlockA {
   Layer qkv, proj, fc1, fc2;
-  void* mlp_img = nullptr;     // mlp_rows.hip: fragment-major image of fc1 + fc2 (null: the two GEMM launches are used)
+  void* mlp_img = nullptr;     // mlp_rows.hip: fragment-major image of [proj |] fc1 + fc2 (null: the GEMM launches are used)
   float* mlp_b1 = nullptr;
+  int mlp_kc = 0;              // > 0: the image starts with the proj fragments and mlp_rows also computes x += proj(ctx)
 };
 
 struct Tap { void* dst; size_t bytes; };
@@ -350,16 +351,19 @@ int build(fsvit_visformer* h, const SD& sd) {
       RC_TRY(pack_layer(h, &blocks[i].proj, wp, C, heads * hd, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, &colmap, heads * hdp));
       RC_TRY(pack_layer(h, &blocks[i].fc1, w1, hid, C, 1, 1, 1, nullptr, &n2.s, prenorm_bias(w1, hid, C, n2.t), true, nullptr, 0, nullptr, 0));
       RC_TRY(pack_layer(h, &blocks[i].fc2, w3, C, hid, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
-      if (mlp_rows_supported(h->dtype, C, hid)) {                // fused row-wise Mlp: re-pack fc1 / fc2 as the MFMA fragment stream
+      if (mlp_rows_supported(h->dtype, C, hid)) {                // fused row-wise Mlp: re-pack [proj,] fc1, fc2 as the MFMA fragment stream
+        const int kc = mlp_rows_proj_supported(C, hid, heads * hdp) ? heads * hdp : 0;
         void *img = nullptr, *b1i = nullptr;
-        HIP_TRY(hipMalloc(&img, mlp_rows_image_bytes(C, hid)));
+        HIP_TRY(hipMalloc(&img, mlp_rows_image_bytes(C, hid, kc)));
         h->allocs.push_back(img);
         HIP_TRY(hipMalloc(&b1i, (size_t)hid * 4));
         h->allocs.push_back(b1i);
-        RC_TRY(launch_mlp_pack(blocks[i].fc1.w, blocks[i].fc1.Kw, blocks[i].fc1.bias, blocks[i].fc2.w, blocks[i].fc2.Kw, img, (float*)b1i, C, hid, nullptr));
+        RC_TRY(launch_mlp_pack(blocks[i].fc1.w, blocks[i].fc1.Kw, blocks[i].fc1.bias, blocks[i].fc2.w, blocks[i].fc2.Kw, blocks[i].proj.w, blocks[i].proj.Kw,
+                               kc, img, (float*)b1i, C, hid, nullptr));
         HIP_TRY(hipDeviceSynchronize());
         blocks[i].mlp_img = img;
         blocks[i].mlp_b1 = (float*)b1i;
+        blocks[i].mlp_kc = kc;
       }
     }
   }
@@ -551,10 +555,16 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
       RC_TRY(run_gemm(h, st, (sp + ".attn.qkv").c_str(), b.qkv, conv_params(b.qkv, xs, qkv, Bc, Ho, Ho, C, C, 1, 1, 1, 0, 3 * heads * hdp, ACT_NONE, nullptr, 0, nullptr), 3.0 * heads * hd, C));
       RC_TRY(timed(h, st, (sp + ".attn.core").c_str(), KID_ATTN, 4.0 * Bc * heads * (double)S * S * hd,
                    [&]() { return launch_attention(qkv, ctx, Bc, S, heads, hdp, scale, dt, st); }));
+      if (b.mlp_img && b.mlp_kc) {   // proj + residual + conv1 + GELU + conv3 + residual in one launch
+        RC_TRY(timed(h, st, (sp + ".proj+mlp").c_str(), KID_MLPROWS, 2.0 * Bc * S * ((double)C * heads * hd + 2.0 * hidc * C),
+                     [&]() { return launch_mlp_rows(xs, xs, b.mlp_img, b.mlp_b1, b.fc2.bias, ctx, b.mlp_kc, Bc * S, C, hidc, st); }));
+        RC_TRY(tap(h, sp + "." + std::to_string(i), xs, xbytes, first, st));
+        continue;
+      }
       RC_TRY(run_gemm(h, st, (sp + ".attn.proj").c_str(), b.proj, conv_params(b.proj, ctx, xs, Bc, Ho, Ho, heads * hdp, heads * hdp, 1, 1, 1, 0, C, ACT_NONE, xs, 0, nullptr), C, (double)heads * hd));
       if (b.mlp_img) {     // conv1 + GELU + conv3 + residual in one launch, the hidden map stays in registers
         RC_TRY(timed(h, st, (sp + ".mlp").c_str(), KID_MLPROWS, 4.0 * Bc * S * (double)hidc * C,
-                     [&]() { return launch_mlp_rows(xs, xs, b.mlp_img, b.mlp_b1, b.fc2.bias, Bc * S, C, hidc, st); }));
+                     [&]() { return launch_mlp_rows(xs, xs, b.mlp_img, b.mlp_b1, b.fc2.bias, nullptr, 0, Bc * S, C, hidc, st); }));
       } else {
         RC_TRY(run_gemm(h, st, (sp + ".mlp.conv1").c_str(), b.fc1, conv_params(b.fc1, xs, hid, Bc, Ho, Ho, C, C, 1, 1, 1, 0, hidc, ACT_GELU, nullptr, 0, nullptr), hidc, C));
         RC_TRY(run_gemm(h, st, (sp + ".mlp.conv3").c_str(), b.fc2, conv_params(b.fc2, hid, xs, Bc, Ho, Ho, hidc, hidc, 1, 1, 1, 0, C, ACT_NONE, xs, 0, nullptr), C, hidc));
@@ -718,16 +728,23 @@ extern "C" int fsvit_stage1_block(const void* x, void* y, const void* w1, const 
 
 extern "C" int fsvit_mlp_rows(const void* x, void* y, const void* w1, int k1w, const float* b1, const void* w2, int k2w, const float* b2,
                               int M, int C, int hid, void* stream) {
+  return fsvit_proj_mlp_rows(x, y, nullptr, nullptr, 0, 0, w1, k1w, b1, w2, k2w, b2, M, C, hid, stream);
+}
+
+extern "C" int fsvit_proj_mlp_rows(const void* x, void* y, const void* ctx, const void* wp, int kpw, int KC, const void* w1, int k1w, const float* b1,
+                                   const void* w2, int k2w, const float* b2, int M, int C, int hid, void* stream) {
   if (!x || !y || !w1 || !w2) return fail(FSVIT_ERR_ARG, "null argument");
   if (!mlp_rows_supported(FSVIT_BF16, C, hid)) return fail(FSVIT_ERR_ARG, "fsvit_mlp_rows: only C = 256 / hidden = 1024 and C = 512 / hidden = 2048 (bf16) are built");
   if (k1w < C || k2w < hid) return fail(FSVIT_ERR_ARG, "weight rows shorter than K");
+  if (ctx && (!wp || kpw < KC || !mlp_rows_proj_supported(C, hid, KC))) return fail(FSVIT_ERR_ARG, "proj fusion: (C, KC) must be (256, 384) or (512, 576)");
+  if (!ctx) KC = 0;
   hipStream_t st = (hipStream_t)stream;
   void *img = nullptr, *b1i = nullptr;
-  HIP_TRY(hipMalloc(&img, mlp_rows_image_bytes(C, hid)));
+  HIP_TRY(hipMalloc(&img, mlp_rows_image_bytes(C, hid, KC)));
   hipError_t e = hipMalloc(&b1i, (size_t)hid * 4);
   if (e != hipSuccess) { (void)hipFree(img); return hipfail(e, "hipMalloc"); }
-  int rc = launch_mlp_pack(w1, k1w, b1, w2, k2w, img, (float*)b1i, C, hid, st);
-  if (rc == 0) rc = launch_mlp_rows(x, y, img, (const float*)b1i, b2, M, C, hid, st);
+  int rc = launch_mlp_pack(w1, k1w, b1, w2, k2w, wp, kpw, KC, img, (float*)b1i, C, hid, st);
+  if (rc == 0) rc = launch_mlp_rows(x, y, img, (const float*)b1i, b2, ctx, KC, M, C, hid, st);
   (void)hipStreamSynchronize(st);
   (void)hipFree(img);
   (void)hipFree(b1i);

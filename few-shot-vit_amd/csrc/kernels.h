@@ -33,9 +33,12 @@ int launch_stage1_rows(const void* x, void* y, const void* wimg, const float* b1
 // fused row-wise Mlp of the attention blocks (mlp_rows.hip; bf16, C = 256, hidden = 1024): y = x + W2 GELU(W1 x + b1) (+ b2), in place allowed.
 // wimg / b1img are built once by launch_mlp_pack from the standard packed layers (w1 [hid][k1w], w2 [C][k2w]).
 bool mlp_rows_supported(int dtype, int C, int hid);
-size_t mlp_rows_image_bytes(int C, int hid);
-int launch_mlp_pack(const void* w1, int k1w, const float* b1, const void* w2, int k2w, void* wimg, float* b1img, int C, int hid, hipStream_t s);
-int launch_mlp_rows(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, int M, int C, int hid, hipStream_t s);
+bool mlp_rows_proj_supported(int C, int hid, int KC);        // the attention block's proj conv + residual as a prologue on the same rows
+size_t mlp_rows_image_bytes(int C, int hid, int KC);
+int launch_mlp_pack(const void* w1, int k1w, const float* b1, const void* w2, int k2w, const void* wp, int kpw, int KC, void* wimg, float* b1img, int C,
+                    int hid, hipStream_t s);
+int launch_mlp_rows(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, const void* ctx, int KC, int M, int C, int hid,
+                    hipStream_t s);
 
 // distillation head (token_label.hip; fp32): LinearClassifier forward / backward, generate_softlabel, SoftTargetCrossEntropy, AdamW
 int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, hipStream_t s);

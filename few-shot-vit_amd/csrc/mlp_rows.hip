@@ -85,6 +85,13 @@ __device__ __forceinline__ u32x4 mr_gload16(const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
+// s_waitcnt vmcnt(0) with N (a multiple of 4) asm-loaded registers threaded through, so that no use can be scheduled above the wait
+template <int N> __device__ __forceinline__ void mr_wait_loads(u32x4* a) {
+  static_assert(N % 4 == 0 && N >= 4, "groups of 4");
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) :: "memory");
+#pragma unroll
+  for (int o = 4; o < N; o += 4) asm volatile("" : "+v"(a[o]), "+v"(a[o + 1]), "+v"(a[o + 2]), "+v"(a[o + 3]) :: "memory");
+}
 __device__ __forceinline__ unsigned mr_pk2(float a, float b) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
   const bf16x2_t v = {(bf16)a, (bf16)b};
@@ -112,10 +119,17 @@ __device__ __forceinline__ void mfma32_a_zero(f32x16& c) {
 
 }  // namespace
 
-template <int C, int HID, int RB>
+// KC > 0: the attention block's proj conv + residual (visformer.py:176,:261) runs as a prologue on the same rows:
+//   x1 = x + Wp ctx  (ctx = attention output [M][KC], head dims zero-padded; Wp's fragments = the first KC/16 * C/32 fragments of the image)
+// accumulated in the output AGPRs, rounded to bf16 into the x registers (exactly what the separate proj launch stored), and the Mlp
+// continues from there: proj is HBM-bound as a GEMM of its own (K = 384 / 576, N = C, + residual read and write).
+template <int C, int HID, int RB, int KC>
 __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
-                                                          const float* __restrict__ b1img, const float* __restrict__ b2, const int M, const int n_tiles) {
+                                                          const float* __restrict__ b1img, const float* __restrict__ b2, const bf16* __restrict__ CTX,
+                                                          const int M, const int n_tiles) {
   constexpr int NCT = C / 32, NKS = C / 16, NCH = HID / 32;
+  constexpr int PKS = KC / 16, PSLOTS = PKS * NCT / 32;  // proj: k-steps of 16 ctx channels, ring slots of 32 fragments (order: k-step outer, c-tile inner)
+  static_assert(KC % 16 == 0 && (PKS * NCT) % 32 == 0, "proj fragments fill whole slots");
   constexpr int PPC = 2 * NKS / 32;                      // ring slots per hidden chunk: 1 (W1 | W2) or 2 (W1, W2)
   constexpr int BM = MR_NW * 32 * RB;                    // token rows per workgroup tile
   constexpr int NACC = RB == 1 ? 2 : 1;                  // GEMM1 accumulators per row block (two independent MFMA chains per wave)
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
   int issue_img = 0, issue_slot = 0;
   auto issue = [&]() {
     mr_dma8(voff, wimg + (size_t)issue_img * MR_SLOT, lds0 + issue_slot * MR_SLOT + wave * 8192);
-    issue_img = issue_img == NCH * PPC - 1 ? 0 : issue_img + 1;
+    issue_img = issue_img == PSLOTS + NCH * PPC - 1 ? 0 : issue_img + 1;
     issue_slot = issue_slot == MR_NST - 1 ? 0 : issue_slot + 1;
   };
 #pragma unroll
@@ -165,30 +179,81 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
     // ---- this wave's 32 RB token rows -> registers (tail rows re-read the last valid row; their results are never stored)
     bool mok[RB];
     size_t rowoff[RB];
+    int mrow[RB];
     u32x4 xr[RB][NKS];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       const int m = tile * BM + (wave * RB + rb) * 32 + r;
       mok[rb] = m < M;
-      rowoff[rb] = (size_t)(mok[rb] ? m : M - 1) * C + 16 * kh;
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) xr[rb][s] = mr_gload16(X + rowoff[rb] + 32 * (s >> 1) + 8 * (s & 1));
+      mrow[rb] = mok[rb] ? m : M - 1;
+      rowoff[rb] = (size_t)mrow[rb] * C + 16 * kh;
     }
-    // The x loads and the previous tile's stores share the vmcnt queue with the ring's DMAs: drain once per tile (every DMA older
+    // The x (ctx) loads and the previous tile's stores share the vmcnt queue with the ring's DMAs: drain once per tile (every DMA older
     // than these loads landed long ago).  The registers are threaded through the wait so no use can be scheduled above it.
-    {
-      u32x4* xf = &xr[0][0];
-      asm volatile("s_waitcnt vmcnt(0)"
-                   : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(xf[4]), "+v"(xf[5]), "+v"(xf[6]), "+v"(xf[7]),
-                     "+v"(xf[8]), "+v"(xf[9]), "+v"(xf[10]), "+v"(xf[11]), "+v"(xf[12]), "+v"(xf[13]), "+v"(xf[14]), "+v"(xf[15])
-                   :: "memory");
-      asm volatile(""
-                   : "+v"(xf[16]), "+v"(xf[17]), "+v"(xf[18]), "+v"(xf[19]), "+v"(xf[20]), "+v"(xf[21]), "+v"(xf[22]), "+v"(xf[23]),
-                     "+v"(xf[24]), "+v"(xf[25]), "+v"(xf[26]), "+v"(xf[27]), "+v"(xf[28]), "+v"(xf[29]), "+v"(xf[30]), "+v"(xf[31])
-                   :: "memory");
-    }
-    if (first) { mr_bar(); first = false; }             // one barrier between the drain above and the first reads of image 0
+    auto load_x = [&]() {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) xr[rb][s] = mr_gload16(X + rowoff[rb] + 32 * (s >> 1) + 8 * (s & 1));
+      mr_wait_loads<RB * NKS>(&xr[0][0]);
+    };
     f32x16 yacc[RB][NCT];
+    if constexpr (KC > 0) {
+      u32x4 cr[RB][PKS];                                   // ctx rows as B operands: token r, channels 16 ks + 8 kh .. +7
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int ks = 0; ks < PKS; ++ks) cr[rb][ks] = mr_gload16(CTX + (size_t)mrow[rb] * KC + 16 * ks + 8 * kh);
+      mr_wait_loads<RB * PKS>(&cr[0][0]);
+      if (first) { mr_bar(); first = false; }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) mfma32_a_zero(yacc[rb][ct]);
+#pragma unroll
+      for (int ps = 0; ps < PSLOTS; ++ps) {
+        ring_sync();
+        const unsigned char* sp = smem + slot * MR_SLOT + lane * 16;
+        u32x4 fr[FD];
+#pragma unroll
+        for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int fi = 0; fi < 32; ++fi) {
+          const int g = ps * 32 + fi, ks = g / NCT, ct = g % NCT;
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) mfma32_a(fr[fi % FD], cr[rb][ks], yacc[rb][ct]);
+          if (fi + FD < 32) fr[fi % FD] = *reinterpret_cast<const u32x4*>(sp + (fi + FD) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        next_slot();
+      }
+      // x1 = proj + x, rounded to bf16 into the x registers (accumulator channel order == x register order)
+      load_x();
+      {
+        f32x16* yf = &yacc[0][0];
+        static_assert(RB * NCT == 16, "operand list");
+        asm volatile("s_nop 15\n\ts_nop 3"
+                     : "+a"(yf[0]), "+a"(yf[1]), "+a"(yf[2]), "+a"(yf[3]), "+a"(yf[4]), "+a"(yf[5]), "+a"(yf[6]), "+a"(yf[7]),
+                       "+a"(yf[8]), "+a"(yf[9]), "+a"(yf[10]), "+a"(yf[11]), "+a"(yf[12]), "+a"(yf[13]), "+a"(yf[14]), "+a"(yf[15]));
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const bf16x8 xv = __builtin_bit_cast(bf16x8, xr[rb][2 * ct + q]);
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              o[e] = mr_pk2(yacc[rb][ct][8 * q + 2 * e] + (float)xv[2 * e], yacc[rb][ct][8 * q + 2 * e + 1] + (float)xv[2 * e + 1]);
+            xr[rb][2 * ct + q] = o;
+          }
+    } else {
+      load_x();
+      if (first) { mr_bar(); first = false; }             // one barrier between the drain above and the first reads of image 0
+    }
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -299,22 +364,33 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may be in flight into the LDS of a finished workgroup
 }
 
-// Builds the fragment-major weight image + bias table from the engine's standard packed layers (w1 [HID][k1w], w2 [C][k2w],
-// K-contiguous bf16 rows).  One thread per bf16 element of the image.
+// Builds the fragment-major weight image + bias table from the engine's standard packed layers (w1 [HID][k1w], w2 [C][k2w], optional
+// wp [C][kpw] = the proj conv, K-contiguous bf16 rows).  Image = [proj: KC/16 k-steps x C/32 c-tiles of 1 KB fragments][per hidden
+// chunk: C/16 W1 fragments, C/16 W2 fragments].  One thread per bf16 element of the image.
 __global__ void mlp_pack_kernel(const bf16* __restrict__ w1, int k1w, const float* __restrict__ b1, const bf16* __restrict__ w2, int k2w,
-                                bf16* __restrict__ wimg, float* __restrict__ b1img, int C, int HID) {
+                                const bf16* __restrict__ wp, int kpw, int KC, bf16* __restrict__ wimg, float* __restrict__ b1img, int C, int HID) {
   const int NCT = C / 32, NKS = C / 16, NCH = HID / 32;
   const int per_chunk = (NKS + 2 * NCT) * 512;
+  const long proj_elems = (long)(KC / 16) * NCT * 512;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < HID) {
     const int j = (int)idx >> 5, w = (int)idx & 31, kh = w >> 4, i = w & 15;
     b1img[idx] = b1 ? b1[j * 32 + 8 * (i >> 2) + 4 * kh + (i & 3)] : 0.0f;
   }
-  if (idx >= (long)NCH * per_chunk) return;
-  const int j = (int)(idx / per_chunk), e = (int)(idx % per_chunk);
+  if (idx >= proj_elems + (long)NCH * per_chunk) return;
+  bf16 v;
+  if (idx < proj_elems) {       // fragment g = ks * NCT + ct: row = output channel (accumulator order), k = ctx channel 16 ks + 8 kh + e8
+    const int g = (int)(idx >> 9), lane = (int)(idx >> 3) & 63, e8 = (int)idx & 7;
+    const int ks = g / NCT, ct = g % NCT, kh = lane >> 5, r = lane & 31;
+    const int c = 32 * ct + 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
+    v = wp[(size_t)c * kpw + 16 * ks + 8 * kh + e8];
+    wimg[idx] = v;
+    return;
+  }
+  const long ii = idx - proj_elems;
+  const int j = (int)(ii / per_chunk), e = (int)(ii % per_chunk);
   const int piece = e >> 9, lane = (e >> 3) & 63, e8 = e & 7;
   const int kh = lane >> 5, r = lane & 31;
-  bf16 v;
   if (piece < NKS) {
     const int s = piece;
     v = w1[(size_t)(j * 32 + r) * k1w + 32 * (s >> 1) + 16 * kh + 8 * (s & 1) + e8];
@@ -328,22 +404,28 @@ __global__ void mlp_pack_kernel(const bf16* __restrict__ w1, int k1w, const floa
 }
 
 bool mlp_rows_supported(int dtype, int C, int hid) {
-  static const int mode = [] { const char* e = getenv("FSVIT_MLP_ROWS"); return e ? atoi(e) : 3; }();      // bit 0: C = 256, bit 1: C = 512
+  static const int mode = [] { const char* e = getenv("FSVIT_MLP_ROWS"); return e ? atoi(e) : 7; }();      // bit 0: C = 256, bit 1: C = 512, bit 2: proj fusion
   if (dtype != 1) return false;
   return (C == 256 && hid == 1024 && (mode & 1)) || (C == 512 && hid == 2048 && (mode & 2));
 }
-size_t mlp_rows_image_bytes(int C, int hid) { return (size_t)(hid / 32) * (C / 16 + 2 * (C / 32)) * 1024; }
+// proj fusion is built for the Visformer-S geometries: (C, KC) = (256, 384) and (512, 576) (6 heads x head dim padded to 64 / 96)
+bool mlp_rows_proj_supported(int C, int hid, int KC) {
+  static const int mode = [] { const char* e = getenv("FSVIT_MLP_ROWS"); return e ? atoi(e) : 7; }();
+  return (mode & 4) && ((C == 256 && hid == 1024 && KC == 384) || (C == 512 && hid == 2048 && KC == 576));
+}
+size_t mlp_rows_image_bytes(int C, int hid, int KC) { return ((size_t)(KC / 16) * (C / 32) + (size_t)(hid / 32) * (C / 16 + 2 * (C / 32))) * 1024; }
 
-int launch_mlp_pack(const void* w1, int k1w, const float* b1, const void* w2, int k2w, void* wimg, float* b1img, int C, int hid, hipStream_t s) {
-  const long n = (long)mlp_rows_image_bytes(C, hid) / 2;
+int launch_mlp_pack(const void* w1, int k1w, const float* b1, const void* w2, int k2w, const void* wp, int kpw, int KC, void* wimg, float* b1img, int C,
+                    int hid, hipStream_t s) {
+  const long n = (long)mlp_rows_image_bytes(C, hid, KC) / 2;
   hipLaunchKernelGGL(mlp_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)w1, k1w, b1, (const bf16*)w2, k2w,
-                     (bf16*)wimg, b1img, C, hid);
+                     (const bf16*)wp, kpw, KC, (bf16*)wimg, b1img, C, hid);
   return (int)hipGetLastError();
 }
 
-template <int C, int HID, int RB>
-static int launch_mlp_rows_t(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, int M, hipStream_t s) {
-  auto kern = mlp_rows_kernel<C, HID, RB>;
+template <int C, int HID, int RB, int KC>
+static int launch_mlp_rows_t(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, const void* ctx, int M, hipStream_t s) {
+  auto kern = mlp_rows_kernel<C, HID, RB, KC>;
   const int lds = MR_NST * MR_SLOT + HID * 4;
   static bool attr = false;
   if (!attr) {
@@ -354,14 +436,20 @@ static int launch_mlp_rows_t(const void* x, void* y, const void* wimg, const flo
   constexpr int BM = MR_NW * 32 * RB;
   const int n_tiles = (M + BM - 1) / BM;
   const int grid = n_tiles < 256 ? n_tiles : 256;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(MR_NW * 64), lds, s, (const bf16*)x, (bf16*)y, (const unsigned char*)wimg, b1img, b2, M, n_tiles);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(MR_NW * 64), lds, s, (const bf16*)x, (bf16*)y, (const unsigned char*)wimg, b1img, b2, (const bf16*)ctx, M,
+                     n_tiles);
   return (int)hipGetLastError();
 }
 
-int launch_mlp_rows(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, int M, int C, int hid, hipStream_t s) {
+// ctx != nullptr: x1 = x + Wp ctx first (the image must have been packed with the same KC)
+int launch_mlp_rows(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, const void* ctx, int KC, int M, int C, int hid,
+                    hipStream_t s) {
   if (M <= 0) return 0;
-  if (C == 256 && hid == 1024) return launch_mlp_rows_t<256, 1024, 2>(x, y, wimg, b1img, b2, M, s);
-  if (C == 512 && hid == 2048) return launch_mlp_rows_t<512, 2048, 1>(x, y, wimg, b1img, b2, M, s);
+  if (!ctx) KC = 0;
+  if (C == 256 && hid == 1024 && KC == 0) return launch_mlp_rows_t<256, 1024, 2, 0>(x, y, wimg, b1img, b2, nullptr, M, s);
+  if (C == 512 && hid == 2048 && KC == 0) return launch_mlp_rows_t<512, 2048, 1, 0>(x, y, wimg, b1img, b2, nullptr, M, s);
+  if (C == 256 && hid == 1024 && KC == 384) return launch_mlp_rows_t<256, 1024, 2, 384>(x, y, wimg, b1img, b2, ctx, M, s);
+  if (C == 512 && hid == 2048 && KC == 576) return launch_mlp_rows_t<512, 2048, 1, 576>(x, y, wimg, b1img, b2, ctx, M, s);
   return (int)hipErrorInvalidValue;
 }
 

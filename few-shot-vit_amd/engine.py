@@ -380,6 +380,17 @@ class ops:
                                                     float(weight_decay), int(step), _stream_ptr(p.device)))
 
     @staticmethod
+    def proj_mlp_rows(x, ctx, wp, w1, b1, w2, b2=None):
+        """x [M][C], ctx [M][KC] bf16, wp [C][KpW]: x1 = x + ctx wp^T; y = x1 + W2 GELU(W1 x1 + b1) + b2  ((C, KC) = (256, 384) | (512, 576))."""
+        _require_cuda(x, ctx, wp, w1, w2)
+        lib = _lib.load()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.fsvit_proj_mlp_rows(_ptr(x), _ptr(y), _ptr(ctx), _ptr(wp), wp.shape[-1], ctx.shape[1], _ptr(w1), w1.shape[-1], _ptr(b1),
+                                               _ptr(w2), w2.shape[-1], _ptr(b2), x.shape[0], x.shape[1], w1.shape[0], _stream_ptr(x.device)))
+        return y
+
+    @staticmethod
     def mlp_rows(x, w1, b1, w2, b2=None):
         """x [M][C] bf16, C = 256 or 512; w1 [4C][K1w], w2 [C][K2w] packed K-major bf16; b1 [4C], b2 [C] fp32 or None.  y = x + W2 GELU(W1 x + b1) + b2."""
         _require_cuda(x, w1, w2)

@@ -158,6 +158,11 @@ int fsvit_stage1_block(const void* x_dev, void* y_dev, const void* w1_dev, const
  * fp32 or NULL.  The operator form packs the weights on every call (the engine packs once per checkpoint). */
 int fsvit_mlp_rows(const void* x_dev, void* y_dev, const void* w1_dev, int k1w, const float* b1_dev, const void* w2_dev, int k2w,
                    const float* b2_dev, int M, int C, int hid, void* stream);
+/* The same with the attention block's proj conv + residual (visformer.py:176,:261) as a prologue on the same rows:
+ * x1 = x + wp ctx; y = x1 + W2 GELU(W1 x1 + b1) (+ b2).  ctx [M][KC] = attention output with zero-padded head dims, wp [C][kpw];
+ * (C, KC) = (256, 384) or (512, 576).  ctx == NULL: plain fsvit_mlp_rows. */
+int fsvit_proj_mlp_rows(const void* x_dev, void* y_dev, const void* ctx_dev, const void* wp_dev, int kpw, int KC, const void* w1_dev, int k1w,
+                        const float* b1_dev, const void* w2_dev, int k2w, const float* b2_dev, int M, int C, int hid, void* stream);
 /* ---------------------------------------------------------------- distillation head
  * Replaces, for sun_meta_training/offline.py: `LinearClassifier.forward` / its autograd (models/classifier.py:27-34) as used by
  * `TokenLabelOffline` (models/token_label.py:36-60) on the 25 tokens and on the pooled feature, `generate_softlabel`

@@ -241,6 +241,35 @@ def test_mlp_rows_fused_matches_unfused_math(M, C):
     assert torch.equal(lib_y, ops.mlp_rows(xd, w1d, b1.cuda(), w2d, None))
 
 
+@pytest.mark.parametrize('C,KC', [(256, 384), (512, 576)])
+@pytest.mark.parametrize('M', [300, 40000 + 11])
+def test_proj_mlp_rows_fused_matches_unfused_math(M, C, KC):
+    """mlp_rows with the attention block's proj conv + residual as a prologue: x1 = bf16(x + ctx Wp^T), y = x1 + W2 GELU(W1 x1 + b1);
+    fp32 torch with the same bf16 roundings; 5 repeats bit-identical."""
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(M + C)
+    HID = 4 * C
+    x = q(torch.randn(M, C, generator=g), bf)
+    ctx = q(torch.randn(M, KC, generator=g), bf)
+    wp = q(torch.randn(C, KC, generator=g) / math.sqrt(KC), bf)
+    w1 = q(torch.randn(HID, C, generator=g) / math.sqrt(C), bf)
+    b1 = torch.randn(HID, generator=g) * 0.3
+    w2 = q(torch.randn(C, HID, generator=g) / math.sqrt(HID), bf)
+    x1 = q(x + ctx @ wp.t(), bf)
+    ref = x1 + q(F.gelu(x1 @ w1.t() + b1), bf) @ w2.t()
+    args = [t.to('cuda', bf) for t in (x, ctx, wp, w1)] + [b1.cuda(), w2.to('cuda', bf)]
+    y0 = ops.proj_mlp_rows(*args)
+    torch.cuda.synchronize()
+    err = (y0.float().cpu() - ref).abs()
+    # x1 is rounded to bf16 at slightly different fp32 values on the two sides (different summation order): a flipped rounding of x1
+    # moves y by one bf16 ulp of x1 through the residual
+    assert err.max().item() <= 4e-2 * max(1.0, float(ref.abs().max())), (M, C, err.max().item())
+    assert err.mean().item() <= 4e-3, (M, C, err.mean().item())
+    for _ in range(5):
+        assert torch.equal(ops.proj_mlp_rows(*args), y0)
+
+
 def test_gemm256_large_shapes_repeatable_and_correct():
     """Race screen of the pipelined 256x256 kernel (counted-vmcnt LDS-DMA ring, cdna_hip_programming.md: a misplaced wait shows up as
     rare wrong tiles): several persistent items per workgroup, tails in M and N, 25 repeats must be bit-identical and match fp32."""
