@@ -151,7 +151,8 @@ __global__ __launch_bounds__(NW * 64) void attention_v2_kernel(const T* __restri
   constexpr int SKP = NKT * 16;
   constexpr int QS = HDP * ES + 16;            // K row stride (bytes): odd multiple of 16 -> conflict-free b128 reads
   constexpr int VS = SKP * ES + 16;            // V^T row stride
-  constexpr int NKC = HDP * ES / 64;           // 64-byte chunks along the head dim
+  constexpr int NKC = (HDP * ES + 63) / 64;    // 64-byte chunks along the head dim; a head dim of 48 bf16 (1.5 chunks) zero-fills the half chunk in registers
+  constexpr bool HALF_TAIL = (HDP * ES) % 64 != 0;
   unsigned char* const Ks = smem;
   unsigned char* const Vt = smem + SKP * QS;
 
@@ -185,15 +186,21 @@ __global__ __launch_bounds__(NW * 64) void attention_v2_kernel(const T* __restri
     // Q fragments straight from global: row q, 16-byte chunk (kc*4 + lq)
     u32x4 qf[NKC];
 #pragma unroll
-    for (int kc = 0; kc < NKC; ++kc)
-      qf[kc] = q < S ? *reinterpret_cast<const u32x4*>(base + (size_t)q * rowlen + (kc * 4 + lq) * EPC) : zero4;
+    for (int kc = 0; kc < NKC; ++kc) {
+      const bool inrow = !HALF_TAIL || kc + 1 < NKC || lq < 2;                   // 16-byte chunk kc * 4 + lq lies inside the head row
+      qf[kc] = (q < S && inrow) ? *reinterpret_cast<const u32x4*>(base + (size_t)q * rowlen + (kc * 4 + lq) * EPC) : zero4;
+    }
     f32x4 sc[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const unsigned char* ka = Ks + (kt * 16 + lrow) * QS + lq * 16;
 #pragma unroll
-      for (int kc = 0; kc < NKC; ++kc) acc = mma_chunk<T>(*reinterpret_cast<const u32x4*>(ka + kc * 64), qf[kc], acc);
+      for (int kc = 0; kc < NKC; ++kc) {
+        u32x4 kf = *reinterpret_cast<const u32x4*>(ka + kc * 64);
+        if (HALF_TAIL && kc + 1 == NKC && lq >= 2) kf = zero4;                   // beyond the row: the LDS bytes there belong to the pad / the next row
+        acc = mma_chunk<T>(kf, qf[kc], acc);
+      }
       sc[kt] = acc;                      // keys kt*16 + lq*4 + r  x  query lrow
     }
     // bf16 storage: P is rounded to bf16 anyway, so exp runs on the hardware exp2 (v_exp_f32) with log2(e) folded
@@ -271,7 +278,7 @@ static int dispatch_ndt(int ndt, const void* qkv, void* ctx, int B, int S, int h
   switch (ndt) {
     case 1: if constexpr (sizeof(T) == 4) return launch_v2<T, NKT, 1, NW>(qkv, ctx, B, S, heads, scale, s); else return -1;
     case 2: return launch_v2<T, NKT, 2, NW>(qkv, ctx, B, S, heads, scale, s);
-    case 3: if constexpr (sizeof(T) == 4) return launch_v2<T, NKT, 3, NW>(qkv, ctx, B, S, heads, scale, s); else return -1;
+    case 3: return launch_v2<T, NKT, 3, NW>(qkv, ctx, B, S, heads, scale, s);          // bf16: head dim 48 = one and a half 64-byte chunks
     case 4: return launch_v2<T, NKT, 4, NW>(qkv, ctx, B, S, heads, scale, s);
     case 5: if constexpr (sizeof(T) == 4) return launch_v2<T, NKT, 5, NW>(qkv, ctx, B, S, heads, scale, s); else return -1;
     case 6: return launch_v2<T, NKT, 6, NW>(qkv, ctx, B, S, heads, scale, s);
@@ -294,10 +301,22 @@ static int launch_attention_v2(const void* qkv, void* ctx, int B, int S, int hea
   return -1;
 }
 
+// Padded head dim the packer should use: the smallest multiple of 16 the attention kernels take for (hd, S, dtype).  fp32: any
+// multiple of 16.  bf16: 32 / 48 / 64 / 96 / 128 on the register-softmax kernel (48 = one and a half 64-byte MFMA chunks, the half
+// chunk zero-filled in registers: Visformer-S stage 2 pads 42 -> 48 instead of 64, 25 % fewer qkv / ctx bytes and qkv / proj flops);
+// otherwise multiples of 32.
+int attention_padded_head_dim(int hd, int S, int dtype) {
+  const int h16 = (hd + 15) / 16 * 16;
+  if (dtype == 0) return h16;
+  const int ndt = h16 / 16;
+  if (S <= 224 && (ndt == 2 || ndt == 3 || ndt == 4 || ndt == 6 || ndt == 8)) return h16;
+  return (hd + 31) / 32 * 32;
+}
+
 int launch_attention(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, hipStream_t s) {
   if (B <= 0) return 0;
   const int es = dtype == 0 ? 4 : 2;
-  if (S < 1 || hdp % (64 / es) != 0) return (int)hipErrorInvalidValue;
+  if (S < 1 || hdp % 16 != 0) return (int)hipErrorInvalidValue;
   {
     const int rc = launch_attention_v2(qkv, ctx, B, S, heads, hdp, scale, dtype, s);
     if (rc != -1) return rc;

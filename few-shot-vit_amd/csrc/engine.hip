@@ -240,7 +240,9 @@ int build(fsvit_visformer* h, const SD& sd) {
   const int kch = 64 / h->es;                                  // head dim padded to the 64-byte MFMA K chunk
   h->hd2 = (int)std::lround((double)(h->C2 / cf.num_heads));  // round(dim // heads * 1.0), visformer.py:172
   h->hd3 = (int)std::lround((double)(h->C3 / cf.num_heads));
-  h->hdp2 = round_up(h->hd2, kch); h->hdp3 = round_up(h->hd3, kch);
+  h->hdp2 = attention_padded_head_dim(h->hd2, h->H2 * h->H2, h->dtype);
+  h->hdp3 = attention_padded_head_dim(h->hd3, h->H3 * h->H3, h->dtype);
+  (void)kch;
   const int Cg = h->hid1 / cf.group;
   if (h->C0 % epc || h->C1 % epc || h->hid1 % cf.group || Cg % epc)
     return fail(FSVIT_ERR_ARG, "channel counts must be multiples of %d for 16-byte K chunks", epc);
@@ -736,7 +738,7 @@ extern "C" int fsvit_proj_mlp_rows(const void* x, void* y, const void* ctx, cons
   if (!x || !y || !w1 || !w2) return fail(FSVIT_ERR_ARG, "null argument");
   if (!mlp_rows_supported(FSVIT_BF16, C, hid)) return fail(FSVIT_ERR_ARG, "fsvit_mlp_rows: only C = 256 / hidden = 1024 and C = 512 / hidden = 2048 (bf16) are built");
   if (k1w < C || k2w < hid) return fail(FSVIT_ERR_ARG, "weight rows shorter than K");
-  if (ctx && (!wp || kpw < KC || !mlp_rows_proj_supported(C, hid, KC))) return fail(FSVIT_ERR_ARG, "proj fusion: (C, KC) must be (256, 384) or (512, 576)");
+  if (ctx && (!wp || kpw < KC || !mlp_rows_proj_supported(C, hid, KC))) return fail(FSVIT_ERR_ARG, "proj fusion: (C, KC) must be (256, 288) or (512, 576)");
   if (!ctx) KC = 0;
   hipStream_t st = (hipStream_t)stream;
   void *img = nullptr, *b1i = nullptr;

@@ -262,8 +262,8 @@ bool gemm256_eligible(const ConvGemmParams& p, int dtype) {
   if ((size_t)p.M * p.x_cstride * 2 >= (1ull << 32) || (size_t)p.N * p.Kw * 2 >= (1ull << 32)) return false;   // 32-bit DMA offsets
   // One 8-wave workgroup per CU cannot hide its epilogue behind another workgroup's MFMAs, so the HBM-bound layers
   // (few flops per streamed byte: the N = 256 / residual projections) stay on conv_gemm_v2 (2-3 workgroups per CU);
-  // measured crossover ~200 flop/B (profiles/r01_gemm256_layers.txt).
-  static const double min_ai = [] { const char* e = getenv("FSVIT_GEMM256_MIN_AI"); return e ? atof(e) : 200.0; }();
+  // measured crossover ~200 flop/B (profiles/r01_gemm256_layers.txt); 190 keeps the stage-2 qkv layer with 48-wide heads (N = 864, 197.5 flop/B) here.
+  static const double min_ai = [] { const char* e = getenv("FSVIT_GEMM256_MIN_AI"); return e ? atof(e) : 190.0; }();
   const double ai = (double)p.N * p.K / ((double)p.K + (double)p.N * (p.res ? 2.0 : 1.0));
   return ai >= min_ai;
 }

@@ -11,6 +11,7 @@ int launch_maxpool2_pos(const void* in, const float* pos, void* out, int B, int 
 // qkv [B*S][3*heads*hdp] (channel = x*heads*hdp + y*hdp + z) -> ctx [B*S][heads*hdp]
 int launch_attention(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, hipStream_t s);
 size_t attention_lds_bytes(int S, int hdp, int dtype);
+int attention_padded_head_dim(int hd, int S, int dtype);      // what the weight packer pads a head to
 
 // x [B][HW][C] -> feat [B][C] fp32 = scale[c] * mean_hw(x) + shift[c]
 int launch_pool_affine(const void* x, const float* scale, const float* shift, float* feat, int B, int HW, int C, int dtype, hipStream_t s);

@@ -128,8 +128,9 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
                                                           const float* __restrict__ b1img, const float* __restrict__ b2, const bf16* __restrict__ CTX,
                                                           const int M, const int n_tiles) {
   constexpr int NCT = C / 32, NKS = C / 16, NCH = HID / 32;
-  constexpr int PKS = KC / 16, PSLOTS = PKS * NCT / 32;  // proj: k-steps of 16 ctx channels, ring slots of 32 fragments (order: k-step outer, c-tile inner)
-  static_assert(KC % 16 == 0 && (PKS * NCT) % 32 == 0, "proj fragments fill whole slots");
+  constexpr int PKS = KC / 16, PFR = PKS * NCT;          // proj: k-steps of 16 ctx channels, fragments in (k-step outer, c-tile inner) order
+  constexpr int PSLOTS = (PFR + 31) / 32;                // ring slots of 32 fragments, the last one padded (its tail is never read)
+  static_assert(KC % 16 == 0, "whole k-steps");
   constexpr int PPC = 2 * NKS / 32;                      // ring slots per hidden chunk: 1 (W1 | W2) or 2 (W1, W2)
   constexpr int BM = MR_NW * 32 * RB;                    // token rows per workgroup tile
   constexpr int NACC = RB == 1 ? 2 : 1;                  // GEMM1 accumulators per row block (two independent MFMA chains per wave)
@@ -221,9 +222,11 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
 #pragma unroll
         for (int fi = 0; fi < 32; ++fi) {
           const int g = ps * 32 + fi, ks = g / NCT, ct = g % NCT;
+          if (g < PFR) {
 #pragma unroll
-          for (int rb = 0; rb < RB; ++rb) mfma32_a(fr[fi % FD], cr[rb][ks], yacc[rb][ct]);
-          if (fi + FD < 32) fr[fi % FD] = *reinterpret_cast<const u32x4*>(sp + (fi + FD) * 1024);
+            for (int rb = 0; rb < RB; ++rb) mfma32_a(fr[fi % FD], cr[rb][ks < PKS ? ks : 0], yacc[rb][ct]);
+          }
+          if (fi + FD < 32 && g + FD < PFR) fr[fi % FD] = *reinterpret_cast<const u32x4*>(sp + (fi + FD) * 1024);
           __builtin_amdgcn_sched_barrier(0);
         }
         next_slot();
@@ -371,7 +374,7 @@ __global__ void mlp_pack_kernel(const bf16* __restrict__ w1, int k1w, const floa
                                 const bf16* __restrict__ wp, int kpw, int KC, bf16* __restrict__ wimg, float* __restrict__ b1img, int C, int HID) {
   const int NCT = C / 32, NKS = C / 16, NCH = HID / 32;
   const int per_chunk = (NKS + 2 * NCT) * 512;
-  const long proj_elems = (long)(KC / 16) * NCT * 512;
+  const long proj_elems = (long)(((KC / 16) * NCT + 31) / 32) * 32 * 512;      // whole slots; fragments past KC read wp's zero padding (kpw >= 16 * ceil)
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < HID) {
     const int j = (int)idx >> 5, w = (int)idx & 31, kh = w >> 4, i = w & 15;
@@ -383,7 +386,8 @@ __global__ void mlp_pack_kernel(const bf16* __restrict__ w1, int k1w, const floa
     const int g = (int)(idx >> 9), lane = (int)(idx >> 3) & 63, e8 = (int)idx & 7;
     const int ks = g / NCT, ct = g % NCT, kh = lane >> 5, r = lane & 31;
     const int c = 32 * ct + 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
-    v = wp[(size_t)c * kpw + 16 * ks + 8 * kh + e8];
+    const int k = 16 * ks + 8 * kh + e8;
+    v = k < kpw ? wp[(size_t)c * kpw + k] : (bf16)0.0f;
     wimg[idx] = v;
     return;
   }
@@ -408,12 +412,15 @@ bool mlp_rows_supported(int dtype, int C, int hid) {
   if (dtype != 1) return false;
   return (C == 256 && hid == 1024 && (mode & 1)) || (C == 512 && hid == 2048 && (mode & 2));
 }
-// proj fusion is built for the Visformer-S geometries: (C, KC) = (256, 384) and (512, 576) (6 heads x head dim padded to 64 / 96)
+// proj fusion is built for the Visformer-S geometries: (C, KC) = (256, 288) and (512, 576) (6 heads x head dim padded to 48 / 96)
 bool mlp_rows_proj_supported(int C, int hid, int KC) {
   static const int mode = [] { const char* e = getenv("FSVIT_MLP_ROWS"); return e ? atoi(e) : 7; }();
-  return (mode & 4) && ((C == 256 && hid == 1024 && KC == 384) || (C == 512 && hid == 2048 && KC == 576));
+  return (mode & 4) && ((C == 256 && hid == 1024 && KC == 288) || (C == 512 && hid == 2048 && KC == 576));
 }
-size_t mlp_rows_image_bytes(int C, int hid, int KC) { return ((size_t)(KC / 16) * (C / 32) + (size_t)(hid / 32) * (C / 16 + 2 * (C / 32))) * 1024; }
+size_t mlp_rows_image_bytes(int C, int hid, int KC) {
+  const size_t proj_frags = ((size_t)(KC / 16) * (C / 32) + 31) / 32 * 32;
+  return (proj_frags + (size_t)(hid / 32) * (C / 16 + 2 * (C / 32))) * 1024;
+}
 
 int launch_mlp_pack(const void* w1, int k1w, const float* b1, const void* w2, int k2w, const void* wp, int kpw, int KC, void* wimg, float* b1img, int C,
                     int hid, hipStream_t s) {
@@ -448,7 +455,7 @@ int launch_mlp_rows(const void* x, void* y, const void* wimg, const float* b1img
   if (!ctx) KC = 0;
   if (C == 256 && hid == 1024 && KC == 0) return launch_mlp_rows_t<256, 1024, 2, 0>(x, y, wimg, b1img, b2, nullptr, M, s);
   if (C == 512 && hid == 2048 && KC == 0) return launch_mlp_rows_t<512, 2048, 1, 0>(x, y, wimg, b1img, b2, nullptr, M, s);
-  if (C == 256 && hid == 1024 && KC == 384) return launch_mlp_rows_t<256, 1024, 2, 384>(x, y, wimg, b1img, b2, ctx, M, s);
+  if (C == 256 && hid == 1024 && KC == 288) return launch_mlp_rows_t<256, 1024, 2, 288>(x, y, wimg, b1img, b2, ctx, M, s);
   if (C == 512 && hid == 2048 && KC == 576) return launch_mlp_rows_t<512, 2048, 1, 576>(x, y, wimg, b1img, b2, ctx, M, s);
   return (int)hipErrorInvalidValue;
 }

@@ -381,7 +381,7 @@ class ops:
 
     @staticmethod
     def proj_mlp_rows(x, ctx, wp, w1, b1, w2, b2=None):
-        """x [M][C], ctx [M][KC] bf16, wp [C][KpW]: x1 = x + ctx wp^T; y = x1 + W2 GELU(W1 x1 + b1) + b2  ((C, KC) = (256, 384) | (512, 576))."""
+        """x [M][C], ctx [M][KC] bf16, wp [C][KpW]: x1 = x + ctx wp^T; y = x1 + W2 GELU(W1 x1 + b1) + b2  ((C, KC) = (256, 288) | (512, 576))."""
         _require_cuda(x, ctx, wp, w1, w2)
         lib = _lib.load()
         y = torch.empty_like(x)

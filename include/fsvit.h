@@ -160,7 +160,7 @@ int fsvit_mlp_rows(const void* x_dev, void* y_dev, const void* w1_dev, int k1w, 
                    const float* b2_dev, int M, int C, int hid, void* stream);
 /* The same with the attention block's proj conv + residual (visformer.py:176,:261) as a prologue on the same rows:
  * x1 = x + wp ctx; y = x1 + W2 GELU(W1 x1 + b1) (+ b2).  ctx [M][KC] = attention output with zero-padded head dims, wp [C][kpw];
- * (C, KC) = (256, 384) or (512, 576).  ctx == NULL: plain fsvit_mlp_rows. */
+ * (C, KC) = (256, 288) or (512, 576).  ctx == NULL: plain fsvit_mlp_rows. */
 int fsvit_proj_mlp_rows(const void* x_dev, void* y_dev, const void* ctx_dev, const void* wp_dev, int kpw, int KC, const void* w1_dev, int k1w,
                         const float* b1_dev, const void* w2_dev, int k2w, const float* b2_dev, int M, int C, int hid, void* stream);
 /* ---------------------------------------------------------------- distillation head

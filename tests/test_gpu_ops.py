@@ -101,11 +101,13 @@ def test_conv_gemm(case, dt):
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
-@pytest.mark.parametrize('S,heads,hd', [(100, 6, 42), (25, 6, 85), (100, 2, 10), (25, 3, 21)])
-def test_attention(S, heads, hd, dt):
+@pytest.mark.parametrize('S,heads,hd,pad', [(100, 6, 42, 0), (100, 6, 42, 16), (25, 6, 85, 0), (100, 2, 10, 0), (25, 3, 21, 0), (197, 3, 40, 16)])
+def test_attention(S, heads, hd, pad, dt):
+    """pad = 16: head dim padded to a multiple of 16 only (bf16: 42 -> 48 = one and a half MFMA K chunks, the engine's choice for
+    Visformer-S stage 2); pad = 0: to the full 64-byte chunk."""
     from fewshot_vit_amd.engine import ops
     dtype = DT[dt]
-    kch = 16 if dt == 'f32' else 32
+    kch = pad or (16 if dt == 'f32' else 32)
     hdp = (hd + kch - 1) // kch * kch
     B = 3
     g = torch.Generator().manual_seed(S * 7 + hd)
@@ -241,7 +243,7 @@ def test_mlp_rows_fused_matches_unfused_math(M, C):
     assert torch.equal(lib_y, ops.mlp_rows(xd, w1d, b1.cuda(), w2d, None))
 
 
-@pytest.mark.parametrize('C,KC', [(256, 384), (512, 576)])
+@pytest.mark.parametrize('C,KC', [(256, 288), (512, 576)])
 @pytest.mark.parametrize('M', [300, 40000 + 11])
 def test_proj_mlp_rows_fused_matches_unfused_math(M, C, KC):
     """mlp_rows with the attention block's proj conv + residual as a prologue: x1 = bf16(x + ctx Wp^T), y = x1 + W2 GELU(W1 x1 + b1);
