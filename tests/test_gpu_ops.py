@@ -57,6 +57,7 @@ CASES = [
     ('g256_fc1_gelu',   13, 10, 10, 256,   1024, 1, 1, 0, 1, 1, False, 0, True, False),
     ('g256_fc2_res',    11, 10, 10, 1024,  256, 1, 1, 0, 1, 0, True, 0, True, False),
     ('g256_qkv_tailN',  12, 10, 10, 256,   1152, 1, 1, 0, 1, 0, False, 0, True, False),
+    ('g256_qkv_n864',   12, 10, 10, 256,   864, 1, 1, 0, 1, 0, False, 0, True, False),     # 48-wide heads: 197.5 flop/B, the lowest gemm256 takes
     ('g256_proj_k384',  41, 5,  5,  384,   704, 1, 1, 0, 1, 2, True, 1, False, False),
     ('g256_k128',       3, 20, 20, 128,    320, 1, 1, 0, 1, 0, False, 0, False, False),
     ('g256_bigK',       45, 5,  5,  2048,  512, 1, 1, 0, 1, 0, True, 0, True, False),

@@ -174,3 +174,20 @@ def test_ragged_batches_and_chunking(full_sd):
     with torch.no_grad():
         logits = m(xs, xq)
     assert logits.shape == (2, 50, 10) and torch.isfinite(logits).all()
+
+
+def test_full_size_step_equals_small_launches(full_sd):
+    """BASELINE configs[1] at bench size (64 episodes x 100 images in ONE encoder pass: every persistent kernel walks many tiles per
+    workgroup, tile tails included) against the same episodes run 8 at a time: bit-identical logits.  Size-independent property:
+    eval-mode episodes are independent and no kernel's arithmetic may depend on where a row sits in the launch."""
+    from fewshot_vit_amd import synthetic
+    from fewshot_vit_amd.utils import few_shot as fs
+    m = _model(full_sd, 'bf16')
+    E = 64
+    x = synthetic.synthetic_episodes(2024, E, 5, 5, 15)
+    xs, xq = fs.split_shot_query(x, 5, 5, 15, E)
+    with torch.no_grad():
+        big = m(xs.cuda(), xq.cuda()).cpu()
+        small = torch.cat([m(xs[e:e + 8].cuda(), xq[e:e + 8].cuda()).cpu() for e in range(0, E, 8)])
+    assert big.shape == (E, 75, 5) and torch.isfinite(big).all()
+    assert torch.equal(big, small)
