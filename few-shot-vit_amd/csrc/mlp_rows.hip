@@ -33,6 +33,8 @@
 // fragment read-ahead nor MFMA reordering moved it.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "fsvit_common.h"
 #include "kernels.h"
 
@@ -70,6 +72,20 @@ __device__ __forceinline__ void mr_dma8(unsigned voff, const void* sbase, unsign
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "v"(voff), "v"(voff + 4096u), "s"(sbase), "s"(lds), "s"(lds + 4096u)
+      : "memory");
+}
+// One 1 KiB piece.  A VMEM instruction of 64 x 16 bytes keeps the wave's issue stage for ~64 cycles; back to back they queue behind
+// each other and hold up the MFMAs that follow, so inside the chunk loop the refill goes out one piece at a time, pieces >= 4 MFMAs apart.
+__device__ __forceinline__ void mr_dma1(unsigned voff, const void* sbase, unsigned lds) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds)
       : "memory");
 }
 __device__ __forceinline__ void mr_bar() {
@@ -110,6 +126,10 @@ __device__ __forceinline__ void mfma32_v(u32x4 a, u32x4 b, f32x16& c) {
 __device__ __forceinline__ void mfma32_a(u32x4 a, u32x4 b, f32x16& c) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
+// first MFMA of an accumulation chain that starts from zero: D = A B + 0
+__device__ __forceinline__ void mfma32_v_z(u32x4 a, u32x4 b, f32x16& d) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+}
 // accumulator := 0 without ever being a VGPR value (a C++ `= 0` makes the loop-carried accumulators VGPR-class and every asm use
 // a 16-register round trip through v_accvgpr_write / read)
 __device__ __forceinline__ void mfma32_a_zero(f32x16& c) {
@@ -126,14 +146,13 @@ __device__ __forceinline__ void mfma32_a_zero(f32x16& c) {
 template <int C, int HID, int RB, int KC>
 __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
                                                           const float* __restrict__ b1img, const float* __restrict__ b2, const bf16* __restrict__ CTX,
-                                                          const int M, const int n_tiles) {
+                                                          const int M, const int n_tiles, const int skew_ticks) {
   constexpr int NCT = C / 32, NKS = C / 16, NCH = HID / 32;
   constexpr int PKS = KC / 16, PFR = PKS * NCT;          // proj: k-steps of 16 ctx channels, fragments in (k-step outer, c-tile inner) order
   constexpr int PSLOTS = (PFR + 31) / 32;                // ring slots of 32 fragments, the last one padded (its tail is never read)
   static_assert(KC % 16 == 0, "whole k-steps");
   constexpr int PPC = 2 * NKS / 32;                      // ring slots per hidden chunk: 1 (W1 | W2) or 2 (W1, W2)
   constexpr int BM = MR_NW * 32 * RB;                    // token rows per workgroup tile
-  constexpr int NACC = RB == 1 ? 2 : 1;                  // GEMM1 accumulators per row block (two independent MFMA chains per wave)
   constexpr int FD = MR_FD;
   static_assert(RB * NKS == 32 && (PPC == 1 || PPC == 2), "register budget: 128 x + 256 y VGPRs");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -169,12 +188,36 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
   for (int i = 0; i < MR_NST - 1; ++i) issue();
   int slot = 0;
   bool first = true;
-  auto ring_sync = [&]() {
+  auto ring_wait = [&]() {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // all but the newest slot image of this wave have landed: the image read after the NEXT barrier
+#if !(defined(MR_DIAG) && (MR_DIAG & 2))
     mr_bar();
+#endif
+  };
+  auto ring_sync = [&]() {
+    ring_wait();
     issue();
   };
+  // the same refill piece by piece (0..7 in order), each placed between MFMAs of the interval that follows ring_wait()
+  auto issue1 = [&](int piece) {
+    mr_dma1(voff + piece * 1024, wimg + (size_t)issue_img * MR_SLOT, lds0 + issue_slot * MR_SLOT + wave * 8192 + piece * 1024);
+    if (piece == 7) {
+      issue_img = issue_img == PSLOTS + NCH * PPC - 1 ? 0 : issue_img + 1;
+      issue_slot = issue_slot == MR_NST - 1 ? 0 : issue_slot + 1;
+    }
+  };
   auto next_slot = [&]() { slot = slot == MR_NST - 1 ? 0 : slot + 1; };
+
+  // Every workgroup walks equally long tiles, so left alone all 256 of them load their x rows (and store y) in the same few
+  // microseconds and then leave HBM idle for a whole tile: the memory phases add to the compute time instead of hiding behind other
+  // workgroups' MFMAs.  A one-time start offset proportional to blockIdx spreads the phases over skew_ticks (100 MHz ticks).
+#ifdef MR_CLK      // diagnostics (tools/build_variant.sh): achieved shader clock and MFMA share of this workgroup
+  const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_w0 = wall_clock64();
+#endif
+  if (skew_ticks > 0) {
+    const unsigned long long until = wall_clock64() + (unsigned long long)((long long)skew_ticks * blockIdx.x / gridDim.x);
+    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
+  }
 
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     // ---- this wave's 32 RB token rows -> registers (tail rows re-read the last valid row; their results are never stored)
@@ -262,81 +305,206 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) mfma32_a_zero(yacc[rb][ct]);
 
-#pragma unroll 1
-    for (int j = 0; j < NCH; ++j) {
-      ring_sync();
-      u32x4 fr[FD];
-      f32x16 hacc[RB][NACC];
-      // ---- GEMM1: hidden chunk j of this wave's tokens.  The NKS W1 fragments are read FD ahead of their MFMAs through a rotating
-      // register set (left alone hipcc reads every fragment into the same VGPRs right before its MFMA: full LDS latency each time).
-      {
-        const unsigned char* sp = smem + slot * MR_SLOT + lane * 16;
-#pragma unroll
-        for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + i * 1024);
-        const float* bp = b1tab + j * 32 + kh * 16;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 4 * g);
-#pragma unroll
-          for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              hacc[rb][0][4 * g + e] = b[e];
-              if (NACC == 2) hacc[rb][1][4 * g + e] = 0.0f;
-            }
-        }
-        // the bias reaches the accumulators through ds_read / v_mov: wait states VALU -> MFMA SrcC (hipcc's hazard recognizer does not
-        // look inside inline asm), accumulators threaded through so the moves cannot sink below
-        asm volatile("s_nop 7" : "+v"(hacc[0][0]), "+v"(hacc[RB - 1][NACC - 1]));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-#pragma unroll
-          for (int rb = 0; rb < RB; ++rb) mfma32_v(fr[s % FD], xr[rb][s], hacc[rb][s % NACC]);
-          if (s + FD < NKS) fr[s % FD] = *reinterpret_cast<const u32x4*>(sp + (s + FD) * 1024);
-          __builtin_amdgcn_sched_barrier(0);             // pin: MFMAs of step s, then the read FD ahead (the waitcnt pass then emits lgkmcnt(FD-1))
-        }
+    // ---- hidden chunks, software-pipelined inside the wave.  One wave per SIMD issues in order and MFMA shares its issue port with
+    // the VALU, so GEMM1 -> GELU -> GEMM2 run back to back left the matrix pipe idle through every GELU, every exposed LDS latency
+    // and every block of LDS-DMA issues.  Measured on gfx950 (tools/probes/mfma_valu_overlap.hip, mfma_chain.hip): behind one
+    // 32x32x16 MFMA (32 cycles) ~7 plain VALU issue slots are free (a transcendental takes two); PACKED fp32 (v_pk_*) does not
+    // overlap at all; a chain of dependent MFMAs on one accumulator issues at the full rate.  So body j of the chunk loop is 64 MFMA
+    // slots with the (scalar) GELU of chunk j sliced between them:
+    //     slots  0..31   GEMM2(j-1)   (B operands hp_prev; fragment-major, row blocks inner)
+    //     slots 32..63   GEMM1(j+1)   (one chain per row block, row block 0 first: its accumulator is free after slot 31, row
+    //                                  block 1's only after slot 47 - the GELU window is 48 slots at RB = 2)
+    // hacc(j) is read by the GELU micro-stages only before its chain is restarted; hp is double-buffered across bodies.  The weight
+    // stream is packed in exactly this order of 16 / 32-fragment groups:  W1(0) W1(1) | W2(0) W1(2) | W2(1) W1(3) | ... |
+    // W2(NCH-3) W1(NCH-1) | W2(NCH-2) W2(NCH-1)   (one ring slot per pair at C = 256, per group at C = 512).
+    f32x16 hacc[RB];
+    u32x4 hpA[RB][2], hpB[RB][2];
+    bool half = false;                                     // C = 256: which half of the current slot the next group sits in
+    auto begin_group = [&]() -> const unsigned char* {
+      unsigned a;
+      if (PPC == 2) {
+        ring_wait();
+        a = slot * MR_SLOT + lane * 16;
+        next_slot();
+      } else {
+        if (!half) ring_wait();
+        a = slot * MR_SLOT + (half ? NKS * 1024 : 0) + lane * 16;
+        if (half) next_slot();
+        half = !half;
       }
-      // wait states MFMA -> VALU; the accumulators are threaded through so that no GELU instruction can be scheduled above them
-      if constexpr (RB * NACC == 2)
-        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(hacc[0][0]), "+v"(hacc[RB - 1][NACC - 1]));
-      __builtin_amdgcn_sched_barrier(0);
-      if (PPC == 2) next_slot();
-      // ---- GELU, pack: the accumulator becomes GEMM2's B operand
-      u32x4 hp[RB][2];
+      // opaque: the unrolled loop walks the ring with a fixed period, and hipcc otherwise hoists one address VGPR per fragment
+      // beyond the 64 KB ds_read offset field (40 registers, spills); one base per group + immediate offsets is what is wanted
+      asm volatile("" : "+v"(a));
+      return smem + a;
+    };
+    // this group's share of the ring refill, called after every MFMA slot m (0..31) of a group: 4 (C = 256: half a slot image,
+    // `half` was already flipped by begin_group) or 8 (C = 512) single pieces, 8 / 4 MFMAs apart
+    auto refill = [&](int m) {
+      constexpr int EVERY = 32 / (4 * PPC);
+#if !(defined(MR_DIAG) && (MR_DIAG & 4))
+      if (m % EVERY == 1) issue1((PPC == 1 && !half ? 4 : 0) + m / EVERY);
+#endif
+    };
+    // conv1's bias = initial value of a chain, read from LDS straight into the accumulator registers a few slots ahead of the chain
+    auto bias_init = [&](int rb, int j) {
+      const float* bp = b1tab + j * 32 + kh * 16;
 #pragma unroll
-      for (int rb = 0; rb < RB; ++rb)
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 4 * g);
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float a0 = hacc[rb][0][8 * s2 + 2 * e], a1 = hacc[rb][0][8 * s2 + 2 * e + 1];
-            if (NACC == 2) { a0 += hacc[rb][1][8 * s2 + 2 * e]; a1 += hacc[rb][1][8 * s2 + 2 * e + 1]; }
-            const f32x2 gg = gelu_sig2(f32x2{a0, a1});
-            hp[rb][s2][e] = mr_pk2(gg[0], gg[1]);
-          }
-      if (PPC == 2) ring_sync();
-      // ---- GEMM2: all C output channels, K = this chunk's 32 hidden units; fragment order (s2 outer, ct inner) so that consecutive
-      // MFMAs hit different accumulators (the image order is [ct][s2])
-      {
-        const unsigned char* sp = smem + slot * MR_SLOT + (PPC == 2 ? 0 : NKS) * 1024 + lane * 16;
-        auto foff = [](int f) { return (2 * (f % NCT) + f / NCT) * 1024; };
-#pragma unroll
-        for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + foff(i));
-        if constexpr (RB == 2) asm volatile("s_nop 7" : "+v"(hp[0][0]), "+v"(hp[0][1]), "+v"(hp[1][0]), "+v"(hp[1][1]));   // VALU-written hp -> MFMA SrcB
-        else asm volatile("s_nop 7" : "+v"(hp[0][0]), "+v"(hp[0][1]));
+        for (int e = 0; e < 4; ++e) hacc[rb][4 * g + e] = b[e];
+      }
+    };
 
+    // GELU of the chunk in hacc as micro-stages per PAIR of hidden units (pair q = 8 rb + 4 s2 + e -> hp[rb][s2][e]); the
+    // schedule below keeps every dependent instruction at least one MFMA behind its producer.  The image carries W1 / 8, b1 / 8 and
+    // 8 W2 (exact in bf16), so hacc = h / 8 and min(h^2, 64) / 64 is ONE multiply with the clamp modifier; the polynomial's
+    // coefficients absorb the powers of two (every intermediate is the unscaled one times a power of two: results are bit-identical to
+    // gelu_sig) and the product h/8 * sigmoid is what 8 W2 expects.
+    constexpr int NP = RB * 8;
+    float gx[NP][2], gu[NP][2], ge[NP][2];
+    auto gA1 = [&](int q) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#ifdef MR_X2
+        asm volatile("v_mov_b32 %0, %1" : "=v"(gx[q][h]) : "v"(hacc[q >> 3][2 * (q & 7) + h]));
+#else
+        gx[q][h] = hacc[q >> 3][2 * (q & 7) + h];
+#endif
+#if defined(MR_DIAG) && (MR_DIAG & 1)
+        gu[q][h] = 0.f; continue;
+#endif
+        asm("v_mul_f32_e64 %0, %1, %1 clamp" : "=v"(gu[q][h]) : "v"(gx[q][h]));
+      }
+    };
+    auto gA2 = [&](int q) {
+#if defined(MR_DIAG) && (MR_DIAG & 1)
+      return;
+#endif
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float pp = fmaf(1.0153755e-3f * 32768.0f, gu[q][h], -1.0678257e-1f * 512.0f);
+        pp = fmaf(pp, gu[q][h], -2.3011138f * 8.0f);
+        gu[q][h] = gx[q][h] * pp;
+      }
+    };
+    auto gE = [&](int q) {
+#if defined(MR_DIAG) && (MR_DIAG & 1)
+      ge[q][0] = ge[q][1] = 1.0f; return;
+#endif
+#pragma unroll
+      for (int h = 0; h < 2; ++h) ge[q][h] = __builtin_amdgcn_exp2f(gu[q][h]);
+    };
+    auto gBa = [&](int q) {
+#if defined(MR_DIAG) && (MR_DIAG & 1)
+      return;
+#endif
+#pragma unroll
+      for (int h = 0; h < 2; ++h) ge[q][h] = 1.0f + ge[q][h];
+    };
+    auto gBr = [&](int q) {
+#if defined(MR_DIAG) && (MR_DIAG & 1)
+      return;
+#endif
+#pragma unroll
+      for (int h = 0; h < 2; ++h) ge[q][h] = __builtin_amdgcn_rcpf(ge[q][h]);
+    };
+    auto gC = [&](int q, u32x4 (&hp)[RB][2]) { hp[q >> 3][(q >> 2) & 1][q & 3] = mr_pk2(gx[q][0] * ge[q][0], gx[q][1] * ge[q][1]); };
+    // issue slots per MFMA:  RB = 2 (a pair every 3 slots): 7 / 7 / 7;   RB = 1 (a pair every 4 slots): 6 / 6 / 4 / 5
+    constexpr int CAD = RB == 2 ? 3 : 4;
+    constexpr int O_A2 = 1, O_E = 2, O_BA = RB == 2 ? 4 : 3, O_BR = RB == 2 ? 5 : 4, O_C = RB == 2 ? 6 : 7;
+    constexpr int G_LAST = CAD * (NP - 1) + O_C;          // slot of the last micro-stage
+    auto gelu_slot = [&](int m, u32x4 (&hp)[RB][2]) {
+      auto at = [&](int o) { return m >= o && (m - o) % CAD == 0 && (m - o) / CAD < NP; };
+      if (at(0)) gA1(m / CAD);
+      if (at(O_A2)) gA2((m - O_A2) / CAD);
+      if (at(O_E)) gE((m - O_E) / CAD);
+      if (at(O_BA)) gBa((m - O_BA) / CAD);
+      if (at(O_BR)) gBr((m - O_BR) / CAD);
+      if (at(O_C)) gC((m - O_C) / CAD, hp);
+    };
+    static_assert(G_LAST < 64, "the GELU fits in one body");
+
+    // One body.  G2: slots 0..31 carry GEMM2 of the previous chunk (B operands hp_prev);  G1: slots 32..63 carry GEMM1 of chunk jn;
+    // GE: the GELU of the chunk in hacc runs through the slots (-> hp_cur).
+    auto body = [&](auto g2_, auto ge_, auto g1_, const int jn, u32x4 (&hp_prev)[RB][2], u32x4 (&hp_cur)[RB][2]) {
+      constexpr bool G2 = decltype(g2_)::value, GE = decltype(ge_)::value, G1 = decltype(g1_)::value;
+      auto foff2 = [](int f) { return (2 * (f % NCT) + f / NCT) * 1024; };       // image order [ct][s2], consumption (s2 outer, ct inner)
+      auto foff1 = [](int i) { return (RB == 2 ? i % NKS : i) * 1024; };         // RB = 2: the NKS fragments once per row block
+      u32x4 fr[FD];
+      if (G2) {
+        const unsigned char* sp = begin_group();
+#pragma unroll
+        for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + foff2(i));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int f = 0; f < 2 * NCT; ++f) {
-#pragma unroll
-          for (int rb = 0; rb < RB; ++rb) mfma32_a(fr[f % FD], hp[rb][f / NCT], yacc[rb][f % NCT]);
-          if (f + FD < 2 * NCT) fr[f % FD] = *reinterpret_cast<const u32x4*>(sp + foff(f + FD));
+        for (int m = 0; m < 32; ++m) {
+          const int f = m / RB, rb = m % RB;
+          mfma32_a(fr[f % FD], hp_prev[rb][f / NCT], yacc[rb][f % NCT]);
+#if !(defined(MR_DIAG) && (MR_DIAG & 8))
+          if (rb == RB - 1 && f + FD < NKS) fr[f % FD] = *reinterpret_cast<const u32x4*>(sp + foff2(f + FD));
+#endif
+          refill(m);
+          // wait states MFMA (last of GEMM1) -> VALU read of hacc, spent behind the MFMA just issued; the accumulators are threaded
+          // through so that no GELU instruction can be scheduled above
+          if (m == 0 && GE) {
+            if constexpr (RB == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(hacc[0]), "+v"(hacc[RB - 1]));
+            else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(hacc[0]));
+          }
+          if (GE) gelu_slot(m, hp_cur);
+#ifdef MR_X1
+          if (G1 && m == 31) bias_init(0, jn);
+#else
+          if (G1 && m == 28) bias_init(0, jn);
+#endif              // after the GELU's last direct read of row block 0's accumulator
           __builtin_amdgcn_sched_barrier(0);
         }
+      } else if (GE) {                                     // body 0: the GELU of chunk 0 on its own
+        if constexpr (RB == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(hacc[0]), "+v"(hacc[RB - 1]));
+        else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(hacc[0]));
+#pragma unroll
+        for (int m = 0; m < 32; ++m) gelu_slot(m, hp_cur);
+        if (G1) bias_init(0, jn);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      next_slot();
+      if (G1) {
+        const unsigned char* sp = begin_group();
+#pragma unroll
+        for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + foff1(i));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          const int rb = RB == 2 ? i / NKS : 0, s = RB == 2 ? i % NKS : i;
+          mfma32_v(fr[i % FD], xr[rb][s], hacc[rb]);
+#if !(defined(MR_DIAG) && (MR_DIAG & 8))
+          if (i + FD < 32) fr[i % FD] = *reinterpret_cast<const u32x4*>(sp + foff1(i + FD));
+#endif
+          refill(i);
+          if (GE) gelu_slot(32 + i, hp_cur);
+          if (RB == 2 && i == NKS - 2) bias_init(1, jn);        // after the last GELU read of row block 1's accumulator (slot 45)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if (GE) {                                     // last body: the tail of the GELU on its own
+#pragma unroll
+        for (int m = 32; m <= G_LAST; ++m) gelu_slot(m, hp_cur);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    using yes_t = std::integral_constant<bool, true>;
+    using no_t = std::integral_constant<bool, false>;
+
+    bias_init(0, 0);
+    body(no_t{}, no_t{}, yes_t{}, 0, hpA, hpA);            // GEMM1(0)   (the chain of row block 1 starts from bias_init inside)
+    body(no_t{}, yes_t{}, yes_t{}, 1, hpB, hpA);           // body 0:    GELU(0) | GEMM1(1)
+#pragma unroll 1
+    for (int j = 1; j < NCH - 1; j += 2) {
+      body(yes_t{}, yes_t{}, yes_t{}, j + 1, hpA, hpB);    // body j (odd):  GEMM2(j-1) | GELU(j) | GEMM1(j+1)
+      body(yes_t{}, yes_t{}, yes_t{}, j + 2, hpB, hpA);    // body j + 1
     }
+    body(yes_t{}, yes_t{}, no_t{}, 0, hpA, hpB);           // body NCH-1: GEMM2(NCH-2) | GELU(NCH-1)
+    if constexpr (RB == 2) asm volatile("s_nop 7" : "+v"(hpB[0][0]), "+v"(hpB[0][1]), "+v"(hpB[1][0]), "+v"(hpB[1][1]));   // VALU-written hp -> MFMA SrcB
+    else asm volatile("s_nop 7" : "+v"(hpB[0][0]), "+v"(hpB[0][1]));
+    body(yes_t{}, no_t{}, no_t{}, 0, hpB, hpB);            // GEMM2(NCH-1)
 
     {   // wait states MFMA -> v_accvgpr_read, accumulators threaded through
       f32x16* yf = &yacc[0][0];
@@ -365,6 +533,13 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
       }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may be in flight into the LDS of a finished workgroup
+#ifdef MR_CLK
+  if (t == 0 && (blockIdx.x % 37 == 0 || blockIdx.x == 255)) {
+    const unsigned long long dc = __builtin_readcyclecounter() - clk_c0, w1 = wall_clock64();
+    printf("[mlp_rows C=%d wg %3d] start %llu end %llu (x10ns)  %.1f us  %.0f MHz\n", C, (int)blockIdx.x, clk_w0 % 10000000ull, w1 % 10000000ull,
+           (w1 - clk_w0) / 100.0, dc / ((w1 - clk_w0) / 100.0));
+  }
+#endif
 }
 
 // Builds the fragment-major weight image + bias table from the engine's standard packed layers (w1 [HID][k1w], w2 [C][k2w], optional
@@ -378,7 +553,7 @@ __global__ void mlp_pack_kernel(const bf16* __restrict__ w1, int k1w, const floa
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < HID) {
     const int j = (int)idx >> 5, w = (int)idx & 31, kh = w >> 4, i = w & 15;
-    b1img[idx] = b1 ? b1[j * 32 + 8 * (i >> 2) + 4 * kh + (i & 3)] : 0.0f;
+    b1img[idx] = b1 ? 0.125f * b1[j * 32 + 8 * (i >> 2) + 4 * kh + (i & 3)] : 0.0f;      // conv1 is carried at 1/8 scale (GELU clamp trick)
   }
   if (idx >= proj_elems + (long)NCH * per_chunk) return;
   bf16 v;
@@ -392,17 +567,22 @@ __global__ void mlp_pack_kernel(const bf16* __restrict__ w1, int k1w, const floa
     return;
   }
   const long ii = idx - proj_elems;
-  const int j = (int)(ii / per_chunk), e = (int)(ii % per_chunk);
-  const int piece = e >> 9, lane = (e >> 3) & 63, e8 = e & 7;
+  // the stream is a sequence of 2 NCH groups of NKS fragments in the order the pipelined chunk loop consumes them:
+  //   W1(0) W1(1) | W2(0) W1(2) | W2(1) W1(3) | ... | W2(NCH-3) W1(NCH-1) | W2(NCH-2) W2(NCH-1)
+  const int e = (int)(ii % per_chunk);
+  const int grp = 2 * (int)(ii / per_chunk) + ((e >> 9) >= NKS ? 1 : 0);
+  const bool is_w2 = grp >= 2 && (grp == 2 * NCH - 1 || (grp & 1) == 0);
+  const int j = grp < 2 ? grp : grp == 2 * NCH - 1 ? NCH - 1 : is_w2 ? grp / 2 - 1 : (grp + 1) / 2;
+  const int piece = (e >> 9) % NKS, lane = (e >> 3) & 63, e8 = e & 7;
   const int kh = lane >> 5, r = lane & 31;
-  if (piece < NKS) {
+  if (!is_w2) {
     const int s = piece;
-    v = w1[(size_t)(j * 32 + r) * k1w + 32 * (s >> 1) + 16 * kh + 8 * (s & 1) + e8];
+    v = (bf16)(0.125f * (float)w1[(size_t)(j * 32 + r) * k1w + 32 * (s >> 1) + 16 * kh + 8 * (s & 1) + e8]);      // exact: a power of two
   } else {
-    const int q = piece - NKS, ct = q >> 1, s2 = q & 1;
+    const int q = piece, ct = q >> 1, s2 = q & 1;
     const int c = 32 * ct + 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
     const int n = j * 32 + 8 * (2 * s2 + (e8 >> 2)) + 4 * kh + (e8 & 3);
-    v = w2[(size_t)c * k2w + n];
+    v = (bf16)(8.0f * (float)w2[(size_t)c * k2w + n]);
   }
   wimg[idx] = v;
 }
@@ -443,8 +623,9 @@ static int launch_mlp_rows_t(const void* x, void* y, const void* wimg, const flo
   constexpr int BM = MR_NW * 32 * RB;
   const int n_tiles = (M + BM - 1) / BM;
   const int grid = n_tiles < 256 ? n_tiles : 256;
+  static const int skew_us = [] { const char* e = getenv("FSVIT_MLP_SKEW_US"); return e ? atoi(e) : 0; }();
   hipLaunchKernelGGL(kern, dim3(grid), dim3(MR_NW * 64), lds, s, (const bf16*)x, (bf16*)y, (const unsigned char*)wimg, b1img, b2, (const bf16*)ctx, M,
-                     n_tiles);
+                     n_tiles, n_tiles > grid ? skew_us * 100 : 0);
   return (int)hipGetLastError();
 }
 

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Runs the fused row Mlp (mlp_rows.hip) on the stage-2 shape a few times (for rocprofv3 --pmc passes)."""
+"""Runs the fused row Mlp (mlp_rows.hip) on the stage-2 (default) or stage-3 shape a few times (for rocprofv3 --pmc passes):
+   python3 tools/pmc_mlp.py [launches] [2|3]"""
 import sys, os, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fewshot_vit_amd import _lib
 from fewshot_vit_amd.engine import _ptr, _stream_ptr
 
-M, C, HID = 320000, 256, 1024
+M, C, HID = (160000, 512, 2048) if len(sys.argv) > 2 and sys.argv[2] == '3' else (320000, 256, 1024)
 x = torch.randn(M, C, device='cuda').bfloat16()
 w1 = (torch.randn(HID, C, device='cuda') / math.sqrt(C)).bfloat16()
 w2 = (torch.randn(C, HID, device='cuda') / math.sqrt(HID)).bfloat16()
