@@ -20,17 +20,24 @@
 //     per 32-channel tile: 16-byte loads and stores, and the residual comes from the very registers that fed GEMM1;
 //   * the weight stream is periodic (1 / 4 MB per tile), so one ring of four 32 KB LDS slots (32 fragments each: a whole chunk
 //     at C = 256, its W1 / W2 half at C = 512) with counted vmcnt runs across the tiles of the persistent workgroup; the
-//     only workgroup-wide synchronisation is the ring's barrier (one per slot); waves never exchange data.
+//     only workgroup-wide synchronisation is the ring's barrier (one per slot); waves never exchange data;
+//   * the chunk loop is software-pipelined INSIDE the wave (one wave per SIMD issues in order): body j = GEMM2(j-1)'s MFMAs, then
+//     GEMM1(j+1)'s, with the scalar GELU of chunk j cut into micro-stages that issue behind those MFMAs, the ring refill going out
+//     one LDS-DMA piece at a time between them, and the weight image packed in that consumption order (see the loop's comment).
+//     The image carries W1 / 8, b1 / 8 and 8 W2 (exact in bf16): min(h^2, 64) / 64 becomes one multiply with the clamp modifier.
 // Layout contract with the pack kernel (lane = 32 * kh + r):
 //   x regs   xr[s], s < C/16     : token r, channels 32 (s/2) + 16 kh + 8 (s&1) + 0..7
 //   W1 frag  (chunk j, step s)   : hidden unit 32 j + r, the same 8 channels
-//   hacc[i], i = 4 g + e         : hidden unit 32 j + 8 g + 4 kh + e of token r          (32x32 MFMA C/D layout)
-//   hp[s2]                       : hacc[8 s2 .. 8 s2 + 8) packed to bf16
+//   hacc[i], i = 4 g + e         : hidden unit 32 j + 8 g + 4 kh + e of token r, at 1/8 scale   (32x32 MFMA C/D layout)
+//   hp[s2]                       : GELU(hacc[8 s2 .. 8 s2 + 8)) / 8 packed to bf16
 //   W2 frag  (j, ct, s2)         : output channel 32 ct + 16 (r>>2 & 1) + 4 (r>>3) + (r&3), hidden units as hp[s2] of lane kh
 //   yacc[ct][i]                  : channel 32 ct + 16 kh + i of token r
 // History: the first version ran 8 waves x 32 rows (two waves per SIMD, 256 registers each) at C = 256 only:
 // 757 TFLOP/s; PMC showed MFMA 34 % and VALU 32 % busy with no overlap, and neither a phase shift between SIMD partners, deeper
-// fragment read-ahead nor MFMA reordering moved it.
+// fragment read-ahead nor MFMA reordering moved it.  The second ran GEMM1 -> GELU -> GEMM2 back to back per chunk (846 / 665 us per
+// launch at the bench shapes of stage 2 / 3); the pipelined loop measures 793 / 621 us.
+// Diagnostics (never in the shipped build; tools/build_variant.sh): -DMR_CLK prints per-workgroup time and achieved shader clock,
+// -DMR_DIAG=<bits> drops one cost at a time for timing (1 GELU, 2 ring barrier, 4 refill, 8 in-loop fragment reads) - wrong results.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -146,7 +153,7 @@ __device__ __forceinline__ void mfma32_a_zero(f32x16& c) {
 template <int C, int HID, int RB, int KC>
 __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
                                                           const float* __restrict__ b1img, const float* __restrict__ b2, const bf16* __restrict__ CTX,
-                                                          const int M, const int n_tiles, const int skew_ticks) {
+                                                          const int M, const int n_tiles) {
   constexpr int NCT = C / 32, NKS = C / 16, NCH = HID / 32;
   constexpr int PKS = KC / 16, PFR = PKS * NCT;          // proj: k-steps of 16 ctx channels, fragments in (k-step outer, c-tile inner) order
   constexpr int PSLOTS = (PFR + 31) / 32;                // ring slots of 32 fragments, the last one padded (its tail is never read)
@@ -208,17 +215,9 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
   };
   auto next_slot = [&]() { slot = slot == MR_NST - 1 ? 0 : slot + 1; };
 
-  // Every workgroup walks equally long tiles, so left alone all 256 of them load their x rows (and store y) in the same few
-  // microseconds and then leave HBM idle for a whole tile: the memory phases add to the compute time instead of hiding behind other
-  // workgroups' MFMAs.  A one-time start offset proportional to blockIdx spreads the phases over skew_ticks (100 MHz ticks).
-#ifdef MR_CLK      // diagnostics (tools/build_variant.sh): achieved shader clock and MFMA share of this workgroup
+#ifdef MR_CLK
   const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_w0 = wall_clock64();
 #endif
-  if (skew_ticks > 0) {
-    const unsigned long long until = wall_clock64() + (unsigned long long)((long long)skew_ticks * blockIdx.x / gridDim.x);
-    while (wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
-  }
-
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     // ---- this wave's 32 RB token rows -> registers (tail rows re-read the last valid row; their results are never stored)
     bool mok[RB];
@@ -366,11 +365,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
     auto gA1 = [&](int q) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-#ifdef MR_X2
-        asm volatile("v_mov_b32 %0, %1" : "=v"(gx[q][h]) : "v"(hacc[q >> 3][2 * (q & 7) + h]));
-#else
         gx[q][h] = hacc[q >> 3][2 * (q & 7) + h];
-#endif
 #if defined(MR_DIAG) && (MR_DIAG & 1)
         gu[q][h] = 0.f; continue;
 #endif
@@ -410,18 +405,25 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
       for (int h = 0; h < 2; ++h) ge[q][h] = __builtin_amdgcn_rcpf(ge[q][h]);
     };
     auto gC = [&](int q, u32x4 (&hp)[RB][2]) { hp[q >> 3][(q >> 2) & 1][q & 3] = mr_pk2(gx[q][0] * ge[q][0], gx[q][1] * ge[q][1]); };
-    // issue slots per MFMA:  RB = 2 (a pair every 3 slots): 7 / 7 / 7;   RB = 1 (a pair every 4 slots): 6 / 6 / 4 / 5
-    constexpr int CAD = RB == 2 ? 3 : 4;
+    // Pair q starts at slot st(q) = q CAD2 / 2:  RB = 2: a pair every 3.5 slots (6 issue slots per MFMA), RB = 1: every 4 (6 / 6 / 4 / 5).
+    // Seven per MFMA already stretch the MFMA slot by ~20 % (mfma_valu_overlap probe); six cost ~10 %.  The stage that reads the
+    // accumulator (A1) may not slip behind the restart of its chain (slot 28 for row block 0, 46 for row block 1): the last pairs of
+    // row block 1 run A1 early and carry (x, u) in registers.
+    constexpr int CAD2 = RB == 2 ? 7 : 8;
     constexpr int O_A2 = 1, O_E = 2, O_BA = RB == 2 ? 4 : 3, O_BR = RB == 2 ? 5 : 4, O_C = RB == 2 ? 6 : 7;
-    constexpr int G_LAST = CAD * (NP - 1) + O_C;          // slot of the last micro-stage
+    auto st = [](int q) { return q * CAD2 / 2; };
+    auto st_a1 = [&](int q) { const int lim = 45 - (NP - 1 - q); return RB == 2 && q >= 8 && st(q) > lim ? lim : st(q); };
+    constexpr int G_LAST = (NP - 1) * CAD2 / 2 + O_C;     // slot of the last micro-stage
     auto gelu_slot = [&](int m, u32x4 (&hp)[RB][2]) {
-      auto at = [&](int o) { return m >= o && (m - o) % CAD == 0 && (m - o) / CAD < NP; };
-      if (at(0)) gA1(m / CAD);
-      if (at(O_A2)) gA2((m - O_A2) / CAD);
-      if (at(O_E)) gE((m - O_E) / CAD);
-      if (at(O_BA)) gBa((m - O_BA) / CAD);
-      if (at(O_BR)) gBr((m - O_BR) / CAD);
-      if (at(O_C)) gC((m - O_C) / CAD, hp);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        if (m == st_a1(q)) gA1(q);
+        if (m == st(q) + O_A2) gA2(q);
+        if (m == st(q) + O_E) gE(q);
+        if (m == st(q) + O_BA) gBa(q);
+        if (m == st(q) + O_BR) gBr(q);
+        if (m == st(q) + O_C) gC(q, hp);
+      }
     };
     static_assert(G_LAST < 64, "the GELU fits in one body");
 
@@ -452,11 +454,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
             else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(hacc[0]));
           }
           if (GE) gelu_slot(m, hp_cur);
-#ifdef MR_X1
-          if (G1 && m == 31) bias_init(0, jn);
-#else
-          if (G1 && m == 28) bias_init(0, jn);
-#endif              // after the GELU's last direct read of row block 0's accumulator
+          if (G1 && m == 28) bias_init(0, jn);              // after the GELU's last direct read of row block 0's accumulator              // after the GELU's last direct read of row block 0's accumulator
           __builtin_amdgcn_sched_barrier(0);
         }
       } else if (GE) {                                     // body 0: the GELU of chunk 0 on its own
@@ -623,9 +621,8 @@ static int launch_mlp_rows_t(const void* x, void* y, const void* wimg, const flo
   constexpr int BM = MR_NW * 32 * RB;
   const int n_tiles = (M + BM - 1) / BM;
   const int grid = n_tiles < 256 ? n_tiles : 256;
-  static const int skew_us = [] { const char* e = getenv("FSVIT_MLP_SKEW_US"); return e ? atoi(e) : 0; }();
   hipLaunchKernelGGL(kern, dim3(grid), dim3(MR_NW * 64), lds, s, (const bf16*)x, (bf16*)y, (const unsigned char*)wimg, b1img, b2, (const bf16*)ctx, M,
-                     n_tiles, n_tiles > grid ? skew_us * 100 : 0);
+                     n_tiles);
   return (int)hipGetLastError();
 }
 

@@ -19,6 +19,13 @@
 #include "fsvit_common.h"
 #include "kernels.h"
 
+// GELU of a register pair: packed (gelu_sig2) or two scalar gelu_sig (-DS1_SCALAR_GELU: packed fp32 does not issue behind MFMAs)
+#ifdef S1_SCALAR_GELU
+#define S1_GELU2(v) (f32x2{gelu_sig((v)[0]), gelu_sig((v)[1])})
+#else
+#define S1_GELU2(v) gelu_sig2(v)
+#endif
+
 namespace fsvit {
 
 namespace s1 {
@@ -151,13 +158,13 @@ __global__ __launch_bounds__(1024) void stage1_block_kernel(const bf16* __restri
       const int pr = tk / W, pc = tk - pr * W;
       const int pix = (pr + (hsel ? 0 : 1)) * PW + pc + 1;
       a += bias;
-      const f32x2 g0 = gelu_sig2(f32x2{a[0], a[1]}), g1 = gelu_sig2(f32x2{a[2], a[3]});
+      const f32x2 g0 = S1_GELU2((f32x2{a[0], a[1]})), g1 = S1_GELU2((f32x2{a[2], a[3]}));
       const bf16x4 o = {(bf16)g0[0], (bf16)g0[1], (bf16)g1[0], (bf16)g1[1]};
       *reinterpret_cast<bf16x4*>(H1 + (nt * 2 + (lq >> 1)) * H1_PLANE + pix * 16 + (lq & 1) * 8) = o;
     }
   };
   auto h2_store = [&](int mt, f32x4 a) {
-    const f32x2 g0 = gelu_sig2(f32x2{a[0], a[1]}), g1 = gelu_sig2(f32x2{a[2], a[3]});
+    const f32x2 g0 = S1_GELU2((f32x2{a[0], a[1]})), g1 = S1_GELU2((f32x2{a[2], a[3]}));
     const bf16x4 o = {(bf16)g0[0], (bf16)g0[1], (bf16)g1[0], (bf16)g1[1]};
     *reinterpret_cast<bf16x4*>(H2 + (nt * 2 + (lq >> 1)) * H2_PLANE + (mt * 16 + lrow) * 16 + (lq & 1) * 8) = o;
   };

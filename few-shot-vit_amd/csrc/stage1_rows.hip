@@ -26,6 +26,13 @@
 #include "fsvit_common.h"
 #include "kernels.h"
 
+// GELU of a register pair: packed (gelu_sig2) or two scalar gelu_sig (-DS1_SCALAR_GELU: packed fp32 does not issue behind MFMAs)
+#ifdef S1_SCALAR_GELU
+#define S1_GELU2(v) (f32x2{gelu_sig((v)[0]), gelu_sig((v)[1])})
+#else
+#define S1_GELU2(v) gelu_sig2(v)
+#endif
+
 namespace fsvit {
 
 typedef __attribute__((address_space(3))) void* lptrs_t;
@@ -41,7 +48,7 @@ constexpr int OTOK = BAND * W;                        // 80 output tokens
 constexpr int MT1 = (RT + 15) / 16, MT2 = (OTOK + 15) / 16;   // m-tiles of 16 tokens: conv1, conv2 / conv3
 constexpr int PW = W + 2;                             // zero-bordered H1 grid is 6 x 22 pixels
 constexpr int PLANE = ((BAND + 2) * PW * 16 + 255) / 256 * 256;   // pixels x 16 B, rounded so that the plane stride is 0 mod 256 B
-constexpr int NFRAG = 34, SLOT = 36 * 1024;           // 8 (W1) + 18 (W2) + 8 (W3) fragments, padded to 9 KiB per wave
+constexpr int SLOT = 36 * 1024;                      // 8 (W1) + 18 (W2) + 8 (W3) fragments, padded to 9 KiB per wave
 constexpr int NW = BAND == 4 ? 4 : 8;                  // band 4: one wave per SIMD (512 registers); band 2: two per SIMD (256)
 constexpr int NST = BAND == 4 ? 3 : 2;                // ring slots
 constexpr int OFF_H1 = NST * SLOT;                    // 110592
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(s1r::NW * 64, s1r::NW / 4) void stage1_rows_kernel(
       // read the register).  sched_barrier(0) pins each (MFMAs, VALU slice, reads) group in source order.
       auto h1_store = [&](int nt, int t8, const f32x4& a) {
         // lane holds channels 16 nt + 4 q .. +3 of token (t8, m): plane 2 nt + q / 2, bytes (q & 1) * 8 of the pixel's 16-byte slot
-        const f32x2 g0 = gelu_sig2(f32x2{a[0], a[1]}), g1 = gelu_sig2(f32x2{a[2], a[3]});
+        const f32x2 g0 = S1_GELU2((f32x2{a[0], a[1]})), g1 = S1_GELU2((f32x2{a[2], a[3]}));
         u32x2 o;
         o[0] = s1r_pk2(g0[0], g0[1]);
         o[1] = s1r_pk2(g1[0], g1[1]);
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(s1r::NW * 64, s1r::NW / 4) void stage1_rows_kernel(
           if (tap + FD < 9) fr[fi] = *reinterpret_cast<const u32x4*>(sp + (8 + 2 * (tap + FD) + 1) * 1024);
           if ((tap & 1) == 0 && tap / 2 < MT2) {
             const int t5 = tap / 2;
-            const f32x2 g0 = gelu_sig2(f32x2{acc0[t5][0], acc0[t5][1]}), g1 = gelu_sig2(f32x2{acc0[t5][2], acc0[t5][3]});
+            const f32x2 g0 = S1_GELU2((f32x2{acc0[t5][0], acc0[t5][1]})), g1 = S1_GELU2((f32x2{acc0[t5][2], acc0[t5][3]}));
             hp[t5][0] = s1r_pk2(g0[0], g0[1]);
             hp[t5][1] = s1r_pk2(g1[0], g1[1]);
           }
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(s1r::NW * 64, s1r::NW / 4) void stage1_rows_kernel(
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t5 = 0; t5 < MT2; ++t5) {
-          const f32x2 g0 = gelu_sig2(f32x2{acc1[t5][0], acc1[t5][1]}), g1 = gelu_sig2(f32x2{acc1[t5][2], acc1[t5][3]});
+          const f32x2 g0 = S1_GELU2((f32x2{acc1[t5][0], acc1[t5][1]})), g1 = S1_GELU2((f32x2{acc1[t5][2], acc1[t5][3]}));
           hp[t5][2] = s1r_pk2(g0[0], g0[1]);
           hp[t5][3] = s1r_pk2(g1[0], g1[1]);
         }

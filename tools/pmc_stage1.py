@@ -3,6 +3,8 @@
 import sys, os, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from fewshot_vit_amd import _lib
+if len(sys.argv) > 2: _lib.LIB_PATH = os.path.abspath(sys.argv[2])
 from fewshot_vit_amd.engine import ops
 from bench_ops import pack_w
 bf = torch.bfloat16
@@ -10,6 +12,6 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 3200
 x = torch.randn(B, 20, 20, 128, device='cuda').to(bf)
 w1 = pack_w(256, 128, 1, 1, bf)[0]; w2 = pack_w(256, 32, 3, 8, bf); w3 = pack_w(128, 256, 1, 1, bf)[0]
 b1 = torch.randn(256, device='cuda')
-for _ in range(3):
+for _ in range(8):
     ops.stage1_block(x, w1, b1, w2, w3)
 torch.cuda.synchronize()
