@@ -76,6 +76,7 @@ SIGNATURES = {
     'fsvit_proj_mlp_rows': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _fp, _vp, _i, _fp, _i, _i, _i, _vp]),
     'fsvit_mlp_rows': (_i, [_vp, _vp, _vp, _i, _fp, _vp, _i, _fp, _i, _i, _i, _vp]),
     'fsvit_attention': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    'fsvit_qkv_attention': (_i, [_vp, _vp, _i, _fp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'fsvit_im2col27': (_i, [_fp, _vp, _i, _i, _i, _i, _vp]),
     'fsvit_maxpool2_pos': (_i, [_vp, _fp, _vp, _i, _i, _i, _i, _i, _vp]),
     'fsvit_pool_affine': (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),

@@ -315,7 +315,7 @@ int attention_padded_head_dim(int hd, int S, int dtype) {
 
 int launch_attention(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, hipStream_t s) {
   if (B <= 0) return 0;
-  const int es = dtype == 0 ? 4 : 2;
+
   if (S < 1 || hdp % 16 != 0) return (int)hipErrorInvalidValue;
   {
     const int rc = launch_attention_v2(qkv, ctx, B, S, heads, hdp, scale, dtype, s);

@@ -81,6 +81,7 @@ struct BlockA {
   void* mlp_img = nullptr;     // mlp_rows.hip: fragment-major image of [proj |] fc1 + fc2 (null: the GEMM launches are used)
   float* mlp_b1 = nullptr;
   int mlp_kc = 0;              // > 0: the image starts with the proj fragments and mlp_rows also computes x += proj(ctx)
+  void* qa_img = nullptr;      // qkv_attn.hip: fragment-major image of the qkv conv (null: qkv GEMM + attention launches)
 };
 
 struct Tap { void* dst; size_t bytes; };
@@ -367,6 +368,14 @@ int build(fsvit_visformer* h, const SD& sd) {
         blocks[i].mlp_b1 = (float*)b1i;
         blocks[i].mlp_kc = kc;
       }
+      if (qkv_attn_supported(h->dtype, C, heads, hdp, (s == 2 ? h->H2 : h->H3) * (s == 2 ? h->H2 : h->H3))) {   // fused qkv conv + attention: re-pack qkv as the MFMA fragment stream
+        void* img = nullptr;
+        HIP_TRY(hipMalloc(&img, qkv_attn_image_bytes()));
+        h->allocs.push_back(img);
+        RC_TRY(launch_qkv_attn_pack(blocks[i].qkv.w, blocks[i].qkv.Kw, img, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        blocks[i].qa_img = img;
+      }
     }
   }
   // ---- final BN -> pooled feature affine (visformer.py:455-462)
@@ -453,7 +462,7 @@ int tap(EngineBase* h, const std::string& name, const void* src, size_t bytes, b
 }
 
 // kernel ids reported by the profiler (names in fsvit_kernel_name)
-enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_STAGE1R = 14 };
+enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_STAGE1R = 14, KID_QKVATTN = 15 };
 
 
 // Runs one launch; in profiling mode brackets it with HIP events on the same stream.
@@ -554,9 +563,14 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
     const int S = Ho * Ho;
     for (size_t i = 0; i < blocks.size(); ++i) {
       const BlockA& b = blocks[i];
+      if (b.qa_img) {     // qkv conv + attention core in one launch: q / k / v never leave the chip
+        RC_TRY(timed(h, st, (sp + ".attn.qkv+core").c_str(), KID_QKVATTN, 2.0 * Bc * S * (3.0 * heads * hd) * C + 4.0 * Bc * heads * (double)S * S * hd,
+                     [&]() { return launch_qkv_attn(xs, ctx, b.qa_img, b.qkv.bias, Bc, S, scale, st); }));
+      } else {
       RC_TRY(run_gemm(h, st, (sp + ".attn.qkv").c_str(), b.qkv, conv_params(b.qkv, xs, qkv, Bc, Ho, Ho, C, C, 1, 1, 1, 0, 3 * heads * hdp, ACT_NONE, nullptr, 0, nullptr), 3.0 * heads * hd, C));
       RC_TRY(timed(h, st, (sp + ".attn.core").c_str(), KID_ATTN, 4.0 * Bc * heads * (double)S * S * hd,
                    [&]() { return launch_attention(qkv, ctx, Bc, S, heads, hdp, scale, dt, st); }));
+      }
       if (b.mlp_img && b.mlp_kc) {   // proj + residual + conv1 + GELU + conv3 + residual in one launch
         RC_TRY(timed(h, st, (sp + ".proj+mlp").c_str(), KID_MLPROWS, 2.0 * Bc * S * ((double)C * heads * hd + 2.0 * hidc * C),
                      [&]() { return launch_mlp_rows(xs, xs, b.mlp_img, b.mlp_b1, b.fc2.bias, ctx, b.mlp_kc, Bc * S, C, hidc, st); }));
@@ -785,6 +799,22 @@ extern "C" int fsvit_adamw_step(float* p, const float* g, float* m, float* v, si
   return 0;
 }
 
+extern "C" int fsvit_qkv_attention(const void* x, const void* wqkv, int kw, const float* bias, void* ctx, int B, int S, int C, int heads, int hdp,
+                                   float scale, void* stream) {
+  if (!x || !wqkv || !ctx) return fail(FSVIT_ERR_ARG, "null argument");
+  if (!qkv_attn_supported(FSVIT_BF16, C, heads, hdp, S) || kw < C)
+    return fail(FSVIT_ERR_ARG, "fsvit_qkv_attention: only C = 256, 6 heads x 48 (padded), S <= 128 (bf16) is built");
+  hipStream_t st = (hipStream_t)stream;
+  void* img = nullptr;
+  HIP_TRY(hipMalloc(&img, qkv_attn_image_bytes()));
+  int rc = launch_qkv_attn_pack(wqkv, kw, img, st);
+  if (rc == 0) rc = launch_qkv_attn(x, ctx, img, bias, B, S, scale, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(img);
+  if (rc != 0) return hipfail((hipError_t)rc, "fsvit_qkv_attention");
+  return 0;
+}
+
 extern "C" int fsvit_attention(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, void* stream) {
   if (!qkv || !ctx) return fail(FSVIT_ERR_ARG, "null argument");
   int rc = launch_attention(qkv, ctx, B, S, heads, hdp, scale, dtype, (hipStream_t)stream);
@@ -815,11 +845,11 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
   static const char* f32n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
                                "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<float,128,128,2,2,2>",
-                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel", "stage1_rows_kernel"};
+                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel", "stage1_rows_kernel", "qkv_attn_kernel"};
   static const char* bf16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
                                 "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<__bf16,128,128,2,2,2>",
-                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "stage1_rows_kernel"};
-  if (kernel_id < 0 || kernel_id > 14) return "?";
+                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "stage1_rows_kernel", "qkv_attn_kernel"};
+  if (kernel_id < 0 || kernel_id > 15) return "?";
   return dtype == FSVIT_F32 ? f32n[kernel_id] : bf16n[kernel_id];
 }
 

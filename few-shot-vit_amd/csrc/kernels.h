@@ -41,6 +41,13 @@ int launch_mlp_pack(const void* w1, int k1w, const float* b1, const void* w2, in
 int launch_mlp_rows(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, const void* ctx, int KC, int M, int C, int hid,
                     hipStream_t s);
 
+// fused qkv conv + attention core of the Visformer stage-2 block (qkv_attn.hip; bf16, C = 256, 6 heads x 48, S <= 128): ctx rows
+// [B*S][heads*hdp] from x rows [B*S][C]; wimg is built once by launch_qkv_attn_pack from the packed qkv layer (w [3*heads*hdp][kw])
+bool qkv_attn_supported(int dtype, int C, int heads, int hdp, int S);
+size_t qkv_attn_image_bytes();
+int launch_qkv_attn_pack(const void* w, int kw, void* img, hipStream_t s);
+int launch_qkv_attn(const void* x, void* ctx, const void* wimg, const float* bias, int B, int S, float scale, hipStream_t s);
+
 // distillation head (token_label.hip; fp32): LinearClassifier forward / backward, generate_softlabel, SoftTargetCrossEntropy, AdamW
 int launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, hipStream_t s);
 int launch_linear_bwd(const float* dy, const float* x, const float* w, float* dx, int accumulate_dx, float* dw, float* db, int M, int N, int K, hipStream_t s);

@@ -411,6 +411,17 @@ class ops:
         return ctx
 
     @staticmethod
+    def qkv_attention(x, wqkv, bias, B, S, heads, hdp, scale):
+        """Fused qkv conv + attention core (qkv_attn.hip): x [B*S, C] bf16, wqkv [3*heads*hdp, kw] bf16 -> ctx [B*S, heads*hdp]."""
+        _require_cuda(x)
+        lib = _lib.load()
+        ctx = torch.empty(B * S, heads * hdp, dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.fsvit_qkv_attention(_ptr(x), _ptr(wqkv), wqkv.shape[-1], _ptr(bias), _ptr(ctx), B, S, x.shape[1], heads, hdp,
+                                               float(scale), _stream_ptr(x.device)))
+        return ctx
+
+    @staticmethod
     def im2col27(x, dtype):
         _require_cuda(x)
         lib = _lib.load()

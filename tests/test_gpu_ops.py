@@ -127,6 +127,43 @@ def test_attention(S, heads, hd, pad, dt):
     assert err <= (2e-5 if dt == 'f32' else 2e-2), (dt, err)
 
 
+@pytest.mark.parametrize('B,S,use_bias', [(3, 100, True), (1, 100, False), (300, 100, True), (5, 37, True), (2, 128, True), (4, 1, True)])
+def test_qkv_attention_fused_matches_unfused_math(B, S, use_bias):
+    """qkv_attn.hip (qkv conv + attention in one launch, qkv kept on chip) against the unfused math with the same bf16 rounding
+    points (q / k / v and P rounded to bf16, fp32 accumulation), Visformer-S stage-2 geometry; ragged token counts, one workgroup
+    walking several images (B > 256), the single-token edge."""
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    C, heads, hd, hdp = 256, 6, 42, 48
+    g = torch.Generator().manual_seed(B * 131 + S)
+    x = q(torch.randn(B * S, C, generator=g), bf)
+    w = torch.zeros(3, heads, hdp, C)
+    w[:, :, :hd] = torch.randn(3, heads, hd, C, generator=g) / math.sqrt(C)
+    w = q(w, bf).reshape(3 * heads * hdp, C)
+    bias = torch.zeros(3, heads, hdp)
+    if use_bias:
+        bias[:, :, :hd] = torch.randn(3, heads, hd, generator=g) * 0.3
+    bias = bias.reshape(-1)
+    scale = hd ** -0.5
+    qkv = q(x @ w.t() + bias, bf).reshape(B, S, 3, heads, hdp)
+    qq, kk, vv = [qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
+    p = ((qq @ kk.transpose(-1, -2)) * scale).softmax(-1)
+    ref = (p @ vv).permute(0, 2, 1, 3).reshape(B * S, heads * hdp)
+    got = ops.qkv_attention(x.to('cuda', bf), w.to('cuda', bf), bias.cuda() if use_bias else None, B, S, heads, hdp, scale)
+    torch.cuda.synchronize()
+    got = got.float().cpu()
+    assert torch.isfinite(got).all()
+    assert got.reshape(B * S, heads, hdp)[..., hd:].abs().max().item() == 0.0       # padded head dims stay exactly 0
+    err = (got - ref).abs()
+    assert err.max().item() <= 3e-2 * max(1.0, float(ref.abs().max())), (B, S, err.max().item())
+    assert err.mean().item() <= 3e-3, (B, S, err.mean().item())
+    # and against the two-launch path of the same library (identical rounding points; the fp32 accumulation order differs)
+    two = ops.attention(ops.conv_gemm(x.to('cuda', bf).reshape(B, S, 1, C), w.to('cuda', bf).reshape(1, 3 * heads * hdp, C), bias.cuda() if use_bias else None,
+                                      None, None, B, S, 1, C, 1, 1, 1, 0, 3 * heads * hdp, 1, 0, 0).reshape(B * S, 3 * heads * hdp), B, S, heads, hdp, scale)
+    d = (got - two.float().cpu()).abs()
+    assert d.max().item() <= 2e-2 * max(1.0, float(ref.abs().max())) and d.mean().item() <= 1e-3, (d.max().item(), d.mean().item())
+
+
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 def test_im2col_maxpool_pool(dt):
     from fewshot_vit_amd.engine import ops
