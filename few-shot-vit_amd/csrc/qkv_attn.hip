@@ -4,17 +4,20 @@
 //
 // As two launches the block is bound by the qkv tensor: at C = 256 the conv writes 3.4 x its input (864 channels per token,
 // 1.1 GB per 6400-image launch) only for the attention kernel to read it back one (image, head) at a time - both launches sit at about
-// half of their HBM bounds (0.50 + 0.58 ms).  Here qkv never leaves the chip.  One 8-wave workgroup owns an IMAGE (S <= 128
-// tokens, 16 per wave, held in registers as MFMA operands for the whole image) and walks its 6 heads:
+// half of their HBM bounds (0.50 + 0.58 ms).  Here qkv never leaves the chip.  One 8-wave workgroup owns TWO images per pass (waves
+// 0-3 / 4-7; S <= 128 tokens, 32 per wave, held in registers as MFMA operands for the whole pass) and walks their 6 heads:
 //   * q_h, k_h: D^T = W X^T (v_mfma_f32_16x16x32_bf16, A = weight fragment, B = the wave's tokens): a lane ends up with 4 consecutive
-//     channels of one token -> 8-byte stores into the row-major Q / K images in LDS;
+//     channels of one token per 16-channel tile.  q stays in REGISTERS: packed to bf16 the three tiles are already a valid B operand
+//     of the score MFMA in the k order (tile 0 rows | tile 1 rows), (tile 2 rows | zeros); k is stored to LDS in exactly that order
+//     (8-byte stores, the zero half written once), so q . k is unchanged and no permutation is ever applied;
 //     v_h: the same two registers with the operands SWAPPED (D = X W^T): 4 consecutive tokens of one channel -> 8-byte stores into
 //     the V^T image.  No transposing pass, no scalar LDS writes;
-//   * the attention of the head then runs on those images exactly as attention_v2_kernel does on its staged copies (register
-//     softmax, P fed back as the second MFMA's B operand); each wave owns the 16 queries whose q it just computed;
-//   * only weights stream: 442 KB per image (L2-resident), as 18 slot images of 24 fragment-major 1 KB fragments (one per
-//     (head, q|k|v)) through a 4-slot LDS ring filled by linear LDS-DMA with counted vmcnt (the ring of mlp_rows.hip), one piece at
-//     a time between MFMAs.
+//   * the attention of the head then runs as in attention_v2_kernel (register softmax, P fed back as the second MFMA's B operand);
+//     each wave owns the 32 queries whose q it just computed;
+//   * only weights stream: 442 KB per pass (L2-resident), as 18 slot images of 24 fragment-major 1 KB fragments (one per
+//     (head, q|k|v)) through a 3-slot LDS ring filled by linear LDS-DMA with counted vmcnt (the ring of mlp_rows.hip), one piece at
+//     a time between MFMAs; a fragment feeds the wave's two token tiles;
+//   * the next pass's token rows are requested during the last head.
 // Two waves per SIMD: one wave's softmax VALU runs under the other's MFMAs.  Padding tokens (rows S..127) carry x = 0, so their
 // q / k / v equal the bias: finite, masked as keys, never stored as queries.
 #include <stdlib.h>
@@ -29,14 +32,15 @@ typedef __attribute__((address_space(3))) void* lptrq_t;
 namespace qa {
 constexpr int C = 256, HEADS = 6, HDP = 48;
 constexpr int NCT = HDP / 16, NKS = C / 32;           // channel tiles of a head part, k-steps of 32 input channels
-constexpr int NW = 8, TOK = NW * 16;                   // waves, token rows per workgroup
+constexpr int NW = 8, IMGS = 2, WPI = NW / IMGS;       // waves, images per pass, waves per image
+constexpr int TT = 2, TOK = WPI * TT * 16;             // token tiles per wave, token rows per image (128)
 constexpr int NKT = TOK / 16;                          // key tiles
 constexpr int FRAGS = NCT * NKS, SLOT = FRAGS * 1024;  // one (head, part) weight image: 24 KB
-constexpr int NST = 4, NIMG = HEADS * 3;
+constexpr int NST = 3, NIMG = HEADS * 3;
 constexpr int PPW = FRAGS / NW;                        // LDS-DMA pieces per wave and slot image
-constexpr int QS = HDP * 2 + 16;                       // Q / K row stride (bytes): odd multiple of 16
+constexpr int KS = 128 + 16;                           // K row stride (bytes): 64 k positions (48 real) + pad, odd multiple of 16
 constexpr int VS = TOK * 2 + 16;                       // V^T row stride
-constexpr int OFF_Q = NST * SLOT, OFF_K = OFF_Q + TOK * QS, OFF_V = OFF_K + TOK * QS, OFF_B = OFF_V + HDP * VS;
+constexpr int OFF_K = NST * SLOT, OFF_V = OFF_K + IMGS * TOK * KS, OFF_B = OFF_V + IMGS * HDP * VS;
 constexpr int LDS_BYTES = OFF_B + 3 * HEADS * HDP * 4;
 static_assert(FRAGS % NW == 0, "whole pieces per wave");
 }  // namespace qa
@@ -55,7 +59,7 @@ __device__ __forceinline__ void qa_dma1(unsigned voff, const void* sbase, unsign
       : "v"(voff), "s"(sbase), "s"(lds)
       : "memory");
 }
-// x rows through inline asm: a compiler-visible global load in the image loop would make hipcc's waitcnt pass drain the ring
+// x rows through inline asm: a compiler-visible global load in the pass loop would make hipcc's waitcnt pass drain the ring
 __device__ __forceinline__ u32x4 qa_gload16(const void* p) {
   u32x4 v;
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
@@ -64,6 +68,11 @@ __device__ __forceinline__ u32x4 qa_gload16(const void* p) {
 __device__ __forceinline__ void qa_lds_barrier() {      // LDS writes of this wave done, then the workgroup barrier (no vmcnt: the ring stays in flight)
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+__device__ __forceinline__ unsigned qa_pk2(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const bf16x2_t v = {(bf16)a, (bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
 
 }  // namespace
 
@@ -71,23 +80,26 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
                                                                const float* __restrict__ bias, const int B, const int S, const float scale) {
   using namespace qa;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const Qs = smem + OFF_Q;
-  unsigned char* const Ks = smem + OFF_K;
-  unsigned char* const Vt = smem + OFF_V;
   float* const btab = reinterpret_cast<float*>(smem + OFF_B);
   const unsigned lds0 = (unsigned)(size_t)(lptrq_t)smem;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int sub = wave / WPI, tokbase = (wave % WPI) * (TT * 16);       // image of the pass, first token of this wave
+  unsigned char* const Ks = smem + OFF_K + sub * (TOK * KS);
+  unsigned char* const Vt = smem + OFF_V + sub * (HDP * VS);
   const int m = lane & 15, lq = lane >> 4;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  if ((int)blockIdx.x >= B) return;
+  const int n_pass = (B + IMGS - 1) / IMGS;
+  if ((int)blockIdx.x >= n_pass) return;
 
   for (int i = t; i < 3 * HEADS * HDP; i += NW * 64) btab[i] = bias ? bias[i] : 0.0f;
+  for (int i = t; i < IMGS * TOK * (KS / 16); i += NW * 64) *reinterpret_cast<u32x4*>(smem + OFF_K + i * 16) = zero4;   // the zero halves of the K rows
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
-  // weight ring (mlp_rows.hip): slot image n is issued after barrier n-3, waited for (this wave's counted vmcnt) before barrier n-1 and
-  // first read after barrier n.  Every wave issues PPW pieces per image; vmcnt(PPW) = everything but the newest PPW operations has
-  // landed (the ctx stores of the attention phase share the queue and only make the wait stricter).
+  // weight ring: slot image n is issued after barrier n-2 (into the slot read during interval n-3), waited for (this wave's
+  // vmcnt(0): it is the newest thing in flight) before barrier n-1 and first read after barrier n - one full interval (~1500
+  // cycles of MFMAs) of flight time for an L2-resident 24 KB image; LDS-DMA data is ordered for a ds_read by the issuing wave's
+  // vmcnt followed by a barrier the reader passes, kept one interval apart as in mlp_rows.hip.
   int issue_img = 0, issue_slot = 0;
   const unsigned voff = (unsigned)(wave * PPW * 1024 + lane * 16);
   auto issue1 = [&](int piece) {
@@ -102,117 +114,143 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
 #pragma unroll
     for (int pc = 0; pc < PPW; ++pc) issue1(pc);
   int slot = 0;
-  asm volatile("s_barrier" ::: "memory");                  // bias table visible
+  asm volatile("s_barrier" ::: "memory");                  // bias table / zeroed K rows visible
 
-  const int tok = wave * 16 + m;                           // this lane's token as an MFMA row / column
   const float sscale = scale * 1.44269504088896340736f;    // exp runs on v_exp_f32 (2^x): log2(e) folded into the score scale
 
-  for (int img = blockIdx.x; img < B; img += gridDim.x) {
-    // ---- the wave's 16 tokens -> registers: xr[ks] = channels 32 ks + 8 lq .. +7 of token `tok` (A or B operand alike)
-    u32x4 xr[NKS];
-    {
-      const bf16* src = X + ((size_t)img * S + (tok < S ? tok : S - 1)) * C + lq * 8;
+  // token rows of (pass, this wave) -> registers: xr[tt][ks] = channels 32 ks + 8 lq .. +7 of token tokbase + 16 tt + m (A or B operand alike)
+  u32x4 xr[TT][NKS];
+  auto load_x = [&](int pass) {
+    const int img = pass * IMGS + sub;
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) xr[ks] = qa_gload16(src + ks * 32);
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]) :: "memory");
-      asm volatile("" : "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]) :: "memory");
-      if (tok >= S) {
+    for (int tt = 0; tt < TT; ++tt) {
+      const int tok = tokbase + 16 * tt + m;
+      const bool ok = img < B && tok < S;
+      const bf16* src = X + ((size_t)(img < B ? img : B - 1) * S + (tok < S ? tok : S - 1)) * C + lq * 8;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) xr[ks] = zero4;
-      }
+      for (int ks = 0; ks < NKS; ++ks) xr[tt][ks] = ok ? qa_gload16(src + ks * 32) : zero4;
     }
+  };
+  load_x(blockIdx.x);
+
+  for (int pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
+    const int img = pass * IMGS + sub;
+    // the rows requested one pass ago (or just above) have landed; registers threaded through so no use moves above the wait
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0][0]), "+v"(xr[0][1]), "+v"(xr[0][2]), "+v"(xr[0][3]) :: "memory");
+    asm volatile("" : "+v"(xr[0][4]), "+v"(xr[0][5]), "+v"(xr[0][6]), "+v"(xr[0][7]) :: "memory");
+    asm volatile("" : "+v"(xr[1][0]), "+v"(xr[1][1]), "+v"(xr[1][2]), "+v"(xr[1][3]) :: "memory");
+    asm volatile("" : "+v"(xr[1][4]), "+v"(xr[1][5]), "+v"(xr[1][6]), "+v"(xr[1][7]) :: "memory");
     bf16* const obase = CTX + (size_t)img * S * (HEADS * HDP);
 
 #pragma unroll 1
     for (int h = 0; h < HEADS; ++h) {
-      // ---- q_h, k_h, v_h of the wave's tokens -> the Q / K / V^T images
+      u32x4 qf[TT][2];
+      // ---- q_h (registers), k_h, v_h (LDS images) of the wave's tokens
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // image n + 1 (everything issued so far) has landed: read after the NEXT barrier
         asm volatile("s_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* sp = smem + slot * SLOT + lane * 16;
         slot = slot == NST - 1 ? 0 : slot + 1;
         const float* bp = btab + (p * HEADS + h) * HDP;
-        f32x4 acc[NCT];
+        f32x4 acc[NCT][TT];
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-          if (p < 2) acc[c] = *reinterpret_cast<const f32x4*>(bp + 16 * c + 4 * lq);      // rows = channels 16 c + 4 lq + e
-          else { const float bv = bp[16 * c + m]; acc[c] = f32x4{bv, bv, bv, bv}; }        // column = channel 16 c + m
-        }
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt) {
+            if (p < 2) acc[c][tt] = *reinterpret_cast<const f32x4*>(bp + 16 * c + 4 * lq);      // rows = channels 16 c + 4 lq + e
+            else { const float bv = bp[16 * c + m]; acc[c][tt] = f32x4{bv, bv, bv, bv}; }        // column = channel 16 c + m
+          }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
           for (int c = 0; c < NCT; ++c) {
             const u32x4 wf = *reinterpret_cast<const u32x4*>(sp + (ks * NCT + c) * 1024);
-            acc[c] = p < 2 ? mma_chunk<bf16>(wf, xr[ks], acc[c]) : mma_chunk<bf16>(xr[ks], wf, acc[c]);
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+              acc[c][tt] = p < 2 ? mma_chunk<bf16>(wf, xr[tt][ks], acc[c][tt]) : mma_chunk<bf16>(xr[tt][ks], wf, acc[c][tt]);
           }
           if (ks % 3 == 0 && ks / 3 < PPW) issue1(ks / 3);
         }
 #pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-          const bf16x4 o = {(bf16)acc[c][0], (bf16)acc[c][1], (bf16)acc[c][2], (bf16)acc[c][3]};
-          if (p < 2) *reinterpret_cast<bf16x4*>((p == 0 ? Qs : Ks) + tok * QS + (16 * c + 4 * lq) * 2) = o;
-          else *reinterpret_cast<bf16x4*>(Vt + (16 * c + m) * VS + (wave * 16 + 4 * lq) * 2) = o;   // rows = tokens 16 wave + 4 lq + e
+        for (int tt = 0; tt < TT; ++tt) {
+          const int tok = tokbase + 16 * tt + m;
+          if (p == 0) {
+            qf[tt][0] = u32x4{qa_pk2(acc[0][tt][0], acc[0][tt][1]), qa_pk2(acc[0][tt][2], acc[0][tt][3]),
+                              qa_pk2(acc[1][tt][0], acc[1][tt][1]), qa_pk2(acc[1][tt][2], acc[1][tt][3])};
+            qf[tt][1] = u32x4{qa_pk2(acc[2][tt][0], acc[2][tt][1]), qa_pk2(acc[2][tt][2], acc[2][tt][3]), 0u, 0u};
+          } else if (p == 1) {      // k positions: chunk 0 = (tile 0 rows 4 lq.. | tile 1 rows 4 lq..) per lq, chunk 1 = (tile 2 rows | zeros)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+              const u32x2 o = {qa_pk2(acc[c][tt][0], acc[c][tt][1]), qa_pk2(acc[c][tt][2], acc[c][tt][3])};
+              *reinterpret_cast<u32x2*>(Ks + tok * KS + (c == 2 ? 64 : 8 * c) + 16 * lq) = o;
+            }
+          } else {                  // rows = tokens tokbase + 16 tt + 4 lq + e of channel 16 c + m
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+              const u32x2 o = {qa_pk2(acc[c][tt][0], acc[c][tt][1]), qa_pk2(acc[c][tt][2], acc[c][tt][3])};
+              *reinterpret_cast<u32x2*>(Vt + (16 * c + m) * VS + (tokbase + 16 * tt + 4 * lq) * 2) = o;
+            }
+          }
         }
       }
+      if (h == HEADS - 1 && pass + (int)gridDim.x < n_pass) load_x(pass + gridDim.x);     // xr is dead from here on: next pass's rows
       qa_lds_barrier();
 
-      // ---- attention of head h for the wave's query tile (attention_v2_kernel's body on the LDS images)
-      if (wave * 16 < S) {
-        const int q = tok;
-        u32x4 qf[2];
-        qf[0] = *reinterpret_cast<const u32x4*>(Qs + q * QS + lq * 16);
-        qf[1] = lq < 2 ? *reinterpret_cast<const u32x4*>(Qs + q * QS + (4 + lq) * 16) : zero4;   // head dim 48 = 1.5 MFMA k-chunks
-        f32x4 sc[NKT];
+      // ---- attention of head h for the wave's two query tiles (attention_v2_kernel's body on the LDS images)
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-          const unsigned char* ka = Ks + (kt * 16 + m) * QS + lq * 16;
-          f32x4 a = {0.f, 0.f, 0.f, 0.f};
-          a = mma_chunk<bf16>(*reinterpret_cast<const u32x4*>(ka), qf[0], a);
-          u32x4 kf = *reinterpret_cast<const u32x4*>(ka + 64);
-          if (lq >= 2) kf = zero4;                                       // beyond the row: pad / next row
-          sc[kt] = mma_chunk<bf16>(kf, qf[1], a);                        // keys kt*16 + lq*4 + r  x  query m
-        }
-        float mx = -INFINITY;
+      for (int tt = 0; tt < TT; ++tt) {
+        if (img < B && tokbase + 16 * tt < S) {
+          const int q = tokbase + 16 * tt + m;
+          f32x4 sc[NKT];
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool ok = kt * 16 + lq * 4 + r < S;
-            sc[kt][r] = ok ? sc[kt][r] * sscale : -INFINITY;
-            mx = fmaxf(mx, sc[kt][r]);
+          for (int kt = 0; kt < NKT; ++kt) {
+            const unsigned char* ka = Ks + (kt * 16 + m) * KS + lq * 16;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = mma_chunk<bf16>(*reinterpret_cast<const u32x4*>(ka), qf[tt][0], a);
+            sc[kt] = mma_chunk<bf16>(*reinterpret_cast<const u32x4*>(ka + 64), qf[tt][1], a);     // keys kt*16 + lq*4 + r  x  query m
           }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
+          float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
+          for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float e = __builtin_amdgcn_exp2f(sc[kt][r] - mx);      // -inf for masked keys -> 0
-            sc[kt][r] = e;
-            sum += e;
+            for (int r = 0; r < 4; ++r) {
+              const bool ok = kt * 16 + lq * 4 + r < S;
+              sc[kt][r] = ok ? sc[kt][r] * sscale : -INFINITY;
+              mx = fmaxf(mx, sc[kt][r]);
+            }
+          mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          float sum = 0.f;
+#pragma unroll
+          for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float e = __builtin_amdgcn_exp2f(sc[kt][r] - mx);      // -inf for masked keys -> 0
+              sc[kt][r] = e;
+              sum += e;
+            }
+          sum += __shfl_xor(sum, 16, 64);
+          sum += __shfl_xor(sum, 32, 64);
+          const float inv = 1.0f / sum;
+          // ctx^T[d][q] = sum_key V^T[d][key] P[q][key]; P in the C layout of S^T is the B operand, the k permutation it implies is
+          // applied to the V^T fragment read (two 8-byte reads per 32-key chunk)
+#pragma unroll
+          for (int dt = 0; dt < NCT; ++dt) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            const unsigned char* va = Vt + (dt * 16 + m) * VS;
+#pragma unroll
+            for (int kc = 0; kc < NKT / 2; ++kc) {
+              const u32x2 v0 = *reinterpret_cast<const u32x2*>(va + (32 * kc + lq * 4) * 2);
+              const u32x2 v1 = *reinterpret_cast<const u32x2*>(va + (32 * kc + 16 + lq * 4) * 2);
+              const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+              const u32x4 pb = {qa_pk2(sc[2 * kc][0], sc[2 * kc][1]), qa_pk2(sc[2 * kc][2], sc[2 * kc][3]),
+                                qa_pk2(sc[2 * kc + 1][0], sc[2 * kc + 1][1]), qa_pk2(sc[2 * kc + 1][2], sc[2 * kc + 1][3])};
+              a = mma_chunk<bf16>(vf, pb, a);
+            }
+            if (q < S) store4<bf16>(obase + (size_t)q * (HEADS * HDP) + h * HDP + dt * 16 + lq * 4, a * inv);
           }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-        // ctx^T[d][q] = sum_key V^T[d][key] P[q][key]; P in the C layout of S^T is the B operand, the k permutation it implies is
-        // applied to the V^T fragment read (two 8-byte reads per 32-key chunk)
-#pragma unroll
-        for (int dt = 0; dt < NCT; ++dt) {
-          f32x4 a = {0.f, 0.f, 0.f, 0.f};
-          const unsigned char* va = Vt + (dt * 16 + m) * VS;
-#pragma unroll
-          for (int kc = 0; kc < NKT / 2; ++kc) {
-            const u32x2 v0 = *reinterpret_cast<const u32x2*>(va + (32 * kc + lq * 4) * 2);
-            const u32x2 v1 = *reinterpret_cast<const u32x2*>(va + (32 * kc + 16 + lq * 4) * 2);
-            const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
-            const bf16x8 pb = {(bf16)sc[2 * kc][0], (bf16)sc[2 * kc][1], (bf16)sc[2 * kc][2], (bf16)sc[2 * kc][3],
-                               (bf16)sc[2 * kc + 1][0], (bf16)sc[2 * kc + 1][1], (bf16)sc[2 * kc + 1][2], (bf16)sc[2 * kc + 1][3]};
-            a = mma_chunk<bf16>(vf, __builtin_bit_cast(u32x4, pb), a);
-          }
-          if (q < S) store4<bf16>(obase + (size_t)q * (HEADS * HDP) + h * HDP + dt * 16 + lq * 4, a * inv);
         }
       }
       // the next part's ring barrier is passed only after every wave has finished these reads: it also releases the images
@@ -252,7 +290,8 @@ int launch_qkv_attn(const void* x, void* ctx, const void* wimg, const float* bia
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  const int grid = B < 256 ? B : 256;
+  const int n_pass = (B + qa::IMGS - 1) / qa::IMGS;
+  const int grid = n_pass < 256 ? n_pass : 256;
   hipLaunchKernelGGL(qkv_attn_kernel, dim3(grid), dim3(qa::NW * 64), qa::LDS_BYTES, s, (const bf16*)x, (bf16*)ctx, (const unsigned char*)wimg, bias, B, S,
                      scale);
   return (int)hipGetLastError();
