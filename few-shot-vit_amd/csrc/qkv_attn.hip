@@ -146,9 +146,13 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
     for (int h = 0; h < HEADS; ++h) {
       u32x4 qf[TT][2];
       // ---- q_h (registers), k_h, v_h (LDS images) of the wave's tokens
+      // Stream order per head: k, v, q.  The ring barrier in front of the q part also publishes the K / V^T images every wave wrote
+      // after its k / v parts (lgkmcnt(0) in front of each barrier), so the attention needs no barrier of its own; the ring barrier in
+      // front of the next head's k part is passed only after every wave has finished reading them.
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // image n + 1 (everything issued so far) has landed: read after the NEXT barrier
+      for (int pi = 0; pi < 3; ++pi) {
+        const int p = pi == 2 ? 0 : pi + 1;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // image n + 1 (everything issued so far) has landed: read after the NEXT barrier
         asm volatile("s_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* sp = smem + slot * SLOT + lane * 16;
@@ -196,29 +200,34 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
         }
       }
       if (h == HEADS - 1 && pass + (int)gridDim.x < n_pass) load_x(pass + gridDim.x);     // xr is dead from here on: next pass's rows
-      qa_lds_barrier();
 
-      // ---- attention of head h for the wave's two query tiles (attention_v2_kernel's body on the LDS images)
+      // ---- attention of head h for the wave's two query tiles (attention_v2_kernel's body on the LDS images).  Both tiles run in one
+      // straight-line block - padding tiles compute on finite bias-valued rows and are simply not stored - so that the scheduler can
+      // put one tile's softmax under the other tile's MFMAs.
+      {
+        f32x4 sc[TT][NKT];
 #pragma unroll
-      for (int tt = 0; tt < TT; ++tt) {
-        if (img < B && tokbase + 16 * tt < S) {
-          const int q = tokbase + 16 * tt + m;
-          f32x4 sc[NKT];
+        for (int kt = 0; kt < NKT; ++kt) {
+          const unsigned char* ka = Ks + (kt * 16 + m) * KS + lq * 16;
+          const u32x4 k0 = *reinterpret_cast<const u32x4*>(ka), k1 = *reinterpret_cast<const u32x4*>(ka + 64);
 #pragma unroll
-          for (int kt = 0; kt < NKT; ++kt) {
-            const unsigned char* ka = Ks + (kt * 16 + m) * KS + lq * 16;
+          for (int tt = 0; tt < TT; ++tt) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            a = mma_chunk<bf16>(*reinterpret_cast<const u32x4*>(ka), qf[tt][0], a);
-            sc[kt] = mma_chunk<bf16>(*reinterpret_cast<const u32x4*>(ka + 64), qf[tt][1], a);     // keys kt*16 + lq*4 + r  x  query m
+            a = mma_chunk<bf16>(k0, qf[tt][0], a);
+            sc[tt][kt] = mma_chunk<bf16>(k1, qf[tt][1], a);               // keys kt*16 + lq*4 + r  x  query m
           }
+        }
+        float inv[TT];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
           float mx = -INFINITY;
 #pragma unroll
           for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const bool ok = kt * 16 + lq * 4 + r < S;
-              sc[kt][r] = ok ? sc[kt][r] * sscale : -INFINITY;
-              mx = fmaxf(mx, sc[kt][r]);
+              sc[tt][kt][r] = ok ? sc[tt][kt][r] * sscale : -INFINITY;
+              mx = fmaxf(mx, sc[tt][kt][r]);
             }
           mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
           mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -227,46 +236,57 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
           for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const float e = __builtin_amdgcn_exp2f(sc[kt][r] - mx);      // -inf for masked keys -> 0
-              sc[kt][r] = e;
+              const float e = __builtin_amdgcn_exp2f(sc[tt][kt][r] - mx);  // -inf for masked keys -> 0
+              sc[tt][kt][r] = e;
               sum += e;
             }
           sum += __shfl_xor(sum, 16, 64);
           sum += __shfl_xor(sum, 32, 64);
-          const float inv = 1.0f / sum;
-          // ctx^T[d][q] = sum_key V^T[d][key] P[q][key]; P in the C layout of S^T is the B operand, the k permutation it implies is
-          // applied to the V^T fragment read (two 8-byte reads per 32-key chunk)
+          inv[tt] = 1.0f / sum;
+        }
+        // ctx^T[d][q] = sum_key V^T[d][key] P[q][key]; P in the C layout of S^T is the B operand, the k permutation it implies is
+        // applied to the V^T fragment read (two 8-byte reads per 32-key chunk)
+        u32x4 pb[TT][NKT / 2];
 #pragma unroll
-          for (int dt = 0; dt < NCT; ++dt) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            const unsigned char* va = Vt + (dt * 16 + m) * VS;
+        for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-            for (int kc = 0; kc < NKT / 2; ++kc) {
-              const u32x2 v0 = *reinterpret_cast<const u32x2*>(va + (32 * kc + lq * 4) * 2);
-              const u32x2 v1 = *reinterpret_cast<const u32x2*>(va + (32 * kc + 16 + lq * 4) * 2);
-              const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
-              const u32x4 pb = {qa_pk2(sc[2 * kc][0], sc[2 * kc][1]), qa_pk2(sc[2 * kc][2], sc[2 * kc][3]),
-                                qa_pk2(sc[2 * kc + 1][0], sc[2 * kc + 1][1]), qa_pk2(sc[2 * kc + 1][2], sc[2 * kc + 1][3])};
-              a = mma_chunk<bf16>(vf, pb, a);
-            }
-            if (q < S) store4<bf16>(obase + (size_t)q * (HEADS * HDP) + h * HDP + dt * 16 + lq * 4, a * inv);
+          for (int kc = 0; kc < NKT / 2; ++kc)
+            pb[tt][kc] = u32x4{qa_pk2(sc[tt][2 * kc][0], sc[tt][2 * kc][1]), qa_pk2(sc[tt][2 * kc][2], sc[tt][2 * kc][3]),
+                               qa_pk2(sc[tt][2 * kc + 1][0], sc[tt][2 * kc + 1][1]), qa_pk2(sc[tt][2 * kc + 1][2], sc[tt][2 * kc + 1][3])};
+#pragma unroll
+        for (int dt = 0; dt < NCT; ++dt) {
+          f32x4 a[TT];
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt) a[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const unsigned char* va = Vt + (dt * 16 + m) * VS;
+#pragma unroll
+          for (int kc = 0; kc < NKT / 2; ++kc) {
+            const u32x2 v0 = *reinterpret_cast<const u32x2*>(va + (32 * kc + lq * 4) * 2);
+            const u32x2 v1 = *reinterpret_cast<const u32x2*>(va + (32 * kc + 16 + lq * 4) * 2);
+            const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) a[tt] = mma_chunk<bf16>(vf, pb[tt][kc], a[tt]);
+          }
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt) {
+            const int q = tokbase + 16 * tt + m;
+            if (img < B && q < S) store4<bf16>(obase + (size_t)q * (HEADS * HDP) + h * HDP + dt * 16 + lq * 4, a[tt] * inv[tt]);
           }
         }
       }
-      // the next part's ring barrier is passed only after every wave has finished these reads: it also releases the images
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no DMA may be in flight into the LDS of a finished workgroup
 }
 
 // Fragment-major weight image from the engine's packed qkv layer (w [3 * HEADS * HDP][kw] bf16, rows (part, head, z)):
-//   image (h, p), fragment ks * NCT + c, lane (m, lq), 8 elements: row (p, h, 16 c + m), columns 32 ks + 8 lq .. +7
+//   image 3 h + (k, v, q), fragment ks * NCT + c, lane (m, lq), 8 elements: row (p, h, 16 c + m), columns 32 ks + 8 lq .. +7
 __global__ void qkv_attn_pack_kernel(const bf16* __restrict__ w, int kw, bf16* __restrict__ img) {
   using namespace qa;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)NIMG * FRAGS * 512) return;
   const int e8 = (int)idx & 7, lane = (int)(idx >> 3) & 63, f = (int)(idx >> 9) % FRAGS, n = (int)(idx >> 9) / FRAGS;
-  const int h = n / 3, p = n % 3, ks = f / NCT, c = f % NCT, m = lane & 15, lq = lane >> 4;
+  const int h = n / 3, p = (n % 3 + 1) % 3, ks = f / NCT, c = f % NCT, m = lane & 15, lq = lane >> 4;      // stream order per head: k, v, q
   img[idx] = w[(size_t)((p * HEADS + h) * HDP + 16 * c + m) * kw + 32 * ks + 8 * lq + e8];
 }
 
