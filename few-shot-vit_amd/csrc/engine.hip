@@ -803,7 +803,7 @@ extern "C" int fsvit_qkv_attention(const void* x, const void* wqkv, int kw, cons
                                    float scale, void* stream) {
   if (!x || !wqkv || !ctx) return fail(FSVIT_ERR_ARG, "null argument");
   if (!qkv_attn_supported(FSVIT_BF16, C, heads, hdp, S) || kw < C)
-    return fail(FSVIT_ERR_ARG, "fsvit_qkv_attention: only C = 256, 6 heads x 48 (padded), S <= 128 (bf16) is built");
+    return fail(FSVIT_ERR_ARG, "fsvit_qkv_attention: only C = 256, 6 heads x 48 (padded), S <= 112 (bf16) is built");
   hipStream_t st = (hipStream_t)stream;
   void* img = nullptr;
   HIP_TRY(hipMalloc(&img, qkv_attn_image_bytes()));

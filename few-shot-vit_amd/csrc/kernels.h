@@ -41,7 +41,7 @@ int launch_mlp_pack(const void* w1, int k1w, const float* b1, const void* w2, in
 int launch_mlp_rows(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, const void* ctx, int KC, int M, int C, int hid,
                     hipStream_t s);
 
-// fused qkv conv + attention core of the Visformer stage-2 block (qkv_attn.hip; bf16, C = 256, 6 heads x 48, S <= 128): ctx rows
+// fused qkv conv + attention core of the Visformer stage-2 block (qkv_attn.hip; bf16, C = 256, 6 heads x 48, S <= 112): ctx rows
 // [B*S][heads*hdp] from x rows [B*S][C]; wimg is built once by launch_qkv_attn_pack from the packed qkv layer (w [3*heads*hdp][kw])
 bool qkv_attn_supported(int dtype, int C, int heads, int hdp, int S);
 size_t qkv_attn_image_bytes();

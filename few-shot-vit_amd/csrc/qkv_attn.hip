@@ -5,7 +5,7 @@
 // As two launches the block is bound by the qkv tensor: at C = 256 the conv writes 3.4 x its input (864 channels per token,
 // 1.1 GB per 6400-image launch) only for the attention kernel to read it back one (image, head) at a time - both launches sit at about
 // half of their HBM bounds (0.50 + 0.58 ms).  Here qkv never leaves the chip.  One 8-wave workgroup owns TWO images per pass (waves
-// 0-3 / 4-7; S <= 128 tokens, 32 per wave, held in registers as MFMA operands for the whole pass) and walks their 6 heads:
+// 0-3 / 4-7; S <= 112 tokens, 32 per wave, held in registers as MFMA operands for the whole pass) and walks their 6 heads:
 //   * q_h, k_h: D^T = W X^T (v_mfma_f32_16x16x32_bf16, A = weight fragment, B = the wave's tokens): a lane ends up with 4 consecutive
 //     channels of one token per 16-channel tile.  q stays in REGISTERS: packed to bf16 the three tiles are already a valid B operand
 //     of the score MFMA in the k order (tile 0 rows | tile 1 rows), (tile 2 rows | zeros); k is stored to LDS in exactly that order
@@ -34,13 +34,14 @@ constexpr int C = 256, HEADS = 6, HDP = 48;
 constexpr int NCT = HDP / 16, NKS = C / 32;           // channel tiles of a head part, k-steps of 32 input channels
 constexpr int NW = 8, IMGS = 2, WPI = NW / IMGS;       // waves, images per pass, waves per image
 constexpr int TT = 2, TOK = WPI * TT * 16;             // token tiles per wave, token rows per image (128)
-constexpr int NKT = TOK / 16;                          // key tiles
+constexpr int TOKK = 112, NKT = TOKK / 16;             // key rows held / key tiles scored: S <= 112 (keys 112..127 of the last PV chunk carry P = 0)
 constexpr int FRAGS = NCT * NKS, SLOT = FRAGS * 1024;  // one (head, part) weight image: 24 KB
-constexpr int NST = 3, NIMG = HEADS * 3;
+constexpr int NST = 4, NIMG = HEADS * 3;
 constexpr int PPW = FRAGS / NW;                        // LDS-DMA pieces per wave and slot image
 constexpr int KS = 128 + 16;                           // K row stride (bytes): 64 k positions (48 real) + pad, odd multiple of 16
 constexpr int VS = TOK * 2 + 16;                       // V^T row stride
-constexpr int OFF_K = NST * SLOT, OFF_V = OFF_K + IMGS * TOK * KS, OFF_B = OFF_V + IMGS * HDP * VS;
+constexpr int OFF_K = NST * SLOT, OFF_V = OFF_K + IMGS * TOKK * KS, OFF_B = OFF_V + IMGS * HDP * VS;
+static_assert(OFF_B + 3 * HEADS * HDP * 4 <= 160 * 1024, "LDS budget");
 constexpr int LDS_BYTES = OFF_B + 3 * HEADS * HDP * 4;
 static_assert(FRAGS % NW == 0, "whole pieces per wave");
 }  // namespace qa
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int sub = wave / WPI, tokbase = (wave % WPI) * (TT * 16);       // image of the pass, first token of this wave
-  unsigned char* const Ks = smem + OFF_K + sub * (TOK * KS);
+  unsigned char* const Ks = smem + OFF_K + sub * (TOKK * KS);
   unsigned char* const Vt = smem + OFF_V + sub * (HDP * VS);
   const int m = lane & 15, lq = lane >> 4;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -93,13 +94,14 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
   if ((int)blockIdx.x >= n_pass) return;
 
   for (int i = t; i < 3 * HEADS * HDP; i += NW * 64) btab[i] = bias ? bias[i] : 0.0f;
-  for (int i = t; i < IMGS * TOK * (KS / 16); i += NW * 64) *reinterpret_cast<u32x4*>(smem + OFF_K + i * 16) = zero4;   // the zero halves of the K rows
+  for (int i = t; i < (OFF_B - OFF_K) / 16; i += NW * 64) *reinterpret_cast<u32x4*>(smem + OFF_K + i * 16) = zero4;   // the zero halves of the K rows, V^T columns 112..127
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
-  // weight ring: slot image n is issued after barrier n-2 (into the slot read during interval n-3), waited for (this wave's
-  // vmcnt(0): it is the newest thing in flight) before barrier n-1 and first read after barrier n - one full interval (~1500
-  // cycles of MFMAs) of flight time for an L2-resident 24 KB image; LDS-DMA data is ordered for a ds_read by the issuing wave's
-  // vmcnt followed by a barrier the reader passes, kept one interval apart as in mlp_rows.hip.
+  // weight ring (mlp_rows.hip): slot image n is issued after barrier n-3, waited for before barrier n-1 and first read after barrier
+  // n.  Every wave issues PPW pieces per image; vmcnt(PPW) = at most PPW operations outstanding.  Loads return in issue order, so if
+  // a piece of image n+1 were still in flight all PPW pieces of image n+2 would be too, plus the piece itself: the wait certifies
+  // image n+1 whatever the ctx stores (which may complete out of order with loads) do - they can only make it stricter, which is why
+  // they are issued right after the q part's barrier, a whole attention phase ahead of the next wait.
   int issue_img = 0, issue_slot = 0;
   const unsigned voff = (unsigned)(wave * PPW * 1024 + lane * 16);
   auto issue1 = [&](int piece) {
@@ -141,6 +143,21 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
     asm volatile("" : "+v"(xr[1][0]), "+v"(xr[1][1]), "+v"(xr[1][2]), "+v"(xr[1][3]) :: "memory");
     asm volatile("" : "+v"(xr[1][4]), "+v"(xr[1][5]), "+v"(xr[1][6]), "+v"(xr[1][7]) :: "memory");
     bf16* const obase = CTX + (size_t)img * S * (HEADS * HDP);
+    // ctx rows of the previous head, stored one head late (see the ring comment)
+    u32x2 pend[TT][NCT];
+    int pend_h = -1;
+    auto flush_ctx = [&]() {
+      if (pend_h < 0) return;
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const int q = tokbase + 16 * tt + m;
+        if (img < B && q < S) {
+#pragma unroll
+          for (int dt = 0; dt < NCT; ++dt) *reinterpret_cast<u32x2*>(obase + (size_t)q * (HEADS * HDP) + pend_h * HDP + dt * 16 + lq * 4) = pend[tt][dt];
+        }
+      }
+      pend_h = -1;
+    };
 
 #pragma unroll 1
     for (int h = 0; h < HEADS; ++h) {
@@ -152,8 +169,9 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
 #pragma unroll
       for (int pi = 0; pi < 3; ++pi) {
         const int p = pi == 2 ? 0 : pi + 1;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // image n + 1 (everything issued so far) has landed: read after the NEXT barrier
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(PPW) : "memory");
         asm volatile("s_barrier" ::: "memory");
+        if (pi == 2) flush_ctx();                          // the previous head's ctx rows: a q part and an attention phase until the next wait
         __builtin_amdgcn_sched_barrier(0);
         const unsigned char* sp = smem + slot * SLOT + lane * 16;
         slot = slot == NST - 1 ? 0 : slot + 1;
@@ -184,6 +202,8 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
             qf[tt][0] = u32x4{qa_pk2(acc[0][tt][0], acc[0][tt][1]), qa_pk2(acc[0][tt][2], acc[0][tt][3]),
                               qa_pk2(acc[1][tt][0], acc[1][tt][1]), qa_pk2(acc[1][tt][2], acc[1][tt][3])};
             qf[tt][1] = u32x4{qa_pk2(acc[2][tt][0], acc[2][tt][1]), qa_pk2(acc[2][tt][2], acc[2][tt][3]), 0u, 0u};
+          } else if (tokbase + 16 * tt >= TOKK) {
+            // token tile beyond the 112 key rows kept (never valid for S <= 112): no K / V^T entry
           } else if (p == 1) {      // k positions: chunk 0 = (tile 0 rows 4 lq.. | tile 1 rows 4 lq..) per lq, chunk 1 = (tile 2 rows | zeros)
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
@@ -244,15 +264,20 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
           sum += __shfl_xor(sum, 32, 64);
           inv[tt] = 1.0f / sum;
         }
+        pend_h = h;
         // ctx^T[d][q] = sum_key V^T[d][key] P[q][key]; P in the C layout of S^T is the B operand, the k permutation it implies is
         // applied to the V^T fragment read (two 8-byte reads per 32-key chunk)
-        u32x4 pb[TT][NKT / 2];
+        constexpr int NPC = (NKT + 1) / 2;                  // 32-key chunks of the PV product; the last one is half empty
+        u32x4 pb[TT][NPC];
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-          for (int kc = 0; kc < NKT / 2; ++kc)
+          for (int kc = 0; kc < NPC; ++kc) {
+            const bool two = 2 * kc + 1 < NKT;
             pb[tt][kc] = u32x4{qa_pk2(sc[tt][2 * kc][0], sc[tt][2 * kc][1]), qa_pk2(sc[tt][2 * kc][2], sc[tt][2 * kc][3]),
-                               qa_pk2(sc[tt][2 * kc + 1][0], sc[tt][2 * kc + 1][1]), qa_pk2(sc[tt][2 * kc + 1][2], sc[tt][2 * kc + 1][3])};
+                               two ? qa_pk2(sc[tt][two ? 2 * kc + 1 : 0][0], sc[tt][two ? 2 * kc + 1 : 0][1]) : 0u,
+                               two ? qa_pk2(sc[tt][two ? 2 * kc + 1 : 0][2], sc[tt][two ? 2 * kc + 1 : 0][3]) : 0u};
+          }
 #pragma unroll
         for (int dt = 0; dt < NCT; ++dt) {
           f32x4 a[TT];
@@ -260,7 +285,7 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
           for (int tt = 0; tt < TT; ++tt) a[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
           const unsigned char* va = Vt + (dt * 16 + m) * VS;
 #pragma unroll
-          for (int kc = 0; kc < NKT / 2; ++kc) {
+          for (int kc = 0; kc < NPC; ++kc) {
             const u32x2 v0 = *reinterpret_cast<const u32x2*>(va + (32 * kc + lq * 4) * 2);
             const u32x2 v1 = *reinterpret_cast<const u32x2*>(va + (32 * kc + 16 + lq * 4) * 2);
             const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
@@ -269,12 +294,13 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
           }
 #pragma unroll
           for (int tt = 0; tt < TT; ++tt) {
-            const int q = tokbase + 16 * tt + m;
-            if (img < B && q < S) store4<bf16>(obase + (size_t)q * (HEADS * HDP) + h * HDP + dt * 16 + lq * 4, a[tt] * inv[tt]);
+            const f32x4 o = a[tt] * inv[tt];
+            pend[tt][dt] = u32x2{qa_pk2(o[0], o[1]), qa_pk2(o[2], o[3])};
           }
         }
       }
     }
+    flush_ctx();                                            // the last head's rows
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no DMA may be in flight into the LDS of a finished workgroup
 }
@@ -292,7 +318,7 @@ __global__ void qkv_attn_pack_kernel(const bf16* __restrict__ w, int kw, bf16* _
 
 bool qkv_attn_supported(int dtype, int C, int heads, int hdp, int S) {
   static const int on = [] { const char* e = getenv("FSVIT_QKV_ATTN"); return e ? atoi(e) : 1; }();
-  return on && dtype == 1 && C == qa::C && heads == qa::HEADS && hdp == qa::HDP && S >= 1 && S <= qa::TOK;
+  return on && dtype == 1 && C == qa::C && heads == qa::HEADS && hdp == qa::HDP && S >= 1 && S <= qa::TOKK;
 }
 size_t qkv_attn_image_bytes() { return (size_t)qa::NIMG * qa::SLOT; }
 

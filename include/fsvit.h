@@ -147,7 +147,7 @@ int fsvit_conv_gemm(const void* x_dev, const void* w_dev, const float* bias_dev,
 int fsvit_attention(const void* qkv_dev, void* ctx_dev, int B, int S, int heads, int hdp, float scale,
                     int dtype, void* stream);
 /* Fused qkv conv + attention core of a Visformer stage-2 Attention block (visformer.py:172-190; the eval BatchNorm folded into the
- * conv as column scale + bias by the caller), bf16, Visformer-S geometry only (C = 256, 6 heads, head dim padded to 48, S <= 128):
+ * conv as column scale + bias by the caller), bf16, Visformer-S geometry only (C = 256, 6 heads, head dim padded to 48, S <= 112):
  * x rows [B*S][C] -> ctx rows [B*S][heads*hdp].  wqkv [3*heads*hdp][kw] K-major bf16, rows ordered (q|k|v, head, z); bias fp32
  * [3*heads*hdp] or NULL.  Equals fsvit_conv_gemm (1x1, N = 3*heads*hdp) followed by fsvit_attention without the qkv tensor. */
 int fsvit_qkv_attention(const void* x_dev, const void* wqkv_dev, int kw, const float* bias_dev, void* ctx_dev, int B, int S, int C,

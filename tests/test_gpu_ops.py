@@ -127,7 +127,7 @@ def test_attention(S, heads, hd, pad, dt):
     assert err <= (2e-5 if dt == 'f32' else 2e-2), (dt, err)
 
 
-@pytest.mark.parametrize('B,S,use_bias', [(3, 100, True), (1, 100, False), (300, 100, True), (5, 37, True), (2, 128, True), (4, 1, True)])
+@pytest.mark.parametrize('B,S,use_bias', [(3, 100, True), (1, 100, False), (300, 100, True), (5, 37, True), (2, 112, True), (7, 97, True), (4, 1, True)])
 def test_qkv_attention_fused_matches_unfused_math(B, S, use_bias):
     """qkv_attn.hip (qkv conv + attention in one launch, qkv kept on chip) against the unfused math with the same bf16 rounding
     points (q / k / v and P rounded to bf16, fp32 accumulation), Visformer-S stage-2 geometry; ragged token counts, one workgroup
