@@ -299,13 +299,16 @@ def main():
             achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
             traffic = None          # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
             import glob
-            tfs = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_hbm_traffic.json')))      # newest committed PMC passes
+            import re
+            tfs = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_hbm_traffic.json')),      # newest committed PMC passes (r01_v10 after r01_v9)
+                         key=lambda p: [int(x) if x.isdigit() else x for x in re.split(r'(\d+)', os.path.basename(p))])
             if tfs and args.model == 'visformer_micro_80' and args.numerics == 'bf16' and E == 64 and args.chunk == 6400 and args.mode == 'eval':
                 with open(tfs[-1]) as f:
                     tj = json.load(f)
                 cand = [k for k in tj if k == dom] or [k for k in tj if k.split('<')[0] == dom.split('<')[0]]
-                if len(cand) == 1:
-                    traffic = tj[cand[0]].get('hbm_bytes_per_launch')
+                if cand:       # several template instantiations behind one kernel name (conv2 / conv3 of the stem): launch-weighted mean
+                    n = sum(tj[k].get('launches', 1) for k in cand)
+                    traffic = sum(tj[k].get('launches', 1) * tj[k].get('hbm_bytes_per_launch', 0.0) for k in cand) / n
             out['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                                'traffic': traffic, 'kernel': dom, 'launches': d['launches'],
                                'avg_launch_us': 1e3 * d['ms'] / d['launches'],
