@@ -152,6 +152,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const ConvGemmPara
     // of g+1 is read (after the counted wait + barrier that publishes the weight stage of g+1).  With all 8 waves in
     // lockstep the unrotated loop exposed the whole read burst (144 ds_read_b128 per K tile per CU) before every MFMA block.
     u32x4 xf0[MT], xf1[MT], wf0[NT], wf1[NT];
+    // Fragment addresses of the current K tile: computed once by read_k0 (6 VALU each), chunk 1 of the same tile is the same
+    // address with bit 6 flipped.  Recomputing them in read_k1 put 2.6 VALU instructions beside every 16-cycle MFMA (PMC: VALU
+    // 26 % busy) - more than issue for free behind it (tools/probes/mfma_valu_overlap.hip).
+    unsigned xa[MT];
     auto read_k0 = [&](int toff, int kh, int stage) {
       const unsigned char* wb = wst0 + stage * H_STAGE + b_rd;
 #pragma unroll
@@ -159,18 +163,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const ConvGemmPara
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int hp = hp0[i] + toff;
-        xf0[i] = *reinterpret_cast<const u32x4*>(smem + ((unsigned)hp * PXB + (unsigned)((((kh * 8 + lq) ^ hp) & (CPP - 1)) << 4)));
+        xa[i] = (unsigned)hp * PXB + (unsigned)((((kh * 8 + lq) ^ hp) & (CPP - 1)) << 4);
+        xf0[i] = *reinterpret_cast<const u32x4*>(smem + xa[i]);
       }
     };
-    auto read_k1 = [&](int toff, int kh, int stage) {
+    auto read_k1 = [&](int stage) {
       const unsigned char* wb = wst0 + stage * H_STAGE + b_rd;
 #pragma unroll
       for (int j = 0; j < NT; ++j) wf1[j] = *reinterpret_cast<const u32x4*>(wb + j * 2048 + sw1);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int hp = hp0[i] + toff;
-        xf1[i] = *reinterpret_cast<const u32x4*>(smem + (((unsigned)hp * PXB + (unsigned)((((kh * 8 + lq) ^ hp) & (CPP - 1)) << 4)) ^ 64u));   // chunk + 4
-      }
+      for (int i = 0; i < MT; ++i) xf1[i] = *reinterpret_cast<const u32x4*>(smem + (xa[i] ^ 64u));   // chunk + 4
     };
     auto read_tail0 = [&](int stage) {   // identity / downsample conv: A rows = the 27 (padded to 32) im2col taps, straight from global
       const unsigned char* wb = wst0 + stage * H_STAGE + b_rd;
@@ -207,10 +209,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const ConvGemmPara
     // to lgkmcnt(4..0) in front of the second MFMA block, i.e. waits for the reads it was meant to overlap.
     auto ktile = [&](auto more_c, auto next_c, bool more_rt) {
       constexpr int MORE = decltype(more_c)::value, NEXT = decltype(next_c)::value;     // MORE: 1 yes, 0 no, 2 runtime
-      const int toff = ky * H_HW + kx;
       const bool more = MORE == 2 ? more_rt : MORE == 1;
       if (more) issue_w(wk_pre, st_pre);                     // the K tile two ahead (of this output tile, or of the next one)
-      read_k1(toff, kh, st_cur);
+      read_k1(st_cur);
       __builtin_amdgcn_sched_barrier(0);                     // reads are ISSUED before the MFMA block they run under
       mma0();
       if (more) HWAIT_VM(2); else HWAIT_VM(0);               // everything but the K tile just issued has landed
