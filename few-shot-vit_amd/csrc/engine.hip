@@ -462,7 +462,7 @@ int tap(EngineBase* h, const std::string& name, const void* src, size_t bytes, b
 }
 
 // kernel ids reported by the profiler (names in fsvit_kernel_name)
-enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_STAGE1R = 14, KID_QKVATTN = 15 };
+enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_STAGE1R = 14, KID_QKVATTN = 15, KID_STEMCONV1 = 16 };
 
 
 // Runs one launch; in profiling mode brackets it with HIP events on the same stream.
@@ -503,11 +503,22 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
   // stem: conv1 / downsample as K=32 GEMMs over the im2col rows, conv2, conv3 (+identity, LeakyReLU), max-pool + pos1
   h->prof_last = nullptr;
   if (!xsrc2) B1 = Bc;
-  RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() { return launch_im2col27(x, patches, B1, img, img, h->H0, h->H0, dt, st); }));
-  if (Bc > B1)
-    RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() {
-      return launch_im2col27(xsrc2, (unsigned char*)patches + (size_t)B1 * h->H0 * h->H0 * 32 * es, Bc - B1, img, img, h->H0, h->H0, dt, st); }));
-  RC_TRY(run_gemm(h, st, "stem.conv1", h->conv1, conv_params(h->conv1, patches, c1, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C0, ACT_LRELU, nullptr, 0, nullptr), h->C0, 27));
+  static const bool stem_fused_on = [] { const char* e = getenv("FSVIT_STEM_CONV1"); return !e || e[0] != '0'; }();
+  if (stem_fused_on && stem_conv1_supported(dt, img, h->C0)) {      // im2col + conv1 + bn1 + LeakyReLU in one pass over the image
+    const double fl1 = 2.0 * 27.0 * h->C0 * h->H0 * h->H0;
+    RC_TRY(timed(h, st, "stem.im2col+conv1", KID_STEMCONV1, fl1 * B1, [&]() {
+      return launch_stem_conv1(x, patches, c1, h->conv1.w, h->conv1.Kw, h->conv1.bias, B1, st); }));
+    if (Bc > B1)
+      RC_TRY(timed(h, st, "stem.im2col+conv1", KID_STEMCONV1, fl1 * (Bc - B1), [&]() {
+        return launch_stem_conv1(xsrc2, (unsigned char*)patches + (size_t)B1 * h->H0 * h->H0 * 32 * es, (unsigned char*)c1 + (size_t)B1 * h->H0 * h->H0 * h->C0 * es,
+                                 h->conv1.w, h->conv1.Kw, h->conv1.bias, Bc - B1, st); }));
+  } else {
+    RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() { return launch_im2col27(x, patches, B1, img, img, h->H0, h->H0, dt, st); }));
+    if (Bc > B1)
+      RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() {
+        return launch_im2col27(xsrc2, (unsigned char*)patches + (size_t)B1 * h->H0 * h->H0 * 32 * es, Bc - B1, img, img, h->H0, h->H0, dt, st); }));
+    RC_TRY(run_gemm(h, st, "stem.conv1", h->conv1, conv_params(h->conv1, patches, c1, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C0, ACT_LRELU, nullptr, 0, nullptr), h->C0, 27));
+  }
   RC_TRY(run_gemm(h, st, "stem.conv2", h->conv2, conv_params(h->conv2, c1, c2, Bc, h->H0, h->H0, h->C0, h->C0, 3, 3, 1, 1, h->C1, ACT_LRELU, nullptr, 0, nullptr), h->C1, 9.0 * h->C0));
   static const bool split_stem = [] { const char* e = getenv("FSVIT_NO_FUSE"); return e && e[0] == '1'; }();
   if (!split_stem) {
@@ -845,11 +856,11 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
   static const char* f32n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
                                "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<float,128,128,2,2,2>",
-                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel", "stage1_rows_kernel", "qkv_attn_kernel"};
+                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel", "stage1_rows_kernel", "qkv_attn_kernel", "stem_conv1_kernel"};
   static const char* bf16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
                                 "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<__bf16,128,128,2,2,2>",
-                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "stage1_rows_kernel", "qkv_attn_kernel"};
-  if (kernel_id < 0 || kernel_id > 15) return "?";
+                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "stage1_rows_kernel", "qkv_attn_kernel", "stem_conv1_kernel"};
+  if (kernel_id < 0 || kernel_id > 16) return "?";
   return dtype == FSVIT_F32 ? f32n[kernel_id] : bf16n[kernel_id];
 }
 

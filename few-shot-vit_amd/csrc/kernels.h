@@ -6,6 +6,9 @@
 namespace fsvit {
 
 int launch_im2col27(const float* x_nchw, void* out, int B, int H, int W, int OH, int OW, int dtype, hipStream_t s);
+// im2col + stem conv1 + bn1 + LeakyReLU in one pass (bf16, 80x80 images, 64 channels): patches [B*1600][32], c1 [B*1600][64]; w = the packed conv1 layer [64][kw]
+bool stem_conv1_supported(int dtype, int img, int C0);
+int launch_stem_conv1(const float* x_nchw, void* patches, void* c1, const void* w, int kw, const float* bias, int B, hipStream_t s);
 int launch_maxpool2_pos(const void* in, const float* pos, void* out, int B, int OH, int OW, int C, int dtype, hipStream_t s);
 
 // qkv [B*S][3*heads*hdp] (channel = x*heads*hdp + y*hdp + z) -> ctx [B*S][heads*hdp]

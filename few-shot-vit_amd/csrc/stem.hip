@@ -62,6 +62,89 @@ __global__ __launch_bounds__(256) void maxpool2_pos_kernel(const T* __restrict__
   }
 }
 
+// Fused im2col + stem conv1 (bf16): NCHW fp32 image -> the [B*OH*OW][32] patch rows (still needed by the downsample tail of the
+// conv3 kernel) AND c1 = LeakyReLU(bn1(conv1(x))) [B*OH*OW][64] in one pass (visformer.py:209-210,:218).
+// As two launches the pair moves 3.1 GB for 1.03 ms (im2col: scalar gathers, 2.7 TB/s; conv1 as a K = 32 GEMM re-reads the rows it just
+// wrote).  Here a 4-wave workgroup owns 8 output rows of one image: the 17 x 80 x 3 input window goes to LDS as bf16 (coalesced float4
+// reads, zero border for the pad = 1 taps), and each wave builds the patch rows of a 16-pixel tile DIRECTLY in MFMA operand layout
+// (lane (pixel m, lq) gathers taps 8 lq .. 8 lq + 7 with eight 2-byte LDS reads): that one register quartet is both the 16-byte
+// chunk of the patch row it stores (64 lanes x 16 B = 1 KB contiguous) and the B operand of the four conv1 MFMAs of the tile
+// (D^T = W X^T: a lane ends up with 4 consecutive channels of its pixel -> 8-byte stores).
+namespace stem1 {
+constexpr int IMG = 80, OH = 40, ROWS = 8;                  // output rows per workgroup
+constexpr int IR = 2 * ROWS + 1, ICP = IMG + 2;             // input rows held, padded row length (col -1 .. 80)
+constexpr int PLANE = IR * ICP;                             // elements per channel plane
+constexpr int NW = 4;
+}  // namespace stem1
+
+__global__ __launch_bounds__(stem1::NW * 64) void stem_conv1_kernel(const float* __restrict__ x, bf16* __restrict__ patches, bf16* __restrict__ c1,
+                                                                    const bf16* __restrict__ w, const int kw, const float* __restrict__ bias) {
+  using namespace stem1;
+  __shared__ __attribute__((aligned(16))) bf16 tile[3 * PLANE];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m = lane & 15, lq = lane >> 4;
+  const int b = blockIdx.x / (OH / ROWS), strip = blockIdx.x % (OH / ROWS);
+  const int oy0 = strip * ROWS, iy0 = 2 * oy0 - 1;          // first output row, first input row held
+  const float* xb = x + (size_t)b * 3 * IMG * IMG;
+
+  // ---- input window -> LDS (bf16, zero border): 3 channels x 17 rows x 20 float4
+  for (int i = t; i < 3 * IR * (IMG / 4); i += NW * 64) {
+    const int c = i / (IR * (IMG / 4)), r = (i / (IMG / 4)) % IR, q4 = i % (IMG / 4);
+    const int iy = iy0 + r;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (iy >= 0 && iy < IMG) v = *reinterpret_cast<const f32x4*>(xb + ((size_t)c * IMG + iy) * IMG + q4 * 4);
+    bf16* d = tile + c * PLANE + r * ICP + 1 + q4 * 4;
+    d[0] = (bf16)v[0]; d[1] = (bf16)v[1]; d[2] = (bf16)v[2]; d[3] = (bf16)v[3];
+  }
+  for (int i = t; i < 3 * IR; i += NW * 64) {               // columns -1 and 80
+    tile[(i / IR) * PLANE + (i % IR) * ICP] = (bf16)0.0f;
+    tile[(i / IR) * PLANE + (i % IR) * ICP + ICP - 1] = (bf16)0.0f;
+  }
+  // conv1 weights: A fragments of the four 16-channel tiles (rows = channels 16 ct + m, k = 8 lq .. +7), bias of the lane's channels
+  u32x4 wf[4];
+  f32x4 bv[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    wf[ct] = *reinterpret_cast<const u32x4*>(w + (size_t)(16 * ct + m) * kw + 8 * lq);
+    bv[ct] = bias ? *reinterpret_cast<const f32x4*>(bias + 16 * ct + 4 * lq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // this lane's taps: k = 8 lq + j = (ky * 3 + kx) * 3 + c  ->  LDS element offset of the tap relative to the pixel's window origin
+  int koff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * lq + j, tap = k / 3, c = k - 3 * tap;
+    koff[j] = k < 27 ? c * PLANE + (tap / 3) * ICP + (tap % 3) : -1;
+  }
+  __syncthreads();
+
+  const size_t prow0 = ((size_t)b * OH + oy0) * OH;         // first output pixel (row-major) of the strip
+  for (int tl = wave; tl < ROWS * OH / 16; tl += NW) {      // 20 tiles of 16 pixels
+    const int pix = tl * 16 + m, oy = pix / OH, ox = pix - oy * OH;
+    const int org = (2 * oy) * ICP + 2 * ox;                // window origin: input row 2 oy - 1 = held row 2 oy, column 2 ox - 1 = padded column 2 ox
+    unsigned short e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = koff[j] >= 0 ? __builtin_bit_cast(unsigned short, tile[org + koff[j]]) : (unsigned short)0;
+    const u32x4 pf = {(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16), (unsigned)e[4] | ((unsigned)e[5] << 16),
+                      (unsigned)e[6] | ((unsigned)e[7] << 16)};
+    *reinterpret_cast<u32x4*>(patches + (prow0 + pix) * 32 + 8 * lq) = pf;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      f32x4 a = mma_chunk<bf16>(wf[ct], pf, bv[ct]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] = a[q] > 0.0f ? a[q] : 0.1f * a[q];
+      store4<bf16>(c1 + (prow0 + pix) * 64 + 16 * ct + 4 * lq, a);
+    }
+  }
+}
+
+bool stem_conv1_supported(int dtype, int img, int C0) { return dtype == 1 && img == stem1::IMG && C0 == 64; }
+
+int launch_stem_conv1(const float* x, void* patches, void* c1, const void* w, int kw, const float* bias, int B, hipStream_t s) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(stem_conv1_kernel, dim3(B * (stem1::OH / stem1::ROWS)), dim3(stem1::NW * 64), 0, s, x, (bf16*)patches, (bf16*)c1, (const bf16*)w, kw, bias);
+  return (int)hipGetLastError();
+}
+
 int launch_im2col27(const float* x, void* out, int B, int H, int W, int OH, int OW, int dtype, hipStream_t s) {
   const int M = B * OH * OW;
   if (M <= 0) return 0;

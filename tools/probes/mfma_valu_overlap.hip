@@ -2,6 +2,7 @@
 // classes cost?  One wave per SIMD (256 threads, one workgroup per CU).  Each loop iteration = 4 independent
 // v_mfma_f32_32x32x16_bf16 (4 accumulators) with K VALU instructions of a class after every MFMA.
 //   class 0: v_pk_fma_f32   class 1: v_exp_f32   class 2: v_rcp_f32   class 3: v_fma_f32   class 4: v_cvt_pk_bf16_f32   class 5: v_min_f32
+//   class 6: v_pk_fma_f16   class 7: v_exp_f16   class 8: v_rcp_f16   class 9: v_cvt_pkrtz_f16_f32
 // Prints shader cycles per (MFMA + its K VALU ops) from s_memtime.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -16,6 +17,10 @@ template <int CLS> __device__ __forceinline__ void valu(f32x2& v, float c) {
   if (CLS == 3) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[0]) : "v"(c));
   if (CLS == 4) { unsigned o; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o) : "v"(v[0]), "v"(v[1])); v[0] = __builtin_bit_cast(float, o); }
   if (CLS == 5) asm volatile("v_min_f32 %0, %0, %1" : "+v"(v[0]) : "v"(c));
+  if (CLS == 6) asm volatile("v_pk_fma_f16 %0, %0, %1, %0" : "+v"(v[0]) : "v"(c));
+  if (CLS == 7) asm volatile("v_exp_f16 %0, %0" : "+v"(v[0]));
+  if (CLS == 8) asm volatile("v_rcp_f16 %0, %0" : "+v"(v[0]));
+  if (CLS == 9) { unsigned o; asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(o) : "v"(v[0]), "v"(v[1])); v[0] = __builtin_bit_cast(float, o); }
 }
 
 template <int CLS, int K, bool MFMA>
@@ -73,5 +78,9 @@ int main() {
   ROW(3, "v_fma_f32")
   ROW(4, "v_cvt_pk_bf16_f32")
   ROW(5, "v_min_f32")
+  ROW(6, "v_pk_fma_f16")
+  ROW(7, "v_exp_f16")
+  ROW(8, "v_rcp_f16")
+  ROW(9, "v_cvt_pkrtz_f16_f32")
   return 0;
 }
