@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void maxpool2_pos_kernel(const T* __restrict__
 // (D^T = W X^T: a lane ends up with 4 consecutive channels of its pixel -> 8-byte stores).
 namespace stem1 {
 constexpr int IMG = 80, OH = 40, ROWS = 8;                  // output rows per workgroup
-constexpr int IR = 2 * ROWS + 1, ICP = IMG + 2;             // input rows held, padded row length (col -1 .. 80)
+constexpr int IR = 2 * ROWS + 1, LPAD = 4, ICP = IMG + 2 * LPAD;   // input rows held; row = 4 pad elements (column -1 is the last of them), 80 columns, 4 pad: 8-byte aligned groups of 4
 constexpr int PLANE = IR * ICP;                             // elements per channel plane
 constexpr int NW = 4;
 }  // namespace stem1
@@ -93,20 +93,20 @@ __global__ __launch_bounds__(stem1::NW * 64) void stem_conv1_kernel(const float*
     const int iy = iy0 + r;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (iy >= 0 && iy < IMG) v = *reinterpret_cast<const f32x4*>(xb + ((size_t)c * IMG + iy) * IMG + q4 * 4);
-    bf16* d = tile + c * PLANE + r * ICP + 1 + q4 * 4;
-    d[0] = (bf16)v[0]; d[1] = (bf16)v[1]; d[2] = (bf16)v[2]; d[3] = (bf16)v[3];
+    *reinterpret_cast<bf16x4*>(tile + c * PLANE + r * ICP + LPAD + q4 * 4) = bf16x4{(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
   }
-  for (int i = t; i < 3 * IR; i += NW * 64) {               // columns -1 and 80
-    tile[(i / IR) * PLANE + (i % IR) * ICP] = (bf16)0.0f;
-    tile[(i / IR) * PLANE + (i % IR) * ICP + ICP - 1] = (bf16)0.0f;
-  }
-  // conv1 weights: A fragments of the four 16-channel tiles (rows = channels 16 ct + m, k = 8 lq .. +7), bias of the lane's channels
+  for (int i = t; i < 3 * IR; i += NW * 64)                 // column -1 (with its three pad neighbours)
+    *reinterpret_cast<bf16x4*>(tile + (i / IR) * PLANE + (i % IR) * ICP) = bf16x4{(bf16)0.0f, (bf16)0.0f, (bf16)0.0f, (bf16)0.0f};
+  // conv1 weights: A fragments of the four 16-channel tiles, k = 8 lq .. +7.  Which channel sits in which MFMA row is free: row
+  // 4 g + e of tile 2 p + h carries channel 32 p + 8 g + 4 h + e, so a lane (rows 4 lq + e of both tiles of a pair) ends up with 8
+  // CONSECUTIVE channels of its pixel - one 16-byte store per tile pair instead of two 8-byte ones.
   u32x4 wf[4];
   f32x4 bv[4];
 #pragma unroll
   for (int ct = 0; ct < 4; ++ct) {
-    wf[ct] = *reinterpret_cast<const u32x4*>(w + (size_t)(16 * ct + m) * kw + 8 * lq);
-    bv[ct] = bias ? *reinterpret_cast<const f32x4*>(bias + 16 * ct + 4 * lq) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int p = ct >> 1, hh = ct & 1;
+    wf[ct] = *reinterpret_cast<const u32x4*>(w + (size_t)(32 * p + 8 * (m >> 2) + 4 * hh + (m & 3)) * kw + 8 * lq);
+    bv[ct] = bias ? *reinterpret_cast<const f32x4*>(bias + 32 * p + 8 * lq + 4 * hh) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   // this lane's taps: k = 8 lq + j = (ky * 3 + kx) * 3 + c  ->  LDS element offset of the tap relative to the pixel's window origin
   int koff[8];
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(stem1::NW * 64) void stem_conv1_kernel(const float*
   const size_t prow0 = ((size_t)b * OH + oy0) * OH;         // first output pixel (row-major) of the strip
   for (int tl = wave; tl < ROWS * OH / 16; tl += NW) {      // 20 tiles of 16 pixels
     const int pix = tl * 16 + m, oy = pix / OH, ox = pix - oy * OH;
-    const int org = (2 * oy) * ICP + 2 * ox;                // window origin: input row 2 oy - 1 = held row 2 oy, column 2 ox - 1 = padded column 2 ox
+    const int org = (2 * oy) * ICP + 2 * ox + LPAD - 1;     // window origin: input row 2 oy - 1 = held row 2 oy, column 2 ox - 1 = element LPAD - 1 + 2 ox
     unsigned short e[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) e[j] = koff[j] >= 0 ? __builtin_bit_cast(unsigned short, tile[org + koff[j]]) : (unsigned short)0;
@@ -128,11 +128,15 @@ __global__ __launch_bounds__(stem1::NW * 64) void stem_conv1_kernel(const float*
                       (unsigned)e[6] | ((unsigned)e[7] << 16)};
     *reinterpret_cast<u32x4*>(patches + (prow0 + pix) * 32 + 8 * lq) = pf;
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      f32x4 a = mma_chunk<bf16>(wf[ct], pf, bv[ct]);
+    for (int p = 0; p < 2; ++p) {
+      const f32x4 a0 = mma_chunk<bf16>(wf[2 * p], pf, bv[2 * p]), a1 = mma_chunk<bf16>(wf[2 * p + 1], pf, bv[2 * p + 1]);
+      bf16x8 o;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) a[q] = a[q] > 0.0f ? a[q] : 0.1f * a[q];
-      store4<bf16>(c1 + (prow0 + pix) * 64 + 16 * ct + 4 * lq, a);
+      for (int q = 0; q < 4; ++q) {                          // LeakyReLU(0.1) = max(v, 0.1 v)
+        o[q] = (bf16)fmaxf(a0[q], 0.1f * a0[q]);
+        o[4 + q] = (bf16)fmaxf(a1[q], 0.1f * a1[q]);
+      }
+      *reinterpret_cast<bf16x8*>(c1 + (prow0 + pix) * 64 + 32 * p + 8 * lq) = o;
     }
   }
 }
