@@ -22,7 +22,9 @@
 #include "kernels.h"
 
 // GELU of a register pair: packed (gelu_sig2) or two scalar gelu_sig (-DS1_SCALAR_GELU: packed fp32 does not issue behind MFMAs)
-#ifdef S1_SCALAR_GELU
+#if defined(S1_NO_GELU)      // timing diagnostics only
+#define S1_GELU2(v) (v)
+#elif defined(S1_SCALAR_GELU)
 #define S1_GELU2(v) (f32x2{gelu_sig((v)[0]), gelu_sig((v)[1])})
 #else
 #define S1_GELU2(v) gelu_sig2(v)
@@ -309,6 +311,9 @@ __global__ __launch_bounds__(1024) void stage1_block2_kernel(const bf16* __restr
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
 
   const int t = threadIdx.x, lane = t & 63;
+#ifdef S1_CLK
+  long long ck0 = __builtin_readcyclecounter(), ckA = 0, ckB = 0, ckP = 0, ckl = 0;
+#endif
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lrow = lane & 15, lq = lane >> 4;
   const int b = blockIdx.x >> 1, hsel = blockIdx.x & 1;
@@ -357,6 +362,9 @@ __global__ __launch_bounds__(1024) void stage1_block2_kernel(const bf16* __restr
   }
   s1_dma_wait();
   __syncthreads();
+#ifdef S1_CLK
+  ckP = __builtin_readcyclecounter() - ck0; ckl = __builtin_readcyclecounter();
+#endif
 
   // P3 ownership: output channels 16 (w & 7) .. +15, m-tiles (w >> 3), +2, ...  (7 tiles for the even half, 6 for the odd)
   const int n3 = w & 7, m3 = w >> 3;
@@ -422,6 +430,9 @@ __global__ __launch_bounds__(1024) void stage1_block2_kernel(const bf16* __restr
     }
     s1_dma_wait();
     __syncthreads();
+#ifdef S1_CLK
+    { long long c = __builtin_readcyclecounter(); ckA += c - ckl; ckl = c; }
+#endif
     // ---- interval B: DMA W1(st+1), W3(st); P2: H2 = GELU(grouped 3x3 conv of H1) for the two groups
     if (st + 1 < NSTEP) dma_w1(st + 1);
     dma_w3(st);
@@ -443,6 +454,9 @@ __global__ __launch_bounds__(1024) void stage1_block2_kernel(const bf16* __restr
     }
     s1_dma_wait();
     __syncthreads();
+#ifdef S1_CLK
+    { long long c = __builtin_readcyclecounter(); ckB += c - ckl; ckl = c; }
+#endif
   }
   p3();
 
@@ -461,6 +475,12 @@ __global__ __launch_bounds__(1024) void stage1_block2_kernel(const bf16* __restr
       store4<bf16>(yout + (size_t)tk * C1, v);
     }
   }
+#ifdef S1_CLK
+  if (t == 0 && (blockIdx.x == 0 || blockIdx.x == 5001)) {
+    const long long c = __builtin_readcyclecounter();
+    printf("[stage1 v3 wg %d] total %lld  prologue %lld  intervals A %lld  B %lld  tail+epilogue %lld\n", (int)blockIdx.x, c - ck0, ckP, ckA, ckB, c - ckl);
+  }
+#endif
 }
 
 bool stage1_fused_supported(int dtype, int C1, int hid, int group, int H1) {
