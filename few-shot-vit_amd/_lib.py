@@ -78,6 +78,7 @@ SIGNATURES = {
     'fsvit_attention': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     'fsvit_qkv_attention': (_i, [_vp, _vp, _i, _fp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     'fsvit_im2col27': (_i, [_fp, _vp, _i, _i, _i, _i, _vp]),
+    'fsvit_stem_conv1': (_i, [_fp, _vp, _i, _fp, _vp, _vp, _i, _i, _i, _vp]),
     'fsvit_maxpool2_pos': (_i, [_vp, _fp, _vp, _i, _i, _i, _i, _i, _vp]),
     'fsvit_pool_affine': (_i, [_vp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     'fsvit_visformer_trainer_create': (_i, [C.POINTER(VisformerCfg), _i, C.POINTER(_vp)]),

@@ -839,6 +839,13 @@ extern "C" int fsvit_im2col27(const float* x, void* out, int B, int H, int W, in
   return 0;
 }
 
+extern "C" int fsvit_stem_conv1(const float* x, const void* w, int kw, const float* bias, void* patches, void* c1, int B, int H, int W, void* stream) {
+  if (!x || !w || !patches || !c1 || kw < 32) return fail(FSVIT_ERR_ARG, "bad argument");
+  if (H != W || !stem_conv1_supported(FSVIT_BF16, H, 64)) return fail(FSVIT_ERR_ARG, "fsvit_stem_conv1: only 80x80 images, 64 output channels (bf16) are built");
+  RC_TRY(launch_stem_conv1(x, patches, c1, w, kw, bias, B, (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int fsvit_maxpool2_pos(const void* in, const float* pos, void* out, int B, int OH, int OW, int C, int dtype, void* stream) {
   if (!in || !out || C % 4) return fail(FSVIT_ERR_ARG, "bad argument");
   RC_TRY(launch_maxpool2_pos(in, pos, out, B, OH, OW, C, dtype, (hipStream_t)stream));

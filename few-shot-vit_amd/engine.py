@@ -432,6 +432,18 @@ class ops:
         return out
 
     @staticmethod
+    def stem_conv1(x, w, bias):
+        """im2col + stem conv1 + LeakyReLU in one pass (stem.hip): x [B,3,80,80] fp32, w [64, kw] bf16 -> (patches [B*1600,32], c1 [B*1600,64])."""
+        _require_cuda(x, w)
+        lib = _lib.load()
+        B, _, H, W = x.shape
+        patches = torch.empty(B * (H // 2) * (W // 2), 32, dtype=w.dtype, device=x.device)
+        c1 = torch.empty(B * (H // 2) * (W // 2), 64, dtype=w.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.fsvit_stem_conv1(_ptr(x.contiguous()), _ptr(w), w.shape[-1], _ptr(bias), _ptr(patches), _ptr(c1), B, H, W, _stream_ptr(x.device)))
+        return patches, c1
+
+    @staticmethod
     def maxpool2_pos(x, pos):
         _require_cuda(x)
         lib = _lib.load()

@@ -196,6 +196,10 @@ int fsvit_adamw_step(float* p_dev, const float* g_dev, float* m_dev, float* v_de
                      float weight_decay, int step, void* stream);
 
 int fsvit_im2col27(const float* x_nchw_dev, void* out_dev, int B, int H, int W, int dtype, void* stream);
+/* im2col27 + stem conv1 + bn1 (folded) + LeakyReLU(0.1) in one pass (visformer.py:209-210,218), bf16, 80x80 images, 64 channels:
+ * patches [B*1600][32] (the rows fsvit_im2col27 writes) and c1 [B*1600][64]; w [64][kw] K-major bf16 with K columns (ky,kx,c), kw >= 32. */
+int fsvit_stem_conv1(const float* x_nchw_dev, const void* w_dev, int kw, const float* bias_dev, void* patches_dev, void* c1_dev,
+                     int B, int H, int W, void* stream);
 int fsvit_maxpool2_pos(const void* in_dev, const float* pos_dev, void* out_dev, int B, int OH, int OW, int C,
                        int dtype, void* stream);
 int fsvit_pool_affine(const void* x_dev, const float* scale_dev, const float* shift_dev, float* feat_dev,

@@ -127,6 +127,29 @@ def test_attention(S, heads, hd, pad, dt):
     assert err <= (2e-5 if dt == 'f32' else 2e-2), (dt, err)
 
 
+def test_stem_conv1_fused_equals_im2col_plus_gemm():
+    """stem_conv1_kernel (im2col + conv1 + LeakyReLU in one pass) against the two-launch path of the same library: the patch rows
+    must be bit-identical, conv1 within bf16 rounding of torch's conv on the bf16-rounded operands."""
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    B = 5
+    x = torch.randn(B, 3, 80, 80, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) / math.sqrt(27)
+    bias = torch.randn(64, generator=g) * 0.2
+    wp = torch.zeros(64, 64)
+    wp[:, :27] = w.permute(0, 2, 3, 1).reshape(64, 27)                          # K order (ky, kx, c)
+    wp = q(wp, bf)
+    patches, c1 = ops.stem_conv1(x.cuda(), wp.to('cuda', bf), bias.cuda())
+    ref_p = ops.im2col27(x.cuda(), bf)
+    torch.cuda.synchronize()
+    assert torch.equal(patches, ref_p)
+    ref = F.conv2d(q(x, bf), q(wp[:, :27].reshape(64, 3, 3, 3).permute(0, 3, 1, 2), bf), bias, stride=2, padding=1)
+    ref = F.leaky_relu(ref, 0.1).permute(0, 2, 3, 1).reshape(B * 1600, 64)
+    err = (c1.float().cpu() - ref).abs().max().item()
+    assert err <= 3e-2, err
+
+
 @pytest.mark.parametrize('B,S,use_bias', [(3, 100, True), (1, 100, False), (300, 100, True), (5, 37, True), (2, 112, True), (7, 97, True), (4, 1, True)])
 def test_qkv_attention_fused_matches_unfused_math(B, S, use_bias):
     """qkv_attn.hip (qkv conv + attention in one launch, qkv kept on chip) against the unfused math with the same bf16 rounding
