@@ -37,16 +37,18 @@ constexpr int C1 = 128, HID = 256, G = 8, CG = 32, W = 20;
 constexpr int NW = 16;                    // waves per workgroup (1024 threads, one workgroup per CU)
 constexpr int XT = 220, XTP = 224;        // input tokens held (11 rows), padded to 14 m-tiles
 constexpr int OT = 200, OTP = 208;        // output tokens (10 rows), padded to 13 m-tiles
-constexpr int PW = 22;                    // zero-bordered H1 pixel grid is 12 x 22
-constexpr int H1_PLANE = 4352;            // 264 pixels * 16 B rounded up to 256
+constexpr int PW = 36;                    // pitch of the zero-bordered H1 pixel grid (12 rows; columns -1 .. 20 used).  36 = 20 + 16: the 16 tokens of an
+                                          // m-tile usually straddle a row end, and with the natural pitch 22 the tokens after the wrap land on the 16-byte
+                                          // slots (mod 16) of the ones before it - 6.5 LDS cycles per ds_read_b128 instead of 4 (tools/lds_conflicts.py)
+constexpr int H1_PLANE = 12 * PW * 16;    // 6912 = 27 * 256: the plane stride stays 0 mod 256 B
 constexpr int H2_PLANE = OTP * 16;        // 3328
 constexpr int OFF_H1 = XTP * 256;                  //  57344
-constexpr int OFF_H2 = OFF_H1 + 4 * H1_PLANE;      //  74752
-constexpr int OFF_W1 = OFF_H2 + 4 * H2_PLANE;      //  88064  [16 k-chunks][32 n][16 B]
-constexpr int OFF_W2 = OFF_W1 + 16 * 32 * 16;      //  96256  [9 taps * 4 k-chunks][32 n][16 B]
-constexpr int OFF_W3 = OFF_W2 + 36 * 32 * 16;      // 114688  [4 k-chunks][128 n][16 B]
-constexpr int OFF_B1 = OFF_W3 + 4 * 128 * 16;      // 122880  conv1 folded bias, 256 fp32
-constexpr int LDS_BYTES = OFF_B1 + HID * 4;        // 123904
+constexpr int OFF_H2 = OFF_H1 + 4 * H1_PLANE;      //  84992
+constexpr int OFF_W1 = OFF_H2 + 4 * H2_PLANE;      //  98304  [16 k-chunks][32 n][16 B]
+constexpr int OFF_W2 = OFF_W1 + 16 * 32 * 16;      // 106496  [9 taps * 4 k-chunks][32 n][16 B]
+constexpr int OFF_W3 = OFF_W2 + 36 * 32 * 16;      // 124928  [4 k-chunks][128 n][16 B]
+constexpr int OFF_B1 = OFF_W3 + 4 * 128 * 16;      // 133120  conv1 folded bias, 256 fp32
+constexpr int LDS_BYTES = OFF_B1 + HID * 4;        // 134144
 constexpr int KW2 = 320;                  // packed conv2 row length (9*32 = 288 rounded up to the 64-element K slice)
 }  // namespace s1
 
