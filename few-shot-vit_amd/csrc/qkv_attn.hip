@@ -245,17 +245,22 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
         float inv[TT];
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
+          // The softmax costs as many issue slots as the head's three GEMM parts: keys are masked only in the key tiles that can reach
+          // past S (a scalar test per tile), and the score scale rides in the exp's argument (one fma) instead of a multiply per score.
           float mx = -INFINITY;
 #pragma unroll
-          for (int kt = 0; kt < NKT; ++kt)
+          for (int kt = 0; kt < NKT; ++kt) {
+            if (kt * 16 + 16 > S) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const bool ok = kt * 16 + lq * 4 + r < S;
-              sc[tt][kt][r] = ok ? sc[tt][kt][r] * sscale : -INFINITY;
-              mx = fmaxf(mx, sc[tt][kt][r]);
+              for (int r = 0; r < 4; ++r)
+                if (kt * 16 + lq * 4 + r >= S) sc[tt][kt][r] = -INFINITY;
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[tt][kt][r]);
+          }
           mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
           mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+          const float mxs = mx * sscale;
           float sum = 0.f;
 #pragma unroll
           for (int kt = 0; kt < NKT; ++kt)
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
 #if defined(QA_DIAG) && (QA_DIAG & 1)       // timing diagnostics only (tools/build_variant.sh)
               const float e = sc[tt][kt][r];
 #else
-              const float e = __builtin_amdgcn_exp2f(sc[tt][kt][r] - mx);  // -inf for masked keys -> 0
+              const float e = __builtin_amdgcn_exp2f(fmaf(sc[tt][kt][r], sscale, -mxs));   // -inf for masked keys -> 0
 #endif
               sc[tt][kt][r] = e;
               sum += e;
