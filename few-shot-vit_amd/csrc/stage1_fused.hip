@@ -498,7 +498,7 @@ int launch_stage1_block(const void* x, void* y, const void* w1, const float* b1,
     attr_set = true;
   }
   static const int ver = [] { const char* e = getenv("FSVIT_STAGE1_V"); return e ? atoi(e) : 1; }();      // 3: stage1_block2_kernel (x in registers, two groups per interval; measured 8 % slower)
-  if (ver >= 3) {
+  if (ver == 3) {
     static bool attr2 = false;
     if (!attr2) {
       hipError_t e = hipFuncSetAttribute((const void*)stage1_block2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, s1b::V3_LDS_BYTES);
