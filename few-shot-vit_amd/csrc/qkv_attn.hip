@@ -66,9 +66,6 @@ __device__ __forceinline__ u32x4 qa_gload16(const void* p) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
-__device__ __forceinline__ void qa_lds_barrier() {      // LDS writes of this wave done, then the workgroup barrier (no vmcnt: the ring stays in flight)
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 __device__ __forceinline__ unsigned qa_pk2(float a, float b) {
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
   const bf16x2_t v = {(bf16)a, (bf16)b};
