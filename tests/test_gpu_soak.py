@@ -1,0 +1,46 @@
+"""Determinism soak (bench-size launches, repeated): the kernels that order LDS-DMA data with counted vmcnt + barriers (mlp_rows,
+qkv_attn) must return bit-identical results run after run.  A wait that is one short shows up as a rare differing tile, which the
+small op tests cannot see (tools/soak.py is the long version)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _repeat(fn, n):
+    ref = fn()
+    torch.cuda.synchronize()
+    assert torch.isfinite(ref.float()).all()
+    bad = sum(0 if torch.equal(fn(), ref) else 1 for _ in range(n))
+    torch.cuda.synchronize()
+    return bad
+
+
+@pytest.mark.parametrize('C,KC,M', [(256, 288, 640000), (512, 576, 160000)])
+def test_mlp_rows_is_deterministic_at_bench_size(C, KC, M):
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    g = torch.Generator(device='cuda').manual_seed(C)
+    rn = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    x, ctx = rn(M, C).to(bf), rn(M, KC).to(bf)
+    wp = (rn(C, KC) / math.sqrt(KC)).to(bf)
+    w1, w2 = (rn(4 * C, C) / math.sqrt(C)).to(bf), (rn(C, 4 * C) / math.sqrt(4 * C)).to(bf)
+    b1 = rn(4 * C) * 0.3
+    assert _repeat(lambda: ops.proj_mlp_rows(x, ctx, wp, w1, b1, w2, None), 40) == 0
+    assert _repeat(lambda: ops.mlp_rows(x, w1, b1, w2, None), 40) == 0
+
+
+def test_qkv_attention_is_deterministic_at_bench_size():
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    B, S, heads, hd, hdp = 6400, 100, 6, 42, 48
+    g = torch.Generator(device='cuda').manual_seed(7)
+    rn = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    x = rn(B * S, 256).to(bf)
+    w = torch.zeros(3, heads, hdp, 256, device='cuda')
+    w[:, :, :hd] = rn(3, heads, hd, 256) / 16.0
+    w = w.reshape(3 * heads * hdp, 256).to(bf)
+    bias = rn(3 * heads * hdp) * 0.3
+    assert _repeat(lambda: ops.qkv_attention(x, w, bias, B, S, heads, hdp, hd ** -0.5), 40) == 0
