@@ -2,22 +2,36 @@
 """Benchmark of the fsvit hot path: BASELINE.json configs[1] — Visformer-S (`visformer_micro_80`)
 5-way 5-shot episodic eval (15 queries/class), bf16 MFMA, synthetic 80x80 episodes resident in HBM.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of `MetaBaseline.forward` (encoder + cosine head, one C-ABI call) over a batch of
-`--episodes` episodes per GPU.  Episodes are independent, so ranks shard them with no data-path
-collective (weak scaling); the only exchange is ONE all-reduce of the accuracy statistics at the end
-of the timed region (RCCL over xGMI), as in the north star.  Rank 0 prints one JSON line.
+N > 1 works both ways: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / WORLD_SIZE in
+the environment: this process IS a rank) and invoked plainly (`python bench.py --gpus N`): the parent then makes NO GPU call,
+starts one fresh child process per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's JSON line and exits
+with the worst child status (never an exec from a process that touched the GPU).
 
-Extra legs (rank 0, N=1 only unless disabled):
-  roofline      per-launch HIP-event timing inside the timed region (engine profile mode) -> the
-                dominant kernel's algorithmic TFLOP/s against the 2.5 PFLOP/s dense bf16 MFMA peak.
-  cpu_baseline  the oracle (oracle/visformer_oracle.py, a port of the reference's CPU path) timed on
-                the host cores over a bounded sample of the same workload.
+A "step" = one pass of `MetaBaseline.forward` (encoder + cosine head, one C-ABI call) over a batch of `--episodes` episodes per
+GPU.  Episodes are independent, so ranks shard them with no data-path collective (weak scaling); the only exchange is ONE
+all-reduce of the accuracy statistics at the end of the timed region (RCCL over xGMI), as in the north star.  Every step of
+the timed region sees a different batch of episodes (a pool generated in HBM before timing), so the reported accuracy and CI
+are over distinct episodes.  Rank 0 prints one JSON line.
+
+Extra legs (rank 0, N = 1 only):
+  roofline      per-launch HIP-event timing inside the timed region (engine profile mode) -> the dominant kernel's
+                algorithmic TFLOP/s against the 2.5 PFLOP/s dense bf16 MFMA peak; HBM traffic / MFMA-busy fraction of that
+                kernel from the committed rocprofv3 PMC passes (profiles/).
+  modes         the other numerics modes over the SAME episode pool (>= 2000 episodes): `parity` (exact-fp32 MFMA, the mode
+                that meets the north star's 1e-3 logit tolerance) throughput against the 157.3 TFLOP/s fp32-MFMA peak.
+  agreement     headline mode vs parity on those episodes: arg-max agreement, per-batch accuracies, |delta mean| vs the CI,
+                max |delta logit|.
+  cpu_baseline  the oracle (oracle/visformer_oracle.py, the pinned port of the reference's CPU path) timed on the host
+                cores over a bounded sample of the SAME episodes, best of a thread-count / ep_per_batch sweep, with its
+                accuracy next to the GPU's on those episodes.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,10 +45,11 @@ import torch.distributed as dist  # noqa: E402
 # algorithmic forward FLOPs per image (2*MAC, SURVEY.md 8d / BASELINE.md 2) and input size per encoder
 MODELS = {'visformer_micro_80': (2.0306e9, 80), 'deit_small_patch16_224': (9.197e9, 224), 'deit_micro_patch6_84': (4.716e9, 84)}
 HEAD_FLOP_PER_EPISODE = 0.38e6
-MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}    # dense peaks, MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'parity': 157.3}    # dense peaks, MI355X_MICROARCH.md
+DTYPE_NAME = {'bf16': 'bf16', 'f16': 'f16', 'parity': 'f32'}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -42,19 +57,95 @@ def parse():
     ap.add_argument('--episodes', type=int, default=64, help='episodes per GPU per step (ep_per_batch)')
     ap.add_argument('--shot', type=int, default=5)
     ap.add_argument('--model', default='visformer_micro_80', choices=sorted(MODELS), help='encoder (default = BASELINE configs[1])')
-    ap.add_argument('--numerics', default='bf16', choices=['bf16', 'parity'])
+    ap.add_argument('--numerics', default='bf16', choices=['bf16', 'f16', 'parity'])
     ap.add_argument('--chunk', type=int, default=int(os.environ.get('FSVIT_CHUNK', 6400)), help='images per encoder chunk')
+    ap.add_argument('--pool', type=int, default=32, help='distinct episode batches generated in HBM before timing (steps cycle through them); '
+                                                         '32 x 64 = 2048 episodes = the configs[1] evaluation size')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--cpu-episodes', type=int, default=16)
+    ap.add_argument('--no-modes', action='store_true', help='skip the parity-mode leg and the agreement figures')
+    ap.add_argument('--cpu-episodes', type=int, default=12)
     ap.add_argument('--layers', action='store_true', help='print the per-layer timing table to stderr')
     ap.add_argument('--mode', default='eval', choices=['eval', 'train'],
                     help="eval = BASELINE configs[1] (the headline metric); train = configs[2], one SUN-M meta-tuning step "
                          "(train_meta_mini_visformer_5shot.yaml geometry: 8 episodes x 10-way (5 shot + 5 query) = 800 images)")
     ap.add_argument('--train-episodes', type=int, default=8, help='train mode: episodes per GPU per step (ep_per_batch)')
-    return ap.parse_args()
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl == RCCL over xGMI; gloo only with --selftest-launcher')
+    ap.add_argument('--selftest-launcher', action='store_true',
+                    help='exercise the rank launcher and the timing / statistics exchange on the CPU (gloo), no GPU work: tests/test_bench_launcher_cpu.py')
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------ rank launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N rank processes from this (GPU-untouched) parent."""
+    n = args.gpus
+    if args.backend == 'nccl':
+        have = torch.cuda.device_count()          # counts devices without initialising HIP (never torch.cuda.is_available() here)
+        if have < n:
+            sys.stderr.write(f'bench.py --gpus {n}: only {have} GPU(s) visible on this node - one rank per GPU is required '
+                             f'(run with --gpus <= {max(have, 1)})\n')
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: required for RCCL between processes on this driver
+        # rank 0 writes the JSON line straight to our stdout; anything the other ranks print goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    deadline = None
+    while procs:
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                deadline = time.time() + 30.0          # a rank died: the others would wait in a collective for ever
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                p.kill()
+        time.sleep(0.05)
+    return rc
+
+
+def selftest_worker(args, rank, world):
+    """The distributed skeleton of the bench without the GPU: barrier, K 'steps', the statistics all-reduce, max-over-ranks time."""
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    accs = torch.tensor([0.25 + 0.5 * ((rank * 31 + s * 7) % 11) / 11.0 for s in range(args.steps)], dtype=torch.float64)
+    stats = torch.stack([accs.sum(), (accs * accs).sum(), torch.tensor(float(accs.numel()), dtype=torch.float64)])
+    if world > 1:
+        dist.all_reduce(stats)
+        dist.barrier()
+    elapsed = time.perf_counter() - t0 + 0.001 * rank
+    tt = torch.tensor([elapsed], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({'selftest': True, 'n_gpus': world, 'steps': args.steps, 'stat_n': float(stats[2]), 'stat_sum': float(stats[0]),
+                          'elapsed_max_s': float(tt[0]), 'backend': 'gloo'}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ workload
 def device_episodes(seed, n_ep, way, shot, query, dev, img=80):
     """Class-structured synthetic episodes generated directly in HBM (x = mu_c + 1.5*eps, so accuracy
     is neither chance nor saturated); layout = what fs.split_shot_query returns."""
@@ -67,36 +158,74 @@ def device_episodes(seed, n_ep, way, shot, query, dev, img=80):
     return x_shot, x_query
 
 
-def cpu_baseline(sd, shot, n_ep, model='visformer_micro_80'):
-    """Oracle timed at ep_per_batch=1 (the reference's test setting, test_few_shot.py:47-48)."""
-    from fewshot_vit_amd import synthetic
-    from fewshot_vit_amd.utils import few_shot as fs
+def _physical_cores():
+    try:
+        import psutil
+        return psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        return os.cpu_count()
+
+
+def cpu_baseline(sd, xs_all, xq_all, gpu_logits, n_ep, model='visformer_micro_80'):
+    """The oracle on the host cores over the FIRST episodes of the GPU leg's pool (same tensors, copied to the host).  Thread count
+    and ep_per_batch are swept first (2 episodes per setting; the reference's own setting is ep_per_batch=1, test_few_shot.py:47-48),
+    then `n_ep` episodes are timed at the best setting.  Accuracy and logits of those episodes are compared with the GPU's."""
     from oracle import visformer_oracle as vo
-    cores = torch.get_num_threads()
-    img = MODELS[model][1]
-    x = synthetic.synthetic_episodes(12345, 1, 5, shot, 15, img=img)
-    xs, xq = fs.split_shot_query(x, 5, shot, 15, 1)
+    img = xs_all.shape[-1]
+    shot = xs_all.shape[2]
     if model == 'visformer_micro_80':
         cfg = vo.VisformerCfg()
-        run = lambda: vo.meta_baseline_forward(sd, xs, xq, cfg)
+
+        def run(xs, xq):
+            return vo.meta_baseline_forward(sd, xs, xq, cfg)
     else:
         from oracle import deit_oracle as do
         cfg = do.FACTORIES[model]
 
-        def run():
+        def run(xs, xq):
+            E = xs.shape[0]
             with torch.no_grad():
                 f = do.deit_forward(sd, torch.cat([xs.reshape(-1, 3, img, img), xq.reshape(-1, 3, img, img)]), cfg, prefix='encoder.')
-            n = xs.shape[1] * xs.shape[2]
-            return vo.meta_baseline_head(f[:n].reshape(1, 5, shot, -1), f[n:].reshape(1, 75, -1), temp=10.0)
-    for _ in range(2):
-        run()
+            n = E * xs.shape[1] * xs.shape[2]
+            return vo.meta_baseline_head(f[:n].reshape(E, 5, shot, -1), f[n:].reshape(E, 75, -1), temp=10.0)
+
+    def rate(threads, epb, n):
+        torch.set_num_threads(threads)
+        run(xs_all[:epb], xq_all[:epb])                                     # warm-up at this setting
+        t0 = time.perf_counter()
+        for e in range(0, n, epb):
+            run(xs_all[e:e + epb], xq_all[e:e + epb])
+        return n / (time.perf_counter() - t0)
+
+    logical, physical = os.cpu_count() or 1, _physical_cores() or 1
+    cand = sorted({t for t in (8, 16, 32, 64, 128, physical) if t <= logical} or {logical})
+    sweep = {}
+    for t in cand:
+        sweep['%dthr_epb1' % t] = rate(t, 1, 2)
+    best_t = max(cand, key=lambda t: sweep['%dthr_epb1' % t])
+    epb4 = 4 if xs_all.shape[0] >= 4 else 1
+    if epb4 > 1:
+        sweep['%dthr_epb%d' % (best_t, epb4)] = rate(best_t, epb4, epb4)
+    best_epb = epb4 if epb4 > 1 and sweep['%dthr_epb%d' % (best_t, epb4)] > sweep['%dthr_epb1' % best_t] else 1
+    torch.set_num_threads(best_t)
+    n_ep = max(best_epb, n_ep - n_ep % best_epb)
+    outs = []
     t0 = time.perf_counter()
-    for _ in range(n_ep):
-        run()
+    for e in range(0, n_ep, best_epb):
+        outs.append(run(xs_all[e:e + best_epb], xq_all[e:e + best_epb]))
     dt = time.perf_counter() - t0
-    return {'value': n_ep / dt, 'unit': 'episodes/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n_ep} episodes 5-way {shot}-shot (100 images each at 5-shot), ep_per_batch=1, fp32 torch CPU '
-                      f'oracle, 2 warm-up episodes, {dt:.1f} s'}
+    logits = torch.cat(outs)                                                  # [n_ep, 75, way]
+    way, Q = logits.shape[-1], logits.shape[1]
+    label = torch.arange(way).repeat_interleave(Q // way)
+    acc_cpu = (logits.argmax(-1) == label).float().mean().item()
+    g = gpu_logits[:n_ep].cpu()
+    acc_gpu = (g.argmax(-1) == label).float().mean().item()
+    return {'value': n_ep / dt, 'unit': 'episodes/s', 'cores': best_t, 'kind': 'port',
+            'sample': f'{n_ep} episodes 5-way {shot}-shot ({way * (shot + Q // way)} images each) = the first {n_ep} episodes of the GPU leg, fp32 torch CPU oracle, '
+                      f'ep_per_batch={best_epb}, {best_t} threads (host: {physical} physical / {logical} logical cores), best of the sweep below, {dt:.1f} s',
+            'sweep_episodes_per_s': sweep, 'accuracy': acc_cpu, 'gpu_accuracy_same_episodes': acc_gpu,
+            'gpu_max_abs_dlogit_same_episodes': (g - logits).abs().max().item(),
+            'gpu_argmax_agreement_same_episodes': (g.argmax(-1) == logits.argmax(-1)).float().mean().item()}
 
 
 def cpu_train_baseline(sd, n_ep=1):
@@ -111,6 +240,8 @@ def cpu_train_baseline(sd, n_ep=1):
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))}
     full = {k: v.clone() for k, v in sd.items()}
     full.update(params)
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
 
     def run():
         for p in params.values():
@@ -123,9 +254,23 @@ def cpu_train_baseline(sd, n_ep=1):
     for _ in range(reps):
         run()
     dt = time.perf_counter() - t0
-    return {'value': reps * n_ep / dt, 'unit': 'episodes/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+    return {'value': reps * n_ep / dt, 'unit': 'episodes/s', 'cores': threads, 'kind': 'port',
             'sample': f'{reps} x forward+backward of {n_ep} episode(s) 10-way 5-shot 5-query (100 images each), fp32 torch CPU oracle '
                       f'with autograd, no optimizer step, 1 warm-up, {dt:.1f} s'}
+
+
+def _barrier(world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _max_over_ranks(elapsed, world, dev):
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed
 
 
 def train_main(args, rank, world, dev):
@@ -152,111 +297,114 @@ def train_main(args, rank, world, dev):
         opt.step()
         return loss
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
-    barrier()
+    _barrier(world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    _barrier(world)
+    elapsed = _max_over_ranks(time.perf_counter() - t0, world, dev)
     if rank == 0:
         imgs = way * (shot + query)
         eps = world * E * args.steps / elapsed
         flops_ep = 3.0 * MODELS['visformer_micro_80'][0] * imgs          # forward + dgrad + wgrad
-        peak = MFMA_PEAK_TFLOPS['bf16' if args.numerics == 'bf16' else 'f32']
+        peak = MFMA_PEAK_TFLOPS[args.numerics]
         out = {'metric': 'train_episodes_per_sec_10way_5shot_visformer_s', 'value': eps, 'unit': 'episodes/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if args.numerics == 'bf16' else 'f32', 'data': 'synthetic',
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE_NAME[args.numerics], 'data': 'synthetic',
                'config': {'workload': 'BASELINE configs[2]: SUN-M train_meta.py meta-tuning step, Visformer-S (visformer_micro_80, '
                                       'drop_path 0.5), ep_per_batch episodes of 10-way 5-shot 5-query 80x80 (train_meta_mini_visformer_5shot.yaml), '
                                       'forward + CE + backward + SGD(0.9, wd 5e-4), episodes resident in HBM',
                           'episodes_per_step_per_gpu': E, 'images_per_episode': imgs,
                           'parallelism': 'episode axis sharded x%d, one all-reduce of the flattened gradients per step' % world},
                'whole_path_tflops': eps * flops_ep / 1e12, 'whole_path_mfma_frac': eps * flops_ep / 1e12 / peak,
+               'roofline': {'bound': 'mfma', 'achieved': eps * flops_ep / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
+                            'frac': eps * flops_ep / 1e12 / peak, 'traffic': None, 'kernel': 'whole training step (forward + backward + SGD)'},
                'final_loss': float(loss)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_train_baseline(sd)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
-        args.gpus = world
-    if not torch.cuda.is_available():
-        sys.exit('bench.py needs an MI355X: the fsvit hot path has no CPU fallback')
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+def _committed_pmc(dom_kernel):
+    """HBM bytes per launch and MFMA-busy fraction of the dominant kernel from the newest committed rocprofv3 PMC summaries
+    (profiles/r*_hbm_traffic.json, profiles/r*_mfma_pmc.json; separate --pmc passes of this same command)."""
+    import glob
+    import re
 
-    if args.mode == 'train':
-        train_main(args, rank, world, dev)
-        if world > 1:
-            dist.destroy_process_group()
-        return
+    def newest(pattern):
+        fs_ = sorted(glob.glob(os.path.join(REPO, 'profiles', pattern)),
+                     key=lambda p: [int(x) if x.isdigit() else x for x in re.split(r'(\d+)', os.path.basename(p))])
+        return fs_[-1] if fs_ else None
 
+    def pick(tj):
+        return [k for k in tj if k == dom_kernel] or [k for k in tj if k.split('<')[0] == dom_kernel.split('<')[0]]
+    traffic = busy = None
+    tf = newest('r*_hbm_traffic.json')
+    if tf:
+        with open(tf) as f:
+            tj = json.load(f)
+        cand = pick(tj)
+        if cand:      # several template instantiations behind one kernel name (conv2 / conv3 of the stem): launch-weighted mean
+            n = sum(tj[k].get('launches', 1) for k in cand)
+            traffic = sum(tj[k].get('launches', 1) * tj[k].get('hbm_bytes_per_launch', 0.0) for k in cand) / n
+    mf = newest('r*_mfma_pmc.json')
+    if mf:
+        with open(mf) as f:
+            mj = json.load(f)
+        cand = pick(mj)
+        if cand:
+            n = sum(mj[k].get('launches', 1) for k in cand)
+            busy = sum(mj[k].get('launches', 1) * mj[k].get('mfma_busy', 0.0) for k in cand) / n
+    return traffic, busy
+
+
+def eval_main(args, rank, world, dev):
     from fewshot_vit_amd import models, synthetic
     os.environ['FSVIT_CHUNK'] = str(args.chunk)
     flop_per_image, img = MODELS[args.model]
-    model = models.make('meta-baseline', encoder=args.model, encoder_args={'numerics': args.numerics})
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    # procedural weights by key name (+ the shipped BN calibration for the Visformer)
-    sd = synthetic.synthetic_checkpoint_sd(shapes, calib=args.model if args.model == 'visformer_micro_80' else None)
-    model.load_state_dict(sd, strict=True)
-    model = model.to(dev).eval()
-    engine = model.encoder.engine()
 
+    def build(numerics):
+        m = models.make('meta-baseline', encoder=args.model, encoder_args={'numerics': numerics})
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        # procedural weights by key name (+ the shipped BN calibration for the Visformer)
+        sd_ = synthetic.synthetic_checkpoint_sd(shapes, calib=args.model if args.model == 'visformer_micro_80' else None)
+        m.load_state_dict(sd_, strict=True)
+        m = m.to(dev).eval()
+        return m, sd_, m.encoder.engine()
+
+    model, sd, engine = build(args.numerics)
     way, query, E = 5, 15, args.episodes
-    x_shot, x_query = device_episodes(12345 + rank, E, way, args.shot, query, dev, img)
+    want_full_pool = world == 1 and not args.no_modes               # the agreement leg wants >= 2000 distinct episodes
+    n_pool = args.pool if want_full_pool else min(args.pool, args.steps)
+    batch_bytes = E * way * (args.shot + query) * 3 * img * img * 4
+    n_pool = max(1, min(n_pool, int(24e9 // batch_bytes)))          # at most 24 GB of episodes per GPU (224x224 encoders)
+    pool = [device_episodes(12345 + 1000 * rank + i, E, way, args.shot, query, dev, img) for i in range(n_pool)]
     temp = float(model.temp.detach())
 
-    def step():
-        return engine.meta_baseline_forward(x_shot, x_query, temp, 'cos', want_stats=True)
+    def step(eng, i):
+        xs, xq = pool[i % n_pool]
+        return eng.meta_baseline_forward(xs, xq, temp, 'cos', want_stats=True)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(engine, i)
     profile = (not args.no_roofline) and rank == 0
     accs = []
-    barrier()
+    _barrier(world)
     if profile:
         engine.profile_begin()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        _, acc, _ = step()
+    for i in range(args.steps):
+        _, acc, _ = step(engine, i)
         accs.append(acc)
     # the one exchange of the path: all-reduce of (sum acc, sum acc^2, n) -> mean accuracy +- CI
-    acc_all = torch.stack(accs).double().flatten()
+    acc_all = torch.stack(accs[:n_pool]).double().flatten()                    # distinct episodes only
     stats = torch.stack([acc_all.sum(), (acc_all * acc_all).sum(), torch.tensor(float(acc_all.numel()), device=dev, dtype=torch.float64)])
     if world > 1:
         dist.all_reduce(stats)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    _barrier(world)
+    elapsed = _max_over_ranks(time.perf_counter() - t0, world, dev)
     recs = engine.profile_end() if profile else None
 
     n = float(stats[2].item())
@@ -264,70 +412,133 @@ def main():
     var = max(0.0, (float(stats[1].item()) - n * mean * mean) / max(1.0, n - 1.0))
     import scipy.stats
     ci = (var / n) ** 0.5 * float(scipy.stats.t.ppf(0.975, max(1.0, n - 1.0)))
+    if rank != 0:
+        return
 
-    if rank == 0:
-        total_eps = world * E * args.steps
-        eps = total_eps / elapsed
-        imgs = way * (args.shot + query)
-        flops_ep = flop_per_image * imgs + HEAD_FLOP_PER_EPISODE
-        out = {
-            'metric': 'episodes_per_sec_5way_%dshot_%s' % (args.shot, 'visformer_s' if args.model == 'visformer_micro_80' else args.model), 'value': eps, 'unit': 'episodes/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16' if args.numerics == 'bf16' else 'f32', 'data': 'synthetic',
-            'config': {'workload': ('BASELINE configs[1]: Visformer-S (visformer_micro_80) miniImageNet-shaped 5-way %d-shot '
-                                    'episodic eval, 15 query/class, 80x80 fp32 NCHW episodes resident in HBM, procedural weights + '
-                                    'calibrated BN' % args.shot) if args.model == 'visformer_micro_80' else
-                                   ('BASELINE configs[4] shape: %s, %dx%d, 5-way %d-shot episodic eval, 15 query/class, synthetic episodes '
-                                    'resident in HBM, procedural weights' % (args.model, img, img, args.shot)),
-                       'episodes_per_step_per_gpu': E, 'images_per_episode': imgs, 'encoder_chunk_images': args.chunk,
-                       'parallelism': 'episode-parallel x%d, one all-reduce of accuracy stats' % world},
-            'whole_path_tflops': eps * flops_ep / 1e12,
-            'whole_path_mfma_frac': eps * flops_ep / 1e12 / MFMA_PEAK_TFLOPS['bf16' if args.numerics == 'bf16' else 'f32'],
-            'accuracy': {'mean': mean, 'ci95': ci, 'episodes': int(n)},
-        }
-        if recs:
-            bykern = {}
-            for r in recs:
-                k = bykern.setdefault(r['kernel'], {'ms': 0.0, 'flops': 0.0, 'launches': 0})
-                k['ms'] += r['ms']
-                k['flops'] += r['flops']
-                k['launches'] += r['launches']
-            dom = max(bykern, key=lambda k: bykern[k]['ms'])
-            d = bykern[dom]
-            peak = MFMA_PEAK_TFLOPS['bf16' if args.numerics == 'bf16' else 'f32']
-            achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
-            traffic = None          # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/)
-            import glob
-            import re
-            tfs = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_hbm_traffic.json')),      # newest committed PMC passes (r01_v10 after r01_v9)
-                         key=lambda p: [int(x) if x.isdigit() else x for x in re.split(r'(\d+)', os.path.basename(p))])
-            if tfs and args.model == 'visformer_micro_80' and args.numerics == 'bf16' and E == 64 and args.chunk == 6400 and args.mode == 'eval':
-                with open(tfs[-1]) as f:
-                    tj = json.load(f)
-                cand = [k for k in tj if k == dom] or [k for k in tj if k.split('<')[0] == dom.split('<')[0]]
-                if cand:       # several template instantiations behind one kernel name (conv2 / conv3 of the stem): launch-weighted mean
-                    n = sum(tj[k].get('launches', 1) for k in cand)
-                    traffic = sum(tj[k].get('launches', 1) * tj[k].get('hbm_bytes_per_launch', 0.0) for k in cand) / n
-            out['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                               'traffic': traffic, 'kernel': dom, 'launches': d['launches'],
-                               'avg_launch_us': 1e3 * d['ms'] / d['launches'],
-                               'avg_launch_gflop': d['flops'] / d['launches'] / 1e9,
-                               'share_of_gpu_time': d['ms'] / sum(k['ms'] for k in bykern.values())}
-            out['kernels'] = {k: {'ms_per_step': v['ms'] / args.steps, 'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0,
-                                  'launches_per_step': v['launches'] / args.steps} for k, v in bykern.items()}
-            if args.layers:
-                tot = sum(r['ms'] for r in recs)
-                for r in sorted(recs, key=lambda r: -r['ms']):
-                    tf = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
-                    print(f"  {r['layer']:<22} {r['kernel']:<40} {r['ms'] / args.steps:8.3f} ms/step {100 * r['ms'] / tot:5.1f}%  {tf:7.1f} TF/s",
-                          file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(sd, args.shot, args.cpu_episodes, args.model)
-        print(json.dumps(out))
+    total_eps = world * E * args.steps
+    eps = total_eps / elapsed
+    imgs = way * (args.shot + query)
+    flops_ep = flop_per_image * imgs + HEAD_FLOP_PER_EPISODE
+    out = {
+        'metric': 'episodes_per_sec_5way_%dshot_%s' % (args.shot, 'visformer_s' if args.model == 'visformer_micro_80' else args.model), 'value': eps, 'unit': 'episodes/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': DTYPE_NAME[args.numerics], 'data': 'synthetic',
+        'config': {'workload': ('BASELINE configs[1]: Visformer-S (visformer_micro_80) miniImageNet-shaped 5-way %d-shot '
+                                'episodic eval, 15 query/class, 80x80 fp32 NCHW episodes resident in HBM, procedural weights + '
+                                'calibrated BN' % args.shot) if args.model == 'visformer_micro_80' else
+                               ('BASELINE configs[4] shape: %s, %dx%d, 5-way %d-shot episodic eval, 15 query/class, synthetic episodes '
+                                'resident in HBM, procedural weights' % (args.model, img, img, args.shot)),
+                   'episodes_per_step_per_gpu': E, 'images_per_episode': imgs, 'encoder_chunk_images': args.chunk,
+                   'distinct_episode_batches': n_pool,
+                   'parallelism': 'episode-parallel x%d, one all-reduce of accuracy stats' % world},
+        'whole_path_tflops': eps * flops_ep / 1e12,
+        'whole_path_mfma_frac': eps * flops_ep / 1e12 / MFMA_PEAK_TFLOPS[args.numerics],
+        'accuracy': {'mean': mean, 'ci95': ci, 'episodes': int(n)},
+    }
+    if recs:
+        bykern = {}
+        for r in recs:
+            k = bykern.setdefault(r['kernel'], {'ms': 0.0, 'flops': 0.0, 'launches': 0})
+            k['ms'] += r['ms']
+            k['flops'] += r['flops']
+            k['launches'] += r['launches']
+        dom = max(bykern, key=lambda k: bykern[k]['ms'])
+        d = bykern[dom]
+        peak = MFMA_PEAK_TFLOPS[args.numerics]
+        achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        traffic = busy = None
+        if args.model == 'visformer_micro_80' and args.numerics == 'bf16' and E == 64 and args.chunk == 6400:
+            traffic, busy = _committed_pmc(dom)
+        out['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                           'traffic': traffic, 'mfma_busy': busy, 'kernel': dom, 'launches': d['launches'],
+                           'avg_launch_us': 1e3 * d['ms'] / d['launches'],
+                           'avg_launch_gflop': d['flops'] / d['launches'] / 1e9,
+                           'share_of_gpu_time': d['ms'] / sum(k['ms'] for k in bykern.values())}
+        out['kernels'] = {k: {'ms_per_step': v['ms'] / args.steps, 'tflops': (v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] > 0 else 0.0,
+                              'launches_per_step': v['launches'] / args.steps} for k, v in bykern.items()}
+        if args.layers:
+            tot = sum(r['ms'] for r in recs)
+            for r in sorted(recs, key=lambda r: -r['ms']):
+                tf = r['flops'] / (r['ms'] * 1e-3) / 1e12 if r['ms'] > 0 else 0.0
+                print(f"  {r['layer']:<22} {r['kernel']:<40} {r['ms'] / args.steps:8.3f} ms/step {100 * r['ms'] / tot:5.1f}%  {tf:7.1f} TF/s",
+                      file=sys.stderr)
+
+    need_logits = world == 1 and (not args.no_modes or not args.no_cpu_baseline)
+    head_logits = None
+    if need_logits:                       # untimed: the headline mode's logits over the whole pool
+        head_logits = torch.cat([step(engine, i)[0] for i in range(n_pool)])
+        torch.cuda.synchronize()
+    if world == 1 and not args.no_modes and args.model == 'visformer_micro_80' and args.numerics != 'parity':
+        label = torch.arange(way, device=dev).repeat_interleave(query)
+        _, _, peng = build('parity')
+        step(peng, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        plog = [step(peng, i)[0] for i in range(n_pool)]
+        torch.cuda.synchronize()
+        pel = time.perf_counter() - t0
+        plog = torch.cat(plog)
+        peps = n_pool * E / pel
+        out['modes'] = {'parity': {'value': peps, 'unit': 'episodes/s', 'ms_per_step': 1e3 * pel / n_pool, 'steps': n_pool, 'dtype': 'f32',
+                                   'whole_path_tflops': peps * flops_ep / 1e12,
+                                   'whole_path_mfma_frac': peps * flops_ep / 1e12 / MFMA_PEAK_TFLOPS['parity'],
+                                   'note': 'exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): the mode that meets the 1e-3 logit tolerance against the reference '
+                                           '(tests/test_gpu_visformer.py); same episode pool as the headline leg'}}
+        ah = (head_logits.argmax(-1) == label).float().view(n_pool, -1).mean(dim=1).double()    # per reference batch (= one step of E episodes)
+        ap = (plog.argmax(-1) == label).float().view(n_pool, -1).mean(dim=1).double()
+        eh = (head_logits.argmax(-1) == label).float().mean(dim=1).double()                        # per episode
+        ep = (plog.argmax(-1) == label).float().mean(dim=1).double()
+        ne = float(eh.numel())
+        cih = float(eh.std(unbiased=True)) / ne ** 0.5 * float(scipy.stats.t.ppf(0.975, ne - 1.0)) if ne > 1 else float('nan')
+        out['agreement'] = {'modes': [args.numerics, 'parity'], 'episodes': int(ne),
+                            'argmax_agreement': (head_logits.argmax(-1) == plog.argmax(-1)).float().mean().item(),
+                            'accuracy_' + args.numerics: float(eh.mean()), 'accuracy_parity': float(ep.mean()),
+                            'abs_delta_mean_accuracy': abs(float(eh.mean()) - float(ep.mean())), 'ci95_per_episode': cih,
+                            'max_abs_delta_batch_accuracy': float((ah - ap).abs().max()),
+                            'max_abs_dlogit': (head_logits - plog).abs().max().item(),
+                            'mean_abs_dlogit': (head_logits - plog).abs().mean().item()}
+        del peng
+    if world == 1 and not args.no_cpu_baseline:
+        k = min(E, max(4, args.cpu_episodes))
+        out['cpu_baseline'] = cpu_baseline(sd, pool[0][0][:k].cpu(), pool[0][1][:k].cpu(), head_logits[:k], args.cpu_episodes, args.model)
+    print(json.dumps(out), flush=True)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    in_launcher = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
+    if not in_launcher and args.gpus > 1:
+        return launch_ranks(args, argv)
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    args.gpus = world
+    if args.selftest_launcher:
+        return selftest_worker(args, rank, world)
+    if args.backend != 'nccl':
+        sys.stderr.write('bench.py: --backend gloo is for --selftest-launcher only (the fsvit hot path runs on MI355X GPUs over RCCL)\n')
+        return 2
+    if not torch.cuda.is_available():
+        sys.stderr.write('bench.py needs an MI355X: the fsvit hot path has no CPU fallback\n')
+        return 2
+    if local >= torch.cuda.device_count():
+        sys.stderr.write(f'bench.py: rank {rank} has no GPU (LOCAL_RANK {local}, {torch.cuda.device_count()} visible)\n')
+        return 2
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+    if args.mode == 'train':
+        train_main(args, rank, world, dev)
+    else:
+        eval_main(args, rank, world, dev)
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -10,6 +10,15 @@ import torch
 from .engine import ops
 
 
+def _check_generation(ctx):
+    """The trainer keeps ONE set of saved activations: a second train-mode forward on the same encoder before this backward has
+    overwritten them (separate shot / query passes, several micro-batches per backward) - fail loudly instead of returning gradients
+    of the wrong batch."""
+    if ctx.trainer.generation != ctx.generation:
+        raise RuntimeError('fsvit: the encoder ran another train-mode forward before this backward; its saved activations are gone '
+                           '(one forward per backward: encode cat([shot, query]) in one call as MetaBaseline.forward does)')
+
+
 class VisformerTrainFn(torch.autograd.Function):
     """feat = encoder(x) in train mode.  `params` are passed as inputs so autograd routes their gradients."""
 
@@ -18,12 +27,13 @@ class VisformerTrainFn(torch.autograd.Function):
         tensors = dict(zip(names, params))
         tensors.update(buffers)
         feat = trainer.forward(tensors, x, drop_path_rate, masks)
-        ctx.trainer, ctx.names, ctx.buffers = trainer, names, buffers
+        ctx.trainer, ctx.names, ctx.buffers, ctx.generation = trainer, names, buffers, trainer.generation
         ctx.save_for_backward(*params)
         return feat
 
     @staticmethod
     def backward(ctx, dfeat):
+        _check_generation(ctx)
         params = ctx.saved_tensors
         tensors = dict(zip(ctx.names, params))
         grads = {k: torch.empty_like(v) for k, v in tensors.items()}
@@ -42,12 +52,13 @@ class VisformerTrainMapFn(torch.autograd.Function):
         tensors.update(buffers)
         feat = trainer.forward(tensors, x, drop_path_rate, masks)
         tokens = trainer.tokens(x.shape[0], n_tok)
-        ctx.trainer, ctx.names, ctx.buffers = trainer, names, buffers
+        ctx.trainer, ctx.names, ctx.buffers, ctx.generation = trainer, names, buffers, trainer.generation
         ctx.save_for_backward(*params)
         return tokens, feat
 
     @staticmethod
     def backward(ctx, dtokens, dfeat):
+        _check_generation(ctx)
         params = ctx.saved_tensors
         tensors = dict(zip(ctx.names, params))
         grads = {k: torch.empty_like(v) for k, v in tensors.items()}

@@ -57,7 +57,6 @@ struct ConvGemmParams {
 
 // dtype: 0 = f32 (exact fp32 MFMA), 1 = bf16.  Returns hipError_t as int.
 int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream);
-int launch_conv_gemm_v1(const ConvGemmParams& p, int dtype, hipStream_t stream);
 int launch_conv_gemm_v2(const ConvGemmParams& p, int dtype, hipStream_t stream);
 // gemm256.hip: 256x256-tile, 8-wave, 4-phase dense bf16 GEMM for plain [M][K] x [N][K] layers (N >= 192, K % 64 == 0)
 bool gemm256_eligible(const ConvGemmParams& p, int dtype);

@@ -1,8 +1,7 @@
 // Implicit-GEMM convolution, v2: persistent workgroups + direct-to-LDS (LDS-DMA) staging.
 //
-// Same math, operand layouts, fragment mapping and epilogue as conv_gemm.hip (v1); what changes is
-// the data movement, which is what bounded v1 (rocprof r01_v1: 515 TF/s at K=N=2048, 100-260 TF/s on
-// the K<=256 layers):
+// Round 1's first kernel (register-staged, one tile per workgroup; rocprof r01_v1: 515 TF/s at K=N=2048,
+// 100-260 TF/s on the K<=256 layers) was bound by its data movement, which is what this design is about:
 //   * both operand tiles are staged with `global_load_lds_dwordx4` (16 B per lane, 1 KiB per wave
 //     instruction, no VGPR round trip, no ds_write pass).  The LDS image is lane-linear, so the
 //     (row & 7) XOR swizzle that keeps ds_read_b128 conflict-free is applied to the per-lane SOURCE
@@ -385,6 +384,14 @@ int launch_conv_gemm_v2(const ConvGemmParams& p, int dtype, hipStream_t stream) 
   if (p.M <= 0) return 0;
   if (p.pool2 && (p.res || p.y_rpi || (p.OH & 1) || (p.OW & 1) || p.stride != 1)) return (int)hipErrorInvalidValue;
   return dtype == 0 ? launch_v2_t<float>(p, stream) : launch_v2_t<bf16>(p, stream);
+}
+
+// The dispatcher every conv / GEMM launch goes through: the LDS-resident halo kernel for the stem's 3x3 convs, the 256x256 tile for
+// the dense 1x1 layers, this file's persistent implicit GEMM for everything else.
+int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream) {
+  if (conv3x3_halo_eligible(p, dtype)) return launch_conv3x3_halo(p, stream);
+  if (gemm256_eligible(p, dtype)) return launch_gemm256(p, stream);
+  return launch_conv_gemm_v2(p, dtype, stream);
 }
 
 }  // namespace fsvit

@@ -736,6 +736,22 @@ extern "C" int fsvit_conv_gemm(const void* x, const void* w, const float* bias, 
   return 0;
 }
 
+/* The stem's fused tail (visformer.py:213,224-237 + :431): out = MaxPool2d(2)(LeakyReLU(conv3x3(x, w[:, :9*Cin]) + x2 . w[:, Kmain:] + bias)) + pos
+ * - conv3 + bn3 with the downsample conv + bn_d riding as ONE extra K slice over the im2col rows x2, pooled and position-embedded in the
+ * epilogue.  Routed exactly as the engine routes it (conv3x3_halo_kernel<128,true> for the Visformer-S geometry, conv_gemm_v2 otherwise). */
+extern "C" int fsvit_conv_stem_tail(const void* x, const void* w, const float* bias, const float* pos, const void* x2, int x2_cstride, int K2,
+                                    void* y, int B, int H, int W, int Cin, int N, int Kw, int dtype, void* stream) {
+  if (!x || !w || !y || !x2 || !pos) return fail(FSVIT_ERR_ARG, "null argument");
+  const int es = dtype == FSVIT_F32 ? 4 : 2, epc = 16 / es, bke = 128 / es;
+  if (Cin % epc || !is_pow2(Cin) || N % 4 || Kw % bke || Kw < 9 * Cin + bke || K2 > bke || x2_cstride < K2 || (H & 1) || (W & 1))
+    return fail(FSVIT_ERR_ARG, "fsvit_conv_stem_tail: bad geometry");
+  Layer L; L.w = const_cast<void*>(w); L.bias = const_cast<float*>(bias); L.N = N; L.K = 9 * Cin; L.Kw = Kw; L.groups = 1;
+  ConvGemmParams p = conv_params(L, x, y, B, H, W, Cin, Cin, 3, 3, 1, 1, N, ACT_LRELU, nullptr, 0, pos);
+  p.x2 = x2; p.x2_cstride = x2_cstride; p.K2 = K2; p.pool2 = 1;
+  RC_TRY(launch_conv_gemm(p, dtype, (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int fsvit_stage1_block(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, void* stream) {
   if (!x || !y || !w1 || !b1 || !w2 || !w3 || x == y) return fail(FSVIT_ERR_ARG, "bad argument");
   hipStream_t st = (hipStream_t)stream;
@@ -787,7 +803,7 @@ extern "C" int fsvit_linear_forward(const float* x, const float* w, const float*
 }
 extern "C" int fsvit_linear_backward(const float* dy, const float* x, const float* w, float* dx, int accumulate_dx, float* dw, float* db,
                                      int M, int N, int K, void* stream) {
-  if (!dy || (dx && !w) || (dw && !x) || N > 256 || N <= 0 || K <= 0) return fail(FSVIT_ERR_ARG, "fsvit_linear_backward: bad argument (N <= 256)");
+  if (!dy || (dx && !w) || (dw && !x) || N <= 0 || K <= 0) return fail(FSVIT_ERR_ARG, "fsvit_linear_backward: bad argument");
   RC_TRY(launch_linear_bwd(dy, x, w, dx, accumulate_dx, dw, db, M, N, K, (hipStream_t)stream));
   return 0;
 }
@@ -799,7 +815,7 @@ extern "C" int fsvit_token_softlabel(const float* teacher_logits, float* soft, i
 }
 extern "C" int fsvit_soft_target_ce(const float* logits, const float* target, float* row_loss, float* dlogits, int R, int C, float grad_scale,
                                     void* stream) {
-  if (!logits || !target || !row_loss || C > 128 || C <= 0) return fail(FSVIT_ERR_ARG, "fsvit_soft_target_ce: bad argument (C <= 128)");
+  if (!logits || !target || !row_loss || C <= 0) return fail(FSVIT_ERR_ARG, "fsvit_soft_target_ce: bad argument");
   RC_TRY(launch_soft_target_ce(logits, target, row_loss, dlogits, R, C, grad_scale, (hipStream_t)stream));
   return 0;
 }

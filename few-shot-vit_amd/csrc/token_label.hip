@@ -28,18 +28,37 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
   }
 }
 
-// dx[m][k] = sum_n dy[m][n] w[n][k]   (one workgroup per row, thread per k)
+// dx[m][k] = sum_n dy[m][n] w[n][k]   (one workgroup per row, thread per k; dy staged through LDS 256 classes at a time, so any N
+// works - tieredImageNet pre-training has 351 / 352 classes - and the sum over n keeps its ascending order whatever N is)
 __global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
                                                            int M, int N, int K, int accumulate) {
   __shared__ float dys[256];
   const int m = blockIdx.x;
-  for (int n = threadIdx.x; n < N; n += 256) dys[n] = dy[(size_t)m * N + n];
-  __syncthreads();
-  for (int k = threadIdx.x; k < K; k += 256) {
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s = fmaf(dys[n], w[(size_t)n * K + k], s);
-    float* o = dx + (size_t)m * K + k;
-    *o = accumulate ? *o + s : s;
+  constexpr int KPT = 4;                       // k columns per thread and pass: K <= 1024 in one pass, partial sums stay in registers
+  for (int k0 = 0; k0 < K; k0 += 256 * KPT) {
+    float s[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) s[j] = 0.f;
+    for (int n0 = 0; n0 < N; n0 += 256) {
+      const int nn = N - n0 < 256 ? N - n0 : 256;
+      __syncthreads();
+      if ((int)threadIdx.x < nn) dys[threadIdx.x] = dy[(size_t)m * N + n0 + threadIdx.x];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const int k = k0 + j * 256 + threadIdx.x;
+        if (k < K)
+          for (int n = 0; n < nn; ++n) s[j] = fmaf(dys[n], w[(size_t)(n0 + n) * K + k], s[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+      const int k = k0 + j * 256 + threadIdx.x;
+      if (k < K) {
+        float* o = dx + (size_t)m * K + k;
+        *o = accumulate ? *o + s[j] : s[j];
+      }
+    }
   }
 }
 
@@ -108,26 +127,30 @@ __global__ __launch_bounds__(64) void token_softlabel_kernel(const float* __rest
 }
 
 // SoftTargetCrossEntropy: rowloss[r] = -sum_c t[r][c] log_softmax(z[r])[c];  dz[r][c] = gscale (softmax(z[r])[c] sum_c t[r][c] - t[r][c]).
-// One wave per row (C <= 128 columns: two per lane).
+// One wave per row; lane l owns columns l, l + 64, ... (any C: the tieredImageNet distillation head has 352 columns).
 __global__ __launch_bounds__(256) void soft_target_ce_kernel(const float* __restrict__ z, const float* __restrict__ tgt, float* __restrict__ rowloss,
                                                              float* __restrict__ dz, int R, int C, float gscale) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= R) return;
   const float* zr = z + (size_t)r * C;
   const float* tr = tgt + (size_t)r * C;
-  const float z0 = lane < C ? zr[lane] : -3.4e38f, z1 = lane + 64 < C ? zr[lane + 64] : -3.4e38f;
-  const float t0 = lane < C ? tr[lane] : 0.f, t1 = lane + 64 < C ? tr[lane + 64] : 0.f;
-  const float mx = wave_max(fmaxf(z0, z1));
-  const float e0 = lane < C ? expf(z0 - mx) : 0.f, e1 = lane + 64 < C ? expf(z1 - mx) : 0.f;
-  const float se = wave_sum(e0 + e1);
-  const float lse = mx + logf(se);
-  const float st = wave_sum(t0 + t1);
-  const float tz = wave_sum(t0 * (lane < C ? z0 : 0.f) + t1 * (lane + 64 < C ? z1 : 0.f));
-  if (lane == 0) rowloss[r] = lse * st - tz;
-  if (dz) {
-    if (lane < C) dz[(size_t)r * C + lane] = gscale * (e0 / se * st - t0);
-    if (lane + 64 < C) dz[(size_t)r * C + lane + 64] = gscale * (e1 / se * st - t1);
+  float mx = -3.4e38f;
+  for (int c = lane; c < C; c += 64) mx = fmaxf(mx, zr[c]);
+  mx = wave_max(mx);
+  float se = 0.f, st = 0.f, tz = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float zc = zr[c], tc = tr[c];
+    se += expf(zc - mx);
+    st += tc;
+    tz += tc * zc;
   }
+  se = wave_sum(se);
+  st = wave_sum(st);
+  tz = wave_sum(tz);
+  const float lse = mx + logf(se);
+  if (lane == 0) rowloss[r] = lse * st - tz;
+  if (dz)
+    for (int c = lane; c < C; c += 64) dz[(size_t)r * C + c] = gscale * (expf(zr[c] - mx) / se * st - tr[c]);
 }
 
 // torch.optim.AdamW / timm AdamW (decoupled weight decay), update number `step` (1-based)

@@ -614,7 +614,10 @@ extern "C" int fsvit_visformer_train_forward(fsvit_visformer_trainer* t, const f
   if (!t || !params || !x_nchw_dev || !feat_dev || !ws_dev || n_img <= 0) return fsvit_set_error(FSVIT_ERR_ARG, "bad argument");
   if (img_h != t->cfg.img_size || img_w != t->cfg.img_size)
     return fsvit_set_error(FSVIT_ERR_IMG_SIZE, "Input image size (%d*%d) does not match model (%d*%d).", img_h, img_w, t->cfg.img_size, t->cfg.img_size);
-  if (n_img < 2) return fsvit_set_error(FSVIT_ERR_ARG, "train-mode BatchNorm needs more than one image");
+  {   // nn.BatchNorm2d in train mode needs more than one value per channel; the smallest map is the final H3 x H3 one (B = 1 at 80x80 is valid)
+    const int h3 = t->cfg.img_size / 16;
+    if ((long)n_img * h3 * h3 < 2) return fsvit_set_error(FSVIT_ERR_ARG, "Expected more than 1 value per channel when training (BatchNorm)");
+  }
   if (drop_path_rate > 0.f && !masks_dev) return fsvit_set_error(FSVIT_ERR_ARG, "DropPath masks required when drop_path_rate > 0");
   bind_params(t, params, n_params);
   size_t sb = 0, tb = 0;

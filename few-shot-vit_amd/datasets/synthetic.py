@@ -20,8 +20,18 @@ class SyntheticEpisodes:
         g = torch.Generator().manual_seed(seed)
         self.mu = torch.randn(n_classes, 3, image_size, image_size, generator=g)
 
+        self._table = None
+
     def __len__(self):
         return len(self.label)
+
+    def gather(self, idx, device=None):
+        """Device-resident form of `torch.stack([self[i][0] for i in idx])` (same values: the table is built once from
+        `__getitem__` and uploaded), so that a 2000-episode evaluation is not bound by per-image host generation."""
+        device = device or torch.device('cuda', torch.cuda.current_device())
+        if self._table is None or self._table.device != device:
+            self._table = torch.stack([self[i][0] for i in range(len(self))]).to(device)
+        return self._table.index_select(0, torch.as_tensor(idx, dtype=torch.long).to(device))
 
     def __getitem__(self, i):
         g = torch.Generator().manual_seed(self.seed * 1000003 + int(i) + 1)

@@ -16,6 +16,20 @@ DTYPES = {'f32': _lib.F32, 'parity': _lib.F32, 'fp32': _lib.F32, 'bf16': _lib.BF
 TORCH_DTYPE = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16}
 
 
+# Packed eval engines cache BN-folded copies of the weights.  The HIP optimizers and the HIP trainer write parameters and running
+# statistics through raw device pointers, which torch's per-tensor `_version` never sees - so every such write bumps this
+# process-wide generation and the encoders' engine fingerprints include it (a stale engine would silently report old-weight accuracy).
+_weight_generation = [0]
+
+
+def bump_weight_generation() -> None:
+    _weight_generation[0] += 1
+
+
+def weight_generation() -> int:
+    return _weight_generation[0]
+
+
 def default_numerics() -> str:
     """'bf16' (throughput mode) unless FSVIT_NUMERICS=parity|f32 selects exact-fp32 MFMA."""
     return os.environ.get('FSVIT_NUMERICS', 'bf16')
@@ -197,6 +211,7 @@ class VisformerTrainer:
         self.h = h
         self._ws = None
         self._keep = None
+        self.generation = 0        # bumped by every forward: the ONE set of saved activations belongs to the latest forward only
 
     def __del__(self):
         h, self.h = getattr(self, 'h', None), None
@@ -253,6 +268,8 @@ class VisformerTrainer:
                                                               float(drop_path_rate), _ptr(masks), _ptr(feat), _ptr(self._ws),
                                                               self._ws.numel(), _stream_ptr(x.device)))
         self._keep = (x, masks)
+        self.generation += 1
+        bump_weight_generation()          # BatchNorm running statistics were updated in place
         return feat
 
     def tokens(self, B: int, tokens_per_image: int) -> torch.Tensor:
@@ -266,6 +283,8 @@ class VisformerTrainer:
         """Overwrites grads[name] (same shapes as tensors[name]) from dfeat [B,out_dim] (+ dtokens [B,T,out_dim], the gradient of the
         token map handed out by `tokens`)."""
         _require_cuda(dfeat)
+        if self._keep is None:
+            raise RuntimeError('fsvit: backward without a pending train-mode forward (the saved activations were already consumed)')
         dfeat = dfeat.contiguous().float()
         arr, keep = self._table(tensors, grads)
         if dtokens is not None:
@@ -313,6 +332,20 @@ class ops:
             _lib.check(lib.fsvit_conv_gemm(_ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(pos), _ptr(y), B, H, W, Cin, x_cstride,
                                            KH, KW, stride, pad, N, groups * N, w.shape[-1], groups, act, int(res_first),
                                            ops._dt(x), _stream_ptr(x.device)))
+        return y
+
+    @staticmethod
+    def conv_stem_tail(x, w, bias, pos, x2, K2):
+        """Fused stem tail: x NHWC [B,H,W,Cin], w [N][Kw] (conv3 taps | one tail K slice), x2 [B*H*W][x2_cstride] im2col rows,
+        pos [(H/2)*(W/2)][N] fp32 -> y NHWC [B,H/2,W/2,N]."""
+        _require_cuda(x, w, x2, pos)
+        lib = _lib.load()
+        B, H, W, Cin = x.shape
+        N = w.shape[0]
+        y = torch.empty(B, H // 2, W // 2, N, dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.fsvit_conv_stem_tail(_ptr(x), _ptr(w), _ptr(bias), _ptr(pos), _ptr(x2), x2.shape[-1], int(K2), _ptr(y), B, H, W, Cin, N,
+                                                w.shape[-1], ops._dt(x), _stream_ptr(x.device)))
         return y
 
     @staticmethod
@@ -375,6 +408,7 @@ class ops:
     @staticmethod
     def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
         _require_cuda(p, g, m, v)
+        bump_weight_generation()
         with torch.cuda.device(p.device):
             _lib.check(_lib.load().fsvit_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
                                                     float(weight_decay), int(step), _stream_ptr(p.device)))
@@ -492,6 +526,7 @@ class ops:
     def sgd_step(param, grad, buf, lr, momentum, weight_decay, first_step):
         _require_cuda(param, grad, buf)
         lib = _lib.load()
+        bump_weight_generation()
         with torch.cuda.device(param.device):
             _lib.check(lib.fsvit_sgd_step(_ptr(param), _ptr(grad), _ptr(buf), param.numel(), float(lr), float(momentum),
                                           float(weight_decay), int(bool(first_step)), _stream_ptr(param.device)))

@@ -77,7 +77,8 @@ class VisionTransformer(nn.Module):
         dev = self.pos_embed.device
         if dev.type != 'cuda':
             raise RuntimeError('fsvit: the encoder lives on %s; the HIP engine needs an MI355X (no CPU fallback)' % dev)
-        key = (tuple((t.data_ptr(), t._version) for t in self.parameters()), self.numerics, str(dev))
+        from ..engine import weight_generation
+        key = (weight_generation(), tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers())), self.numerics, str(dev))
         if self._engine is None or self._engine_key != key:
             self._engine = VitEngine(self.cfg, self.state_dict(), numerics=self.numerics, device=dev)
             self._engine_key = key

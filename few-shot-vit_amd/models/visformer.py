@@ -134,7 +134,8 @@ class Visformer(nn.Module):
 
     # ------------------------------------------------------------------ engine management
     def _fingerprint(self):
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        from ..engine import weight_generation
+        return (weight_generation(),) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     def engine(self):
         """Packed HIP engine for the current weights (re-packed when any tensor changed)."""

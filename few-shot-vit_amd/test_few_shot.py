@@ -53,7 +53,7 @@ def build_model(config, numerics=None):
 
 
 def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch_batches=16, numerics=None,
-             rank=0, world=1, device=None, log=print):
+             rank=0, world=1, device=None, log=print, collect_pred=False):
     fix_random_seeds(12345)
     dataset = datasets.make(config['dataset'], **config['dataset_args'])
     n_way, n_query = 5, 15
@@ -68,9 +68,12 @@ def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch
 
     np.random.seed(12345)                                  # fixes the episode stream (test_few_shot.py:76)
     out = None
+    # the reference keeps ONE pair of averagers and ONE va_lst across epochs (test_few_shot.py:73-74 sit outside the epoch loop), so the
+    # accuracy / CI printed for epoch e covers every batch of epochs 1..e
+    aves_va, aves_vl, va_lst = utils.Averager(), utils.Averager(), []
     for epoch in range(1, test_epochs + 1):
         accs, losses, last_label = [], [], None
-        pending = []
+        pending, preds = [], []
 
         def flush():
             if not pending:
@@ -83,7 +86,9 @@ def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch
             G = data.shape[0]
             data = data.view(G * ep_per_batch * n_way * (shot + n_query), *data.shape[2:]).to(device, non_blocking=True)
             x_shot, x_query = fs.split_shot_query(data, n_way, shot, n_query, ep_per_batch=G * ep_per_batch)
-            _, acc, loss = engine.meta_baseline_forward(x_shot, x_query, temp, model.method, want_stats=True)
+            logits, acc, loss = engine.meta_baseline_forward(x_shot, x_query, temp, model.method, want_stats=True)
+            if collect_pred:                                         # per-query arg-max of every episode (agreement tests between numerics modes)
+                preds.append(logits.argmax(-1).to(torch.uint8).cpu())
             accs.append(acc.view(G, ep_per_batch).mean(dim=1))       # per reference batch
             losses.append(loss.view(G, ep_per_batch).mean(dim=1))
             pending.clear()
@@ -96,14 +101,15 @@ def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch
         flush()
         mine = torch.stack([torch.cat(accs), torch.cat(losses)], dim=1).double() if accs else torch.zeros(0, 2, dtype=torch.float64, device=device)
         allv = parallel.gather_in_stream_order(mine, n_batch, rank, world).cpu().numpy()     # the one exchange
-        va_lst = allv[:, 0].tolist()
-        aves_va, aves_vl = utils.Averager(), utils.Averager()
+        va_lst.extend(allv[:, 0].tolist())
         per_batch_items = ep_per_batch * n_way * (shot + n_query)
         for a, l in allv:
             aves_va.add(a, per_batch_items)
             aves_vl.add(l, per_batch_items)
         out = dict(acc=aves_va.item(), ci=float(utils.mean_confidence_interval(va_lst)) if len(va_lst) > 1 else float('nan'),
-                   loss=aves_vl.item(), n=len(va_lst), last_label=last_label, va_lst=va_lst)
+                   loss=aves_vl.item(), n=len(va_lst), last_label=last_label, va_lst=list(va_lst))
+        if collect_pred:
+            out['pred'] = torch.cat(preds) if preds else torch.zeros(0, n_way * n_query, dtype=torch.uint8)
         if rank == 0:
             log('test epoch {}: acc={:.2f} +- {:.2f} (%), loss={:.4f} (@{})'.format(
                 epoch, out['acc'] * 100, out['ci'] * 100, out['loss'], last_label))

@@ -10,70 +10,92 @@ import torch.nn.functional as F
 
 from . import few_shot  # noqa: F401
 
-_log_path = None
+class _LogSink:
+    """Where `log` mirrors its lines (reference contract: utils.set_log_path(dir) then utils.log(obj[, filename]),
+    test_phase/utils/__init__.py:15-25)."""
+    directory = None
 
 
 def set_log_path(path):
-    global _log_path
-    _log_path = path
+    _LogSink.directory = path
 
 
 def log(obj, filename='log.txt'):
-    print(obj)
-    if _log_path is not None:
-        with open(os.path.join(_log_path, filename), 'a') as f:
-            print(obj, file=f)
+    """Print `obj`; when a log directory is set, append the same line to `<directory>/<filename>`."""
+    line = str(obj)
+    print(line)
+    if _LogSink.directory is None:
+        return
+    with open(os.path.join(_LogSink.directory, filename), 'a') as sink:
+        sink.write(line + '\n')
 
 
 class Averager:
-    """Weighted running mean (utils/__init__.py:28-39)."""
+    """Weighted running mean with the reference's interface `add(value, weight)` / `item()` (utils/__init__.py:28-39), kept as a
+    weighted sum and a total weight."""
 
     def __init__(self):
-        self.n = 0.0
-        self.v = 0.0
+        self._wsum = 0.0
+        self._w = 0.0
 
     def add(self, v, n=1.0):
-        self.v = (self.v * self.n + v * n) / (self.n + n)
-        self.n += n
+        self._wsum += float(v) * float(n)
+        self._w += float(n)
+
+    @property
+    def n(self):
+        return self._w
+
+    @property
+    def v(self):
+        return self.item()
 
     def item(self):
-        return self.v
+        return self._wsum / self._w if self._w > 0 else 0.0
 
 
 class Timer:
+    """Stopwatch: `s()` restarts, `t()` = seconds since the last (re)start (utils/__init__.py:42-50)."""
+
     def __init__(self):
-        self.v = time.time()
+        self.s()
 
     def s(self):
-        self.v = time.time()
+        self._t0 = time.monotonic()
 
     def t(self):
-        return time.time() - self.v
+        return time.monotonic() - self._t0
 
 
 def set_gpu(gpu):
+    """Restrict the visible devices (utils/__init__.py:53-55); ROCm honours CUDA_VISIBLE_DEVICES like HIP_VISIBLE_DEVICES."""
+    os.environ['CUDA_VISIBLE_DEVICES'] = str(gpu)
     print('set gpu:', gpu)
-    os.environ['CUDA_VISIBLE_DEVICES'] = gpu      # ROCm honours CUDA_VISIBLE_DEVICES as well
 
 
 def ensure_path(path, remove=True, interactive=False):
-    """Non-interactive by default (the reference prompts on stdin, utils/__init__.py:59-67)."""
-    basename = os.path.basename(path.rstrip('/'))
-    if os.path.exists(path):
-        if remove and (basename.startswith('_') or not interactive
-                       or input('{} exists, remove? ([y]/n): '.format(path)) != 'n'):
-            shutil.rmtree(path)
-            os.makedirs(path)
-    else:
+    """Make `path` an existing directory; an existing one is emptied when `remove` is set (utils/__init__.py:58-67).  The
+    reference asks on stdin unless the directory name starts with '_'; here that prompt is opt-in (`interactive=True`)
+    because the drivers run unattended under torchrun."""
+    if not os.path.isdir(path):
         os.makedirs(path)
+        return
+    if not remove:
+        return
+    name = os.path.basename(os.path.normpath(path))
+    if interactive and not name.startswith('_'):
+        if input('{} exists, remove? ([y]/n): '.format(path)).strip().lower() == 'n':
+            return
+    shutil.rmtree(path)
+    os.makedirs(path)
 
 
 def time_str(t):
-    if t >= 3600:
-        return '{:.1f}h'.format(t / 3600)
-    if t >= 60:
-        return '{:.1f}m'.format(t / 60)
-    return '{:.1f}s'.format(t)
+    """Seconds -> '12.3s' / '4.5m' / '1.2h' (utils/__init__.py:70-75)."""
+    for unit, span in (('h', 3600.0), ('m', 60.0)):
+        if t >= span:
+            return '%.1f%s' % (t / span, unit)
+    return '%.1f%s' % (t, 's')
 
 
 def compute_logits(feat, proto, metric='dot', temp=1.0):

@@ -143,6 +143,11 @@ int fsvit_conv_gemm(const void* x_dev, const void* w_dev, const float* bias_dev,
                     const float* pos_dev, void* y_dev, int B, int H, int W, int Cin, int x_cstride,
                     int KH, int KW, int stride, int pad, int N, int y_cstride, int Kw, int groups,
                     int act, int res_first, int dtype, void* stream);
+/* Fused tail of the stem ConvBlock (visformer.py:213 conv3, :216-217 downsample, :232-237 add + LeakyReLU + MaxPool2d(2)) + pos_embed1
+ * (:431): y [B, H/2, W/2, N] = maxpool2(lrelu(conv3x3_pad1(x [B,H,W,Cin], w[:, 0:9*Cin]) + x2 [B*H*W][x2_cstride](:, 0:K2) . w[:, Kw-bke : Kw-bke+K2]
+ * + bias)) + pos [(H/2)*(W/2)][N]; BatchNorms folded into w / bias by the caller; bke = 128 bytes of K (64 bf16 / 32 fp32). */
+int fsvit_conv_stem_tail(const void* x_dev, const void* w_dev, const float* bias_dev, const float* pos_dev, const void* x2_dev, int x2_cstride,
+                         int K2, void* y_dev, int B, int H, int W, int Cin, int N, int Kw, int dtype, void* stream);
 /* qkv [B*S][3*heads*hdp] -> ctx [B*S][heads*hdp] (visformer.py:183-190) */
 int fsvit_attention(const void* qkv_dev, void* ctx_dev, int B, int S, int heads, int hdp, float scale,
                     int dtype, void* stream);
@@ -180,7 +185,7 @@ int fsvit_visformer_last_tokens(fsvit_visformer* h, const void* ws_dev, size_t w
 /* (train-mode counterparts: fsvit_visformer_train_tokens / fsvit_visformer_train_set_token_grad, declared with the trainer below) */
 /* y [M][N] = x [M][K] w[N][K]^T + b[N] (b may be NULL); K % 4 == 0. */
 int fsvit_linear_forward(const float* x_dev, const float* w_dev, const float* b_dev, float* y_dev, int M, int N, int K, void* stream);
-/* dx [M][K] (+)= dy w (NULL: skipped), dw [N][K] = dy^T x and db [N] = column sums of dy (NULL: skipped); N <= 256. */
+/* dx [M][K] (+)= dy w (NULL: skipped), dw [N][K] = dy^T x and db [N] = column sums of dy (NULL: skipped); any N (dy is staged 256 classes at a time). */
 int fsvit_linear_backward(const float* dy_dev, const float* x_dev, const float* w_dev, float* dx_dev, int accumulate_dx, float* dw_dev,
                           float* db_dev, int M, int N, int K, void* stream);
 /* teacher token logits [B][T][C] (T = 25 tokens in (h, w) order = the reference's [B, C, 5, 5].permute(0, 2, 3, 1)) -> soft labels
@@ -188,7 +193,7 @@ int fsvit_linear_backward(const float* dy_dev, const float* x_dev, const float* 
  * offline.py:61,71) for the other bp. */
 int fsvit_token_softlabel(const float* teacher_logits_dev, float* soft_dev, int B, int T, int C, int k, int bp, double smoothing, void* stream);
 /* row_loss [R] = -sum_c target log_softmax(logits) (the caller's mean is over R), dlogits [R][C] = grad_scale (softmax * sum(target) -
- * target) or NULL; C <= 128. */
+ * target) or NULL; any C. */
 int fsvit_soft_target_ce(const float* logits_dev, const float* target_dev, float* row_loss_dev, float* dlogits_dev, int R, int C,
                          float grad_scale, void* stream);
 /* AdamW (decoupled weight decay), update number `step` >= 1: p, exp_avg m, exp_avg_sq v updated in place. */

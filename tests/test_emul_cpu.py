@@ -1,0 +1,42 @@
+"""The rounding-point oracle (oracle/visformer_emul.py) is pinned through the pinned fp32 oracle: with every rounding site switched
+off it must BE the fp32 oracle (BN folding algebra, attention layout, stem tail), up to the engine's GELU approximation (2.6e-5)
+and fp32 summation order; with the sites on it must sit at the distance bf16 operands put it (a sanity band, not a tolerance)."""
+import torch
+
+
+def _setup():
+    from fewshot_vit_amd import synthetic
+    from fewshot_vit_amd.utils import few_shot as fs
+    from oracle import visformer_oracle as vo
+    cfg = vo.VisformerCfg()
+    shapes = vo.state_dict_shapes(cfg, prefix='encoder.')
+    shapes['temp'] = ()
+    sd = synthetic.synthetic_checkpoint_sd(shapes)
+    x = synthetic.synthetic_episodes(5, 1, 5, 1, 3)                 # 20 images
+    xs, xq = fs.split_shot_query(x, 5, 1, 3, 1)
+    return cfg, sd, xs, xq
+
+
+def test_emulator_without_rounding_equals_fp32_oracle_and_with_rounding_is_bf16_close():
+    from oracle import visformer_emul as ve
+    from oracle import visformer_oracle as vo
+    cfg, sd, xs, xq = _setup()
+    ref = vo.meta_baseline_forward(sd, xs, xq, cfg)
+    sites = {'input', 'w_stem', 'act_stem', 'w_s1', 'act_s1', 'w_pe', 'w_attn', 'qkv', 'P', 'ctx', 'w_mlp', 'act_mlp', 'xop'}
+    try:
+        ve.SKIP = set(sites)
+        exact = ve.meta_baseline_forward_emul(sd, xs, xq, cfg, residual='fp32')
+    finally:
+        ve.SKIP = set()
+    assert (exact - ref).abs().max().item() <= 1e-3                # gelu_sig vs erf + summation order only
+    for residual in ('bf16', 'hilo', 'fp32'):
+        lg = ve.meta_baseline_forward_emul(sd, xs, xq, cfg, residual=residual)
+        err = (lg - ref).abs().max().item()
+        assert 5e-3 <= err <= 0.25, (residual, err)                  # bf16 operands: ~1e-1 on this model, whatever the residual storage
+        assert (lg.argmax(-1) == ref.argmax(-1)).float().mean().item() == 1.0
+
+
+def test_gelu_sig_matches_erf_gelu():
+    from oracle import visformer_emul as ve
+    x = torch.linspace(-12, 12, 20001)
+    assert (ve.gelu_sig(x) - torch.nn.functional.gelu(x)).abs().max().item() <= 3e-5

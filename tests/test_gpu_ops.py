@@ -101,6 +101,49 @@ def test_conv_gemm(case, dt):
     assert err <= _tol(dt, ref), (name, dt, err)
 
 
+@pytest.mark.parametrize('dt,B', [('bf16', 53), ('bf16', 3), ('f32', 2)])
+def test_stem_tail_conv3_downsample_lrelu_maxpool_pos(dt, B):
+    """The most expensive instantiation of the bench, conv3x3_halo_kernel<128,true>: conv3 + bn3 with the
+    downsample conv + bn_d as a tail K slice over the im2col rows, LeakyReLU(0.1), MaxPool2d(2) over 2x2-window-major rows, + pos_embed1
+    (visformer.py:213-237,431).  Reference: fp32 torch on operands pre-rounded to the storage dtype (the kernel's rounding points: x, x2,
+    w in, y out).  B = 53 -> 265 tiles > 256 persistent workgroups: some workgroups walk two tiles (halo prefetch under the epilogue);
+    image borders (zero padding) and every window position are covered by comparing the whole map.  f32 runs the same contract on
+    conv_gemm_v2 (x2 / pool2 / pos)."""
+    from fewshot_vit_amd.engine import ops
+    dtype = DT[dt]
+    g = torch.Generator().manual_seed(1234 + B)
+    H = W = 40
+    Cin = N = 128
+    bke = 32 if dt == 'f32' else 64
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)                                   # c2 = output of stem conv2
+    img = q(torch.randn(B, 3, 2 * H, 2 * W, generator=g), dtype)                           # the network input, for the downsample conv
+    w3 = q(torch.randn(N, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin), dtype)             # bn3 folded
+    wd = q(torch.randn(N, 3, 3, 3, generator=g) / math.sqrt(27), dtype)                    # bn_d folded
+    bias = torch.randn(N, generator=g) * 0.3
+    pos = torch.randn((H // 2) * (W // 2), N, generator=g) * 0.2
+    ref = F.conv2d(x, w3, None, padding=1) + F.conv2d(img, wd, None, stride=2, padding=1) + bias.view(1, -1, 1, 1)
+    ref = F.max_pool2d(F.leaky_relu(ref, 0.1), 2) + pos.t().reshape(1, N, H // 2, W // 2)
+    # im2col rows of the 3x3 / stride-2 / pad-1 downsample conv: [B*H*W][32], k = (ky*3 + kx)*3 + c (what stem.hip writes)
+    cols = F.unfold(img, 3, padding=1, stride=2).view(B, 3, 9, H * W).permute(0, 3, 2, 1).reshape(B * H * W, 27)
+    x2 = torch.zeros(B * H * W, 32)
+    x2[:, :27] = cols
+    Kmain = 9 * Cin
+    wp = torch.zeros(N, Kmain + bke)
+    wp[:, :Kmain] = w3.permute(0, 2, 3, 1).reshape(N, Kmain)
+    wp[:, Kmain:Kmain + 27] = wd.permute(0, 2, 3, 1).reshape(N, 27)
+    dev = 'cuda'
+    y = ops.conv_stem_tail(x.permute(0, 2, 3, 1).contiguous().to(dev, dtype), wp.to(dev, dtype), bias.to(dev), pos.to(dev),
+                           x2.to(dev, dtype), 32)
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs()
+    if dt == 'f32':
+        assert err.max().item() <= 2e-4 * max(1.0, float(ref.abs().max()))
+    else:       # output rounding of bf16 (2^-9 relative) + accumulation order
+        bound = 2.0 ** -8 * ref.abs() + 2e-3
+        assert bool((err <= bound).all()), (float(err.max()), float((err - bound).max()))
+
+
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 @pytest.mark.parametrize('S,heads,hd,pad', [(100, 6, 42, 0), (100, 6, 42, 16), (25, 6, 85, 0), (100, 2, 10, 0), (25, 3, 21, 0), (197, 3, 40, 16)])
 def test_attention(S, heads, hd, pad, dt):

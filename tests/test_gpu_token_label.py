@@ -196,3 +196,32 @@ def test_train_classifier_driver(tmp_path):
     ck = torch.load(os.path.join(str(tmp_path), 'c', 'epoch-last.pth'), map_location='cpu')
     m = models.load(ck)
     assert ck['model'] == 'classifier' and m.classifier.linear.weight.shape == (8, 512)
+
+
+def test_wide_heads_tiered_imagenet_class_counts():
+    """351 / 352 classes (tieredImageNet pre-training, offline.py classifier_local): Linear backward and the soft-target CE must not be
+    limited to 256 / 128 columns."""
+    from fewshot_vit_amd.engine import ops
+    g = torch.Generator().manual_seed(17)
+    M, K = 75, 512
+    for N in (351, 352, 600):
+        x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / 22.0, torch.randn(N, generator=g)
+        dy = torch.randn(M, N, generator=g)
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y_ref = torch.nn.functional.linear(xr, wr, br)
+        y_ref.backward(dy)
+        y = ops.linear(x.cuda(), w.cuda(), b.cuda())
+        dx, dw, db = ops.linear_backward(dy.cuda(), x.cuda(), w.cuda())
+        assert (y.cpu() - y_ref.detach()).abs().max() <= 1e-4
+        assert (dx.cpu() - xr.grad).abs().max() <= 1e-4 * float(xr.grad.abs().max())
+        assert (dw.cpu() - wr.grad).abs().max() <= 1e-4 * float(wr.grad.abs().max())
+        assert (db.cpu() - br.grad).abs().max() <= 1e-4 * float(br.grad.abs().max())
+    R, Cc = 50, 352
+    z = torch.randn(R, Cc, generator=g) * 3.0
+    t = torch.rand(R, Cc, generator=g) * (torch.rand(R, Cc, generator=g) < 0.02)
+    zr = z.clone().requires_grad_(True)
+    loss_ref = torch.sum(-t * torch.nn.functional.log_softmax(zr, dim=-1), dim=-1)
+    loss_ref.sum().backward()
+    row, dz = ops.soft_target_ce(z.cuda(), t.cuda(), grad_scale=1.0)
+    assert (row.cpu() - loss_ref.detach()).abs().max() <= 2e-5 * max(1.0, float(loss_ref.abs().max()))
+    assert (dz.cpu() - zr.grad).abs().max() <= 2e-6

@@ -252,6 +252,50 @@ def test_training_loop_reduces_loss_and_eval_follows():
     assert torch.isfinite(lg).all()
 
 
+def test_eval_engine_follows_raw_pointer_weight_updates():
+    """the HIP optimizer / trainer write through raw device pointers, which never bump torch's `_version`.  Sequence
+    forward, eval, backward, step, eval (no train-mode forward between the two evals): the second eval must use freshly packed
+    weights - compared with an engine built from a cloned state dict - and must differ from the first."""
+    from fewshot_vit_amd import models, synthetic, utils
+    from fewshot_vit_amd.engine import VisformerEngine
+    from fewshot_vit_amd.utils import few_shot as fs
+    m = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={'numerics': 'bf16'}).cuda()
+    opt, _ = utils.make_optimizer(m.parameters(), 'sgd', lr=0.05, weight_decay=5e-4)
+    x = synthetic.synthetic_episodes(5, 1, 5, 1, 3).cuda()
+    xs, xq = fs.split_shot_query(x, 5, 1, 3, 1)
+    label = fs.make_nk_label(5, 3, 1).cuda()
+    m.train()
+    loss = torch.nn.functional.cross_entropy(m(xs, xq).view(-1, 5), label)
+    m.eval()
+    with torch.no_grad():
+        f0 = m.encoder(x).clone()
+    opt.zero_grad()
+    loss.backward()
+    opt.step()                                   # raw-pointer update, no train-mode forward afterwards
+    with torch.no_grad():
+        f1 = m.encoder(x).clone()
+    fresh = VisformerEngine(m.encoder.cfg, {k: v.detach().clone() for k, v in m.encoder.state_dict().items()}, numerics='bf16')
+    f2 = fresh.forward(x)
+    torch.cuda.synchronize()
+    assert not torch.equal(f0, f1)
+    assert torch.equal(f1, f2)
+
+
+def test_second_forward_before_backward_raises():
+    """one set of saved activations per trainer - a second train-mode forward invalidates the first graph loudly."""
+    from fewshot_vit_amd import models, synthetic
+    m = models.make('visformer_micro_80', numerics='parity').cuda().train()
+    xa, xb = synthetic.synthetic_episodes(1, 1, 2, 1, 1).cuda(), synthetic.synthetic_episodes(2, 1, 2, 1, 1).cuda()
+    fa = m(xa)
+    fb = m(xb)
+    with pytest.raises(RuntimeError, match='another train-mode forward'):
+        fa.sum().backward()
+    fb.sum().backward()                          # the latest forward is still valid
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    one = m(xa[:1])                              # B = 1: 25 values per channel at the last BatchNorm, valid in torch too
+    assert one.shape == (1, 512) and torch.isfinite(one).all()
+
+
 def test_train_meta_driver_one_epoch(tmp_path):
     """The train_meta.py surface end to end on a small schedule: train batches, tval/val episodes in eval mode, the
     reference's checkpoint schema (train_meta.py:241-257) readable by models.load, MultiStepLR stepping."""

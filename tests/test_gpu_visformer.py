@@ -14,7 +14,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 LOGIT_TOL_PARITY = 1e-3        # BASELINE.json north_star
-LOGIT_TOL_BF16 = 0.25          # loose guard; the measured value is printed and recorded in DESIGN.md
+# bf16 throughput mode against the fp32 reference golden: 1.5 x the measured 1.07e-1 (5-shot) / 8.7e-2 (1-shot).  This deviation is
+# the bf16 rounding of the (BN-folded) WEIGHTS - a fixed perturbation of the model that does not average out over tokens - not of
+# the stored activations or the residual stream (ablation on the rounding-point emulator: DESIGN.md 2, tools/emul_ablation.py).
+LOGIT_TOL_BF16 = 0.16
+# ... and against the oracle that rounds where the kernels round (oracle/visformer_emul.py): only accumulation order and the
+# softmax / GELU instruction sequences differ.  Set from the measurement printed by the test (1.5 x).
+LOGIT_TOL_BF16_EMUL = 3e-2
+TAP_TOL_BF16_EMUL = 2e-2
 
 
 @pytest.fixture(scope='module')
@@ -69,7 +76,58 @@ def test_logits_bf16_mode_vs_reference_golden(full_sd, golden_dir, name, seed, s
     assert agree == 1.0
 
 
-@pytest.mark.parametrize('numerics,tol', [('parity', 2e-4), ('bf16', 0.3)])
+@pytest.mark.parametrize('name,seed,shot', [('5shot', 11, 5), ('1shot', 12, 1)])
+def test_logits_bf16_mode_vs_rounding_point_oracle(full_sd, name, seed, shot):
+    """a bf16 gate that means something.  The emulated oracle applies bf16 rounding exactly where the engine
+    stores / feeds MFMA operands, so a kernel regression (a wrong fragment, a dropped K slice, a missing bias) cannot hide inside the
+    0.1 logit deviation that bf16 weights cause against the fp32 reference."""
+    from oracle import visformer_emul as ve
+    from oracle import visformer_oracle as vo
+    m = _model(full_sd, 'bf16')
+    xs, xq = _episode(seed, shot)
+    ref = ve.meta_baseline_forward_emul(full_sd, xs, xq, vo.VisformerCfg(), residual='bf16').numpy()
+    with torch.no_grad():
+        logits = m(xs.cuda(), xq.cuda()).cpu().numpy()
+    err = np.abs(logits - ref).max()
+    print(f'[bf16] {name} max|dlogit| vs rounding-point oracle = {err:.3e} (mean {np.abs(logits - ref).mean():.3e})')
+    assert err <= LOGIT_TOL_BF16_EMUL
+    assert (logits.argmax(-1) == ref.argmax(-1)).mean() >= 0.98
+
+
+def test_residual_stream_taps_bf16_vs_rounding_point_oracle(full_sd):
+    """Every residual-stream checkpoint of the bf16 engine against the rounding-point oracle (relative to the tap's max)."""
+    from fewshot_vit_amd import synthetic
+    from oracle import visformer_emul as ve
+    from oracle import visformer_oracle as vo
+    cfg = vo.VisformerCfg()
+    m = _model(full_sd, 'bf16')
+    eng = m.encoder.engine()
+    x = synthetic.synthetic_episodes(31, 1, 3, 1, 1)            # 6 images
+    B = x.shape[0]
+    shapes = {'stem': (B, 20, 20, 128), 'patch_embed2': (B, 10, 10, 256), 'patch_embed3': (B, 5, 5, 512)}
+    shapes.update({f'stage1.{i}': (B, 20, 20, 128) for i in range(4)})
+    shapes.update({f'stage2.{i}': (B, 10, 10, 256) for i in range(2)})
+    shapes.update({f'stage3.{i}': (B, 5, 5, 512) for i in range(3)})
+    bufs = {k: eng.set_tap(k, s) for k, s in shapes.items()}
+    with torch.no_grad():
+        feat = m.encoder(x.cuda())
+    torch.cuda.synchronize()
+    taps = {}
+    with torch.no_grad():
+        pooled = ve.visformer_forward_emul(full_sd, x, cfg, prefix='encoder.', residual='bf16', taps=taps)
+    worst = {}
+    for k, buf in bufs.items():
+        got = buf.float().cpu().permute(0, 3, 1, 2)
+        worst[k] = ((got - taps[k]).abs().max() / max(1.0, float(taps[k].abs().max()))).item()
+    print('[bf16 vs rounding-point oracle] tap rel errors:', {k: f'{v:.2e}' for k, v in worst.items()})
+    perr = (feat.cpu() - pooled).abs().max().item() / max(1.0, float(pooled.abs().max()))
+    print(f'[bf16 vs rounding-point oracle] pooled feature rel err = {perr:.3e}')
+    for k, v in worst.items():
+        assert v <= TAP_TOL_BF16_EMUL, (k, v)
+    assert perr <= TAP_TOL_BF16_EMUL
+
+
+@pytest.mark.parametrize('numerics,tol', [('parity', 2e-4), ('bf16', 0.06)])
 def test_residual_stream_taps_vs_oracle(full_sd, numerics, tol):
     """Every residual-stream checkpoint of the encoder against the oracle's NCHW taps."""
     from fewshot_vit_amd import synthetic
