@@ -47,6 +47,7 @@ MODELS = {'visformer_micro_80': (2.0306e9, 80), 'deit_small_patch16_224': (9.197
 HEAD_FLOP_PER_EPISODE = 0.38e6
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'parity': 157.3}    # dense peaks, MI355X_MICROARCH.md
 DTYPE_NAME = {'bf16': 'bf16', 'f16': 'f16', 'parity': 'f32'}
+NOISE = 1.0
 
 
 def parse(argv=None):
@@ -147,12 +148,14 @@ def selftest_worker(args, rank, world):
 
 # ------------------------------------------------------------------------------------------------ workload
 def device_episodes(seed, n_ep, way, shot, query, dev, img=80):
-    """Class-structured synthetic episodes generated directly in HBM (x = mu_c + 1.5*eps, so accuracy
-    is neither chance nor saturated); layout = what fs.split_shot_query returns."""
+    """Class-structured synthetic episodes generated directly in HBM, x = mu_c + NOISE * eps.  NOISE = 1.0 puts the 5-way 5-shot
+    accuracy of the procedural-weight model at ~80 %, where the reference sits on miniImageNet (83.25 %); round 1 used 1.5, which is
+    30 % = near chance, where arg-max agreement between numerics modes measures coin flips (tools/calib_noise.py).  Layout = what
+    fs.split_shot_query returns."""
     g = torch.Generator(device=dev).manual_seed(seed)
     per = shot + query
     mu = torch.randn(n_ep, way, 1, 3, img, img, device=dev, generator=g)
-    x = mu + 1.5 * torch.randn(n_ep, way, per, 3, img, img, device=dev, generator=g)
+    x = mu + NOISE * torch.randn(n_ep, way, per, 3, img, img, device=dev, generator=g)
     x_shot = x[:, :, :shot].contiguous()
     x_query = x[:, :, shot:].contiguous().view(n_ep, way * query, 3, img, img)
     return x_shot, x_query

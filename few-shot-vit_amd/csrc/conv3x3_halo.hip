@@ -1,23 +1,36 @@
 // 3x3 / stride 1 / pad 1 convolution with the input tile + halo RESIDENT IN LDS (stem conv2, conv3 of the Visformer,
-// test_phase/models/visformer.py:211-213,224-237), bf16.
+// test_phase/models/visformer.py:211-213,224-237), bf16.  Round-2 design ("channel-half phases").
 //
-// Why: conv_gemm_v2 runs a 3x3 conv as an implicit GEMM that re-stages every input pixel once per tap - 9 x the
-// activation bytes through the LDS-DMA path, which delivers only ~16 B/clk/CU (tools/bench_gemm256.py) - so it sits on
-// the fill roof of a 128x128 tile (64 flop per staged byte, ~620 TFLOP/s; measured 627).  Here a workgroup owns 8 output
-// rows x 40 columns x 128 channels: the 10 x 42 pixel halo tile is staged ONCE (107 KB at 128 input channels) and the nine
-// taps are shifted LDS reads of it; only the weights stream (16 KB per 64-wide K tile, 3-stage ring, counted vmcnt,
-// shared by every tile of the persistent workgroup).  235 flop per staged byte: the kernel is MFMA / LDS-read bound.
-//   * 8 waves = 4 (pixels) x 2 (channels): a wave holds 5 x 4 accumulator tiles (80 pixels x 64 channels), per K tile
-//     10 + 8 ds_read_b128 and 40 MFMAs;
-//   * halo pixels are 128 / 256 bytes; the 16-byte chunk position inside a pixel is XOR-swizzled with the low bits of the
-//     halo pixel index (applied to the per-lane DMA source, as in conv_gemm_v2), so the 16 pixels of a fragment read hit
-//     16 different bank groups whatever the tap shift;
-//   * FUSE_TAIL (conv3): the downsample/identity conv rides as one extra K tile whose A fragments come straight from the
-//     im2col rows in global memory, rows are enumerated 2x2-window-major so LeakyReLU -> MaxPool2d(2) is a max over 4
-//     adjacent lanes, and pos_embed1 is added in the same epilogue (same contract as conv_gemm_v2's x2 / pool2 / pos).
+// A workgroup owns 8 output rows x 40 columns x 128 output channels.  Round 1 staged the whole 10 x 42-pixel halo tile of all input
+// channels once per tile (107 KB at 128 channels) and walked the nine taps as shifted LDS reads of it.  rocprof / PMC of that kernel
+// (profiles/r02_a_*): MFMA pipe 39 % busy, 33 % of the LDS cycles bank conflicts, 3.7 VALU per MFMA, and three structural costs:
+//   (1) the next tile's halo could only be requested after the K loop (one buffer fills the LDS): ~9k of a tile's 56k cycles exposed;
+//   (2) the XOR swizzle of the halo pixels made every fragment address depend on the tap: ~40 VALU per 40 MFMAs, issued between the
+//       MFMA blocks, and hipcc's waitcnt pass put lgkmcnt(0) in front of the loop-carried first MFMA block, i.e. waited for the
+//       fragment reads it was meant to overlap (found in the -save-temps ISA);
+//   (3) with the 2x2-window-major pixel order of the pooled variant the 16 pixels of a fragment wrapped onto the same 16-byte slots.
+// This version:
+//   * K loop order (channel half, tap) instead of (tap, channel half): a PHASE is one 64-channel half of the input under all nine
+//     taps, its halo tile 54 KB - TWO such buffers fit, so the next phase's halo (the other half of this tile, or the first half of
+//     the workgroup's next tile) streams in under the current phase's 9 K tiles (one 1 KB LDS-DMA piece per wave and K tile, issued
+//     behind the K tile's barrier so that no weight wait ever queues behind an HBM load that was just issued);
+//   * the halo buffer is chunk-PLANAR, [8 k-chunks][10 rows x 44 pixels][16 B] (plane stride 0 mod 256 B), and an MFMA m-tile is a
+//     4 x 4 pixel block: its 16 pixels sit on 16 different 16-byte slots whatever the tap shift (row pitch 44 = 12 mod 16), with no
+//     XOR - a tap is a compile-time ADDITIVE offset, the nine taps of a phase are unrolled and every fragment read is
+//     `ds_read_b128 base offset:imm` on five per-lane bases: no address arithmetic in the loop;
+//   * fragments are not carried across the (runtime) phase loop: the first read of a phase is exposed once per 9 K tiles, and inside
+//     the unrolled body the compiler's own counted lgkmcnt waits are exact;
+//   * 16-byte stores: weight rows are fetched in the order 8 (r / 4) + 4 (tile & 1) + r % 4 inside each 32-channel block, so the
+//     accumulators a lane holds of an n-tile pair are 8 consecutive channels (the gemm256 epilogue trick).
+// Weights stream as before: 16 KB per 64-wide K tile through a 3-stage ring with counted vmcnt, two K tiles ahead.
+// LDS: 2 x 56 KB halo + 3 x 16 KB weights = 160 KB exactly.
+//   * FUSE_TAIL (conv3): the downsample/identity conv rides as one extra K tile whose A fragments come straight from the im2col rows
+//     in global memory; LeakyReLU -> MaxPool2d(2) is a max over 4 adjacent lanes (the 4 x 4 block is enumerated 2x2-window-major) and
+//     pos_embed1 is added in the same epilogue (same contract as conv_gemm_v2's x2 / pool2 / pos).
 #include <stdlib.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "conv_gemm.h"
 #include "fsvit_common.h"
@@ -54,77 +67,103 @@ __device__ __forceinline__ void hdma2s(unsigned off0, unsigned off1, const void*
       : "v"(off0), "v"(off1), "s"(sbase), "s"(lds0), "s"(lds1)
       : "memory");
 }
-#define HWAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+__device__ __forceinline__ u32x4 hgload16(const void* p) {      // hidden from hipcc's waitcnt pass like the DMAs: counted by hand
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+#define HWAIT(vm) asm volatile("s_waitcnt vmcnt(" #vm ") lgkmcnt(0)" ::: "memory")
 __device__ __forceinline__ void hbar() {
   asm volatile("s_barrier" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
 
-constexpr int H_TR = 8, H_TW = 40, H_HW = H_TW + 2, H_HR = H_TR + 2, H_HP = H_HR * H_HW;   // 8 x 40 outputs, 10 x 42 halo
-constexpr int H_NST = 3, H_STAGE = 16384;
-__host__ __device__ constexpr int halo_bytes(int cin) { return (H_HP * cin * 2 + 1023) / 1024 * 1024; }
+template <int CTRL>
+__device__ __forceinline__ float quad_xor(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+namespace halo {
+constexpr int TR = 8, TW = 40;                 // output tile
+constexpr int HR = TR + 2, HP = 44;            // halo rows, halo row pitch in pixels (42 used; 44 = 12 mod 16, see the header)
+constexpr int PLANE = 7168;                    // one k-chunk plane: 448 16-byte slots (440 used) = 7 LDS-DMA pieces; 28 x 256 B
+constexpr int NPIECE = 7;                      // pieces per plane = per wave (wave w fills plane w)
+constexpr int HBUF = 8 * PLANE;                // 57344: one 64-channel halo buffer
+constexpr int NST = 3, STAGE = 16384;          // weight ring
+constexpr int OFF_W = 2 * HBUF;
+constexpr int LDS_BYTES = OFF_W + NST * STAGE; // 163840 = 160 KiB
+static_assert(LDS_BYTES == 160 * 1024, "the two halo buffers and the weight ring fill the LDS exactly");
+}  // namespace halo
+
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
 
 template <int CIN, bool FUSE_TAIL>
-__global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const ConvGemmParams p, const int n_tiles) {
+__global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvGemmParams p, const int n_tiles) {
+  using namespace halo;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int PXB = CIN * 2, CPP = CIN / 8;                 // bytes / 16-byte chunks per pixel
-  constexpr int HALO = halo_bytes(CIN), ND = HALO / 1024;     // halo DMAs per tile
-  constexpr int KH64 = CIN / 64, NKM = 9 * KH64, NKT = NKM + (FUSE_TAIL ? 1 : 0);
+  constexpr int NH = CIN / 64;                                  // phases (64-channel halves) per tile
+  constexpr int NKM = 9 * NH, NKT = NKM + (FUSE_TAIL ? 1 : 0);  // weight K tiles per output tile (64 k each; the tail tile uses 32)
   constexpr int MT = 5, NT = 4;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int lrow = lane & 15, lq = lane >> 4;
   const unsigned lds0 = (unsigned)(size_t)(lptrh_t)smem;
-  unsigned char* const wst0 = smem + HALO;
+  unsigned char* const wst0 = smem + OFF_W;
 
-  const bf16* __restrict__ X = reinterpret_cast<const bf16*>(p.x);
+  const unsigned char* const Xb = reinterpret_cast<const unsigned char*>(p.x);
   const unsigned char* const Wb = reinterpret_cast<const unsigned char*>(p.w);
   bf16* __restrict__ Y = reinterpret_cast<bf16*>(p.y);
-  const int tiles_per_img = p.H / H_TR;
+  const int tiles_per_img = p.H / TR;
 
-  // this lane's 5 output pixels (tile-local) -> halo pixel index of tap (0, 0)
-  int hp0[MT], prow[MT], pcol[MT];
+  // ---- this lane's 5 output pixels: m-tile = 4 x 4 pixel block (wm * 5 + i), lane lrow = window * 4 + dy * 2 + dx inside it.
+  // Pixel (row, column) inside the tile = (4 br + fr, 4 bc + fc) with the block position (br, bc) wave-uniform.
+  const int fr = ((lrow >> 3) & 1) * 2 + ((lrow >> 1) & 1), fc = ((lrow >> 2) & 1) * 2 + (lrow & 1);
+  auto blk_r = [&](int i) { return (wm * MT + i) / (TW / 4); };
+  auto blk_c = [&](int i) { return (wm * MT + i) % (TW / 4); };
+  unsigned xb[MT];                         // LDS byte offset of the tap-(0,0) halo pixel in plane lq of the CURRENT halo buffer
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int q = (wm * MT + i) * 16 + lrow;
-    int r, c;
-    if (FUSE_TAIL) {                 // 2x2-window-major: q = window * 4 + dy * 2 + dx
-      const int win = q >> 2, lpy = win / (H_TW / 2), lpx = win - lpy * (H_TW / 2);
-      r = 2 * lpy + ((q >> 1) & 1);
-      c = 2 * lpx + (q & 1);
-    } else {
-      r = q / H_TW;
-      c = q - r * H_TW;
-    }
-    prow[i] = r; pcol[i] = c;
-    hp0[i] = r * H_HW + c;
-  }
-  // weight DMA rows of this wave (128 rows of 128 bytes per K tile = 16 groups of 8)
+  for (int i = 0; i < MT; ++i) xb[i] = (unsigned)(((blk_r(i) * 4 + fr) * HP + blk_c(i) * 4 + fc) * 16 + lq * PLANE);
+  // ---- weight DMA rows of this wave (128 rows of 128 bytes per K tile = 16 groups of 8); LDS row R holds output channel
+  // (R & ~31) + 8 ((R & 15) >> 2) + 4 ((R >> 4) & 1) + (R & 3): see the 16-byte epilogue
   const int srow = lane >> 3;
   const unsigned schunk = (unsigned)(((lane & 7) ^ srow) << 4);
   unsigned offB[2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) offB[j] = (unsigned)((2 * wave + j) * 8 + srow) * (unsigned)(p.Kw * 2) + schunk;
+  for (int j = 0; j < 2; ++j) {
+    const int R = (2 * wave + j) * 8 + srow;
+    const int ch = (R & ~31) + 8 * ((R & 15) >> 2) + 4 * ((R >> 4) & 1) + (R & 3);
+    offB[j] = (unsigned)ch * (unsigned)(p.Kw * 2) + schunk;
+  }
   const unsigned b_rd = (unsigned)((wn * 64 + lrow) * 128);
   const unsigned sw0 = (unsigned)((lq ^ (lrow & 7)) << 4), sw1 = (unsigned)(((4 + lq) ^ (lrow & 7)) << 4);
 
+  // ---- halo pieces of this wave: plane `wave`, piece j = slots [64 j, 64 j + 64) of the plane; lane's slot -> halo pixel (hr, hc)
+  // -> source byte offset relative to pixel (image b, row r0 - 1, column 0); padding slots and the left / right border read zeros
   auto issue_w = [&](int wk, int stage) {
-    const unsigned d = lds0 + HALO + stage * H_STAGE;
+    const unsigned d = lds0 + OFF_W + stage * STAGE;
     hdma2s(offB[0], offB[1], Wb + (size_t)wk * 128, d + (2 * wave) * 1024, d + (2 * wave + 1) * 1024);
   };
-  auto issue_halo = [&](int tix) {
-    const int b = tix / tiles_per_img, r0 = (tix - b * tiles_per_img) * H_TR;
-    for (int d = wave; d < ND; d += 8) {
-      const int slot = d * 64 + lane;
-      const int hp = slot / CPP, pos = slot - hp * CPP;
-      const int c = pos ^ (hp & (CPP - 1));
-      const int hr = hp / H_HW, hc = hp - hr * H_HW;
-      const int iy = r0 + hr - 1, ix = hc - 1;
-      const bool ok = hp < H_HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const void* src = ok ? static_cast<const void*>(X + ((size_t)(b * p.H + iy) * p.W + ix) * CIN + c * 8) : static_cast<const void*>(g_zero_page_halo);
-      hdma1(src, lds0 + d * 1024);
-    }
+  // one piece of the halo tile whose pixel (row r0 - 1, column 0, first channel of the half) is at `base` into buffer nb; base == nullptr:
+  // nothing to fetch (zero page) - the piece is still issued so that the counted waits below see the same number of operations in
+  // flight on every path.  top / bot: the tile touches the upper / lower image border (halo row 0 / 9 is zero padding).
+  auto issue_piece = [&](int j, int lane_o, const unsigned char* base, bool top, bool bot, int nb) {
+    const int s = j * 64 + lane_o, hr = s / HP, hc = s - hr * HP;
+    // branch-free (bitwise & / one select): an exec-masked branch here is a scheduling boundary that keeps the whole address computation
+    // in front of the MFMA block instead of between its MFMAs
+    const bool ok = (base != nullptr) & (s < HR * HP) & (hc >= 1) & (hc <= TW) & !(top & (hr == 0)) & !(bot & (hr == HR - 1));
+    const unsigned long a = (unsigned long)base + (unsigned long)(unsigned)(((hr * p.W + hc - 1) * CIN + wave * 8) * 2);
+    const unsigned long z = (unsigned long)g_zero_page_halo;
+    hdma1(reinterpret_cast<const void*>(ok ? a : z), lds0 + nb * HBUF + wave * PLANE + j * 1024);
+  };
+  auto halo_base = [&](int tile, int h) {
+    const int bb = tile / tiles_per_img, rr = (tile - bb * tiles_per_img) * TR;
+    return Xb + ((long)(bb * p.H + rr - 1) * p.W) * (CIN * 2) + h * 128;
   };
 
   f32x4 acc[MT][NT];
@@ -135,148 +174,231 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const ConvGemmPara
 
   int tix = blockIdx.x;
   if (tix >= n_tiles) return;
-  issue_halo(tix);
-  issue_w(0, 0);
-  issue_w(1 % NKT, 1);
-  HWAIT_VM(0);
+  const int my_tiles = (n_tiles - tix + (int)gridDim.x - 1) / (int)gridDim.x;
+  int steps_left = my_tiles * NKT;                              // K-tile steps this workgroup still has to run (incl. the current one)
+
+  // weight K tile of step q of a tile (steps run phase-major, weights are packed tap-major): q -> (tap, half) -> tap * NH + half
+  auto wk_of = [&](int q) { return q >= NKM ? NKM : (NH == 2 ? (q >= 9 ? (q - 9) * 2 + 1 : q * 2) : q); };
+
+  // ---- prologue: whole halo of (tile, half 0) into buffer 0, weight K tiles of steps 0 and 1
+  {
+    const int r00 = (tix % tiles_per_img) * TR;
+    const unsigned char* b0 = halo_base(tix, 0);
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) issue_piece(j, lane, b0, r00 == 0, r00 + TR == p.H, 0);
+  }
+  issue_w(wk_of(0), 0);
+  issue_w(wk_of(1 % NKT), 1);
+  HWAIT(0);
   hbar();
-  // wave-uniform ring state, advanced incrementally (no divisions in the loop): stage of the K tile being consumed, stage and
-  // weight K-tile index of the one being prefetched (two ahead)
-  int st_cur = 0, st_pre = 2, wk_pre = 2 % NKT;
+  int st_cur = 0, st_pre = 2, q_pre = 2 % NKT;                  // ring state: stage being consumed, stage / step-in-tile being prefetched
+  int buf = 0;                                                  // halo buffer of the current phase
+#ifdef H_CLK      // timing diagnostics (tools/build_variant.sh): where a workgroup's cycles go, printed by wave 0 of workgroups 0 and 100
+  long long ck0 = __builtin_readcyclecounter(), ckl = ck0, ckA = 0, ckW = 0, ckB = 0, ckE = 0, ckP = 0, ckT = 0, ckV = 0;
+#define H_STAMP(acc_) { const long long c_ = __builtin_readcyclecounter(); acc_ += c_ - ckl; ckl = c_; }
+#else
+#define H_STAMP(acc_)
+#endif
+
+  auto advance = [&]() {
+    st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
+    st_pre = st_pre == NST - 1 ? 0 : st_pre + 1;
+    q_pre = q_pre == NKT - 1 ? 0 : q_pre + 1;
+    --steps_left;
+  };
+
   while (true) {
-    const int tnext = tix + gridDim.x;
+    const int tnext = tix + (int)gridDim.x;
     const bool has_next = tnext < n_tiles;
-    const int b = tix / tiles_per_img, r0 = (tix - b * tiles_per_img) * H_TR;
-    // K loop, rotated by half a K tile so that LDS reads always run under MFMAs: the two 32-wide k-chunks of a K tile live
-    // in two fragment sets; while chunk 0 of tile g multiplies, chunk 1 of g is read, and while chunk 1 multiplies, chunk 0
-    // of g+1 is read (after the counted wait + barrier that publishes the weight stage of g+1).  With all 8 waves in
-    // lockstep the unrotated loop exposed the whole read burst (144 ds_read_b128 per K tile per CU) before every MFMA block.
-    u32x4 xf0[MT], xf1[MT], wf0[NT], wf1[NT];
-    // Fragment addresses of the current K tile: computed once by read_k0 (6 VALU each), chunk 1 of the same tile is the same
-    // address with bit 6 flipped.  Recomputing them in read_k1 put 2.6 VALU instructions beside every 16-cycle MFMA (PMC: VALU
-    // 26 % busy) - more than issue for free behind it (tools/probes/mfma_valu_overlap.hip).
-    unsigned xa[MT];
-    auto read_k0 = [&](int toff, int kh, int stage) {
-      const unsigned char* wb = wst0 + stage * H_STAGE + b_rd;
+    const int b = tix / tiles_per_img, r0 = (tix - b * tiles_per_img) * TR;
+    u32x4 xf0[MT], wf0[NT];                                      // chunk-0 fragments; after the last tap they hold the tail K tile's (FUSE_TAIL)
+
+#pragma unroll 1
+    for (int h = 0; h < NH; ++h) {
+      // the phase after this one: the other half of this tile, or half 0 of the next tile, or none (dummy pieces)
+      const int n_tix = h + 1 < NH ? tix : (has_next ? tnext : -1), n_h = h + 1 < NH ? h + 1 : 0;
+      const unsigned char* nbase = n_tix >= 0 ? halo_base(n_tix, n_h) : nullptr;
+      const int n_r0 = n_tix >= 0 ? (n_tix % tiles_per_img) * TR : 0;
+      const bool n_top = n_r0 == 0, n_bot = n_r0 + TR == p.H;
+      // Register pressure: everything derived from the lane index for the pieces / the tail loads / the epilogue is loop-invariant, and
+      // hipcc would hoist ~80 VGPRs of addresses out of the tile loop (spills in the K loop); an opaque copy per phase keeps the
+      // arithmetic where it is used.
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      u32x4 xf1[MT], wf1[NT];
+      // chunk 0 of tap 0 (exposed once per phase: fragments are not carried over the phase loop, see the header)
+      {
+        const unsigned char* wb = wst0 + st_cur * STAGE + b_rd;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) wf0[j] = *reinterpret_cast<const u32x4*>(wb + j * 2048 + sw0);
+        for (int j = 0; j < NT; ++j) wf0[j] = *reinterpret_cast<const u32x4*>(wb + j * 2048 + sw0);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int hp = hp0[i] + toff;
-        xa[i] = (unsigned)hp * PXB + (unsigned)((((kh * 8 + lq) ^ hp) & (CPP - 1)) << 4);
-        xf0[i] = *reinterpret_cast<const u32x4*>(smem + xa[i]);
+        for (int i = 0; i < MT; ++i) xf0[i] = *reinterpret_cast<const u32x4*>(smem + xb[i]);
       }
-    };
-    auto read_k1 = [&](int stage) {
-      const unsigned char* wb = wst0 + stage * H_STAGE + b_rd;
+      H_STAMP(ckP);
+      static_for<9>([&](auto tapc) {
+        constexpr int TAP = decltype(tapc)::value;
+        constexpr int TOFF = ((TAP / 3) * HP + TAP % 3) * 16;                       // this tap's shift inside a plane
+        constexpr int TOFF_N = (((TAP + 1) / 3) * HP + (TAP + 1) % 3) * 16;         // the next tap's
+        const bool pre_w = steps_left > 2;
+        if (pre_w) issue_w(wk_of(q_pre), st_pre);                                    // weights of the step two ahead
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- region A: the 20 MFMAs of chunk 0, with the 9 fragment reads of chunk 1 (k 32..63 of the half) issued one behind each
+        // of the first 9 MFMAs.  All eight waves pass the same barriers, so whatever a wave issues OUTSIDE an MFMA block is time the
+        // SIMD's matrix pipe idles (both of its waves are in that section together): every other instruction rides between MFMAs.
+        {
+          const unsigned char* wb = wst0 + st_cur * STAGE + b_rd;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) wf1[j] = *reinterpret_cast<const u32x4*>(wb + j * 2048 + sw1);
+          for (int j = 0; j < NT; ++j) wf1[j] = *reinterpret_cast<const u32x4*>(wb + j * 2048 + sw1);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) xf1[i] = *reinterpret_cast<const u32x4*>(smem + (xa[i] ^ 64u));   // chunk + 4
-    };
-    auto read_tail0 = [&](int stage) {   // identity / downsample conv: A rows = the 27 (padded to 32) im2col taps, straight from global
-      const unsigned char* wb = wst0 + stage * H_STAGE + b_rd;
+          for (int i = 0; i < MT; ++i) xf1[i] = *reinterpret_cast<const u32x4*>(smem + xb[i] + 4 * PLANE + TOFF);
+        }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) wf0[j] = *reinterpret_cast<const u32x4*>(wb + j * 2048 + sw0);
-      const bf16* X2 = reinterpret_cast<const bf16*>(p.x2);
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const size_t pix = (size_t)(b * p.H + r0 + prow[i]) * p.W + pcol[i];
-        xf0[i] = *reinterpret_cast<const u32x4*>(X2 + pix * p.x2_cstride + lq * 8);
+          for (int j = 0; j < NT; ++j) acc[i][j] = mma_chunk<bf16>(wf0[j], xf0[i], acc[i][j]);
+#pragma unroll
+        for (int k = 0; k < MT + NT; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                         // 1 DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT), 0);
+        __builtin_amdgcn_sched_barrier(0);
+        H_STAMP(ckA);
+        // Everything older than the youngest operations has landed: the weights of the NEXT step (issued one step ago), and at tap 8
+        // every halo piece of the next phase.  Younger: the halo piece issued behind the previous step's barrier (taps 1..7) and the
+        // two weight DMAs just issued.  lgkmcnt(0): this wave's reads of the current weight stage are complete before anyone may
+        // overwrite it.
+        if (TAP >= 1 && TAP <= NPIECE) { if (pre_w) HWAIT(3); else HWAIT(1); }
+        else { if (pre_w) HWAIT(2); else HWAIT(0); }
+        H_STAMP(ckV);
+        hbar();
+        H_STAMP(ckW);
+        // ---- region B: the 20 MFMAs of chunk 1; between them the halo piece of the next phase (address arithmetic + one LDS-DMA) and
+        // the 9 fragment reads of the next tap's chunk 0
+        if constexpr (TAP < NPIECE) issue_piece(TAP, lane_o, nbase, n_top, n_bot, buf ^ 1);
+        const int st_next = st_cur == NST - 1 ? 0 : st_cur + 1;
+        if constexpr (TAP < 8) {                                                     // chunk 0 of the next tap
+          const unsigned char* wb = wst0 + st_next * STAGE + b_rd;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) wf0[j] = *reinterpret_cast<const u32x4*>(wb + j * 2048 + sw0);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) xf0[i] = *reinterpret_cast<const u32x4*>(smem + xb[i] + TOFF_N);
+        } else if (FUSE_TAIL) {
+          if (h == NH - 1) {                                                         // im2col rows of the tile's pixels for the tail K tile
+            const bf16* X2 = reinterpret_cast<const bf16*>(p.x2);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              const int lr = lane_o & 15;
+              const int fr_o = ((lr >> 3) & 1) * 2 + ((lr >> 1) & 1), fc_o = ((lr >> 2) & 1) * 2 + (lr & 1);
+              const size_t pix = (size_t)(b * p.H + r0 + blk_r(i) * 4 + fr_o) * p.W + blk_c(i) * 4 + fc_o;
+              xf0[i] = hgload16(X2 + pix * p.x2_cstride + lq * 8);      // asynchronous: certified by the counted wait of the tail step
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mma_chunk<bf16>(wf1[j], xf1[i], acc[i][j]);
+        if constexpr (TAP < NPIECE) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                       // 3 VALU of the piece's address
+          }
+#pragma unroll
+          for (int k = 0; k < MT + NT; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - 8 - (MT + NT), 0);
+        } else if constexpr (TAP < 8) {
+#pragma unroll
+          for (int k = 0; k < MT + NT; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - (MT + NT), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        H_STAMP(ckB);
+        advance();
+      });
+      buf ^= 1;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xb[i] = buf ? xb[i] + (unsigned)HBUF : xb[i] - (unsigned)HBUF;
+    }
+
+    if constexpr (FUSE_TAIL) {   // tail K tile: 32 im2col taps of the downsample conv, one k-chunk
+      // The five im2col loads (asynchronous, into xf0) were issued behind the previous barrier; everything older - the weights of this
+      // step and of the next - was issued a whole K tile ago, so one unconditional vmcnt(0) costs nothing.  ONE asm statement carries
+      // the registers: with a wait per branch hipcc tied each branch's operands to different registers and copied the fragments
+      // BEFORE the wait on one path (stale data in the last tile of every workgroup).
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xf0[0]), "+v"(xf0[1]), "+v"(xf0[2]), "+v"(xf0[3]), "+v"(xf0[4]) :: "memory");
+      const bool pre_w = steps_left > 2;
+      if (pre_w) issue_w(wk_of(q_pre), st_pre);
+      {
+        const unsigned char* wb = wst0 + st_cur * STAGE + b_rd;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf0[j] = *reinterpret_cast<const u32x4*>(wb + j * 2048 + sw0);
       }
-    };
-    auto mma0 = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = mma_chunk<bf16>(wf0[j], xf0[i], acc[i][j]);
-    };
-    auto mma1 = [&]() {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = mma_chunk<bf16>(wf1[j], xf1[i], acc[i][j]);
-    };
-    auto advance = [&]() {
-      st_cur = st_cur == H_NST - 1 ? 0 : st_cur + 1;
-      st_pre = st_pre == H_NST - 1 ? 0 : st_pre + 1;
-      wk_pre = wk_pre == NKT - 1 ? 0 : wk_pre + 1;
-    };
-    int ky = 0, kx = 0, kh = 0;                              // tap / 64-channel slice of the current K tile
-    read_k0(0, 0, st_cur);
-    // One K tile.  NEXT: 0 = another main K tile follows, 1 = the tail K tile follows, 2 = nothing follows.  The steady-state
-    // instance (MORE known, NEXT = 0) is straight-line code: with a branch around the reads hipcc's waitcnt pass falls back
-    // to lgkmcnt(4..0) in front of the second MFMA block, i.e. waits for the reads it was meant to overlap.
-    auto ktile = [&](auto more_c, auto next_c, bool more_rt) {
-      constexpr int MORE = decltype(more_c)::value, NEXT = decltype(next_c)::value;     // MORE: 1 yes, 0 no, 2 runtime
-      const bool more = MORE == 2 ? more_rt : MORE == 1;
-      if (more) issue_w(wk_pre, st_pre);                     // the K tile two ahead (of this output tile, or of the next one)
-      read_k1(st_cur);
-      __builtin_amdgcn_sched_barrier(0);                     // reads are ISSUED before the MFMA block they run under
-      mma0();
-      if (more) HWAIT_VM(2); else HWAIT_VM(0);               // everything but the K tile just issued has landed
-      hbar();
-      int kh2 = kh + 1, kx2 = kx, ky2 = ky;
-      if (kh2 == KH64) { kh2 = 0; ++kx2; if (kx2 == 3) { kx2 = 0; ++ky2; } }
-      const int st_next = st_cur == H_NST - 1 ? 0 : st_cur + 1;
-      if constexpr (NEXT == 0) read_k0(ky2 * H_HW + kx2, kh2, st_next);
-      else if constexpr (NEXT == 1) read_tail0(st_next);
       __builtin_amdgcn_sched_barrier(0);
-      mma1();
-      kh = kh2; kx = kx2; ky = ky2;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      hbar();
       advance();
-    };
-#pragma unroll 1
-    for (int kt = 0; kt + 2 < NKM; ++kt) ktile(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, true);
-    if constexpr (FUSE_TAIL) {
-      ktile(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, true);           // kt = NKM-2: the tail is 2 ahead
-      ktile(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, has_next);       // kt = NKM-1
-      if (has_next) issue_w(wk_pre, st_pre);                                                     // tail K tile: 32 taps, one k-chunk
-      mma0();
-      if (has_next) HWAIT_VM(2); else HWAIT_VM(0);
-      advance();
-    } else {
-      ktile(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, has_next);       // kt = NKM-2
-      ktile(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, has_next);       // kt = NKM-1
+      H_STAMP(ckT);
     }
-    hbar();                                               // every wave is done reading this halo tile
-    if (has_next) issue_halo(tnext);                      // lands under the epilogue stores
 
-    // ---- epilogue: lane holds 4 consecutive channels of pixel lrow per 16x16 tile
+    // ---- epilogue: per n-tile pair a lane holds 8 consecutive channels (wn * 64 + 32 jp + 8 lq .. + 7) of pixel lrow
     {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));                          // see the phase loop: keeps the store addresses out of the K loop's registers
+      const int lrow_e = lane_e & 15, lq_e = lane_e >> 4;
+      const int fr_e = ((lrow_e >> 3) & 1) * 2 + ((lrow_e >> 1) & 1), fc_e = ((lrow_e >> 2) & 1) * 2 + (lrow_e & 1);
       f32x4 bv[NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bv[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + wn * 64 + j * 16 + lq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NT; ++j)
+        bv[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + wn * 64 + (j >> 1) * 32 + lq_e * 8 + (j & 1) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       auto finish = [&](auto actf) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           size_t orow;
           const float* posrow = nullptr;
+          const int prow_i = blk_r(i) * 4 + fr_e, pcol_i = blk_c(i) * 4 + fc_e;
           if (FUSE_TAIL) {
             const int ph = p.H >> 1, pw = p.W >> 1;
-            const int py = (r0 + prow[i]) >> 1, px = pcol[i] >> 1;
+            const int py = (r0 + prow_i) >> 1, px = pcol_i >> 1;
             orow = (size_t)(b * ph + py) * pw + px;
             posrow = p.pos + (size_t)(py * pw + px) * p.y_cstride;
           } else {
-            orow = (size_t)(b * p.H + r0 + prow[i]) * p.W + pcol[i];
+            orow = (size_t)(b * p.H + r0 + prow_i) * p.W + pcol_i;
           }
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const int n = wn * 64 + j * 16 + lq * 4;
-            f32x4 v = acc[i][j] + bv[j];
-            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int jp = 0; jp < NT / 2; ++jp) {
+            const int n = wn * 64 + jp * 32 + lq_e * 8;
+            f32x4 v[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = actf(v[e]);
-            if (FUSE_TAIL) {
+            for (int u = 0; u < 2; ++u) {
+              v[u] = acc[i][2 * jp + u] + bv[2 * jp + u];
+              acc[i][2 * jp + u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                v[e] = fmaxf(v[e], __shfl_xor(v[e], 1, 64));
-                v[e] = fmaxf(v[e], __shfl_xor(v[e], 2, 64));
+              for (int e = 0; e < 4; ++e) v[u][e] = actf(v[u][e]);
+              if (FUSE_TAIL) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {        // max over the window's 4 lanes with DPP quad permutes (VALU): __shfl_xor is an LDS ds_bpermute per value
+                  v[u][e] = fmaxf(v[u][e], quad_xor<0xB1>(v[u][e]));      // lanes ^ 1: quad_perm [1,0,3,2]
+                  v[u][e] = fmaxf(v[u][e], quad_xor<0x4E>(v[u][e]));      // lanes ^ 2: quad_perm [2,3,0,1]
+                }
+                v[u] += *reinterpret_cast<const f32x4*>(posrow + n + 4 * u);
               }
-              v += *reinterpret_cast<const f32x4*>(posrow + n);
-              if ((lrow & 3) == 0) store4<bf16>(Y + orow * p.y_cstride + n, v);
-            } else {
-              store4<bf16>(Y + orow * p.y_cstride + n, v);
+            }
+            if (!FUSE_TAIL || (lrow_e & 3) == 0) {
+              const bf16x8 o = {(bf16)v[0][0], (bf16)v[0][1], (bf16)v[0][2], (bf16)v[0][3], (bf16)v[1][0], (bf16)v[1][1], (bf16)v[1][2], (bf16)v[1][3]};
+              *reinterpret_cast<bf16x8*>(Y + orow * p.y_cstride + n) = o;
             }
           }
         }
@@ -285,18 +407,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_halo_kernel(const ConvGemmPara
       else if (p.act == ACT_LRELU) finish([](float x) { return x > 0.0f ? x : 0.1f * x; });
       else finish([](float x) { return x; });
     }
+    H_STAMP(ckE);
     if (!has_next) break;
-    HWAIT_VM(0);                                          // halo + the two prefetched weight tiles of the next output tile
-    hbar();
     tix = tnext;
   }
+#ifdef H_CLK
+  if (t == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
+    printf("[halo<%d,%d> wg %d] tiles %d total %lld | phase-start reads %lld  region A %lld  waitcnt %lld  barrier %lld  region B %lld  tail %lld  epilogue %lld\n", CIN, (int)FUSE_TAIL,
+           (int)blockIdx.x, my_tiles, __builtin_readcyclecounter() - ck0, ckP, ckA, ckV, ckW, ckB, ckT, ckE);
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no DMA (dummy pieces) may be in flight into the LDS of a finished workgroup
 }
 
 bool conv3x3_halo_eligible(const ConvGemmParams& p, int dtype) {
   static const bool off = [] { const char* e = getenv("FSVIT_HALO"); return e && e[0] == '0'; }();
   if (off || dtype != 1) return false;
   if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.groups != 1) return false;
-  if (p.N != 128 || p.y_cstride != 128 || p.W != H_TW || (p.H % H_TR) || p.OH != p.H || p.OW != p.W) return false;
+  if (p.N != 128 || p.y_cstride != 128 || p.W != halo::TW || (p.H % halo::TR) || p.OH != p.H || p.OW != p.W) return false;
   if (p.res || p.y_rpi || p.out_f32 || p.w_rstride || p.w_gstride) return false;
   if (p.Cin != p.x_cstride || p.K != 9 * p.Cin) return false;
   if (p.pool2) return p.Cin == 128 && p.x2 && p.K2 == 32 && p.x2_cstride >= 32 && p.pos && p.Kw == p.K + 64;
@@ -305,13 +432,12 @@ bool conv3x3_halo_eligible(const ConvGemmParams& p, int dtype) {
 
 template <int CIN, bool FUSE_TAIL>
 static int launch_halo_t(const ConvGemmParams& p, hipStream_t stream) {
-  const int n_tiles = p.B * (p.H / H_TR);
-  const int lds = halo_bytes(CIN) + H_NST * H_STAGE;
+  const int n_tiles = p.B * (p.H / halo::TR);
   auto kern = conv3x3_halo_kernel<CIN, FUSE_TAIL>;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, halo::LDS_BYTES);
   if (e != hipSuccess) return (int)e;
   const int grid = n_tiles < 256 ? n_tiles : 256;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p, n_tiles);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), halo::LDS_BYTES, stream, p, n_tiles);
   return (int)hipGetLastError();
 }
 

@@ -14,14 +14,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 LOGIT_TOL_PARITY = 1e-3        # BASELINE.json north_star
-# bf16 throughput mode against the fp32 reference golden: 1.5 x the measured 1.07e-1 (5-shot) / 8.7e-2 (1-shot).  This deviation is
+# bf16 throughput mode against the fp32 reference golden: 1.5 x the measured 1.07e-1 (round 1) / 9.2e-2 .. 9.6e-2 (round 2).  This deviation is
 # the bf16 rounding of the (BN-folded) WEIGHTS - a fixed perturbation of the model that does not average out over tokens - not of
 # the stored activations or the residual stream (ablation on the rounding-point emulator: DESIGN.md 2, tools/emul_ablation.py).
 LOGIT_TOL_BF16 = 0.16
 # ... and against the oracle that rounds where the kernels round (oracle/visformer_emul.py): only accumulation order and the
-# softmax / GELU instruction sequences differ.  Set from the measurement printed by the test (1.5 x).
-LOGIT_TOL_BF16_EMUL = 3e-2
-TAP_TOL_BF16_EMUL = 2e-2
+# softmax / GELU instruction sequences differ - one-ulp flips of stored bf16 activations (2^-8 relative) that then propagate.
+# 1.5 x the measured 3.1e-2 / 3.5e-2 (logits, mean 7e-3) and 1.2e-2 (taps, relative to the tap's max).
+LOGIT_TOL_BF16_EMUL = 5.3e-2
+TAP_TOL_BF16_EMUL = 1.8e-2
 
 
 @pytest.fixture(scope='module')
@@ -127,7 +128,7 @@ def test_residual_stream_taps_bf16_vs_rounding_point_oracle(full_sd):
     assert perr <= TAP_TOL_BF16_EMUL
 
 
-@pytest.mark.parametrize('numerics,tol', [('parity', 2e-4), ('bf16', 0.06)])
+@pytest.mark.parametrize('numerics,tol', [('parity', 2e-4), ('bf16', 0.027)])     # bf16: 1.5 x the measured 1.8e-2
 def test_residual_stream_taps_vs_oracle(full_sd, numerics, tol):
     """Every residual-stream checkpoint of the encoder against the oracle's NCHW taps."""
     from fewshot_vit_amd import synthetic

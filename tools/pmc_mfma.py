@@ -8,9 +8,9 @@ utilisation").  Input: one or two rocpd databases of
     python tools/pmc_mfma.py <db1> [<db2>] "<note>" > profiles/rNN_mfma_pmc.json        (text table on stderr)
 
 Derived per kernel (means over its launches):
-    mfma_busy      = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs)     fraction of the chip's matrix-pipe cycles in use
+    mfma_busy      = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs)     fraction of the chip's matrix-pipe cycles in use
                      (SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs: 16 per v_mfma_f32_16x16x32_bf16, 32 per 32x32x16;
-                     GRBM_GUI_ACTIVE = shader-clock cycles of the launch) - comparable with roofline.frac, which counts only the
+                     GRBM_GUI_ACTIVE = shader-clock cycles of the launch SUMMED over the 8 XCDs, as rocprofv3 reports it: a 1.3 ms launch reads ~2e7) - comparable with roofline.frac, which counts only the
                      ALGORITHMIC flops (padded head dims / K slices are MFMA-busy but not algorithmic)
     valu_active    = 4 * SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES ... reported as fractions of wave cycles (quad-cycle counters):
     wave_valu, wave_lds, wave_wait_any (parked at s_waitcnt / barrier), wave_wait_inst (issue stalls), lds_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
@@ -43,7 +43,7 @@ def main():
     for p in dbs:
         load(p, acc)
     out = {'_meta': {'source': 'rocprofv3 --pmc SQ_* / GRBM_GUI_ACTIVE passes (kernels serialised by the profiler); ' + note,
-                     'mfma_busy': 'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs)'}}
+                     'mfma_busy': 'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)'}}
     rows = []
     for k, d in acc.items():
         gui = d.get('GRBM_GUI_ACTIVE')
@@ -51,14 +51,14 @@ def main():
             continue
         wc = d.get('SQ_WAVE_CYCLES', 0.0)
         rec = {'launches': d['_launches'], 'gui_active_cycles': gui,
-               'mfma_busy': d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui * 1024.0)}
+               'mfma_busy': d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui / 8.0 * 1024.0)}
         for key, ctr in (('wave_valu', 'SQ_ACTIVE_INST_VALU'), ('wave_lds', 'SQ_ACTIVE_INST_LDS'), ('wave_wait_any', 'SQ_WAIT_ANY'),
                          ('wave_wait_inst', 'SQ_WAIT_INST_ANY'), ('wave_wait_inst_lds', 'SQ_WAIT_INST_LDS'), ('wave_active_any', 'SQ_ACTIVE_INST_ANY')):
             if ctr in d and wc:
                 rec[key] = d[ctr] / wc
         if d.get('SQ_LDS_IDX_ACTIVE'):
             rec['lds_conflict'] = d.get('SQ_LDS_BANK_CONFLICT', 0.0) / d['SQ_LDS_IDX_ACTIVE']
-            rec['lds_busy'] = d['SQ_LDS_IDX_ACTIVE'] / (gui * 256.0)
+            rec['lds_busy'] = d['SQ_LDS_IDX_ACTIVE'] / (gui / 8.0 * 256.0)
         for ctr in ('SQ_INSTS_VALU', 'SQ_INSTS_MFMA', 'SQ_INSTS_LDS', 'SQ_INSTS_SALU', 'SQ_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_LDS_BANK_CONFLICT'):
             if ctr in d:
                 rec[ctr] = d[ctr]
