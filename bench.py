@@ -474,34 +474,48 @@ def eval_main(args, rank, world, dev):
         torch.cuda.synchronize()
     if world == 1 and not args.no_modes and args.model == 'visformer_micro_80' and args.numerics != 'parity':
         label = torch.arange(way, device=dev).repeat_interleave(query)
-        _, _, peng = build('parity')
-        step(peng, 0)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        plog = [step(peng, i)[0] for i in range(n_pool)]
-        torch.cuda.synchronize()
-        pel = time.perf_counter() - t0
-        plog = torch.cat(plog)
+
+        def run_mode(numerics):
+            _, _, eng = build(numerics)
+            step(eng, 0)
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            lg = [step(eng, i)[0] for i in range(n_pool)]
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0_
+            return torch.cat(lg), el
+
+        def agreement(a_name, a_log, b_name, b_log):
+            ea = (a_log.argmax(-1) == label).float().mean(dim=1).double()                       # per episode
+            eb = (b_log.argmax(-1) == label).float().mean(dim=1).double()
+            ba = (a_log.argmax(-1) == label).float().view(n_pool, -1).mean(dim=1).double()      # per reference batch (= one step of E episodes)
+            bb = (b_log.argmax(-1) == label).float().view(n_pool, -1).mean(dim=1).double()
+            ne = float(ea.numel())
+            cia = float(ea.std(unbiased=True)) / ne ** 0.5 * float(scipy.stats.t.ppf(0.975, ne - 1.0)) if ne > 1 else float('nan')
+            return {'modes': [a_name, b_name], 'episodes': int(ne),
+                    'argmax_agreement': (a_log.argmax(-1) == b_log.argmax(-1)).float().mean().item(),
+                    'accuracy_' + a_name: float(ea.mean()), 'accuracy_' + b_name: float(eb.mean()),
+                    'abs_delta_mean_accuracy': abs(float(ea.mean()) - float(eb.mean())), 'ci95_per_episode': cia,
+                    'max_abs_delta_batch_accuracy': float((ba - bb).abs().max()),
+                    'max_abs_dlogit': (a_log - b_log).abs().max().item(), 'mean_abs_dlogit': (a_log - b_log).abs().mean().item()}
+
+        plog, pel = run_mode('parity')
         peps = n_pool * E / pel
         out['modes'] = {'parity': {'value': peps, 'unit': 'episodes/s', 'ms_per_step': 1e3 * pel / n_pool, 'steps': n_pool, 'dtype': 'f32',
                                    'whole_path_tflops': peps * flops_ep / 1e12,
                                    'whole_path_mfma_frac': peps * flops_ep / 1e12 / MFMA_PEAK_TFLOPS['parity'],
                                    'note': 'exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): the mode that meets the 1e-3 logit tolerance against the reference '
                                            '(tests/test_gpu_visformer.py); same episode pool as the headline leg'}}
-        ah = (head_logits.argmax(-1) == label).float().view(n_pool, -1).mean(dim=1).double()    # per reference batch (= one step of E episodes)
-        ap = (plog.argmax(-1) == label).float().view(n_pool, -1).mean(dim=1).double()
-        eh = (head_logits.argmax(-1) == label).float().mean(dim=1).double()                        # per episode
-        ep = (plog.argmax(-1) == label).float().mean(dim=1).double()
-        ne = float(eh.numel())
-        cih = float(eh.std(unbiased=True)) / ne ** 0.5 * float(scipy.stats.t.ppf(0.975, ne - 1.0)) if ne > 1 else float('nan')
-        out['agreement'] = {'modes': [args.numerics, 'parity'], 'episodes': int(ne),
-                            'argmax_agreement': (head_logits.argmax(-1) == plog.argmax(-1)).float().mean().item(),
-                            'accuracy_' + args.numerics: float(eh.mean()), 'accuracy_parity': float(ep.mean()),
-                            'abs_delta_mean_accuracy': abs(float(eh.mean()) - float(ep.mean())), 'ci95_per_episode': cih,
-                            'max_abs_delta_batch_accuracy': float((ah - ap).abs().max()),
-                            'max_abs_dlogit': (head_logits - plog).abs().max().item(),
-                            'mean_abs_dlogit': (head_logits - plog).abs().mean().item()}
-        del peng
+        out['agreement'] = agreement(args.numerics, head_logits, 'parity', plog)
+        other = 'f16' if args.numerics == 'bf16' else 'bf16'
+        olog, oel = run_mode(other)
+        oeps = n_pool * E / oel
+        out['modes'][other] = {'value': oeps, 'unit': 'episodes/s', 'ms_per_step': 1e3 * oel / n_pool, 'steps': n_pool, 'dtype': other,
+                               'whole_path_tflops': oeps * flops_ep / 1e12, 'whole_path_mfma_frac': oeps * flops_ep / 1e12 / MFMA_PEAK_TFLOPS[other],
+                               'agreement_with_parity': agreement(other, olog, 'parity', plog),
+                               'note': 'the same kernels compiled for the other 16-bit type (namespace fsvit_f16 = _Float16 storage + v_mfma_*_f16; '
+                                       'namespace fsvit = __bf16): same episode pool, same MFMA peak; untimed-profile wall clock of %d steps' % n_pool}
+        del plog, olog
     if world == 1 and not args.no_cpu_baseline:
         k = min(E, max(4, args.cpu_episodes))
         out['cpu_baseline'] = cpu_baseline(sd, pool[0][0][:k].cpu(), pool[0][1][:k].cpu(), head_logits[:k], args.cpu_episodes, args.model)

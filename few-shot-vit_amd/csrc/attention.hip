@@ -12,7 +12,7 @@
 #include "fsvit_common.h"
 #include "kernels.h"
 
-namespace fsvit {
+namespace FSVIT_NS {
 
 struct AttnGeom {
   int SP;    // tokens rounded up to 16 (MFMA tile rows)
@@ -338,4 +338,4 @@ int launch_attention(const void* qkv, void* ctx, int B, int S, int heads, int hd
   return (int)hipGetLastError();
 }
 
-}  // namespace fsvit
+}  // namespace FSVIT_NS

@@ -35,7 +35,7 @@
 #include "conv_gemm.h"
 #include "fsvit_common.h"
 
-namespace fsvit {
+namespace FSVIT_NS {
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page_halo[256];
 typedef __attribute__((address_space(3))) void* lptrh_t;
@@ -446,4 +446,4 @@ int launch_conv3x3_halo(const ConvGemmParams& p, hipStream_t stream) {
   return p.Cin == 64 ? launch_halo_t<64, false>(p, stream) : launch_halo_t<128, false>(p, stream);
 }
 
-}  // namespace fsvit
+}  // namespace FSVIT_NS

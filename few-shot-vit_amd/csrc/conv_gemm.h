@@ -10,7 +10,10 @@
 #include <stddef.h>
 #include <hip/hip_runtime.h>
 
-namespace fsvit {
+// Types shared by every kernel namespace.  They live in a namespace WITHOUT functions so that argument-dependent lookup on a
+// ConvGemmParams argument never drags in the other 16-bit build's launchers (see fsvit_common.h: kernel sources are compiled twice).
+namespace fsvit_types {
+
 
 enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_LRELU = 2 };
 
@@ -55,15 +58,22 @@ struct ConvGemmParams {
   int out_f32;
 };
 
-// dtype: 0 = f32 (exact fp32 MFMA), 1 = bf16.  Returns hipError_t as int.
-int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream);
-int launch_conv_gemm_v2(const ConvGemmParams& p, int dtype, hipStream_t stream);
-// gemm256.hip: 256x256-tile, 8-wave, 4-phase dense bf16 GEMM for plain [M][K] x [N][K] layers (N >= 192, K % 64 == 0)
-bool gemm256_eligible(const ConvGemmParams& p, int dtype);
-int launch_gemm256(const ConvGemmParams& p, hipStream_t stream);
-// conv3x3_halo.hip: 3x3 / stride 1 conv with the input tile + halo resident in LDS (stem conv2 / conv3 geometry)
-bool conv3x3_halo_eligible(const ConvGemmParams& p, int dtype);
-int launch_conv3x3_halo(const ConvGemmParams& p, hipStream_t stream);
-int conv_gemm_v2_config(const ConvGemmParams& p);   // which tile configuration launch_conv_gemm_v2 picks
+}  // namespace fsvit_types
 
-}  // namespace fsvit
+// The launchers exist twice: namespace fsvit (16-bit type = __bf16) and namespace fsvit_f16 (16-bit type = _Float16); `dtype` is
+// 0 = f32 (exact fp32 MFMA), 1 = the namespace's 16-bit type.  Returns hipError_t as int.
+#define FSVIT_DECLARE_CONV_GEMM(NS)                                                                                        \
+  namespace NS {                                                                                                           \
+  using namespace fsvit_types;                                                                                             \
+  int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream);                                            \
+  int launch_conv_gemm_v2(const ConvGemmParams& p, int dtype, hipStream_t stream);                                         \
+  /* gemm256.hip: 256x256-tile, 8-wave, 4-phase dense 16-bit GEMM for plain [M][K] x [N][K] layers (N >= 192, K % 64 == 0) */ \
+  bool gemm256_eligible(const ConvGemmParams& p, int dtype);                                                               \
+  int launch_gemm256(const ConvGemmParams& p, hipStream_t stream);                                                         \
+  /* conv3x3_halo.hip: 3x3 / stride 1 conv with the input tile + halo resident in LDS (stem conv2 / conv3 geometry) */      \
+  bool conv3x3_halo_eligible(const ConvGemmParams& p, int dtype);                                                          \
+  int launch_conv3x3_halo(const ConvGemmParams& p, hipStream_t stream);                                                    \
+  int conv_gemm_v2_config(const ConvGemmParams& p); /* which tile configuration launch_conv_gemm_v2 picks */               \
+  }
+FSVIT_DECLARE_CONV_GEMM(fsvit)
+FSVIT_DECLARE_CONV_GEMM(fsvit_f16)

@@ -19,7 +19,7 @@
 #include "conv_gemm.h"
 #include "fsvit_common.h"
 
-namespace fsvit {
+namespace FSVIT_NS {
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
@@ -394,4 +394,4 @@ int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream) {
   return launch_conv_gemm_v2(p, dtype, stream);
 }
 
-}  // namespace fsvit
+}  // namespace FSVIT_NS

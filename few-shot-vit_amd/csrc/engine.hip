@@ -21,6 +21,12 @@
 
 using namespace fsvit;
 
+// Kernel-namespace dispatch: every kernel exists for the two 16-bit storage types (namespace fsvit = bf16, fsvit_f16 = fp16; see
+// fsvit_common.h).  K(fn) picks the build that matches `kdt` (a FSVIT_* dtype in scope); kd() maps the public dtype to the kernels'
+// own convention (0 = f32, 1 = the namespace's 16-bit type).
+#define K(fn) (kdt == FSVIT_F16 ? fsvit_f16::fn : fsvit::fn)
+static inline int kd(int dtype) { return dtype == FSVIT_F32 ? 0 : 1; }
+
 // ------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
@@ -63,6 +69,23 @@ static inline uint16_t f32_to_bf16(float f) {   // round to nearest even
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+static inline uint16_t f32_to_f16(float f) {    // IEEE binary16, round to nearest even, gradual underflow, overflow -> inf
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+  const uint32_t a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                    // NaN
+  if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                   // >= 65520 rounds to inf
+  if (a < 0x33000001u) return sign;                                          // < 2^-25 (or exactly 2^-25: ties to even = 0)
+  const int e = (int)(a >> 23) - 127;                                        // unbiased exponent
+  uint32_t m = (a & 0x7fffffu) | 0x800000u;                                  // 24-bit significand
+  int shift = e >= -14 ? 13 : 13 + (-14 - e);                                // bits dropped (subnormal halves drop more)
+  const uint32_t half = 1u << (shift - 1), rest = m & ((1u << shift) - 1u);
+  uint32_t q = m >> shift;
+  if (rest > half || (rest == half && (q & 1u))) ++q;
+  if (e >= -14) return (uint16_t)(sign | (uint16_t)(((uint32_t)(e + 15 - 1) << 10) + q));   // the hidden bit carries into the exponent
+  return (uint16_t)(sign | (uint16_t)q);                                     // subnormal (q may carry into the smallest normal)
+}
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -74,7 +97,6 @@ struct Layer {
 };
 struct Block1 {
   Layer c1, c2, c3;
-  void* rows_img = nullptr;    // stage1_rows.hip: fragment-major image of the three convs (null: stage1_fused / unfused path)
 };
 struct BlockA {
   Layer qkv, proj, fc1, fc2;
@@ -157,9 +179,9 @@ Affine bn_affine(const SD& sd, const std::string& p, int C, double eps) {
 
 int upload(EngineBase* h, const std::vector<float>& src, bool as_storage, void** out) {
   void* d = nullptr;
-  if (as_storage && h->dtype == FSVIT_BF16) {
+  if (as_storage && h->dtype != FSVIT_F32) {
     std::vector<uint16_t> tmp(src.size());
-    for (size_t i = 0; i < src.size(); ++i) tmp[i] = f32_to_bf16(src[i]);
+    for (size_t i = 0; i < src.size(); ++i) tmp[i] = h->dtype == FSVIT_F16 ? f32_to_f16(src[i]) : f32_to_bf16(src[i]);
     HIP_TRY(hipMalloc(&d, tmp.size() * 2));
     h->allocs.push_back(d);
     HIP_TRY(hipMemcpy(d, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
@@ -227,6 +249,7 @@ int pack_pos(EngineBase* h, const float* pos, int C, int HW, float** out) {
 }
 
 int build(fsvit_visformer* h, const SD& sd) {
+  const int kdt = h->dtype;
   const fsvit_visformer_cfg& cf = h->cfg;
   const double eps = cf.bn_eps;
   const int epc = 16 / h->es;
@@ -241,8 +264,8 @@ int build(fsvit_visformer* h, const SD& sd) {
   const int kch = 64 / h->es;                                  // head dim padded to the 64-byte MFMA K chunk
   h->hd2 = (int)std::lround((double)(h->C2 / cf.num_heads));  // round(dim // heads * 1.0), visformer.py:172
   h->hd3 = (int)std::lround((double)(h->C3 / cf.num_heads));
-  h->hdp2 = attention_padded_head_dim(h->hd2, h->H2 * h->H2, h->dtype);
-  h->hdp3 = attention_padded_head_dim(h->hd3, h->H3 * h->H3, h->dtype);
+  h->hdp2 = K(attention_padded_head_dim)(h->hd2, h->H2 * h->H2, kd(kdt));
+  h->hdp3 = K(attention_padded_head_dim)(h->hd3, h->H3 * h->H3, kd(kdt));
   (void)kch;
   const int Cg = h->hid1 / cf.group;
   if (h->C0 % epc || h->C1 % epc || h->hid1 % cf.group || Cg % epc)
@@ -306,14 +329,6 @@ int build(fsvit_visformer* h, const SD& sd) {
     RC_TRY(pack_layer(h, &h->s1[i].c1, w1, h->hid1, h->C1, 1, 1, 1, nullptr, &n2.s, prenorm_bias(w1, h->hid1, h->C1, n2.t), true, nullptr, 0, nullptr, 0));
     RC_TRY(pack_layer(h, &h->s1[i].c2, w2, h->hid1, Cg, 3, 3, cf.group, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
     RC_TRY(pack_layer(h, &h->s1[i].c3, w3, h->C1, h->hid1, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
-    if (stage1_rows_supported(h->dtype, h->C1, h->hid1, cf.group, h->H1)) {
-      void* img = nullptr;
-      HIP_TRY(hipMalloc(&img, stage1_rows_image_bytes()));
-      h->allocs.push_back(img);
-      RC_TRY(launch_stage1_pack(h->s1[i].c1.w, h->s1[i].c2.w, h->s1[i].c3.w, img, nullptr));
-      HIP_TRY(hipDeviceSynchronize());
-      h->s1[i].rows_img = img;
-    }
   }
   // ---- patch embeds (visformer.py:266-288): conv k2 s2 + bias -> BN ; pos_embed added in the epilogue
   for (int s = 2; s <= 3; ++s) {
@@ -354,25 +369,25 @@ int build(fsvit_visformer* h, const SD& sd) {
       RC_TRY(pack_layer(h, &blocks[i].proj, wp, C, heads * hd, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, &colmap, heads * hdp));
       RC_TRY(pack_layer(h, &blocks[i].fc1, w1, hid, C, 1, 1, 1, nullptr, &n2.s, prenorm_bias(w1, hid, C, n2.t), true, nullptr, 0, nullptr, 0));
       RC_TRY(pack_layer(h, &blocks[i].fc2, w3, C, hid, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
-      if (mlp_rows_supported(h->dtype, C, hid)) {                // fused row-wise Mlp: re-pack [proj,] fc1, fc2 as the MFMA fragment stream
-        const int kc = mlp_rows_proj_supported(C, hid, heads * hdp) ? heads * hdp : 0;
+      if (K(mlp_rows_supported)(kd(kdt), C, hid)) {                // fused row-wise Mlp: re-pack [proj,] fc1, fc2 as the MFMA fragment stream
+        const int kc = K(mlp_rows_proj_supported)(C, hid, heads * hdp) ? heads * hdp : 0;
         void *img = nullptr, *b1i = nullptr;
-        HIP_TRY(hipMalloc(&img, mlp_rows_image_bytes(C, hid, kc)));
+        HIP_TRY(hipMalloc(&img, K(mlp_rows_image_bytes)(C, hid, kc)));
         h->allocs.push_back(img);
         HIP_TRY(hipMalloc(&b1i, (size_t)hid * 4));
         h->allocs.push_back(b1i);
-        RC_TRY(launch_mlp_pack(blocks[i].fc1.w, blocks[i].fc1.Kw, blocks[i].fc1.bias, blocks[i].fc2.w, blocks[i].fc2.Kw, blocks[i].proj.w, blocks[i].proj.Kw,
+        RC_TRY(K(launch_mlp_pack)(blocks[i].fc1.w, blocks[i].fc1.Kw, blocks[i].fc1.bias, blocks[i].fc2.w, blocks[i].fc2.Kw, blocks[i].proj.w, blocks[i].proj.Kw,
                                kc, img, (float*)b1i, C, hid, nullptr));
         HIP_TRY(hipDeviceSynchronize());
         blocks[i].mlp_img = img;
         blocks[i].mlp_b1 = (float*)b1i;
         blocks[i].mlp_kc = kc;
       }
-      if (qkv_attn_supported(h->dtype, C, heads, hdp, (s == 2 ? h->H2 : h->H3) * (s == 2 ? h->H2 : h->H3))) {   // fused qkv conv + attention: re-pack qkv as the MFMA fragment stream
+      if (K(qkv_attn_supported)(kd(kdt), C, heads, hdp, (s == 2 ? h->H2 : h->H3) * (s == 2 ? h->H2 : h->H3))) {   // fused qkv conv + attention: re-pack qkv as the MFMA fragment stream
         void* img = nullptr;
-        HIP_TRY(hipMalloc(&img, qkv_attn_image_bytes()));
+        HIP_TRY(hipMalloc(&img, K(qkv_attn_image_bytes)()));
         h->allocs.push_back(img);
-        RC_TRY(launch_qkv_attn_pack(blocks[i].qkv.w, blocks[i].qkv.Kw, img, nullptr));
+        RC_TRY(K(launch_qkv_attn_pack)(blocks[i].qkv.w, blocks[i].qkv.Kw, img, nullptr));
         HIP_TRY(hipDeviceSynchronize());
         blocks[i].qa_img = img;
       }
@@ -462,7 +477,7 @@ int tap(EngineBase* h, const std::string& name, const void* src, size_t bytes, b
 }
 
 // kernel ids reported by the profiler (names in fsvit_kernel_name)
-enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_STAGE1R = 14, KID_QKVATTN = 15, KID_STEMCONV1 = 16 };
+enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_QKVATTN = 15, KID_STEMCONV1 = 16 };
 
 
 // Runs one launch; in profiling mode brackets it with HIP events on the same stream.
@@ -481,10 +496,11 @@ int timed(EngineBase* h, hipStream_t st, const char* layer, int kernel, double f
 }
 
 int run_gemm(EngineBase* h, hipStream_t st, const char* layer, const Layer& L, const ConvGemmParams& p, double n_true, double k_true) {
+  const int kdt = h->dtype;
   const double flops = 2.0 * (double)p.M * n_true * k_true * (double)p.groups;     // algorithmic: unpadded N and K
   static const int kid_of_cfg[4] = {KID_GEMM256, KID_GEMM64, KID_GEMM32, KID_GEMM128};
-  const int kid = conv3x3_halo_eligible(p, h->dtype) ? KID_HALO : gemm256_eligible(p, h->dtype) ? KID_GEMM256 : kid_of_cfg[conv_gemm_v2_config(p)];
-  return timed(h, st, layer, kid, flops, [&]() { return launch_conv_gemm(p, h->dtype, st); });
+  const int kid = K(conv3x3_halo_eligible)(p, kd(kdt)) ? KID_HALO : K(gemm256_eligible)(p, kd(kdt)) ? KID_GEMM256 : kid_of_cfg[K(conv_gemm_v2_config)(p)];
+  return timed(h, st, layer, kid, flops, [&]() { return K(launch_conv_gemm)(p, kd(kdt), st); });
 }
 
 // xsrc2 != nullptr: images [0, B1) come from x, images [B1, Bc) from xsrc2 (the shot and query tensors of one MetaBaseline call: one
@@ -492,7 +508,7 @@ int run_gemm(EngineBase* h, hipStream_t st, const char* layer, const Layer& L, c
 int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsigned char* ws, bool first, hipStream_t st,
                   const float* xsrc2 = nullptr, int B1 = 0) {
   const Plan pl = make_plan(h, Bc);
-  const int dt = h->dtype;
+  const int kdt = h->dtype, dt = kd(kdt);
   const size_t es = h->es;
   const int heads = h->cfg.num_heads;
   void *patches = ws + pl.patches, *c1 = ws + pl.c1, *ident = ws + pl.ident, *c2 = ws + pl.c2, *c3 = ws + pl.c3;
@@ -504,19 +520,19 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
   h->prof_last = nullptr;
   if (!xsrc2) B1 = Bc;
   static const bool stem_fused_on = [] { const char* e = getenv("FSVIT_STEM_CONV1"); return !e || e[0] != '0'; }();
-  if (stem_fused_on && stem_conv1_supported(dt, img, h->C0)) {      // im2col + conv1 + bn1 + LeakyReLU in one pass over the image
+  if (stem_fused_on && K(stem_conv1_supported)(dt, img, h->C0)) {      // im2col + conv1 + bn1 + LeakyReLU in one pass over the image
     const double fl1 = 2.0 * 27.0 * h->C0 * h->H0 * h->H0;
     RC_TRY(timed(h, st, "stem.im2col+conv1", KID_STEMCONV1, fl1 * B1, [&]() {
-      return launch_stem_conv1(x, patches, c1, h->conv1.w, h->conv1.Kw, h->conv1.bias, B1, st); }));
+      return K(launch_stem_conv1)(x, patches, c1, h->conv1.w, h->conv1.Kw, h->conv1.bias, B1, st); }));
     if (Bc > B1)
       RC_TRY(timed(h, st, "stem.im2col+conv1", KID_STEMCONV1, fl1 * (Bc - B1), [&]() {
-        return launch_stem_conv1(xsrc2, (unsigned char*)patches + (size_t)B1 * h->H0 * h->H0 * 32 * es, (unsigned char*)c1 + (size_t)B1 * h->H0 * h->H0 * h->C0 * es,
+        return K(launch_stem_conv1)(xsrc2, (unsigned char*)patches + (size_t)B1 * h->H0 * h->H0 * 32 * es, (unsigned char*)c1 + (size_t)B1 * h->H0 * h->H0 * h->C0 * es,
                                  h->conv1.w, h->conv1.Kw, h->conv1.bias, Bc - B1, st); }));
   } else {
-    RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() { return launch_im2col27(x, patches, B1, img, img, h->H0, h->H0, dt, st); }));
+    RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() { return K(launch_im2col27)(x, patches, B1, img, img, h->H0, h->H0, dt, st); }));
     if (Bc > B1)
       RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() {
-        return launch_im2col27(xsrc2, (unsigned char*)patches + (size_t)B1 * h->H0 * h->H0 * 32 * es, Bc - B1, img, img, h->H0, h->H0, dt, st); }));
+        return K(launch_im2col27)(xsrc2, (unsigned char*)patches + (size_t)B1 * h->H0 * h->H0 * 32 * es, Bc - B1, img, img, h->H0, h->H0, dt, st); }));
     RC_TRY(run_gemm(h, st, "stem.conv1", h->conv1, conv_params(h->conv1, patches, c1, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C0, ACT_LRELU, nullptr, 0, nullptr), h->C0, 27));
   }
   RC_TRY(run_gemm(h, st, "stem.conv2", h->conv2, conv_params(h->conv2, c1, c2, Bc, h->H0, h->H0, h->C0, h->C0, 3, 3, 1, 1, h->C1, ACT_LRELU, nullptr, 0, nullptr), h->C1, 9.0 * h->C0));
@@ -529,24 +545,20 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
   } else {
     RC_TRY(run_gemm(h, st, "stem.downsample", h->down, conv_params(h->down, patches, ident, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C1, ACT_NONE, nullptr, 0, nullptr), h->C1, 27));
     RC_TRY(run_gemm(h, st, "stem.conv3", h->conv3, conv_params(h->conv3, c2, c3, Bc, h->H0, h->H0, h->C1, h->C1, 3, 3, 1, 1, h->C1, ACT_LRELU, ident, 1, nullptr), h->C1, 9.0 * h->C1));
-    RC_TRY(timed(h, st, "stem.maxpool", KID_MAXPOOL, 0.0, [&]() { return launch_maxpool2_pos(c3, h->pos1, x1, Bc, h->H1, h->H1, h->C1, dt, st); }));
+    RC_TRY(timed(h, st, "stem.maxpool", KID_MAXPOOL, 0.0, [&]() { return K(launch_maxpool2_pos)(c3, h->pos1, x1, Bc, h->H1, h->H1, h->C1, dt, st); }));
   }
   RC_TRY(tap(h, "stem", x1, (size_t)Bc * h->H1 * h->H1 * h->C1 * es, first, st));
 
   // stage 1: x += conv3(GELU(conv2_g(GELU(conv1(BN(x))))))
   const int Cg = h->hid1 / h->cfg.group;
   static const bool no_fuse = [] { const char* e = getenv("FSVIT_NO_FUSE"); return e && e[0] == '1'; }();
-  const bool fuse1 = !no_fuse && stage1_fused_supported(dt, h->C1, h->hid1, h->cfg.group, h->H1);
+  const bool fuse1 = !no_fuse && K(stage1_fused_supported)(dt, h->C1, h->hid1, h->cfg.group, h->H1);
   for (size_t i = 0; i < h->s1.size(); ++i) {
     const Block1& b = h->s1[i];
-    if (fuse1 && b.rows_img) {   // band-per-wave kernel: activations in registers, only weights through LDS; ping-pong x1 / x1b
-      const double fl = 2.0 * Bc * h->H1 * h->H1 * ((double)h->hid1 * h->C1 + (double)h->hid1 * 9 * Cg + (double)h->C1 * h->hid1);
-      RC_TRY(timed(h, st, "stage1.block", KID_STAGE1R, fl, [&]() { return launch_stage1_rows(x1, x1b, b.rows_img, b.c1.bias, Bc, st); }));
-      std::swap(x1, x1b);
-    } else if (fuse1) {   // one LDS-resident kernel per block, ping-pong between x1 and x1b
+    if (fuse1) {   // one LDS-resident kernel per block, ping-pong between x1 and x1b
       const double fl = 2.0 * Bc * h->H1 * h->H1 * ((double)h->hid1 * h->C1 + (double)h->hid1 * 9 * Cg + (double)h->C1 * h->hid1);
       RC_TRY(timed(h, st, "stage1.block", KID_STAGE1, fl,
-                   [&]() { return launch_stage1_block(x1, x1b, b.c1.w, b.c1.bias, b.c2.w, b.c3.w, Bc, st); }));
+                   [&]() { return K(launch_stage1_block)(x1, x1b, b.c1.w, b.c1.bias, b.c2.w, b.c3.w, Bc, st); }));
       std::swap(x1, x1b);
     } else {
       RC_TRY(run_gemm(h, st, "stage1.mlp.conv1", b.c1, conv_params(b.c1, x1, ha, Bc, h->H1, h->H1, h->C1, h->C1, 1, 1, 1, 0, h->hid1, ACT_GELU, nullptr, 0, nullptr), h->hid1, h->C1));
@@ -576,22 +588,22 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
       const BlockA& b = blocks[i];
       if (b.qa_img) {     // qkv conv + attention core in one launch: q / k / v never leave the chip
         RC_TRY(timed(h, st, (sp + ".attn.qkv+core").c_str(), KID_QKVATTN, 2.0 * Bc * S * (3.0 * heads * hd) * C + 4.0 * Bc * heads * (double)S * S * hd,
-                     [&]() { return launch_qkv_attn(xs, ctx, b.qa_img, b.qkv.bias, Bc, S, scale, st); }));
+                     [&]() { return K(launch_qkv_attn)(xs, ctx, b.qa_img, b.qkv.bias, Bc, S, scale, st); }));
       } else {
       RC_TRY(run_gemm(h, st, (sp + ".attn.qkv").c_str(), b.qkv, conv_params(b.qkv, xs, qkv, Bc, Ho, Ho, C, C, 1, 1, 1, 0, 3 * heads * hdp, ACT_NONE, nullptr, 0, nullptr), 3.0 * heads * hd, C));
       RC_TRY(timed(h, st, (sp + ".attn.core").c_str(), KID_ATTN, 4.0 * Bc * heads * (double)S * S * hd,
-                   [&]() { return launch_attention(qkv, ctx, Bc, S, heads, hdp, scale, dt, st); }));
+                   [&]() { return K(launch_attention)(qkv, ctx, Bc, S, heads, hdp, scale, dt, st); }));
       }
       if (b.mlp_img && b.mlp_kc) {   // proj + residual + conv1 + GELU + conv3 + residual in one launch
         RC_TRY(timed(h, st, (sp + ".proj+mlp").c_str(), KID_MLPROWS, 2.0 * Bc * S * ((double)C * heads * hd + 2.0 * hidc * C),
-                     [&]() { return launch_mlp_rows(xs, xs, b.mlp_img, b.mlp_b1, b.fc2.bias, ctx, b.mlp_kc, Bc * S, C, hidc, st); }));
+                     [&]() { return K(launch_mlp_rows)(xs, xs, b.mlp_img, b.mlp_b1, b.fc2.bias, ctx, b.mlp_kc, Bc * S, C, hidc, st); }));
         RC_TRY(tap(h, sp + "." + std::to_string(i), xs, xbytes, first, st));
         continue;
       }
       RC_TRY(run_gemm(h, st, (sp + ".attn.proj").c_str(), b.proj, conv_params(b.proj, ctx, xs, Bc, Ho, Ho, heads * hdp, heads * hdp, 1, 1, 1, 0, C, ACT_NONE, xs, 0, nullptr), C, (double)heads * hd));
       if (b.mlp_img) {     // conv1 + GELU + conv3 + residual in one launch, the hidden map stays in registers
         RC_TRY(timed(h, st, (sp + ".mlp").c_str(), KID_MLPROWS, 4.0 * Bc * S * (double)hidc * C,
-                     [&]() { return launch_mlp_rows(xs, xs, b.mlp_img, b.mlp_b1, b.fc2.bias, nullptr, 0, Bc * S, C, hidc, st); }));
+                     [&]() { return K(launch_mlp_rows)(xs, xs, b.mlp_img, b.mlp_b1, b.fc2.bias, nullptr, 0, Bc * S, C, hidc, st); }));
       } else {
         RC_TRY(run_gemm(h, st, (sp + ".mlp.conv1").c_str(), b.fc1, conv_params(b.fc1, xs, hid, Bc, Ho, Ho, C, C, 1, 1, 1, 0, hidc, ACT_GELU, nullptr, 0, nullptr), hidc, C));
         RC_TRY(run_gemm(h, st, (sp + ".mlp.conv3").c_str(), b.fc2, conv_params(b.fc2, hid, xs, Bc, Ho, Ho, hidc, hidc, 1, 1, 1, 0, C, ACT_NONE, xs, 0, nullptr), C, hidc));
@@ -599,7 +611,7 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
       RC_TRY(tap(h, sp + "." + std::to_string(i), xs, xbytes, first, st));
     }
   }
-  RC_TRY(timed(h, st, "norm.pool", KID_POOL, 0.0, [&]() { return launch_pool_affine(x3, h->fscale, h->fshift, feat, Bc, h->H3 * h->H3, h->C3, dt, st); }));
+  RC_TRY(timed(h, st, "norm.pool", KID_POOL, 0.0, [&]() { return K(launch_pool_affine)(x3, h->fscale, h->fshift, feat, Bc, h->H3 * h->H3, h->C3, dt, st); }));
   return 0;
 }
 
@@ -609,7 +621,7 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
 extern "C" int fsvit_visformer_create(const fsvit_visformer_cfg* cfg, const fsvit_tensor* state_dict, int n_tensors,
                                       int dtype, fsvit_visformer** out) {
   if (!cfg || !state_dict || !out || n_tensors <= 0) return fail(FSVIT_ERR_ARG, "null argument");
-  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (cfg->num_heads < 1 || cfg->embed_dim < 2 || cfg->init_channels < 1 || cfg->depth[0] < 0 || cfg->depth[1] < 0 || cfg->depth[2] < 0)
     return fail(FSVIT_ERR_ARG, "bad Visformer configuration");
   fsvit_visformer* h = new fsvit_visformer();
@@ -676,19 +688,21 @@ extern "C" int fsvit_visformer_forward(fsvit_visformer* h, const float* x, int n
  * untouched since; the call must have fitted one chunk): the `x` of `return x, pooled` in the distillation phase's encoder
  * (sun_meta_training/models/visformer.py:464) for the eval-mode teacher. */
 extern "C" int fsvit_visformer_last_tokens(fsvit_visformer* h, const void* ws, size_t ws_bytes, int n_img, float* tokens, void* stream) {
+  const int kdt = h ? h->dtype : FSVIT_BF16;
   if (!h || !ws || !tokens || n_img <= 0) return fail(FSVIT_ERR_ARG, "bad argument");
   const Plan pl = make_plan(h, (size_t)n_img);
   if (pl.total > ws_bytes) return fail(FSVIT_ERR_WORKSPACE, "last_tokens: the forward of %d images did not fit one chunk of this workspace", n_img);
-  RC_TRY(launch_tokens_to_f32((const unsigned char*)ws + pl.x3, h->fscale, h->fshift, tokens, (size_t)n_img * h->H3 * h->H3 * h->C3, h->C3, h->dtype,
+  RC_TRY(K(launch_tokens_to_f32)((const unsigned char*)ws + pl.x3, h->fscale, h->fshift, tokens, (size_t)n_img * h->H3 * h->H3 * h->C3, h->C3, kd(kdt),
                               (hipStream_t)stream));
   return 0;
 }
 
 extern "C" int fsvit_proto_head(const float* fs, const float* fq, int E, int way, int shot, int Q, int D, float temp,
                                 int method, float* logits, float* acc, float* loss, void* stream) {
+  const int kdt = FSVIT_BF16;
   if (!fs || !fq || !logits) return fail(FSVIT_ERR_ARG, "null argument");
   if (method != FSVIT_HEAD_COS && method != FSVIT_HEAD_SQR && method != FSVIT_HEAD_DOT) return fail(FSVIT_ERR_ARG, "unknown head method %d", method);
-  RC_TRY(launch_proto_head(fs, fq, E, way, shot, Q, D, temp, method, logits, acc, loss, (hipStream_t)stream));
+  RC_TRY(K(launch_proto_head)(fs, fq, E, way, shot, Q, D, temp, method, logits, acc, loss, (hipStream_t)stream));
   return 0;
 }
 
@@ -725,14 +739,16 @@ extern "C" int fsvit_meta_baseline_forward(void* hv, const float* x_shot, const 
 extern "C" int fsvit_conv_gemm(const void* x, const void* w, const float* bias, const void* res, const float* pos, void* y,
                                int B, int H, int W, int Cin, int x_cstride, int KH, int KW, int stride, int pad, int N,
                                int y_cstride, int Kw, int groups, int act, int res_first, int dtype, void* stream) {
+  const int kdt = dtype;
+  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (!x || !w || !y) return fail(FSVIT_ERR_ARG, "null argument");
-  const int es = dtype == FSVIT_F32 ? 4 : 2, epc = 16 / es, bke = 128 / es;
+  const int es = dtype == FSVIT_F32 ? 4 : 2, epc = 16 / es, bke = 128 / es;      // FSVIT_BF16 and FSVIT_F16 are both 2-byte storage
   if (Cin % epc || x_cstride % epc || N % 4 || y_cstride % 4 || Kw % bke || Kw < KH * KW * Cin)
     return fail(FSVIT_ERR_ARG, "conv_gemm alignment: Cin/x_cstride %% %d, N/y_cstride %% 4, Kw %% %d", epc, bke);
   if (KH * KW > 1 && !is_pow2(Cin)) return fail(FSVIT_ERR_ARG, "multi-tap conv needs power-of-two Cin");
   Layer L; L.w = const_cast<void*>(w); L.bias = const_cast<float*>(bias); L.N = N; L.K = KH * KW * Cin; L.Kw = Kw; L.groups = groups;
   ConvGemmParams p = conv_params(L, x, y, B, H, W, Cin, x_cstride, KH, KW, stride, pad, y_cstride, act, res, res_first, pos);
-  RC_TRY(launch_conv_gemm(p, dtype, (hipStream_t)stream));
+  RC_TRY(K(launch_conv_gemm)(p, kd(dtype), (hipStream_t)stream));
   return 0;
 }
 
@@ -741,31 +757,24 @@ extern "C" int fsvit_conv_gemm(const void* x, const void* w, const float* bias, 
  * epilogue.  Routed exactly as the engine routes it (conv3x3_halo_kernel<128,true> for the Visformer-S geometry, conv_gemm_v2 otherwise). */
 extern "C" int fsvit_conv_stem_tail(const void* x, const void* w, const float* bias, const float* pos, const void* x2, int x2_cstride, int K2,
                                     void* y, int B, int H, int W, int Cin, int N, int Kw, int dtype, void* stream) {
+  const int kdt = dtype;
+  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (!x || !w || !y || !x2 || !pos) return fail(FSVIT_ERR_ARG, "null argument");
-  const int es = dtype == FSVIT_F32 ? 4 : 2, epc = 16 / es, bke = 128 / es;
+  const int es = dtype == FSVIT_F32 ? 4 : 2, epc = 16 / es, bke = 128 / es;      // FSVIT_BF16 and FSVIT_F16 are both 2-byte storage
   if (Cin % epc || !is_pow2(Cin) || N % 4 || Kw % bke || Kw < 9 * Cin + bke || K2 > bke || x2_cstride < K2 || (H & 1) || (W & 1))
     return fail(FSVIT_ERR_ARG, "fsvit_conv_stem_tail: bad geometry");
   Layer L; L.w = const_cast<void*>(w); L.bias = const_cast<float*>(bias); L.N = N; L.K = 9 * Cin; L.Kw = Kw; L.groups = 1;
   ConvGemmParams p = conv_params(L, x, y, B, H, W, Cin, Cin, 3, 3, 1, 1, N, ACT_LRELU, nullptr, 0, pos);
   p.x2 = x2; p.x2_cstride = x2_cstride; p.K2 = K2; p.pool2 = 1;
-  RC_TRY(launch_conv_gemm(p, dtype, (hipStream_t)stream));
+  RC_TRY(K(launch_conv_gemm)(p, kd(dtype), (hipStream_t)stream));
   return 0;
 }
 
 extern "C" int fsvit_stage1_block(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, void* stream) {
+  const int kdt = FSVIT_BF16;
   if (!x || !y || !w1 || !b1 || !w2 || !w3 || x == y) return fail(FSVIT_ERR_ARG, "bad argument");
   hipStream_t st = (hipStream_t)stream;
-  if (stage1_rows_supported(FSVIT_BF16, 128, 256, 8, 20)) {      // operator form: packs the fragment image on every call
-    void* img = nullptr;
-    HIP_TRY(hipMalloc(&img, stage1_rows_image_bytes()));
-    int rc = launch_stage1_pack(w1, w2, w3, img, st);
-    if (rc == 0) rc = launch_stage1_rows(x, y, img, b1, B, st);
-    (void)hipStreamSynchronize(st);
-    (void)hipFree(img);
-    if (rc != 0) return hipfail((hipError_t)rc, "fsvit_stage1_block");
-    return 0;
-  }
-  RC_TRY(launch_stage1_block(x, y, w1, b1, w2, w3, B, st));
+  RC_TRY(K(launch_stage1_block)(x, y, w1, b1, w2, w3, B, st));
   return 0;
 }
 
@@ -776,18 +785,19 @@ extern "C" int fsvit_mlp_rows(const void* x, void* y, const void* w1, int k1w, c
 
 extern "C" int fsvit_proj_mlp_rows(const void* x, void* y, const void* ctx, const void* wp, int kpw, int KC, const void* w1, int k1w, const float* b1,
                                    const void* w2, int k2w, const float* b2, int M, int C, int hid, void* stream) {
+  const int kdt = FSVIT_BF16;
   if (!x || !y || !w1 || !w2) return fail(FSVIT_ERR_ARG, "null argument");
-  if (!mlp_rows_supported(FSVIT_BF16, C, hid)) return fail(FSVIT_ERR_ARG, "fsvit_mlp_rows: only C = 256 / hidden = 1024 and C = 512 / hidden = 2048 (bf16) are built");
+  if (!K(mlp_rows_supported)(1, C, hid)) return fail(FSVIT_ERR_ARG, "fsvit_mlp_rows: only C = 256 / hidden = 1024 and C = 512 / hidden = 2048 (bf16) are built");
   if (k1w < C || k2w < hid) return fail(FSVIT_ERR_ARG, "weight rows shorter than K");
-  if (ctx && (!wp || kpw < KC || !mlp_rows_proj_supported(C, hid, KC))) return fail(FSVIT_ERR_ARG, "proj fusion: (C, KC) must be (256, 288) or (512, 576)");
+  if (ctx && (!wp || kpw < KC || !K(mlp_rows_proj_supported)(C, hid, KC))) return fail(FSVIT_ERR_ARG, "proj fusion: (C, KC) must be (256, 288) or (512, 576)");
   if (!ctx) KC = 0;
   hipStream_t st = (hipStream_t)stream;
   void *img = nullptr, *b1i = nullptr;
-  HIP_TRY(hipMalloc(&img, mlp_rows_image_bytes(C, hid, KC)));
+  HIP_TRY(hipMalloc(&img, K(mlp_rows_image_bytes)(C, hid, KC)));
   hipError_t e = hipMalloc(&b1i, (size_t)hid * 4);
   if (e != hipSuccess) { (void)hipFree(img); return hipfail(e, "hipMalloc"); }
-  int rc = launch_mlp_pack(w1, k1w, b1, w2, k2w, wp, kpw, KC, img, (float*)b1i, C, hid, st);
-  if (rc == 0) rc = launch_mlp_rows(x, y, img, (const float*)b1i, b2, ctx, KC, M, C, hid, st);
+  int rc = K(launch_mlp_pack)(w1, k1w, b1, w2, k2w, wp, kpw, KC, img, (float*)b1i, C, hid, st);
+  if (rc == 0) rc = K(launch_mlp_rows)(x, y, img, (const float*)b1i, b2, ctx, KC, M, C, hid, st);
   (void)hipStreamSynchronize(st);
   (void)hipFree(img);
   (void)hipFree(b1i);
@@ -797,45 +807,51 @@ extern "C" int fsvit_proj_mlp_rows(const void* x, void* y, const void* ctx, cons
 
 // ---- distillation head (sun_meta_training/offline.py, models/token_label.py, models/classifier.py)
 extern "C" int fsvit_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int N, int K, void* stream) {
+  const int kdt = FSVIT_BF16;
   if (!x || !w || !y || (K & 3) || N <= 0 || K <= 0) return fail(FSVIT_ERR_ARG, "fsvit_linear_forward: null argument or K %% 4 != 0");
-  RC_TRY(launch_linear_fwd(x, w, b, y, M, N, K, (hipStream_t)stream));
+  RC_TRY(K(launch_linear_fwd)(x, w, b, y, M, N, K, (hipStream_t)stream));
   return 0;
 }
 extern "C" int fsvit_linear_backward(const float* dy, const float* x, const float* w, float* dx, int accumulate_dx, float* dw, float* db,
                                      int M, int N, int K, void* stream) {
+  const int kdt = FSVIT_BF16;
   if (!dy || (dx && !w) || (dw && !x) || N <= 0 || K <= 0) return fail(FSVIT_ERR_ARG, "fsvit_linear_backward: bad argument");
-  RC_TRY(launch_linear_bwd(dy, x, w, dx, accumulate_dx, dw, db, M, N, K, (hipStream_t)stream));
+  RC_TRY(K(launch_linear_bwd)(dy, x, w, dx, accumulate_dx, dw, db, M, N, K, (hipStream_t)stream));
   return 0;
 }
 extern "C" int fsvit_token_softlabel(const float* teacher_logits, float* soft, int B, int T, int C, int k, int bp, double smoothing, void* stream) {
+  const int kdt = FSVIT_BF16;
   if (!teacher_logits || !soft || T > 64 || T <= 0 || C < 2 || k < 1 || k > C || bp < 0 || bp > T)
     return fail(FSVIT_ERR_ARG, "fsvit_token_softlabel: bad argument (T <= 64, 1 <= k <= C, 0 <= bp <= T)");
-  RC_TRY(launch_token_softlabel(teacher_logits, soft, B, T, C, k, bp, smoothing, (hipStream_t)stream));
+  RC_TRY(K(launch_token_softlabel)(teacher_logits, soft, B, T, C, k, bp, smoothing, (hipStream_t)stream));
   return 0;
 }
 extern "C" int fsvit_soft_target_ce(const float* logits, const float* target, float* row_loss, float* dlogits, int R, int C, float grad_scale,
                                     void* stream) {
+  const int kdt = FSVIT_BF16;
   if (!logits || !target || !row_loss || C <= 0) return fail(FSVIT_ERR_ARG, "fsvit_soft_target_ce: bad argument");
-  RC_TRY(launch_soft_target_ce(logits, target, row_loss, dlogits, R, C, grad_scale, (hipStream_t)stream));
+  RC_TRY(K(launch_soft_target_ce)(logits, target, row_loss, dlogits, R, C, grad_scale, (hipStream_t)stream));
   return 0;
 }
 extern "C" int fsvit_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                                 float weight_decay, int step, void* stream) {
+  const int kdt = FSVIT_BF16;
   if (!p || !g || !m || !v || step < 1) return fail(FSVIT_ERR_ARG, "fsvit_adamw_step: bad argument");
-  RC_TRY(launch_adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream));
+  RC_TRY(K(launch_adamw)(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream));
   return 0;
 }
 
 extern "C" int fsvit_qkv_attention(const void* x, const void* wqkv, int kw, const float* bias, void* ctx, int B, int S, int C, int heads, int hdp,
                                    float scale, void* stream) {
+  const int kdt = FSVIT_BF16;
   if (!x || !wqkv || !ctx) return fail(FSVIT_ERR_ARG, "null argument");
-  if (!qkv_attn_supported(FSVIT_BF16, C, heads, hdp, S) || kw < C)
+  if (!K(qkv_attn_supported)(1, C, heads, hdp, S) || kw < C)
     return fail(FSVIT_ERR_ARG, "fsvit_qkv_attention: only C = 256, 6 heads x 48 (padded), S <= 112 (bf16) is built");
   hipStream_t st = (hipStream_t)stream;
   void* img = nullptr;
-  HIP_TRY(hipMalloc(&img, qkv_attn_image_bytes()));
-  int rc = launch_qkv_attn_pack(wqkv, kw, img, st);
-  if (rc == 0) rc = launch_qkv_attn(x, ctx, img, bias, B, S, scale, st);
+  HIP_TRY(hipMalloc(&img, K(qkv_attn_image_bytes)()));
+  int rc = K(launch_qkv_attn_pack)(wqkv, kw, img, st);
+  if (rc == 0) rc = K(launch_qkv_attn)(x, ctx, img, bias, B, S, scale, st);
   (void)hipStreamSynchronize(st);
   (void)hipFree(img);
   if (rc != 0) return hipfail((hipError_t)rc, "fsvit_qkv_attention");
@@ -843,35 +859,44 @@ extern "C" int fsvit_qkv_attention(const void* x, const void* wqkv, int kw, cons
 }
 
 extern "C" int fsvit_attention(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, void* stream) {
+  const int kdt = dtype;
+  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (!qkv || !ctx) return fail(FSVIT_ERR_ARG, "null argument");
-  int rc = launch_attention(qkv, ctx, B, S, heads, hdp, scale, dtype, (hipStream_t)stream);
+  int rc = K(launch_attention)(qkv, ctx, B, S, heads, hdp, scale, kd(dtype), (hipStream_t)stream);
   if (rc != 0) return hipfail((hipError_t)rc, "attention");
   return 0;
 }
 
 extern "C" int fsvit_im2col27(const float* x, void* out, int B, int H, int W, int dtype, void* stream) {
+  const int kdt = dtype;
+  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (!x || !out || (H & 1) || (W & 1)) return fail(FSVIT_ERR_ARG, "bad argument");
-  RC_TRY(launch_im2col27(x, out, B, H, W, H / 2, W / 2, dtype, (hipStream_t)stream));
+  RC_TRY(K(launch_im2col27)(x, out, B, H, W, H / 2, W / 2, kd(dtype), (hipStream_t)stream));
   return 0;
 }
 
 extern "C" int fsvit_stem_conv1(const float* x, const void* w, int kw, const float* bias, void* patches, void* c1, int B, int H, int W, void* stream) {
+  const int kdt = FSVIT_BF16;
   if (!x || !w || !patches || !c1 || kw < 32) return fail(FSVIT_ERR_ARG, "bad argument");
-  if (H != W || !stem_conv1_supported(FSVIT_BF16, H, 64)) return fail(FSVIT_ERR_ARG, "fsvit_stem_conv1: only 80x80 images, 64 output channels (bf16) are built");
-  RC_TRY(launch_stem_conv1(x, patches, c1, w, kw, bias, B, (hipStream_t)stream));
+  if (H != W || !K(stem_conv1_supported)(1, H, 64)) return fail(FSVIT_ERR_ARG, "fsvit_stem_conv1: only 80x80 images, 64 output channels (bf16) are built");
+  RC_TRY(K(launch_stem_conv1)(x, patches, c1, w, kw, bias, B, (hipStream_t)stream));
   return 0;
 }
 
 extern "C" int fsvit_maxpool2_pos(const void* in, const float* pos, void* out, int B, int OH, int OW, int C, int dtype, void* stream) {
+  const int kdt = dtype;
+  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (!in || !out || C % 4) return fail(FSVIT_ERR_ARG, "bad argument");
-  RC_TRY(launch_maxpool2_pos(in, pos, out, B, OH, OW, C, dtype, (hipStream_t)stream));
+  RC_TRY(K(launch_maxpool2_pos)(in, pos, out, B, OH, OW, C, kd(dtype), (hipStream_t)stream));
   return 0;
 }
 
 extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float* shift, float* feat, int B, int HW, int C,
                                  int dtype, void* stream) {
+  const int kdt = dtype;
+  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (!x || !scale || !shift || !feat || C % 4) return fail(FSVIT_ERR_ARG, "bad argument");
-  RC_TRY(launch_pool_affine(x, scale, shift, feat, B, HW, C, dtype, (hipStream_t)stream));
+  RC_TRY(K(launch_pool_affine)(x, scale, shift, feat, B, HW, C, kd(dtype), (hipStream_t)stream));
   return 0;
 }
 
@@ -879,12 +904,15 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
   static const char* f32n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
                                "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<float,128,128,2,2,2>",
-                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel", "stage1_rows_kernel", "qkv_attn_kernel", "stem_conv1_kernel"};
+                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel"};
   static const char* bf16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
                                 "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<__bf16,128,128,2,2,2>",
-                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "stage1_rows_kernel", "qkv_attn_kernel", "stem_conv1_kernel"};
+                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel"};
+  static const char* f16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<_Float16,128,64,2,2,3>", "conv_gemm_v2_kernel<_Float16,128,32,4,1,3>",
+                               "im2col27_kernel<_Float16>", "maxpool2_pos_kernel<_Float16>", "attention_v2_kernel<_Float16,...>", "pool_affine_kernel<_Float16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<_Float16,128,128,2,2,2>",
+                               "patchify_kernel<_Float16>", "layernorm_kernel<_Float16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel"};
   if (kernel_id < 0 || kernel_id > 16) return "?";
-  return dtype == FSVIT_F32 ? f32n[kernel_id] : bf16n[kernel_id];
+  return dtype == FSVIT_F32 ? f32n[kernel_id] : dtype == FSVIT_F16 ? f16n[kernel_id] : bf16n[kernel_id];
 }
 
 extern "C" int fsvit_encoder_profile_begin(void* hv) {
@@ -1047,33 +1075,33 @@ enum { KID_PATCHIFY = 10, KID_LN = 11 };
 
 int vit_forward_chunk(fsvit_vit* h, const float* x, int Bc, float* feat, unsigned char* ws, bool first, hipStream_t st) {
   const VitPlan pl = make_vit_plan(h, Bc);
-  const int dt = h->dtype, D = h->D, S = h->S, heads = h->cfg.num_heads, hdp = h->hdp;
+  const int kdt = h->dtype, dt = kd(kdt), D = h->D, S = h->S, heads = h->cfg.num_heads, hdp = h->hdp;
   const size_t es = h->es;
   void *patches = ws + pl.patches, *tokens = ws + pl.tokens, *xn = ws + pl.xn, *qkv = ws + pl.qkv, *ctx = ws + pl.ctx, *hid = ws + pl.hid;
   const int M = Bc * S;
   h->prof_last = nullptr;
-  RC_TRY(timed(h, st, "patch_embed.patchify", KID_PATCHIFY, 0.0, [&]() { return launch_patchify(x, patches, Bc, h->cfg.img_size, h->cfg.patch_size, h->Kp, dt, st); }));
+  RC_TRY(timed(h, st, "patch_embed.patchify", KID_PATCHIFY, 0.0, [&]() { return K(launch_patchify)(x, patches, Bc, h->cfg.img_size, h->cfg.patch_size, h->Kp, dt, st); }));
   {
     ConvGemmParams p = conv_params(h->pe, patches, tokens, Bc, h->npw, h->npw, h->Kp, h->Kp, 1, 1, 1, 0, D, ACT_NONE, nullptr, 0, h->pos_patch);
     p.y_rpi = S; p.y_row0 = 1;                                   // patch token i of image b -> row b*S + 1 + i
     RC_TRY(run_gemm(h, st, "patch_embed.proj", h->pe, p, D, 3.0 * h->cfg.patch_size * h->cfg.patch_size));
   }
-  RC_TRY(timed(h, st, "cls_token", KID_PATCHIFY, 0.0, [&]() { return launch_cls_pos(h->cls_pos0, tokens, Bc, S, D, dt, st); }));
+  RC_TRY(timed(h, st, "cls_token", KID_PATCHIFY, 0.0, [&]() { return K(launch_cls_pos)(h->cls_pos0, tokens, Bc, S, D, dt, st); }));
   RC_TRY(tap(h, "embed", tokens, (size_t)M * D * es, first, st));
   const float scale = 1.0f / std::sqrt((float)h->hd);
   for (size_t i = 0; i < h->blocks.size(); ++i) {
     const VitBlock& b = h->blocks[i];
-    RC_TRY(timed(h, st, "blocks.norm1", KID_LN, 0.0, [&]() { return launch_layernorm(tokens, xn, M, D, h->cfg.ln_eps, dt, st); }));
+    RC_TRY(timed(h, st, "blocks.norm1", KID_LN, 0.0, [&]() { return K(launch_layernorm)(tokens, xn, M, D, h->cfg.ln_eps, dt, st); }));
     RC_TRY(run_gemm(h, st, "blocks.attn.qkv", b.qkv, conv_params(b.qkv, xn, qkv, Bc, S, 1, D, D, 1, 1, 1, 0, 3 * heads * hdp, ACT_NONE, nullptr, 0, nullptr), 3.0 * D, D));
     RC_TRY(timed(h, st, "blocks.attn.core", KID_ATTN, 4.0 * Bc * heads * (double)S * S * h->hd,
-                 [&]() { return launch_attention(qkv, ctx, Bc, S, heads, hdp, scale, dt, st); }));
+                 [&]() { return K(launch_attention)(qkv, ctx, Bc, S, heads, hdp, scale, dt, st); }));
     RC_TRY(run_gemm(h, st, "blocks.attn.proj", b.proj, conv_params(b.proj, ctx, tokens, Bc, S, 1, heads * hdp, heads * hdp, 1, 1, 1, 0, D, ACT_NONE, tokens, 0, nullptr), D, D));
-    RC_TRY(timed(h, st, "blocks.norm2", KID_LN, 0.0, [&]() { return launch_layernorm(tokens, xn, M, D, h->cfg.ln_eps, dt, st); }));
+    RC_TRY(timed(h, st, "blocks.norm2", KID_LN, 0.0, [&]() { return K(launch_layernorm)(tokens, xn, M, D, h->cfg.ln_eps, dt, st); }));
     RC_TRY(run_gemm(h, st, "blocks.mlp.fc1", b.fc1, conv_params(b.fc1, xn, hid, Bc, S, 1, D, D, 1, 1, 1, 0, h->hid, ACT_GELU, nullptr, 0, nullptr), h->hid, D));
     RC_TRY(run_gemm(h, st, "blocks.mlp.fc2", b.fc2, conv_params(b.fc2, hid, tokens, Bc, S, 1, h->hid, h->hid, 1, 1, 1, 0, D, ACT_NONE, tokens, 0, nullptr), D, h->hid));
     RC_TRY(tap(h, "blocks." + std::to_string(i), tokens, (size_t)M * D * es, first, st));
   }
-  RC_TRY(timed(h, st, "norm.cls", KID_LN, 0.0, [&]() { return launch_final_ln_cls(tokens, h->ng, h->nb, feat, Bc, S, D, h->cfg.ln_eps, dt, st); }));
+  RC_TRY(timed(h, st, "norm.cls", KID_LN, 0.0, [&]() { return K(launch_final_ln_cls)(tokens, h->ng, h->nb, feat, Bc, S, D, h->cfg.ln_eps, dt, st); }));
   return 0;
 }
 
@@ -1081,7 +1109,7 @@ int vit_forward_chunk(fsvit_vit* h, const float* x, int Bc, float* feat, unsigne
 
 extern "C" int fsvit_vit_create(const fsvit_vit_cfg* cfg, const fsvit_tensor* state_dict, int n_tensors, int dtype, fsvit_vit** out) {
   if (!cfg || !state_dict || !out || n_tensors <= 0) return fail(FSVIT_ERR_ARG, "null argument");
-  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (cfg->num_heads < 1 || cfg->embed_dim < 8 || cfg->depth < 0 || cfg->patch_size < 1) return fail(FSVIT_ERR_ARG, "bad ViT configuration");
   fsvit_vit* h = new fsvit_vit();
   h->kind = KIND_VIT;

@@ -4,15 +4,30 @@
 #include <stdint.h>
 #include "conv_gemm.h"
 
-namespace fsvit {
+// The 16-bit storage / MFMA operand type of this translation unit.  Every kernel source that handles 16-bit activations is compiled
+// TWICE by the Makefile: into namespace fsvit with __bf16 (the `bf16` numerics mode) and, under -DFSVIT_HALF_F16, into namespace
+// fsvit_f16 with _Float16 (the `f16` mode: same width, same MFMA rate, 3 more mantissa bits - 8 x smaller logit deviation on this
+// network, whose bf16 error is dominated by the rounding of the WEIGHTS).  Inside a source the alias `bf16` means
+// "this build's 16-bit type"; nothing else changes between the two builds except the MFMA opcode.
+#ifdef FSVIT_HALF_F16
+#define FSVIT_NS fsvit_f16
+#define FSVIT_MFMA_16x16x32 "v_mfma_f32_16x16x32_f16"
+#define FSVIT_MFMA_32x32x16 "v_mfma_f32_32x32x16_f16"
+namespace fsvit_f16 { typedef _Float16 bf16; }
+#else
+#define FSVIT_NS fsvit
+#define FSVIT_MFMA_16x16x32 "v_mfma_f32_16x16x32_bf16"
+#define FSVIT_MFMA_32x32x16 "v_mfma_f32_32x32x16_bf16"
+namespace fsvit { typedef __bf16 bf16; }
+#endif
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+namespace FSVIT_NS {
+
+typedef __attribute__((ext_vector_type(8))) bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-
-typedef __bf16 bf16;
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -31,7 +46,11 @@ template <> struct Elem<bf16> {
 // both operands, so the dot product covers each k exactly once.
 template <typename T> __device__ __forceinline__ f32x4 mma_chunk(u32x4 a, u32x4 b, f32x4 acc);
 template <> __device__ __forceinline__ f32x4 mma_chunk<bf16>(u32x4 a, u32x4 b, f32x4 acc) {
+#ifdef FSVIT_HALF_F16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+#else
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+#endif
 }
 template <> __device__ __forceinline__ f32x4 mma_chunk<float>(u32x4 a, u32x4 b, f32x4 acc) {
   f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
@@ -121,4 +140,4 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-}  // namespace fsvit
+}  // namespace FSVIT_NS

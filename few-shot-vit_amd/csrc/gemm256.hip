@@ -26,7 +26,7 @@
 #include "conv_gemm.h"
 #include "fsvit_common.h"
 
-namespace fsvit {
+namespace FSVIT_NS {
 
 typedef __attribute__((address_space(3))) void* lptr256_t;
 
@@ -283,4 +283,4 @@ int launch_gemm256(const ConvGemmParams& p, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-}  // namespace fsvit
+}  // namespace FSVIT_NS

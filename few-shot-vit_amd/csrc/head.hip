@@ -10,7 +10,7 @@
 #include "kernels.h"
 #include "train_kernels.h"
 
-namespace fsvit {
+namespace FSVIT_NS {
 
 template <typename T>
 __global__ __launch_bounds__(256) void pool_affine_kernel(const T* __restrict__ x, const float* __restrict__ scale,
@@ -210,4 +210,4 @@ int launch_proto_head_bwd(const float* feat_shot, const float* feat_query, const
   return (int)hipGetLastError();
 }
 
-}  // namespace fsvit
+}  // namespace FSVIT_NS

@@ -45,7 +45,7 @@
 #include "fsvit_common.h"
 #include "kernels.h"
 
-namespace fsvit {
+namespace FSVIT_NS {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void* lptrm_t;
@@ -116,7 +116,7 @@ template <int N> __device__ __forceinline__ void mr_wait_loads(u32x4* a) {
   for (int o = 4; o < N; o += 4) asm volatile("" : "+v"(a[o]), "+v"(a[o + 1]), "+v"(a[o + 2]), "+v"(a[o + 3]) :: "memory");
 }
 __device__ __forceinline__ unsigned mr_pk2(float a, float b) {
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) bf16 bf16x2_t;
   const bf16x2_t v = {(bf16)a, (bf16)b};
   return __builtin_bit_cast(unsigned, v);
 }
@@ -128,20 +128,20 @@ __device__ __forceinline__ unsigned mr_pk2(float a, float b) {
 // writes an accumulator and the first VALU / v_accvgpr_read that reads it (s_nop blocks below), and between the VALU that packs hp
 // and the first MFMA that reads it.  Dependent MFMAs on one accumulator issue back to back (same opcode, same vDst).
 __device__ __forceinline__ void mfma32_v(u32x4 a, u32x4 b, f32x16& c) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  asm volatile(FSVIT_MFMA_32x32x16 " %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void mfma32_a(u32x4 a, u32x4 b, f32x16& c) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  asm volatile(FSVIT_MFMA_32x32x16 " %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 // first MFMA of an accumulation chain that starts from zero: D = A B + 0
 __device__ __forceinline__ void mfma32_v_z(u32x4 a, u32x4 b, f32x16& d) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+  asm volatile(FSVIT_MFMA_32x32x16 " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
 }
 // accumulator := 0 without ever being a VGPR value (a C++ `= 0` makes the loop-carried accumulators VGPR-class and every asm use
 // a 16-register round trip through v_accvgpr_write / read)
 __device__ __forceinline__ void mfma32_a_zero(f32x16& c) {
   const u32x4 z = {0u, 0u, 0u, 0u};
-  asm volatile("s_nop 7\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %1, 0" : "=a"(c) : "v"(z));      // s_nop: VALU-written z -> MFMA SrcA/B
+  asm volatile("s_nop 7\n\t" FSVIT_MFMA_32x32x16 " %0, %1, %1, 0" : "=a"(c) : "v"(z));      // s_nop: VALU-written z -> MFMA SrcA/B
 }
 
 }  // namespace
@@ -638,4 +638,4 @@ int launch_mlp_rows(const void* x, void* y, const void* wimg, const float* b1img
   return (int)hipErrorInvalidValue;
 }
 
-}  // namespace fsvit
+}  // namespace FSVIT_NS

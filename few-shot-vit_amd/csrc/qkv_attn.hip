@@ -25,7 +25,7 @@
 #include "fsvit_common.h"
 #include "kernels.h"
 
-namespace fsvit {
+namespace FSVIT_NS {
 
 typedef __attribute__((address_space(3))) void* lptrq_t;
 
@@ -67,7 +67,7 @@ __device__ __forceinline__ u32x4 qa_gload16(const void* p) {
   return v;
 }
 __device__ __forceinline__ unsigned qa_pk2(float a, float b) {
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) bf16 bf16x2_t;
   const bf16x2_t v = {(bf16)a, (bf16)b};
   return __builtin_bit_cast(unsigned, v);
 }
@@ -361,4 +361,4 @@ int launch_qkv_attn(const void* x, void* ctx, const void* wimg, const float* bia
   return (int)hipGetLastError();
 }
 
-}  // namespace fsvit
+}  // namespace FSVIT_NS

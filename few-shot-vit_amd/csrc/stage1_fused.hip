@@ -30,7 +30,7 @@
 #define S1_GELU2(v) gelu_sig2(v)
 #endif
 
-namespace fsvit {
+namespace FSVIT_NS {
 
 namespace s1 {
 constexpr int C1 = 128, HID = 256, G = 8, CG = 32, W = 20;
@@ -281,210 +281,6 @@ __global__ __launch_bounds__(1024) void stage1_block_kernel(const bf16* __restri
 #endif
 }
 
-// v3 of the kernel.  Two changes against stage1_block_kernel, both aimed at its 16 barrier intervals (each one a full
-// fill / drain of the LDS -> MFMA -> GELU -> LDS pipeline with all 16 waves in the same phase) and at its LDS traffic:
-//   * conv1's input never goes through LDS: a wave's two m-tiles are the same for every group, so their 8 x fragments (32 VGPRs)
-//     are loaded once from global and stay in registers as the MFMA B operands of all 8 groups (P1 read 12 fragments per 8 MFMAs,
-//     now 4); the residual is re-read from global (L2) in the epilogue;
-//   * the 56 KB that frees hold the H1 / H2 planes and weight slices of TWO groups: 4 steps x 2 intervals instead of 8 x 2.
-namespace s1b {
-using namespace s1;
-constexpr int G2 = 2, NSTEP = G / G2;
-constexpr int V3_OFF_H1 = 0;                                   // 8 planes: [group of the step][k-chunk plane]
-constexpr int V3_OFF_H2 = V3_OFF_H1 + G2 * 4 * H1_PLANE;          //  34816
-constexpr int V3_OFF_W1 = V3_OFF_H2 + G2 * 4 * H2_PLANE;          //  61440   [g2][16 k-chunks][32 n][16 B]
-constexpr int V3_OFF_W2 = V3_OFF_W1 + G2 * 16 * 32 * 16;          //  77824   [g2][36][32 n][16 B]
-constexpr int V3_OFF_W3 = V3_OFF_W2 + G2 * 36 * 32 * 16;          // 114688   [8 k-chunks][128 n][16 B]
-constexpr int V3_OFF_B1 = V3_OFF_W3 + G2 * 4 * 128 * 16;          // 131072
-constexpr int V3_LDS_BYTES = V3_OFF_B1 + HID * 4;                 // 132096
-}  // namespace s1b
-
-__global__ __launch_bounds__(1024) void stage1_block2_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
-                                                             const bf16* __restrict__ w1, const float* __restrict__ b1,
-                                                             const bf16* __restrict__ w2, const bf16* __restrict__ w3) {
-  using namespace s1b;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const H1 = smem + V3_OFF_H1;
-  unsigned char* const H2 = smem + V3_OFF_H2;
-  unsigned char* const W1b = smem + V3_OFF_W1;
-  unsigned char* const W2b = smem + V3_OFF_W2;
-  unsigned char* const W3b = smem + V3_OFF_W3;
-  float* const B1s = reinterpret_cast<float*>(smem + V3_OFF_B1);
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
-
-  const int t = threadIdx.x, lane = t & 63;
-#ifdef S1_CLK
-  long long ck0 = __builtin_readcyclecounter(), ckA = 0, ckB = 0, ckP = 0, ckl = 0;
-#endif
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int lrow = lane & 15, lq = lane >> 4;
-  const int b = blockIdx.x >> 1, hsel = blockIdx.x & 1;
-  const int xr0 = hsel ? 9 : 0;                       // first image row of the 11 conv1 rows
-  const int r0 = hsel * 10;                           // first output row
-  const bf16* xin = x + ((size_t)b * 400 + xr0 * W) * C1;
-
-  auto dma_w1 = [&](int st) {                         // 16 KB: groups 2 st, 2 st + 1
-    for (int i = w; i < G2 * 8; i += NW) {
-      const int g2 = i >> 3, sl = (i & 7) * 64 + lane, ch = sl >> 5, n = sl & 31;
-      s1_dma16(w1 + (size_t)((G2 * st + g2) * CG + n) * C1 + ch * 8, __builtin_amdgcn_readfirstlane(lds0 + V3_OFF_W1 + i * 1024));
-    }
-  };
-  auto dma_w2 = [&](int st) {                         // 36 KB
-    for (int i = w; i < G2 * 18; i += NW) {
-      const int g2 = i / 18, sl = (i % 18) * 64 + lane, qq = sl >> 5, n = sl & 31;
-      s1_dma16(w2 + (size_t)((G2 * st + g2) * CG + n) * KW2 + (qq >> 2) * CG + (qq & 3) * 8, __builtin_amdgcn_readfirstlane(lds0 + V3_OFF_W2 + i * 1024));
-    }
-  };
-  auto dma_w3 = [&](int st) {                         // 16 KB: the 64 hidden channels of the step = 8 k-chunks
-    for (int i = w; i < G2 * 8; i += NW) {
-      const int sl = i * 64 + lane, ch = sl >> 7, n = sl & 127;
-      s1_dma16(w3 + (size_t)n * HID + G2 * st * CG + ch * 8, __builtin_amdgcn_readfirstlane(lds0 + V3_OFF_W3 + i * 1024));
-    }
-  };
-
-  // P1 / P2 work split as in v1: (m-tile, n-tile) pairs p and p + 16 share the n-tile (w & 1)
-  const int nt = w & 1;
-  const int mtA = w >> 1, mtB = (w + NW) >> 1;
-  const bool p1B = w + NW < 2 * (XTP / 16);            // second conv1 pair exists  (28 pairs)
-  const bool p2B = w + NW < 2 * (OTP / 16);            // second conv2 pair exists  (26 pairs)
-
-  // ---- W1(0) on its way; this wave's conv1 tokens -> registers (zero rows for the padding tokens), H1 zeroed, bias table
-  dma_w1(0);
-  u32x4 xa[4], xb[4];
-  {
-    const int ta = mtA * 16 + lrow, tb = mtB * 16 + lrow;
-    const u32x4 z = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-      xa[kc] = ta < XT ? *reinterpret_cast<const u32x4*>(xin + (size_t)ta * C1 + (kc * 4 + lq) * 8) : z;
-      xb[kc] = (p1B && tb < XT) ? *reinterpret_cast<const u32x4*>(xin + (size_t)tb * C1 + (kc * 4 + lq) * 8) : z;
-    }
-    for (int i = t; i < (G2 * 4 * H1_PLANE) / 16; i += NW * 64) *reinterpret_cast<u32x4*>(H1 + i * 16) = z;   // the border must stay 0
-    if (t < HID) B1s[t] = b1[t];
-  }
-  s1_dma_wait();
-  __syncthreads();
-#ifdef S1_CLK
-  ckP = __builtin_readcyclecounter() - ck0; ckl = __builtin_readcyclecounter();
-#endif
-
-  // P3 ownership: output channels 16 (w & 7) .. +15, m-tiles (w >> 3), +2, ...  (7 tiles for the even half, 6 for the odd)
-  const int n3 = w & 7, m3 = w >> 3;
-  f32x4 acc[7];
-#pragma unroll
-  for (int i = 0; i < 7; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto p3 = [&]() {
-#pragma unroll
-    for (int g2 = 0; g2 < G2; ++g2) {
-      const u32x4 wf = *reinterpret_cast<const u32x4*>(W3b + ((g2 * 4 + lq) * 128 + n3 * 16 + lrow) * 16);
-      const unsigned char* hb = H2 + (g2 * 4 + lq) * H2_PLANE + (m3 * 16 + lrow) * 16;
-      u32x4 af[7];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) af[i] = *reinterpret_cast<const u32x4*>(hb + i * 512);
-      af[6] = m3 == 0 ? *reinterpret_cast<const u32x4*>(hb + 6 * 512) : u32x4{0u, 0u, 0u, 0u};     // m-tile 12 exists only for the even half
-#pragma unroll
-      for (int i = 0; i < 7; ++i) acc[i] = mma_chunk<bf16>(wf, af[i], acc[i]);
-    }
-  };
-
-  int hpA, hpB;                                        // H1 pixel (top-left tap) of this lane's output token, pairs A / B
-  {
-    int tk = mtA * 16 + lrow; tk = tk < OT ? tk : OT - 1;
-    hpA = (tk / W) * PW + tk % W;
-    tk = mtB * 16 + lrow; tk = tk < OT ? tk : OT - 1;  // padded output rows recompute token 199 (ignored later)
-    hpB = (tk / W) * PW + tk % W;
-  }
-  auto h1_store = [&](int g2, int mt, f32x4 a, f32x4 bias) {
-    const int tk = mt * 16 + lrow;
-    if (tk < XT) {
-      const int pr = tk / W, pc = tk - pr * W;
-      const int pix = (pr + (hsel ? 0 : 1)) * PW + pc + 1;
-      a += bias;
-      const f32x2 g0 = S1_GELU2((f32x2{a[0], a[1]})), g1 = S1_GELU2((f32x2{a[2], a[3]}));
-      const bf16x4 o = {(bf16)g0[0], (bf16)g0[1], (bf16)g1[0], (bf16)g1[1]};
-      *reinterpret_cast<bf16x4*>(H1 + (g2 * 4 + nt * 2 + (lq >> 1)) * H1_PLANE + pix * 16 + (lq & 1) * 8) = o;
-    }
-  };
-  auto h2_store = [&](int g2, int mt, f32x4 a) {
-    const f32x2 g0 = S1_GELU2((f32x2{a[0], a[1]})), g1 = S1_GELU2((f32x2{a[2], a[3]}));
-    const bf16x4 o = {(bf16)g0[0], (bf16)g0[1], (bf16)g1[0], (bf16)g1[1]};
-    *reinterpret_cast<bf16x4*>(H2 + (g2 * 4 + nt * 2 + (lq >> 1)) * H2_PLANE + (mt * 16 + lrow) * 16 + (lq & 1) * 8) = o;
-  };
-
-#pragma unroll 1
-  for (int st = 0; st < NSTEP; ++st) {
-    // ---- interval A: DMA W2(st); P3(st-1); P1: H1 = GELU(conv1) for the step's two groups, x from registers
-    dma_w2(st);
-    if (st > 0) p3();
-#pragma unroll
-    for (int g2 = 0; g2 < G2; ++g2) {
-      const f32x4 bias = *reinterpret_cast<const f32x4*>(B1s + (G2 * st + g2) * CG + nt * 16 + lq * 4);
-      const unsigned char* wr = W1b + g2 * 8192 + (nt * 16 + lrow) * 16;
-      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kc = 0; kc < 4; ++kc) {
-        const u32x4 wf = *reinterpret_cast<const u32x4*>(wr + (kc * 4 + lq) * 512);
-        a0 = mma_chunk<bf16>(wf, xa[kc], a0);
-        if (p1B) a1 = mma_chunk<bf16>(wf, xb[kc], a1);
-      }
-      h1_store(g2, mtA, a0, bias);
-      if (p1B) h1_store(g2, mtB, a1, bias);
-    }
-    s1_dma_wait();
-    __syncthreads();
-#ifdef S1_CLK
-    { long long c = __builtin_readcyclecounter(); ckA += c - ckl; ckl = c; }
-#endif
-    // ---- interval B: DMA W1(st+1), W3(st); P2: H2 = GELU(grouped 3x3 conv of H1) for the two groups
-    if (st + 1 < NSTEP) dma_w1(st + 1);
-    dma_w3(st);
-#pragma unroll
-    for (int g2 = 0; g2 < G2; ++g2) {
-      const unsigned char* wr = W2b + g2 * 18432 + (lq * 32 + nt * 16 + lrow) * 16;
-      const unsigned char* ha = H1 + (g2 * 4 + lq) * H1_PLANE + hpA * 16;
-      const unsigned char* hb = H1 + (g2 * 4 + lq) * H1_PLANE + hpB * 16;
-      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int toff = ((tap / 3) * PW + tap % 3) * 16;
-        const u32x4 wf = *reinterpret_cast<const u32x4*>(wr + tap * 2048);
-        a0 = mma_chunk<bf16>(wf, *reinterpret_cast<const u32x4*>(ha + toff), a0);
-        if (p2B) a1 = mma_chunk<bf16>(wf, *reinterpret_cast<const u32x4*>(hb + toff), a1);
-      }
-      h2_store(g2, mtA, a0);
-      if (p2B) h2_store(g2, mtB, a1);
-    }
-    s1_dma_wait();
-    __syncthreads();
-#ifdef S1_CLK
-    { long long c = __builtin_readcyclecounter(); ckB += c - ckl; ckl = c; }
-#endif
-  }
-  p3();
-
-  // ---- y = acc + x (residual re-read from global: it is in L2 since the prologue); lane holds channels 16 n3 + 4 lq .. +3 of token mt*16 + lrow
-  bf16* yout = y + ((size_t)b * 400 + r0 * W) * C1 + n3 * 16 + lq * 4;
-  const bf16* xres = x + ((size_t)b * 400 + r0 * W) * C1 + n3 * 16 + lq * 4;
-#pragma unroll
-  for (int i = 0; i < 7; ++i) {
-    const int mt = m3 + 2 * i;
-    const int tk = mt * 16 + lrow;
-    if (mt < 13 && tk < OT) {
-      const bf16x4 r = *reinterpret_cast<const bf16x4*>(xres + (size_t)tk * C1);
-      f32x4 v = acc[i];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-      store4<bf16>(yout + (size_t)tk * C1, v);
-    }
-  }
-#ifdef S1_CLK
-  if (t == 0 && (blockIdx.x == 0 || blockIdx.x == 5001)) {
-    const long long c = __builtin_readcyclecounter();
-    printf("[stage1 v3 wg %d] total %lld  prologue %lld  intervals A %lld  B %lld  tail+epilogue %lld\n", (int)blockIdx.x, c - ck0, ckP, ckA, ckB, c - ckl);
-  }
-#endif
-}
-
 bool stage1_fused_supported(int dtype, int C1, int hid, int group, int H1) {
   return dtype == 1 && C1 == s1::C1 && hid == s1::HID && group == s1::G && H1 == s1::W;
 }
@@ -497,21 +293,9 @@ int launch_stage1_block(const void* x, void* y, const void* w1, const float* b1,
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  static const int ver = [] { const char* e = getenv("FSVIT_STAGE1_V"); return e ? atoi(e) : 1; }();      // 3: stage1_block2_kernel (x in registers, two groups per interval; measured 8 % slower)
-  if (ver == 3) {
-    static bool attr2 = false;
-    if (!attr2) {
-      hipError_t e = hipFuncSetAttribute((const void*)stage1_block2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, s1b::V3_LDS_BYTES);
-      if (e != hipSuccess) return (int)e;
-      attr2 = true;
-    }
-    hipLaunchKernelGGL(stage1_block2_kernel, dim3(B * 2), dim3(s1::NW * 64), s1b::V3_LDS_BYTES, s, (const bf16*)x, (bf16*)y, (const bf16*)w1, b1,
-                       (const bf16*)w2, (const bf16*)w3);
-    return (int)hipGetLastError();
-  }
   hipLaunchKernelGGL(stage1_block_kernel, dim3(B * 2), dim3(s1::NW * 64), s1::LDS_BYTES, s, (const bf16*)x, (bf16*)y, (const bf16*)w1, b1,
                      (const bf16*)w2, (const bf16*)w3);
   return (int)hipGetLastError();
 }
 
-}  // namespace fsvit
+}  // namespace FSVIT_NS

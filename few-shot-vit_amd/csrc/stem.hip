@@ -6,7 +6,7 @@
 #include "fsvit_common.h"
 #include "kernels.h"
 
-namespace fsvit {
+namespace FSVIT_NS {
 
 template <typename T>
 __global__ __launch_bounds__(256) void im2col27_kernel(const float* __restrict__ x, T* __restrict__ out,
@@ -169,4 +169,4 @@ int launch_maxpool2_pos(const void* in, const float* pos, void* out, int B, int 
   return (int)hipGetLastError();
 }
 
-}  // namespace fsvit
+}  // namespace FSVIT_NS

@@ -9,7 +9,7 @@
 #include "fsvit_common.h"
 #include "kernels.h"
 
-namespace fsvit {
+namespace FSVIT_NS {
 
 // y[m][n] = x[m][:] . w[n][:] + b[n];  one workgroup per row m, wave w takes n = w, w + 4, ...; K % 4 == 0
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
@@ -229,4 +229,4 @@ int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float l
   return (int)hipGetLastError();
 }
 
-}  // namespace fsvit
+}  // namespace FSVIT_NS

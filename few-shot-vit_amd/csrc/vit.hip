@@ -8,7 +8,7 @@
 #include "fsvit_common.h"
 #include "kernels.h"
 
-namespace fsvit {
+namespace FSVIT_NS {
 
 template <typename T>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int img, int p, int Kp) {
@@ -153,4 +153,4 @@ int launch_final_ln_cls(const void* tokens, const float* gamma, const float* bet
   return (int)hipGetLastError();
 }
 
-}  // namespace fsvit
+}  // namespace FSVIT_NS

@@ -12,8 +12,8 @@ import torch
 
 from . import _lib
 
-DTYPES = {'f32': _lib.F32, 'parity': _lib.F32, 'fp32': _lib.F32, 'bf16': _lib.BF16}
-TORCH_DTYPE = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16}
+DTYPES = {'f32': _lib.F32, 'parity': _lib.F32, 'fp32': _lib.F32, 'bf16': _lib.BF16, 'f16': _lib.F16, 'fp16': _lib.F16}
+TORCH_DTYPE = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.F16: torch.float16}
 
 
 # Packed eval engines cache BN-folded copies of the weights.  The HIP optimizers and the HIP trainer write parameters and running
@@ -31,7 +31,8 @@ def weight_generation() -> int:
 
 
 def default_numerics() -> str:
-    """'bf16' (throughput mode) unless FSVIT_NUMERICS=parity|f32 selects exact-fp32 MFMA."""
+    """'bf16' (throughput mode) unless FSVIT_NUMERICS selects another one: 'f16' (fp16 storage + MFMA: same kernels and rate, 8 x smaller
+    logit deviation than bf16, eval only) or 'parity' / 'f32' (exact-fp32 MFMA)."""
     return os.environ.get('FSVIT_NUMERICS', 'bf16')
 
 
@@ -62,7 +63,7 @@ class _EncoderEngine:
         self.lib = _lib.load()
         numerics = numerics or default_numerics()
         if numerics not in DTYPES:
-            raise ValueError(f'unknown numerics mode {numerics!r} (bf16 | parity)')
+            raise ValueError(f'unknown numerics mode {numerics!r} (bf16 | f16 | parity)')
         self.dtype = DTYPES[numerics]
         self.device = torch.device(device if device is not None else 'cuda')
         if self.device.type != 'cuda':
@@ -199,6 +200,8 @@ class VisformerTrainer:
         numerics = numerics or default_numerics()
         if numerics not in DTYPES:
             raise ValueError(f'unknown numerics mode {numerics!r} (bf16 | parity)')
+        if DTYPES[numerics] == _lib.F16:
+            raise NotImplementedError("fsvit: the 'f16' numerics mode is an eval mode (no loss scaling is built); train in 'bf16' or 'parity'")
         self.dtype = DTYPES[numerics]
         self.device = torch.device(device if device is not None else 'cuda')
         if self.device.type != 'cuda':
@@ -317,6 +320,8 @@ class ops:
             return _lib.F32
         if t.dtype == torch.bfloat16:
             return _lib.BF16
+        if t.dtype == torch.float16:
+            return _lib.F16
         raise TypeError(t.dtype)
 
     @staticmethod

@@ -12,7 +12,9 @@
  *   - return 0 on success; > 0 is a hipError_t, < 0 an fsvit error; `fsvit_last_error()` (thread
  *     local) describes the last failure;
  *   - `dtype` selects storage + MFMA arithmetic of activations/weights: FSVIT_F32 = exact fp32
- *     MFMA (v_mfma_f32_16x16x4_f32, the parity mode), FSVIT_BF16 = bf16 MFMA with fp32 accumulate.
+ *     MFMA (v_mfma_f32_16x16x4_f32, the parity mode), FSVIT_BF16 = bf16 MFMA with fp32 accumulate, FSVIT_F16 = fp16 MFMA with
+ *     fp32 accumulate (eval engines only: same kernels, same rate, 3 more mantissa bits than bf16; |activations| must stay
+ *     below 65504, which BatchNorm / LayerNorm networks do with a wide margin).
  */
 #ifndef FSVIT_H
 #define FSVIT_H
@@ -23,7 +25,7 @@
 extern "C" {
 #endif
 
-enum { FSVIT_F32 = 0, FSVIT_BF16 = 1 };
+enum { FSVIT_F32 = 0, FSVIT_BF16 = 1, FSVIT_F16 = 2 };
 enum { FSVIT_ACT_NONE = 0, FSVIT_ACT_GELU = 1, FSVIT_ACT_LRELU = 2 };
 enum { FSVIT_HEAD_COS = 0, FSVIT_HEAD_SQR = 1, FSVIT_HEAD_DOT = 2 };
 enum {

@@ -30,13 +30,14 @@ from .visformer_oracle import VisformerCfg, meta_baseline_head
 
 
 SKIP = set()       # analysis only (tools/emul_ablation.py): rounding sites left in fp32
+STORAGE = torch.bfloat16     # the engine's 16-bit storage / MFMA operand type: torch.bfloat16 ('bf16' mode) or torch.float16 ('f16' mode)
 
 
 def bf(t: torch.Tensor, site: str = '') -> torch.Tensor:
-    """Round to bf16 (nearest even) and back: the value a bf16 store keeps."""
+    """Round to the 16-bit storage type (nearest even) and back: the value a store keeps / an MFMA operand carries."""
     if site and site in SKIP:
         return t
-    return t.to(torch.bfloat16).to(torch.float32)
+    return t.to(STORAGE).to(torch.float32)
 
 
 def gelu_sig(x: torch.Tensor) -> torch.Tensor:
@@ -153,8 +154,16 @@ def visformer_forward_emul(sd: Dict[str, torch.Tensor], x: torch.Tensor, cfg: Vi
     return xfull.mean(dim=(2, 3)) * sN.float() + tN.float()
 
 
-def meta_baseline_forward_emul(sd, x_shot, x_query, cfg: VisformerCfg, method='cos', residual='hilo'):
-    """MetaBaseline.forward (meta_baseline.py:24-47) on the emulated encoder; the head is fp32 in the engine too."""
+def meta_baseline_forward_emul(sd, x_shot, x_query, cfg: VisformerCfg, method='cos', residual='hilo', storage=None):
+    """MetaBaseline.forward (meta_baseline.py:24-47) on the emulated encoder; the head is fp32 in the engine too.
+    storage: torch.bfloat16 / torch.float16 for this call (default: the module-level STORAGE)."""
+    global STORAGE
+    if storage is not None:
+        keep, STORAGE = STORAGE, storage
+        try:
+            return meta_baseline_forward_emul(sd, x_shot, x_query, cfg, method=method, residual=residual)
+        finally:
+            STORAGE = keep
     img_shape = x_shot.shape[-3:]
     xs, xq = x_shot.reshape(-1, *img_shape), x_query.reshape(-1, *img_shape)
     with torch.no_grad():

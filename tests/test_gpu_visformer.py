@@ -77,6 +77,51 @@ def test_logits_bf16_mode_vs_reference_golden(full_sd, golden_dir, name, seed, s
     assert agree == 1.0
 
 
+# f16 mode (fp16 storage + MFMA, same kernels compiled for _Float16): the rounding-point oracle predicts 1.3e-2 / 9e-3 against the fp32
+# reference for these two episodes; set from the GPU measurement (1.5 x).
+LOGIT_TOL_F16 = 1.8e-2          # 1.5 x the measured 1.18e-2 (5-shot) / 9.4e-3 (1-shot)
+LOGIT_TOL_F16_EMUL = 7.5e-3     # 1.5 x the measured 4.9e-3 / 4.4e-3
+
+
+@pytest.mark.parametrize('name,seed,shot', [('5shot', 11, 5), ('1shot', 12, 1)])
+def test_logits_f16_mode_vs_reference_golden_and_rounding_point_oracle(full_sd, golden_dir, name, seed, shot):
+    """The `f16` numerics mode: every 16-bit kernel of the engine compiled for _Float16 (namespace fsvit_f16).  Against the reference's
+    golden logits it must sit ~8 x closer than bf16 (3 more mantissa bits; the bf16 deviation is weight rounding), and
+    against the oracle that rounds to fp16 where the kernels do, closer still."""
+    from oracle import visformer_emul as ve
+    from oracle import visformer_oracle as vo
+    z = np.load(os.path.join(golden_dir, 'full_visformer_micro_80.npz'))
+    ref = z[f'logits_{name}']
+    m = _model(full_sd, 'f16')
+    xs, xq = _episode(seed, shot)
+    with torch.no_grad():
+        logits = m(xs.cuda(), xq.cuda()).cpu().numpy()
+    err = np.abs(logits - ref).max()
+    emu = ve.meta_baseline_forward_emul(full_sd, xs, xq, vo.VisformerCfg(), residual='bf16', storage=torch.float16).numpy()
+    err_e = np.abs(logits - emu).max()
+    print(f'[f16] {name} max|dlogit| vs reference golden = {err:.3e}, vs fp16 rounding-point oracle = {err_e:.3e}')
+    assert err <= LOGIT_TOL_F16
+    assert err_e <= LOGIT_TOL_F16_EMUL
+    assert (logits.argmax(-1) == ref.argmax(-1)).mean() == 1.0
+
+
+def test_f16_mode_is_launch_size_invariant_and_bf16_engine_is_untouched(full_sd):
+    """Two engines of different 16-bit types side by side in one process (two kernel namespaces in one library): each keeps its own
+    results, and the f16 engine is batch-size invariant like the bf16 one."""
+    from fewshot_vit_amd import synthetic
+    from fewshot_vit_amd.utils import few_shot as fs
+    mb, mf = _model(full_sd, 'bf16'), _model(full_sd, 'f16')
+    x = synthetic.synthetic_episodes(78, 3, 5, 1, 15)
+    xs, xq = fs.split_shot_query(x, 5, 1, 15, 3)
+    with torch.no_grad():
+        b0 = mb(xs.cuda(), xq.cuda()).cpu()
+        f_all = mf(xs.cuda(), xq.cuda()).cpu()
+        b1 = mb(xs.cuda(), xq.cuda()).cpu()
+        f_single = torch.cat([mf(xs[e:e + 1].cuda(), xq[e:e + 1].cuda()).cpu() for e in range(3)])
+    assert torch.equal(b0, b1) and torch.equal(f_all, f_single)
+    assert not torch.equal(b0, f_all) and (b0 - f_all).abs().max() < 0.3
+
+
 @pytest.mark.parametrize('name,seed,shot', [('5shot', 11, 5), ('1shot', 12, 1)])
 def test_logits_bf16_mode_vs_rounding_point_oracle(full_sd, name, seed, shot):
     """a bf16 gate that means something.  The emulated oracle applies bf16 rounding exactly where the engine
