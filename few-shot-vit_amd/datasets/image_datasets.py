@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .datasets import register
-from .transforms import DeviceTransform
+from .transforms import IMAGENET_MEAN, IMAGENET_STD, DeviceTransform
 
 
 class _DeviceImageDataset:
@@ -35,7 +35,8 @@ class _DeviceImageDataset:
             if self.device.type != 'cuda':
                 raise RuntimeError('fsvit: the dataset transform runs on an MI355X (no CPU fallback)')
             self._on_device = self.images.to(self.device)
-            self._transform = DeviceTransform(tuple(self.images.shape[1:3]), self.resize, self.crop, self.device)
+            self._transform = DeviceTransform(tuple(self.images.shape[1:3]), self.resize, self.crop, self.device,
+                                              mean=getattr(self, 'mean', IMAGENET_MEAN), std=getattr(self, 'std', IMAGENET_STD))
         return self._on_device
 
     def gather(self, index) -> torch.Tensor:
