@@ -73,6 +73,8 @@ SIGNATURES = {
     'fsvit_linear_backward': (_i, [_fp, _fp, _fp, _fp, _i, _fp, _fp, _i, _i, _i, _vp]),
     'fsvit_token_softlabel': (_i, [_fp, _fp, _i, _i, _i, _i, _i, C.c_double, _vp]),
     'fsvit_soft_target_ce': (_i, [_fp, _fp, _fp, _fp, _i, _i, _f, _vp]),
+    'fsvit_row_normalize': (_i, [_fp, _fp, _fp, _i, _i, _vp]),
+    'fsvit_row_normalize_backward': (_i, [_fp, _fp, _fp, _fp, _i, _i, _vp]),
     'fsvit_adamw_step': (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _i, _vp]),
     'fsvit_proj_mlp_rows': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _fp, _vp, _i, _fp, _i, _i, _i, _vp]),
     'fsvit_mlp_rows': (_i, [_vp, _vp, _vp, _i, _fp, _vp, _i, _fp, _i, _i, _i, _vp]),

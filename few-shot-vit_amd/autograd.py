@@ -104,6 +104,21 @@ class LinearFn(torch.autograd.Function):
         return (dx.view(ctx.xshape) if dx is not None else None), dw, (db if ctx.has_b else None)
 
 
+class RowNormalizeFn(torch.autograd.Function):
+    """F.normalize(x, dim=-1) for [R, D] fp32 rows on the HIP kernels (utils.compute_logits metric 'cos')."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y, inv = ops.row_normalize(x)
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        return ops.row_normalize_backward(y, inv, dy)
+
+
 class SoftTargetCEFn(torch.autograd.Function):
     """SoftTargetCrossEntropy (offline.py:34-45): mean over rows of sum(-target * log_softmax(logits)); the gradient comes out of
     the same kernel launch as the loss."""

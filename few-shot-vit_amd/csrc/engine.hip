@@ -833,6 +833,16 @@ extern "C" int fsvit_soft_target_ce(const float* logits, const float* target, fl
   RC_TRY(K(launch_soft_target_ce)(logits, target, row_loss, dlogits, R, C, grad_scale, (hipStream_t)stream));
   return 0;
 }
+extern "C" int fsvit_row_normalize(const float* x, float* y, float* inv_norm, int R, int D, void* stream) {
+  if (!x || !y || !inv_norm || D <= 0) return fail(FSVIT_ERR_ARG, "fsvit_row_normalize: bad argument");
+  RC_TRY(fsvit::launch_row_normalize(x, y, inv_norm, R, D, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int fsvit_row_normalize_backward(const float* y, const float* inv_norm, const float* dy, float* dx, int R, int D, void* stream) {
+  if (!y || !inv_norm || !dy || !dx || D <= 0) return fail(FSVIT_ERR_ARG, "fsvit_row_normalize_backward: bad argument");
+  RC_TRY(fsvit::launch_row_normalize_bwd(y, inv_norm, dy, dx, R, D, (hipStream_t)stream));
+  return 0;
+}
 extern "C" int fsvit_adamw_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                                 float weight_decay, int step, void* stream) {
   const int kdt = FSVIT_BF16;

@@ -153,6 +153,42 @@ __global__ __launch_bounds__(256) void soft_target_ce_kernel(const float* __rest
     for (int c = lane; c < C; c += 64) dz[(size_t)r * C + c] = gscale * (expf(zr[c] - mx) / se * st - tr[c]);
 }
 
+// F.normalize(x, dim=-1) rows (utils.compute_logits metric 'cos', test_phase/utils/__init__.py:82-84; the nn-classifier head,
+// test_phase/models/classifier.py:38-55): y = x / max(|x|, 1e-12), inv[r] = 1 / max(|x_r|, 1e-12) kept for the backward.  One wave per row.
+__global__ __launch_bounds__(256) void row_normalize_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv, int R, int D) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float* xr = x + (size_t)r * D;
+  float ss = 0.f;
+  for (int d = lane; d < D; d += 64) ss = fmaf(xr[d], xr[d], ss);
+  const float iv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+  for (int d = lane; d < D; d += 64) y[(size_t)r * D + d] = xr[d] * iv;
+  if (lane == 0) inv[r] = iv;
+}
+// dx = (dy - y <y, dy>) * inv   (the Jacobian of x / |x|; for |x| < 1e-12 torch's clamp makes it dy * 1e12 - not distinguished here)
+__global__ __launch_bounds__(256) void row_normalize_bwd_kernel(const float* __restrict__ y, const float* __restrict__ inv, const float* __restrict__ dy,
+                                                                float* __restrict__ dx, int R, int D) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float* yr = y + (size_t)r * D;
+  const float* gr = dy + (size_t)r * D;
+  float dot = 0.f;
+  for (int d = lane; d < D; d += 64) dot = fmaf(yr[d], gr[d], dot);
+  dot = wave_sum(dot);
+  const float iv = inv[r];
+  for (int d = lane; d < D; d += 64) dx[(size_t)r * D + d] = (gr[d] - yr[d] * dot) * iv;
+}
+int launch_row_normalize(const float* x, float* y, float* inv, int R, int D, hipStream_t s) {
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL(row_normalize_kernel, dim3((R + 3) / 4), dim3(256), 0, s, x, y, inv, R, D);
+  return (int)hipGetLastError();
+}
+int launch_row_normalize_bwd(const float* y, const float* inv, const float* dy, float* dx, int R, int D, hipStream_t s) {
+  if (R <= 0) return 0;
+  hipLaunchKernelGGL(row_normalize_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, s, y, inv, dy, dx, R, D);
+  return (int)hipGetLastError();
+}
+
 // torch.optim.AdamW / timm AdamW (decoupled weight decay), update number `step` (1-based)
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
                              float beta1, float beta2, float eps, float wd, float bc1, float rsqrt_bc2) {

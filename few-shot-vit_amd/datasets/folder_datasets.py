@@ -125,7 +125,7 @@ class ImageFolder:
         return self._normalise(u8.to(self.device, non_blocking=True))
 
     def __getitem__(self, i):
-        return self._normalise(self._load_u8(i).unsqueeze(0))[0], self.label[i]
+        return self._normalise(self._load_u8(i).unsqueeze(0).to(self.device))[0], self.label[i]       # same device arithmetic as `gather`
 
     def convert_raw(self, x):
         return x * self._std[0].type_as(x) + self._mean[0].type_as(x)

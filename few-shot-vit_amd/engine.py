@@ -411,6 +411,25 @@ class ops:
         return row, dz
 
     @staticmethod
+    def row_normalize(x):
+        """F.normalize(x, dim=-1) of a [R, D] fp32 matrix -> (y, inv_norm [R])."""
+        _require_cuda(x)
+        x = x.contiguous().float()
+        y, inv = torch.empty_like(x), torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().fsvit_row_normalize(_ptr(x), _ptr(y), _ptr(inv), x.shape[0], x.shape[1], _stream_ptr(x.device)))
+        return y, inv
+
+    @staticmethod
+    def row_normalize_backward(y, inv, dy):
+        _require_cuda(y, inv, dy)
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(y)
+        with torch.cuda.device(y.device):
+            _lib.check(_lib.load().fsvit_row_normalize_backward(_ptr(y), _ptr(inv), _ptr(dy), _ptr(dx), y.shape[0], y.shape[1], _stream_ptr(y.device)))
+        return dx
+
+    @staticmethod
     def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
         _require_cuda(p, g, m, v)
         bump_weight_generation()

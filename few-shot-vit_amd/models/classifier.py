@@ -31,6 +31,33 @@ class LinearClassifier(nn.Module):
         return LinearFn.apply(x, self.linear.weight, self.linear.bias)
 
 
+@register('nn-classifier')
+class NNClassifier(nn.Module):
+    """test_phase/models/classifier.py:38-55: logits = utils.compute_logits(x, proto, metric, temp) with learnable prototypes
+    [n_classes, in_dim] (and a learnable temperature, initial 10, for the default 'cos' metric).  'cos' = row normalisation of both
+    operands (fsvit_row_normalize) + the HIP Linear kernel; 'dot' = the Linear kernel alone; differentiable through both."""
+
+    def __init__(self, in_dim, n_classes, metric='cos', temp=None):
+        super().__init__()
+        if metric not in ('cos', 'dot'):
+            raise NotImplementedError("fsvit: nn-classifier is built for metric 'cos' (the reference default) and 'dot'")
+        self.proto = nn.Parameter(torch.empty(n_classes, in_dim))
+        nn.init.kaiming_uniform_(self.proto, a=math.sqrt(5))
+        if temp is None:
+            temp = nn.Parameter(torch.tensor(10.)) if metric == 'cos' else 1.0
+        self.metric = metric
+        self.temp = temp
+
+    def forward(self, x):
+        if x.device.type != 'cuda':
+            raise RuntimeError('fsvit: NNClassifier needs cuda tensors (no CPU fallback)')
+        from ..autograd import RowNormalizeFn
+        p = self.proto
+        if self.metric == 'cos':
+            x, p = RowNormalizeFn.apply(x), RowNormalizeFn.apply(p)
+        return LinearFn.apply(x, p, None) * self.temp
+
+
 @register('classifier')
 class Classifier(nn.Module):
     """sun_meta_training/models/classifier.py:11-24: encoder (returning `(map, pooled)`) + classifier on the pooled feature."""

@@ -7,7 +7,7 @@ reference's schema.  The teacher of the distillation phase (`offline.py`, key `l
 
 MI355X-native: encoder forward / backward on the HIP trainer, Linear head, AdamW update and the few-shot evaluation on the HIP engine;
 multi-GPU = one process per GPU with one gradient all-reduce per step and rank-sharded few-shot episodes.  Not restated: tensorboard,
-dataset visualisation, train-time augmentation, `epoch_ex`, `nn-classifier`.
+dataset visualisation, train-time augmentation.
 
   python -m fewshot_vit_amd.train_classifier --config few-shot-vit_amd/configs/train_classifier_synthetic.yaml
 """
@@ -87,7 +87,14 @@ def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, sa
     trlog = {k: [] for k in keys}
     gen = torch.Generator().manual_seed(config.get('seed', 0))
 
-    for epoch in range(1, max_epoch + 1):
+    for epoch in range(1, max_epoch + 1 + 1):
+        if epoch == max_epoch + 1:
+            # `epoch_ex` (sun_train_teacher/train_classifier.py:141-148): ONE extra epoch over the training set under its default
+            # (un-augmented) transform.  The datasets here only have that transform, so the switch itself is a no-op.
+            if not config.get('epoch_ex'):
+                break
+            if hasattr(train_dataset, 'default_transform'):
+                train_dataset.transform = train_dataset.default_transform
         timer_epoch.s()
         aves = {k: utils.Averager() for k in keys}
         model.train()

@@ -198,6 +198,11 @@ int fsvit_token_softlabel(const float* teacher_logits_dev, float* soft_dev, int 
  * target) or NULL; any C. */
 int fsvit_soft_target_ce(const float* logits_dev, const float* target_dev, float* row_loss_dev, float* dlogits_dev, int R, int C,
                          float grad_scale, void* stream);
+/* F.normalize(x, dim=-1) of R rows of length D (utils.compute_logits metric 'cos', test_phase/utils/__init__.py:82-84; the
+ * `nn-classifier` head, test_phase/models/classifier.py:38-55): y = x / max(|x|, 1e-12), inv_norm [R] for the backward
+ * dx = (dy - y <y, dy>) * inv_norm. */
+int fsvit_row_normalize(const float* x_dev, float* y_dev, float* inv_norm_dev, int R, int D, void* stream);
+int fsvit_row_normalize_backward(const float* y_dev, const float* inv_norm_dev, const float* dy_dev, float* dx_dev, int R, int D, void* stream);
 /* AdamW (decoupled weight decay), update number `step` >= 1: p, exp_avg m, exp_avg_sq v updated in place. */
 int fsvit_adamw_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, size_t n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, void* stream);

@@ -225,3 +225,48 @@ def test_wide_heads_tiered_imagenet_class_counts():
     row, dz = ops.soft_target_ce(z.cuda(), t.cuda(), grad_scale=1.0)
     assert (row.cpu() - loss_ref.detach()).abs().max() <= 2e-5 * max(1.0, float(loss_ref.abs().max()))
     assert (dz.cpu() - zr.grad).abs().max() <= 2e-6
+
+
+def test_train_classifier_epoch_ex_and_nn_classifier(tmp_path):
+    """f3 leftovers: `epoch_ex` = one extra epoch after max_epoch (sun_train_teacher/train_classifier.py:141-148) and the
+    `nn-classifier` head (test_phase/models/classifier.py:38-55) - cosine logits against learnable prototypes with a learnable
+    temperature - trained through the same driver."""
+    from fewshot_vit_amd import train_classifier
+    config = dict(train_dataset='synthetic-episodes', train_dataset_args=dict(split='train', n_classes=6, n_per_class=12, noise=1.0, seed=1),
+                  model='classifier', model_args=dict(encoder='visformer_micro_80', encoder_args=dict(drop_path_rate=0.0),
+                                                      classifier='nn-classifier', classifier_args=dict(n_classes=6)),
+                  synthetic_checkpoint='visformer_micro_80', batch_size=12, train_batches=2, max_epoch=2, epoch_ex=True, optimizer='adamw',
+                  optimizer_args=dict(lr=5e-4, weight_decay=0.05, warmup_lr=1e-6, warmup=1))
+    lines = []
+    trlog = train_classifier.main(config, name='nn', device=torch.device('cuda', 0), log=lines.append, save_root=str(tmp_path))
+    assert len(trlog['tl']) == 3 and np.isfinite(trlog['tl']).all()              # max_epoch + the extra epoch
+    assert any(l.startswith('epoch 3,') for l in lines)
+    ck = torch.load(os.path.join(str(tmp_path), 'nn', 'epoch-last.pth'), map_location='cpu')
+    assert ck['model_sd']['classifier.proto'].shape == (6, 512) and 'classifier.temp' in ck['model_sd']
+
+
+def test_nn_classifier_forward_backward_vs_torch():
+    from fewshot_vit_amd import models
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(37, 96, generator=g)
+    for metric in ('cos', 'dot'):
+        m = models.make('nn-classifier', in_dim=96, n_classes=11, metric=metric).cuda()
+        xg = x.clone().cuda().requires_grad_(True)
+        w = torch.randn(37, 11, generator=g)
+        (m(xg) * w.cuda()).sum().backward()
+        xr = x.clone().requires_grad_(True)
+        pr = m.proto.detach().cpu().clone().requires_grad_(True)
+        if metric == 'cos':
+            tr = m.temp.detach().cpu().clone().requires_grad_(True)
+            ref = torch.nn.functional.normalize(xr, dim=-1) @ torch.nn.functional.normalize(pr, dim=-1).t() * tr
+        else:
+            ref = xr @ pr.t() * m.temp
+        (ref * w).sum().backward()
+        with torch.no_grad():
+            assert (m(x.cuda()).cpu() - ref.detach()).abs().max() <= 1e-5 * max(1.0, float(ref.abs().max()))
+        assert (xg.grad.cpu() - xr.grad).abs().max() <= 1e-5 * max(1.0, float(xr.grad.abs().max()))
+        assert (m.proto.grad.cpu() - pr.grad).abs().max() <= 1e-5 * max(1.0, float(pr.grad.abs().max()))
+        if metric == 'cos':
+            assert abs(float(m.temp.grad) - float(tr.grad)) <= 1e-4 * max(1.0, abs(float(tr.grad)))
+    with pytest.raises(NotImplementedError):
+        models.make('nn-classifier', in_dim=8, n_classes=2, metric='sqr')
