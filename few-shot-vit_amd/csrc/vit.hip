@@ -45,38 +45,58 @@ __global__ __launch_bounds__(256) void cls_pos_kernel(const float* __restrict__ 
   }
 }
 
-// one wave per row; D % 4 == 0, D <= 64 * 4 * 8
-template <typename T>
+// LayerNorm without affine (gamma / beta are folded into the following Linear): y = (x - mean) * rstd, biased variance as nn.LayerNorm.
+// HBM-bound (read + write of the token stream, 24 calls per DeiT forward = 13 % of the step in round 1): a row of D elements is handled
+// by G = 16 / 32 / 64 lanes with 16-byte accesses (8 bf16 / 4 fp32 per lane and pass), so a wave normalises 64 / G rows at once and
+// every lane is busy - the first version gave a 768-byte DeiT-S row to a whole wave of 8-byte accesses (1.5 of 8 passes populated).
+template <typename T, int G>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, T* __restrict__ y, int M, int D, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const T* xr = x + (size_t)row * D;
-  f32x4 v[8];
+  constexpr int EPL = 16 / sizeof(T);                 // elements per lane and pass
+  constexpr int MAXP = 4;                             // passes: D <= G * EPL * MAXP
+  const int lane = threadIdx.x & 63, sub = lane % G;
+  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / G) + lane / G;
+  const bool rok = row < M;
+  const T* xr = x + (size_t)(rok ? row : 0) * D;
+  float v[MAXP][EPL];
   float s = 0.f;
-  const int n4 = D / 4;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = lane + 64 * i;
-    v[i] = c < n4 ? load4<T>(xr + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-  }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
+  for (int i = 0; i < MAXP; ++i) {
+    const int c = (sub + G * i) * EPL;
+    if (c < D) {
+      const u32x4 raw = *reinterpret_cast<const u32x4*>(xr + c);
+      const T* e = reinterpret_cast<const T*>(&raw);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = lane + 64 * i;
-    if (c < n4) {
+      for (int j = 0; j < EPL; ++j) { v[i][j] = to_f32<T>(e[j]); s += v[i][j]; }
+    } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+      for (int j = 0; j < EPL; ++j) v[i][j] = 0.f;
     }
   }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);     // biased variance, as nn.LayerNorm
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i)
+    if ((sub + G * i) * EPL < D) {
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = 1.0f / sqrtf(q / (float)D + eps);
+  if (!rok) return;
   T* yr = y + (size_t)row * D;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = lane + 64 * i;
-    if (c < n4) store4<T>(yr + c * 4, (v[i] - mean) * rstd);
+  for (int i = 0; i < MAXP; ++i) {
+    const int c = (sub + G * i) * EPL;
+    if (c < D) {
+      u32x4 raw;
+      T* e = reinterpret_cast<T*>(&raw);
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) e[j] = from_f32<T>((v[i][j] - mean) * rstd);
+      *reinterpret_cast<u32x4*>(yr + c) = raw;
+    }
   }
 }
 
@@ -138,10 +158,16 @@ int launch_cls_pos(const float* cls_plus_pos0, void* tokens, int B, int S, int D
 
 int launch_layernorm(const void* x, void* y, int M, int D, float eps, int dtype, hipStream_t s) {
   if (M <= 0) return 0;
-  if (D % 4 || D > 2048) return (int)hipErrorInvalidValue;
-  dim3 grid((M + 3) / 4), block(256);
-  if (dtype == 0) hipLaunchKernelGGL(layernorm_kernel<float>, grid, block, 0, s, (const float*)x, (float*)y, M, D, eps);
-  else hipLaunchKernelGGL(layernorm_kernel<bf16>, grid, block, 0, s, (const bf16*)x, (bf16*)y, M, D, eps);
+  const int epl = dtype == 0 ? 4 : 8;
+  if (D % epl || D > 64 * epl * 4) return (int)hipErrorInvalidValue;
+  const int lanes = (D / epl + 3) / 4;                           // lanes a row needs with 4 passes
+  const int G = lanes <= 16 ? 16 : (lanes <= 32 ? 32 : 64);
+  const int rows_per_wg = 4 * (64 / G);
+  dim3 grid((M + rows_per_wg - 1) / rows_per_wg), block(256);
+#define FSVIT_LN(TT, GG) hipLaunchKernelGGL((layernorm_kernel<TT, GG>), grid, block, 0, s, (const TT*)x, (TT*)y, M, D, eps)
+  if (dtype == 0) { if (G == 16) FSVIT_LN(float, 16); else if (G == 32) FSVIT_LN(float, 32); else FSVIT_LN(float, 64); }
+  else { if (G == 16) FSVIT_LN(bf16, 16); else if (G == 32) FSVIT_LN(bf16, 32); else FSVIT_LN(bf16, 64); }
+#undef FSVIT_LN
   return (int)hipGetLastError();
 }
 
