@@ -403,8 +403,42 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvGemmPara
           }
         }
       };
-      if (p.act == ACT_GELU) finish([](float x) { return gelu_sig(x); });
-      else if (p.act == ACT_LRELU) finish([](float x) { return x > 0.0f ? x : 0.1f * x; });
+      // Pooled variant with a monotone activation (LeakyReLU / none; the bias is per channel): max(act(a_i + b)) = act(max(a_i) + b), so
+      // the window maximum is taken on the raw accumulators (2 DPP + 2 max per value), after which the window's four lanes hold the SAME
+      // four f32x4 - lane u = lrow & 3 finishes only the u-th of them (bias, activation, pos_embed, 8-byte store): the per-value tail
+      // work and the bias / pos loads drop 4 x (the epilogue was 27 % of this kernel: 16 values x 8.5 VALU per m-tile and lane).
+      auto finish_pooled = [&](auto actf) {
+        const int u_e = lrow_e & 3;
+        const int nq = wn * 64 + (u_e >> 1) * 32 + lq_e * 8 + (u_e & 1) * 4;             // the 4 channels this lane finishes
+        const f32x4 bq = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nq) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int ph = p.H >> 1, pw = p.W >> 1;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int py = (r0 + blk_r(i) * 4 + fr_e) >> 1, px = (blk_c(i) * 4 + fc_e) >> 1;
+          const f32x4 pq = *reinterpret_cast<const f32x4*>(p.pos + (size_t)(py * pw + px) * p.y_cstride + nq);
+          f32x4 m[NT];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            m[j] = acc[i][j];
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              m[j][e] = fmaxf(m[j][e], quad_xor<0xB1>(m[j][e]));      // lanes ^ 1: quad_perm [1,0,3,2]
+              m[j][e] = fmaxf(m[j][e], quad_xor<0x4E>(m[j][e]));      // lanes ^ 2: quad_perm [2,3,0,1]
+            }
+          }
+          f32x4 v = u_e == 0 ? m[0] : (u_e == 1 ? m[1] : (u_e == 2 ? m[2] : m[3]));
+          v += bq;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = actf(v[e]);
+          v += pq;
+          store4<bf16>(Y + ((size_t)(b * ph + py) * pw + px) * p.y_cstride + nq, v);
+        }
+      };
+      if (FUSE_TAIL && p.act == ACT_LRELU) finish_pooled([](float x) { return fmaxf(x, 0.1f * x); });
+      else if (FUSE_TAIL && p.act == ACT_NONE) finish_pooled([](float x) { return x; });
+      else if (p.act == ACT_GELU) finish([](float x) { return gelu_sig(x); });
+      else if (p.act == ACT_LRELU) finish([](float x) { return fmaxf(x, 0.1f * x); });
       else finish([](float x) { return x; });
     }
     H_STAMP(ckE);

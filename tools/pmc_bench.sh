@@ -9,7 +9,7 @@ cd /tmp; export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-roofline --no-modes --steps 3 --warmup 1 $*"
 rm -rf /tmp/pb_*
 rocprofv3 --kernel-trace --stats -d /tmp/pb_kt -o kt -- $B > $out/kt_bench.json 2> $out/kt.err
-python3 $R/tools/rocpd_stats.py $(ls /tmp/pb_kt/*.db | head -1) 3 > $out/kernel_stats.csv
+python3 $R/tools/rocpd_stats.py $(ls /tmp/pb_kt/*.db | head -1) 4 > $out/kernel_stats.csv   # 1 warm-up + 3 timed steps
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d /tmp/pb_s1 -o s1 -- $B > /dev/null 2> $out/s1.err
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d /tmp/pb_s2 -o s2 -- $B > /dev/null 2> $out/s2.err
 python3 $R/tools/pmc_mfma.py $(ls /tmp/pb_s1/*.db | head -1) $(ls /tmp/pb_s2/*.db | head -1) "$B" > $out/mfma_pmc.json 2> $out/mfma_pmc.txt
