@@ -12,6 +12,12 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 3200
 x = torch.randn(B, 20, 20, 128, device='cuda').to(bf)
 w1 = pack_w(256, 128, 1, 1, bf)[0]; w2 = pack_w(256, 32, 3, 8, bf); w3 = pack_w(128, 256, 1, 1, bf)[0]
 b1 = torch.randn(256, device='cuda')
-for _ in range(8):
+import time
+for _ in range(3):
     ops.stage1_block(x, w1, b1, w2, w3)
 torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    ops.stage1_block(x, w1, b1, w2, w3)
+torch.cuda.synchronize()
+print("stage1_block B=%d (FSVIT_STAGE1_PIPE=%s): %.1f us per launch" % (B, os.environ.get("FSVIT_STAGE1_PIPE", "1"), (time.perf_counter() - t0) * 1e5))
