@@ -97,6 +97,7 @@ struct Layer {
 };
 struct Block1 {
   Layer c1, c2, c3;
+  void* img = nullptr;                    // fused stage-1 block: the three layers as per-group LDS images (stage1_fused.hip)
 };
 struct BlockA {
   Layer qkv, proj, fc1, fc2;
@@ -329,6 +330,14 @@ int build(fsvit_visformer* h, const SD& sd) {
     RC_TRY(pack_layer(h, &h->s1[i].c1, w1, h->hid1, h->C1, 1, 1, 1, nullptr, &n2.s, prenorm_bias(w1, h->hid1, h->C1, n2.t), true, nullptr, 0, nullptr, 0));
     RC_TRY(pack_layer(h, &h->s1[i].c2, w2, h->hid1, Cg, 3, 3, cf.group, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
     RC_TRY(pack_layer(h, &h->s1[i].c3, w3, h->C1, h->hid1, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
+    if (K(stage1_fused_supported)(kd(kdt), h->C1, h->hid1, cf.group, h->H1)) {
+      void* img = nullptr;
+      HIP_TRY(hipMalloc(&img, K(stage1_image_bytes)()));
+      h->allocs.push_back(img);
+      RC_TRY(K(launch_stage1_pack)(h->s1[i].c1.w, h->s1[i].c2.w, h->s1[i].c3.w, img, nullptr));
+      HIP_TRY(hipDeviceSynchronize());
+      h->s1[i].img = img;
+    }
   }
   // ---- patch embeds (visformer.py:266-288): conv k2 s2 + bias -> BN ; pos_embed added in the epilogue
   for (int s = 2; s <= 3; ++s) {
@@ -558,7 +567,7 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
     if (fuse1) {   // one LDS-resident kernel per block, ping-pong between x1 and x1b
       const double fl = 2.0 * Bc * h->H1 * h->H1 * ((double)h->hid1 * h->C1 + (double)h->hid1 * 9 * Cg + (double)h->C1 * h->hid1);
       RC_TRY(timed(h, st, "stage1.block", KID_STAGE1, fl,
-                   [&]() { return K(launch_stage1_block)(x1, x1b, b.c1.w, b.c1.bias, b.c2.w, b.c3.w, Bc, st); }));
+                   [&]() { return K(launch_stage1_block)(x1, x1b, b.img, b.c1.bias, Bc, st); }));
       std::swap(x1, x1b);
     } else {
       RC_TRY(run_gemm(h, st, "stage1.mlp.conv1", b.c1, conv_params(b.c1, x1, ha, Bc, h->H1, h->H1, h->C1, h->C1, 1, 1, 1, 0, h->hid1, ACT_GELU, nullptr, 0, nullptr), h->hid1, h->C1));
@@ -774,7 +783,13 @@ extern "C" int fsvit_stage1_block(const void* x, void* y, const void* w1, const 
   const int kdt = FSVIT_BF16;
   if (!x || !y || !w1 || !b1 || !w2 || !w3 || x == y) return fail(FSVIT_ERR_ARG, "bad argument");
   hipStream_t st = (hipStream_t)stream;
-  RC_TRY(K(launch_stage1_block)(x, y, w1, b1, w2, w3, B, st));
+  void* img = nullptr;
+  HIP_TRY(hipMalloc(&img, K(stage1_image_bytes)()));
+  int rc = K(launch_stage1_pack)(w1, w2, w3, img, st);
+  if (rc == 0) rc = K(launch_stage1_block)(x, y, img, b1, B, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(img);
+  if (rc != 0) return hipfail((hipError_t)rc, "fsvit_stage1_block");
   return 0;
 }
 
