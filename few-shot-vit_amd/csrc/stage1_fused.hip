@@ -48,8 +48,11 @@
 #define S1_GELU2(v) gelu_sig2(v)
 #endif
 
+#ifndef S1_MT
+#define S1_MT 1
+#endif
 #ifndef S1_LEAD
-#define S1_LEAD 8
+#define S1_LEAD (S1_MT == 1 ? 3 : 8)        // fragment reads run this many MFMA steps ahead (MT = 1: 128-VGPR budget)
 #endif
 #ifndef S1_VPM
 #define S1_VPM 5
@@ -57,9 +60,15 @@
 
 namespace FSVIT_NS {
 
+typedef __attribute__((ext_vector_type(2))) bf16 bf16x2;
+
 namespace s1 {
 constexpr int C1 = 128, HID = 256, G = 8, CG = 32, W = 20;
-constexpr int NW = 8;                     // waves per workgroup: 7 compute waves + the weight wave (one workgroup per CU)
+constexpr int MT = S1_MT;                 // token tiles per compute wave
+constexpr int NCW = 14 / MT;              // compute waves (14 token tiles incl. the halo row)
+constexpr int NHW = 3 - MT;               // weight waves (34 staging registers x 4 would not fit the 128-VGPR budget of a 16-wave workgroup)
+constexpr int NW = NCW + NHW;             // 8 (MT = 2) or 16 (MT = 1) waves, one workgroup per CU
+constexpr int NSTEP = 34 * MT;            // MFMAs per wave and interval
 constexpr int XT = 220;                   // input tokens (10 rows + one halo row): 14 m-tiles, the last 4 tokens empty
 constexpr int OT = 200;                   // output tokens (10 rows): 13 m-tiles, the last half empty
 constexpr int PW = 36;                    // pitch of the zero-bordered H1 pixel grid (12 rows; columns -1 .. 20 used).  36 = 20 + 16: the 16 tokens of an
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256) void stage1_pack_kernel(const bf16* __restrict
 // previous tile's last group; the next tile's x fragments are loaded at k & 7 == 6 after P1 has consumed the current ones.
 // Weight buffers (read in interval k: W1(k+1), W2(k), W3(k-2)): the weight wave writes W1(k+2), W2(k+1), W3(k-1) during interval k into the other
 // buffer of each kind, from registers it filled one interval earlier.
-__global__ __launch_bounds__(512) void stage1_block_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const unsigned char* __restrict__ wimg,
+__global__ __launch_bounds__(s1::NW * 64) void stage1_block_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const unsigned char* __restrict__ wimg,
                                                            const float* __restrict__ b1, int n_img) {
   using namespace s1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -166,33 +175,29 @@ __global__ __launch_bounds__(512) void stage1_block_kernel(const bf16* __restric
     if (t < HID) B1s[t] = b1[t];        // bias table: an in-loop global load would cost a full round trip per tile
   }
 
-  if (w == NW - 1) {
-    // ================================================================ the weight wave
-    // Streams 34 KB per interval through its own registers: global_load_dwordx4 x 34 one interval ahead, ds_write_b128 x 34 into the buffers whose
-    // readers passed the last barrier.  (LDS-DMA, global_load_lds_dwordx4, costs a wave ~100-200 cycles of issue per 1 KB piece whatever the source -
-    // measured here with an L1-hot source: 13 pieces = 2400 cycles on this wave, 3 pieces = 300 cycles on each compute wave.)
-    u32x4 stg[NPIECE];
-    auto ld = [&](int j) {               // the set written during interval j: W1(j+2), W2(j+1), W3(j-1)
-      const unsigned char* p1 = wimg + (size_t)((j + 2) & (G - 1)) * WSET + lane * 16;
-      const unsigned char* p2 = wimg + (size_t)((j + 1) & (G - 1)) * WSET + WS_W2 + lane * 16;
-      const unsigned char* p3 = wimg + (size_t)((j - 1) & (G - 1)) * WSET + WS_W3 + lane * 16;
+  if (w >= NCW) {
+    // ================================================================ the weight wave(s)
+    // Stream 34 KB per interval through their own registers: global_load_dwordx4 one interval ahead, ds_write_b128 into the buffers whose readers
+    // passed the last barrier.  (LDS-DMA, global_load_lds_dwordx4, costs a wave ~100-200 cycles of issue per 1 KB piece whatever the source -
+    // measured here with an L1-hot source: 13 pieces = 2400 cycles on one wave, 3 pieces = 300 cycles on each compute wave.)
+    constexpr int PPW = NPIECE / NHW;                   // pieces per weight wave
+    const int p0 = (w - NCW) * PPW;
+    u32x4 stg[PPW];
+    auto src_of = [&](int j, int i) -> const unsigned char* {      // piece i of the set written during interval j: W1(j+2), W2(j+1), W3(j-1)
+      const int g = i < 8 ? j + 2 : i < 26 ? j + 1 : j - 1;
+      return wimg + (size_t)(g & (G - 1)) * WSET + i * 1024 + lane * 16;
+    };
+    auto dst_of = [&](int j, int i) -> unsigned char* {
+      return smem + (i < 8 ? OFF_W1 + (j & 1) * W1_BYTES + i * 1024
+                     : i < 26 ? OFF_W2 + ((j + 1) & 1) * W2_BYTES + (i - 8) * 1024 : OFF_W3 + ((j + 1) & 1) * W3_BYTES + (i - 26) * 1024) + lane * 16;
+    };
+    auto ld = [&](int j) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) stg[i] = *reinterpret_cast<const u32x4*>(p1 + i * 1024);
-#pragma unroll
-      for (int i = 0; i < 18; ++i) stg[8 + i] = *reinterpret_cast<const u32x4*>(p2 + i * 1024);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) stg[26 + i] = *reinterpret_cast<const u32x4*>(p3 + i * 1024);
+      for (int i = 0; i < PPW; ++i) stg[i] = *reinterpret_cast<const u32x4*>(src_of(j, p0 + i));
     };
     auto wr = [&](int j) {
-      unsigned char* q1 = smem + OFF_W1 + (j & 1) * W1_BYTES + lane * 16;
-      unsigned char* q2 = smem + OFF_W2 + ((j + 1) & 1) * W2_BYTES + lane * 16;
-      unsigned char* q3 = smem + OFF_W3 + ((j + 1) & 1) * W3_BYTES + lane * 16;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(q1 + i * 1024) = stg[i];
-#pragma unroll
-      for (int i = 0; i < 18; ++i) *reinterpret_cast<u32x4*>(q2 + i * 1024) = stg[8 + i];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) *reinterpret_cast<u32x4*>(q3 + i * 1024) = stg[26 + i];
+      for (int i = 0; i < PPW; ++i) *reinterpret_cast<u32x4*>(dst_of(j, p0 + i)) = stg[i];
     };
     ld(-2);
     wr(-2);                               // W1(0) for the prologue interval
@@ -200,35 +205,23 @@ __global__ __launch_bounds__(512) void stage1_block_kernel(const bf16* __restric
     s1_bar_lds();
 #pragma unroll 1
     for (int k = -1; k <= k_end; ++k) {
-#ifdef S1_CLK
-      ckl = __builtin_readcyclecounter();
-#endif
       wr(k);
-#ifdef S1_CLK
-      ckB += __builtin_readcyclecounter() - ckl;
-#endif
       ld(k + 1);
-#ifdef S1_CLK
-      ckW += __builtin_readcyclecounter() - ckl;
-#endif
       s1_bar_lds();
     }
-#ifdef S1_CLK
-    if (lane == 0 && blockIdx.x == 0) printf("[stage1 weight wave] written after %lld, loads issued after %lld (sums over %d intervals)\n", ckB, ckW, k_end + 2);
-#endif
     return;
   }
 
-  // ================================================================ compute waves: token tiles 2w, 2w+1
-  const int mt0 = 2 * w;
-  // conv1 B fragments of the wave's two token tiles (all of K = 128), straight from global memory: lane = (token lrow, 8 channels (4 kc + lq) * 8 ..)
-  u32x4 xr[2][4];
+  // ================================================================ compute waves: token tiles MT w .. MT w + MT - 1
+  const int mt0 = MT * w;
+  // conv1 B fragments of the wave's token tiles (all of K = 128), straight from global memory: lane = (token lrow, 8 channels (4 kc + lq) * 8 ..)
+  u32x4 xr[MT][4];
   auto load_x = [&](int tile) {
     int b = first + tile * stride;
     b = b < n_img ? b : (first < n_img ? first : 0);              // past the end: any valid image (the result is never stored)
     const bf16* xin = x + (size_t)b * 400 * C1;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MT; ++m) {
       const int tk = (mt0 + m) * 16 + lrow;
       const int gt = tk < OT ? r0 * W + tk : hrow * W + (tk - OT);      // image token
 #pragma unroll
@@ -237,15 +230,15 @@ __global__ __launch_bounds__(512) void stage1_block_kernel(const bf16* __restric
     }
   };
   load_x(0);
-  int hoff[2];                                         // P2: byte offset (in an H1 buffer) of the top-left tap pixel of this lane's output token, plane lq
+  int hoff[MT];                                        // P2: byte offset (in an H1 buffer) of the top-left tap pixel of this lane's output token, plane lq
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
+  for (int m = 0; m < MT; ++m) {
     int tk = (mt0 + m) * 16 + lrow; tk = tk < OT ? tk : OT - 1;      // padded output rows recompute token 199 (ignored later)
     hoff[m] = lq * H1_PLANE + ((tk / W) * PW + tk % W) * 16;
   }
-  int h1off[2];                                        // P1: byte offset this lane's conv1 token is stored to (tile nt adds 2 planes)
+  int h1off[MT];                                       // P1: byte offset this lane's conv1 token is stored to (tile nt adds 2 planes)
 #pragma unroll
-  for (int m = 0; m < 2; ++m) {
+  for (int m = 0; m < MT; ++m) {
     const int tk = (mt0 + m) * 16 + lrow;
     const int pr = tk / W, pc = tk - pr * W;
     const int hr = pr < 10 ? pr + 1 : (hsel ? 0 : 11);              // H1 rows 1..10 = the output rows; the halo row above (lower half) / below them
@@ -253,21 +246,18 @@ __global__ __launch_bounds__(512) void stage1_block_kernel(const bf16* __restric
     h1off[m] = (lq >> 1) * H1_PLANE + pix * 16 + (lq & 1) * 8;
   }
   // residual: y = x + ...  The output accumulators start as E_p . X^T, E_p[r][k] = (k == 16 p + r): an exact copy of the wave's own x fragments
-  // into the accumulator layout (channel 16 n + r <- chunk n >> 1, k = 16 (n & 1) + r), 16 MFMAs per tile instead of an LDS copy of x.
-  u32x4 eye[2];
-  {
-    const unsigned one = (unsigned)__builtin_bit_cast(unsigned short, (bf16)1.0f) << (16 * (lrow & 1));
+  // into the accumulator layout (channel 16 n + r <- chunk n >> 1, k = 16 (n & 1) + r), 8 MFMAs per tile instead of an LDS copy of x.
+  const unsigned eye_one = (unsigned)__builtin_bit_cast(unsigned short, (bf16)1.0f) << (16 * (lrow & 1));
+  auto eye = [&](int p) {
+    u32x4 e = {0u, 0u, 0u, 0u};
+    if (lq == 2 * p + (lrow >> 3)) e[(lrow & 7) >> 1] = eye_one;
+    return e;
+  };
+  f32x4 acc[MT][8], a2[MT][2];
+  u32x4 pb[MT];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      eye[p] = u32x4{0u, 0u, 0u, 0u};
-      if (lq == 2 * p + (lrow >> 3)) eye[p][(lrow & 7) >> 1] = one;
-    }
-  }
-  f32x4 acc[2][8], a2[2][2];
-  u32x4 pbq[2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    pbq[m] = u32x4{0u, 0u, 0u, 0u};
+  for (int m = 0; m < MT; ++m) {
+    pb[m] = u32x4{0u, 0u, 0u, 0u};
     a2[m][0] = a2[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -287,120 +277,81 @@ __global__ __launch_bounds__(512) void stage1_block_kernel(const bf16* __restric
     unsigned char* const H1w = smem + OFF_H1 + (par ^ 1) * H1_BYTES;
     const float* const bias = B1s + ((k + 1) & (G - 1)) * CG + lq * 4;
 
-    // ---- the interval as 68 pinned steps: MFMA i, the fragment reads of MFMA i + LEAD, and a slice of the two GELU passes.  (Left to itself - and
-    // with sched_group_barrier patterns too - hipcc issues the MFMAs first and the ~400 VALU after them; the two waves of a SIMD pass the same barrier,
-    // so their MFMA blocks collide and their VALU blocks collide: measured 5-7k cycles of own work per wave and interval.)
-    //   MFMA  0..15  P1(k+1): a1[m][nt] += W1[kc][nt] . x[m][kc]          i = 4 kc + 2 m + nt
-    //   MFMA 16..51  P2(k):   a2n[m][nt] += W2[tap][nt] . H1[tap][m]      i = 16 + 4 tap + 2 m + nt
-    //   MFMA 52..67  P3(k-2): acc[m][n] += W3[n] . pbq[m]                 i = 52 + 2 n + m
-    //   GELU eval e after MFMA 2e: e < 16 of a2 (P2(k-1), -> pbn), e >= 16 of a1 + bias (-> H1[(k+1) & 1])
-    f32x4 a1[2][2], a2n[2][2];
+    // ---- the interval as 34 MT pinned steps: MFMA i, the fragment reads of MFMA i + LEAD, and a slice of the two GELU passes.  (Left to itself - and
+    // with sched_group_barrier patterns too - hipcc issues the MFMAs first and the VALU after them; the waves of a SIMD pass the same barrier, so
+    // their MFMA blocks collide and their VALU blocks collide.)  With S = 2 MT:
+    //   MFMA        0 ..  4S-1  P3(k-2): acc[m][n] += W3[n] . pb[m]                  i = MT n + m
+    //   MFMA       4S ..  8S-1  P1(k+1): a1[m][nt] += W1[kc][nt] . x[m][kc]          i = 4S + S kc + 2 m + nt
+    //   MFMA       8S .. 17S-1  P2(k):   a2[m][nt] += W2[tap][nt] . H1[tap][m]       i = 8S + S tap + 2 m + nt
+    //   GELU: one value per step - steps 4S .. 8S-1: a2 (= P2(k-1)) -> pb, dead as P3's operand by then and P2(k) restarts a2 only at step 8S;
+    //         steps 8S .. 12S-1: a1 + bias -> H1[(k+1) & 1]
+    constexpr int S = 2 * MT;
+    f32x4 a1[MT][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      a1[m][0] = a1[m][1] = a2n[m][0] = a2n[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; ++m)
       asm volatile("" : "+v"(a2[m][0]), "+v"(a2[m][1]));      // opaque: keeps hipcc from computing GELU(a2) at the end of the previous interval
-    }
-    u32x4 f1[4][2], f2w[9][2], f2h[9][2], f3[8];
+    u32x4 f1[4][2], f2w[9][2], f2h[9][MT], f3[8];
     f32x4 bv[2];
-    float ga[2][8];                                      // GELU'd a2, [m][4 nt + e]
-    float gb[4];
-    u32x4 pbn[2];
+    float ga[2];
+    unsigned hb[2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto reads_of = [&](auto ic) {                        // the fragment reads first used by MFMA I
       constexpr int I = decltype(ic)::value;
-      if constexpr (I < 16) {
-        if constexpr ((I & 2) == 0) f1[I >> 2][I & 1] = *reinterpret_cast<const u32x4*>(W1r + (I >> 2) * 2048 + (I & 1) * 256);
-      } else if constexpr (I < 52) {
-        constexpr int J = I - 16, TAP = J >> 2, R = J & 3, TOFF = ((TAP / 3) * PW + TAP % 3) * 16;
-        if constexpr (R == 0) {
-          f2w[TAP][0] = *reinterpret_cast<const u32x4*>(W2r + TAP * 2048);
-          f2h[TAP][0] = *reinterpret_cast<const u32x4*>(H1r + hoff[0] + TOFF);
-        } else if constexpr (R == 1) {
-          f2w[TAP][1] = *reinterpret_cast<const u32x4*>(W2r + TAP * 2048 + 256);
-        } else if constexpr (R == 2) {
-          f2h[TAP][1] = *reinterpret_cast<const u32x4*>(H1r + hoff[1] + TOFF);
-        }
-      } else if constexpr (I < 68) {
-        if constexpr (((I - 52) & 1) == 0) f3[(I - 52) >> 1] = *reinterpret_cast<const u32x4*>(W3r + ((I - 52) >> 1) * 256);
+      if constexpr (I < 4 * S) {
+        if constexpr (I % MT == 0) f3[I / MT] = *reinterpret_cast<const u32x4*>(W3r + (I / MT) * 256);
+      } else if constexpr (I < 8 * S) {
+        constexpr int J = I - 4 * S;
+        if constexpr (J % S < 2) f1[J / S][J % S] = *reinterpret_cast<const u32x4*>(W1r + (J / S) * 2048 + (J % S) * 256);
+      } else if constexpr (I < 17 * S) {
+        constexpr int J = I - 8 * S, TAP = J / S, R = J % S, TOFF = ((TAP / 3) * PW + TAP % 3) * 16;
+        if constexpr (R < 2) f2w[TAP][R] = *reinterpret_cast<const u32x4*>(W2r + TAP * 2048 + R * 256);
+        if constexpr ((R & 1) == 0) f2h[TAP][R >> 1] = *reinterpret_cast<const u32x4*>(H1r + hoff[R >> 1] + TOFF);
       }
-      if constexpr (I == 30) { bv[0] = *reinterpret_cast<const f32x4*>(bias); bv[1] = *reinterpret_cast<const f32x4*>(bias + 16); }
+      if constexpr (I == 8 * S) bv[0] = *reinterpret_cast<const f32x4*>(bias);
+      if constexpr (I == 10 * S) bv[1] = *reinterpret_cast<const f32x4*>(bias + 16);
     };
     static_for<S1_LEAD>([&](auto ic) { reads_of(ic); });
     __builtin_amdgcn_sched_barrier(0);
-    static_for<68>([&](auto ic) {
+    static_for<NSTEP>([&](auto ic) {
       constexpr int I = decltype(ic)::value;
-      if constexpr (I < 16) {
-        constexpr int KC = I >> 2, M = (I >> 1) & 1, NT = I & 1;
-        a1[M][NT] = mma_chunk<bf16>(f1[KC][NT], xr[M][KC], a1[M][NT]);
-      } else if constexpr (I < 52) {
-        constexpr int J = I - 16, TAP = J >> 2, M = (J >> 1) & 1, NT = J & 1;
-        a2n[M][NT] = mma_chunk<bf16>(f2w[TAP][NT], f2h[TAP][M], a2n[M][NT]);
+      if constexpr (I < 4 * S) {
+        constexpr int N = I / MT, M = I % MT;
+        acc[M][N] = mma_chunk<bf16>(f3[N], pb[M], acc[M][N]);
+      } else if constexpr (I < 8 * S) {
+        constexpr int J = I - 4 * S, KC = J / S, M = (J % S) >> 1, NT = J & 1;
+        a1[M][NT] = mma_chunk<bf16>(f1[KC][NT], xr[M][KC], KC == 0 ? zero4 : a1[M][NT]);
       } else {
-        constexpr int J = I - 52, N = J >> 1, M = J & 1;
-        acc[M][N] = mma_chunk<bf16>(f3[N], pbq[M], acc[M][N]);
+        constexpr int J = I - 8 * S, TAP = J / S, M = (J % S) >> 1, NT = J & 1;
+        a2[M][NT] = mma_chunk<bf16>(f2w[TAP][NT], f2h[TAP][M], TAP == 0 ? zero4 : a2[M][NT]);
       }
       reads_of(std::integral_constant<int, I + S1_LEAD>{});
-#ifdef S1_SCALAR_GELU
-      if constexpr ((I & 1) == 0 && I < 64) {
-        constexpr int E = I >> 1;
-        if constexpr (E < 16) {                           // a2 of the previous interval: m = E / 8, tile nt = (E / 4) & 1, element E & 3
-          constexpr int M = E >> 3, Q = E & 7;
-          ga[M][Q] = S1_GELU(a2[M][Q >> 2][Q & 3]);
-          asm volatile("" : "+v"(ga[M][Q]));             // pinned here: LLVM's sink pass would move the whole pass to the block that uses pbn (the loop latch)
-          if constexpr (Q == 7) {
-            const bf16x8 o = {(bf16)ga[M][0], (bf16)ga[M][1], (bf16)ga[M][2], (bf16)ga[M][3], (bf16)ga[M][4], (bf16)ga[M][5], (bf16)ga[M][6], (bf16)ga[M][7]};
-            pbn[M] = __builtin_bit_cast(u32x4, o);
-            asm volatile("" : "+v"(pbn[M]));
-          }
-        } else {                                          // a1 + bias: tile nt = (E - 16) / 8, m = ((E - 16) / 4) & 1, element E & 3
-          constexpr int D = E - 16, NT = D >> 3, M = (D >> 2) & 1, EL = D & 3;
-          gb[EL] = S1_GELU(a1[M][NT][EL] + bv[NT][EL]);
-          if constexpr (EL == 3) {
-            const bf16x4 o = {(bf16)gb[0], (bf16)gb[1], (bf16)gb[2], (bf16)gb[3]};
-            *reinterpret_cast<bf16x4*>(H1w + NT * 2 * H1_PLANE + h1off[M]) = o;
-          }
+      if constexpr (I >= 4 * S && I < 8 * S) {            // a2 of the previous interval: m = E / 8, tile nt = (E / 4) & 1, element E & 3
+        constexpr int E = I - 4 * S, M = E >> 3, Q = E & 7;
+        ga[Q & 1] = S1_GELU(a2[M][Q >> 2][Q & 3]);
+        asm volatile("" : "+v"(ga[Q & 1]));              // pinned here: LLVM's sink pass would move the whole pass to the block that uses pb (the loop latch)
+        if constexpr (Q & 1) {
+          const bf16x2 o = {(bf16)ga[0], (bf16)ga[1]};
+          pb[M][Q >> 1] = __builtin_bit_cast(unsigned, o);
+          asm volatile("" : "+v"(pb[M][Q >> 1]));
         }
-      }
-#else
-      // packed GELU on value pairs (a wave issues one VALU instruction per ~6 cycles whatever its width - tools/probes/valu_rates.hip - so the
-      // v_pk_* forms halve the issue slots of the arithmetic): unit U after MFMA 4 U + 1
-      if constexpr ((I & 3) == 1 && I < 64) {
-        constexpr int U = I >> 2;
-        if constexpr (U < 8) {                            // a2 of the previous interval: m = U / 4, elements 2 (U & 3), +1 of the 8 (tile nt = element / 4)
-          constexpr int M = U >> 2, Q = 2 * (U & 3);
-          f32x2 g = S1_GELU2((f32x2{a2[M][Q >> 2][Q & 3], a2[M][Q >> 2][(Q & 3) + 1]}));
-          asm volatile("" : "+v"(g));                    // pinned here: LLVM's sink pass would move the whole pass to the block that uses pbn (the loop latch)
-          ga[M][Q] = g[0]; ga[M][Q + 1] = g[1];
-          if constexpr (Q == 6) {
-            const bf16x8 o = {(bf16)ga[M][0], (bf16)ga[M][1], (bf16)ga[M][2], (bf16)ga[M][3], (bf16)ga[M][4], (bf16)ga[M][5], (bf16)ga[M][6], (bf16)ga[M][7]};
-            pbn[M] = __builtin_bit_cast(u32x4, o);
-            asm volatile("" : "+v"(pbn[M]));
-          }
-        } else {                                          // a1 + bias: tile nt = (U - 8) / 4, m = ((U - 8) / 2) & 1, elements 2 (U & 1), +1
-          constexpr int D = U - 8, NT = D >> 2, M = (D >> 1) & 1, EL = 2 * (D & 1);
-          const f32x2 g = S1_GELU2((f32x2{a1[M][NT][EL] + bv[NT][EL], a1[M][NT][EL + 1] + bv[NT][EL + 1]}));
-          gb[EL] = g[0]; gb[EL + 1] = g[1];
-          if constexpr (EL == 2) {
-            const bf16x4 o = {(bf16)gb[0], (bf16)gb[1], (bf16)gb[2], (bf16)gb[3]};
-            *reinterpret_cast<bf16x4*>(H1w + NT * 2 * H1_PLANE + h1off[M]) = o;
-          }
+      } else if constexpr (I >= 8 * S && I < 12 * S) {    // a1 + bias: tile nt = D / (4 MT), m = (D / 4) % MT, element D & 3
+        constexpr int D = I - 8 * S, NT = D / (4 * MT), M = (D >> 2) % MT, EL = D & 3;
+        ga[EL & 1] = S1_GELU(a1[M][NT][EL] + bv[NT][EL]);
+        if constexpr (EL & 1) {
+          const bf16x2 o = {(bf16)ga[0], (bf16)ga[1]};
+          hb[EL >> 1] = __builtin_bit_cast(unsigned, o);
         }
+        if constexpr (EL == 3) *reinterpret_cast<u32x2*>(H1w + NT * 2 * H1_PLANE + h1off[M]) = u32x2{hb[0], hb[1]};
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);
     });
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      pbq[m] = pbn[m];
-      a2[m][0] = a2n[m][0];
-      a2[m][1] = a2n[m][1];
-    }
 
     if ((k & 7) == 1) {                   // P3 of a tile's last group is in: store it (k > 1), seed the accumulators of the current tile with its residual
       if (k > 1) {
         const int b = first + ((k - 2) >> 3) * stride;
         bf16* yout = y + ((size_t)b * 400 + r0 * W) * C1 + lq * 4;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < MT; ++m) {
           const int tk = (mt0 + m) * 16 + lrow;
           if (tk < OT) {
 #pragma unroll
@@ -408,10 +359,11 @@ __global__ __launch_bounds__(512) void stage1_block_kernel(const bf16* __restric
           }
         }
       }
+      const u32x4 e0 = eye(0), e1 = eye(1);
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 8; ++n) acc[m][n] = mma_chunk<bf16>(eye[n & 1], xr[m][n >> 1], f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int n = 0; n < 8; ++n) acc[m][n] = mma_chunk<bf16>((n & 1) ? e1 : e0, xr[m][n >> 1], zero4);
     }
     if ((k & 7) == 6) load_x((k >> 3) + 1);        // P1 of this tile's last group has consumed xr: the next tile's tokens (one interval in flight)
 #ifdef S1_CLK
