@@ -793,6 +793,21 @@ extern "C" int fsvit_stage1_block(const void* x, void* y, const void* w1, const 
   return 0;
 }
 
+extern "C" int fsvit_conv3x3_wgrad(const void* x, const void* dz, float* dw, int B, int H, int W, int O, int Ig, int groups, int dtype, void* stream) {
+  const int kdt = dtype;
+  if (!x || !dz || !dw) return fail(FSVIT_ERR_ARG, "null argument");
+  if (dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "fsvit_conv3x3_wgrad: 16-bit storage only (bf16 / f16)");
+  if (!K(wgrad3x3_supported)(1, O, Ig, groups, W)) return fail(FSVIT_ERR_ARG, "fsvit_conv3x3_wgrad: built for 8 groups of 32 -> 32 channels (W <= 20) and dense 64 / 128 -> 128 (W <= 40)");
+  hipStream_t st = (hipStream_t)stream;
+  void* scratch = nullptr;
+  HIP_TRY(hipMalloc(&scratch, K(wgrad3x3_scratch_bytes)(O, Ig, groups, B * H * W)));
+  int rc = K(launch_wgrad3x3)(x, groups * Ig, dz, O, dw, (float*)scratch, B, H, W, O, Ig, groups, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(scratch);
+  if (rc != 0) return hipfail((hipError_t)rc, "fsvit_conv3x3_wgrad");
+  return 0;
+}
+
 extern "C" int fsvit_mlp_rows(const void* x, void* y, const void* w1, int k1w, const float* b1, const void* w2, int k2w, const float* b2,
                               int M, int C, int hid, void* stream) {
   return fsvit_proj_mlp_rows(x, y, nullptr, nullptr, 0, 0, w1, k1w, b1, w2, k2w, b2, M, C, hid, stream);

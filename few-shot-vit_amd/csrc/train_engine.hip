@@ -164,6 +164,15 @@ int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W
   const int rows = c.groups * c.rows_fwd();                                     // all output channels (padded)
   const int Cin_tot = c.via_patches ? 32 : c.groups * (c.kpad_cols() / (c.KH * c.KW));
   const int Kc_pad = c.via_patches ? 32 : round_up(c.KH * c.KW * Cin_tot, 4);
+  if (!c.via_patches && c.KH == 3 && c.KW == 3 && c.stride == 1 && c.pad == 1 && wgrad3x3_supported(t->dtype, c.O, c.Ig, c.groups, W)) {
+    // direct kernel: no transposed copies of dz / im2col(x) (wgrad3x3.hip)
+    const size_t tmp_mark = t->tmp.off;
+    float* scratch = (float*)t->tmp.take(wgrad3x3_scratch_bytes(c.O, c.Ig, c.groups, M));
+    if (!scratch) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (wgrad3x3)");
+    T_RUN(launch_wgrad3x3(x, Cin_tot, dz, rows, w->grad, scratch, B, H, W, c.O, c.Ig, c.groups, t->st));
+    t->tmp.off = tmp_mark;
+    return 0;
+  }
   const int tiles = ((rows + 127) / 128) * ((Kc_pad + 127) / 128);
   int splits = (1024 + tiles - 1) / tiles;
   if (splits > 64) splits = 64;

@@ -1,0 +1,227 @@
+// Weight gradient of the 3x3 / stride 1 / pad 1 convolutions of the meta-tuning step (stem conv2 / conv3, the grouped stage-1 conv2;
+// the reference gets it from autograd: meta_tuning_sun_m/train_meta.py:228-232 loss.backward() through visformer.py:209-237, :152-163):
+//     dW[o][i][ky][kx] = sum_m dz[m][o] * x[pix(m) + (ky-1, kx-1)][i]            m = (b, oy, ox), zero outside the image
+// computed directly from the NHWC activations.  Round 1 fed a split-K GEMM with TRANSPOSED operands: dz^T [N][M] and a transposed
+// im2col [9 C][M] written to HBM first (profiles/r02_train_kernel_stats.csv: im2col_t 4.75 ms + transposes 1.6 ms of a 34.5 ms step, and
+// the grouped conv ran as a dense GEMM with 8 x the useful flops).  The contraction index of this product is the ROW index of both
+// operands, i.e. both MFMA fragments want 8 consecutive rows of one column: that is what gfx950's ds_read_b64_tr_b16 delivers from a
+// row-major LDS tile (tools/probes/tr_read_probe.hip: within a 16-lane group lane i supplies the address of 4 contiguous columns
+// 4 (i & 3) .. of row i >> 2 and receives rows 0..3 of column i).  So:
+//   * a workgroup (8 waves) stages 64 rows of dz and the matching window of x pixels (64 + 2 (W + 1), so that every tap's shifted row is
+//     present) in LDS as [16-column subtile][row][32 B] - the conflict-free image for the transposing read - through registers, the next
+//     chunk's global loads in flight while the current one is multiplied;
+//   * wave j owns one (32 output channels) x (32 input channels) x 9 taps block = 36 accumulator tiles (144 VGPRs): a group of the grouped
+//     conv, or an (n-block, c-block) pair of a dense one; per 32 rows: 4 transposing reads for dz, 4 per tap for x, 36 MFMAs;
+//   * a tap is an ADDRESS: the lane that supplies row r's address adds the tap's pixel shift, or points at a zero chunk when the tap
+//     leaves the image - no im2col, no padded copy;
+//   * split over row chunks across workgroups: fp32 partials [split][job][tap][32][32], summed in fixed order by wgrad3x3_finalize_kernel
+//     into the PyTorch weight layout (deterministic, like the round-1 path).
+#include <stdlib.h>
+
+#include "fsvit_common.h"
+#include "kernels.h"
+
+namespace FSVIT_NS {
+
+namespace wg3 {
+constexpr int NW = 8;            // waves = (n-block, c-block) jobs per workgroup
+constexpr int CH = 64;           // rows per stage = 2 MFMA K steps
+constexpr int JOB = 9 * 32 * 32; // fp32 partials per job
+typedef short s4 __attribute__((ext_vector_type(4)));
+}  // namespace wg3
+
+// NC / CC: dz / x columns staged per workgroup.  (256, 256): grouped conv, wave j = group j.  (128, 64): dense conv, wave j = n-block j & 3,
+// c-block j >> 2 of the 64 input channels blockIdx.y * 64 ..
+template <int NC, int CC, int MAXW>
+__global__ __launch_bounds__(512) void wgrad3x3_kernel(const bf16* __restrict__ x, int xld, const bf16* __restrict__ dz, int zld, float* __restrict__ part,
+                                                       int M, int H, int W, int n_chunks, int chunks_per_wg) {
+  using namespace wg3;
+  constexpr int WINP = CH + 2 * (MAXW + 1) + 2;               // pixels of the x window (W <= MAXW), rounded up
+  constexpr int ZT_BYTES = (NC / 16) * CH * 32;
+  constexpr int XW_BYTES = (CC / 16) * WINP * 32;
+  constexpr int NPZ = (CH * NC / 8) / 512;                     // 16-byte units of dz per thread and chunk
+  constexpr int NPX = (WINP * (CC / 8) + 511) / 512;           // of the x window
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const ZT = smem;
+  unsigned char* const XW = smem + ZT_BYTES;
+  unsigned char* const ZERO = smem + ZT_BYTES + XW_BYTES;      // a zero row (32 B) here and another one subtile pitch further (the c-tile offset is an immediate)
+
+  const int t = threadIdx.x, lane = t & 63, i = lane & 15, lq = lane >> 4;
+  const int j = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nb = NC == 256 ? j : (j & 3), cb = NC == 256 ? j : (j >> 2);
+  const int xc0 = NC == 256 ? 0 : blockIdx.y * CC;
+  const int halo = W + 1, winp = CH + 2 * halo;                // pixels actually used (<= WINP)
+  const int q0 = blockIdx.x * chunks_per_wg;
+  int q1 = q0 + chunks_per_wg; q1 = q1 < n_chunks ? q1 : n_chunks;
+
+  if (t < 8) { reinterpret_cast<unsigned*>(ZERO)[t] = 0u; reinterpret_cast<unsigned*>(ZERO + WINP * 32)[t] = 0u; }   // one zero row (32 B) each
+
+  u32x4 pz[NPZ], px[NPX];
+  auto gload = [&](int q) {                                    // chunk q -> registers
+    const long m0 = (long)q * CH;
+#pragma unroll
+    for (int u0 = 0; u0 < NPZ; ++u0) {
+      const int u = t + 512 * u0, r = u / (NC / 8), c8 = u % (NC / 8);
+      const long m = m0 + r;
+      pz[u0] = m < M ? *reinterpret_cast<const u32x4*>(dz + (size_t)m * zld + c8 * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < NPX; ++u0) {
+      const int u = t + 512 * u0, p = u / (CC / 8), c8 = u % (CC / 8);
+      const long m = m0 - halo + p;
+      px[u0] = (p < winp && m >= 0 && m < M) ? *reinterpret_cast<const u32x4*>(x + (size_t)m * xld + xc0 + c8 * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto lstore = [&]() {                                        // registers -> the subtile images
+#pragma unroll
+    for (int u0 = 0; u0 < NPZ; ++u0) {
+      const int u = t + 512 * u0, r = u / (NC / 8), c8 = u % (NC / 8);
+      *reinterpret_cast<u32x4*>(ZT + (c8 >> 1) * (CH * 32) + r * 32 + (c8 & 1) * 16) = pz[u0];
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < NPX; ++u0) {
+      const int u = t + 512 * u0, p = u / (CC / 8), c8 = u % (CC / 8);
+      if (p < WINP) *reinterpret_cast<u32x4*>(XW + (c8 >> 1) * (WINP * 32) + p * 32 + (c8 & 1) * 16) = px[u0];
+    }
+  };
+
+  f32x4 acc[9][2][2];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[tp][a >> 1][a & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned zt_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ZT + (nb * 2) * (CH * 32) + (lq * 4 + (i >> 2)) * 32 + (i & 3) * 8;
+  const unsigned xw_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)XW + (cb * 2) * (WINP * 32) + (i & 3) * 8;
+  const unsigned zero_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ZERO + (i & 3) * 8;
+  auto tr = [&](unsigned addr) -> u32x2 {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(size_t)addr));
+  };
+  const int HW = H * W;
+
+  if (q0 < q1) gload(q0);
+  for (int q = q0; q < q1; ++q) {
+    __syncthreads();                                            // the previous chunk's fragment reads are done
+    lstore();
+    __syncthreads();
+    if (q + 1 < q1) gload(q + 1);
+    const long m0 = (long)q * CH;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // dz^T fragments: rows (= K slots) ks*32 + h*16 + lq*4 + 0..3, column 16 nt + i
+      u32x4 af[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const u32x2 r1 = tr(zt_lane + nt * (CH * 32) + ks * 1024), r2 = tr(zt_lane + nt * (CH * 32) + ks * 1024 + 512);
+        af[nt] = u32x4{r1[0], r1[1], r2[0], r2[1]};
+      }
+      // this lane SUPPLIES the addresses of rows ks*32 + h*16 + lq*4 + (i >> 2), h = 0, 1
+      int oy[2], ox[2];
+      unsigned rowa[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int rr = ks * 32 + h * 16 + lq * 4 + (i >> 2);
+        const int m = (int)m0 + rr;
+        const int rem = m % HW;
+        oy[h] = rem / W; ox[h] = rem - oy[h] * W;
+        if (m >= M) oy[h] = -4;                                 // rows past the end: every tap invalid (their dz rows are zero anyway)
+        rowa[h] = xw_lane + (rr + halo) * 32;
+      }
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int dy = tp / 3 - 1, dx = tp % 3 - 1;
+        const int shift = (dy * W + dx) * 32;
+        unsigned ad[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool ok = (unsigned)(oy[h] + dy) < (unsigned)H && (unsigned)(ox[h] + dx) < (unsigned)W;
+          ad[h] = ok ? rowa[h] + shift : zero_lane;
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const u32x2 r1 = tr(ad[0] + ct * (WINP * 32)), r2 = tr(ad[1] + ct * (WINP * 32));
+          const u32x4 bf = {r1[0], r1[1], r2[0], r2[1]};
+          acc[tp][0][ct] = mma_chunk<bf16>(af[0], bf, acc[tp][0][ct]);
+          acc[tp][1][ct] = mma_chunk<bf16>(af[1], bf, acc[tp][1][ct]);
+        }
+      }
+    }
+  }
+
+  // fp32 partials of this row range: [split][job][tap][n 32][c 32]; lane holds n = 16 nt + 4 lq + e, c = 16 ct + i
+  const int job = (NC == 256 ? 0 : blockIdx.y * NW) + j, njobs = (NC == 256 ? 1 : gridDim.y) * NW;
+  float* out = part + ((size_t)blockIdx.x * njobs + job) * JOB;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[(tp * 32 + nt * 16 + lq * 4 + e) * 32 + ct * 16 + i] = acc[tp][nt][ct][e];
+}
+
+// dW[o][ig][ky][kx] (PyTorch layout, overwrite) = sum over splits, in split order.  One thread per partial element in PARTIAL order (c fastest: the
+// reads of a wave are contiguous 128-byte rows, split after split); the 4-byte scatter into the weight layout is 74 k .. 147 k stores per layer.
+// grouped: o = 32 job + n, ig = c;  dense: job = (ig / 64) * 8 + (ig % 64 / 32) * 4 + o / 32
+__global__ __launch_bounds__(256) void wgrad3x3_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw, int O, int Ig, int grouped, int njobs,
+                                                                int splits) {
+  const int total = njobs * wg3::JOB;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int c = idx & 31, n = (idx >> 5) & 31, tp = (idx >> 10) % 9, job = idx / wg3::JOB;
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += part[(size_t)sp * total + idx];
+    const int o = grouped ? job * 32 + n : (job & 3) * 32 + n;
+    const int ig = grouped ? c : (job >> 3) * 64 + ((job >> 2) & 1) * 32 + c;
+    dw[((size_t)o * Ig + ig) * 9 + tp] = s;
+  }
+}
+
+// Supported: 3x3 / stride 1 / pad 1, 16-bit storage; grouped with 32 -> 32 channels per group and 8 groups, or dense with 128 output
+// channels and 64 / 128 input channels.
+bool wgrad3x3_supported(int dtype, int O, int Ig, int groups, int W) {
+  static const bool off = [] { const char* e = getenv("FSVIT_WGRAD3X3"); return e && e[0] == '0'; }();
+  if (off || dtype != 1) return false;
+  if (groups == 8) return O == 256 && Ig == 32 && W <= 20;
+  return groups == 1 && O == 128 && (Ig == 64 || Ig == 128) && W <= 40;
+}
+static int wgrad3x3_plan(int O, int Ig, int groups, int M, int* splits, int* cpw, int* njobs) {
+  const int n_chunks = (M + wg3::CH - 1) / wg3::CH;
+  const int gy = groups == 8 ? 1 : Ig / 64;
+  int s = 256 / gy;                     // one workgroup per CU: fewer partials to write and sum
+  if (s > n_chunks) s = n_chunks;
+  *cpw = (n_chunks + s - 1) / s;
+  *splits = (n_chunks + *cpw - 1) / *cpw;
+  *njobs = gy * wg3::NW;
+  return n_chunks;
+}
+size_t wgrad3x3_scratch_bytes(int O, int Ig, int groups, int M) {
+  int splits, cpw, njobs;
+  wgrad3x3_plan(O, Ig, groups, M, &splits, &cpw, &njobs);
+  return (size_t)splits * njobs * wg3::JOB * sizeof(float);
+}
+int launch_wgrad3x3(const void* x, int xld, const void* dz, int zld, float* dw, float* scratch, int B, int H, int W, int O, int Ig, int groups, hipStream_t s) {
+  const int M = B * H * W;
+  int splits, cpw, njobs;
+  const int n_chunks = wgrad3x3_plan(O, Ig, groups, M, &splits, &cpw, &njobs);
+  if (groups == 8) {
+    constexpr int WINP = wg3::CH + 2 * 21 + 2, lds = (256 / 16) * wg3::CH * 32 + (256 / 16) * WINP * 32 + WINP * 32 + 32;
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_kernel<256, 256, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+      attr = true;
+    }
+    hipLaunchKernelGGL((wgrad3x3_kernel<256, 256, 20>), dim3(splits), dim3(512), lds, s, (const bf16*)x, xld, (const bf16*)dz, zld, scratch, M, H, W, n_chunks, cpw);
+  } else {
+    constexpr int WINP = wg3::CH + 2 * 41 + 2, lds = (128 / 16) * wg3::CH * 32 + (64 / 16) * WINP * 32 + WINP * 32 + 32;
+    hipLaunchKernelGGL((wgrad3x3_kernel<128, 64, 40>), dim3(splits, Ig / 64), dim3(512), lds, s, (const bf16*)x, xld, (const bf16*)dz, zld, scratch, M, H, W, n_chunks, cpw);
+  }
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  const int total = njobs * wg3::JOB;
+  hipLaunchKernelGGL(wgrad3x3_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, scratch, dw, O, Ig, groups == 8 ? 1 : 0, njobs, splits);
+  return (int)hipGetLastError();
+}
+
+}  // namespace FSVIT_NS

@@ -547,6 +547,21 @@ class ops:
         return ds, dq, dt.sum()
 
     @staticmethod
+    def conv3x3_wgrad(x_nhwc, dz, O, Ig, groups):
+        """x [B,H,W,groups*Ig], dz [B,H,W,O] (bf16 / fp16) -> dW [O,Ig,3,3] fp32 of a 3x3 / stride 1 / pad 1 convolution (fsvit_conv3x3_wgrad)."""
+        _require_cuda(x_nhwc, dz)
+        lib = _lib.load()
+        assert x_nhwc.dtype == dz.dtype and x_nhwc.dtype in (torch.bfloat16, torch.float16)
+        B, H, W, C = x_nhwc.shape
+        assert C == groups * Ig and dz.shape == (B, H, W, O)
+        x_nhwc, dz = x_nhwc.contiguous(), dz.contiguous()
+        dw = torch.empty(O, Ig, 3, 3, dtype=torch.float32, device=x_nhwc.device)
+        with torch.cuda.device(x_nhwc.device):
+            _lib.check(lib.fsvit_conv3x3_wgrad(_ptr(x_nhwc), _ptr(dz), _ptr(dw), B, H, W, O, Ig, groups,
+                                               _lib.BF16 if x_nhwc.dtype == torch.bfloat16 else _lib.F16, _stream_ptr(x_nhwc.device)))
+        return dw
+
+    @staticmethod
     def sgd_step(param, grad, buf, lr, momentum, weight_decay, first_step):
         _require_cuda(param, grad, buf)
         lib = _lib.load()

@@ -12,6 +12,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -335,3 +336,25 @@ def test_train_meta_warmup_driver(tmp_path):
     assert len(trlog['tl']) == 3 and all(np.isfinite(trlog[k]).all() for k in ('tl', 'ta', 'vl', 'va'))
     ck = torch.load(os.path.join(str(tmp_path), 'w', 'epoch-last.pth'), map_location='cpu')
     assert ck['training']['optimizer_sd']['param_groups'][0]['lr'] == pytest.approx(1e-5 + 2 * (1e-3 - 1e-5) / 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(3, 20, 20, 256, 32, 8), (2, 40, 40, 128, 64, 1), (2, 40, 40, 128, 128, 1), (5, 20, 20, 256, 32, 8), (1, 12, 16, 128, 64, 1)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_conv3x3_wgrad_direct_vs_torch(shape, dtype):
+    """fsvit_conv3x3_wgrad (transposing LDS reads, taps as addresses) vs torch's conv2d weight gradient on the same 16-bit-rounded operands
+    (fp32 accumulation on both sides: only the summation order differs)."""
+    from fewshot_vit_amd.engine import ops
+    B, H, W, O, Ig, groups = shape
+    g = torch.Generator().manual_seed(17 + B + O + Ig)
+    x = torch.randn(B, groups * Ig, H, W, generator=g).to(dtype).float()
+    dz = (torch.randn(B, O, H, W, generator=g) * 0.1).to(dtype).float()
+    wref = torch.zeros(O, Ig, 3, 3, requires_grad=True)
+    F.conv2d(x, wref, padding=1, groups=groups).backward(dz)
+    got = ops.conv3x3_wgrad(x.permute(0, 2, 3, 1).contiguous().to('cuda', dtype), dz.permute(0, 2, 3, 1).contiguous().to('cuda', dtype), O, Ig, groups).cpu()
+    ref = wref.grad
+    err = (got - ref).abs().max().item()
+    print(f'conv3x3_wgrad {shape} {dtype}: max err {err:.3e} (max |dW| {ref.abs().max():.2f})')
+    assert err <= 2e-4 * max(1.0, ref.abs().max().item())
+    # border structure: the tap that reads outside the image must contribute nothing (a wrong mask shows up on the corner taps first)
+    assert (got[:, :, 0, 0] - ref[:, :, 0, 0]).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
