@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "train_kernels.h"
 
 using namespace fsvit;
 
@@ -805,6 +806,23 @@ extern "C" int fsvit_conv3x3_wgrad(const void* x, const void* dz, float* dw, int
   (void)hipStreamSynchronize(st);
   (void)hipFree(scratch);
   if (rc != 0) return hipfail((hipError_t)rc, "fsvit_conv3x3_wgrad");
+  return 0;
+}
+
+extern "C" int fsvit_conv1x1_wgrad(const void* x, const void* dz, float* dw, int M, int N, int C, int dtype, void* stream) {
+  const int kdt = dtype;
+  if (!x || !dz || !dw || M <= 0) return fail(FSVIT_ERR_ARG, "bad argument");
+  if (dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "fsvit_conv1x1_wgrad: 16-bit storage only (bf16 / f16)");
+  if (!K(wgrad1x1_supported)(1, N, C)) return fail(FSVIT_ERR_ARG, "fsvit_conv1x1_wgrad: N and C must be multiples of 8");
+  hipStream_t st = (hipStream_t)stream;
+  const int splits = K(wgrad1x1_splits)(N, C, M), Kc_pad = (C + 3) / 4 * 4;
+  void* ysp = nullptr;
+  HIP_TRY(hipMalloc(&ysp, (size_t)((N + 3) / 4 * 4) * splits * Kc_pad * 4));
+  int rc = K(launch_wgrad1x1)(x, C, C, dz, N, N, (float*)ysp, M, Kc_pad, st);
+  if (rc == 0) rc = fsvit::launch_wgrad_finalize((const float*)ysp, dw, N, C, 1, 1, 0, splits, Kc_pad, 1, 1, 1, 1, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(ysp);
+  if (rc != 0) return hipfail((hipError_t)rc, "fsvit_conv1x1_wgrad");
   return 0;
 }
 

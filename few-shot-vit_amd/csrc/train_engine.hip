@@ -173,6 +173,18 @@ int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W
     t->tmp.off = tmp_mark;
     return 0;
   }
+  if ((c.via_patches || (c.KH == 1 && c.KW == 1 && c.stride == 1 && c.groups == 1)) && wgrad1x1_supported(t->dtype, rows, Cin_tot)) {
+    // direct kernel on the row-major operands (x [M][Cin_tot] - or the 32-wide patch rows - and dz [M][rows]); the finalize pass is the round-1 one
+    const size_t tmp_mark = t->tmp.off;
+    const int splits = wgrad1x1_splits(rows, Cin_tot, M);
+    float* ysp = (float*)t->tmp.take((size_t)round_up(rows, 4) * splits * Kc_pad * 4);
+    if (!ysp) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (wgrad1x1)");
+    T_RUN(launch_wgrad1x1(x, Cin_tot, Cin_tot, dz, rows, rows, ysp, M, Kc_pad, t->st));
+    const int KHf = c.via_patches ? 3 : c.KH, KWf = c.via_patches ? 3 : c.KW;
+    T_RUN(launch_wgrad_finalize(ysp, w->grad, c.O, c.Ig, KHf, KWf, 0, splits, Kc_pad, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols, t->st));
+    t->tmp.off = tmp_mark;
+    return 0;
+  }
   const int tiles = ((rows + 127) / 128) * ((Kc_pad + 127) / 128);
   int splits = (1024 + tiles - 1) / tiles;
   if (splits > 64) splits = 64;

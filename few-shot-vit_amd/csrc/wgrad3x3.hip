@@ -224,4 +224,124 @@ int launch_wgrad3x3(const void* x, int xld, const void* dz, int zld, float* dw, 
   return (int)hipGetLastError();
 }
 
+// ---- 1x1 convolutions (conv1 / conv3 of the Mlps, qkv, proj):  Y[n][split * Kc_pad + c] = sum_{m in split} dz[m][n] * x[m][c]
+// The same transposing-read scheme without taps: a workgroup owns a 256 (n) x 128 (c) block, its 8 waves 64 x 64 each (16 accumulator tiles);
+// per 64 rows it stages 32 + 16 KB and issues 32 MFMAs per wave.  Output is the split-K partial layout wgrad_finalize_kernel already sums (it also
+// undoes the head-dim padding of qkv rows / proj columns).
+__global__ __launch_bounds__(512) void wgrad1x1_kernel(const bf16* __restrict__ x, int xld, int C, const bf16* __restrict__ dz, int zld, int N,
+                                                       float* __restrict__ y, int M, int n_chunks, int chunks_per_wg, int splits, int Kc_pad) {
+  using namespace wg3;
+  constexpr int NT = 256, CT = 128;
+  constexpr int ZT_BYTES = (NT / 16) * CH * 32, XT_BYTES = (CT / 16) * CH * 32;
+  constexpr int NPZ = (CH * NT / 8) / 512, NPX = (CH * CT / 8) / 512;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[ZT_BYTES + XT_BYTES];
+  unsigned char* const ZT = smem;
+  unsigned char* const XT = smem + ZT_BYTES;
+  const int t = threadIdx.x, lane = t & 63, i = lane & 15, lq = lane >> 4;
+  const int j = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wn = j & 3, wc = j >> 2;                              // wave's 64-column blocks inside the tile
+  const int n0 = blockIdx.y * NT, c0 = blockIdx.z * CT;
+  const int q0 = blockIdx.x * chunks_per_wg;
+  int q1 = q0 + chunks_per_wg; q1 = q1 < n_chunks ? q1 : n_chunks;
+
+  u32x4 pz[NPZ], px[NPX];
+  auto gload = [&](int q) {
+    const long m0 = (long)q * CH;
+#pragma unroll
+    for (int u0 = 0; u0 < NPZ; ++u0) {
+      const int u = t + 512 * u0, r = u / (NT / 8), c8 = u % (NT / 8);
+      const long m = m0 + r;
+      pz[u0] = (m < M && n0 + c8 * 8 < N) ? *reinterpret_cast<const u32x4*>(dz + (size_t)m * zld + n0 + c8 * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < NPX; ++u0) {
+      const int u = t + 512 * u0, r = u / (CT / 8), c8 = u % (CT / 8);
+      const long m = m0 + r;
+      px[u0] = (m < M && c0 + c8 * 8 < C) ? *reinterpret_cast<const u32x4*>(x + (size_t)m * xld + c0 + c8 * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int u0 = 0; u0 < NPZ; ++u0) {
+      const int u = t + 512 * u0, r = u / (NT / 8), c8 = u % (NT / 8);
+      *reinterpret_cast<u32x4*>(ZT + (c8 >> 1) * (CH * 32) + r * 32 + (c8 & 1) * 16) = pz[u0];
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < NPX; ++u0) {
+      const int u = t + 512 * u0, r = u / (CT / 8), c8 = u % (CT / 8);
+      *reinterpret_cast<u32x4*>(XT + (c8 >> 1) * (CH * 32) + r * 32 + (c8 & 1) * 16) = px[u0];
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 16; ++a) acc[a >> 2][a & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned lane_off = (lq * 4 + (i >> 2)) * 32 + (i & 3) * 8;
+  const unsigned zt_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ZT + (wn * 4) * (CH * 32) + lane_off;
+  const unsigned xt_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)XT + (wc * 4) * (CH * 32) + lane_off;
+  auto tr = [&](unsigned addr) -> u32x2 {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(size_t)addr));
+  };
+
+  if (q0 < q1) gload(q0);
+  for (int q = q0; q < q1; ++q) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (q + 1 < q1) gload(q + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 af[4], bf[4];
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const u32x2 a1 = tr(zt_lane + k4 * (CH * 32) + ks * 1024), a2 = tr(zt_lane + k4 * (CH * 32) + ks * 1024 + 512);
+        af[k4] = u32x4{a1[0], a1[1], a2[0], a2[1]};
+        const u32x2 b1 = tr(xt_lane + k4 * (CH * 32) + ks * 1024), b2 = tr(xt_lane + k4 * (CH * 32) + ks * 1024 + 512);
+        bf[k4] = u32x4{b1[0], b1[1], b2[0], b2[1]};
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[nt][ct] = mma_chunk<bf16>(af[nt], bf[ct], acc[nt][ct]);
+    }
+  }
+  // partials: lane holds n = n0 + 64 wn + 16 nt + 4 lq + e, c = c0 + 64 wc + 16 ct + i
+  const size_t ldy = (size_t)splits * Kc_pad;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = n0 + wn * 64 + nt * 16 + lq * 4 + e;
+      if (n < N) {
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const int c = c0 + wc * 64 + ct * 16 + i;
+          if (c < C) y[(size_t)n * ldy + (size_t)blockIdx.x * Kc_pad + c] = acc[nt][ct][e];
+        }
+      }
+    }
+}
+
+bool wgrad1x1_supported(int dtype, int N, int C) {
+  static const bool off = [] { const char* e = getenv("FSVIT_WGRAD1X1"); return e && e[0] == '0'; }();
+  return !off && dtype == 1 && (N % 8) == 0 && (C % 8) == 0;
+}
+// number of row splits (= partial slabs of Y) the launch will use
+int wgrad1x1_splits(int N, int C, int M) {
+  const int n_chunks = (M + wg3::CH - 1) / wg3::CH;
+  const int tiles = ((N + 255) / 256) * ((C + 127) / 128);
+  int s = (512 + tiles - 1) / tiles;
+  if (s > n_chunks) s = n_chunks;
+  if (s < 1) s = 1;
+  const int cpw = (n_chunks + s - 1) / s;
+  return (n_chunks + cpw - 1) / cpw;
+}
+int launch_wgrad1x1(const void* x, int xld, int C, const void* dz, int zld, int N, float* y, int M, int Kc_pad, hipStream_t s) {
+  const int n_chunks = (M + wg3::CH - 1) / wg3::CH;
+  const int splits = wgrad1x1_splits(N, C, M);
+  const int cpw = (n_chunks + splits - 1) / splits;
+  hipLaunchKernelGGL(wgrad1x1_kernel, dim3(splits, (N + 255) / 256, (C + 127) / 128), dim3(512), 0, s, (const bf16*)x, xld, C, (const bf16*)dz, zld, N, y, M, n_chunks,
+                     cpw, splits, Kc_pad);
+  return (int)hipGetLastError();
+}
+
 }  // namespace FSVIT_NS

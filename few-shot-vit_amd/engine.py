@@ -547,6 +547,19 @@ class ops:
         return ds, dq, dt.sum()
 
     @staticmethod
+    def conv1x1_wgrad(x, dz):
+        """x [M,C], dz [M,N] (bf16 / fp16) -> dW [N,C] fp32 (fsvit_conv1x1_wgrad)."""
+        _require_cuda(x, dz)
+        lib = _lib.load()
+        assert x.dtype == dz.dtype and x.dtype in (torch.bfloat16, torch.float16) and x.shape[0] == dz.shape[0]
+        x, dz = x.contiguous(), dz.contiguous()
+        dw = torch.empty(dz.shape[1], x.shape[1], dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.fsvit_conv1x1_wgrad(_ptr(x), _ptr(dz), _ptr(dw), x.shape[0], dz.shape[1], x.shape[1],
+                                               _lib.BF16 if x.dtype == torch.bfloat16 else _lib.F16, _stream_ptr(x.device)))
+        return dw
+
+    @staticmethod
     def conv3x3_wgrad(x_nhwc, dz, O, Ig, groups):
         """x [B,H,W,groups*Ig], dz [B,H,W,O] (bf16 / fp16) -> dW [O,Ig,3,3] fp32 of a 3x3 / stride 1 / pad 1 convolution (fsvit_conv3x3_wgrad)."""
         _require_cuda(x_nhwc, dz)

@@ -279,6 +279,10 @@ int fsvit_image_transform_gather(const uint8_t* images_dev, int H, int W, const 
  * Built shapes: groups = 8 with 32 -> 32 channels per group (W <= 20); dense O = 128, Ig = 64 / 128 (W <= 40). */
 int fsvit_conv3x3_wgrad(const void* x_dev, const void* dz_dev, float* dw_dev, int B, int H, int W, int O, int Ig, int groups, int dtype, void* stream);
 
+/* Weight gradient of a 1x1 convolution / Linear from the row-major activations: dw[N][C] (fp32, overwritten) = sum_m dz[m][n] * x[m][c].
+ * x [M][C], dz [M][N], dtype FSVIT_BF16 / FSVIT_F16, N and C multiples of 8.  (conv1 / conv3 of the Mlps, qkv, proj in train_meta.py:228-232.) */
+int fsvit_conv1x1_wgrad(const void* x_dev, const void* dz_dev, float* dw_dev, int M, int N, int C, int dtype, void* stream);
+
 int fsvit_attention_backward(const void* qkv_dev, const void* dctx_dev, void* dqkv_dev, int B, int S, int heads, int hd, int hdp,
                              float scale, int dtype, void* stream);
 

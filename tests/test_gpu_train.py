@@ -358,3 +358,20 @@ def test_conv3x3_wgrad_direct_vs_torch(shape, dtype):
     assert err <= 2e-4 * max(1.0, ref.abs().max().item())
     # border structure: the tap that reads outside the image must contribute nothing (a wrong mask shows up on the corner taps first)
     assert (got[:, :, 0, 0] - ref[:, :, 0, 0]).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(8000, 1024, 256), (2000, 864, 256), (2000, 512, 576), (5000, 128, 32), (777, 256, 128), (64, 1728, 512), (130, 8, 8)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_conv1x1_wgrad_direct_vs_torch(shape, dtype):
+    """fsvit_conv1x1_wgrad vs dz^T @ x in fp32 on the same 16-bit-rounded operands (ragged M, N, C tails included)."""
+    from fewshot_vit_amd.engine import ops
+    M, N, C = shape
+    g = torch.Generator().manual_seed(M + N + C)
+    x = torch.randn(M, C, generator=g).to(dtype)
+    dz = (torch.randn(M, N, generator=g) * 0.1).to(dtype)
+    ref = dz.double().t() @ x.double()
+    got = ops.conv1x1_wgrad(x.cuda(), dz.cuda()).cpu().double()
+    err = (got - ref).abs().max().item()
+    print(f'conv1x1_wgrad {shape} {dtype}: max err {err:.3e} (max |dW| {ref.abs().max():.2f})')
+    assert err <= 2e-4 * max(1.0, ref.abs().max().item())
