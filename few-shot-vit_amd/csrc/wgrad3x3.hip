@@ -329,7 +329,7 @@ bool wgrad1x1_supported(int dtype, int N, int C) {
 int wgrad1x1_splits(int N, int C, int M) {
   const int n_chunks = (M + wg3::CH - 1) / wg3::CH;
   const int tiles = ((N + 255) / 256) * ((C + 127) / 128);
-  int s = (512 + tiles - 1) / tiles;
+  int s = (256 + tiles - 1) / tiles;           // ~one workgroup per CU: the partial slabs (N x C x 4 B per split) are written and summed once each
   if (s > n_chunks) s = n_chunks;
   if (s < 1) s = 1;
   const int cpw = (n_chunks + s - 1) / s;
