@@ -85,3 +85,40 @@ def test_vit_ops_layernorm_rows(dt):
     tok = torch.nn.functional.conv2d(x, w, b, stride=6).flatten(2).transpose(1, 2)
     ref = torch.cat([sd['encoder.cls_token'].expand(2, -1, -1), tok], 1) + sd['encoder.pos_embed']
     assert (got - ref).abs().max().item() <= (2e-5 if dt == 'f32' else 3e-2)
+
+
+def test_deit_small_full_episode_224():
+    """BASELINE configs[4] shape: one whole 5-way 5-shot episode (25 + 75 images of 224 x 224) through 'meta-baseline' with DeiT-S/16 -
+    parity mode vs the fp32 oracle on the same episode (1e-3, north star), the 16-bit modes vs parity (printed, bounded)."""
+    from fewshot_vit_amd import models, synthetic
+    from fewshot_vit_amd.utils import few_shot as fs
+    from oracle import deit_oracle as do
+    from oracle import visformer_oracle as vo
+    name = 'deit_small_patch16_224'
+    cfg = do.FACTORIES[name]
+    x = synthetic.synthetic_episodes(23, 1, 5, 5, 15, img=224)
+    xs, xq = fs.split_shot_query(x, 5, 5, 15, 1)
+    logits = {}
+    sd = None
+    for numerics in ('parity', 'f16', 'bf16'):
+        m = models.make('meta-baseline', encoder=name, encoder_args={'numerics': numerics})
+        if sd is None:
+            sd = synthetic.procedural_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            logits[numerics] = m(xs.cuda(), xq.cuda()).cpu()
+        del m
+        torch.cuda.empty_cache()
+    with torch.no_grad():
+        f = do.deit_forward(sd, torch.cat([xs.reshape(-1, 3, 224, 224), xq.reshape(-1, 3, 224, 224)]), cfg, prefix='encoder.')
+    ref = vo.meta_baseline_head(f[:25].reshape(1, 5, 5, -1), f[25:].reshape(1, 75, -1), temp=10.0)
+    e_par = (logits['parity'] - ref).abs().max().item()
+    e_f16 = (logits['f16'] - logits['parity']).abs().max().item()
+    e_bf16 = (logits['bf16'] - logits['parity']).abs().max().item()
+    agree = {k: (logits[k].argmax(-1) == ref.argmax(-1)).float().mean().item() for k in logits}
+    print(f'DeiT-S/16 full episode: parity vs oracle {e_par:.3e}; f16 vs parity {e_f16:.3e}; bf16 vs parity {e_bf16:.3e}; argmax agreement with the oracle {agree}')
+    assert logits['parity'].shape == (1, 75, 5)
+    assert e_par <= 1e-3
+    assert e_f16 <= 2e-3 and e_bf16 <= 1.2e-2            # measured 9.9e-4 / 6.1e-3 (2x)
+    assert agree['parity'] == 1.0 and agree['f16'] >= 0.97 and agree['bf16'] >= 0.9
