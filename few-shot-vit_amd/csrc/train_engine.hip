@@ -682,6 +682,13 @@ extern "C" int fsvit_attention_backward(const void* qkv, const void* dctx, void*
   return rc ? fsvit_set_error(rc, "attention_bwd") : 0;
 }
 
+extern "C" int fsvit_sgd_step_multi(const void* items_dev, int n_items, size_t max_numel, float lr, float momentum, float weight_decay, int first_step,
+                                    void* stream) {
+  if (!items_dev && n_items > 0) return fsvit_set_error(FSVIT_ERR_ARG, "fsvit_sgd_step_multi: null table");
+  int rc = launch_sgd_multi(items_dev, n_items, max_numel, lr, momentum, weight_decay, first_step, (hipStream_t)stream);
+  return rc ? fsvit_set_error(rc, "sgd_multi") : 0;
+}
+
 extern "C" int fsvit_sgd_step(float* param, const float* grad, float* momentum_buf, size_t n, float lr, float momentum, float weight_decay, int first_step,
                               void* stream) {
   if (!param || !grad || !momentum_buf) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");

@@ -37,6 +37,7 @@ int launch_fill_f32(float* p, float v, size_t n, hipStream_t s);
 int launch_scale_copy(const float* in, float* out, size_t n, float sc, hipStream_t s);
 // out[c] = sum_m a[m][c]; partial: bn_reduce_blocks(M) * 2 * C floats of scratch
 int launch_colsum(const void* a, float* partial, float* out, int M, int C, int dtype, hipStream_t s);
+int launch_sgd_multi(const void* items_dev, int n_items, size_t max_numel, float lr, float momentum, float wd, int first, hipStream_t s);
 int launch_sgd(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, int first, hipStream_t s);
 // attention backward (attention_bwd.hip): qkv [B*S][3*heads*hdp], dctx [B*S][heads*hdp] -> dqkv [B*S][3*heads*hdp]
 int launch_attention_bwd(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, int hd, int hdp, float scale, int dtype, hipStream_t s);

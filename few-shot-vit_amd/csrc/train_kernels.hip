@@ -479,6 +479,18 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   }
 }
 
+// the same update for a table of tensors in ONE launch (blockIdx.y = tensor): 86 parameter tensors per meta-tuning step
+struct SgdItem { float* p; const float* g; float* buf; size_t n; };
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdItem* __restrict__ items, float lr, float momentum, float wd, int first) {
+  const SgdItem it = items[blockIdx.y];
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < it.n; idx += (size_t)gridDim.x * 256) {
+    const float d = it.g[idx] + wd * it.p[idx];
+    const float b = first ? d : momentum * it.buf[idx] + d;
+    it.buf[idx] = b;
+    it.p[idx] -= lr * b;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == 0) { CALL_F32; } else { CALL_BF16; } } while (0)
 
@@ -628,6 +640,13 @@ int launch_colsum(const void* a, float* partial, float* out, int M, int C, int d
   int rc = launch_bn_reduce(a, nullptr, nullptr, nullptr, partial, M, C, 0, dtype, s);
   if (rc) return rc;
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, partial, bn_reduce_blocks(M), C, out);
+  return (int)hipGetLastError();
+}
+int launch_sgd_multi(const void* items_dev, int n_items, size_t max_numel, float lr, float momentum, float wd, int first, hipStream_t s) {
+  if (n_items <= 0 || max_numel == 0) return 0;
+  size_t gx = (max_numel + 1023) / 1024;                 // 4 elements per thread at the largest tensor; smaller ones leave blocks idle
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)gx, (unsigned)n_items), dim3(256), 0, s, (const SgdItem*)items_dev, lr, momentum, wd, first);
   return (int)hipGetLastError();
 }
 int launch_sgd(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, int first, hipStream_t s) {

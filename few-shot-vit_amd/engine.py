@@ -575,6 +575,22 @@ class ops:
         return dw
 
     @staticmethod
+    def sgd_step_multi(params, grads, bufs, lr, momentum, weight_decay, first_step):
+        """One launch for a list of fp32 tensors (fsvit_sgd_step_multi): the pointer table is built on the host and copied with the stream."""
+        if not params:
+            return
+        _require_cuda(*params)
+        lib = _lib.load()
+        bump_weight_generation()
+        dev = params[0].device
+        table = torch.tensor([[p.data_ptr(), g.data_ptr(), b.data_ptr(), p.numel()] for p, g, b in zip(params, grads, bufs)], dtype=torch.int64)
+        with torch.cuda.device(dev):
+            table_dev = table.pin_memory().to(dev, non_blocking=True)
+            _lib.check(lib.fsvit_sgd_step_multi(_ptr(table_dev), len(params), max(p.numel() for p in params), float(lr), float(momentum),
+                                                float(weight_decay), int(bool(first_step)), _stream_ptr(dev)))
+        return table_dev          # keep alive until the caller's next synchronisation point (the allocator is stream-ordered anyway)
+
+    @staticmethod
     def sgd_step(param, grad, buf, lr, momentum, weight_decay, first_step):
         _require_cuda(param, grad, buf)
         lib = _lib.load()

@@ -150,6 +150,7 @@ class FsvitSGD(torch.optim.Optimizer):
     def step(self, closure=None):
         from ..engine import ops
         for group in self.param_groups:
+            batches = {True: ([], [], []), False: ([], [], [])}            # first step of a tensor (no momentum buffer yet) or not
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -158,10 +159,12 @@ class FsvitSGD(torch.optim.Optimizer):
                 if first:
                     st['momentum_buffer'] = torch.empty_like(p, memory_format=torch.contiguous_format)
                 data = p.data
-                if data.dim() == 0:
-                    data = data.view(1)
-                ops.sgd_step(data, p.grad.contiguous().view(-1), st['momentum_buffer'].view(-1), group['lr'], group['momentum'],
-                             group['weight_decay'], first)
+                if not data.is_contiguous() or data.dtype != torch.float32 or not data.is_cuda:
+                    raise RuntimeError('FsvitSGD: parameters must be contiguous fp32 CUDA tensors')
+                ps, gs, bs = batches[first]
+                ps.append(data.view(-1)); gs.append(p.grad.contiguous().view(-1)); bs.append(st['momentum_buffer'].view(-1))
+            for first, (ps, gs, bs) in batches.items():
+                ops.sgd_step_multi(ps, gs, bs, group['lr'], group['momentum'], group['weight_decay'], first)      # one launch per param_group
 
 
 def make_optimizer(params, name, lr, weight_decay=None, milestones=None, gamma=0.1):

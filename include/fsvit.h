@@ -256,6 +256,12 @@ int fsvit_visformer_train_backward(fsvit_visformer_trainer* t, const fsvit_param
 int fsvit_proto_head_backward(const float* feat_shot_dev, const float* feat_query_dev, const float* dlogits_dev, int E, int way,
                               int shot, int Q, int D, float temp, float* dfeat_shot_dev, float* dfeat_query_dev,
                               float* dtemp_per_episode_dev, void* stream);
+/* The same update for a table of tensors in one launch.  items_dev: DEVICE array of n_items records {float* param; const float* grad;
+ * float* momentum_buf; size_t numel} (4 x 8 bytes each); max_numel = the largest numel.  All tensors share lr / momentum / weight_decay /
+ * first_step (one param_group of torch.optim.SGD, meta_tuning_sun_m/utils/__init__.py:128-139). */
+int fsvit_sgd_step_multi(const void* items_dev, int n_items, size_t max_numel, float lr, float momentum, float weight_decay, int first_step,
+                         void* stream);
+
 /* torch.optim.SGD(momentum, weight_decay) update of one fp32 tensor (utils/__init__.py:127-139) */
 int fsvit_sgd_step(float* param_dev, const float* grad_dev, float* momentum_buf_dev, size_t n, float lr, float momentum,
                    float weight_decay, int first_step, void* stream);

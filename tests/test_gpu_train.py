@@ -225,6 +225,30 @@ def test_sgd_step_matches_torch_optim():
     assert float((p.cpu() - ref.detach()).abs().max()) <= 1e-6
 
 
+def test_fsvit_sgd_multi_tensor_matches_torch_optim():
+    """utils.FsvitSGD (one table-driven launch per param_group, fsvit_sgd_step_multi) vs torch.optim.SGD over ragged tensors, three steps,
+    a tensor without gradient and one whose first gradient arrives late (its momentum buffer starts at that step)."""
+    from fewshot_vit_amd import utils
+    g = torch.Generator().manual_seed(5)
+    shapes = [(33,), (128, 32, 3, 3), (1,), (1000, 7), (256,), (5, 5)]
+    init = [torch.randn(*sh, generator=g) for sh in shapes]
+    ref = [t.clone().requires_grad_(True) for t in init]
+    mine = [t.clone().cuda().requires_grad_(True) for t in init]
+    o_ref = torch.optim.SGD(ref, lr=0.02, momentum=0.9, weight_decay=5e-4)
+    o_mine = utils.FsvitSGD(mine, lr=0.02, momentum=0.9, weight_decay=5e-4)
+    for step in range(3):
+        for k, (r, m) in enumerate(zip(ref, mine)):
+            if k == 2 or (k == 4 and step == 0):
+                r.grad = None; m.grad = None
+                continue
+            gr = torch.randn(*shapes[k], generator=g)
+            r.grad = gr.clone(); m.grad = gr.cuda()
+        o_ref.step(); o_mine.step()
+    torch.cuda.synchronize()
+    for r, m in zip(ref, mine):
+        assert float((m.detach().cpu() - r.detach()).abs().max()) <= 1e-6
+
+
 def test_training_loop_reduces_loss_and_eval_follows():
     """train_meta.py:155-177 shape: model.train(); loss.backward(); optimizer.step() repeated on one batch of episodes
     drives the loss down; the eval engine then repacks from the updated weights."""
