@@ -242,13 +242,14 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* __restrict__ a,
   }
 }
 
-// sum of the per-block partials of one channel: 8 threads per channel (32 channels per block), fp64 accumulation
+// sum of the per-block partials of one channel: one wave per channel (4 channels per block), fp64 accumulation.  (8 threads per channel made the two
+// finalize kernels 20 us each - 64 dependent loads per thread - times 294 launches per step.)
 __device__ __forceinline__ void bn_partial_sums(const float* __restrict__ partial, int nblk, int C, int c, int sub, double& s0, double& s1) {
   s0 = 0.0; s1 = 0.0;
   if (c < C)
-    for (int b = sub; b < nblk; b += 8) { s0 += partial[((size_t)b * 2 + 0) * C + c]; s1 += partial[((size_t)b * 2 + 1) * C + c]; }
+    for (int b = sub; b < nblk; b += 64) { s0 += partial[((size_t)b * 2 + 0) * C + c]; s1 += partial[((size_t)b * 2 + 1) * C + c]; }
 #pragma unroll
-  for (int o = 1; o < 8; o <<= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+  for (int o = 1; o < 64; o <<= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
 }
 
 // forward finalize: mean / invstd (biased variance), scale/shift for the apply pass, running-stat update (momentum, unbiased var)
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
                                                               float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ sa, float* __restrict__ sb) {
-  const int c = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;
   double s0, s1;
   bn_partial_sums(partial, nblk, C, c, sub, s0, s1);
   if (c >= C || sub) return;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __res
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int M, int C, const float* __restrict__ gamma,
                                                               const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc) {
-  const int c = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;
   double s0, s1;
   bn_partial_sums(partial, nblk, C, c, sub, s0, s1);
   if (c >= C || sub) return;
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256) void fill_f32_kernel(float* __restrict__ p, fl
 __global__ __launch_bounds__(256) void scale_copy_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, float s) { GS_LOOP(idx, n) out[idx] = in[idx] * s; }
 // column sums from bn_reduce partials (conv bias gradient)
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;
   double s0, s1;
   bn_partial_sums(partial, nblk, C, c, sub, s0, s1);
   if (c >= C || sub) return;
@@ -557,12 +558,12 @@ int launch_bn_reduce(const void* a, const void* z, const float* mean, const floa
 }
 int launch_bn_fwd_finalize(const float* partial, int M, int C, float eps, float momentum, const float* gamma, const float* beta, float* rmean, float* rvar,
                            float* mean, float* invstd, float* sa, float* sb, hipStream_t s) {
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, partial, bn_reduce_blocks(M), M, C, eps, momentum, gamma, beta, rmean, rvar, mean, invstd, sa, sb);
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, bn_reduce_blocks(M), M, C, eps, momentum, gamma, beta, rmean, rvar, mean, invstd, sa, sb);
   return (int)hipGetLastError();
 }
 int launch_bn_bwd_finalize(const float* partial, int M, int C, const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* ca, float* cb,
                            float* cc, hipStream_t s) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, partial, bn_reduce_blocks(M), M, C, gamma, invstd, dgamma, dbeta, ca, cb, cc);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, bn_reduce_blocks(M), M, C, gamma, invstd, dgamma, dbeta, ca, cb, cc);
   return (int)hipGetLastError();
 }
 int launch_bn_apply(const void* z, const float* sa, const float* sb, const void* res, void* y, size_t M, int C, int act, int dtype, hipStream_t s) {
@@ -639,7 +640,7 @@ int launch_scale_copy(const float* in, float* out, size_t n, float sc, hipStream
 int launch_colsum(const void* a, float* partial, float* out, int M, int C, int dtype, hipStream_t s) {
   int rc = launch_bn_reduce(a, nullptr, nullptr, nullptr, partial, M, C, 0, dtype, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, partial, bn_reduce_blocks(M), C, out);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, bn_reduce_blocks(M), C, out);
   return (int)hipGetLastError();
 }
 int launch_sgd_multi(const void* items_dev, int n_items, size_t max_numel, float lr, float momentum, float wd, int first, hipStream_t s) {
