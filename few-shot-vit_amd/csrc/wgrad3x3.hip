@@ -225,13 +225,15 @@ int launch_wgrad3x3(const void* x, int xld, const void* dz, int zld, float* dw, 
 }
 
 // ---- 1x1 convolutions (conv1 / conv3 of the Mlps, qkv, proj):  Y[n][split * Kc_pad + c] = sum_{m in split} dz[m][n] * x[m][c]
-// The same transposing-read scheme without taps: a workgroup owns a 256 (n) x 128 (c) block, its 8 waves 64 x 64 each (16 accumulator tiles);
-// per 64 rows it stages 32 + 16 KB and issues 32 MFMAs per wave.  Output is the split-K partial layout wgrad_finalize_kernel already sums (it also
+// The same transposing-read scheme without taps: a workgroup owns an NT (n) x CT (c) block (256 where the layer has >= 256 columns, else 128), its
+// 8 waves (4 x 2) NT/4 x CT/2 each (up to 32 accumulator tiles); per 64 rows it stages (NT + CT) x 128 B and issues up to 64 MFMAs per wave.  Output is the split-K partial layout wgrad_finalize_kernel already sums (it also
 // undoes the head-dim padding of qkv rows / proj columns).
+template <int NT, int CT>
 __global__ __launch_bounds__(512) void wgrad1x1_kernel(const bf16* __restrict__ x, int xld, int C, const bf16* __restrict__ dz, int zld, int N,
                                                        float* __restrict__ y, int M, int n_chunks, int chunks_per_wg, int splits, int Kc_pad) {
   using namespace wg3;
-  constexpr int NT = 256, CT = 128;
+  constexpr int WN = NT / 4, WC = CT / 2;                          // a wave's block: 4 x 2 waves
+  constexpr int TN = WN / 16, TC = WC / 16;
   constexpr int ZT_BYTES = (NT / 16) * CH * 32, XT_BYTES = (CT / 16) * CH * 32;
   constexpr int NPZ = (CH * NT / 8) / 512, NPX = (CH * CT / 8) / 512;
   __shared__ __attribute__((aligned(16))) unsigned char smem[ZT_BYTES + XT_BYTES];
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(512) void wgrad1x1_kernel(const bf16* __restrict__ 
   unsigned char* const XT = smem + ZT_BYTES;
   const int t = threadIdx.x, lane = t & 63, i = lane & 15, lq = lane >> 4;
   const int j = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wn = j & 3, wc = j >> 2;                              // wave's 64-column blocks inside the tile
+  const int wn = j & 3, wc = j >> 2;
   const int n0 = blockIdx.y * NT, c0 = blockIdx.z * CT;
   const int q0 = blockIdx.x * chunks_per_wg;
   int q1 = q0 + chunks_per_wg; q1 = q1 < n_chunks ? q1 : n_chunks;
@@ -272,12 +274,12 @@ __global__ __launch_bounds__(512) void wgrad1x1_kernel(const bf16* __restrict__ 
       *reinterpret_cast<u32x4*>(XT + (c8 >> 1) * (CH * 32) + r * 32 + (c8 & 1) * 16) = px[u0];
     }
   };
-  f32x4 acc[4][4];
+  f32x4 acc[TN][TC];
 #pragma unroll
-  for (int a = 0; a < 16; ++a) acc[a >> 2][a & 3] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < TN * TC; ++a) acc[a / TC][a % TC] = f32x4{0.f, 0.f, 0.f, 0.f};
   const unsigned lane_off = (lq * 4 + (i >> 2)) * 32 + (i & 3) * 8;
-  const unsigned zt_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ZT + (wn * 4) * (CH * 32) + lane_off;
-  const unsigned xt_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)XT + (wc * 4) * (CH * 32) + lane_off;
+  const unsigned zt_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ZT + (wn * TN) * (CH * 32) + lane_off;
+  const unsigned xt_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)XT + (wc * TC) * (CH * 32) + lane_off;
   auto tr = [&](unsigned addr) -> u32x2 {
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(size_t)addr));
   };
@@ -290,31 +292,32 @@ __global__ __launch_bounds__(512) void wgrad1x1_kernel(const bf16* __restrict__ 
     if (q + 1 < q1) gload(q + 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      u32x4 af[4], bf[4];
+      u32x4 af[TN];
 #pragma unroll
-      for (int k4 = 0; k4 < 4; ++k4) {
+      for (int k4 = 0; k4 < TN; ++k4) {
         const u32x2 a1 = tr(zt_lane + k4 * (CH * 32) + ks * 1024), a2 = tr(zt_lane + k4 * (CH * 32) + ks * 1024 + 512);
         af[k4] = u32x4{a1[0], a1[1], a2[0], a2[1]};
-        const u32x2 b1 = tr(xt_lane + k4 * (CH * 32) + ks * 1024), b2 = tr(xt_lane + k4 * (CH * 32) + ks * 1024 + 512);
-        bf[k4] = u32x4{b1[0], b1[1], b2[0], b2[1]};
       }
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int ct = 0; ct < TC; ++ct) {
+        const u32x2 b1 = tr(xt_lane + ct * (CH * 32) + ks * 1024), b2 = tr(xt_lane + ct * (CH * 32) + ks * 1024 + 512);
+        const u32x4 bf = {b1[0], b1[1], b2[0], b2[1]};
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[nt][ct] = mma_chunk<bf16>(af[nt], bf[ct], acc[nt][ct]);
+        for (int nt = 0; nt < TN; ++nt) acc[nt][ct] = mma_chunk<bf16>(af[nt], bf, acc[nt][ct]);
+      }
     }
   }
-  // partials: lane holds n = n0 + 64 wn + 16 nt + 4 lq + e, c = c0 + 64 wc + 16 ct + i
+  // partials: lane holds n = n0 + WN wn + 16 nt + 4 lq + e, c = c0 + WC wc + 16 ct + i
   const size_t ldy = (size_t)splits * Kc_pad;
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
+  for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int n = n0 + wn * 64 + nt * 16 + lq * 4 + e;
+      const int n = n0 + wn * WN + nt * 16 + lq * 4 + e;
       if (n < N) {
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-          const int c = c0 + wc * 64 + ct * 16 + i;
+        for (int ct = 0; ct < TC; ++ct) {
+          const int c = c0 + wc * WC + ct * 16 + i;
           if (c < C) y[(size_t)n * ldy + (size_t)blockIdx.x * Kc_pad + c] = acc[nt][ct][e];
         }
       }
@@ -325,10 +328,14 @@ bool wgrad1x1_supported(int dtype, int N, int C) {
   static const bool off = [] { const char* e = getenv("FSVIT_WGRAD1X1"); return e && e[0] == '0'; }();
   return !off && dtype == 1 && (N % 8) == 0 && (C % 8) == 0;
 }
+// block shape per layer: 256 along a dimension that has >= 256 columns, else 128 (wave blocks 64 / 32 rows x 128 / 64 columns)
+static void wgrad1x1_tile(int N, int C, int* NT, int* CT) { *NT = N >= 256 ? 256 : 128; *CT = C >= 256 ? 256 : 128; }
 // number of row splits (= partial slabs of Y) the launch will use
 int wgrad1x1_splits(int N, int C, int M) {
+  int NT, CT;
+  wgrad1x1_tile(N, C, &NT, &CT);
   const int n_chunks = (M + wg3::CH - 1) / wg3::CH;
-  const int tiles = ((N + 255) / 256) * ((C + 127) / 128);
+  const int tiles = ((N + NT - 1) / NT) * ((C + CT - 1) / CT);
   int s = (256 + tiles - 1) / tiles;           // ~one workgroup per CU: the partial slabs (N x C x 4 B per split) are written and summed once each
   if (s > n_chunks) s = n_chunks;
   if (s < 1) s = 1;
@@ -336,11 +343,18 @@ int wgrad1x1_splits(int N, int C, int M) {
   return (n_chunks + cpw - 1) / cpw;
 }
 int launch_wgrad1x1(const void* x, int xld, int C, const void* dz, int zld, int N, float* y, int M, int Kc_pad, hipStream_t s) {
+  int NT, CT;
+  wgrad1x1_tile(N, C, &NT, &CT);
   const int n_chunks = (M + wg3::CH - 1) / wg3::CH;
   const int splits = wgrad1x1_splits(N, C, M);
   const int cpw = (n_chunks + splits - 1) / splits;
-  hipLaunchKernelGGL(wgrad1x1_kernel, dim3(splits, (N + 255) / 256, (C + 127) / 128), dim3(512), 0, s, (const bf16*)x, xld, C, (const bf16*)dz, zld, N, y, M, n_chunks,
-                     cpw, splits, Kc_pad);
+  const dim3 grid(splits, (N + NT - 1) / NT, (C + CT - 1) / CT);
+#define WG1_LAUNCH(A, B) hipLaunchKernelGGL((wgrad1x1_kernel<A, B>), grid, dim3(512), 0, s, (const bf16*)x, xld, C, (const bf16*)dz, zld, N, y, M, n_chunks, cpw, splits, Kc_pad)
+  if (NT == 256 && CT == 256) WG1_LAUNCH(256, 256);
+  else if (NT == 256) WG1_LAUNCH(256, 128);
+  else if (CT == 256) WG1_LAUNCH(128, 256);
+  else WG1_LAUNCH(128, 128);
+#undef WG1_LAUNCH
   return (int)hipGetLastError();
 }
 
