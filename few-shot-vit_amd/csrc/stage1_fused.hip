@@ -205,8 +205,14 @@ __global__ __launch_bounds__(s1::NW * 64) void stage1_block_kernel(const bf16* _
     s1_bar_lds();
 #pragma unroll 1
     for (int k = -1; k <= k_end; ++k) {
+#ifndef S1_NO_WEIGHTS       // timing diagnostics only
+#ifndef S1_NO_WWRITE
       wr(k);
+#endif
+#ifndef S1_NO_WLOAD
       ld(k + 1);
+#endif
+#endif
       s1_bar_lds();
     }
     return;
