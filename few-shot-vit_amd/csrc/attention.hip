@@ -173,9 +173,16 @@ __global__ __launch_bounds__(NW * 64) void attention_v2_kernel(const T* __restri
       v = *reinterpret_cast<const u32x4*>(src + heads * HDP);
     }
     *reinterpret_cast<u32x4*>(Ks + row * QS + ch * 16) = k;
-    const T* ve = reinterpret_cast<const T*>(&v);
+    if constexpr (ES == 2) {
+      // 16-bit storage: V stays ROW-major, as [16-column subtile][key][32 B]; the PV step reads its A fragments (8 keys of one head-dim column
+      // per lane) with the transposing ds_read_b64_tr_b16.  (Round 1 wrote V^T with eight 2-byte stores per chunk: 79 % of the kernel's LDS
+      // cycles were bank conflicts.)
+      *reinterpret_cast<u32x4*>(Vt + (ch >> 1) * (SKP * 32) + row * 32 + (ch & 1) * 16) = v;
+    } else {
+      const T* ve = reinterpret_cast<const T*>(&v);
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) *reinterpret_cast<T*>(Vt + (ch * EPC + e) * VS + row * ES) = ve[e];
+      for (int e = 0; e < EPC; ++e) *reinterpret_cast<T*>(Vt + (ch * EPC + e) * VS + row * ES) = ve[e];
+    }
   }
   __syncthreads();
 
@@ -244,10 +251,14 @@ __global__ __launch_bounds__(NW * 64) void attention_v2_kernel(const T* __restri
           acc = mma_chunk<T>(vf, __builtin_bit_cast(u32x4, sc[kt]), acc);
         }
       } else {
+        // lane (i = lrow, lq) supplies the address of columns 4 (i & 3) .. of key row 32 kc + 4 lq + (i >> 2) (+ 16) and receives keys
+        // 32 kc + 4 lq + 0..3 (+ 16) of column i: the K-slot order the packed P fragment below has (tools/probes/tr_read_probe.hip)
+        const unsigned vaddr = (unsigned)(size_t)(__attribute__((address_space(3))) void*)Vt + dt * (SKP * 32) + (lq * 4 + (lrow >> 2)) * 32 + (lrow & 3) * 8;
+        typedef short s4v __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int kc = 0; kc < NKT / 2; ++kc) {
-          const u32x2 v0 = *reinterpret_cast<const u32x2*>(va + (32 * kc + lq * 4) * 2);
-          const u32x2 v1 = *reinterpret_cast<const u32x2*>(va + (32 * kc + 16 + lq * 4) * 2);
+          const u32x2 v0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(size_t)(vaddr + kc * 1024)));
+          const u32x2 v1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(size_t)(vaddr + kc * 1024 + 512)));
           const u32x4 vf = {v0[0], v0[1], v1[0], v1[1]};
           const bf16x8 pb = {(bf16)sc[2 * kc][0], (bf16)sc[2 * kc][1], (bf16)sc[2 * kc][2], (bf16)sc[2 * kc][3],
                              (bf16)sc[2 * kc + 1][0], (bf16)sc[2 * kc + 1][1], (bf16)sc[2 * kc + 1][2], (bf16)sc[2 * kc + 1][3]};

@@ -80,7 +80,7 @@ constexpr int H1_BYTES = 4 * H1_PLANE;    // 27648
 constexpr int W1_BYTES = 16 * 32 * 16;    //  8192  [16 k-chunks][32 n][16 B]
 constexpr int W2_BYTES = 36 * 32 * 16;    // 18432  [9 taps * 4 k-chunks][32 n][16 B], row n = hidden channel sigma(n)
 constexpr int W3_BYTES = 4 * 128 * 16;    //  8192  [4 k-chunks][128 n][16 B]
-constexpr int WS_W2 = W1_BYTES, WS_W3 = W1_BYTES + W2_BYTES;
+constexpr int WS_W3 = W1_BYTES + W2_BYTES;
 constexpr int WSET = WS_W3 + W3_BYTES;    // 34816: one group of the weight image = 34 pieces of 1 KB
 constexpr int NPIECE = WSET / 1024;
 constexpr int OFF_H1 = 0;                          // two H1 buffers
