@@ -81,6 +81,7 @@ struct fsvit_visformer_trainer {
   Arena save, tmp;
   int B = 0;
   float dp_rate = 0.f;
+  bool freeze_bn = false;                 // BatchNorm layers in eval mode inside the step (utils.freeze_bn): running statistics, no update
   const float* masks = nullptr;           // [n_droppath_calls][B] 0/1
   // saved forward state (pointers into `save`)
   struct Stem { void *patches, *z1, *a1, *zd, *ad, *z2, *a2, *z3, *a3; unsigned char* arg; BnSave b1, bd, b2, b3; void* x1; } stem;
@@ -222,8 +223,12 @@ int bn_fwd(TR* t, const std::string& name, const void* z, int M, int C, int act,
   if (!stats || !partial) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (bn)");
   sv->z = const_cast<void*>(z); sv->M = M; sv->C = C;
   sv->mean = stats; sv->invstd = stats + C; sv->sa = stats + 2 * C; sv->sb = stats + 3 * C;
-  T_RUN(launch_bn_reduce(z, nullptr, nullptr, nullptr, partial, M, C, 0, t->dtype, t->st));
-  T_RUN(launch_bn_fwd_finalize(partial, M, C, t->cfg.bn_eps, 0.1f, g->data, b->data, rm->data, rv->data, sv->mean, sv->invstd, sv->sa, sv->sb, t->st));
+  if (t->freeze_bn) {
+    T_RUN(launch_bn_frozen_coeffs(C, t->cfg.bn_eps, g->data, b->data, rm->data, rv->data, sv->mean, sv->invstd, sv->sa, sv->sb, t->st));
+  } else {
+    T_RUN(launch_bn_reduce(z, nullptr, nullptr, nullptr, partial, M, C, 0, t->dtype, t->st));
+    T_RUN(launch_bn_fwd_finalize(partial, M, C, t->cfg.bn_eps, 0.1f, g->data, b->data, rm->data, rv->data, sv->mean, sv->invstd, sv->sa, sv->sb, t->st));
+  }
   T_RUN(launch_bn_apply(z, sv->sa, sv->sb, res, y, (size_t)M, C, act, t->dtype, t->st));
   return 0;
 }
@@ -239,7 +244,7 @@ int bn_bwd(TR* t, const std::string& name, const BnSave& sv, const void* dy, voi
   float* dgamma = g->grad ? g->grad : coef + 3 * sv.C;
   float* dbeta = b->grad ? b->grad : coef + 4 * sv.C;
   T_RUN(launch_bn_reduce(dy, sv.z, sv.mean, sv.invstd, partial, sv.M, sv.C, 1, t->dtype, t->st));
-  T_RUN(launch_bn_bwd_finalize(partial, sv.M, sv.C, g->data, sv.invstd, dgamma, dbeta, coef, coef + sv.C, coef + 2 * sv.C, t->st));
+  T_RUN(launch_bn_bwd_finalize(partial, sv.M, sv.C, g->data, sv.invstd, dgamma, dbeta, coef, coef + sv.C, coef + 2 * sv.C, t->freeze_bn ? 1 : 0, t->st));
   T_RUN(launch_bn_bwd_apply(dy, sv.z, sv.mean, sv.invstd, coef, coef + sv.C, coef + 2 * sv.C, dz, (size_t)sv.M, sv.C, t->dtype, t->st));
   t->tmp.off = mark;
   return 0;
@@ -680,6 +685,12 @@ extern "C" int fsvit_attention_backward(const void* qkv, const void* dctx, void*
   if (!qkv || !dctx || !dqkv) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
   int rc = launch_attention_bwd(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, dtype, (hipStream_t)stream);
   return rc ? fsvit_set_error(rc, "attention_bwd") : 0;
+}
+
+extern "C" int fsvit_visformer_trainer_set_freeze_bn(fsvit_visformer_trainer* t, int on) {
+  if (!t) return fsvit_set_error(FSVIT_ERR_ARG, "null trainer");
+  t->freeze_bn = on != 0;
+  return 0;
 }
 
 extern "C" int fsvit_sgd_step_multi(const void* items_dev, int n_items, size_t max_numel, float lr, float momentum, float weight_decay, int first_step,

@@ -20,7 +20,9 @@ int launch_bn_reduce(const void* a, const void* z, const float* mean, const floa
 int launch_bn_fwd_finalize(const float* partial, int M, int C, float eps, float momentum, const float* gamma, const float* beta, float* rmean, float* rvar,
                            float* mean, float* invstd, float* sa, float* sb, hipStream_t s);
 int launch_bn_bwd_finalize(const float* partial, int M, int C, const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* ca, float* cb,
-                           float* cc, hipStream_t s);
+                           float* cc, int frozen, hipStream_t s);
+int launch_bn_frozen_coeffs(int C, float eps, const float* gamma, const float* beta, const float* rmean, const float* rvar, float* mean, float* invstd, float* sa,
+                            float* sb, hipStream_t s);
 int launch_bn_apply(const void* z, const float* sa, const float* sb, const void* res, void* y, size_t M, int C, int act, int dtype, hipStream_t s);
 int launch_bn_act_bwd(const void* dout, const void* z, const float* sa, const float* sb, const void* res, void* g, size_t M, int C, int dtype, hipStream_t s);
 int launch_bn_bwd_apply(const void* dy, const void* z, const float* mean, const float* invstd, const float* ca, const float* cb, const float* cc, void* dz,

@@ -275,10 +275,23 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __res
   }
 }
 
-// backward finalize: dgamma = sum(dy * xhat), dbeta = sum(dy); coefficients of dz = ca * dy + cb + cc * xhat
+// frozen BatchNorm inside a training step (utils.freeze_bn, meta_tuning_sun_m/train_meta.py:156-157): the running statistics normalise, nothing is updated
+__global__ __launch_bounds__(256) void bn_frozen_coeffs_kernel(int C, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                                               float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ sa, float* __restrict__ sb) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float is = (float)(1.0 / sqrt((double)running_var[c] + (double)eps));
+  mean[c] = running_mean[c];
+  invstd[c] = is;
+  sa[c] = gamma[c] * is;
+  sb[c] = beta[c] - running_mean[c] * gamma[c] * is;
+}
+
+// backward finalize: dgamma = sum(dy * xhat), dbeta = sum(dy); coefficients of dz = ca * dy + cb + cc * xhat  (frozen statistics: dz = ca * dy)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int M, int C, const float* __restrict__ gamma,
                                                               const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc) {
+                                                              float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc, int frozen) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;
   double s0, s1;
   bn_partial_sums(partial, nblk, C, c, sub, s0, s1);
@@ -287,8 +300,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   dgamma[c] = (float)s1;
   const float gi = gamma[c] * invstd[c];
   ca[c] = gi;
-  cb[c] = (float)(-gi * s0 / M);
-  cc[c] = (float)(-gi * s1 / M);
+  cb[c] = frozen ? 0.f : (float)(-gi * s0 / M);
+  cc[c] = frozen ? 0.f : (float)(-gi * s1 / M);
 }
 
 // y = act(sa[c] * z + sb[c] (+ res))      act: 0 none, 2 LeakyReLU(0.1)
@@ -562,8 +575,13 @@ int launch_bn_fwd_finalize(const float* partial, int M, int C, float eps, float 
   return (int)hipGetLastError();
 }
 int launch_bn_bwd_finalize(const float* partial, int M, int C, const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* ca, float* cb,
-                           float* cc, hipStream_t s) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, bn_reduce_blocks(M), M, C, gamma, invstd, dgamma, dbeta, ca, cb, cc);
+                           float* cc, int frozen, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, bn_reduce_blocks(M), M, C, gamma, invstd, dgamma, dbeta, ca, cb, cc, frozen);
+  return (int)hipGetLastError();
+}
+int launch_bn_frozen_coeffs(int C, float eps, const float* gamma, const float* beta, const float* rmean, const float* rvar, float* mean, float* invstd, float* sa,
+                            float* sb, hipStream_t s) {
+  hipLaunchKernelGGL(bn_frozen_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, s, C, eps, gamma, beta, rmean, rvar, mean, invstd, sa, sb);
   return (int)hipGetLastError();
 }
 int launch_bn_apply(const void* z, const float* sa, const float* sb, const void* res, void* y, size_t M, int C, int act, int dtype, hipStream_t s) {

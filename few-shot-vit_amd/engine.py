@@ -224,6 +224,11 @@ class VisformerTrainer:
             except Exception:
                 pass
 
+    def set_freeze_bn(self, on: bool):
+        """BatchNorm layers in eval mode inside the step (utils.freeze_bn): the running statistics normalise and are not updated; gamma / beta
+        still receive gradients, dz = gamma * invstd * dy."""
+        _lib.check(self.lib.fsvit_visformer_trainer_set_freeze_bn(self.h, int(bool(on))))
+
     def n_droppath_calls(self, rate: float) -> int:
         d = self.cfg['depth']
         depth = sum(d)

@@ -186,9 +186,11 @@ class Visformer(nn.Module):
                 return feat
             tok = self.engine().last_tokens(x.shape[0], hw * hw)
             return tok.permute(0, 2, 1).reshape(x.shape[0], self.out_dim, hw, hw), feat
-        for m in self.modules():
-            if isinstance(m, nn.BatchNorm2d) and not m.training:
-                raise NotImplementedError('fsvit: freeze_bn (BatchNorm in eval mode inside a training step) is not built')
+        bn_modes = {m.training for m in self.modules() if isinstance(m, nn.BatchNorm2d)}
+        if len(bn_modes) > 1:
+            raise NotImplementedError('fsvit: BatchNorm layers must be all in train mode or all frozen (utils.freeze_bn) inside a training step')
+        frozen = bn_modes == {False}                    # utils.freeze_bn (train_meta.py:156-157): running statistics normalise, nothing is updated
+        self.trainer().set_freeze_bn(frozen)
         from ..autograd import VisformerTrainFn
         named = [(k, p) for k, p in self.named_parameters()]
         names = tuple(k for k, _ in named)
@@ -199,9 +201,10 @@ class Visformer(nn.Module):
             tok, feat = VisformerTrainMapFn.apply(x, self.trainer(), names, buffers, self.drop_path_rate, masks, hw * hw, *[p for _, p in named])
         else:
             feat = VisformerTrainFn.apply(x, self.trainer(), names, buffers, self.drop_path_rate, masks, *[p for _, p in named])
-        for k, b in self.named_buffers():
-            if k.endswith('num_batches_tracked'):
-                b += 1
+        if not frozen:
+            for k, b in self.named_buffers():
+                if k.endswith('num_batches_tracked'):
+                    b += 1
         if self.return_map:
             return tok.permute(0, 2, 1).reshape(x.shape[0], self.out_dim, hw, hw), feat
         return feat

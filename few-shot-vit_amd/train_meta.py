@@ -109,8 +109,6 @@ def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, sa
         log('train dataset: {} (x{}), {}'.format(tuple(train_dataset[0][0].shape), len(train_dataset), train_dataset.n_classes))
 
     model = build_model(config).to(device)
-    if config.get('freeze_bn'):
-        raise NotImplementedError('fsvit: freeze_bn training is not built')
     if rank == 0:
         log('num params: {}'.format(utils.compute_n_params(model)))
     if warmup:    # train_meta_warmup.py:140-141: SGD(momentum 0.9) + epoch-indexed multi-step schedule with a 3-epoch linear warm-up
@@ -131,6 +129,8 @@ def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, sa
         timer_epoch.s()
         aves = {k: utils.Averager() for k in aves_keys}
         model.train()
+        if config.get('freeze_bn'):          # train_meta.py:156-157
+            utils.freeze_bn(model)
         np.random.seed(epoch)
         for idx in train_sampler:                               # every rank replays the same stream ...
             idx = parallel.shard_episode_axis(idx, ep_per_batch, rank, world)                            # ... and keeps its episodes

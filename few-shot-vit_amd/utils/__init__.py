@@ -182,7 +182,8 @@ def make_optimizer(params, name, lr, weight_decay=None, milestones=None, gamma=0
 
 
 def freeze_bn(model):
-    """utils/__init__.py:150-153; the HIP trainer does not implement frozen-BN training and says so at forward time."""
+    """utils/__init__.py:150-153: BatchNorm2d modules to eval(); the HIP trainer then normalises with the running statistics
+    (fsvit_visformer_trainer_set_freeze_bn)."""
     for m in model.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
             m.eval()

@@ -241,6 +241,11 @@ void fsvit_visformer_trainer_destroy(fsvit_visformer_trainer* t);
 /* bytes of workspace one forward+backward over n_img images needs (saved activations + temporaries) */
 size_t fsvit_visformer_trainer_workspace_bytes(fsvit_visformer_trainer* t, const fsvit_param* params, int n_params, int n_img,
                                                float drop_path_rate);
+/* BatchNorm layers frozen inside the training step (utils.freeze_bn, meta_tuning_sun_m/train_meta.py:156-157, utils/__init__.py:150-153):
+ * train_forward normalises with the running statistics and leaves them untouched; train_backward returns dz = gamma * invstd * dy and the
+ * gamma / beta gradients against the running statistics.  Default off. */
+int fsvit_visformer_trainer_set_freeze_bn(fsvit_visformer_trainer* t, int on);
+
 /* x_nchw_dev [n_img,3,H,W] fp32 -> feat_dev [n_img,out_dim] fp32.  masks_dev: the DropPath Bernoulli draws, one row of
  * n_img 0/1 floats per DropPath call with a non-zero rate, in call order (stage-1 blocks: one call; stage-2/3 blocks: attn
  * then mlp) - the caller draws them (floor(keep + rand), visformer.py:93-95) so the random stream stays the framework's.

@@ -178,7 +178,7 @@ def visformer_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, cfg: Visform
                       prefix: str = '', mode: str = 'eval',
                       stats_out: Optional[dict] = None, taps: Optional[dict] = None,
                       return_map: bool = False, drop_path_rate: float = 0.0,
-                      droppath_masks: Optional[list] = None, masks_out: Optional[list] = None):
+                      droppath_masks: Optional[list] = None, masks_out: Optional[list] = None, freeze_bn: bool = False):
     """Visformer.forward, visformer.py:424-462 (eval: DropPath is identity, all Dropout p=0).
 
     sd      state dict (reference key names, optionally under `prefix`)
@@ -194,7 +194,8 @@ def visformer_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, cfg: Visform
         sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
     assert x.shape[-1] == cfg.img_size and x.shape[-2] == cfg.img_size, \
         f"Input image size ({x.shape[-2]}*{x.shape[-1]}) does not match model ({cfg.img_size}*{cfg.img_size})."
-    bn = _BN(sd, cfg.bn_eps, 'eval' if mode == 'eval' else mode, stats_out)
+    # freeze_bn: utils.freeze_bn inside a training step (train_meta.py:156-157) - BatchNorm2d modules in eval(), everything else in train mode
+    bn = _BN(sd, cfg.bn_eps, 'eval' if (mode == 'eval' or freeze_bn) else mode, stats_out)
 
     def tap(name, t):
         if taps is not None:

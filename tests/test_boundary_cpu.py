@@ -60,7 +60,11 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         m(torch.zeros(1, 5, 1, 3, 80, 80), torch.zeros(1, 75, 3, 80, 80))
     from fewshot_vit_amd import utils
-    utils.freeze_bn(m)             # frozen-BN training is not built: say so rather than train with the wrong statistics
+    utils.freeze_bn(m)             # frozen-BN training (train_meta.py:156-157) runs on the HIP trainer too: still no CPU path
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(torch.zeros(1, 5, 1, 3, 80, 80), torch.zeros(1, 75, 3, 80, 80))
+    m.train()
+    m.encoder.stem.bn1.eval()      # a MIX of frozen and live BatchNorm layers is not built: say so rather than train with the wrong statistics
     with pytest.raises(NotImplementedError):
         m(torch.zeros(1, 5, 1, 3, 80, 80), torch.zeros(1, 75, 3, 80, 80))
 

@@ -108,9 +108,10 @@ def test_tiny_train_step_vs_reference_golden(golden_dir, numerics):
     print(f'[{numerics}] tiny train step: worst sampled grad error / grad norm = {worst:.3e}')
 
 
-@pytest.mark.parametrize('numerics,drop', [('parity', 0.0), ('parity', 0.5), ('bf16', 0.5)])
-def test_micro_train_step_vs_oracle_autograd(numerics, drop):
-    """visformer_micro_80, 2 episodes x (5-way 1-shot + 10 queries) = 30 images: every gradient vs torch.autograd of the oracle."""
+@pytest.mark.parametrize('numerics,drop,freeze', [('parity', 0.0, False), ('parity', 0.5, False), ('bf16', 0.5, False), ('parity', 0.5, True), ('bf16', 0.0, True)])
+def test_micro_train_step_vs_oracle_autograd(numerics, drop, freeze):
+    """visformer_micro_80, 2 episodes x (5-way 1-shot + 10 queries) = 30 images: every gradient vs torch.autograd of the oracle.
+    freeze: utils.freeze_bn after model.train() (train_meta.py:156-157) - running statistics normalise and stay untouched."""
     from fewshot_vit_amd import synthetic
     from fewshot_vit_amd.utils import few_shot as fs
     from oracle import visformer_oracle as vo
@@ -130,12 +131,15 @@ def test_micro_train_step_vs_oracle_autograd(numerics, drop):
     full.update(params)
     stats = {}
     ref_logits = vo.meta_baseline_forward(full, xs, xq, cfg, mode='train', drop_path_rate=drop,
-                                          droppath_masks=list(masks) if masks is not None else None, stats_out=stats).view(-1, 5)
+                                          droppath_masks=list(masks) if masks is not None else None, stats_out=stats, freeze_bn=freeze).view(-1, 5)
     ref_loss = torch.nn.functional.cross_entropy(ref_logits, label)
     ref_loss.backward()
     ref_grads = {k: p.grad.detach() for k, p in params.items()}
     # HIP
     m = _make(dict(img_size=80, init_channels=64, embed_dim=256, depth=[4, 2, 3], num_heads=6, mlp_ratio=4., group=8), sd, numerics, drop)
+    if freeze:
+        from fewshot_vit_amd import utils
+        utils.freeze_bn(m)
     if masks is not None:
         mc = masks.cuda()
         m.encoder.draw_droppath_masks = lambda n, dev: mc
@@ -151,9 +155,16 @@ def test_micro_train_step_vs_oracle_autograd(numerics, drop):
     # parity: max-pool argmax / LeakyReLU sign decisions flip at rounding-level ties (6M stem activations), so the stem's
     # gradients carry a few discrete differences: 5e-3 of the norm; every other layer is at the 1e-5 level (printed)
     worst = _grad_check(grads, ref_grads, 5e-3 if par else 0.15, numerics, 1e-5 if par else 2e-3)
-    print(f'[{numerics} drop={drop}] micro train step: max|dlogit| = {dl:.3e}, |dloss| = {abs(float(loss) - float(ref_loss)):.3e}, '
+    print(f'[{numerics} drop={drop} freeze_bn={freeze}] micro train step: max|dlogit| = {dl:.3e}, |dloss| = {abs(float(loss) - float(ref_loss)):.3e}, '
           f'worst grad rel err = {worst:.3e}')
     assert dl <= (1e-3 if par else 0.3)
+    if freeze:                           # nothing may have been updated
+        assert not stats
+        for k, v in m.state_dict().items():
+            if k.endswith(('running_mean', 'running_var')):
+                assert torch.equal(v.cpu(), sd[k]), k
+        assert int(m.encoder.norm.bn.num_batches_tracked) == n0
+        return
     for k, v in stats.items():          # updated running statistics
         got = m.state_dict()['encoder.' + k].cpu()
         torch.testing.assert_close(got, v, rtol=1e-3 if par else 5e-2, atol=1e-4 if par else 2e-2, msg=k)
