@@ -90,6 +90,7 @@ SIGNATURES = {
     'fsvit_visformer_train_forward': (_i, [_vp, C.POINTER(Param), _i, _fp, _i, _i, _i, _f, _fp, _fp, _vp, _sz, _vp]),
     'fsvit_visformer_train_backward': (_i, [_vp, C.POINTER(Param), _i, _fp, _vp]),
     'fsvit_proto_head_backward': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _fp, _fp, _vp]),
+    'fsvit_proto_head_backward_sqr': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _fp, _fp, _vp]),
     'fsvit_visformer_trainer_set_freeze_bn': (_i, [_vp, _i]),
     'fsvit_sgd_step_multi': (_i, [_vp, _i, _sz, _f, _f, _f, _i, _vp]),
     'fsvit_sgd_step': (_i, [_fp, _fp, _fp, _sz, _f, _f, _f, _i, _vp]),

@@ -70,20 +70,21 @@ class VisformerTrainMapFn(torch.autograd.Function):
 
 
 class ProtoHeadFn(torch.autograd.Function):
-    """logits = temp * cos(query, mean_shot(prototypes)) (meta_baseline.py:33-47, method 'cos')."""
+    """logits = temp * cos(query, mean_shot) or -temp * |query - mean_shot|^2 (meta_baseline.py:33-47, methods 'cos' / 'sqr')."""
 
     @staticmethod
-    def forward(ctx, feat_shot, feat_query, temp):
+    def forward(ctx, feat_shot, feat_query, temp, method='cos'):
         feat_shot, feat_query = feat_shot.contiguous(), feat_query.contiguous()
-        logits, _, _ = ops.proto_head(feat_shot, feat_query, float(temp), 'cos')
+        logits, _, _ = ops.proto_head(feat_shot, feat_query, float(temp), method)
         ctx.save_for_backward(feat_shot, feat_query, temp)
+        ctx.method = method
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         feat_shot, feat_query, temp = ctx.saved_tensors
-        ds, dq, dt = ops.proto_head_backward(feat_shot, feat_query, dlogits, float(temp))
-        return ds, dq, dt.reshape(temp.shape)
+        ds, dq, dt = ops.proto_head_backward(feat_shot, feat_query, dlogits, float(temp), ctx.method)
+        return ds, dq, dt.reshape(temp.shape), None
 
 
 class LinearFn(torch.autograd.Function):

@@ -199,6 +199,62 @@ __global__ __launch_bounds__(256) void proto_head_bwd_kernel(const float* __rest
   }
 }
 
+// Backward of the squared-distance head (meta_baseline.py:38-41 method 'sqr', utils compute_logits 'sqr'): logits[q][c] = -temp * |q - p_c|^2,
+// p_c = mean_s f_shot[c][s].  dq = -2 temp sum_c dl (q - p_c);  dp_c = 2 temp sum_q dl (q - p_c);  dtemp = -sum dl |q - p_c|^2.
+__global__ __launch_bounds__(256) void proto_head_sqr_bwd_kernel(const float* __restrict__ feat_shot, const float* __restrict__ feat_query,
+                                                                 const float* __restrict__ dlogits, int way, int shot, int Q, int D, float temp,
+                                                                 float* __restrict__ dfeat_shot, float* __restrict__ dfeat_query, float* __restrict__ dtemp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* proto = reinterpret_cast<float*>(smem);            // [way][D]
+  float* red = proto + (size_t)way * D;                       // [4]
+  const int e = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* fs = feat_shot + (size_t)e * way * shot * D;
+  const float* fq = feat_query + (size_t)e * Q * D;
+  const float* dl = dlogits + (size_t)e * Q * way;
+  for (int i = t; i < way * D; i += 256) {
+    const int c = i / D, d = i - c * D;
+    float s = 0.f;
+    for (int k = 0; k < shot; ++k) s += fs[((size_t)c * shot + k) * D + d];
+    proto[i] = s / (float)shot;
+  }
+  __syncthreads();
+  float dt_acc = 0.f;
+  for (int q = wave; q < Q; q += 4) {
+    const float* x = fq + (size_t)q * D;
+    for (int c = 0; c < way; ++c) {
+      float s = 0.f;
+      for (int d = lane; d < D; d += 64) { const float df = x[d] - proto[c * D + d]; s += df * df; }
+      dt_acc -= dl[q * way + c] * wave_sum(s);
+    }
+    for (int d = lane; d < D; d += 64) {
+      float g = 0.f;
+      for (int c = 0; c < way; ++c) g += dl[q * way + c] * (x[d] - proto[c * D + d]);
+      dfeat_query[((size_t)e * Q + q) * D + d] = -2.0f * temp * g;
+    }
+  }
+  if (lane == 0) red[wave] = dt_acc;
+  __syncthreads();
+  if (t == 0 && dtemp) dtemp[e] = red[0] + red[1] + red[2] + red[3];
+  for (int i = t; i < way * D; i += 256) {
+    const int c = i / D, d = i - c * D;
+    float g = 0.f;
+    for (int q = 0; q < Q; ++q) g += dl[q * way + c] * (fq[(size_t)q * D + d] - proto[i]);
+    g *= 2.0f * temp / (float)shot;
+    for (int k = 0; k < shot; ++k) dfeat_shot[(((size_t)e * way + c) * shot + k) * D + d] = g;
+  }
+}
+
+int launch_proto_head_sqr_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
+                              float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s) {
+  if (E <= 0) return 0;
+  const size_t lds = ((size_t)way * D + 4) * sizeof(float);
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute((const void*)proto_head_sqr_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(proto_head_sqr_bwd_kernel, dim3(E), dim3(256), lds, s, feat_shot, feat_query, dlogits, way, shot, Q, D, temp, dfeat_shot, dfeat_query, dtemp);
+  return (int)hipGetLastError();
+}
+
 int launch_proto_head_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
                           float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s) {
   if (E <= 0) return 0;

@@ -680,6 +680,13 @@ extern "C" int fsvit_proto_head_backward(const float* feat_shot, const float* fe
   return rc ? fsvit_set_error(rc, "proto_head_bwd") : 0;
 }
 
+extern "C" int fsvit_proto_head_backward_sqr(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D,
+                                             float temp, float* dfeat_shot, float* dfeat_query, float* dtemp_per_episode, void* stream) {
+  if (!feat_shot || !feat_query || !dlogits || !dfeat_shot || !dfeat_query) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
+  int rc = launch_proto_head_sqr_bwd(feat_shot, feat_query, dlogits, E, way, shot, Q, D, temp, dfeat_shot, dfeat_query, dtemp_per_episode, (hipStream_t)stream);
+  return rc ? fsvit_set_error(rc, "proto_head_sqr_bwd") : 0;
+}
+
 extern "C" int fsvit_attention_backward(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, int hd, int hdp, float scale, int dtype,
                                         void* stream) {
   if (!qkv || !dctx || !dqkv) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");

@@ -46,5 +46,7 @@ int launch_attention_bwd(const void* qkv, const void* dctx, void* dqkv, int B, i
 // prototype head backward (head.hip): dlogits [E,Q,way] -> dfeat_shot [E,way,shot,D], dfeat_query [E,Q,D], dtemp[E] (cos method)
 int launch_proto_head_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
                           float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s);
+int launch_proto_head_sqr_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
+                          float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s);
 
 }  // namespace fsvit

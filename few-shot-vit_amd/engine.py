@@ -537,8 +537,10 @@ class ops:
         return dqkv
 
     @staticmethod
-    def proto_head_backward(feat_shot, feat_query, dlogits, temp):
-        """-> dfeat_shot [E,way,shot,D], dfeat_query [E,Q,D], dtemp (scalar tensor); method 'cos'."""
+    def proto_head_backward(feat_shot, feat_query, dlogits, temp, method='cos'):
+        """-> dfeat_shot [E,way,shot,D], dfeat_query [E,Q,D], dtemp (scalar tensor); method 'cos' or 'sqr'."""
+        if method not in ('cos', 'sqr'):
+            raise ValueError(method)
         _require_cuda(feat_shot, feat_query, dlogits)
         lib = _lib.load()
         E, way, shot, D = feat_shot.shape
@@ -547,8 +549,9 @@ class ops:
         ds, dq = torch.empty_like(feat_shot), torch.empty_like(feat_query)
         dt = torch.empty(E, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.fsvit_proto_head_backward(_ptr(feat_shot), _ptr(feat_query), _ptr(dlogits.contiguous().float()), E, way,
-                                                     shot, Q, D, float(temp), _ptr(ds), _ptr(dq), _ptr(dt), _stream_ptr(dev)))
+            fn = lib.fsvit_proto_head_backward if method == 'cos' else lib.fsvit_proto_head_backward_sqr
+            _lib.check(fn(_ptr(feat_shot), _ptr(feat_query), _ptr(dlogits.contiguous().float()), E, way, shot, Q, D, float(temp), _ptr(ds), _ptr(dq), _ptr(dt),
+                          _stream_ptr(dev)))
         return ds, dq, dt.sum()
 
     @staticmethod

@@ -33,9 +33,7 @@ class MetaBaseline(nn.Module):
 
     def _forward_train(self, x_shot, x_query):
         """The meta-tuning step's forward (train_meta.py:167): one encoder pass over shot + query images of all
-        episodes (so BatchNorm sees the whole batch, meta_baseline.py:31), then the differentiable cosine head."""
-        if self.method != 'cos':
-            raise NotImplementedError("fsvit: the training head is built for method 'cos' (every shipped config)")
+        episodes (so BatchNorm sees the whole batch, meta_baseline.py:31), then the differentiable head ('cos' or 'sqr')."""
         if not hasattr(self.encoder, 'trainer'):
             raise NotImplementedError('fsvit: the training path is built for the Visformer encoders')
         from ..autograd import ProtoHeadFn
@@ -49,7 +47,7 @@ class MetaBaseline(nn.Module):
         f_shot = x_tot[:n_shot].view(E, way, shot, -1)
         f_query = x_tot[n_shot:].view(E, Q, -1)
         temp = self.temp if isinstance(self.temp, torch.Tensor) else torch.tensor(float(self.temp), device=x_tot.device)
-        return ProtoHeadFn.apply(f_shot, f_query, temp)
+        return ProtoHeadFn.apply(f_shot, f_query, temp, self.method)
 
     def _forward_eval(self, x_shot, x_query):
         engine = self.encoder.engine()

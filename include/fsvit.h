@@ -261,6 +261,10 @@ int fsvit_visformer_train_backward(fsvit_visformer_trainer* t, const fsvit_param
 int fsvit_proto_head_backward(const float* feat_shot_dev, const float* feat_query_dev, const float* dlogits_dev, int E, int way,
                               int shot, int Q, int D, float temp, float* dfeat_shot_dev, float* dfeat_query_dev,
                               float* dtemp_per_episode_dev, void* stream);
+/* The same for method 'sqr' (meta_baseline.py:38-41: logits = -temp * |q - mean_shot|^2). */
+int fsvit_proto_head_backward_sqr(const float* feat_shot_dev, const float* feat_query_dev, const float* dlogits_dev, int E, int way,
+                                  int shot, int Q, int D, float temp, float* dfeat_shot_dev, float* dfeat_query_dev,
+                                  float* dtemp_per_episode_dev, void* stream);
 /* The same update for a table of tensors in one launch.  items_dev: DEVICE array of n_items records {float* param; const float* grad;
  * float* momentum_buf; size_t numel} (4 x 8 bytes each); max_numel = the largest numel.  All tensors share lr / momentum / weight_decay /
  * first_step (one param_group of torch.optim.SGD, meta_tuning_sun_m/utils/__init__.py:128-139). */

@@ -219,6 +219,28 @@ def test_proto_head_backward_vs_torch():
     assert abs(float(dt) - float(t.grad)) <= 1e-4 * abs(float(t.grad)) + 1e-6
 
 
+def test_proto_head_sqr_backward_vs_torch():
+    """method 'sqr' (meta_baseline.py:38-41): logits = -temp * |q - mean_shot|^2, forward and backward vs torch."""
+    from fewshot_vit_amd.engine import ops
+    E, way, shot, Q, D = 3, 5, 5, 15, 512
+    g = torch.Generator().manual_seed(19)
+    fs_ = torch.randn(E, way, shot, D, generator=g) * 0.1
+    fq = torch.randn(E, Q, D, generator=g) * 0.1
+    dl = torch.randn(E, Q, way, generator=g)
+    a, b = fs_.clone().requires_grad_(True), fq.clone().requires_grad_(True)
+    t = torch.tensor(2.0, requires_grad=True)
+    proto = a.mean(dim=-2)
+    logits = -(b.unsqueeze(2) - proto.unsqueeze(1)).pow(2).sum(dim=-1) * t
+    logits.backward(dl)
+    got, _, _ = ops.proto_head(fs_.cuda(), fq.cuda(), 2.0, 'sqr')
+    assert float((got.cpu() - logits.detach()).abs().max()) <= 1e-4
+    ds, dq, dt = ops.proto_head_backward(fs_.cuda(), fq.cuda(), dl.cuda(), 2.0, 'sqr')
+    torch.cuda.synchronize()
+    assert float((ds.cpu() - a.grad).abs().max()) <= 1e-5 * float(a.grad.abs().max()) + 1e-7
+    assert float((dq.cpu() - b.grad).abs().max()) <= 1e-5 * float(b.grad.abs().max()) + 1e-7
+    assert abs(float(dt) - float(t.grad)) <= 1e-4 * abs(float(t.grad)) + 1e-6
+
+
 def test_sgd_step_matches_torch_optim():
     """torch.optim.SGD(momentum=0.9, weight_decay) semantics of utils.make_optimizer (utils/__init__.py:128-132)."""
     from fewshot_vit_amd.engine import ops
