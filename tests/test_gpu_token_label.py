@@ -227,6 +227,65 @@ def test_wide_heads_tiered_imagenet_class_counts():
     assert (dz.cpu() - zr.grad).abs().max() <= 2e-6
 
 
+def test_train_classifier_loop_matches_oracle_loop(tmp_path):
+    """f3: the supervised loop itself (sun_meta_training/train_classifier.py:139-160: model.train(); CE; AdamW step; cosine schedule per epoch)
+    replayed in plain fp32 torch - the oracle's train-mode Visformer under autograd, torch.optim.AdamW, the same permutations and batches -
+    must give the same per-epoch training loss and the same head weights as the HIP driver in `parity` mode."""
+    from fewshot_vit_amd import datasets, models, synthetic, train_classifier
+    from fewshot_vit_amd.utils.schedulers import CosineLRScheduler
+    from oracle import visformer_oracle as vo
+    margs = dict(encoder='visformer_micro_80', encoder_args=dict(drop_path_rate=0.0, numerics='parity'),
+                 classifier='linear-classifier', classifier_args=dict(n_classes=8))
+    torch.manual_seed(1234)
+    m0 = models.make('classifier', **margs)
+    esd = synthetic.synthetic_checkpoint_sd({'encoder.' + k: tuple(v.shape) for k, v in m0.encoder.state_dict().items()}, calib='visformer_micro_80')
+    m0.encoder.load_state_dict({k[len('encoder.'):]: v for k, v in esd.items()})
+    ck_path = os.path.join(str(tmp_path), 'init.pth')
+    torch.save({'model': 'classifier', 'model_args': margs, 'model_sd': m0.state_dict()}, ck_path)
+    dargs = dict(split='train', n_classes=8, n_per_class=20, noise=1.0, seed=1)
+    config = dict(train_dataset='synthetic-episodes', train_dataset_args=dargs, model='classifier', model_args=margs, load=ck_path,
+                  batch_size=16, train_batches=2, max_epoch=2, optimizer='adamw', seed=5,
+                  optimizer_args=dict(lr=5e-4, weight_decay=0.05, warmup_lr=1e-6, warmup=1))
+    trlog = train_classifier.main(config, name='par', device=torch.device('cuda', 0), log=lambda *_: None, save_root=str(tmp_path))
+    final = torch.load(os.path.join(str(tmp_path), 'par', 'epoch-last.pth'), map_location='cpu')['model_sd']
+
+    # ---- the same loop on the CPU oracle
+    cfg = vo.VisformerCfg()
+    sd = {k: v.detach().cpu().clone() for k, v in m0.state_dict().items()}
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if not k.endswith(('running_mean', 'running_var', 'num_batches_tracked'))}
+    opt = torch.optim.AdamW(list(params.values()), betas=(0.9, 0.999), eps=1e-8, lr=5e-4 * 16 / 512, weight_decay=0.05)
+    sched = CosineLRScheduler(opt, warmup_lr_init=1e-6, t_initial=2, cycle_decay=0.1, warmup_t=1)
+    ds = datasets.make('synthetic-episodes', **dargs)
+    gen = torch.Generator().manual_seed(5)
+    ref_tl = []
+    for epoch in range(1, 3):
+        losses = []
+        perm = torch.randperm(len(ds), generator=gen)
+        for bi in range(2):
+            idx = perm[bi * 16:(bi + 1) * 16]
+            data, label = train_classifier._gather(ds, idx, torch.device('cuda', 0))
+            stats = {}
+            feat = vo.visformer_forward(sd, data.cpu(), cfg, prefix='encoder.', mode='train', stats_out=stats)
+            logits = torch.nn.functional.linear(feat, sd['classifier.linear.weight'], sd['classifier.linear.bias'])
+            loss = torch.nn.functional.cross_entropy(logits, label.cpu())
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            with torch.no_grad():
+                for k, v in stats.items():
+                    sd['encoder.' + k].copy_(v)
+            losses.append(float(loss))
+        sched.step(epoch - 1)
+        ref_tl.append(float(np.mean(losses)))
+    print('train_classifier loop: HIP per-epoch loss', trlog['tl'], 'oracle loop', ref_tl)
+    assert np.allclose(trlog['tl'], ref_tl, rtol=2e-4, atol=2e-5)
+    for k in ('classifier.linear.weight', 'classifier.linear.bias', 'encoder.norm.bn.weight', 'encoder.stage3.2.mlp.conv3.weight'):
+        a, b = final[k], sd[k].detach()
+        assert float((a - b).abs().max()) <= 2e-3 * max(1e-3, float(b.abs().max())), k
+    for k in ('encoder.norm.bn.running_mean', 'encoder.stem.bn1.running_var'):
+        assert torch.allclose(final[k], sd[k], rtol=2e-3, atol=1e-4), k
+
+
 def test_train_classifier_epoch_ex_and_nn_classifier(tmp_path):
     """f3 leftovers: `epoch_ex` = one extra epoch after max_epoch (sun_train_teacher/train_classifier.py:141-148) and the
     `nn-classifier` head (test_phase/models/classifier.py:38-55) - cosine logits against learnable prototypes with a learnable
