@@ -10,7 +10,7 @@ from fewshot_vit_amd.engine import ops
 from bench_ops import pack_w, time_it
 bf = torch.bfloat16
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 6400
-reps = 1 if len(sys.argv) > 2 else 5
+reps = 5
 for cin in (64, 128):
     x = torch.randn(B, 40, 40, cin, device='cuda').to(bf)
     w = pack_w(128, cin, 3, 1, bf)
