@@ -77,9 +77,10 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// bf16 MFMA version.  One workgroup per (image, head); S <= 128 keys, everything of the head lives in LDS:
-//   row-major   Q, K, V, dO  [SKP][HDP]   (score-type products: both operands read 16-byte k-chunks of a row)
-//   transposed  K^T, Q^T, dO^T [HDP][SKP] (the A operand of the three products that contract over keys / queries)
+// bf16 MFMA version.  One workgroup per (image, head); S <= 224 keys, everything of the head lives in LDS, ROW-major only:
+//   Q, K, V, dO  [SKP][HDP]   score-type products read 16-byte k-chunks of a row; the three products that contract over keys / queries take
+//   their A operand (8 consecutive rows of one column) from the same images with ds_read_b64_tr_b16 (tools/probes/tr_read_probe.hip) -
+//   round 1 kept transposed copies K^T, Q^T, dO^T written with 2-byte stores (126 KB at 100 tokens, S <= 128)
 // pass 1 (per 16-query tile, one wave): S^T = K Q^T and dP^T = V dO^T in the [key x query] orientation, in-register
 //   softmax (2 shuffles), D = rowsum(P o dP), dS = scale P o (dP - D); dQ^T = K^T dS^T with dS fed back as the MFMA B
 //   operand straight from registers (keys permuted consistently in both operands, as attention_v2 does for P V).
@@ -92,17 +93,13 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_mfma_kernel(const bf16*
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HDP = NDT * 16, SKP = NKT * 16;
   constexpr int RS = HDP * 2 + 16;             // row-major row stride (bytes): odd multiple of 16 -> conflict-free b128 reads
-  constexpr int TS = SKP * 2 + 16;             // transposed row stride
   constexpr int NKC = HDP / 32;                // 32-element MFMA chunks along the head dim
   constexpr int CPR = HDP / 8;                 // 16-byte chunks per row
   unsigned char* const Qr = smem;
   unsigned char* const Kr = Qr + SKP * RS;
   unsigned char* const Vr = Kr + SKP * RS;
   unsigned char* const Or = Vr + SKP * RS;
-  unsigned char* const Kt = Or + SKP * RS;
-  unsigned char* const Qt = Kt + HDP * TS;
-  unsigned char* const Ot = Qt + HDP * TS;
-  float* const st_m = reinterpret_cast<float*>(Ot + HDP * TS);
+  float* const st_m = reinterpret_cast<float*>(Or + SKP * RS);
   float* const st_inv = st_m + SKP;
   float* const st_D = st_inv + SKP;
 
@@ -129,19 +126,19 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_mfma_kernel(const bf16*
     *reinterpret_cast<u32x4*>(Kr + row * RS + ch * 16) = k;
     *reinterpret_cast<u32x4*>(Vr + row * RS + ch * 16) = v;
     *reinterpret_cast<u32x4*>(Or + row * RS + ch * 16) = o;
-    const bf16* qe = reinterpret_cast<const bf16*>(&q);
-    const bf16* ke = reinterpret_cast<const bf16*>(&k);
-    const bf16* oe = reinterpret_cast<const bf16*>(&o);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      *reinterpret_cast<bf16*>(Qt + (ch * 8 + e) * TS + row * 2) = qe[e];
-      *reinterpret_cast<bf16*>(Kt + (ch * 8 + e) * TS + row * 2) = ke[e];
-      *reinterpret_cast<bf16*>(Ot + (ch * 8 + e) * TS + row * 2) = oe[e];
-    }
   }
   __syncthreads();
 
   const float sscale = scale * 1.44269504088896340736f;        // exp2 domain, exactly as the forward kernel
+  // A fragment (16 columns c0 .. c0 + 15 as MFMA rows, K slots = rows r0 + 4 lq + j and r0 + 16 + 4 lq + j) of a row-major image: this lane
+  // supplies the address of columns 4 (lrow & 3) .. of row r0 + 4 lq + (lrow >> 2) and receives rows r0 + 4 lq + 0..3 of column c0 + lrow
+  typedef short s4t __attribute__((ext_vector_type(4)));
+  auto trA = [&](const unsigned char* img, int r0, int c0) -> u32x4 {
+    const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)img + (r0 + lq * 4 + (lrow >> 2)) * RS + (c0 + (lrow & 3) * 4) * 2;
+    const u32x2 v0 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4t*)(size_t)a));
+    const u32x2 v1 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4t*)(size_t)(a + 16 * RS)));
+    return u32x4{v0[0], v0[1], v1[0], v1[1]};
+  };
   const int nt = (S + 15) / 16;
 
   // ------------------------------------------------------------------ pass 1: dQ + per-query statistics
@@ -210,12 +207,9 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_mfma_kernel(const bf16*
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const unsigned char* ka = Kt + (dt * 16 + lrow) * TS;
 #pragma unroll
       for (int kc = 0; kc < NKT / 2; ++kc) {
-        const u32x2 v0 = *reinterpret_cast<const u32x2*>(ka + (32 * kc + lq * 4) * 2);
-        const u32x2 v1 = *reinterpret_cast<const u32x2*>(ka + (32 * kc + 16 + lq * 4) * 2);
-        const u32x4 kf = {v0[0], v0[1], v1[0], v1[1]};
+        const u32x4 kf = trA(Kr, 32 * kc, dt * 16);
         const bf16x8 sb = {(bf16)sc[2 * kc][0], (bf16)sc[2 * kc][1], (bf16)sc[2 * kc][2], (bf16)sc[2 * kc][3],
                            (bf16)sc[2 * kc + 1][0], (bf16)sc[2 * kc + 1][1], (bf16)sc[2 * kc + 1][2], (bf16)sc[2 * kc + 1][3]};
         acc = mma_chunk<bf16>(kf, __builtin_bit_cast(u32x4, sb), acc);
@@ -263,14 +257,8 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_mfma_kernel(const bf16*
       }
 #pragma unroll
       for (int dt = 0; dt < NDT; ++dt) {
-        const unsigned char* oa = Ot + (dt * 16 + lrow) * TS;
-        const unsigned char* qa = Qt + (dt * 16 + lrow) * TS;
-        const u32x2 o0 = *reinterpret_cast<const u32x2*>(oa + (32 * qc + lq * 4) * 2);
-        const u32x2 o1 = *reinterpret_cast<const u32x2*>(oa + (32 * qc + 16 + lq * 4) * 2);
-        const u32x2 q0 = *reinterpret_cast<const u32x2*>(qa + (32 * qc + lq * 4) * 2);
-        const u32x2 q1 = *reinterpret_cast<const u32x2*>(qa + (32 * qc + 16 + lq * 4) * 2);
-        accV[dt] = mma_chunk<bf16>(u32x4{o0[0], o0[1], o1[0], o1[1]}, __builtin_bit_cast(u32x4, pb), accV[dt]);
-        accK[dt] = mma_chunk<bf16>(u32x4{q0[0], q0[1], q1[0], q1[1]}, __builtin_bit_cast(u32x4, sb), accK[dt]);
+        accV[dt] = mma_chunk<bf16>(trA(Or, 32 * qc, dt * 16), __builtin_bit_cast(u32x4, pb), accV[dt]);
+        accK[dt] = mma_chunk<bf16>(trA(Qr, 32 * qc, dt * 16), __builtin_bit_cast(u32x4, sb), accK[dt]);
       }
     }
     if (kok) {
@@ -287,7 +275,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_mfma_kernel(const bf16*
 template <int NKT, int NDT, int NW>
 static int launch_bwd_mfma(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, float scale, hipStream_t s, bool* ran) {
   constexpr int HDP = NDT * 16, SKP = NKT * 16;
-  const size_t lds = (size_t)4 * SKP * (HDP * 2 + 16) + (size_t)3 * HDP * (SKP * 2 + 16) + (size_t)3 * SKP * sizeof(float);
+  const size_t lds = (size_t)4 * SKP * (HDP * 2 + 16) + (size_t)3 * SKP * sizeof(float);
   *ran = false;
   if (lds > 160 * 1024) return 0;
   auto kern = attention_bwd_mfma_kernel<NKT, NDT, NW>;
@@ -300,7 +288,7 @@ static int launch_bwd_mfma(const void* qkv, const void* dctx, void* dqkv, int B,
 
 int launch_attention_bwd(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, int hd, int hdp, float scale, int dtype, hipStream_t s) {
   if (B <= 0) return 0;
-  if (dtype == 1 && hdp % 32 == 0 && S <= 128 && getenv("FSVIT_ATTN_BWD_VALU") == nullptr) {      // bf16: MFMA kernel
+  if (dtype == 1 && hdp % 32 == 0 && S <= 224 && getenv("FSVIT_ATTN_BWD_VALU") == nullptr) {      // bf16: MFMA kernel
     bool ran = false;
     int rc = 0;
     const int ndt = hdp / 16;
@@ -309,10 +297,13 @@ int launch_attention_bwd(const void* qkv, const void* dctx, void* dqkv, int B, i
       else if (ndt == 4) rc = launch_bwd_mfma<2, 4, 2>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
       else if (ndt == 6) rc = launch_bwd_mfma<2, 6, 2>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
       else if (ndt == 8) rc = launch_bwd_mfma<2, 8, 2>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
-    } else {
+    } else if (S <= 128) {
       if (ndt == 2) rc = launch_bwd_mfma<8, 2, 8>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
       else if (ndt == 4) rc = launch_bwd_mfma<8, 4, 8>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
       else if (ndt == 6) rc = launch_bwd_mfma<8, 6, 8>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
+    } else {                                            // ViT: 196 patches + cls
+      if (ndt == 2) rc = launch_bwd_mfma<14, 2, 8>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
+      else if (ndt == 4) rc = launch_bwd_mfma<14, 4, 8>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
     }
     if (rc || ran) return rc;
   }
