@@ -66,6 +66,7 @@ struct ConvGemmParams {
   namespace NS {                                                                                                           \
   using namespace fsvit_types;                                                                                             \
   int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream);                                            \
+  int conv_gemm_route(const ConvGemmParams& p, int dtype); /* 0 conv3x3_halo, 1 gemm256 (whole or row slices), 2 conv_gemm_v2 */ \
   int launch_conv_gemm_v2(const ConvGemmParams& p, int dtype, hipStream_t stream);                                         \
   /* gemm256.hip: 256x256-tile, 8-wave, 4-phase dense 16-bit GEMM for plain [M][K] x [N][K] layers (N >= 192, K % 64 == 0) */ \
   bool gemm256_eligible(const ConvGemmParams& p, int dtype);                                                               \

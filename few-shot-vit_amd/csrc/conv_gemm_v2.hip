@@ -388,9 +388,41 @@ int launch_conv_gemm_v2(const ConvGemmParams& p, int dtype, hipStream_t stream) 
 
 // The dispatcher every conv / GEMM launch goes through: the LDS-resident halo kernel for the stem's 3x3 convs, the 256x256 tile for
 // the dense 1x1 layers, this file's persistent implicit GEMM for everything else.
+// rows per gemm256 slice of an over-long plain 1x1 layer, 0: not sliced (see launch_conv_gemm)
+static int gemm256_slice_rows(const ConvGemmParams& p, int dtype) {
+  const size_t row_bytes = (size_t)p.x_cstride * 2;
+  if (dtype != 1 || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.groups != 1 || p.pos || p.y_rpi || p.x2 || p.pool2) return 0;
+  if ((size_t)p.M * row_bytes < (1ull << 32)) return 0;
+  const int rows_max = (int)((((1ull << 32) - 1) / row_bytes) / 256 * 256);
+  ConvGemmParams q = p;
+  q.B = rows_max < p.M ? rows_max : p.M; q.H = q.W = q.OH = q.OW = 1; q.M = q.B;
+  return rows_max >= 1024 && gemm256_eligible(q, dtype) ? rows_max : 0;
+}
+// which kernel launch_conv_gemm runs for p: 0 conv3x3_halo, 1 gemm256 (whole or in row slices), 2 conv_gemm_v2
+int conv_gemm_route(const ConvGemmParams& p, int dtype) {
+  if (conv3x3_halo_eligible(p, dtype)) return 0;
+  if (gemm256_eligible(p, dtype) || gemm256_slice_rows(p, dtype)) return 1;
+  return 2;
+}
+
 int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream) {
   if (conv3x3_halo_eligible(p, dtype)) return launch_conv3x3_halo(p, stream);
   if (gemm256_eligible(p, dtype)) return launch_gemm256(p, stream);
+  // A plain 1x1 layer whose activation matrix is past gemm256's 32-bit DMA offsets (a 12 800-image ViT chunk: 2.5 M rows x 1536 columns)
+  // runs as row slices of < 4 GB each, if a slice is eligible.
+  if (const int rows_max = gemm256_slice_rows(p, dtype)) {
+    ConvGemmParams q = p;
+    q.H = q.W = q.OH = q.OW = 1;
+    for (int m0 = 0; m0 < p.M; m0 += rows_max) {
+      q.M = q.B = p.M - m0 < rows_max ? p.M - m0 : rows_max;
+      q.x = (const unsigned char*)p.x + (size_t)m0 * p.x_cstride * 2;
+      q.y = (unsigned char*)p.y + (size_t)m0 * p.y_cstride * 2;
+      q.res = p.res ? (const unsigned char*)p.res + (size_t)m0 * p.y_cstride * 2 : nullptr;
+      const int rc = gemm256_eligible(q, dtype) ? launch_gemm256(q, stream) : launch_conv_gemm_v2(q, dtype, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   return launch_conv_gemm_v2(p, dtype, stream);
 }
 

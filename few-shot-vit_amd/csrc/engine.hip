@@ -509,7 +509,8 @@ int run_gemm(EngineBase* h, hipStream_t st, const char* layer, const Layer& L, c
   const int kdt = h->dtype;
   const double flops = 2.0 * (double)p.M * n_true * k_true * (double)p.groups;     // algorithmic: unpadded N and K
   static const int kid_of_cfg[4] = {KID_GEMM256, KID_GEMM64, KID_GEMM32, KID_GEMM128};
-  const int kid = K(conv3x3_halo_eligible)(p, kd(kdt)) ? KID_HALO : K(gemm256_eligible)(p, kd(kdt)) ? KID_GEMM256 : kid_of_cfg[K(conv_gemm_v2_config)(p)];
+  const int route = K(conv_gemm_route)(p, kd(kdt));
+  const int kid = route == 0 ? KID_HALO : route == 1 ? KID_GEMM256 : kid_of_cfg[K(conv_gemm_v2_config)(p)];
   return timed(h, st, layer, kid, flops, [&]() { return K(launch_conv_gemm)(p, kd(kdt), st); });
 }
 
