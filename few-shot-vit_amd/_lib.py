@@ -89,6 +89,12 @@ SIGNATURES = {
     'fsvit_visformer_trainer_workspace_bytes': (_sz, [_vp, C.POINTER(Param), _i, _i, _f]),
     'fsvit_visformer_train_forward': (_i, [_vp, C.POINTER(Param), _i, _fp, _i, _i, _i, _f, _fp, _fp, _vp, _sz, _vp]),
     'fsvit_visformer_train_backward': (_i, [_vp, C.POINTER(Param), _i, _fp, _vp]),
+    'fsvit_vit_trainer_create': (_i, [C.POINTER(VitCfg), _i, C.POINTER(_vp)]),
+    'fsvit_vit_trainer_destroy': (None, [_vp]),
+    'fsvit_vit_trainer_droppath_calls': (_i, [_vp, _f]),
+    'fsvit_vit_trainer_workspace_bytes': (_sz, [_vp, C.POINTER(Param), _i, _i, _f]),
+    'fsvit_vit_train_forward': (_i, [_vp, C.POINTER(Param), _i, _fp, _i, _i, _i, _f, _fp, _fp, _vp, _sz, _vp]),
+    'fsvit_vit_train_backward': (_i, [_vp, C.POINTER(Param), _i, _fp, _vp]),
     'fsvit_proto_head_backward': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _fp, _fp, _vp]),
     'fsvit_proto_head_backward_sqr': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _fp, _fp, _vp]),
     'fsvit_visformer_trainer_set_freeze_bn': (_i, [_vp, _i]),

@@ -572,6 +572,320 @@ int train_backward_impl(TR* t, const float* dfeat) {
 
 }  // namespace
 
+// ================================================================ ViT / DeiT trainer (deit.py:61-78 Block, :139-218 VisionTransformer)
+// Same machinery as the Visformer trainer (parameter table, two arenas, conv_fwd / conv_bwd_data / conv_bwd_weight on 1x1 "convs" = nn.Linear,
+// attention forward / backward, GELU, DropPath scales); new: LayerNorm with kept row statistics, token assembly, the final norm on the cls row.
+struct fsvit_vit_trainer : fsvit_visformer_trainer {
+  fsvit_vit_cfg vcfg;
+  int D = 0, S = 0, np = 0, npw = 0, K = 0, Kp = 0, hidv = 0, heads = 0, hd = 0, hdp = 0;
+  struct Blk { void *x, *xn1, *qkv, *ctx, *x1, *xn2, *z1, *h; float *m1, *r1, *m2, *r2; const float *s1, *s2; };
+  std::vector<Blk> blk;
+  void* patches = nullptr;
+  void* xlast = nullptr;
+  float *mf = nullptr, *rf = nullptr;
+};
+
+namespace {
+
+typedef fsvit_vit_trainer VT;
+
+ConvSpec lin(const std::string& w, int O, int I) { ConvSpec c; c.wname = w; c.O = O; c.Ig = I; return c; }
+
+struct VSpecs { ConvSpec pe; std::vector<ConvSpec> qkv, proj, fc1, fc2; };
+VSpecs vit_specs(const VT* t) {
+  VSpecs s;
+  s.pe = lin("patch_embed.proj.weight", t->D, t->K);
+  s.pe.hd_cols = t->K; s.pe.hdp_cols = t->Kp;                      // the patch rows are padded to Kp columns (one "head" of K real ones)
+  for (int i = 0; i < t->vcfg.depth; ++i) {
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    ConvSpec q = lin(p + "attn.qkv.weight", 3 * t->heads * t->hd, t->D);
+    q.hd_rows = t->hd; q.hdp_rows = t->hdp;
+    ConvSpec pr = lin(p + "attn.proj.weight", t->D, t->heads * t->hd);
+    pr.hd_cols = t->hd; pr.hdp_cols = t->hdp;
+    s.qkv.push_back(q); s.proj.push_back(pr);
+    s.fc1.push_back(lin(p + "mlp.fc1.weight", t->hidv, t->D));
+    s.fc2.push_back(lin(p + "mlp.fc2.weight", t->D, t->hidv));
+  }
+  return s;
+}
+
+// bias of a Linear whose output rows are head-padded (qkv): the padded bias vector lives in tmp
+int padded_bias(VT* t, const fsvit_param* b, int n_real, int hd, int hdp, const float** out) {
+  if (hd == hdp) { *out = b->data; return 0; }
+  const int groups = n_real / hd;
+  float* pb = (float*)t->tmp.take((size_t)groups * hdp * 4);
+  if (!pb) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (bias)");
+  if (!t->tmp.dry) {
+    hipError_t e = hipMemsetAsync(pb, 0, (size_t)groups * hdp * 4, t->st);
+    if (e == hipSuccess) e = hipMemcpy2DAsync(pb, (size_t)hdp * 4, b->data, (size_t)hd * 4, (size_t)hd * 4, groups, hipMemcpyDeviceToDevice, t->st);
+    if (e != hipSuccess) return fsvit_set_error((int)e, "padded bias");
+  }
+  *out = pb;
+  return 0;
+}
+// bias gradient = column sums of dz (real columns only when head-padded)
+int bias_grad(VT* t, const fsvit_param* b, const void* dz, int M, int n_real, int hd, int hdp) {
+  if (!b->grad && !t->tmp.dry) return 0;
+  const int cols = n_real / hd * hdp;
+  const size_t mark = t->tmp.off;
+  float* partial = (float*)t->tmp.take((size_t)bn_reduce_blocks(M) * 2 * cols * 4);
+  float* full = hd == hdp ? b->grad : (float*)t->tmp.take((size_t)cols * 4);
+  if (!partial || (!full && !t->tmp.dry)) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (bias grad)");
+  T_RUN(launch_colsum(dz, partial, full, M, cols, t->dtype, t->st));
+  if (hd != hdp && !t->tmp.dry) {
+    hipError_t e = hipMemcpy2DAsync(b->grad, (size_t)hd * 4, full, (size_t)hdp * 4, (size_t)hd * 4, n_real / hd, hipMemcpyDeviceToDevice, t->st);
+    if (e != hipSuccess) return fsvit_set_error((int)e, "bias grad");
+  }
+  t->tmp.off = mark;
+  return 0;
+}
+
+int vit_ln_fwd(VT* t, const std::string& name, const void* x, void* y, float** mean, float** rstd, int M) {
+  const fsvit_param *g = getp(t, name + ".weight"), *b = getp(t, name + ".bias");
+  if (!g || !b) return FSVIT_ERR_KEY;
+  *mean = (float*)t->save.take((size_t)M * 4);
+  *rstd = (float*)t->save.take((size_t)M * 4);
+  if (!*mean || !*rstd) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (ln)");
+  T_RUN(launch_ln_train_fwd(x, g->data, b->data, y, *mean, *rstd, M, t->D, t->vcfg.ln_eps, t->dtype, t->st));
+  return 0;
+}
+// dx = add + LN^T(dy)
+int vit_ln_bwd(VT* t, const std::string& name, const void* dy, const void* x, const float* mean, const float* rstd, const void* add, void* dx, int M) {
+  const fsvit_param *g = getp(t, name + ".weight"), *b = getp(t, name + ".bias");
+  if (!g || !b) return FSVIT_ERR_KEY;
+  const size_t mark = t->tmp.off;
+  float* partial = (float*)t->tmp.take((size_t)ln_bwd_blocks(M) * 2 * t->D * 4);
+  if (!partial) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (ln bwd)");
+  T_RUN(launch_ln_bwd(dy, x, mean, rstd, g->data, add, dx, partial, g->grad, b->grad, M, t->D, t->dtype, t->st));
+  t->tmp.off = mark;
+  return 0;
+}
+
+const float* vit_dp_scale(VT* t, int call, int i) {
+  const int depth = t->vcfg.depth;
+  const float r = depth > 1 ? t->dp_rate * (float)i / (float)(depth - 1) : 0.f;          // deit.py:161 linspace(0, rate, depth)
+  if (r == 0.f || !t->scales) return nullptr;
+  return t->scales + (size_t)call * t->B;
+}
+
+int vit_forward_impl(VT* t, const float* x, float* feat) {
+  const VSpecs sp = vit_specs(t);
+  const int B = t->B, S = t->S, D = t->D, dt = t->dtype, heads = t->heads, hdp = t->hdp, hid = t->hidv;
+  const size_t M = (size_t)B * S, Mp = (size_t)B * t->np;
+  hipStream_t st = t->st;
+  const fsvit_param *cls = getp(t, "cls_token"), *pos = getp(t, "pos_embed"), *peb = getp(t, "patch_embed.proj.bias");
+  if (!cls || !pos || !peb) return FSVIT_ERR_KEY;
+  NEED(t->patches = take_act(t, Mp * t->Kp));
+  T_RUN(launch_patchify(x, t->patches, B, t->vcfg.img_size, t->vcfg.patch_size, t->Kp, dt, st));
+  void* xcur = take_act(t, M * D); NEED(xcur);
+  {
+    const size_t mark = t->tmp.off;
+    void* zpe = take_tmp(t, Mp * D); NEED(zpe);
+    T_TRY(conv_fwd(t, sp.pe, t->patches, (int)Mp, 1, 1, zpe, peb->data));
+    T_RUN(launch_vit_assemble(zpe, cls->data, pos->data, xcur, B, S, D, dt, st));
+    t->tmp.off = mark;
+  }
+  t->blk.resize(t->vcfg.depth);
+  const float scale = 1.0f / std::sqrt((float)t->hd);
+  int dp_call = 0;
+  for (int i = 0; i < t->vcfg.depth; ++i) {
+    auto& b = t->blk[i];
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    const fsvit_param *bq = getp(t, p + "attn.qkv.bias"), *bp = getp(t, p + "attn.proj.bias"), *b1 = getp(t, p + "mlp.fc1.bias"), *b2 = getp(t, p + "mlp.fc2.bias");
+    if (!bq || !bp || !b1 || !b2) return FSVIT_ERR_KEY;
+    b.x = xcur;
+    NEED(b.xn1 = take_act(t, M * D)); NEED(b.qkv = take_act(t, M * 3 * heads * hdp)); NEED(b.ctx = take_act(t, M * heads * hdp));
+    NEED(b.x1 = take_act(t, M * D)); NEED(b.xn2 = take_act(t, M * D)); NEED(b.z1 = take_act(t, M * hid)); NEED(b.h = take_act(t, M * hid));
+    void* xout = take_act(t, M * D); NEED(xout);
+    const size_t mark = t->tmp.off;
+    void* zp = take_tmp(t, M * D); NEED(zp);
+    T_TRY(vit_ln_fwd(t, p + "norm1", b.x, b.xn1, &b.m1, &b.r1, (int)M));
+    const float* bqp = nullptr;
+    T_TRY(padded_bias(t, bq, 3 * heads * t->hd, t->hd, hdp, &bqp));
+    T_TRY(conv_fwd(t, sp.qkv[i], b.xn1, B, S, 1, b.qkv, bqp));
+    T_RUN(launch_attention(b.qkv, b.ctx, B, S, heads, hdp, scale, dt, st));
+    T_TRY(conv_fwd(t, sp.proj[i], b.ctx, B, S, 1, zp, bp->data));
+    b.s1 = vit_dp_scale(t, dp_call, i);
+    if (t->dp_rate * i > 0.f) ++dp_call;
+    T_RUN(launch_add_scaled(b.x, zp, b.s1, b.x1, M * D, (size_t)S * D, dt, st));
+    T_TRY(vit_ln_fwd(t, p + "norm2", b.x1, b.xn2, &b.m2, &b.r2, (int)M));
+    T_TRY(conv_fwd(t, sp.fc1[i], b.xn2, B, S, 1, b.z1, b1->data));
+    T_RUN(launch_gelu_fwd(b.z1, b.h, M * hid, dt, st));
+    T_TRY(conv_fwd(t, sp.fc2[i], b.h, B, S, 1, zp, b2->data));
+    b.s2 = vit_dp_scale(t, dp_call, i);
+    if (t->dp_rate * i > 0.f) ++dp_call;
+    T_RUN(launch_add_scaled(b.x1, zp, b.s2, xout, M * D, (size_t)S * D, dt, st));
+    t->tmp.off = mark;
+    xcur = xout;
+  }
+  t->xlast = xcur;
+  const fsvit_param *ng = getp(t, "norm.weight"), *nb = getp(t, "norm.bias");
+  if (!ng || !nb) return FSVIT_ERR_KEY;
+  t->mf = (float*)t->save.take((size_t)B * 4); t->rf = (float*)t->save.take((size_t)B * 4);
+  NEED(t->mf); NEED(t->rf);
+  T_RUN(launch_vit_cls_ln_fwd(t->xlast, ng->data, nb->data, feat, t->mf, t->rf, B, S, D, t->vcfg.ln_eps, dt, st));
+  return 0;
+}
+
+int vit_backward_impl(VT* t, const float* dfeat) {
+  const VSpecs sp = vit_specs(t);
+  const int B = t->B, S = t->S, D = t->D, dt = t->dtype, heads = t->heads, hdp = t->hdp, hid = t->hidv;
+  const size_t M = (size_t)B * S, Mp = (size_t)B * t->np;
+  hipStream_t st = t->st;
+  const fsvit_param *ng = getp(t, "norm.weight"), *nb = getp(t, "norm.bias");
+  if (!ng || !nb) return FSVIT_ERR_KEY;
+  void* dx = take_tmp(t, M * D); NEED(dx);
+  {
+    if (!t->tmp.dry) { hipError_t e = hipMemsetAsync(dx, 0, M * D * t->es, st); if (e != hipSuccess) return fsvit_set_error((int)e, "memset"); }
+    const size_t mark = t->tmp.off;
+    float* partial = (float*)t->tmp.take((size_t)B * 2 * D * 4); NEED(partial);
+    T_RUN(launch_vit_cls_ln_bwd(dfeat, t->xlast, t->mf, t->rf, ng->data, dx, partial, ng->grad, nb->grad, B, S, D, dt, st));
+    t->tmp.off = mark;
+  }
+  const float scale = 1.0f / std::sqrt((float)t->hd);
+  for (int i = t->vcfg.depth - 1; i >= 0; --i) {
+    auto& b = t->blk[i];
+    const std::string p = "blocks." + std::to_string(i) + ".";
+    const fsvit_param *bq = getp(t, p + "attn.qkv.bias"), *bp = getp(t, p + "attn.proj.bias"), *b1 = getp(t, p + "mlp.fc1.bias"), *b2 = getp(t, p + "mlp.fc2.bias");
+    if (!bq || !bp || !b1 || !b2) return FSVIT_ERR_KEY;
+    const size_t mark = t->tmp.off;
+    // mlp branch: out = x1 + s2 * fc2(gelu(fc1(norm2(x1))))
+    void* dz2 = take_tmp(t, M * D); NEED(dz2);
+    T_RUN(launch_add_scaled(nullptr, dx, b.s2, dz2, M * D, (size_t)S * D, dt, st));
+    T_TRY(conv_bwd_weight(t, sp.fc2[i], b.h, B, S, 1, dz2));
+    T_TRY(bias_grad(t, b2, dz2, (int)M, D, 1, 1));
+    void* dh = take_tmp(t, M * hid); NEED(dh);
+    T_TRY(conv_bwd_data(t, sp.fc2[i], dz2, B, S, 1, dh));
+    T_RUN(launch_gelu_bwd(dh, b.z1, dh, M * hid, dt, st));
+    T_TRY(conv_bwd_weight(t, sp.fc1[i], b.xn2, B, S, 1, dh));
+    T_TRY(bias_grad(t, b1, dh, (int)M, hid, 1, 1));
+    void* dxn = take_tmp(t, M * D); NEED(dxn);
+    T_TRY(conv_bwd_data(t, sp.fc1[i], dh, B, S, 1, dxn));
+    T_TRY(vit_ln_bwd(t, p + "norm2", dxn, b.x1, b.m2, b.r2, dx, dx, (int)M));                // dx := d(x1) total
+    // attention branch: x1 = x + s1 * proj(attn(qkv(norm1(x))))
+    T_RUN(launch_add_scaled(nullptr, dx, b.s1, dz2, M * D, (size_t)S * D, dt, st));
+    T_TRY(conv_bwd_weight(t, sp.proj[i], b.ctx, B, S, 1, dz2));
+    T_TRY(bias_grad(t, bp, dz2, (int)M, D, 1, 1));
+    void* dctx = take_tmp(t, M * heads * hdp); NEED(dctx);
+    T_TRY(conv_bwd_data(t, sp.proj[i], dz2, B, S, 1, dctx));
+    void* dqkv = take_tmp(t, M * 3 * heads * hdp); NEED(dqkv);
+    T_RUN(launch_attention_bwd(b.qkv, dctx, dqkv, B, S, heads, t->hd, hdp, scale, dt, st));
+    T_TRY(conv_bwd_weight(t, sp.qkv[i], b.xn1, B, S, 1, dqkv));
+    T_TRY(bias_grad(t, bq, dqkv, (int)M, 3 * heads * t->hd, t->hd, hdp));
+    T_TRY(conv_bwd_data(t, sp.qkv[i], dqkv, B, S, 1, dxn));
+    T_TRY(vit_ln_bwd(t, p + "norm1", dxn, b.x, b.m1, b.r1, dx, dx, (int)M));
+    t->tmp.off = mark;
+  }
+  // embedding: tokens = [cls + pos0 | conv(patches) + bias + pos]
+  const fsvit_param *cls = getp(t, "cls_token"), *pos = getp(t, "pos_embed"), *peb = getp(t, "patch_embed.proj.bias");
+  if (!cls || !pos || !peb) return FSVIT_ERR_KEY;
+  {
+    float* ps = (float*)t->tmp.take((size_t)S * D * 4); NEED(ps);
+    T_RUN(launch_batch_sum(dx, ps, B, (size_t)S * D, dt, st));
+    if (!t->tmp.dry) {
+      hipError_t e = hipSuccess;
+      if (pos->grad) e = hipMemcpyAsync(pos->grad, ps, (size_t)S * D * 4, hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess && cls->grad) e = hipMemcpyAsync(cls->grad, ps, (size_t)D * 4, hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return fsvit_set_error((int)e, "pos / cls gradient");
+    }
+    void* dzpe = take_tmp(t, Mp * D); NEED(dzpe);
+    T_RUN(launch_vit_patch_rows(dx, dzpe, B, S, D, dt, st));
+    T_TRY(conv_bwd_weight(t, sp.pe, t->patches, (int)Mp, 1, 1, dzpe));
+    T_TRY(bias_grad(t, peb, dzpe, (int)Mp, D, 1, 1));
+  }
+  return 0;
+}
+
+int vit_droppath_calls(const VT* t, float rate, std::vector<float>* keep) {
+  int n = 0;
+  for (int i = 0; i < t->vcfg.depth; ++i) {
+    const float r = t->vcfg.depth > 1 ? rate * (float)i / (float)(t->vcfg.depth - 1) : 0.f;
+    if (r == 0.f) continue;
+    for (int k = 0; k < 2; ++k) if (keep) keep->push_back(1.0f - r);
+    n += 2;
+  }
+  return n;
+}
+
+int vit_size_workspace(VT* t, int n_img, float rate, size_t* save_bytes, size_t* tmp_bytes) {
+  t->B = n_img; t->dp_rate = rate; t->scales = nullptr;
+  t->save = Arena(); t->tmp = Arena();
+  t->save.dry = t->tmp.dry = true;
+  int rc = vit_forward_impl(t, nullptr, nullptr);
+  if (rc) return rc;
+  size_t tp = t->tmp.peak;
+  t->tmp.off = 0;
+  rc = vit_backward_impl(t, nullptr);
+  if (rc) return rc;
+  if (t->tmp.peak > tp) tp = t->tmp.peak;
+  *save_bytes = align256(t->save.peak + (size_t)vit_droppath_calls(t, rate, nullptr) * n_img * 4 + 256);
+  *tmp_bytes = align256(tp);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int fsvit_vit_trainer_create(const fsvit_vit_cfg* cfg, int dtype, fsvit_vit_trainer** out) {
+  if (!cfg || !out) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
+  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16) return fsvit_set_error(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  if (cfg->embed_dim % cfg->num_heads || cfg->img_size % cfg->patch_size || cfg->embed_dim % 8) return fsvit_set_error(FSVIT_ERR_ARG, "bad ViT configuration");
+  VT* t = new VT();
+  t->vcfg = *cfg; t->dtype = dtype; t->es = dtype == FSVIT_F32 ? 4 : 2;
+  const int kch = 64 / t->es;
+  t->D = cfg->embed_dim; t->npw = cfg->img_size / cfg->patch_size; t->np = t->npw * t->npw; t->S = t->np + 1;
+  t->K = 3 * cfg->patch_size * cfg->patch_size; t->Kp = round_up(t->K, 128 / t->es);
+  t->hidv = (int)(cfg->embed_dim * cfg->mlp_ratio); t->heads = cfg->num_heads; t->hd = cfg->embed_dim / cfg->num_heads; t->hdp = round_up(t->hd, kch);
+  *out = t;
+  return 0;
+}
+extern "C" void fsvit_vit_trainer_destroy(fsvit_vit_trainer* t) { delete t; }
+extern "C" int fsvit_vit_trainer_droppath_calls(const fsvit_vit_trainer* t, float drop_path_rate) { return t ? vit_droppath_calls(t, drop_path_rate, nullptr) : 0; }
+
+extern "C" size_t fsvit_vit_trainer_workspace_bytes(fsvit_vit_trainer* t, const fsvit_param* params, int n_params, int n_img, float drop_path_rate) {
+  if (!t || !params || n_img <= 0) return 0;
+  t->P.clear();
+  for (int i = 0; i < n_params; ++i) t->P[params[i].name] = &params[i];
+  size_t sb = 0, tb = 0;
+  if (vit_size_workspace(t, n_img, drop_path_rate, &sb, &tb)) return 0;
+  return sb + tb;
+}
+
+extern "C" int fsvit_vit_train_forward(fsvit_vit_trainer* t, const fsvit_param* params, int n_params, const float* x_nchw_dev, int n_img, int img_h, int img_w,
+                                       float drop_path_rate, const float* masks_dev, float* feat_dev, void* ws_dev, size_t ws_bytes, void* stream) {
+  if (!t || !params || !x_nchw_dev || !feat_dev || !ws_dev || n_img <= 0) return fsvit_set_error(FSVIT_ERR_ARG, "bad argument");
+  if (img_h != t->vcfg.img_size || img_w != t->vcfg.img_size)
+    return fsvit_set_error(FSVIT_ERR_IMG_SIZE, "Input image size (%d*%d) doesn't match model (%d*%d).", img_h, img_w, t->vcfg.img_size, t->vcfg.img_size);
+  if (drop_path_rate > 0.f && !masks_dev) return fsvit_set_error(FSVIT_ERR_ARG, "DropPath masks required when drop_path_rate > 0");
+  t->P.clear();
+  for (int i = 0; i < n_params; ++i) t->P[params[i].name] = &params[i];
+  size_t sb = 0, tb = 0;
+  T_TRY(vit_size_workspace(t, n_img, drop_path_rate, &sb, &tb));
+  if (ws_bytes < sb + tb) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace of %zu bytes is too small (need %zu)", ws_bytes, sb + tb);
+  t->st = (hipStream_t)stream;
+  t->save = Arena(); t->save.base = (unsigned char*)ws_dev; t->save.size = sb;
+  t->tmp = Arena(); t->tmp.base = (unsigned char*)ws_dev + sb; t->tmp.size = ws_bytes - sb;
+  t->scales = nullptr;
+  if (drop_path_rate > 0.f) {                       // DropPath scale = mask / keep_prob per call (timm DropPath, deit.py:70,76-77)
+    std::vector<float> keep;
+    const int ncalls = vit_droppath_calls(t, drop_path_rate, &keep);
+    t->scales = (float*)t->save.take((size_t)ncalls * n_img * 4);
+    if (!t->scales) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small");
+    for (int k = 0; k < ncalls; ++k)
+      T_RUN(launch_scale_copy(masks_dev + (size_t)k * n_img, t->scales + (size_t)k * n_img, n_img, 1.0f / keep[k], t->st));
+  }
+  return vit_forward_impl(t, x_nchw_dev, feat_dev);
+}
+
+extern "C" int fsvit_vit_train_backward(fsvit_vit_trainer* t, const fsvit_param* params, int n_params, const float* dfeat_dev, void* stream) {
+  if (!t || !params || !dfeat_dev) return fsvit_set_error(FSVIT_ERR_ARG, "bad argument");
+  if (!t->save.base || t->save.dry) return fsvit_set_error(FSVIT_ERR_ARG, "train_backward called without a preceding train_forward");
+  t->P.clear();
+  for (int i = 0; i < n_params; ++i) t->P[params[i].name] = &params[i];
+  t->st = (hipStream_t)stream;
+  t->tmp.off = 0;
+  return vit_backward_impl(t, dfeat_dev);
+}
+
 // ================================================================ C ABI
 extern "C" int fsvit_visformer_trainer_create(const fsvit_visformer_cfg* cfg, int dtype, fsvit_visformer_trainer** out) {
   if (!cfg || !out) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");

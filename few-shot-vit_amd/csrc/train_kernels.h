@@ -49,4 +49,15 @@ int launch_proto_head_bwd(const float* feat_shot, const float* feat_query, const
 int launch_proto_head_sqr_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
                           float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s);
 
+// ---- ViT / DeiT training (deit.py): LayerNorm with kept row statistics, token assembly, the final norm on the cls row
+int launch_ln_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M, int D, float eps, int dtype, hipStream_t s);
+int ln_bwd_blocks(int M);
+int launch_ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const void* add, void* dx, float* partial,
+                  float* dgamma, float* dbeta, int M, int D, int dtype, hipStream_t s);
+int launch_vit_assemble(const void* zpe, const float* cls, const float* pos, void* tokens, int B, int S, int D, int dtype, hipStream_t s);
+int launch_vit_patch_rows(const void* dtok, void* dzpe, int B, int S, int D, int dtype, hipStream_t s);
+int launch_vit_cls_ln_fwd(const void* tokens, const float* gamma, const float* beta, float* feat, float* mean, float* rstd, int B, int S, int D, float eps, int dtype,
+                          hipStream_t s);
+int launch_vit_cls_ln_bwd(const float* dfeat, const void* tokens, const float* mean, const float* rstd, const float* gamma, void* dtok, float* partial, float* dgamma,
+                          float* dbeta, int B, int S, int D, int dtype, hipStream_t s);
 }  // namespace fsvit

@@ -505,6 +505,150 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdItem* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------ ViT / DeiT training (deit.py:61-78, 139-218)
+// nn.LayerNorm in train mode: y = (x - mean) * rstd * gamma + beta (biased variance, deit.py:68,73,170), row statistics kept for the backward.
+// One wave per row (D <= 2048), 4 rows per workgroup.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_train_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int M, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const T* xr = x + (size_t)row * D;
+  float s = 0.f, ss = 0.f;
+  for (int d = lane * 4; d < D; d += 256) { const f32x4 v = load4<T>(xr + d); s += v[0] + v[1] + v[2] + v[3]; ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+  const float mu = s / D;
+  float var = ss / D - mu * mu;
+  var = var < 0.f ? 0.f : var;
+  const float rs = 1.0f / sqrtf(var + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  T* yr = y + (size_t)row * D;
+  for (int d = lane * 4; d < D; d += 256) {
+    const f32x4 v = (load4<T>(xr + d) - mu) * rs * *reinterpret_cast<const f32x4*>(gamma + d) + *reinterpret_cast<const f32x4*>(beta + d);
+    store4<T>(yr + d, v);
+  }
+}
+
+// LayerNorm backward: dx = rstd * (g - mean_d(g) - xhat * mean_d(g * xhat)), g = dy * gamma (+ add, the residual's gradient);
+// partial[blk][0][d] = sum over the block's rows of dy, [1][d] of dy * xhat  (-> dbeta, dgamma by ln_param_grad_kernel).
+// gridDim.x blocks of 4 waves, block b owns rows b*R .. (R = rows per block), each wave every 4th of them.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma, const T* __restrict__ add,
+                                                     T* __restrict__ dx, float* __restrict__ partial, int M, int D, int rows_per_blk) {
+  extern __shared__ float red[];                       // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* mine = red + (size_t)wave * 2 * D;
+  for (int d = lane; d < 2 * D; d += 64) mine[d] = 0.f;
+  const long r0 = (long)blockIdx.x * rows_per_blk;
+  for (long row = r0 + wave; row < r0 + rows_per_blk && row < M; row += 4) {
+    const T* dyr = dy + (size_t)row * D;
+    const T* xr = x + (size_t)row * D;
+    const float mu = mean[row], rs = rstd[row];
+    float c1 = 0.f, c2 = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+      const f32x4 g = load4<T>(dyr + d) * *reinterpret_cast<const f32x4*>(gamma + d);
+      const f32x4 xh = (load4<T>(xr + d) - mu) * rs;
+      c1 += g[0] + g[1] + g[2] + g[3];
+      c2 += g[0] * xh[0] + g[1] * xh[1] + g[2] * xh[2] + g[3] * xh[3];
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); }
+    c1 /= D; c2 /= D;
+    for (int d = lane * 4; d < D; d += 256) {
+      const f32x4 dyv = load4<T>(dyr + d);
+      const f32x4 g = dyv * *reinterpret_cast<const f32x4*>(gamma + d);
+      const f32x4 xh = (load4<T>(xr + d) - mu) * rs;
+      f32x4 v = (g - c1 - xh * c2) * rs;
+      if (add) v += load4<T>(add + (size_t)row * D + d);
+      store4<T>(dx + (size_t)row * D + d, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { mine[d + e] += dyv[e]; mine[D + d + e] += dyv[e] * xh[e]; }
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < 2 * D; d += 256)
+    partial[(size_t)blockIdx.x * 2 * D + d] = red[d] + red[2 * D + d] + red[4 * D + d] + red[6 * D + d];
+}
+
+// dbeta[d] = sum_blk partial[blk][0][d], dgamma[d] = sum_blk partial[blk][1][d]  (fp64 accumulation, one wave per channel)
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ partial, int nblk, int D, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;
+  double s0, s1;
+  bn_partial_sums(partial, nblk, D, c, sub, s0, s1);
+  if (c >= D || sub) return;
+  if (dbeta) dbeta[c] = (float)s0;
+  if (dgamma) dgamma[c] = (float)s1;
+}
+
+// tokens[b][0] = cls + pos[0];  tokens[b][1 + i] = zpe[b * np + i] + pos[1 + i]   (deit.py:196-202)
+template <typename T>
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const T* __restrict__ zpe, const float* __restrict__ cls, const float* __restrict__ pos,
+                                                           T* __restrict__ tokens, int B, int S, int D) {
+  const size_t total = (size_t)B * S * (D / 4);
+  GS_LOOP(idx, total) {
+    const int d = (int)(idx % (D / 4)) * 4;
+    const size_t r = idx / (D / 4);
+    const int s = (int)(r % S);
+    const size_t b = r / S;
+    f32x4 v = *reinterpret_cast<const f32x4*>(pos + (size_t)s * D + d);
+    if (s == 0) v += *reinterpret_cast<const f32x4*>(cls + d);
+    else v += load4<T>(zpe + (b * (S - 1) + s - 1) * D + d);
+    store4<T>(tokens + r * D + d, v);
+  }
+}
+// dzpe[b * np + i] = dtok[b][1 + i]
+template <typename T>
+__global__ __launch_bounds__(256) void vit_patch_rows_kernel(const T* __restrict__ dtok, T* __restrict__ dzpe, int B, int S, int D) {
+  const size_t total = (size_t)B * (S - 1) * (D / 4);
+  GS_LOOP(idx, total) {
+    const int d = (int)(idx % (D / 4)) * 4;
+    const size_t r = idx / (D / 4);
+    const size_t b = r / (S - 1), i = r % (S - 1);
+    store4<T>(dzpe + r * D + d, load4<T>(dtok + (b * S + 1 + i) * D + d));
+  }
+}
+// final norm on the cls row (deit.py:204-205: x = norm(x); return x[:, 0]): feat[b] = LN(tokens[b][0]) * gamma + beta, fp32; statistics kept
+template <typename T>
+__global__ __launch_bounds__(64) void vit_cls_ln_fwd_kernel(const T* __restrict__ tokens, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ feat, float* __restrict__ mean, float* __restrict__ rstd, int S, int D, float eps) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const T* xr = tokens + (size_t)b * S * D;
+  float s = 0.f, ss = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = to_f32<T>(xr[d]); s += v; ss += v * v; }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+  const float mu = s / D;
+  float var = ss / D - mu * mu;
+  var = var < 0.f ? 0.f : var;
+  const float rs = 1.0f / sqrtf(var + eps);
+  if (lane == 0) { mean[b] = mu; rstd[b] = rs; }
+  for (int d = lane; d < D; d += 64) feat[(size_t)b * D + d] = (to_f32<T>(xr[d]) - mu) * rs * gamma[d] + beta[d];
+}
+// its backward: dtok[b][0] = LN backward of dfeat[b]; every other row of dtok is zero.  partial[b][2][D] for dgamma / dbeta (one block per image).
+template <typename T>
+__global__ __launch_bounds__(64) void vit_cls_ln_bwd_kernel(const float* __restrict__ dfeat, const T* __restrict__ tokens, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma, T* __restrict__ dtok,
+                                                            float* __restrict__ partial, int S, int D) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const T* xr = tokens + (size_t)b * S * D;
+  const float* dyr = dfeat + (size_t)b * D;
+  const float mu = mean[b], rs = rstd[b];
+  float c1 = 0.f, c2 = 0.f;
+  for (int d = lane; d < D; d += 64) { const float g = dyr[d] * gamma[d], xh = (to_f32<T>(xr[d]) - mu) * rs; c1 += g; c2 += g * xh; }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); }
+  c1 /= D; c2 /= D;
+  for (int d = lane; d < D; d += 64) {
+    const float xh = (to_f32<T>(xr[d]) - mu) * rs;
+    dtok[(size_t)b * S * D + d] = from_f32<T>((dyr[d] * gamma[d] - c1 - xh * c2) * rs);
+    partial[((size_t)b * 2 + 0) * D + d] = dyr[d];
+    partial[((size_t)b * 2 + 1) * D + d] = dyr[d] * xh;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == 0) { CALL_F32; } else { CALL_BF16; } } while (0)
 
@@ -671,6 +815,53 @@ int launch_sgd_multi(const void* items_dev, int n_items, size_t max_numel, float
 int launch_sgd(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, int first, hipStream_t s) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(sgd_kernel, dim3(gs_grid(n)), dim3(256), 0, s, p, g, buf, n, lr, momentum, wd, first);
+  return (int)hipGetLastError();
+}
+
+int launch_ln_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M, int D, float eps, int dtype, hipStream_t s) {
+  if (M <= 0) return 0;
+  if (D % 4) return (int)hipErrorInvalidValue;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(ln_train_fwd_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps),
+             hipLaunchKernelGGL(ln_train_fwd_kernel<bf16>, dim3((M + 3) / 4), dim3(256), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, M, D, eps));
+  return (int)hipGetLastError();
+}
+int ln_bwd_blocks(int M) { int nb = (M + 63) / 64; return nb > 1024 ? 1024 : (nb < 1 ? 1 : nb); }
+// partial: ln_bwd_blocks(M) * 2 * D floats; dgamma / dbeta may be null
+int launch_ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const void* add, void* dx, float* partial,
+                  float* dgamma, float* dbeta, int M, int D, int dtype, hipStream_t s) {
+  if (M <= 0) return 0;
+  if (D % 4 || (size_t)8 * D * 4 > 64 * 1024) return (int)hipErrorInvalidValue;
+  const int nb = ln_bwd_blocks(M), rpb = (M + nb - 1) / nb;
+  const size_t lds = (size_t)8 * D * sizeof(float);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), lds, s, (const float*)dy, (const float*)x, mean, rstd, gamma, (const float*)add, (float*)dx, partial, M, D, rpb),
+             hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(nb), dim3(256), lds, s, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (const bf16*)add, (bf16*)dx, partial, M, D, rpb));
+  hipLaunchKernelGGL(ln_param_grad_kernel, dim3((D + 3) / 4), dim3(256), 0, s, partial, nb, D, dgamma, dbeta);
+  return (int)hipGetLastError();
+}
+int launch_vit_assemble(const void* zpe, const float* cls, const float* pos, void* tokens, int B, int S, int D, int dtype, hipStream_t s) {
+  const size_t total = (size_t)B * S * (D / 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(vit_assemble_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, (const float*)zpe, cls, pos, (float*)tokens, B, S, D),
+             hipLaunchKernelGGL(vit_assemble_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, (const bf16*)zpe, cls, pos, (bf16*)tokens, B, S, D));
+  return (int)hipGetLastError();
+}
+int launch_vit_patch_rows(const void* dtok, void* dzpe, int B, int S, int D, int dtype, hipStream_t s) {
+  const size_t total = (size_t)B * (S - 1) * (D / 4);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(vit_patch_rows_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, (const float*)dtok, (float*)dzpe, B, S, D),
+             hipLaunchKernelGGL(vit_patch_rows_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, (const bf16*)dtok, (bf16*)dzpe, B, S, D));
+  return (int)hipGetLastError();
+}
+int launch_vit_cls_ln_fwd(const void* tokens, const float* gamma, const float* beta, float* feat, float* mean, float* rstd, int B, int S, int D, float eps, int dtype,
+                          hipStream_t s) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL(vit_cls_ln_fwd_kernel<float>, dim3(B), dim3(64), 0, s, (const float*)tokens, gamma, beta, feat, mean, rstd, S, D, eps),
+             hipLaunchKernelGGL(vit_cls_ln_fwd_kernel<bf16>, dim3(B), dim3(64), 0, s, (const bf16*)tokens, gamma, beta, feat, mean, rstd, S, D, eps));
+  return (int)hipGetLastError();
+}
+// dtok must be zeroed by the caller (only the cls rows are written); partial: B * 2 * D floats
+int launch_vit_cls_ln_bwd(const float* dfeat, const void* tokens, const float* mean, const float* rstd, const float* gamma, void* dtok, float* partial, float* dgamma,
+                          float* dbeta, int B, int S, int D, int dtype, hipStream_t s) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL(vit_cls_ln_bwd_kernel<float>, dim3(B), dim3(64), 0, s, dfeat, (const float*)tokens, mean, rstd, gamma, (float*)dtok, partial, S, D),
+             hipLaunchKernelGGL(vit_cls_ln_bwd_kernel<bf16>, dim3(B), dim3(64), 0, s, dfeat, (const bf16*)tokens, mean, rstd, gamma, (bf16*)dtok, partial, S, D));
+  hipLaunchKernelGGL(ln_param_grad_kernel, dim3((D + 3) / 4), dim3(256), 0, s, partial, B, D, dgamma, dbeta);
   return (int)hipGetLastError();
 }
 

@@ -303,6 +303,76 @@ class VisformerTrainer:
         self._keep = None
 
 
+class VitTrainer:
+    """Train-mode ViT / DeiT (deit.py:61-78, 139-218): forward with LayerNorm row statistics + DropPath and saved activations, backward to all
+    parameter gradients - the ViT counterpart of VisformerTrainer, same calling convention."""
+
+    def __init__(self, cfg: dict, numerics: str = None, device=None):
+        self.lib = _lib.load()
+        numerics = numerics or default_numerics()
+        if numerics not in DTYPES:
+            raise ValueError(f'unknown numerics mode {numerics!r} (bf16 | parity)')
+        if DTYPES[numerics] == _lib.F16:
+            raise NotImplementedError("fsvit: the 'f16' numerics mode is an eval mode (no loss scaling is built); train in 'bf16' or 'parity'")
+        self.dtype = DTYPES[numerics]
+        self.device = torch.device(device if device is not None else 'cuda')
+        if self.device.type != 'cuda':
+            raise RuntimeError('VitTrainer needs a GPU device (no CPU fallback)')
+        self.cfg = dict(cfg)
+        self.out_dim = cfg['embed_dim']
+        c = VitEngine._make_cfg(None, cfg)
+        h = C.c_void_p()
+        _lib.check(self.lib.fsvit_vit_trainer_create(C.byref(c), self.dtype, C.byref(h)))
+        self.h = h
+        self._ws = None
+        self._keep = None
+        self.generation = 0
+
+    def __del__(self):
+        h, self.h = getattr(self, 'h', None), None
+        if h:
+            try:
+                self.lib.fsvit_vit_trainer_destroy(h)
+            except Exception:
+                pass
+
+    def n_droppath_calls(self, rate: float) -> int:
+        return int(self.lib.fsvit_vit_trainer_droppath_calls(self.h, float(rate)))
+
+    def forward(self, tensors: Dict[str, torch.Tensor], x: torch.Tensor, drop_path_rate: float = 0.0, masks: Optional[torch.Tensor] = None) -> torch.Tensor:
+        _require_cuda(x)
+        x = x.contiguous().float()
+        B = x.shape[0]
+        arr, keep = VisformerTrainer._table(tensors, None)
+        need = self.lib.fsvit_vit_trainer_workspace_bytes(self.h, arr, len(tensors), B, float(drop_path_rate))
+        if need == 0:
+            _lib.check(_lib.ERR_KEY if 'missing' in self.lib.fsvit_last_error().decode() else _lib.ERR_ARG)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        feat = torch.empty(B, self.out_dim, dtype=torch.float32, device=x.device)
+        if masks is not None:
+            masks = masks.contiguous().float()
+        with torch.cuda.device(x.device):
+            _lib.check(self.lib.fsvit_vit_train_forward(self.h, arr, len(tensors), _ptr(x), B, x.shape[2], x.shape[3], float(drop_path_rate), _ptr(masks),
+                                                        _ptr(feat), _ptr(self._ws), self._ws.numel(), _stream_ptr(x.device)))
+        self._keep = (x, masks)
+        self.generation += 1
+        return feat
+
+    def backward(self, tensors: Dict[str, torch.Tensor], grads: Dict[str, torch.Tensor], dfeat: torch.Tensor, dtokens=None):
+        _require_cuda(dfeat)
+        if self._keep is None:
+            raise RuntimeError('fsvit: backward without a pending train-mode forward (the saved activations were already consumed)')
+        if dtokens is not None:
+            raise NotImplementedError('fsvit: the ViT trainer returns the cls feature only')
+        dfeat = dfeat.contiguous().float()
+        arr, keep = VisformerTrainer._table(tensors, grads)
+        with torch.cuda.device(dfeat.device):
+            _lib.check(self.lib.fsvit_vit_train_backward(self.h, arr, len(tensors), _ptr(dfeat), _stream_ptr(dfeat.device)))
+        self._keep = None
+
+
 class VitEngine(_EncoderEngine):
     """cfg: dict(img_size, patch_size, embed_dim, depth, num_heads[, mlp_ratio, ln_eps]) (deit.py:142-144)."""
     _fn = dict(create='fsvit_vit_create', destroy='fsvit_vit_destroy', out_dim='fsvit_vit_out_dim',

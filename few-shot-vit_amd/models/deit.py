@@ -69,8 +69,10 @@ class VisionTransformer(nn.Module):
             elif isinstance(m, nn.LayerNorm):
                 nn.init.constant_(m.bias, 0)
                 nn.init.constant_(m.weight, 1.0)
+        self.drop_path_rate = float(drop_path_rate)
         self._engine = None
         self._engine_key = None
+        self._trainer = None
 
     def engine(self):
         from ..engine import VitEngine
@@ -84,13 +86,36 @@ class VisionTransformer(nn.Module):
             self._engine_key = key
         return self._engine
 
-    def forward(self, x):
-        """[B,3,img,img] fp32 -> [B,embed_dim] = norm(tokens)[:, 0] (deit.py:196-213), eval mode."""
-        if self.training:
-            raise NotImplementedError('fsvit: train-mode ViT (dropout / DropPath / backward) is not built yet; call .eval()')
+    def trainer(self):
+        from ..engine import VitTrainer
+        dev = self.pos_embed.device
+        if dev.type != 'cuda':
+            raise RuntimeError('fsvit: the encoder lives on %s; the HIP trainer needs an MI355X (no CPU fallback)' % dev)
+        if self._trainer is None or self._trainer.device != dev:
+            self._trainer = VitTrainer(self.cfg, numerics=self.numerics, device=dev)
+        return self._trainer
+
+    def draw_droppath_masks(self, n_img, device):
+        """timm DropPath (deit.py:70,76-77): floor(keep_prob + U[0,1)) per sample, drawn per block in forward order (attention branch, then Mlp)."""
+        masks = []
+        for r in torch.linspace(0, self.drop_path_rate, self.cfg['depth']).tolist():
+            if r > 0:
+                for _ in range(2):
+                    masks.append(torch.floor((1.0 - r) + torch.rand(n_img, device=device)))
+        return torch.stack(masks) if masks else None
+
+    def forward(self, x, droppath_masks=None):
+        """[B,3,img,img] fp32 -> [B,embed_dim] = norm(tokens)[:, 0] (deit.py:196-213).  eval: packed engine; train: LayerNorm / attention / Mlp with
+        saved activations, DropPath, and a backward through the HIP trainer (`droppath_masks` overrides the random draws)."""
         assert x.shape[-2] == self.img_size and x.shape[-1] == self.img_size, \
             f"Input image size ({x.shape[-2]}*{x.shape[-1]}) doesn't match model ({self.img_size}*{self.img_size})."
-        return self.engine().forward(x)
+        if not self.training:
+            return self.engine().forward(x)
+        from ..autograd import VisformerTrainFn
+        named = [(k, p) for k, p in self.named_parameters()]
+        names = tuple(k for k, _ in named)
+        masks = droppath_masks if droppath_masks is not None else self.draw_droppath_masks(x.shape[0], x.device)
+        return VisformerTrainFn.apply(x, self.trainer(), names, {}, self.drop_path_rate, masks, *[p for _, p in named])
 
 
 def _factory(name, **fixed):

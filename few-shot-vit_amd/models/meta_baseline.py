@@ -35,7 +35,7 @@ class MetaBaseline(nn.Module):
         """The meta-tuning step's forward (train_meta.py:167): one encoder pass over shot + query images of all
         episodes (so BatchNorm sees the whole batch, meta_baseline.py:31), then the differentiable head ('cos' or 'sqr')."""
         if not hasattr(self.encoder, 'trainer'):
-            raise NotImplementedError('fsvit: the training path is built for the Visformer encoders')
+            raise NotImplementedError('fsvit: the training path is built for the Visformer and ViT / DeiT encoders')
         from ..autograd import ProtoHeadFn
         E, way, shot = x_shot.shape[:3]
         Q = x_query.shape[1]

@@ -256,6 +256,22 @@ int fsvit_visformer_train_forward(fsvit_visformer_trainer* t, const fsvit_param*
 /* dfeat_dev [n_img,out_dim] fp32 -> every params[i].grad */
 int fsvit_visformer_train_backward(fsvit_visformer_trainer* t, const fsvit_param* params, int n_params, const float* dfeat_dev,
                                    void* stream);
+/* ---- ViT / DeiT training step (test_phase/models/deit.py:61-78 Block, :139-218 VisionTransformer in train mode; what loss.backward() does for
+ * the DeiT encoders in meta_tuning_sun_m/train_meta.py:161-177).  Same contract as the Visformer trainer above: parameters stay in the caller's
+ * fp32 device tensors (fsvit_param table with the reference's state-dict names: cls_token, pos_embed, patch_embed.proj.*, blocks.N.{norm1,norm2}.*,
+ * blocks.N.attn.{qkv,proj}.*, blocks.N.mlp.{fc1,fc2}.*, norm.*), train_forward saves the activations in ws_dev, train_backward overwrites every
+ * params[i].grad.  DropPath: 2 calls per block whose rate linspace(0, drop_path_rate, depth)[i] is non-zero, masks_dev [calls][n_img] of 0 / 1 in
+ * forward order (fsvit_vit_trainer_droppath_calls); Dropout rates are 0 in every shipped factory and are not built.  dtype FSVIT_F32 or FSVIT_BF16
+ * (the fp32 attention backward keeps a head in LDS: <= ~110 tokens; bf16 covers the 197-token factories). */
+typedef struct fsvit_vit_trainer fsvit_vit_trainer;
+int fsvit_vit_trainer_create(const fsvit_vit_cfg* cfg, int dtype, fsvit_vit_trainer** out);
+void fsvit_vit_trainer_destroy(fsvit_vit_trainer* t);
+int fsvit_vit_trainer_droppath_calls(const fsvit_vit_trainer* t, float drop_path_rate);
+size_t fsvit_vit_trainer_workspace_bytes(fsvit_vit_trainer* t, const fsvit_param* params, int n_params, int n_img, float drop_path_rate);
+int fsvit_vit_train_forward(fsvit_vit_trainer* t, const fsvit_param* params, int n_params, const float* x_nchw_dev, int n_img, int img_h, int img_w,
+                            float drop_path_rate, const float* masks_dev, float* feat_dev, void* ws_dev, size_t ws_bytes, void* stream);
+int fsvit_vit_train_backward(fsvit_vit_trainer* t, const fsvit_param* params, int n_params, const float* dfeat_dev, void* stream);
+
 /* Backward of fsvit_proto_head, method 'cos' (meta_baseline.py:33-47): dlogits [E,Q,way] -> dfeat_shot [E,way,shot,D],
  * dfeat_query [E,Q,D], dtemp_per_episode [E] (sum it for the learnable temperature, meta_baseline.py:20-21). */
 int fsvit_proto_head_backward(const float* feat_shot_dev, const float* feat_query_dev, const float* dlogits_dev, int E, int way,

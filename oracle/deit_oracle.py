@@ -72,8 +72,12 @@ def attention(sd, x, p, num_heads):
     return F.linear(x, sd[p + 'proj.weight'], sd[p + 'proj.bias'])
 
 
-def deit_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, cfg: DeitCfg, prefix: str = '', taps: Optional[dict] = None):
-    """VisionTransformer.forward_features, deit.py:196-213 (eval: dropout / DropPath are identity)."""
+def deit_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, cfg: DeitCfg, prefix: str = '', taps: Optional[dict] = None,
+                 drop_path_rate: float = 0.0, droppath_masks: Optional[list] = None):
+    """VisionTransformer.forward_features, deit.py:196-213 (eval: dropout / DropPath are identity).
+    Train mode = drop_path_rate > 0 with `droppath_masks`: per block i with rate r_i = linspace(0, rate, depth)[i] > 0 (deit.py:161) two [B]
+    masks of 0 / 1 (attention branch, then Mlp), the branch is scaled by mask / (1 - r_i) (timm DropPath, deit.py:70,76-77); dropout rates are 0
+    in every factory.  Under torch.enable_grad() the autograd of this function is the reference gradient."""
     if prefix:
         sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
     assert x.shape[-2] == cfg.img_size and x.shape[-1] == cfg.img_size, \
@@ -84,11 +88,22 @@ def deit_forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, cfg: DeitCfg, pre
     x = torch.cat((sd['cls_token'].expand(B, -1, -1), x), dim=1) + sd['pos_embed']                        # :200-202
     if taps is not None:
         taps['embed'] = x
+    rates = torch.linspace(0, drop_path_rate, cfg.depth).tolist()
+    mi = 0
+
+    def dp(branch, r):
+        nonlocal mi
+        if r == 0.0 or droppath_masks is None:
+            return branch
+        m = droppath_masks[mi].to(branch.dtype).view(-1, 1, 1) / (1.0 - r)
+        mi += 1
+        return branch * m
+
     for i in range(cfg.depth):                                                                            # Block.forward :75-78
         b = f'blocks.{i}.'
-        x = x + attention(sd, F.layer_norm(x, (D,), sd[b + 'norm1.weight'], sd[b + 'norm1.bias'], cfg.ln_eps), b + 'attn.', cfg.num_heads)
+        x = x + dp(attention(sd, F.layer_norm(x, (D,), sd[b + 'norm1.weight'], sd[b + 'norm1.bias'], cfg.ln_eps), b + 'attn.', cfg.num_heads), rates[i])
         h = F.linear(F.layer_norm(x, (D,), sd[b + 'norm2.weight'], sd[b + 'norm2.bias'], cfg.ln_eps), sd[b + 'mlp.fc1.weight'], sd[b + 'mlp.fc1.bias'])
-        x = x + F.linear(F.gelu(h), sd[b + 'mlp.fc2.weight'], sd[b + 'mlp.fc2.bias'])
+        x = x + dp(F.linear(F.gelu(h), sd[b + 'mlp.fc2.weight'], sd[b + 'mlp.fc2.bias']), rates[i])
         if taps is not None:
             taps[f'blocks.{i}'] = x
     x = F.layer_norm(x, (D,), sd['norm.weight'], sd['norm.bias'], cfg.ln_eps)                             # :212

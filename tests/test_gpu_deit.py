@@ -122,3 +122,117 @@ def test_deit_small_full_episode_224():
     assert e_par <= 1e-3
     assert e_f16 <= 2e-3 and e_bf16 <= 1.2e-2            # measured 9.9e-4 / 6.1e-3 (2x)
     assert agree['parity'] == 1.0 and agree['f16'] >= 0.97 and agree['bf16'] >= 0.9
+
+
+def _vit_train_check(cfg_kwargs, B, numerics, drop, tol_logit, tol_grad, seed=3):
+    """One train-mode forward + backward of a ViT through the HIP trainer vs torch.autograd of the oracle (same DropPath masks)."""
+    from fewshot_vit_amd.models.deit import VisionTransformer
+    from fewshot_vit_amd import synthetic
+    from oracle import deit_oracle as do
+    cfg = do.DeitCfg(cfg_kwargs['img_size'], cfg_kwargs['patch_size'], cfg_kwargs['embed_dim'], cfg_kwargs['depth'], cfg_kwargs['num_heads'])
+    m = VisionTransformer(**cfg_kwargs, drop_path_rate=drop, numerics=numerics)
+    sd = synthetic.procedural_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    g = torch.Generator().manual_seed(seed)
+    for k in sd:                                       # non-trivial LayerNorm affine / biases so that their gradients are exercised
+        if k.endswith('.bias') or k.endswith('norm1.weight') or k.endswith('norm2.weight') or k == 'norm.weight':
+            sd[k] = sd[k] + 0.1 * torch.randn(sd[k].shape, generator=g)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    x = torch.randn(B, 3, cfg.img_size, cfg.img_size, generator=g)
+    w = torch.randn(B, cfg.embed_dim, generator=g)
+    rates = torch.linspace(0, drop, cfg.depth).tolist()
+    masks = [torch.floor((1.0 - r) + torch.rand(B, generator=g)) for r in rates if r > 0 for _ in range(2)]
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = do.deit_forward(params, x, cfg, drop_path_rate=drop, droppath_masks=masks if masks else None)
+    (ref * w).sum().backward()
+    feat = m(x.cuda(), droppath_masks=torch.stack(masks).cuda() if masks else None)
+    (feat * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    err = (feat.detach().cpu() - ref.detach()).abs().max().item()
+    worst, wk = 0.0, None
+    for k, p in m.named_parameters():
+        r = params[k].grad
+        rel = ((p.grad.cpu() - r).norm() / (r.norm() + 1e-12)).item()
+        if rel > worst:
+            worst, wk = rel, k
+    print(f'[{numerics} drop={drop}] ViT {cfg_kwargs} train step: max|dfeat| = {err:.3e}, worst grad rel err = {worst:.3e} ({wk})')
+    assert err <= tol_logit
+    assert worst <= tol_grad, wk
+
+
+@pytest.mark.parametrize('numerics,drop,tl,tg', [('parity', 0.0, 2e-5, 2e-5), ('parity', 0.3, 2e-5, 2e-5), ('bf16', 0.3, 6e-2, 4e-2)])
+def test_vit_train_step_vs_oracle_autograd_small(numerics, drop, tl, tg):
+    """deit.py:61-78, 139-218 in train mode: LayerNorm / qkv / attention / proj / Mlp / DropPath forward and every parameter gradient (cls_token,
+    pos_embed, patch embedding, 4 blocks, final norm) against torch.autograd of the oracle.  37 tokens, so the fp32 attention backward fits."""
+    _vit_train_check(dict(img_size=36, patch_size=6, embed_dim=128, depth=4, num_heads=4), 6, numerics, drop, tl, tg)
+
+
+def test_vit_train_step_deit_tokens_bf16():
+    """A DeiT-shaped layer stack (197 tokens, head dim 64, patch 16) in the bf16 training mode: the MFMA attention backward with 224 resident keys
+    and the direct weight-gradient kernels; 2 blocks keep the fp32 oracle quick."""
+    _vit_train_check(dict(img_size=224, patch_size=16, embed_dim=384, depth=2, num_heads=6), 4, 'bf16', 0.1, 6e-2, 2.5e-2)
+
+
+def test_vit_train_step_vs_reference_golden(golden_dir):
+    """The HIP ViT trainer (parity mode) against the REFERENCE's own VisionTransformer.train() step - forward with the recorded DropPath masks,
+    loss.backward() (tests/golden/make_deit_train_golden.py): feature, sampled gradients elementwise, the norm of all 54 gradients."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_deit_train_golden as mk
+    from fewshot_vit_amd.models.deit import VisionTransformer
+    z = np.load(os.path.join(golden_dir, 'deit_train_step.npz'))
+    m = VisionTransformer(**mk.CFG, drop_path_rate=mk.DROP, numerics='parity')
+    sd, _ = mk.perturbed_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    feat = m(torch.from_numpy(z['x']).cuda(), droppath_masks=torch.from_numpy(z['masks']).cuda())
+    (feat * torch.from_numpy(z['w']).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert np.abs(feat.detach().cpu().numpy() - z['feat']).max() <= 2e-5
+    grads = {k: p.grad.cpu() for k, p in m.named_parameters()}
+    worst = 0.0
+    for k in z.files:
+        if k.startswith('grad.'):
+            e = np.abs(grads[k[5:]].numpy() - z[k]).max() / max(1.0, np.abs(z[k]).max())
+            worst = max(worst, e)
+            assert e <= 2e-5, k
+        if k.startswith('gnorm.'):
+            assert abs(float(grads[k[6:]].double().norm()) - float(z[k])) <= 2e-5 * max(1.0, float(z[k])), k
+    print(f'ViT train step vs reference golden: worst sampled gradient error {worst:.2e}')
+
+
+def test_meta_tuning_loop_with_deit_encoder():
+    """train_meta.py:155-177 with a ViT encoder: model.train(); CE on the cosine-prototype logits; loss.backward(); SGD step - the loss falls on one
+    batch of episodes, and the eval engine repacks from the updated weights."""
+    from fewshot_vit_amd import models, synthetic, utils
+    from fewshot_vit_amd.models import register
+    from fewshot_vit_amd.models.deit import VisionTransformer
+    from fewshot_vit_amd.utils import few_shot as fs
+    register('_test_vit_36')(lambda **kw: VisionTransformer(img_size=36, patch_size=6, embed_dim=128, depth=3, num_heads=4, **kw))
+    m = models.make('meta-baseline', encoder='_test_vit_36', encoder_args={'numerics': 'bf16', 'drop_path_rate': 0.1})
+    sd = synthetic.procedural_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    x = synthetic.synthetic_episodes(4, 2, 5, 1, 3, img=36)
+    xs, xq = fs.split_shot_query(x, 5, 1, 3, 2)
+    label = fs.make_nk_label(5, 3, 2).cuda()
+    m.eval()
+    with torch.no_grad():
+        before = m(xs.cuda(), xq.cuda()).clone()
+    opt, _ = utils.make_optimizer(m.parameters(), 'sgd', lr=0.05, weight_decay=5e-4)
+    m.train()
+    torch.manual_seed(0)
+    losses = []
+    for _ in range(8):
+        logits = m(xs.cuda(), xq.cuda()).view(-1, 5)
+        loss = torch.nn.functional.cross_entropy(logits, label)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    print('meta-tuning with a ViT encoder, loss per step:', [round(v, 4) for v in losses])
+    assert losses[-1] < losses[0] - 0.02
+    m.eval()
+    with torch.no_grad():
+        after = m(xs.cuda(), xq.cuda())
+    assert float((after - before).abs().max()) > 1e-3            # the packed eval engine followed the update

@@ -262,3 +262,26 @@ def test_oracle_train_step_matches_reference(golden_dir):
         elif k.startswith('bn.'):
             np.testing.assert_allclose(stats[k[len('bn.encoder.'):]].numpy(), z[k], rtol=2e-4, atol=2e-5, err_msg=k)
     assert n == 60
+
+
+def test_deit_train_step_oracle_vs_reference_golden(golden_dir):
+    """oracle.deit_oracle.deit_forward in train mode (DropPath masks, torch.autograd) vs the reference's own VisionTransformer.train() step
+    (tests/golden/make_deit_train_golden.py): feature, a sample of gradients elementwise, the norm of every gradient."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_deit_train_golden as mk
+    from oracle import deit_oracle as do
+    z = np.load(os.path.join(golden_dir, 'deit_train_step.npz'))
+    cfg = do.DeitCfg(mk.CFG['img_size'], mk.CFG['patch_size'], mk.CFG['embed_dim'], mk.CFG['depth'], mk.CFG['num_heads'])
+    sd, _ = mk.perturbed_state_dict(do.state_dict_shapes(cfg))
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    masks = [torch.from_numpy(m) for m in z['masks']]
+    feat = do.deit_forward(params, torch.from_numpy(z['x']), cfg, drop_path_rate=mk.DROP, droppath_masks=masks)
+    (feat * torch.from_numpy(z['w'])).sum().backward()
+    assert np.abs(feat.detach().numpy() - z['feat']).max() <= 1e-5
+    for k in z.files:
+        if k.startswith('grad.'):
+            g = params[k[5:]].grad.numpy()
+            assert np.abs(g - z[k]).max() <= 1e-5 * max(1.0, np.abs(z[k]).max()), k
+        if k.startswith('gnorm.'):
+            assert abs(float(params[k[6:]].grad.double().norm()) - float(z[k])) <= 1e-5 * max(1.0, float(z[k])), k
