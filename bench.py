@@ -281,14 +281,16 @@ def train_main(args, rank, world, dev):
     """BASELINE configs[2]: one meta-tuning step = model.train() forward, CE, backward, (grad all-reduce), SGD step."""
     from fewshot_vit_amd import models, synthetic, utils, parallel
     from fewshot_vit_amd.utils import few_shot as fs
-    model = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={'numerics': args.numerics, 'drop_path_rate': 0.5})
+    vis = args.model == 'visformer_micro_80'
+    flop_per_image, img = MODELS[args.model]
+    model = models.make('meta-baseline', encoder=args.model, encoder_args={'numerics': args.numerics, 'drop_path_rate': 0.5 if vis else 0.1})
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = synthetic.synthetic_checkpoint_sd(shapes, calib='visformer_micro_80')
+    sd = synthetic.synthetic_checkpoint_sd(shapes, calib='visformer_micro_80' if vis else None)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).train()
     opt, _ = utils.make_optimizer(model.parameters(), 'sgd', lr=0.001, weight_decay=5e-4)
     way, shot, query, E = 10, 5, 5, args.train_episodes
-    x_shot, x_query = device_episodes(999 + rank, E, way, shot, query, dev, 80)
+    x_shot, x_query = device_episodes(999 + rank, E, way, shot, query, dev, img)
     label = fs.make_nk_label(way, query, E).to(dev)
 
     def step():
@@ -312,21 +314,23 @@ def train_main(args, rank, world, dev):
     if rank == 0:
         imgs = way * (shot + query)
         eps = world * E * args.steps / elapsed
-        flops_ep = 3.0 * MODELS['visformer_micro_80'][0] * imgs          # forward + dgrad + wgrad
+        flops_ep = 3.0 * flop_per_image * imgs          # forward + dgrad + wgrad
         peak = MFMA_PEAK_TFLOPS[args.numerics]
-        out = {'metric': 'train_episodes_per_sec_10way_5shot_visformer_s', 'value': eps, 'unit': 'episodes/s', 'n_gpus': world,
+        out = {'metric': 'train_episodes_per_sec_10way_5shot_%s' % ('visformer_s' if vis else args.model), 'value': eps, 'unit': 'episodes/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE_NAME[args.numerics], 'data': 'synthetic',
-               'config': {'workload': 'BASELINE configs[2]: SUN-M train_meta.py meta-tuning step, Visformer-S (visformer_micro_80, '
-                                      'drop_path 0.5), ep_per_batch episodes of 10-way 5-shot 5-query 80x80 (train_meta_mini_visformer_5shot.yaml), '
-                                      'forward + CE + backward + SGD(0.9, wd 5e-4), episodes resident in HBM',
+               'config': {'workload': ('BASELINE configs[2]: SUN-M train_meta.py meta-tuning step, Visformer-S (visformer_micro_80, '
+                                       'drop_path 0.5), ep_per_batch episodes of 10-way 5-shot 5-query 80x80 (train_meta_mini_visformer_5shot.yaml), '
+                                       'forward + CE + backward + SGD(0.9, wd 5e-4), episodes resident in HBM') if vis else
+                                      ('train_meta.py meta-tuning step with encoder %s (drop_path 0.1), episodes of 10-way 5-shot 5-query %dx%d, '
+                                       'forward + CE + backward + SGD(0.9, wd 5e-4), episodes resident in HBM' % (args.model, img, img)),
                           'episodes_per_step_per_gpu': E, 'images_per_episode': imgs,
                           'parallelism': 'episode axis sharded x%d, one all-reduce of the flattened gradients per step' % world},
                'whole_path_tflops': eps * flops_ep / 1e12, 'whole_path_mfma_frac': eps * flops_ep / 1e12 / peak,
                'roofline': {'bound': 'mfma', 'achieved': eps * flops_ep / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
                             'frac': eps * flops_ep / 1e12 / peak, 'traffic': None, 'kernel': 'whole training step (forward + backward + SGD)'},
                'final_loss': float(loss)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and vis:
             out['cpu_baseline'] = cpu_train_baseline(sd)
         print(json.dumps(out), flush=True)
 

@@ -3,7 +3,8 @@
 
 As for the Visformer, the nn.Module tree only owns parameters under the reference's key names
 (`cls_token`, `pos_embed`, `patch_embed.proj.*`, `blocks.N.{norm1,attn.qkv,attn.proj,norm2,mlp.fc1,mlp.fc2}.*`,
-`norm.*` - SURVEY.md Appendix A); no arithmetic happens here."""
+`norm.*` - SURVEY.md Appendix A); no arithmetic happens here: eval runs on engine.VitEngine, model.train() on engine.VitTrainer
+(fsvit_vit_train_forward / _backward: LayerNorm / attention / Mlp with saved activations, DropPath, every parameter gradient)."""
 import torch
 import torch.nn as nn
 

@@ -236,3 +236,23 @@ def test_meta_tuning_loop_with_deit_encoder():
     with torch.no_grad():
         after = m(xs.cuda(), xq.cuda())
     assert float((after - before).abs().max()) > 1e-3            # the packed eval engine followed the update
+
+
+def test_train_meta_driver_with_deit_encoder(tmp_path):
+    """The train_meta.py surface (YAML keys, train / tval / val phases, checkpoint schema) with `encoder: deit_nano_patch6_84` - a registry ViT
+    (84 x 84, 197 tokens, 12 blocks) meta-tuned for two short epochs on the bf16 trainer."""
+    from fewshot_vit_amd import models, train_meta
+    ds = dict(n_per_class=20, noise=1.0, image_size=84)
+    config = dict(train_dataset='synthetic-episodes', train_dataset_args=dict(split='train', n_classes=8, seed=1, **ds),
+                  tval_dataset='synthetic-episodes', tval_dataset_args=dict(split='test', n_classes=6, seed=0, **ds),
+                  val_dataset='synthetic-episodes', val_dataset_args=dict(split='val', n_classes=6, seed=2, **ds),
+                  model='meta-baseline', model_args=dict(encoder='deit_nano_patch6_84', encoder_args=dict(drop_path_rate=0.1, numerics='bf16')),
+                  n_train_way=5, n_train_shot=1, n_train_query=3, n_way=5, n_shot=1, n_query=5,
+                  train_batches=2, eval_batches=1, ep_per_batch=2, max_epoch=2, optimizer='sgd',
+                  optimizer_args=dict(lr=0.01, weight_decay=5e-4), save_epoch=1)
+    lines = []
+    trlog = train_meta.main(config, name='d', device=torch.device('cuda', 0), log=lines.append, save_root=str(tmp_path))
+    assert len(trlog['tl']) == 2 and all(np.isfinite(trlog[k]).all() for k in trlog)
+    ck = torch.load(os.path.join(str(tmp_path), 'd', 'epoch-last.pth'), map_location='cpu')
+    m = models.load(ck)
+    assert ck['model_args']['encoder'] == 'deit_nano_patch6_84' and m.encoder.out_dim == 224
