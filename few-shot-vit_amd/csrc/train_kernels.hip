@@ -455,11 +455,16 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
 // out[r][c] = sum_b g[b][r][c]  (pos_embed gradient: r over HW) ; rows = HW, reduces over B images
 template <typename T>
 __global__ __launch_bounds__(256) void batch_sum_kernel(const T* __restrict__ g, float* __restrict__ out, int B, size_t per_img) {
-  GS_LOOP(idx, per_img) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += to_f32<T>(g[(size_t)b * per_img + idx]);
-    out[idx] = s;
-  }
+  // block = 256 consecutive elements (4 per lane) x 4 waves over the batch (wave w sums images w, w + 4, ...), LDS reduce in wave order
+  __shared__ f32x4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t idx = ((size_t)blockIdx.x * 64 + lane) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (idx < per_img)
+    for (int b = wave; b < B; b += 4) s += load4<T>(g + (size_t)b * per_img + idx);
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && idx < per_img) *reinterpret_cast<f32x4*>(out + idx) = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // y[b][i] = x[b][i] + p[i]   (pos_embed add after the PatchEmbed norm, visformer.py:437-438)
@@ -781,8 +786,10 @@ int launch_avgpool_bwd(const float* dfeat, void* dx, int B, int HW, int C, int d
   return (int)hipGetLastError();
 }
 int launch_batch_sum(const void* g, float* out, int B, size_t per_img, int dtype, hipStream_t s) {
-  DISPATCH_T(dtype, hipLaunchKernelGGL(batch_sum_kernel<float>, dim3(gs_grid(per_img)), dim3(256), 0, s, (const float*)g, out, B, per_img),
-             hipLaunchKernelGGL(batch_sum_kernel<bf16>, dim3(gs_grid(per_img)), dim3(256), 0, s, (const bf16*)g, out, B, per_img));
+  if (per_img % 4) return (int)hipErrorInvalidValue;
+  const unsigned nb = (unsigned)((per_img / 4 + 63) / 64);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(batch_sum_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)g, out, B, per_img),
+             hipLaunchKernelGGL(batch_sum_kernel<bf16>, dim3(nb), dim3(256), 0, s, (const bf16*)g, out, B, per_img));
   return (int)hipGetLastError();
 }
 int launch_bcast_add(const void* x, const float* p, void* y, int B, size_t per_img, int dtype, hipStream_t s) {
