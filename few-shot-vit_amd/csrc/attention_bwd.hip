@@ -76,6 +76,82 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const T* __restrict_
   }
 }
 
+// fp32, longer sequences (ViT: 197 tokens x head dim 64 do not fit the all-in-LDS kernel above): K and V stay resident, the queries go through in
+// blocks of QB rows (Q, dO, P and dS tiles of the block in LDS); dQ of the block is final, dK / dV accumulate in the fp32 output rows themselves -
+// element (key, d) is always updated by the same thread of the one workgroup that owns this (image, head), so plain read-modify-write is ordered.
+template <int QB>
+__global__ __launch_bounds__(256) void attention_bwd_tiled_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx, float* __restrict__ dqkv,
+                                                                      int S, int heads, int hd, int hdp, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int ld = hd + 1, ls = S + 1;
+  float* K = reinterpret_cast<float*>(smem);
+  float* V = K + S * ld;
+  float* Q = V + S * ld;           // [QB][ld]
+  float* dO = Q + QB * ld;
+  float* P = dO + QB * ld;         // [QB][ls]
+  float* dS = P + QB * ls;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const int rowlen = 3 * heads * hdp;
+  const float* base = qkv + (size_t)b * S * rowlen + h * hdp;
+  const float* dob = dctx + (size_t)b * S * heads * hdp + h * hdp;
+  float* dq = dqkv + (size_t)b * S * rowlen + h * hdp;
+  for (int idx = t; idx < S * hd; idx += 256) {
+    const int i = idx / hd, d = idx - i * hd;
+    K[i * ld + d] = base[(size_t)i * rowlen + heads * hdp + d];
+    V[i * ld + d] = base[(size_t)i * rowlen + 2 * heads * hdp + d];
+  }
+  for (int idx = t; idx < S * hdp; idx += 256) {             // dK, dV start at 0 (padded head dims stay exact zeros)
+    const int i = idx / hdp, d = idx - i * hdp;
+    dq[(size_t)i * rowlen + heads * hdp + d] = 0.f;
+    dq[(size_t)i * rowlen + 2 * heads * hdp + d] = 0.f;
+  }
+  for (int q0 = 0; q0 < S; q0 += QB) {
+    const int nq = S - q0 < QB ? S - q0 : QB;
+    __syncthreads();
+    for (int idx = t; idx < QB * hd; idx += 256) {
+      const int i = idx / hd, d = idx - i * hd;
+      Q[i * ld + d] = i < nq ? base[(size_t)(q0 + i) * rowlen + d] : 0.f;
+      dO[i * ld + d] = i < nq ? dob[(size_t)(q0 + i) * heads * hdp + d] : 0.f;
+    }
+    __syncthreads();
+    for (int idx = t; idx < QB * S; idx += 256) {
+      const int i = idx / S, j = idx - i * S;
+      float sc = 0.f, dp = 0.f;
+      for (int d = 0; d < hd; ++d) { sc += Q[i * ld + d] * K[j * ld + d]; dp += dO[i * ld + d] * V[j * ld + d]; }
+      P[i * ls + j] = sc * scale;
+      dS[i * ls + j] = dp;
+    }
+    __syncthreads();
+    for (int i = wave; i < QB; i += 4) {
+      float m = -INFINITY;
+      for (int j = lane; j < S; j += 64) m = fmaxf(m, P[i * ls + j]);
+      m = wave_max(m);
+      float sum = 0.f;
+      for (int j = lane; j < S; j += 64) { const float e = expf(P[i * ls + j] - m); P[i * ls + j] = e; sum += e; }
+      const float inv = i < nq ? 1.0f / wave_sum(sum) : 0.f;                 // rows past the end: P = dS = 0
+      float dot = 0.f;
+      for (int j = lane; j < S; j += 64) { const float p = P[i * ls + j] * inv; P[i * ls + j] = p; dot += p * dS[i * ls + j]; }
+      dot = wave_sum(dot);
+      for (int j = lane; j < S; j += 64) dS[i * ls + j] = scale * P[i * ls + j] * (dS[i * ls + j] - dot);
+    }
+    __syncthreads();
+    for (int idx = t; idx < nq * hdp; idx += 256) {            // dQ of this block
+      const int i = idx / hdp, d = idx - i * hdp;
+      float g = 0.f;
+      if (d < hd) for (int j = 0; j < S; ++j) g += dS[i * ls + j] * K[j * ld + d];
+      dq[(size_t)(q0 + i) * rowlen + d] = g;
+    }
+    for (int idx = t; idx < S * hd; idx += 256) {              // dK, dV contributions of this block (thread <-> element mapping fixed)
+      const int j = idx / hd, d = idx - j * hd;
+      float gk = 0.f, gv = 0.f;
+      for (int i = 0; i < QB; ++i) { gk += dS[i * ls + j] * Q[i * ld + d]; gv += P[i * ls + j] * dO[i * ld + d]; }
+      dq[(size_t)j * rowlen + heads * hdp + d] += gk;
+      dq[(size_t)j * rowlen + 2 * heads * hdp + d] += gv;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // bf16 MFMA version.  One workgroup per (image, head); S <= 224 keys, everything of the head lives in LDS, ROW-major only:
 //   Q, K, V, dO  [SKP][HDP]   score-type products read 16-byte k-chunks of a row; the three products that contract over keys / queries take
@@ -308,8 +384,16 @@ int launch_attention_bwd(const void* qkv, const void* dctx, void* dqkv, int B, i
     if (rc || ran) return rc;
   }
   const size_t lds = ((size_t)4 * S * (hd + 1) + (size_t)2 * S * (S + 1)) * sizeof(float);
-  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   hipError_t e;
+  if (lds > 160 * 1024) {
+    constexpr int QB = 16;
+    const size_t lds_t = ((size_t)2 * S * (hd + 1) + (size_t)2 * QB * (hd + 1) + (size_t)2 * QB * (S + 1)) * sizeof(float);
+    if (dtype != 0 || lds_t > 160 * 1024) return (int)hipErrorInvalidValue;
+    e = hipFuncSetAttribute((const void*)attention_bwd_tiled_f32_kernel<QB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(attention_bwd_tiled_f32_kernel<QB>, dim3(B * heads), dim3(256), lds_t, s, (const float*)qkv, (const float*)dctx, (float*)dqkv, S, heads, hd, hdp, scale);
+    return (int)hipGetLastError();
+  }
   if (dtype == 0) {
     e = hipFuncSetAttribute((const void*)attention_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

@@ -262,7 +262,7 @@ int fsvit_visformer_train_backward(fsvit_visformer_trainer* t, const fsvit_param
  * blocks.N.attn.{qkv,proj}.*, blocks.N.mlp.{fc1,fc2}.*, norm.*), train_forward saves the activations in ws_dev, train_backward overwrites every
  * params[i].grad.  DropPath: 2 calls per block whose rate linspace(0, drop_path_rate, depth)[i] is non-zero, masks_dev [calls][n_img] of 0 / 1 in
  * forward order (fsvit_vit_trainer_droppath_calls); Dropout rates are 0 in every shipped factory and are not built.  dtype FSVIT_F32 or FSVIT_BF16
- * (the fp32 attention backward keeps a head in LDS: <= ~110 tokens; bf16 covers the 197-token factories). */
+ * (both cover the 197-token factories; fp32 runs plain FMA loops). */
 typedef struct fsvit_vit_trainer fsvit_vit_trainer;
 int fsvit_vit_trainer_create(const fsvit_vit_cfg* cfg, int dtype, fsvit_vit_trainer** out);
 void fsvit_vit_trainer_destroy(fsvit_vit_trainer* t);

@@ -167,6 +167,12 @@ def test_vit_train_step_vs_oracle_autograd_small(numerics, drop, tl, tg):
     _vit_train_check(dict(img_size=36, patch_size=6, embed_dim=128, depth=4, num_heads=4), 6, numerics, drop, tl, tg)
 
 
+def test_vit_train_step_197_tokens_parity():
+    """The 84 x 84 / patch 6 factories' shape (197 tokens, head dim 56 padded to 64... in bf16; 56 in fp32) in the exact-fp32 mode: the tiled fp32
+    attention backward (K / V resident, query blocks) lifts the old ~110-token limit of `parity` training."""
+    _vit_train_check(dict(img_size=84, patch_size=6, embed_dim=224, depth=3, num_heads=4), 4, 'parity', 0.2, 2e-5, 2e-5)
+
+
 def test_vit_train_step_deit_tokens_bf16():
     """A DeiT-shaped layer stack (197 tokens, head dim 64, patch 16) in the bf16 training mode: the MFMA attention backward with 224 resident keys
     and the direct weight-gradient kernels; 2 blocks keep the fp32 oracle quick."""

@@ -201,6 +201,12 @@ def test_attention_backward_vs_torch(dtype, S, hd, hdp):
         assert float(out.float().view(B, S, 3, heads, hdp)[..., hd:].abs().max()) == 0.0     # padded head dims stay exact zeros
 
 
+@pytest.mark.parametrize('S,hd', [(197, 64), (197, 56), (150, 32)])
+def test_attention_backward_fp32_long_sequences(S, hd):
+    """fp32 (`parity`) attention backward past the all-in-LDS limit: K / V resident, query blocks of 16, dK / dV accumulated in the output."""
+    test_attention_backward_vs_torch(torch.float32, S, hd, hd)
+
+
 @pytest.mark.parametrize('S,hd', [(197, 64), (197, 32), (130, 64)])
 def test_attention_backward_vit_token_counts(S, hd):
     """The ViT shapes (196 patches + cls, deit.py:37-58) on the LDS-resident MFMA kernel: its A operands come from the row-major images through
