@@ -82,6 +82,12 @@ struct fsvit_visformer_trainer {
   int B = 0;
   float dp_rate = 0.f;
   bool freeze_bn = false;                 // BatchNorm layers in eval mode inside the step (utils.freeze_bn): running statistics, no update
+  // batched weight pack: the sizing pass (dry arenas) records every pack of forward + backward in call order; the real forward runs them in
+  // one or two launches and the real conv calls pick their packed weights up by position
+  std::vector<PackJob> jobs;
+  std::vector<size_t> job_off;
+  size_t pack_bytes = 0, job_cursor = 0;
+  unsigned char* pack_base = nullptr;
   const float* masks = nullptr;           // [n_droppath_calls][B] 0/1
   // saved forward state (pointers into `save`)
   struct Stem { void *patches, *z1, *a1, *zd, *ad, *z2, *a2, *z3, *a3; unsigned char* arg; BnSave b1, bd, b2, b3; void* x1; } stem;
@@ -120,14 +126,50 @@ ConvGemmParams gemm_params(const void* x, const void* w, void* y, int B, int H, 
   return p;
 }
 
+// packed weights of one layer: recorded in the sizing pass, served from the batch in the real pass (fallback: packed here and now)
+int packed_weight(TR* t, const PackJob& job, size_t bytes, void** out) {
+  if (t->tmp.dry) {
+    t->jobs.push_back(job);
+    t->job_off.push_back(t->pack_bytes);
+    t->pack_bytes += align256(bytes);
+    *out = (void*)(uintptr_t)256;
+    return 0;
+  }
+  if (t->pack_base && t->job_cursor < t->jobs.size()) {
+    const PackJob& r = t->jobs[t->job_cursor];
+    if (r.w == job.w && r.mode == job.mode && r.rows_pad == job.rows_pad && r.Kw == job.Kw) {
+      *out = t->pack_base + t->job_off[t->job_cursor++];
+      return 0;
+    }
+  }
+  void* pk = t->tmp.take(bytes);
+  if (!pk) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (weights)");
+  T_RUN(launch_pack_weight(job.w, pk, job.O, job.Ig, job.KH, job.KW, job.groups, job.mode, job.rows_pad, job.Kw, job.hd_rows, job.hdp_rows, job.hd_cols, job.hdp_cols,
+                           t->dtype, t->st));
+  *out = pk;
+  return 0;
+}
+// runs every recorded pack (call after the sizing pass, with the real arenas in place)
+int run_packs(TR* t) {
+  t->pack_base = nullptr; t->job_cursor = 0;
+  if (t->jobs.empty()) return 0;
+  unsigned char* base = (unsigned char*)t->save.take(t->pack_bytes);
+  if (!base) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (packed weights)");
+  std::vector<PackJob> js = t->jobs;
+  for (size_t i = 0; i < js.size(); ++i) js[i].out = base + t->job_off[i];
+  T_RUN(launch_pack_weight_multi(js.data(), (int)js.size(), t->dtype, t->st));
+  t->pack_base = base;
+  return 0;
+}
+
 // ---------------------------------------------------------------- conv forward: z = conv(x) (+ bias)
 int conv_fwd(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, void* z, const float* bias) {
   const fsvit_param* w = getp(t, c.wname);
   if (!w) return FSVIT_ERR_KEY;
   const int bke = 128 / t->es, Ng = c.rows_fwd(), K = c.kpad_cols(), Kw = round_up(K, bke);
-  void* pk = t->tmp.take((size_t)c.groups * Ng * Kw * t->es);
-  if (!pk) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (weights)");
-  T_RUN(launch_pack_weight(w->data, pk, c.O, c.Ig, c.KH, c.KW, c.groups, 0, Ng, Kw, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols, t->dtype, t->st));
+  void* pk = nullptr;
+  T_TRY(packed_weight(t, PackJob{w->data, nullptr, c.O, c.Ig, c.KH, c.KW, c.groups, 0, Ng, Kw, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols},
+                      (size_t)c.groups * Ng * Kw * t->es, &pk));
   ConvGemmParams p;
   if (c.via_patches) p = gemm_params(x, pk, z, B, H, W, 32, 32, 1, 1, 1, 0, Ng, Ng, 32, Kw, 1);
   else p = gemm_params(x, pk, z, B, H, W, K / (c.KH * c.KW), c.groups * (K / (c.KH * c.KW)), c.KH, c.KW, c.stride, c.pad, Ng, c.groups * Ng, K, Kw, c.groups);
@@ -144,10 +186,10 @@ int conv_bwd_data(TR* t, const ConvSpec& c, const void* dz, int B, int OH, int O
   const int Ng_pad = c.rows_fwd();                        // dz channels per group (padded)
   const int Ig_pad = c.Ig / c.hd_cols * c.hdp_cols;       // dx channels per group (padded for proj's ctx input)
   const int K = c.KH * c.KW * Ng_pad, Kw = round_up(K, bke);
-  void* pk = t->tmp.take((size_t)c.groups * Ig_pad * Kw * t->es);
-  if (!pk) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (dgrad weights)");
   // rows = input channels (padded like the forward K columns), K = output channels (padded like the forward rows)
-  T_RUN(launch_pack_weight(w->data, pk, c.O, c.Ig, c.KH, c.KW, c.groups, 1, Ig_pad, Kw, c.hd_cols, c.hdp_cols, c.hd_rows, c.hdp_rows, t->dtype, t->st));
+  void* pk = nullptr;
+  T_TRY(packed_weight(t, PackJob{w->data, nullptr, c.O, c.Ig, c.KH, c.KW, c.groups, 1, Ig_pad, Kw, c.hd_cols, c.hdp_cols, c.hd_rows, c.hdp_rows},
+                      (size_t)c.groups * Ig_pad * Kw * t->es, &pk));
   ConvGemmParams p = gemm_params(dz, pk, dx, B, OH, OW, Ng_pad, c.groups * Ng_pad, c.KH, c.KW, 1, c.pad, Ig_pad, c.groups * Ig_pad, K, Kw, c.groups);
   T_RUN(launch_conv_gemm(p, t->dtype, t->st));
   return 0;
@@ -501,8 +543,8 @@ int train_backward_impl(TR* t, const float* dfeat) {
       // data gradient of the non-overlapping k2s2 conv: G[m][(ky,kx,c)] = dz[m] . W[:, c, ky, kx], scattered to the input grid
       const fsvit_param* w = getp(t, pc.wname);
       const int bke = 128 / t->es, Kw = round_up(C, bke);
-      void* pk = t->tmp.take((size_t)4 * Ci * Kw * t->es); NEED(pk);
-      T_RUN(launch_pack_weight(w->data, pk, C, Ci, 2, 2, 1, 2, 4 * Ci, Kw, 1, 1, 1, 1, dt, st));
+      void* pk = nullptr;
+      T_TRY(packed_weight(t, PackJob{w->data, nullptr, C, Ci, 2, 2, 1, 2, 4 * Ci, Kw, 1, 1, 1, 1}, (size_t)4 * Ci * Kw * t->es, &pk));
       void* G = take_tmp(t, M * 4 * Ci); NEED(G);
       ConvGemmParams p = gemm_params(dz, pk, G, B, Ho, Ho, C, C, 1, 1, 1, 0, 4 * Ci, 4 * Ci, C, Kw, 1);
       T_RUN(launch_conv_gemm(p, dt, st));
@@ -811,6 +853,7 @@ int vit_size_workspace(VT* t, int n_img, float rate, size_t* save_bytes, size_t*
   t->B = n_img; t->dp_rate = rate; t->scales = nullptr;
   t->save = Arena(); t->tmp = Arena();
   t->save.dry = t->tmp.dry = true;
+  t->jobs.clear(); t->job_off.clear(); t->pack_bytes = 0; t->pack_base = nullptr; t->job_cursor = 0;
   int rc = vit_forward_impl(t, nullptr, nullptr);
   if (rc) return rc;
   size_t tp = t->tmp.peak;
@@ -818,7 +861,7 @@ int vit_size_workspace(VT* t, int n_img, float rate, size_t* save_bytes, size_t*
   rc = vit_backward_impl(t, nullptr);
   if (rc) return rc;
   if (t->tmp.peak > tp) tp = t->tmp.peak;
-  *save_bytes = align256(t->save.peak + (size_t)vit_droppath_calls(t, rate, nullptr) * n_img * 4 + 256);
+  *save_bytes = align256(t->save.peak + t->pack_bytes + 256 + (size_t)vit_droppath_calls(t, rate, nullptr) * n_img * 4 + 256);
   *tmp_bytes = align256(tp);
   return 0;
 }
@@ -873,6 +916,7 @@ extern "C" int fsvit_vit_train_forward(fsvit_vit_trainer* t, const fsvit_param* 
     for (int k = 0; k < ncalls; ++k)
       T_RUN(launch_scale_copy(masks_dev + (size_t)k * n_img, t->scales + (size_t)k * n_img, n_img, 1.0f / keep[k], t->st));
   }
+  T_TRY(run_packs(t));
   return vit_forward_impl(t, x_nchw_dev, feat_dev);
 }
 
@@ -928,6 +972,7 @@ static int size_workspace(TR* t, int n_img, float rate, size_t* save_bytes, size
   t->B = n_img; t->dp_rate = rate; t->scales = nullptr;
   t->save = Arena(); t->tmp = Arena();
   t->save.dry = t->tmp.dry = true;
+  t->jobs.clear(); t->job_off.clear(); t->pack_bytes = 0; t->pack_base = nullptr; t->job_cursor = 0;
   int rc = train_forward_impl(t, nullptr, nullptr);
   if (rc) return rc;
   size_t tp = t->tmp.peak;
@@ -935,7 +980,7 @@ static int size_workspace(TR* t, int n_img, float rate, size_t* save_bytes, size
   rc = train_backward_impl(t, nullptr);
   if (rc) return rc;
   if (t->tmp.peak > tp) tp = t->tmp.peak;
-  *save_bytes = align256(t->save.peak + (size_t)droppath_calls(t, rate, nullptr) * n_img * 4 + 256);
+  *save_bytes = align256(t->save.peak + t->pack_bytes + 256 + (size_t)droppath_calls(t, rate, nullptr) * n_img * 4 + 256);
   *tmp_bytes = align256(tp);
   return 0;
 }
@@ -975,6 +1020,7 @@ extern "C" int fsvit_visformer_train_forward(fsvit_visformer_trainer* t, const f
     for (int k = 0; k < ncalls; ++k)
       T_RUN(launch_scale_copy(masks_dev + (size_t)k * n_img, t->scales + (size_t)k * n_img, n_img, 1.0f / keep[k], t->st));
   }
+  T_TRY(run_packs(t));                              // every weight pack of this step (forward + data-gradient layouts) in one or two launches
   return train_forward_impl(t, x_nchw_dev, feat_dev);
 }
 

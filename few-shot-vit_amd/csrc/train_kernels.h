@@ -5,6 +5,10 @@
 
 namespace fsvit {
 
+// one job of the batched weight pack (same meaning as launch_pack_weight's arguments); `out` is the packed destination
+struct PackJob { const float* w; void* out; int O, Ig, KH, KW, groups, mode, rows_pad, Kw, hd_rows, hdp_rows, hd_cols, hdp_cols; };
+struct PackJobs { static constexpr int MAX = 40; PackJob job[MAX]; };
+int launch_pack_weight_multi(const PackJob* jobs, int n, int dtype, hipStream_t s);
 int launch_pack_weight(const float* w, void* out, int O, int Ig, int KH, int KW, int groups, int mode, int rows_pad, int Kw, int hd_rows, int hdp_rows,
                        int hd_cols, int hdp_cols, int dtype, hipStream_t s);
 int launch_wgrad_finalize(const float* y, float* dw, int Ng, int Ig, int KH, int KW, int g, int splits, int Kc_pad, int hd_rows, int hdp_rows, int hd_cols,

@@ -59,6 +59,44 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   }
 }
 
+// All weight packs of a training step in one launch (74 layers x (forward | transposed for the data gradient)): the job table travels as a
+// kernel argument (<= 40 jobs of 64 bytes per launch), blockIdx.y = job.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackJobs jobs) {
+  const PackJob j = jobs.job[blockIdx.y];
+  const int Ng = j.O / j.groups;
+  const size_t total = (size_t)j.groups * j.rows_pad * j.Kw;
+  T* out = reinterpret_cast<T*>(j.out);
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int k = (int)(idx % j.Kw);
+    const size_t t2 = idx / j.Kw;
+    const int r = (int)(t2 % j.rows_pad), g = (int)(t2 / j.rows_pad);
+    float v = 0.0f;
+    if (j.mode == 2) {
+      if (r < j.KH * j.KW * j.Ig && k < Ng) {
+        const int tap = r / j.Ig, ch = r % j.Ig;
+        v = j.w[(((size_t)(g * Ng + k) * j.Ig + ch) * j.KH + tap / j.KW) * j.KW + tap % j.KW];
+      }
+      out[idx] = from_f32<T>(v);
+      continue;
+    }
+    const int nin = j.mode == 0 ? j.Ig : Ng;
+    int kk = k;
+    bool ok = true;
+    if (j.hdp_cols != j.hd_cols) { const int y = k / j.hdp_cols, zz = k % j.hdp_cols; ok = zz < j.hd_cols; kk = y * j.hd_cols + zz; }
+    int rr = r;
+    if (j.hdp_rows != j.hd_rows) { const int y = r / j.hdp_rows, zz = r % j.hdp_rows; ok = ok && zz < j.hd_rows; rr = y * j.hd_rows + zz; }
+    const int nrows = j.mode == 0 ? Ng : j.Ig;
+    if (ok && rr < nrows && kk < j.KH * j.KW * nin) {
+      const int tap = kk / nin, ch = kk % nin;
+      const int ky = tap / j.KW, kx = tap % j.KW;
+      if (j.mode == 0) v = j.w[(((size_t)(g * Ng + rr) * j.Ig + ch) * j.KH + ky) * j.KW + kx];
+      else v = j.w[(((size_t)(g * Ng + ch) * j.Ig + rr) * j.KH + (j.KH - 1 - ky)) * j.KW + (j.KW - 1 - kx)];
+    }
+    out[idx] = from_f32<T>(v);
+  }
+}
+
 // split-K wgrad result Y[Ng][splits * Kc] (fp32, Kc = KH*KW*Ig padded to Kc_pad) of ONE group -> dW[O][Ig][KH][KW] (overwrite)
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ y, float* __restrict__ dw, int Ng, int Ig, int KH, int KW,
                                                              int g, int splits, int Kc_pad, int hd_rows, int hdp_rows, int hd_cols, int hdp_cols) {
@@ -663,6 +701,26 @@ int launch_pack_weight(const float* w, void* out, int O, int Ig, int KH, int KW,
   DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, w, (float*)out, O, Ig, KH, KW, groups, mode, rows_pad, Kw, hd_rows, hdp_rows, hd_cols, hdp_cols),
              hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, w, (bf16*)out, O, Ig, KH, KW, groups, mode, rows_pad, Kw, hd_rows, hdp_rows, hd_cols, hdp_cols));
   return (int)hipGetLastError();
+}
+int launch_pack_weight_multi(const PackJob* jobs, int n, int dtype, hipStream_t s) {
+  for (int i0 = 0; i0 < n; i0 += PackJobs::MAX) {
+    PackJobs pj;
+    const int m = n - i0 < PackJobs::MAX ? n - i0 : PackJobs::MAX;
+    size_t biggest = 0;
+    for (int i = 0; i < m; ++i) {
+      pj.job[i] = jobs[i0 + i];
+      const size_t tot = (size_t)pj.job[i].groups * pj.job[i].rows_pad * pj.job[i].Kw;
+      if (tot > biggest) biggest = tot;
+    }
+    unsigned gx = (unsigned)((biggest + 1023) / 1024);
+    if (gx > 128) gx = 128;
+    if (gx < 1) gx = 1;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3(gx, (unsigned)m), dim3(256), 0, s, pj),
+               hipLaunchKernelGGL(pack_weight_multi_kernel<bf16>, dim3(gx, (unsigned)m), dim3(256), 0, s, pj));
+    const int rc = (int)hipGetLastError();
+    if (rc) return rc;
+  }
+  return 0;
 }
 int launch_wgrad_finalize(const float* y, float* dw, int Ng, int Ig, int KH, int KW, int g, int splits, int Kc_pad, int hd_rows, int hdp_rows, int hd_cols,
                           int hdp_cols, hipStream_t s) {
