@@ -170,6 +170,10 @@ int conv_fwd(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, void*
   void* pk = nullptr;
   T_TRY(packed_weight(t, PackJob{w->data, nullptr, c.O, c.Ig, c.KH, c.KW, c.groups, 0, Ng, Kw, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols},
                       (size_t)c.groups * Ng * Kw * t->es, &pk));
+  if (!bias && !c.via_patches && gconv3x3_supported(t->dtype, c.O, c.Ig, c.groups, c.KH, c.KW, c.stride, c.pad, W)) {
+    T_RUN(launch_gconv3x3(x, pk, Kw, z, B, H, W, t->st));          // wave = group, weights in registers (wgrad3x3.hip)
+    return 0;
+  }
   ConvGemmParams p;
   if (c.via_patches) p = gemm_params(x, pk, z, B, H, W, 32, 32, 1, 1, 1, 0, Ng, Ng, 32, Kw, 1);
   else p = gemm_params(x, pk, z, B, H, W, K / (c.KH * c.KW), c.groups * (K / (c.KH * c.KW)), c.KH, c.KW, c.stride, c.pad, Ng, c.groups * Ng, K, Kw, c.groups);
@@ -190,6 +194,10 @@ int conv_bwd_data(TR* t, const ConvSpec& c, const void* dz, int B, int OH, int O
   void* pk = nullptr;
   T_TRY(packed_weight(t, PackJob{w->data, nullptr, c.O, c.Ig, c.KH, c.KW, c.groups, 1, Ig_pad, Kw, c.hd_cols, c.hdp_cols, c.hd_rows, c.hdp_rows},
                       (size_t)c.groups * Ig_pad * Kw * t->es, &pk));
+  if (gconv3x3_supported(t->dtype, c.O, c.Ig, c.groups, c.KH, c.KW, c.stride, c.pad, OW) && Ng_pad == 32 && Ig_pad == 32) {
+    T_RUN(launch_gconv3x3(dz, pk, Kw, dx, B, OH, OW, t->st));      // the same kernel on the transposed, tap-flipped pack
+    return 0;
+  }
   ConvGemmParams p = gemm_params(dz, pk, dx, B, OH, OW, Ng_pad, c.groups * Ng_pad, c.KH, c.KW, 1, c.pad, Ig_pad, c.groups * Ig_pad, K, Kw, c.groups);
   T_RUN(launch_conv_gemm(p, t->dtype, t->st));
   return 0;

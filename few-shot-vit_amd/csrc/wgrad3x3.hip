@@ -224,6 +224,95 @@ int launch_wgrad3x3(const void* x, int xld, const void* dz, int zld, float* dw, 
   return (int)hipGetLastError();
 }
 
+// ---- the grouped 3x3 / s1 / p1 convolution itself (stage-1 conv2 in the training step: forward, and the data gradient with the transposed +
+// tap-flipped weights): 8 groups of 32 -> 32 channels.  As an implicit GEMM with N = 32 per group it ran on conv_gemm_v2's 128 x 32 tile at
+// 220 TF/s (8 launches of 213 us per step).  Here wave g IS group g: its 18 weight fragments (9 taps x 2 channel tiles) stay in 72 VGPRs for the
+// whole launch, the activations go through the same staged pixel window as in wgrad3x3 (planes of 8 channels, a tap = an address, invalid taps
+// read a zero slot): per 16 pixels 9 fragment reads feed 18 MFMAs.
+//   y[m][32 g + n] = sum_{tap, c} x[pix(m) + tap][32 g + c] * w[32 g + n][tap * 32 + c]        w = the trainer's packed layer ([256][Kw], K order (ky, kx, c))
+__global__ __launch_bounds__(512) void gconv3x3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, int Kw, bf16* __restrict__ y, int M, int H, int W,
+                                                       int n_chunks, int chunks_per_wg) {
+  using namespace wg3;
+  constexpr int C = 256, MAXW = 20, WINP = CH + 2 * (MAXW + 1) + 2;      // 108 pixels
+  constexpr int NPX = (WINP * (C / 8) + 511) / 512;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(C / 8) * WINP * 16 + 16];     // [32 channel chunks][pixel][16 B] + a zero slot
+  unsigned char* const ZERO = smem + (C / 8) * WINP * 16;
+  const int t = threadIdx.x, lane = t & 63, lrow = lane & 15, lq = lane >> 4;
+  const int g = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int halo = W + 1, winp = CH + 2 * halo;
+  const int q0 = blockIdx.x * chunks_per_wg;
+  int q1 = q0 + chunks_per_wg; q1 = q1 < n_chunks ? q1 : n_chunks;
+  if (t < 4) reinterpret_cast<unsigned*>(ZERO)[t] = 0u;
+
+  // this wave's weights: A fragments (rows = output channels 16 nt + lrow of the group, k = 8 lq .. of the tap's 32 input channels)
+  u32x4 wf[9][2];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) wf[tp][nt] = *reinterpret_cast<const u32x4*>(w + (size_t)(g * 32 + nt * 16 + lrow) * Kw + tp * 32 + lq * 8);
+
+  u32x4 px[NPX];
+  auto gload = [&](int q) {
+    const long m0 = (long)q * CH;
+#pragma unroll
+    for (int u0 = 0; u0 < NPX; ++u0) {
+      const int u = t + 512 * u0, p = u / (C / 8), c8 = u % (C / 8);
+      const long m = m0 - halo + p;
+      px[u0] = (p < winp && m >= 0 && m < M) ? *reinterpret_cast<const u32x4*>(x + (size_t)m * C + c8 * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int u0 = 0; u0 < NPX; ++u0) {
+      const int u = t + 512 * u0, p = u / (C / 8), c8 = u % (C / 8);
+      if (p < WINP) *reinterpret_cast<u32x4*>(smem + c8 * (WINP * 16) + p * 16) = px[u0];
+    }
+  };
+  const unsigned char* const plane = smem + (g * 4 + lq) * (WINP * 16);     // the 8 channels this lane feeds as k = 8 lq ..
+  const int HW = H * W;
+
+  if (q0 < q1) gload(q0);
+  for (int q = q0; q < q1; ++q) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (q + 1 < q1) gload(q + 1);
+    const int m0 = q * CH;
+#pragma unroll
+    for (int mt = 0; mt < CH / 16; ++mt) {
+      const int m = m0 + mt * 16 + lrow;                              // this lane's pixel (B operand column)
+      const int rem = m % HW, oy = m < M ? rem / W : -4, ox = rem - (rem / W) * W;
+      const unsigned char* const base = plane + (mt * 16 + lrow + halo) * 16;
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int dy = tp / 3 - 1, dx = tp % 3 - 1;
+        const bool ok = (unsigned)(oy + dy) < (unsigned)H && (unsigned)(ox + dx) < (unsigned)W;
+        const u32x4 xf = *reinterpret_cast<const u32x4*>(ok ? base + (dy * W + dx) * 16 : ZERO);
+        acc[0] = mma_chunk<bf16>(wf[tp][0], xf, acc[0]);
+        acc[1] = mma_chunk<bf16>(wf[tp][1], xf, acc[1]);
+      }
+      if (m < M) {                                                    // lane holds channels 32 g + 16 nt + 4 lq .. + 3 of pixel m
+        store4<bf16>(y + (size_t)m * C + g * 32 + lq * 4, acc[0]);
+        store4<bf16>(y + (size_t)m * C + g * 32 + 16 + lq * 4, acc[1]);
+      }
+    }
+  }
+}
+
+bool gconv3x3_supported(int dtype, int O, int Ig, int groups, int KH, int KW, int stride, int pad, int W) {
+  static const bool off = [] { const char* e = getenv("FSVIT_GCONV3X3"); return e && e[0] == '0'; }();
+  return !off && dtype == 1 && O == 256 && Ig == 32 && groups == 8 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && W <= 20;
+}
+int launch_gconv3x3(const void* x, const void* w_packed, int Kw, void* y, int B, int H, int W, hipStream_t s) {
+  const int M = B * H * W, n_chunks = (M + wg3::CH - 1) / wg3::CH;
+  int wgs = n_chunks < 512 ? n_chunks : 512;
+  const int cpw = (n_chunks + wgs - 1) / wgs;
+  wgs = (n_chunks + cpw - 1) / cpw;
+  hipLaunchKernelGGL(gconv3x3_kernel, dim3(wgs), dim3(512), 0, s, (const bf16*)x, (const bf16*)w_packed, Kw, (bf16*)y, M, H, W, n_chunks, cpw);
+  return (int)hipGetLastError();
+}
+
 // ---- 1x1 convolutions (conv1 / conv3 of the Mlps, qkv, proj):  Y[n][split * Kc_pad + c] = sum_{m in split} dz[m][n] * x[m][c]
 // The same transposing-read scheme without taps: a workgroup owns an NT (n) x CT (c) block (256 where the layer has >= 256 columns, else 128), its
 // 8 waves (4 x 2) NT/4 x CT/2 each (up to 32 accumulator tiles); per 64 rows it stages (NT + CT) x 128 B and issues up to 64 MFMAs per wave.  Output is the split-K partial layout wgrad_finalize_kernel already sums (it also
