@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libfsvit.so')
 
-F32, BF16, F16 = 0, 1, 2
+F32, BF16, F16, BF16X2, F16X2 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GELU, ACT_LRELU = 0, 1, 2
 HEAD_COS, HEAD_SQR, HEAD_DOT = 0, 1, 2
 ERR_ARG, ERR_KEY, ERR_IMG_SIZE, ERR_WORKSPACE = -1, -2, -3, -4

@@ -85,6 +85,39 @@ __device__ __forceinline__ void dma16x2(const void* s0, const void* s1, unsigned
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lptr_t)p; }
 
+// ---- two-limb ("x2") arithmetic on fp32 storage: every fp32 operand value v is fed to the 16-bit MFMA as the pair (hi, lo), hi = v rounded
+// to the 16-bit type, lo = (v - hi) rounded to it (v - hi is exact in fp32), interleaved along K: one 16-byte chunk = 4 fp32 values = 8
+// MFMA k-slots [lo0, hi0, lo1, hi1, ...].  MFMA(w, x) then sums w_lo x_lo + w_hi x_hi and MFMA(w, rot16(x)) sums w_lo x_hi + w_hi x_lo:
+// two 16x16x32 MFMAs per chunk give the full (w_hi + w_lo)(x_hi + x_lo) with fp32 accumulation, where the exact-fp32 path needs four
+// v_mfma_f32_16x16x4_f32 at 1/16 of the rate (dense peaks: 2500 / 4 = 625 TFLOP/s against 157).  Operand precision 16 significand bits
+// with bf16 limbs, 22 with fp16 limbs.  The weights arrive pre-split (engine.hip upload()); the activations stay plain fp32
+// in HBM - every other kernel of the fp32 path is shared - and are split on their way into LDS (stash() in the kernel): x2_split() returns
+// the chunk in both slot orders.
+__device__ __forceinline__ void x2_split(const u32x4 v, u32x4& s, u32x4& r) {
+  // (the floats come from ONE bit_cast of the whole vector: hipcc 7.2 compiles __builtin_bit_cast(float, v[e]) of a vector element to
+  // element 0 for every e)
+  const f32x4 fv = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+  for (int e = 0; e < 4; e += 2) {
+    const float x0 = fv[e], x1 = fv[e + 1];
+#ifdef FSVIT_HALF_F16
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+    const h2_t h = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(x0, x1));           // any 11-bit rounding of x keeps x - hi exact
+    const h2_t l = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]));
+    const unsigned ch = __builtin_bit_cast(unsigned, h), cl = __builtin_bit_cast(unsigned, l);
+    s[e] = (ch << 16) | (cl & 0xffffu);             r[e] = (cl << 16) | (ch & 0xffffu);
+    s[e + 1] = (ch & 0xffff0000u) | (cl >> 16);     r[e + 1] = (cl & 0xffff0000u) | (ch >> 16);
+#else
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+    const unsigned u0 = v[e], u1 = v[e + 1];               // hi = the upper 16 bits (truncation; lo picks up the remainder exactly)
+    const b2_t l = {(__bf16)(x0 - __builtin_bit_cast(float, u0 & 0xffff0000u)), (__bf16)(x1 - __builtin_bit_cast(float, u1 & 0xffff0000u))};
+    const unsigned cl = __builtin_bit_cast(unsigned, l);
+    s[e] = (u0 & 0xffff0000u) | (cl & 0xffffu);     r[e] = (cl << 16) | (u0 >> 16);
+    s[e + 1] = (u1 & 0xffff0000u) | (cl >> 16);     r[e + 1] = (cl & 0xffff0000u) | (u1 >> 16);
+#endif
+  }
+}
+
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int MINB>
 __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmParams p, const int tiles_m, const int tiles_n) {
   constexpr int EPC = Elem<T>::kPerChunk;
@@ -94,6 +127,7 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
   constexpr int A_IT = BM / 32;
   constexpr int B_IT = BN / 32;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr bool LIMBS = sizeof(T) == 4 && !__is_same(T, float);      // T = f32x2l: fp32 storage, two-limb MFMA arithmetic
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * 128];
   unsigned char* const ldsA0 = smem;
@@ -160,6 +194,21 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
       wrow[jj] = Wg + (long)(nok[jj] ? n : 0) * wrs + sc * EPC;
     }
   };
+  // Two-limb mode: the activation slice goes through registers - fetched with ordinary loads in issue(), split into (hi, lo) limb words
+  // ONCE per element and written to the slot the DMA would have filled in stash() - so the LDS-DMA engine (the ~16 B/clk/CU fill limit of
+  // this kernel family, gemm256.hip) carries only the weight half of the tile and no wave repeats another's split.
+  u32x4 areg[A_IT];
+  auto stash = [&](int buf) {
+    if constexpr (LIMBS) {
+      unsigned char* const dst = ldsA0 + buf * (BM * 128) + wave * (8 * 128) + lane * 16;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        u32x4 xs, xr;
+        x2_split(areg[i], xs, xr);
+        *reinterpret_cast<u32x4*>(dst + i * (32 * 128)) = xs;
+      }
+    }
+  };
   auto issue = [&](int kt, int buf) {
     const int k = kt * BKE + sc * EPC;
     int ky = 0, kx = 0, cc = k;
@@ -181,14 +230,18 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
         srcs[i] = ok ? Xg + (size_t)(pixbase[i] + iy * p.W + ix) * p.x_cstride + cc : zero;
       }
       static_assert(A_IT == 4, "A tile = 128 rows = 4 row groups per wave");
-      dma16x4(srcs[0], srcs[1], srcs[2], srcs[3], la);
+      if constexpr (LIMBS) {
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) areg[i] = *reinterpret_cast<const u32x4*>(srcs[i]);
+      } else dma16x4(srcs[0], srcs[1], srcs[2], srcs[3], la);
     } else {                               // tail operand: row m of x2, columns sc*EPC .. (no spatial gather)
       const T* X2 = reinterpret_cast<const T*>(p.x2);
       const bool cok = sc * EPC < p.K2;
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
         const T* src = (cok && rowok[i]) ? X2 + (size_t)pixnat[i] * p.x2_cstride + sc * EPC : zero;
-        dma16(src, la + i * (32 * 128));
+        if constexpr (LIMBS) areg[i] = *reinterpret_cast<const u32x4*>(src);
+        else dma16(src, la + i * (32 * 128));
       }
     }
     const T* bs[B_IT];
@@ -219,10 +272,25 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
       for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const u32x4*>(a + i * 16 * 128 + off);
 #pragma unroll
       for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const u32x4*>(b + j * 16 * 128 + off);
+      if constexpr (LIMBS) {              // xf = limb words [hi | lo] (stash()); the cross terms pair them with the half-swapped weight words
+        u32x4 wr[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = mma_chunk<T>(wf[j], xf[i], acc[i][j]);
+          for (int e = 0; e < 4; ++e) wr[j][e] = __builtin_amdgcn_alignbit(wf[j][e], wf[j][e], 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = mma_chunk<bf16>(wr[j], xf[i], acc[i][j]);     // lo x hi + hi x lo first, hi x hi + lo x lo last
+            acc[i][j] = mma_chunk<bf16>(wf[j], xf[i], acc[i][j]);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mma_chunk<T>(wf[j], xf[i], acc[i][j]);
+      }
     }
   };
 
@@ -323,7 +391,7 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
 #pragma unroll
       for (int i0 = 0; i0 < TM; i0 += HB) batch(i0, actf);
     };
-    if (p.act == ACT_GELU) finish([](float x) { return sizeof(T) == 2 ? gelu_sig(x) : gelu_erf(x); });
+    if (p.act == ACT_GELU) finish([](float x) { return sizeof(T) == 2 ? gelu_sig(x) : (LIMBS ? gelu_erfc(x) : gelu_erf(x)); });
     else if (p.act == ACT_LRELU) finish([](float x) { return x > 0.0f ? x : 0.1f * x; });
     else finish([](float x) { return x; });
   };
@@ -335,12 +403,14 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
   int buf = 0;
   setup(slot);
   issue(0, 0);
+  stash(0);
   dma_wait_all();
   __syncthreads();                       // buffer 0 landed in every wave's view
   for (int j = slot; j < cnt; j += P) {
     for (int kt = 0; kt + 1 < nk; ++kt) {
       issue(kt + 1, buf ^ 1);
       compute(buf);
+      stash(buf ^ 1);
       dma_wait_all();                    // this wave's share of the next buffer has landed ...
       __syncthreads();                   // ... so has everyone's, and everyone is done reading `buf`
       buf ^= 1;
@@ -352,6 +422,7 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
     }
     compute(buf);
     epilogue(j);
+    if (jn < cnt) stash(buf ^ 1);
     dma_wait_all();
     __syncthreads();
     buf ^= 1;
@@ -383,6 +454,7 @@ int conv_gemm_v2_config(const ConvGemmParams& p) { return p.N > 64 ? 3 : (p.N > 
 int launch_conv_gemm_v2(const ConvGemmParams& p, int dtype, hipStream_t stream) {
   if (p.M <= 0) return 0;
   if (p.pool2 && (p.res || p.y_rpi || (p.OH & 1) || (p.OW & 1) || p.stride != 1)) return (int)hipErrorInvalidValue;
+  if (dtype == 2) return launch_v2_t<f32x2l>(p, stream);      // fp32 storage, two-limb 16-bit MFMA arithmetic
   return dtype == 0 ? launch_v2_t<float>(p, stream) : launch_v2_t<bf16>(p, stream);
 }
 

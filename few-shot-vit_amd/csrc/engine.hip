@@ -25,8 +25,14 @@ using namespace fsvit;
 // Kernel-namespace dispatch: every kernel exists for the two 16-bit storage types (namespace fsvit = bf16, fsvit_f16 = fp16; see
 // fsvit_common.h).  K(fn) picks the build that matches `kdt` (a FSVIT_* dtype in scope); kd() maps the public dtype to the kernels'
 // own convention (0 = f32, 1 = the namespace's 16-bit type).
-#define K(fn) (kdt == FSVIT_F16 ? fsvit_f16::fn : fsvit::fn)
-static inline int kd(int dtype) { return dtype == FSVIT_F32 ? 0 : 1; }
+// The two-limb modes (FSVIT_BF16X2 / FSVIT_F16X2) are fp32 STORAGE (kd() = 0: every kernel but the GEMM is the fp32 path's) with the GEMM
+// arithmetic selected by kg() = 2 (conv_gemm_v2.hip: x2_split) and the weights uploaded pre-split.
+#define K(fn) ((kdt == FSVIT_F16 || kdt == FSVIT_F16X2) ? fsvit_f16::fn : fsvit::fn)
+static inline bool is_x2(int dtype) { return dtype == FSVIT_BF16X2 || dtype == FSVIT_F16X2; }
+static inline bool known_dtype(int dtype) { return dtype >= FSVIT_F32 && dtype <= FSVIT_F16X2; }
+static inline int kd(int dtype) { return (dtype == FSVIT_F32 || is_x2(dtype)) ? 0 : 1; }
+static inline int kg(int dtype) { return is_x2(dtype) ? 2 : kd(dtype); }
+static inline int storage_bytes(int dtype) { return kd(dtype) == 0 ? 4 : 2; }
 
 // ------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
@@ -86,6 +92,26 @@ static inline uint16_t f32_to_f16(float f) {    // IEEE binary16, round to neare
   if (rest > half || (rest == half && (q & 1u))) ++q;
   if (e >= -14) return (uint16_t)(sign | (uint16_t)(((uint32_t)(e + 15 - 1) << 10) + q));   // the hidden bit carries into the exponent
   return (uint16_t)(sign | (uint16_t)q);                                     // subnormal (q may carry into the smallest normal)
+}
+static inline float f16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  float f;
+  if (e == 0) { f = std::ldexp((float)m, -24); uint32_t u; memcpy(&u, &f, 4); u |= sign; memcpy(&f, &u, 4); return f; }
+  const uint32_t u = sign | (e == 31 ? 0x7f800000u | (m << 13) : ((e + 112) << 23) | (m << 13));
+  memcpy(&f, &u, 4);
+  return f;
+}
+// One fp32 weight as the two-limb dword of the x2 GEMM (conv_gemm_v2.hip): upper half = hi = w rounded to the 16-bit type, lower half =
+// lo = (w - hi) rounded to it.
+static inline uint32_t x2_limbs(float w, bool f16) {
+  uint16_t hi, lo;
+  if (f16) { hi = f32_to_f16(w); lo = f32_to_f16(w - f16_to_f32(hi)); }
+  else {
+    hi = f32_to_bf16(w);
+    uint32_t hu = (uint32_t)hi << 16; float hf; memcpy(&hf, &hu, 4);
+    lo = f32_to_bf16(w - hf);
+  }
+  return ((uint32_t)hi << 16) | lo;
 }
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -181,7 +207,13 @@ Affine bn_affine(const SD& sd, const std::string& p, int C, double eps) {
 
 int upload(EngineBase* h, const std::vector<float>& src, bool as_storage, void** out) {
   void* d = nullptr;
-  if (as_storage && h->dtype != FSVIT_F32) {
+  if (as_storage && is_x2(h->dtype)) {          // GEMM weights of the two-limb modes: 4 bytes per value, (hi, lo) limbs
+    std::vector<uint32_t> tmp(src.size());
+    for (size_t i = 0; i < src.size(); ++i) tmp[i] = x2_limbs(src[i], h->dtype == FSVIT_F16X2);
+    HIP_TRY(hipMalloc(&d, tmp.size() * 4));
+    h->allocs.push_back(d);
+    HIP_TRY(hipMemcpy(d, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+  } else if (as_storage && h->dtype != FSVIT_F32) {
     std::vector<uint16_t> tmp(src.size());
     for (size_t i = 0; i < src.size(); ++i) tmp[i] = h->dtype == FSVIT_F16 ? f32_to_f16(src[i]) : f32_to_bf16(src[i]);
     HIP_TRY(hipMalloc(&d, tmp.size() * 2));
@@ -509,9 +541,9 @@ int run_gemm(EngineBase* h, hipStream_t st, const char* layer, const Layer& L, c
   const int kdt = h->dtype;
   const double flops = 2.0 * (double)p.M * n_true * k_true * (double)p.groups;     // algorithmic: unpadded N and K
   static const int kid_of_cfg[4] = {KID_GEMM256, KID_GEMM64, KID_GEMM32, KID_GEMM128};
-  const int route = K(conv_gemm_route)(p, kd(kdt));
+  const int route = K(conv_gemm_route)(p, kg(kdt));
   const int kid = route == 0 ? KID_HALO : route == 1 ? KID_GEMM256 : kid_of_cfg[K(conv_gemm_v2_config)(p)];
-  return timed(h, st, layer, kid, flops, [&]() { return K(launch_conv_gemm)(p, kd(kdt), st); });
+  return timed(h, st, layer, kid, flops, [&]() { return K(launch_conv_gemm)(p, kg(kdt), st); });
 }
 
 // xsrc2 != nullptr: images [0, B1) come from x, images [B1, Bc) from xsrc2 (the shot and query tensors of one MetaBaseline call: one
@@ -632,14 +664,14 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
 extern "C" int fsvit_visformer_create(const fsvit_visformer_cfg* cfg, const fsvit_tensor* state_dict, int n_tensors,
                                       int dtype, fsvit_visformer** out) {
   if (!cfg || !state_dict || !out || n_tensors <= 0) return fail(FSVIT_ERR_ARG, "null argument");
-  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  if (!known_dtype(dtype)) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (cfg->num_heads < 1 || cfg->embed_dim < 2 || cfg->init_channels < 1 || cfg->depth[0] < 0 || cfg->depth[1] < 0 || cfg->depth[2] < 0)
     return fail(FSVIT_ERR_ARG, "bad Visformer configuration");
   fsvit_visformer* h = new fsvit_visformer();
   h->kind = KIND_VISFORMER;
   h->cfg = *cfg;
   h->dtype = dtype;
-  h->es = dtype == FSVIT_F32 ? 4 : 2;
+  h->es = storage_bytes(dtype);
   SD sd{state_dict, n_tensors};
   int rc = build(h, sd);
   if (rc != 0) { fsvit_visformer_destroy(h); return rc; }
@@ -751,15 +783,15 @@ extern "C" int fsvit_conv_gemm(const void* x, const void* w, const float* bias, 
                                int B, int H, int W, int Cin, int x_cstride, int KH, int KW, int stride, int pad, int N,
                                int y_cstride, int Kw, int groups, int act, int res_first, int dtype, void* stream) {
   const int kdt = dtype;
-  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  if (!known_dtype(dtype)) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (!x || !w || !y) return fail(FSVIT_ERR_ARG, "null argument");
-  const int es = dtype == FSVIT_F32 ? 4 : 2, epc = 16 / es, bke = 128 / es;      // FSVIT_BF16 and FSVIT_F16 are both 2-byte storage
+  const int es = storage_bytes(dtype), epc = 16 / es, bke = 128 / es;
   if (Cin % epc || x_cstride % epc || N % 4 || y_cstride % 4 || Kw % bke || Kw < KH * KW * Cin)
     return fail(FSVIT_ERR_ARG, "conv_gemm alignment: Cin/x_cstride %% %d, N/y_cstride %% 4, Kw %% %d", epc, bke);
   if (KH * KW > 1 && !is_pow2(Cin)) return fail(FSVIT_ERR_ARG, "multi-tap conv needs power-of-two Cin");
   Layer L; L.w = const_cast<void*>(w); L.bias = const_cast<float*>(bias); L.N = N; L.K = KH * KW * Cin; L.Kw = Kw; L.groups = groups;
   ConvGemmParams p = conv_params(L, x, y, B, H, W, Cin, x_cstride, KH, KW, stride, pad, y_cstride, act, res, res_first, pos);
-  RC_TRY(K(launch_conv_gemm)(p, kd(dtype), (hipStream_t)stream));
+  RC_TRY(K(launch_conv_gemm)(p, kg(dtype), (hipStream_t)stream));
   return 0;
 }
 
@@ -769,15 +801,15 @@ extern "C" int fsvit_conv_gemm(const void* x, const void* w, const float* bias, 
 extern "C" int fsvit_conv_stem_tail(const void* x, const void* w, const float* bias, const float* pos, const void* x2, int x2_cstride, int K2,
                                     void* y, int B, int H, int W, int Cin, int N, int Kw, int dtype, void* stream) {
   const int kdt = dtype;
-  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  if (!known_dtype(dtype)) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (!x || !w || !y || !x2 || !pos) return fail(FSVIT_ERR_ARG, "null argument");
-  const int es = dtype == FSVIT_F32 ? 4 : 2, epc = 16 / es, bke = 128 / es;      // FSVIT_BF16 and FSVIT_F16 are both 2-byte storage
+  const int es = storage_bytes(dtype), epc = 16 / es, bke = 128 / es;
   if (Cin % epc || !is_pow2(Cin) || N % 4 || Kw % bke || Kw < 9 * Cin + bke || K2 > bke || x2_cstride < K2 || (H & 1) || (W & 1))
     return fail(FSVIT_ERR_ARG, "fsvit_conv_stem_tail: bad geometry");
   Layer L; L.w = const_cast<void*>(w); L.bias = const_cast<float*>(bias); L.N = N; L.K = 9 * Cin; L.Kw = Kw; L.groups = 1;
   ConvGemmParams p = conv_params(L, x, y, B, H, W, Cin, Cin, 3, 3, 1, 1, N, ACT_LRELU, nullptr, 0, pos);
   p.x2 = x2; p.x2_cstride = x2_cstride; p.K2 = K2; p.pool2 = 1;
-  RC_TRY(K(launch_conv_gemm)(p, kd(dtype), (hipStream_t)stream));
+  RC_TRY(K(launch_conv_gemm)(p, kg(dtype), (hipStream_t)stream));
   return 0;
 }
 
@@ -919,7 +951,7 @@ extern "C" int fsvit_qkv_attention(const void* x, const void* wqkv, int kw, cons
 
 extern "C" int fsvit_attention(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, void* stream) {
   const int kdt = dtype;
-  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  if (!known_dtype(dtype)) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (!qkv || !ctx) return fail(FSVIT_ERR_ARG, "null argument");
   int rc = K(launch_attention)(qkv, ctx, B, S, heads, hdp, scale, kd(dtype), (hipStream_t)stream);
   if (rc != 0) return hipfail((hipError_t)rc, "attention");
@@ -928,7 +960,7 @@ extern "C" int fsvit_attention(const void* qkv, void* ctx, int B, int S, int hea
 
 extern "C" int fsvit_im2col27(const float* x, void* out, int B, int H, int W, int dtype, void* stream) {
   const int kdt = dtype;
-  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  if (!known_dtype(dtype)) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (!x || !out || (H & 1) || (W & 1)) return fail(FSVIT_ERR_ARG, "bad argument");
   RC_TRY(K(launch_im2col27)(x, out, B, H, W, H / 2, W / 2, kd(dtype), (hipStream_t)stream));
   return 0;
@@ -944,7 +976,7 @@ extern "C" int fsvit_stem_conv1(const float* x, const void* w, int kw, const flo
 
 extern "C" int fsvit_maxpool2_pos(const void* in, const float* pos, void* out, int B, int OH, int OW, int C, int dtype, void* stream) {
   const int kdt = dtype;
-  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  if (!known_dtype(dtype)) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (!in || !out || C % 4) return fail(FSVIT_ERR_ARG, "bad argument");
   RC_TRY(K(launch_maxpool2_pos)(in, pos, out, B, OH, OW, C, kd(dtype), (hipStream_t)stream));
   return 0;
@@ -953,7 +985,7 @@ extern "C" int fsvit_maxpool2_pos(const void* in, const float* pos, void* out, i
 extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float* shift, float* feat, int B, int HW, int C,
                                  int dtype, void* stream) {
   const int kdt = dtype;
-  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  if (!known_dtype(dtype)) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (!x || !scale || !shift || !feat || C % 4) return fail(FSVIT_ERR_ARG, "bad argument");
   RC_TRY(K(launch_pool_affine)(x, scale, shift, feat, B, HW, C, kd(dtype), (hipStream_t)stream));
   return 0;
@@ -970,7 +1002,9 @@ extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
   static const char* f16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<_Float16,128,64,2,2,3>", "conv_gemm_v2_kernel<_Float16,128,32,4,1,3>",
                                "im2col27_kernel<_Float16>", "maxpool2_pos_kernel<_Float16>", "attention_v2_kernel<_Float16,...>", "pool_affine_kernel<_Float16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<_Float16,128,128,2,2,2>",
                                "patchify_kernel<_Float16>", "layernorm_kernel<_Float16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel"};
+  static const char* x2n[] = {"-", "conv_gemm_v2_kernel<f32x2l,128,64,2,2,3>", "conv_gemm_v2_kernel<f32x2l,128,32,4,1,3>", "", "", "", "", "", "", "conv_gemm_v2_kernel<f32x2l,128,128,2,2,2>"};
   if (kernel_id < 0 || kernel_id > 16) return "?";
+  if (is_x2(dtype)) return (kernel_id == 1 || kernel_id == 2 || kernel_id == 9) ? x2n[kernel_id] : f32n[kernel_id];
   return dtype == FSVIT_F32 ? f32n[kernel_id] : dtype == FSVIT_F16 ? f16n[kernel_id] : bf16n[kernel_id];
 }
 
@@ -1168,13 +1202,13 @@ int vit_forward_chunk(fsvit_vit* h, const float* x, int Bc, float* feat, unsigne
 
 extern "C" int fsvit_vit_create(const fsvit_vit_cfg* cfg, const fsvit_tensor* state_dict, int n_tensors, int dtype, fsvit_vit** out) {
   if (!cfg || !state_dict || !out || n_tensors <= 0) return fail(FSVIT_ERR_ARG, "null argument");
-  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  if (!known_dtype(dtype)) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
   if (cfg->num_heads < 1 || cfg->embed_dim < 8 || cfg->depth < 0 || cfg->patch_size < 1) return fail(FSVIT_ERR_ARG, "bad ViT configuration");
   fsvit_vit* h = new fsvit_vit();
   h->kind = KIND_VIT;
   h->cfg = *cfg;
   h->dtype = dtype;
-  h->es = dtype == FSVIT_F32 ? 4 : 2;
+  h->es = storage_bytes(dtype);
   SD sd{state_dict, n_tensors};
   int rc = build_vit(h, sd);
   if (rc != 0) { fsvit_vit_destroy(h); return rc; }

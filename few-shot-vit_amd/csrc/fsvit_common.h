@@ -34,6 +34,10 @@ template <> struct Elem<float> {
   static constexpr int kPerChunk = 4;      // elements per 16-byte chunk
   static constexpr int kBK = 32;           // elements per 128-byte K slice
 };
+// fp32 storage whose GEMMs run as two-limb 16-bit MFMAs (conv_gemm_v2.hip x2_split): same layout as float, a distinct type so that the
+// kernel instantiation carries its own name in a profile
+struct f32x2l { float v; };
+template <> struct Elem<f32x2l> : Elem<float> {};
 template <> struct Elem<bf16> {
   static constexpr int kPerChunk = 8;
   static constexpr int kBK = 64;
@@ -62,6 +66,20 @@ template <> __device__ __forceinline__ f32x4 mma_chunk<float>(u32x4 a, u32x4 b, 
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// erf-form GELU through the Abramowitz-Stegun 7.1.26 erfc polynomial: |erfc error| <= 1.5e-7 (|gelu error| <= ~1e-7 |x|, fp32 rounding
+// level) in ~18 VALU issues, against ~60 for erff.  The two-limb GEMM modes use it (their GEMMs deviate by 1e-5 .. 1e-4 already); `parity`
+// keeps erff.
+__device__ __forceinline__ float gelu_erfc(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float q = fmaf(1.061405429f, t, -1.453152027f);
+  q = fmaf(q, t, 1.421413741f);
+  q = fmaf(q, t, -0.284496736f);
+  q = fmaf(q, t, 0.254829592f);
+  const float h = 0.5f * x * (q * t) * __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);    // 0.5 x erfc(|x| / sqrt 2)
+  return x > 0.0f ? x - h : h;
+}
 
 // GELU as x * sigmoid(x * (c0 + c1 x^2 + c2 x^4)): minimax fit of the three coefficients against the exact erf form,
 // max |gelu_sig - gelu_erf| = 2.6e-5 over the whole real line (x^2 is clamped at 64, where the sigmoid has long saturated
@@ -122,7 +140,9 @@ template <> __device__ __forceinline__ f32x4 load4<bf16>(const bf16* p) {
   f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
   return r;
 }
+template <> __device__ __forceinline__ f32x4 load4<f32x2l>(const f32x2l* p) { return *reinterpret_cast<const f32x4*>(p); }
 template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<f32x2l>(f32x2l* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
   bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};

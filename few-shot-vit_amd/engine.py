@@ -12,8 +12,10 @@ import torch
 
 from . import _lib
 
-DTYPES = {'f32': _lib.F32, 'parity': _lib.F32, 'fp32': _lib.F32, 'bf16': _lib.BF16, 'f16': _lib.F16, 'fp16': _lib.F16}
-TORCH_DTYPE = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.F16: torch.float16}
+DTYPES = {'f32': _lib.F32, 'parity': _lib.F32, 'fp32': _lib.F32, 'bf16': _lib.BF16, 'f16': _lib.F16, 'fp16': _lib.F16,
+          'bf16x2': _lib.BF16X2, 'f16x2': _lib.F16X2}
+TORCH_DTYPE = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.F16: torch.float16, _lib.BF16X2: torch.float32, _lib.F16X2: torch.float32}
+EVAL_ONLY = (_lib.F16, _lib.BF16X2, _lib.F16X2)
 
 
 # Packed eval engines cache BN-folded copies of the weights.  The HIP optimizers and the HIP trainer write parameters and running
@@ -32,7 +34,8 @@ def weight_generation() -> int:
 
 def default_numerics() -> str:
     """'bf16' (throughput mode) unless FSVIT_NUMERICS selects another one: 'f16' (fp16 storage + MFMA: same kernels and rate, 8 x smaller
-    logit deviation than bf16, eval only) or 'parity' / 'f32' (exact-fp32 MFMA)."""
+    logit deviation than bf16, eval only), 'bf16x2' / 'f16x2' (fp32 storage, every GEMM on the 16-bit MFMA with two-limb operands: meets the
+    1e-3 logit tolerance at several times the fp32-MFMA rate, eval only) or 'parity' / 'f32' (exact-fp32 MFMA)."""
     return os.environ.get('FSVIT_NUMERICS', 'bf16')
 
 
@@ -63,7 +66,7 @@ class _EncoderEngine:
         self.lib = _lib.load()
         numerics = numerics or default_numerics()
         if numerics not in DTYPES:
-            raise ValueError(f'unknown numerics mode {numerics!r} (bf16 | f16 | parity)')
+            raise ValueError(f'unknown numerics mode {numerics!r} (bf16 | f16 | bf16x2 | f16x2 | parity)')
         self.dtype = DTYPES[numerics]
         self.device = torch.device(device if device is not None else 'cuda')
         if self.device.type != 'cuda':
@@ -200,8 +203,8 @@ class VisformerTrainer:
         numerics = numerics or default_numerics()
         if numerics not in DTYPES:
             raise ValueError(f'unknown numerics mode {numerics!r} (bf16 | parity)')
-        if DTYPES[numerics] == _lib.F16:
-            raise NotImplementedError("fsvit: the 'f16' numerics mode is an eval mode (no loss scaling is built); train in 'bf16' or 'parity'")
+        if DTYPES[numerics] in EVAL_ONLY:
+            raise NotImplementedError(f"fsvit: the {numerics!r} numerics mode is an eval mode; train in 'bf16' or 'parity'")
         self.dtype = DTYPES[numerics]
         self.device = torch.device(device if device is not None else 'cuda')
         if self.device.type != 'cuda':
@@ -312,8 +315,8 @@ class VitTrainer:
         numerics = numerics or default_numerics()
         if numerics not in DTYPES:
             raise ValueError(f'unknown numerics mode {numerics!r} (bf16 | parity)')
-        if DTYPES[numerics] == _lib.F16:
-            raise NotImplementedError("fsvit: the 'f16' numerics mode is an eval mode (no loss scaling is built); train in 'bf16' or 'parity'")
+        if DTYPES[numerics] in EVAL_ONLY:
+            raise NotImplementedError(f"fsvit: the {numerics!r} numerics mode is an eval mode; train in 'bf16' or 'parity'")
         self.dtype = DTYPES[numerics]
         self.device = torch.device(device if device is not None else 'cuda')
         if self.device.type != 'cuda':
@@ -400,8 +403,20 @@ class ops:
         raise TypeError(t.dtype)
 
     @staticmethod
-    def conv_gemm(x, w, bias, res, pos, B, H, W, Cin, KH, KW, stride, pad, N, groups, act, res_first, x_cstride=None):
-        """x NHWC [B,H,W,x_cstride]; w [groups][N][Kw] packed; returns y NHWC [B,OH,OW,groups*N]."""
+    def x2_limbs(w: torch.Tensor, numerics: str) -> torch.Tensor:
+        """fp32 weights -> the two-limb words of the 'bf16x2' / 'f16x2' GEMM (upper half hi = w rounded to the 16-bit type, lower half
+        lo = (w - hi) rounded to it), as a float32-typed tensor of the same shape (fsvit.h: FSVIT_BF16X2 / FSVIT_F16X2)."""
+        t16 = torch.bfloat16 if numerics == 'bf16x2' else torch.float16
+        w = w.float()
+        hi = w.to(t16)
+        lo = (w - hi.float()).to(t16)
+        words = (hi.view(torch.int16).to(torch.int32) << 16) | (lo.view(torch.int16).to(torch.int32) & 0xffff)
+        return words.view(torch.float32)
+
+    @staticmethod
+    def conv_gemm(x, w, bias, res, pos, B, H, W, Cin, KH, KW, stride, pad, N, groups, act, res_first, x_cstride=None, numerics=None):
+        """x NHWC [B,H,W,x_cstride]; w [groups][N][Kw] packed; returns y NHWC [B,OH,OW,groups*N].  numerics 'bf16x2' / 'f16x2': x fp32,
+        w = ops.x2_limbs(packed fp32 weights)."""
         _require_cuda(x, w)
         lib = _lib.load()
         OH = (H + 2 * pad - KH) // stride + 1
@@ -411,7 +426,7 @@ class ops:
         with torch.cuda.device(x.device):
             _lib.check(lib.fsvit_conv_gemm(_ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(pos), _ptr(y), B, H, W, Cin, x_cstride,
                                            KH, KW, stride, pad, N, groups * N, w.shape[-1], groups, act, int(res_first),
-                                           ops._dt(x), _stream_ptr(x.device)))
+                                           DTYPES[numerics] if numerics else ops._dt(x), _stream_ptr(x.device)))
         return y
 
     @staticmethod

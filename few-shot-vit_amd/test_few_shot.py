@@ -125,7 +125,7 @@ def main():
     parser.add_argument('--episodes', type=int, default=2000, help='number of batches (reference: 2000)')
     parser.add_argument('--ep-per-batch', type=int, default=1)
     parser.add_argument('--launch-batches', type=int, default=16)
-    parser.add_argument('--numerics', default=None, choices=[None, 'bf16', 'f16', 'parity'])
+    parser.add_argument('--numerics', default=None, choices=[None, 'bf16', 'f16', 'bf16x2', 'f16x2', 'parity'])
     args = parser.parse_args()
     config = yaml.load(open(args.config, 'r'), Loader=yaml.FullLoader)
     if args.gpu is not None and ',' not in args.gpu:

@@ -14,7 +14,11 @@
  *   - `dtype` selects storage + MFMA arithmetic of activations/weights: FSVIT_F32 = exact fp32
  *     MFMA (v_mfma_f32_16x16x4_f32, the parity mode), FSVIT_BF16 = bf16 MFMA with fp32 accumulate, FSVIT_F16 = fp16 MFMA with
  *     fp32 accumulate (eval engines only: same kernels, same rate, 3 more mantissa bits than bf16; |activations| must stay
- *     below 65504, which BatchNorm / LayerNorm networks do with a wide margin).
+ *     below 65504, which BatchNorm / LayerNorm networks do with a wide margin).  FSVIT_BF16X2 / FSVIT_F16X2 (eval engines and
+ *     fsvit_conv_gemm): fp32 storage as FSVIT_F32, but every GEMM runs on the 16-bit MFMA with both operands split into two 16-bit
+ *     limbs (hi + lo; two MFMAs per K chunk = all four limb products, fp32 accumulate): 16 (bf16 limbs) / 22 (fp16 limbs) significand
+ *     bits per operand at 1/4 of the 16-bit MFMA rate = 4 x the fp32-MFMA rate.  Weights given to fsvit_conv_gemm in these modes are
+ *     4-byte limb pairs (upper half hi, lower half lo).
  */
 #ifndef FSVIT_H
 #define FSVIT_H
@@ -25,7 +29,7 @@
 extern "C" {
 #endif
 
-enum { FSVIT_F32 = 0, FSVIT_BF16 = 1, FSVIT_F16 = 2 };
+enum { FSVIT_F32 = 0, FSVIT_BF16 = 1, FSVIT_F16 = 2, FSVIT_BF16X2 = 3, FSVIT_F16X2 = 4 };
 enum { FSVIT_ACT_NONE = 0, FSVIT_ACT_GELU = 1, FSVIT_ACT_LRELU = 2 };
 enum { FSVIT_HEAD_COS = 0, FSVIT_HEAD_SQR = 1, FSVIT_HEAD_DOT = 2 };
 enum {

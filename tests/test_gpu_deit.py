@@ -19,7 +19,7 @@ def _model(name, numerics):
 
 
 @pytest.mark.parametrize('name,B', [('deit_small_patch16_224', 3), ('deit_micro_patch6_84', 4)])
-@pytest.mark.parametrize('numerics,tol', [('parity', 1e-3), ('bf16', 0.15)])
+@pytest.mark.parametrize('numerics,tol', [('parity', 1e-3), ('bf16x2', 1e-3), ('f16x2', 1e-3), ('bf16', 0.15)])
 def test_deit_features_vs_reference_golden_and_oracle(golden_dir, name, B, numerics, tol):
     from oracle import deit_oracle as do
     z = np.load(os.path.join(golden_dir, 'deit.npz'))
@@ -41,7 +41,7 @@ def test_deit_features_vs_reference_golden_and_oracle(golden_dir, name, B, numer
     assert err <= tol
     assert (feat - ref).abs().max().item() <= tol
     for k, v in worst.items():
-        assert v <= (2e-4 if numerics == 'parity' else 0.1), (k, v)
+        assert v <= (2e-4 if numerics == 'parity' else 1e-3 if numerics.endswith('x2') else 0.1), (k, v)
     assert m.out_dim == D and feat.shape == (B, D)
 
 

@@ -101,6 +101,43 @@ def test_conv_gemm(case, dt):
     assert err <= _tol(dt, ref), (name, dt, err)
 
 
+X2_CASES = ['1x1_gelu', '3x3_lrelu_res', '3x3_grouped', 'k2s2_pos', '1x1_tails', '1x1_qkv_like', 'k32_im2col', '1x1_bigK', '3x3_small_n32']
+
+
+@pytest.mark.parametrize('numerics', ['bf16x2', 'f16x2'])
+@pytest.mark.parametrize('case', [c for c in CASES if c[0] in X2_CASES], ids=X2_CASES)
+def test_conv_gemm_two_limb(case, numerics):
+    """fp32 storage, two-limb 16-bit MFMA arithmetic (conv_gemm_v2_kernel<f32x2l,...>): UN-rounded fp32 operands against an fp64
+    convolution.  Operand precision 2^-16 (bf16 limbs; the activation's hi limb is a truncation) / 2^-21 (fp16 limbs)."""
+    from fewshot_vit_amd.engine import ops
+    name, B, H, W, Cin, O, KH, s, p, groups, act, use_res, res_first, use_bias, use_pos = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000)
+    Ig = Cin // groups
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(O, Ig, KH, KH, generator=g) / math.sqrt(Ig * KH * KH)
+    bias = torch.randn(O, generator=g) * 0.3 if use_bias else None
+    OH = (H + 2 * p - KH) // s + 1
+    res = torch.randn(B, O, OH, OH, generator=g) if use_res else None
+    pos = torch.randn(OH * OH, O, generator=g) * 0.2 if use_pos else None
+    ref = F.conv2d(x.double(), w.double(), bias.double() if use_bias else None, stride=s, padding=p, groups=groups)
+    if use_res and res_first:
+        ref = ref + res
+    ref = {0: lambda t: t, 1: F.gelu, 2: lambda t: F.leaky_relu(t, 0.1)}[act](ref)
+    if use_res and not res_first:
+        ref = ref + res
+    if use_pos:
+        ref = ref + pos.t().reshape(1, O, OH, OH)
+    dev = 'cuda'
+    wd = ops.x2_limbs(pack_w(w, groups, torch.float32), numerics).to(dev)
+    y = ops.conv_gemm(x.permute(0, 2, 3, 1).contiguous().to(dev), wd, bias.to(dev) if use_bias else None,
+                      res.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None, pos.to(dev) if use_pos else None,
+                      B, H, W, Ig, KH, KH, s, p, O // groups, groups, act, res_first, numerics=numerics)
+    torch.cuda.synchronize()
+    err = (y.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
+    print(f'conv_gemm[{numerics}] {name}: max err {err:.3e} (max |y| {ref.abs().max():.2f})')
+    assert err <= (1e-4 if numerics == 'bf16x2' else 2e-5) * max(1.0, float(ref.abs().max())), (name, numerics, err)
+
+
 @pytest.mark.parametrize('dt,B', [('bf16', 53), ('bf16', 3), ('f32', 2)])
 def test_stem_tail_conv3_downsample_lrelu_maxpool_pos(dt, B):
     """The most expensive instantiation of the bench, conv3x3_halo_kernel<128,true>: conv3 + bn3 with the
