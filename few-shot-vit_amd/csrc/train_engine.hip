@@ -284,7 +284,9 @@ int bn_fwd(TR* t, const std::string& name, const void* z, int M, int C, int act,
 }
 
 // dy: gradient w.r.t. the BN output (after undoing the activation) -> dz; writes dgamma / dbeta
-int bn_bwd(TR* t, const std::string& name, const BnSave& sv, const void* dy, void* dz) {
+// acc / scale2 / out2 / rows_per_img: the fused tail of launch_bn_bwd_apply (dz = acc + ..., out2 = scale2[image] * dz)
+int bn_bwd(TR* t, const std::string& name, const BnSave& sv, const void* dy, void* dz, const void* acc = nullptr, const float* scale2 = nullptr,
+           void* out2 = nullptr, size_t rows_per_img = 0) {
   const fsvit_param *g = getp(t, name + ".weight"), *b = getp(t, name + ".bias");
   if (!g || !b) return FSVIT_ERR_KEY;
   const size_t mark = t->tmp.off;
@@ -295,7 +297,7 @@ int bn_bwd(TR* t, const std::string& name, const BnSave& sv, const void* dy, voi
   float* dbeta = b->grad ? b->grad : coef + 4 * sv.C;
   T_RUN(launch_bn_reduce(dy, sv.z, sv.mean, sv.invstd, partial, sv.M, sv.C, 1, t->dtype, t->st));
   T_RUN(launch_bn_bwd_finalize(partial, sv.M, sv.C, g->data, sv.invstd, dgamma, dbeta, coef, coef + sv.C, coef + 2 * sv.C, t->freeze_bn ? 1 : 0, t->st));
-  T_RUN(launch_bn_bwd_apply(dy, sv.z, sv.mean, sv.invstd, coef, coef + sv.C, coef + 2 * sv.C, dz, (size_t)sv.M, sv.C, t->dtype, t->st));
+  T_RUN(launch_bn_bwd_apply(dy, sv.z, sv.mean, sv.invstd, coef, coef + sv.C, coef + 2 * sv.C, dz, (size_t)sv.M, sv.C, t->dtype, t->st, acc, scale2, out2, rows_per_img));
   t->tmp.off = mark;
   return 0;
 }
@@ -504,8 +506,10 @@ int train_backward_impl(TR* t, const float* dfeat) {
       const std::string p = "stage" + std::to_string(sg) + "." + std::to_string(i) + ".";
       const size_t mark = t->tmp.off;
       // mlp branch:  out = xa + s2 * fc2(gelu(fc1(bn2(xa))))
+      // (dz2 sits at the same tmp offset in every block of the stage: the drop-path-scaled copy of dx each branch starts from is written by
+      // the fused tail of the preceding BatchNorm backward, only the stage's first block launches the copy itself)
       void* dz2 = take_tmp(t, M * C); NEED(dz2);
-      T_RUN(launch_add_scaled(nullptr, dx, b.s2, dz2, M * C, (size_t)Ho * Ho * C, dt, st));
+      if (i == (int)blocks.size() - 1) T_RUN(launch_add_scaled(nullptr, dx, b.s2, dz2, M * C, (size_t)Ho * Ho * C, dt, st));
       T_TRY(conv_bwd_weight(t, cs.fc2, b.h, B, Ho, Ho, dz2));
       void* dh = take_tmp(t, M * hid); NEED(dh);
       T_TRY(conv_bwd_data(t, cs.fc2, dz2, B, Ho, Ho, dh));
@@ -513,10 +517,8 @@ int train_backward_impl(TR* t, const float* dfeat) {
       T_TRY(conv_bwd_weight(t, cs.fc1, b.xn2, B, Ho, Ho, dh));
       void* dxn2 = take_tmp(t, M * C); NEED(dxn2);
       T_TRY(conv_bwd_data(t, cs.fc1, dh, B, Ho, Ho, dxn2));
-      T_TRY(bn_bwd(t, p + "norm2.bn", b.bn2, dxn2, dz2));                                      // dz2 := d(xa) through norm2
-      T_RUN(launch_add_scaled(dx, dz2, nullptr, dx, M * C, (size_t)Ho * Ho * C, dt, st));     // dx := d(xa) total
-      // attention branch:  xa = x + s1 * proj(attn(qkv(bn1(x))))
-      T_RUN(launch_add_scaled(nullptr, dx, b.s1, dz2, M * C, (size_t)Ho * Ho * C, dt, st));   // dz2 := dzp
+      // dx := d(xa) total = dx + norm2 backward;  attention branch:  xa = x + s1 * proj(attn(qkv(bn1(x)))):  dz2 := dzp = s1 * dx
+      T_TRY(bn_bwd(t, p + "norm2.bn", b.bn2, dxn2, dx, dx, b.s1, dz2, (size_t)Ho * Ho));
       T_TRY(conv_bwd_weight(t, cs.proj, b.ctx, B, Ho, Ho, dz2));
       void* dctx = take_tmp(t, M * heads * hdp); NEED(dctx);
       T_TRY(conv_bwd_data(t, cs.proj, dz2, B, Ho, Ho, dctx));
@@ -524,8 +526,9 @@ int train_backward_impl(TR* t, const float* dfeat) {
       T_RUN(launch_attention_bwd(b.qkv, dctx, dqkv, B, Ho * Ho, heads, hd, hdp, scale, dt, st));
       T_TRY(conv_bwd_weight(t, cs.qkv, b.xn1, B, Ho, Ho, dqkv));
       T_TRY(conv_bwd_data(t, cs.qkv, dqkv, B, Ho, Ho, dxn2));                                 // dxn2 := d(xn1)
-      T_TRY(bn_bwd(t, p + "norm1.bn", b.bn1, dxn2, dz2));
-      T_RUN(launch_add_scaled(dx, dz2, nullptr, dx, M * C, (size_t)Ho * Ho * C, dt, st));
+      // dx += norm1 backward; the next block (i - 1) of the stage starts from dz2 = s2' * dx
+      if (i > 0) T_TRY(bn_bwd(t, p + "norm1.bn", b.bn1, dxn2, dx, dx, blocks[i - 1].s2, dz2, (size_t)Ho * Ho));
+      else T_TRY(bn_bwd(t, p + "norm1.bn", b.bn1, dxn2, dx, dx));
       t->tmp.off = mark;
     }
     // patch embed:  out = bn(conv_k2s2(xin) + bias) + pos
@@ -570,7 +573,7 @@ int train_backward_impl(TR* t, const float* dfeat) {
     const std::string p = "stage1." + std::to_string(i) + ".";
     const size_t mark = t->tmp.off;
     void* dz3 = take_tmp(t, M1 * t->C1); NEED(dz3);
-    T_RUN(launch_add_scaled(nullptr, dx, b.scale, dz3, M1 * t->C1, (size_t)H1 * H1 * t->C1, dt, st));
+    if (i == (int)t->s1.size() - 1) T_RUN(launch_add_scaled(nullptr, dx, b.scale, dz3, M1 * t->C1, (size_t)H1 * H1 * t->C1, dt, st));
     T_TRY(conv_bwd_weight(t, sp.s1c3[i], b.h2, B, H1, H1, dz3));
     void* dh2 = take_tmp(t, M1 * t->hid1); NEED(dh2);
     T_TRY(conv_bwd_data(t, sp.s1c3[i], dz3, B, H1, H1, dh2));
@@ -581,9 +584,9 @@ int train_backward_impl(TR* t, const float* dfeat) {
     T_RUN(launch_gelu_bwd(dh1, b.z1, dh1, M1 * t->hid1, dt, st));
     T_TRY(conv_bwd_weight(t, sp.s1c1[i], b.xn, B, H1, H1, dh1));
     T_TRY(conv_bwd_data(t, sp.s1c1[i], dh1, B, H1, H1, dz3));                                  // dz3 := d(xn)
-    void* dxb = take_tmp(t, M1 * t->C1); NEED(dxb);
-    T_TRY(bn_bwd(t, p + "norm2.bn", b.bn, dz3, dxb));
-    T_RUN(launch_add_scaled(dx, dxb, nullptr, dx, M1 * t->C1, (size_t)H1 * H1 * t->C1, dt, st));
+    // dx += norm2 backward (read from dz3); the next block's dz3 = scale' * dx goes to the same buffer (in place over the BatchNorm's dy)
+    if (i > 0) T_TRY(bn_bwd(t, p + "norm2.bn", b.bn, dz3, dx, dx, t->s1[i - 1].scale, dz3, (size_t)H1 * H1));
+    else T_TRY(bn_bwd(t, p + "norm2.bn", b.bn, dz3, dx, dx));
     t->tmp.off = mark;
   }
   // ---- stem

@@ -30,7 +30,8 @@ int launch_bn_frozen_coeffs(int C, float eps, const float* gamma, const float* b
 int launch_bn_apply(const void* z, const float* sa, const float* sb, const void* res, void* y, size_t M, int C, int act, int dtype, hipStream_t s);
 int launch_bn_act_bwd(const void* dout, const void* z, const float* sa, const float* sb, const void* res, void* g, size_t M, int C, int dtype, hipStream_t s);
 int launch_bn_bwd_apply(const void* dy, const void* z, const float* mean, const float* invstd, const float* ca, const float* cb, const float* cc, void* dz,
-                        size_t M, int C, int dtype, hipStream_t s);
+                        size_t M, int C, int dtype, hipStream_t s, const void* acc = nullptr, const float* scale2 = nullptr, void* out2 = nullptr,
+                        size_t rows_per_img = 0);
 int launch_gelu_fwd(const void* z, void* h, size_t n, int dtype, hipStream_t s);
 int launch_gelu_bwd(const void* dh, const void* z, void* dz, size_t n, int dtype, hipStream_t s);
 int launch_add_scaled(const void* a, const void* br, const float* scale, void* out, size_t n, size_t per_img, int dtype, hipStream_t s);

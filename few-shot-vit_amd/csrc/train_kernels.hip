@@ -117,6 +117,27 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
   }
 }
 
+// The same for a plain 1x1 layer without head-dim padding (dW[n][i] = sum_sp y[n][sp * Kc_pad + i], Ig % 4 == 0): 16-byte accesses and four
+// independent partial sums per thread - the generic kernel's serial scalar loop ran at ~0.5 TB/s over the 64 MB of partials a layer has.
+__global__ __launch_bounds__(256) void wgrad_finalize_1x1_kernel(const float* __restrict__ y, float* __restrict__ dw, int Ng, int Ig, int splits, int Kc_pad) {
+  const int i4n = Ig / 4;
+  const size_t total = (size_t)Ng * i4n;
+  GS_LOOP(idx, total) {
+    const int i = (int)(idx % i4n) * 4, n = (int)(idx / i4n);
+    const float* src = y + (size_t)n * splits * Kc_pad + i;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int sp = 0;
+    for (; sp + 4 <= splits; sp += 4) {
+      s0 += *reinterpret_cast<const f32x4*>(src + (size_t)sp * Kc_pad);
+      s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 1) * Kc_pad);
+      s2 += *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 2) * Kc_pad);
+      s3 += *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 3) * Kc_pad);
+    }
+    for (; sp < splits; ++sp) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)sp * Kc_pad);
+    *reinterpret_cast<f32x4*>(dw + (size_t)n * Ig + i) = (s0 + s1) + (s2 + s3);
+  }
+}
+
 // Grouped conv computed as ONE dense split-K GEMM (all cross-group products included, only the diagonal blocks are kept):
 // y[groups*Ng][splits * Kc_pad] with k = (ky*KW + kx) * (groups*Ig) + g*Ig + i  ->  dW[groups*Ng][Ig][KH][KW]
 __global__ __launch_bounds__(256) void wgrad_finalize_dense_kernel(const float* __restrict__ y, float* __restrict__ dw, int Ng, int Ig, int KH, int KW,
@@ -380,19 +401,32 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ d
 }
 
 // dz = ca[c] * dy + cb[c] + cc[c] * xhat,  xhat = (z - mean) * invstd
+// Optional fused tail of a residual block's backward (train_engine.hip): acc != nullptr adds the residual-stream gradient (dz = acc + ...,
+// dz may be acc itself), out2 != nullptr also stores scale2[image] * dz - the drop-path-scaled copy the next branch's weight / data
+// gradients start from (out2 may be dy itself: each thread reads its elements before it writes them).
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ z, const float* __restrict__ mean,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, const T* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ ca, const float* __restrict__ cb,
-                                                           const float* __restrict__ cc, T* __restrict__ dz, size_t M, int C) {
+                                                           const float* __restrict__ cc, T* dz, size_t M, int C, const T* acc, const float* __restrict__ scale2,
+                                                           T* out2, size_t rows_per_img) {
   const int c4n = C / 4;
   const size_t total = M * c4n;
   GS_LOOP(idx, total) {
     const int c = (int)(idx % c4n) * 4;
-    const size_t off = (idx / c4n) * C + c;
+    const size_t row = idx / c4n, off = row * C + c;
     const f32x4 xh = (load4<T>(z + off) - *reinterpret_cast<const f32x4*>(mean + c)) * *reinterpret_cast<const f32x4*>(invstd + c);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(ca + c) * load4<T>(dy + off) + *reinterpret_cast<const f32x4*>(cb + c) +
-                    *reinterpret_cast<const f32x4*>(cc + c) * xh;
+    f32x4 v = *reinterpret_cast<const f32x4*>(ca + c) * load4<T>(dy + off) + *reinterpret_cast<const f32x4*>(cb + c) +
+              *reinterpret_cast<const f32x4*>(cc + c) * xh;
+    if (acc) v += load4<T>(acc + off);
     store4<T>(dz + off, v);
+    if (out2) {
+      // the copy scales what the NEXT kernels will read back from dz, i.e. the value rounded to the storage type
+      f32x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = to_f32<T>(from_f32<T>(v[e]));
+      if (scale2) w = w * scale2[row / rows_per_img];
+      store4<T>(out2 + off, w);
+    }
   }
 }
 
@@ -725,6 +759,10 @@ int launch_pack_weight_multi(const PackJob* jobs, int n, int dtype, hipStream_t 
 int launch_wgrad_finalize(const float* y, float* dw, int Ng, int Ig, int KH, int KW, int g, int splits, int Kc_pad, int hd_rows, int hdp_rows, int hd_cols,
                           int hdp_cols, hipStream_t s) {
   const size_t total = (size_t)Ng * Ig * KH * KW;
+  if (KH == 1 && KW == 1 && g == 0 && hd_rows == hdp_rows && hd_cols == hdp_cols && (Ig & 3) == 0 && (Kc_pad & 3) == 0) {
+    hipLaunchKernelGGL(wgrad_finalize_1x1_kernel, dim3(gs_grid((size_t)Ng * (Ig / 4))), dim3(256), 0, s, y, dw, Ng, Ig, splits, Kc_pad);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(gs_grid(total)), dim3(256), 0, s, y, dw, Ng, Ig, KH, KW, g, splits, Kc_pad, hd_rows, hdp_rows, hd_cols, hdp_cols);
   return (int)hipGetLastError();
 }
@@ -804,10 +842,13 @@ int launch_bn_act_bwd(const void* dout, const void* z, const float* sa, const fl
   return (int)hipGetLastError();
 }
 int launch_bn_bwd_apply(const void* dy, const void* z, const float* mean, const float* invstd, const float* ca, const float* cb, const float* cc, void* dz,
-                        size_t M, int C, int dtype, hipStream_t s) {
+                        size_t M, int C, int dtype, hipStream_t s, const void* acc, const float* scale2, void* out2, size_t rows_per_img) {
   const size_t total = M * (C / 4);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, (const float*)dy, (const float*)z, mean, invstd, ca, cb, cc, (float*)dz, M, C),
-             hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, (const bf16*)dy, (const bf16*)z, mean, invstd, ca, cb, cc, (bf16*)dz, M, C));
+  if (!rows_per_img) rows_per_img = 1;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, (const float*)dy, (const float*)z, mean, invstd, ca, cb, cc, (float*)dz, M, C,
+                                       (const float*)acc, scale2, (float*)out2, rows_per_img),
+             hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, (const bf16*)dy, (const bf16*)z, mean, invstd, ca, cb, cc, (bf16*)dz, M, C,
+                                (const bf16*)acc, scale2, (bf16*)out2, rows_per_img));
   return (int)hipGetLastError();
 }
 int launch_gelu_fwd(const void* z, void* h, size_t n, int dtype, hipStream_t s) {
