@@ -127,7 +127,9 @@ int launch_proto_head(const float* feat_shot, const float* feat_query, int E, in
 
 // Backward of the cosine head (meta_baseline.py:33-47 with method 'cos'): logits = temp * <q^, p^_c>, p_c = mean_s f_shot[c][s].
 // One workgroup per episode.  x^ = x / max(|x|, 1e-12):  dx = (dx^ - x^ <x^, dx^>) / |x|.
-__global__ __launch_bounds__(256) void proto_head_bwd_kernel(const float* __restrict__ feat_shot, const float* __restrict__ feat_query,
+// (16 waves per episode: the step has only ep_per_batch workgroups, each a chain of wave reductions - with 4 waves the kernel took 275 us)
+constexpr int HB_NT = 1024;
+__global__ __launch_bounds__(HB_NT) void proto_head_bwd_kernel(const float* __restrict__ feat_shot, const float* __restrict__ feat_query,
                                                              const float* __restrict__ dlogits, int way, int shot, int Q, int D, float temp,
                                                              float* __restrict__ dfeat_shot, float* __restrict__ dfeat_query, float* __restrict__ dtemp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -135,19 +137,19 @@ __global__ __launch_bounds__(256) void proto_head_bwd_kernel(const float* __rest
   float* dproto = proto + (size_t)way * D;                    // [way][D] gradient w.r.t. the normalised prototypes
   float* pinv = dproto + (size_t)way * D;                     // [way] 1 / |p_c|
   float* qinv = pinv + way;                                   // [Q]   1 / |q|
-  float* red = qinv + Q;                                      // [4] per-wave partial of dtemp
+  float* red = qinv + Q;                                      // [HB_NT / 64] per-wave partial of dtemp
   const int e = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const float* fs = feat_shot + (size_t)e * way * shot * D;
   const float* fq = feat_query + (size_t)e * Q * D;
   const float* dl = dlogits + (size_t)e * Q * way;
-  for (int i = t; i < way * D; i += 256) {
+  for (int i = t; i < way * D; i += HB_NT) {
     const int c = i / D, d = i - c * D;
     float s = 0.f;
     for (int k = 0; k < shot; ++k) s += fs[((size_t)c * shot + k) * D + d];
     proto[i] = s / (float)shot;
   }
   __syncthreads();
-  for (int c = wave; c < way; c += 4) {
+  for (int c = wave; c < way; c += HB_NT / 64) {
     float ss = 0.f;
     for (int d = lane; d < D; d += 64) ss += proto[c * D + d] * proto[c * D + d];
     const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void proto_head_bwd_kernel(const float* __rest
   __syncthreads();
   // queries: dq^ = temp * sum_c dl[q][c] p^_c ; dq = (dq^ - q^ <q^, dq^>) / |q| ; dtemp += sum_c dl[q][c] <q^, p^_c>
   float dt_acc = 0.f;
-  for (int q = wave; q < Q; q += 4) {
+  for (int q = wave; q < Q; q += HB_NT / 64) {
     const float* x = fq + (size_t)q * D;
     float ss = 0.f;
     for (int d = lane; d < D; d += 64) ss += x[d] * x[d];
@@ -179,16 +181,20 @@ __global__ __launch_bounds__(256) void proto_head_bwd_kernel(const float* __rest
   }
   if (lane == 0) red[wave] = dt_acc;
   __syncthreads();
-  if (t == 0 && dtemp) dtemp[e] = red[0] + red[1] + red[2] + red[3];
+  if (t == 0 && dtemp) {
+    float s = 0.f;
+    for (int w = 0; w < HB_NT / 64; ++w) s += red[w];
+    dtemp[e] = s;
+  }
   // prototypes: dp^_c[d] = temp * sum_q dl[q][c] q^[d]
-  for (int i = t; i < way * D; i += 256) {
+  for (int i = t; i < way * D; i += HB_NT) {
     const int c = i / D, d = i - c * D;
     float g = 0.f;
     for (int q = 0; q < Q; ++q) g += dl[q * way + c] * fq[(size_t)q * D + d] * qinv[q];
     dproto[i] = temp * g;
   }
   __syncthreads();
-  for (int c = wave; c < way; c += 4) {
+  for (int c = wave; c < way; c += HB_NT / 64) {
     float dot = 0.f;
     for (int d = lane; d < D; d += 64) dot += proto[c * D + d] * dproto[c * D + d];
     dot = wave_sum(dot);
@@ -258,11 +264,11 @@ int launch_proto_head_sqr_bwd(const float* feat_shot, const float* feat_query, c
 int launch_proto_head_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
                           float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s) {
   if (E <= 0) return 0;
-  const size_t lds = ((size_t)2 * way * D + way + Q + 4) * sizeof(float);
+  const size_t lds = ((size_t)2 * way * D + way + Q + HB_NT / 64) * sizeof(float);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute((const void*)proto_head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(proto_head_bwd_kernel, dim3(E), dim3(256), lds, s, feat_shot, feat_query, dlogits, way, shot, Q, D, temp, dfeat_shot, dfeat_query, dtemp);
+  hipLaunchKernelGGL(proto_head_bwd_kernel, dim3(E), dim3(HB_NT), lds, s, feat_shot, feat_query, dlogits, way, shot, Q, D, temp, dfeat_shot, dfeat_query, dtemp);
   return (int)hipGetLastError();
 }
 

@@ -166,12 +166,14 @@ class Visformer(nn.Module):
             return None
         depth = self.cfg['depth']
         rates = torch.linspace(0, self.drop_path_rate, sum(depth)).tolist()
-        rows = []
+        draws, keep = [], []
         for b, r in enumerate(rates):
             if r > 0:
                 for _ in range(1 if b < depth[0] else 2):
-                    rows.append((1.0 - r + torch.rand(n_img, device=device)).floor_())
-        return torch.stack(rows)
+                    draws.append(torch.rand(n_img, device=device))      # one generator call per DropPath call, as the reference makes them
+                    keep.append(1.0 - r)
+        # floor(keep_prob + rand) for all calls in one pass (same fp32 values as per-call arithmetic, a third of the launches)
+        return torch.stack(draws).add_(torch.tensor(keep, dtype=torch.float32, device=device).unsqueeze(1)).floor_()
 
     def forward(self, x, droppath_masks=None):
         """[B,3,img,img] fp32 -> [B,out_dim] pooled features (visformer.py:424-462).
