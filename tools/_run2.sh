@@ -1,3 +1,2 @@
-timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "two_limb or conv_gemm" 2>&1 | tail -2
-timeout 600 python -m pytest tests/test_gpu_visformer.py -x -q -m gpu -k "two_limb" -s 2>&1 | grep -E "dlogit|passed|failed"
-for n in bf16x2 f16x2; do python bench.py --numerics $n --no-cpu-baseline --no-modes --steps 4 --warmup 2 --layers 2>gpurun_out/x2e_layers_$n.txt | tail -1 | cut -c1-200; done
+python bench.py --model deit_small_patch16_224 --no-cpu-baseline --no-modes --steps 3 --warmup 1 --layers 2>gpurun_out/deit_layers_a.txt | tail -1 | cut -c1-160
+FSVIT_GEMM256_MIN_AI=100 python bench.py --model deit_small_patch16_224 --no-cpu-baseline --no-modes --steps 3 --warmup 1 --layers 2>gpurun_out/deit_layers_b.txt | tail -1 | cut -c1-160
