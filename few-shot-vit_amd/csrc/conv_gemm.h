@@ -71,6 +71,7 @@ struct ConvGemmParams {
   /* gemm256.hip: 256x256-tile, 8-wave, 4-phase dense 16-bit GEMM for plain [M][K] x [N][K] layers (N >= 192, K % 64 == 0) */ \
   bool gemm256_eligible(const ConvGemmParams& p, int dtype);                                                               \
   int launch_gemm256(const ConvGemmParams& p, hipStream_t stream);                                                         \
+  int launch_gemm256_x2(const ConvGemmParams& p, hipStream_t stream); /* dtype 2: two-limb arithmetic on fp32 storage */     \
   /* conv3x3_halo.hip: 3x3 / stride 1 conv with the input tile + halo resident in LDS (stem conv2 / conv3 geometry) */      \
   bool conv3x3_halo_eligible(const ConvGemmParams& p, int dtype);                                                          \
   int launch_conv3x3_halo(const ConvGemmParams& p, hipStream_t stream);                                                    \

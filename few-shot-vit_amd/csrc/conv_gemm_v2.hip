@@ -93,31 +93,6 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // with bf16 limbs, 22 with fp16 limbs.  The weights arrive pre-split (engine.hip upload()); the activations stay plain fp32
 // in HBM - every other kernel of the fp32 path is shared - and are split on their way into LDS (stash() in the kernel): x2_split() returns
 // the chunk in both slot orders.
-__device__ __forceinline__ void x2_split(const u32x4 v, u32x4& s, u32x4& r) {
-  // (the floats come from ONE bit_cast of the whole vector: hipcc 7.2 compiles __builtin_bit_cast(float, v[e]) of a vector element to
-  // element 0 for every e)
-  const f32x4 fv = __builtin_bit_cast(f32x4, v);
-#pragma unroll
-  for (int e = 0; e < 4; e += 2) {
-    const float x0 = fv[e], x1 = fv[e + 1];
-#ifdef FSVIT_HALF_F16
-    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
-    const h2_t h = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(x0, x1));           // any 11-bit rounding of x keeps x - hi exact
-    const h2_t l = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]));
-    const unsigned ch = __builtin_bit_cast(unsigned, h), cl = __builtin_bit_cast(unsigned, l);
-    s[e] = (ch << 16) | (cl & 0xffffu);             r[e] = (cl << 16) | (ch & 0xffffu);
-    s[e + 1] = (ch & 0xffff0000u) | (cl >> 16);     r[e + 1] = (cl & 0xffff0000u) | (ch >> 16);
-#else
-    typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
-    const unsigned u0 = v[e], u1 = v[e + 1];               // hi = the upper 16 bits (truncation; lo picks up the remainder exactly)
-    const b2_t l = {(__bf16)(x0 - __builtin_bit_cast(float, u0 & 0xffff0000u)), (__bf16)(x1 - __builtin_bit_cast(float, u1 & 0xffff0000u))};
-    const unsigned cl = __builtin_bit_cast(unsigned, l);
-    s[e] = (u0 & 0xffff0000u) | (cl & 0xffffu);     r[e] = (cl << 16) | (u0 >> 16);
-    s[e + 1] = (u1 & 0xffff0000u) | (cl >> 16);     r[e + 1] = (cl & 0xffff0000u) | (u1 >> 16);
-#endif
-  }
-}
-
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int MINB>
 __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmParams p, const int tiles_m, const int tiles_n) {
   constexpr int EPC = Elem<T>::kPerChunk;
@@ -462,14 +437,16 @@ int launch_conv_gemm_v2(const ConvGemmParams& p, int dtype, hipStream_t stream) 
 // the dense 1x1 layers, this file's persistent implicit GEMM for everything else.
 // rows per gemm256 slice of an over-long plain 1x1 layer, 0: not sliced (see launch_conv_gemm)
 static int gemm256_slice_rows(const ConvGemmParams& p, int dtype) {
-  const size_t row_bytes = (size_t)p.x_cstride * 2;
-  if (dtype != 1 || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.groups != 1 || p.pos || p.y_rpi || p.x2 || p.pool2) return 0;
+  const size_t es = dtype == 2 ? 4 : 2;
+  const size_t row_bytes = (size_t)p.x_cstride * es;
+  if ((dtype != 1 && dtype != 2) || p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.groups != 1 || p.pos || p.y_rpi || p.x2 || p.pool2) return 0;
   if ((size_t)p.M * row_bytes < (1ull << 32)) return 0;
   const int rows_max = (int)((((1ull << 32) - 1) / row_bytes) / 256 * 256);
   ConvGemmParams q = p;
   q.B = rows_max < p.M ? rows_max : p.M; q.H = q.W = q.OH = q.OW = 1; q.M = q.B;
   return rows_max >= 1024 && gemm256_eligible(q, dtype) ? rows_max : 0;
 }
+static int run_gemm256(const ConvGemmParams& p, int dtype, hipStream_t stream) { return dtype == 2 ? launch_gemm256_x2(p, stream) : launch_gemm256(p, stream); }
 // which kernel launch_conv_gemm runs for p: 0 conv3x3_halo, 1 gemm256 (whole or in row slices), 2 conv_gemm_v2
 int conv_gemm_route(const ConvGemmParams& p, int dtype) {
   if (conv3x3_halo_eligible(p, dtype)) return 0;
@@ -479,18 +456,19 @@ int conv_gemm_route(const ConvGemmParams& p, int dtype) {
 
 int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream) {
   if (conv3x3_halo_eligible(p, dtype)) return launch_conv3x3_halo(p, stream);
-  if (gemm256_eligible(p, dtype)) return launch_gemm256(p, stream);
+  if (gemm256_eligible(p, dtype)) return run_gemm256(p, dtype, stream);
   // A plain 1x1 layer whose activation matrix is past gemm256's 32-bit DMA offsets (a 12 800-image ViT chunk: 2.5 M rows x 1536 columns)
   // runs as row slices of < 4 GB each, if a slice is eligible.
   if (const int rows_max = gemm256_slice_rows(p, dtype)) {
+    const size_t es = dtype == 2 ? 4 : 2;
     ConvGemmParams q = p;
     q.H = q.W = q.OH = q.OW = 1;
     for (int m0 = 0; m0 < p.M; m0 += rows_max) {
       q.M = q.B = p.M - m0 < rows_max ? p.M - m0 : rows_max;
-      q.x = (const unsigned char*)p.x + (size_t)m0 * p.x_cstride * 2;
-      q.y = (unsigned char*)p.y + (size_t)m0 * p.y_cstride * 2;
-      q.res = p.res ? (const unsigned char*)p.res + (size_t)m0 * p.y_cstride * 2 : nullptr;
-      const int rc = gemm256_eligible(q, dtype) ? launch_gemm256(q, stream) : launch_conv_gemm_v2(q, dtype, stream);
+      q.x = (const unsigned char*)p.x + (size_t)m0 * p.x_cstride * es;
+      q.y = (unsigned char*)p.y + (size_t)m0 * p.y_cstride * es;
+      q.res = p.res ? (const unsigned char*)p.res + (size_t)m0 * p.y_cstride * es : nullptr;
+      const int rc = gemm256_eligible(q, dtype) ? run_gemm256(q, dtype, stream) : launch_conv_gemm_v2(q, dtype, stream);
       if (rc) return rc;
     }
     return 0;

@@ -149,6 +149,33 @@ template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
   *reinterpret_cast<bf16x4*>(p) = o;
 }
 
+// Two-limb split of one 16-byte chunk of fp32 values (conv_gemm_v2.hip / gemm256.hip, the `bf16x2` / `f16x2` modes): s = limb words
+// [hi | lo] (upper / lower half), r = the same words half-swapped.
+__device__ __forceinline__ void x2_split(const u32x4 v, u32x4& s, u32x4& r) {
+  // (the floats come from ONE bit_cast of the whole vector: hipcc 7.2 compiles __builtin_bit_cast(float, v[e]) of a vector element to
+  // element 0 for every e)
+  const f32x4 fv = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+  for (int e = 0; e < 4; e += 2) {
+    const float x0 = fv[e], x1 = fv[e + 1];
+#ifdef FSVIT_HALF_F16
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+    const h2_t h = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(x0, x1));           // any 11-bit rounding of x keeps x - hi exact
+    const h2_t l = __builtin_bit_cast(h2_t, __builtin_amdgcn_cvt_pkrtz(x0 - (float)h[0], x1 - (float)h[1]));
+    const unsigned ch = __builtin_bit_cast(unsigned, h), cl = __builtin_bit_cast(unsigned, l);
+    s[e] = (ch << 16) | (cl & 0xffffu);             r[e] = (cl << 16) | (ch & 0xffffu);
+    s[e + 1] = (ch & 0xffff0000u) | (cl >> 16);     r[e + 1] = (cl & 0xffff0000u) | (ch >> 16);
+#else
+    typedef __attribute__((ext_vector_type(2))) __bf16 b2_t;
+    const unsigned u0 = v[e], u1 = v[e + 1];               // hi = the upper 16 bits (truncation; lo picks up the remainder exactly)
+    const b2_t l = {(__bf16)(x0 - __builtin_bit_cast(float, u0 & 0xffff0000u)), (__bf16)(x1 - __builtin_bit_cast(float, u1 & 0xffff0000u))};
+    const unsigned cl = __builtin_bit_cast(unsigned, l);
+    s[e] = (u0 & 0xffff0000u) | (cl & 0xffffu);     r[e] = (cl << 16) | (u0 >> 16);
+    s[e + 1] = (u1 & 0xffff0000u) | (cl >> 16);     r[e + 1] = (cl & 0xffff0000u) | (u1 >> 16);
+#endif
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -54,7 +54,13 @@ __device__ __forceinline__ void bar() {
 
 constexpr int G_BM = 256, G_BN = 256, G_STAGE = 65536, G_BOFF = 32768;
 
-__global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvGemmParams p, const int tiles_m, const int tiles_n) {
+// LIMBS = the two-limb mode (`bf16x2` / `f16x2`, conv_gemm_v2.hip): fp32 activations / outputs, weights as (hi, lo) limb words.  The LDS
+// geometry is byte-identical (a 128-byte row = 32 fp32 k instead of 64 16-bit ones), so the whole DMA / phase / vmcnt structure is shared; the
+// activation fragments are split into limbs right after their LDS read (x2_split), the weight fragments half-swapped, and every MFMA of the
+// 16-bit kernel becomes the pair (w_swapped, x) + (w, x) = all four limb products.  64 flop per staged byte (128 in the 16-bit kernel).
+template <bool LIMBS>
+__device__ __forceinline__ void gemm256_body(const ConvGemmParams& p, const int tiles_m, const int tiles_n) {
+  constexpr int ES = LIMBS ? 4 : 2;                 // bytes per operand element
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvGemmParams p,
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, P = gridDim.x >> 3;
   const int cnt = tiles_m > xcd ? ((tiles_m - xcd + 7) / 8) * tiles_n : 0;
   if (slot >= cnt) return;
-  const int nk = p.Kw / 64;
+  const int nk = p.Kw / (128 / ES);
   const unsigned char* const Xb = reinterpret_cast<const unsigned char*>(p.x);
   const unsigned char* const Wb = reinterpret_cast<const unsigned char*>(p.w);
   bf16* __restrict__ Y = reinterpret_cast<bf16*>(p.y);
@@ -105,8 +111,8 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvGemmParams p,
         const int R = rbB[h][j] + srow, r32 = R & 31;
         int n = nt * G_BN + (R & ~31) + 8 * ((r32 & 15) >> 2) + 4 * (r32 >> 4) + (r32 & 3);
         n = n < p.N ? n : p.N - 1;
-        oa[h][j] = (unsigned)m * (unsigned)(p.x_cstride * 2) + schunk;
-        ob[h][j] = (unsigned)n * (unsigned)(p.Kw * 2) + schunk;
+        oa[h][j] = (unsigned)m * (unsigned)(p.x_cstride * ES) + schunk;
+        ob[h][j] = (unsigned)n * (unsigned)(p.Kw * ES) + schunk;
       }
   };
   // mode 1: K tile kt of the current output tile; mode 2: K tile 0 of the NEXT output tile
@@ -127,6 +133,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvGemmParams p,
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   u32x4 xa[4][2], wb[2][2];
+  bool xa_raw = false;                             // LIMBS: xa holds fp32 values not yet split into limb words
   auto readA = [&](int half, int stage) {          // rows wm*128 + half*64 + i*16 + lrow
     const unsigned char* base = smem + stage * G_STAGE + a_rd + half * (64 * 128);
 #pragma unroll
@@ -134,6 +141,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvGemmParams p,
       xa[i][0] = *reinterpret_cast<const u32x4*>(base + i * 2048 + sw0);
       xa[i][1] = *reinterpret_cast<const u32x4*>(base + i * 2048 + sw1);
     }
+    xa_raw = true;
   };
   auto readB = [&](int half, int stage) {          // weight rows wn*64 + half*32 + j*16 + lrow
     const unsigned char* base = smem + stage * G_STAGE + b_rd + half * (32 * 128);
@@ -144,12 +152,39 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvGemmParams p,
     }
   };
   auto mma = [&](int ah, int bh) {                 // quadrant (ah, bh): 4 x 2 tiles x 2 k-chunks
+    if constexpr (LIMBS) {
+      if (xa_raw) {                                // (after the phase's wait + barrier: the split sits next to the MFMAs that consume it)
 #pragma unroll
-    for (int kc = 0; kc < 2; ++kc)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+          for (int kc = 0; kc < 2; ++kc) {
+            u32x4 xs, xr;
+            x2_split(xa[i][kc], xs, xr);
+            xa[i][kc] = xs;
+          }
+        xa_raw = false;
+      }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[ah * 4 + i][bh * 2 + j] = mma_chunk<bf16>(wb[j][kc], xa[i][kc], acc[ah * 4 + i][bh * 2 + j]);
+      for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          u32x4 wr;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) wr[e] = __builtin_amdgcn_alignbit(wb[j][kc][e], wb[j][kc][e], 16);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[ah * 4 + i][bh * 2 + j] = mma_chunk<bf16>(wr, xa[i][kc], acc[ah * 4 + i][bh * 2 + j]);          // lo x hi + hi x lo
+            acc[ah * 4 + i][bh * 2 + j] = mma_chunk<bf16>(wb[j][kc], xa[i][kc], acc[ah * 4 + i][bh * 2 + j]);   // hi x hi + lo x lo
+          }
+        }
+    } else {
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[ah * 4 + i][bh * 2 + j] = mma_chunk<bf16>(wb[j][kc], xa[i][kc], acc[ah * 4 + i][bh * 2 + j]);
+    }
   };
 
   // ---- ONE software pipeline over the flattened (output tile, K tile) sequence of this workgroup
@@ -210,6 +245,37 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvGemmParams p,
         for (int q = 0; q < 2; ++q) bv[jp][q] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncl[jp] + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
       auto finish = [&](auto actf) {
+        if constexpr (LIMBS) {                     // fp32 rows: the lane's 8 consecutive channels = two 16-byte accesses
+          float* const Yf = reinterpret_cast<float*>(p.y);
+          const float* const Rf = reinterpret_cast<const float*>(p.res);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int m = mb + i * 16;
+            const bool mok = m < p.M;
+            const size_t rowoff = (size_t)(mok ? m : p.M - 1) * p.y_cstride;
+            f32x4 rf[2][2];
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+              for (int q = 0; q < 2; ++q) rf[jp][q] = Rf ? *reinterpret_cast<const f32x4*>(Rf + rowoff + ncl[jp] + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                f32x4 v = acc[i][2 * jp + q] + bv[jp][q];
+                acc[i][2 * jp + q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float x = p.res_first ? v[e] + rf[jp][q][e] : v[e];
+                  x = actf(x);
+                  if (!p.res_first) x += rf[jp][q][e];
+                  v[e] = x;
+                }
+                if (mok && nok[jp]) *reinterpret_cast<f32x4*>(Yf + rowoff + ncl[jp] + 4 * q) = v;
+              }
+          }
+          return;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int m = mb + i * 16;
@@ -239,7 +305,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvGemmParams p,
           }
         }
       };
-      if (p.act == ACT_GELU) finish([](float x) { return gelu_sig(x); });
+      if (p.act == ACT_GELU) finish([](float x) { return LIMBS ? gelu_erfc(x) : gelu_sig(x); });
       else if (p.act == ACT_LRELU) finish([](float x) { return x > 0.0f ? x : 0.1f * x; });
       else finish([](float x) { return x; });
     }
@@ -252,14 +318,25 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvGemmParams p,
   }
 }
 
+__global__ __launch_bounds__(512, 1) void gemm256_kernel(const ConvGemmParams p, const int tiles_m, const int tiles_n) { gemm256_body<false>(p, tiles_m, tiles_n); }
+__global__ __launch_bounds__(512, 1) void gemm256_x2_kernel(const ConvGemmParams p, const int tiles_m, const int tiles_n) { gemm256_body<true>(p, tiles_m, tiles_n); }
+
+// dtype 1: the 16-bit kernel; dtype 2: the two-limb kernel on fp32 storage (4-byte operand elements)
 bool gemm256_eligible(const ConvGemmParams& p, int dtype) {
   static const bool off = [] { const char* e = getenv("FSVIT_GEMM256"); return e && e[0] == '0'; }();
-  if (off || dtype != 1) return false;
+  if (off || (dtype != 1 && dtype != 2)) return false;
+  const int es = dtype == 2 ? 4 : 2, bke = 128 / es;
   if (p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.groups != 1) return false;
   if (p.x2 || p.K2 || p.pool2 || p.y_rpi || p.pos || p.out_f32 || p.w_rstride || p.w_gstride) return false;
   if (p.N < 192 || p.M < 1024 || (p.N & 7) || (p.y_cstride & 7)) return false;   // 16-byte epilogue accesses
-  if (p.K != p.Kw || (p.Kw & 63) || p.Kw < 128) return false;                 // whole 64-element K tiles on both operands
-  if ((size_t)p.M * p.x_cstride * 2 >= (1ull << 32) || (size_t)p.N * p.Kw * 2 >= (1ull << 32)) return false;   // 32-bit DMA offsets
+  if (p.K != p.Kw || (p.Kw % bke) || p.Kw < 2 * bke) return false;            // whole 128-byte K tiles on both operands
+  if ((size_t)p.M * p.x_cstride * es >= (1ull << 32) || (size_t)p.N * p.Kw * es >= (1ull << 32)) return false;   // 32-bit DMA offsets
+  if (dtype == 2) {
+    // two-limb mode: conv_gemm_v2's 128 x 128 tile stages 32 flop per byte and runs at 100 .. 270 TFLOP/s; every dense 1x1 layer wide enough for
+    // the 256-wide tile comes here
+    static const bool x2off = [] { const char* e = getenv("FSVIT_GEMM256_X2"); return e && e[0] == '0'; }();
+    return !x2off;
+  }
   // One 8-wave workgroup per CU cannot hide its epilogue behind another workgroup's MFMAs, so the HBM-bound layers
   // (few flops per streamed byte: the N = 256 / residual projections) stay on conv_gemm_v2 (2-3 workgroups per CU);
   // measured crossover ~200 flop/B (profiles/r01_gemm256_layers.txt); 190 keeps the stage-2 qkv layer with 48-wide heads (N = 864, 197.5 flop/B) here.
@@ -268,19 +345,27 @@ bool gemm256_eligible(const ConvGemmParams& p, int dtype) {
   return ai >= min_ai;
 }
 
-int launch_gemm256(const ConvGemmParams& p, hipStream_t stream) {
+template <typename KernT>
+static int launch_gemm256_t(KernT kern, bool& attr, const ConvGemmParams& p, hipStream_t stream) {
   const int tiles_m = (p.M + G_BM - 1) / G_BM, tiles_n = (p.N + G_BN - 1) / G_BN;
   const long items = (long)tiles_m * tiles_n;
   long grid = 256;                                  // persistent: one 8-wave workgroup per CU
   if (items < grid) grid = (items + 7) / 8 * 8;
-  static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_STAGE);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_STAGE);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL(gemm256_kernel, dim3((unsigned)grid), dim3(512), 2 * G_STAGE, stream, p, tiles_m, tiles_n);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), 2 * G_STAGE, stream, p, tiles_m, tiles_n);
   return (int)hipGetLastError();
+}
+int launch_gemm256(const ConvGemmParams& p, hipStream_t stream) {
+  static bool attr = false;
+  return launch_gemm256_t(gemm256_kernel, attr, p, stream);
+}
+int launch_gemm256_x2(const ConvGemmParams& p, hipStream_t stream) {
+  static bool attr = false;
+  return launch_gemm256_t(gemm256_x2_kernel, attr, p, stream);
 }
 
 }  // namespace FSVIT_NS

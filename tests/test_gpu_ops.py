@@ -101,11 +101,13 @@ def test_conv_gemm(case, dt):
     assert err <= _tol(dt, ref), (name, dt, err)
 
 
-X2_CASES = ['1x1_gelu', '3x3_lrelu_res', '3x3_grouped', 'k2s2_pos', '1x1_tails', '1x1_qkv_like', 'k32_im2col', '1x1_bigK', '3x3_small_n32']
+X2_CASES = ['1x1_gelu', '3x3_lrelu_res', '3x3_grouped', 'k2s2_pos', '1x1_tails', '1x1_qkv_like', 'k32_im2col', '1x1_bigK', '3x3_small_n32',
+            # M >= 1024, N >= 192: gemm256_x2_kernel (256 x 256 two-limb tile): M / N tails, every epilogue
+            'g256_fc1_gelu', 'g256_fc2_res', 'g256_qkv_tailN', 'g256_qkv_n864', 'g256_proj_k384', 'g256_k128', 'g256_bigK']
 
 
 @pytest.mark.parametrize('numerics', ['bf16x2', 'f16x2'])
-@pytest.mark.parametrize('case', [c for c in CASES if c[0] in X2_CASES], ids=X2_CASES)
+@pytest.mark.parametrize('case', [c for c in CASES if c[0] in X2_CASES], ids=[c[0] for c in CASES if c[0] in X2_CASES])
 def test_conv_gemm_two_limb(case, numerics):
     """fp32 storage, two-limb 16-bit MFMA arithmetic (conv_gemm_v2_kernel<f32x2l,...>): UN-rounded fp32 operands against an fp64
     convolution.  Operand precision 2^-16 (bf16 limbs; the activation's hi limb is a truncation) / 2^-21 (fp16 limbs)."""
