@@ -265,7 +265,9 @@ int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W
 }
 
 // ---------------------------------------------------------------- BatchNorm (train)
-int bn_fwd(TR* t, const std::string& name, const void* z, int M, int C, int act, const void* res, void* y, BnSave* sv) {
+// A residual add queued by the block that produced z (z = add.a + add.scale[image] * add.b, not yet computed) rides in the reduce pass.
+struct PendingAdd { const void* a = nullptr; const void* b = nullptr; const float* scale = nullptr; void* out = nullptr; size_t n = 0, per_img = 0; };
+int bn_fwd(TR* t, const std::string& name, const void* z, int M, int C, int act, const void* res, void* y, BnSave* sv, PendingAdd* add = nullptr) {
   const fsvit_param *g = getp(t, name + ".weight"), *b = getp(t, name + ".bias"), *rm = getp(t, name + ".running_mean"), *rv = getp(t, name + ".running_var");
   if (!g || !b || !rm || !rv) return FSVIT_ERR_KEY;
   float* stats = (float*)t->save.take((size_t)4 * C * 4);
@@ -273,12 +275,18 @@ int bn_fwd(TR* t, const std::string& name, const void* z, int M, int C, int act,
   if (!stats || !partial) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (bn)");
   sv->z = const_cast<void*>(z); sv->M = M; sv->C = C;
   sv->mean = stats; sv->invstd = stats + C; sv->sa = stats + 2 * C; sv->sb = stats + 3 * C;
+  const bool fuse_add = add && add->out && add->out == z && !t->freeze_bn;
+  if (add && add->out && !fuse_add) {      // a queued add this BatchNorm cannot take (frozen statistics: no reduce pass)
+    T_RUN(launch_add_scaled(add->a, add->b, add->scale, add->out, add->n, add->per_img, t->dtype, t->st));
+  }
   if (t->freeze_bn) {
     T_RUN(launch_bn_frozen_coeffs(C, t->cfg.bn_eps, g->data, b->data, rm->data, rv->data, sv->mean, sv->invstd, sv->sa, sv->sb, t->st));
   } else {
-    T_RUN(launch_bn_reduce(z, nullptr, nullptr, nullptr, partial, M, C, 0, t->dtype, t->st));
+    if (fuse_add) T_RUN(launch_bn_reduce(z, nullptr, nullptr, nullptr, partial, M, C, 0, t->dtype, t->st, add->a, add->b, add->scale, (int)(add->per_img / C)));
+    else T_RUN(launch_bn_reduce(z, nullptr, nullptr, nullptr, partial, M, C, 0, t->dtype, t->st));
     T_RUN(launch_bn_fwd_finalize(partial, M, C, t->cfg.bn_eps, 0.1f, g->data, b->data, rm->data, rv->data, sv->mean, sv->invstd, sv->sa, sv->sb, t->st));
   }
+  if (add) *add = PendingAdd{};
   T_RUN(launch_bn_apply(z, sv->sa, sv->sb, res, y, (size_t)M, C, act, t->dtype, t->st));
   return 0;
 }
@@ -386,6 +394,14 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
     T_RUN(launch_maxpool2_idx(S.a3, pt, S.x1, S.arg, B, H1, H1, t->C1, dt, st));
   }
   void* xcur = S.x1;
+  // residual adds in front of a BatchNorm are queued here and computed by that BatchNorm's reduce pass (bn_fwd); flush_add() launches a queued
+  // add on its own where the consumer is not a BatchNorm
+  PendingAdd pend;
+  auto flush_add = [&]() -> int {
+    if (pend.out) T_RUN(launch_add_scaled(pend.a, pend.b, pend.scale, pend.out, pend.n, pend.per_img, dt, st));
+    pend = PendingAdd{};
+    return 0;
+  };
 
   // ---- stage 1 (Block with attn_disabled: x + DropPath(mlp(norm2(x))), visformer.py:259-263)
   t->s1.resize(t->cfg.depth[0]);
@@ -397,7 +413,7 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
     NEED(b.z2 = take_act(t, M1 * t->hid1)); NEED(b.h2 = take_act(t, M1 * t->hid1)); NEED(b.out = take_act(t, M1 * t->C1));
     const size_t mark = t->tmp.off;
     void* z3 = take_tmp(t, M1 * t->C1); NEED(z3);
-    T_TRY(bn_fwd(t, p + "norm2.bn", b.x, (int)M1, t->C1, ACT_NONE, nullptr, b.xn, &b.bn));
+    T_TRY(bn_fwd(t, p + "norm2.bn", b.x, (int)M1, t->C1, ACT_NONE, nullptr, b.xn, &b.bn, &pend));
     T_TRY(conv_fwd(t, sp.s1c1[i], b.xn, B, H1, H1, b.z1, nullptr));
     T_RUN(launch_gelu_fwd(b.z1, b.h1, M1 * t->hid1, dt, st));
     T_TRY(conv_fwd(t, sp.s1c2[i], b.h1, B, H1, H1, b.z2, nullptr));
@@ -405,7 +421,10 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
     T_TRY(conv_fwd(t, sp.s1c3[i], b.h2, B, H1, H1, z3, nullptr));
     b.scale = dp_scale(t, dp_call, blk, nblk);
     if (t->dp_rate * blk > 0.f) ++dp_call;
-    T_RUN(launch_add_scaled(b.x, z3, b.scale, b.out, M1 * t->C1, (size_t)H1 * H1 * t->C1, dt, st));
+    // b.out = b.x + scale * z3: queued for the next block's BatchNorm reduce pass (z3 must outlive this block's tmp scope: it is the first
+    // allocation after `mark` in every block, and the next block's BatchNorm runs before anything else is written there)
+    pend = PendingAdd{b.x, z3, b.scale, b.out, M1 * t->C1, (size_t)H1 * H1 * t->C1};
+    if (i + 1 == t->cfg.depth[0]) T_TRY(flush_add());
     t->tmp.off = mark;
     xcur = b.out;
   }
@@ -445,20 +464,23 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
       NEED(b.out = take_act(t, M * C));
       const size_t mark = t->tmp.off;
       void* zp = take_tmp(t, M * C); NEED(zp);
-      T_TRY(bn_fwd(t, p + "norm1.bn", b.x, (int)M, C, ACT_NONE, nullptr, b.xn1, &b.bn1));
+      T_TRY(bn_fwd(t, p + "norm1.bn", b.x, (int)M, C, ACT_NONE, nullptr, b.xn1, &b.bn1, &pend));
       T_TRY(conv_fwd(t, cs.qkv, b.xn1, B, Ho, Ho, b.qkv, nullptr));
       T_RUN(launch_attention(b.qkv, b.ctx, B, Ho * Ho, heads, hdp, scale, dt, st));
       T_TRY(conv_fwd(t, cs.proj, b.ctx, B, Ho, Ho, zp, nullptr));
       b.s1 = dp_scale(t, dp_call, blk, nblk);
       if (t->dp_rate * blk > 0.f) ++dp_call;
-      T_RUN(launch_add_scaled(b.x, zp, b.s1, b.xa, M * C, (size_t)Ho * Ho * C, dt, st));
-      T_TRY(bn_fwd(t, p + "norm2.bn", b.xa, (int)M, C, ACT_NONE, nullptr, b.xn2, &b.bn2));
+      pend = PendingAdd{b.x, zp, b.s1, b.xa, M * C, (size_t)Ho * Ho * C};                       // b.xa = b.x + s1 * zp inside norm2's reduce pass
+      T_TRY(bn_fwd(t, p + "norm2.bn", b.xa, (int)M, C, ACT_NONE, nullptr, b.xn2, &b.bn2, &pend));
       T_TRY(conv_fwd(t, cs.fc1, b.xn2, B, Ho, Ho, b.z1, nullptr));
       T_RUN(launch_gelu_fwd(b.z1, b.h, M * hid, dt, st));
       T_TRY(conv_fwd(t, cs.fc2, b.h, B, Ho, Ho, zp, nullptr));
       b.s2 = dp_scale(t, dp_call, blk, nblk);
       if (t->dp_rate * blk > 0.f) ++dp_call;
-      T_RUN(launch_add_scaled(b.xa, zp, b.s2, b.out, M * C, (size_t)Ho * Ho * C, dt, st));
+      // b.out = b.xa + s2 * zp: queued for the next block's norm1 (zp is the first tmp allocation of every block of the stage and is
+      // rewritten only by that block's proj conv, after norm1); the stage's last block adds now
+      pend = PendingAdd{b.xa, zp, b.s2, b.out, M * C, (size_t)Ho * Ho * C};
+      if (i + 1 == t->cfg.depth[sg - 1]) T_TRY(flush_add());
       t->tmp.off = mark;
       xcur = b.out;
     }

@@ -20,7 +20,8 @@ int launch_im2col_t(const void* x, void* out, int B, int H, int W, int ld, int c
                     int dtype, hipStream_t s);
 int launch_unpatch2(const void* g, void* dx, int B, int OH, int OW, int C, int dtype, hipStream_t s);
 int bn_reduce_blocks(int M);
-int launch_bn_reduce(const void* a, const void* z, const float* mean, const float* invstd, float* partial, int M, int C, int bwd, int dtype, hipStream_t s);
+int launch_bn_reduce(const void* a, const void* z, const float* mean, const float* invstd, float* partial, int M, int C, int bwd, int dtype, hipStream_t s,
+                     const void* add_a = nullptr, const void* add_b = nullptr, const float* add_scale = nullptr, int rows_per_img = 0);
 int launch_bn_fwd_finalize(const float* partial, int M, int C, float eps, float momentum, const float* gamma, const float* beta, float* rmean, float* rvar,
                            float* mean, float* invstd, float* sa, float* sb, hipStream_t s);
 int launch_bn_bwd_finalize(const float* partial, int M, int C, const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* ca, float* cb,

@@ -203,10 +203,8 @@ class Visformer(nn.Module):
             tok, feat = VisformerTrainMapFn.apply(x, self.trainer(), names, buffers, self.drop_path_rate, masks, hw * hw, *[p for _, p in named])
         else:
             feat = VisformerTrainFn.apply(x, self.trainer(), names, buffers, self.drop_path_rate, masks, *[p for _, p in named])
-        if not frozen:
-            for k, b in self.named_buffers():
-                if k.endswith('num_batches_tracked'):
-                    b += 1
+        if not frozen:      # nn.BatchNorm2d counts its train-mode forwards (visformer.py:53-64 via torch): one multi-tensor add for the 21 counters
+            torch._foreach_add_([b for k, b in self.named_buffers() if k.endswith('num_batches_tracked')], 1)
         if self.return_map:
             return tok.permute(0, 2, 1).reshape(x.shape[0], self.out_dim, hw, hw), feat
         return feat
