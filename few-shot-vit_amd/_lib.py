@@ -102,6 +102,7 @@ SIGNATURES = {
     'fsvit_sgd_step': (_i, [_fp, _fp, _fp, _sz, _f, _f, _f, _i, _vp]),
     'fsvit_conv1x1_wgrad': (_i, [_vp, _vp, _fp, _i, _i, _i, _i, _vp]),
     'fsvit_conv3x3_wgrad': (_i, [_vp, _vp, _fp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'fsvit_gconv3x3': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     'fsvit_image_transform_gather': (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i,
                                           C.POINTER(C.c_float), C.POINTER(C.c_float), _fp, _vp]),
     'fsvit_attention_backward': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),

@@ -842,6 +842,15 @@ extern "C" int fsvit_conv3x3_wgrad(const void* x, const void* dz, float* dw, int
   return 0;
 }
 
+extern "C" int fsvit_gconv3x3(const void* x, const void* w_packed, int Kw, void* y, int B, int H, int W, int dtype, void* stream) {
+  const int kdt = dtype;
+  if (!x || !w_packed || !y || B <= 0) return fail(FSVIT_ERR_ARG, "bad argument");
+  if (dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "fsvit_gconv3x3: 16-bit storage only (bf16 / f16)");
+  if (!K(gconv3x3_supported)(1, 256, 32, 8, 3, 3, 1, 1, W) || Kw < 288 || (Kw & 7)) return fail(FSVIT_ERR_ARG, "fsvit_gconv3x3: 8 groups of 32 -> 32 channels, W <= 20, Kw >= 288");
+  RC_TRY(K(launch_gconv3x3)(x, w_packed, Kw, y, B, H, W, (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int fsvit_conv1x1_wgrad(const void* x, const void* dz, float* dw, int M, int N, int C, int dtype, void* stream) {
   const int kdt = dtype;
   if (!x || !dz || !dw || M <= 0) return fail(FSVIT_ERR_ARG, "bad argument");

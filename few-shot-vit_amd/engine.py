@@ -430,6 +430,16 @@ class ops:
         return y
 
     @staticmethod
+    def gconv3x3(x, w_packed):
+        """x NHWC [B,H,W,256] (bf16 / fp16), w_packed [256][Kw] -> the grouped 3x3 convolution (8 groups of 32 -> 32) of the training step."""
+        _require_cuda(x, w_packed)
+        B, H, W, _ = x.shape
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().fsvit_gconv3x3(_ptr(x), _ptr(w_packed), w_packed.shape[-1], _ptr(y), B, H, W, ops._dt(x), _stream_ptr(x.device)))
+        return y
+
+    @staticmethod
     def conv_stem_tail(x, w, bias, pos, x2, K2):
         """Fused stem tail: x NHWC [B,H,W,Cin], w [N][Kw] (conv3 taps | one tail K slice), x2 [B*H*W][x2_cstride] im2col rows,
         pos [(H/2)*(W/2)][N] fp32 -> y NHWC [B,H/2,W/2,N]."""

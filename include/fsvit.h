@@ -314,6 +314,11 @@ int fsvit_image_transform_gather(const uint8_t* images_dev, int H, int W, const 
  * Built shapes: groups = 8 with 32 -> 32 channels per group (W <= 20); dense O = 128, Ig = 64 / 128 (W <= 40). */
 int fsvit_conv3x3_wgrad(const void* x_dev, const void* dz_dev, float* dw_dev, int B, int H, int W, int O, int Ig, int groups, int dtype, void* stream);
 
+/* The grouped 3x3 / stride 1 / pad 1 convolution of the stage-1 Mlp (visformer.py:148: conv2, 8 groups of 32 -> 32 channels) as the training step
+ * runs it, forward and - on the transposed, tap-flipped pack - as its data gradient: one wave per group, weights resident in registers.
+ * x, y [B,H,W,256] NHWC; w_packed [256][Kw], row o = output channel, columns (ky, kx, c) of its group, Kw >= 288; dtype FSVIT_BF16 / FSVIT_F16; W <= 20. */
+int fsvit_gconv3x3(const void* x_dev, const void* w_packed_dev, int Kw, void* y_dev, int B, int H, int W, int dtype, void* stream);
+
 /* Weight gradient of a 1x1 convolution / Linear from the row-major activations: dw[N][C] (fp32, overwritten) = sum_m dz[m][n] * x[m][c].
  * x [M][C], dz [M][N], dtype FSVIT_BF16 / FSVIT_F16, N and C multiples of 8.  (conv1 / conv3 of the Mlps, qkv, proj in train_meta.py:228-232.) */
 int fsvit_conv1x1_wgrad(const void* x_dev, const void* dz_dev, float* dw_dev, int M, int N, int C, int dtype, void* stream);

@@ -446,3 +446,34 @@ def test_conv1x1_wgrad_direct_vs_torch(shape, dtype):
     err = (got - ref).abs().max().item()
     print(f'conv1x1_wgrad {shape} {dtype}: max err {err:.3e} (max |dW| {ref.abs().max():.2f})')
     assert err <= 2e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(3, 20, 20), (1, 12, 16), (7, 20, 20), (2, 5, 7)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_gconv3x3_vs_torch(shape, dtype):
+    """fsvit_gconv3x3 (wave = group, register-resident weights, taps as addresses into the staged pixel window) vs torch's grouped conv2d on
+    the same 16-bit-rounded operands: forward, and the data gradient as the trainer computes it - the same kernel on the transposed, tap-flipped
+    weights - vs torch's conv_transpose (image borders, ragged last chunk, several images per 64-pixel chunk)."""
+    from fewshot_vit_amd.engine import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, 256, H, W, generator=g).to(dtype).float()
+    w = (torch.randn(256, 32, 3, 3, generator=g) / 17.0).to(dtype).float()
+
+    def pack(wt):                         # [256][32][3][3] -> [256][320], columns (ky, kx, c)
+        p = torch.zeros(256, 320)
+        p[:, :288] = wt.permute(0, 2, 3, 1).reshape(256, 288)
+        return p.to(dtype).cuda()
+    xd = x.permute(0, 2, 3, 1).contiguous().to('cuda', dtype)
+    ref = F.conv2d(x, w, padding=1, groups=8)
+    got = ops.gconv3x3(xd, pack(w)).float().cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    # data gradient: dx = conv(dz, W^T flipped) per group
+    wt = w.reshape(8, 32, 32, 3, 3).transpose(1, 2).flip(-1, -2).reshape(256, 32, 3, 3)
+    ref_t = F.conv_transpose2d(x, w, padding=1, groups=8)
+    got_t = ops.gconv3x3(xd, pack(wt)).float().cpu().permute(0, 3, 1, 2)
+    err_t = (got_t - ref_t).abs().max().item()
+    print(f'gconv3x3 {shape} {dtype}: forward {err:.3e}, data gradient {err_t:.3e} (max |y| {ref.abs().max():.2f})')
+    tol = 1.2e-2 * max(1.0, ref.abs().max().item())       # the 16-bit rounding of the output
+    assert err <= tol and err_t <= tol
