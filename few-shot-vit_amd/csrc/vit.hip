@@ -21,6 +21,11 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const size_t b = row / np;
     const int py0 = (pi / npw) * p, px0 = (pi % npw) * p;
     f32x4 v;
+    if ((p & 3) == 0 && (img & 3) == 0 && k4 + 3 < K) {      // 4 consecutive pixels of one patch row: one 16-byte load
+      const int c = k4 / (p * p), r = k4 - c * p * p, py = r / p, px = r - py * p;
+      store4<T>(out + row * Kp + k4, *reinterpret_cast<const f32x4*>(x + ((b * 3 + c) * img + py0 + py) * img + px0 + px));
+      continue;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int k = k4 + e;
