@@ -76,6 +76,9 @@ struct ConvGemmParams {
   bool conv3x3_halo_eligible(const ConvGemmParams& p, int dtype);                                                          \
   int launch_conv3x3_halo(const ConvGemmParams& p, hipStream_t stream);                                                    \
   int conv_gemm_v2_config(const ConvGemmParams& p); /* which tile configuration launch_conv_gemm_v2 picks */               \
+  /* wgrad3x3.hip: the grouped 3x3 conv of the stage-1 Mlp in the two-limb modes (wave = group, weights in registers) */     \
+  bool gconv3x3_x2_eligible(const ConvGemmParams& p, int dtype);                                                           \
+  int launch_gconv3x3_x2(const ConvGemmParams& p, hipStream_t stream);                                                     \
   }
 FSVIT_DECLARE_CONV_GEMM(fsvit)
 FSVIT_DECLARE_CONV_GEMM(fsvit_f16)

@@ -447,15 +447,17 @@ static int gemm256_slice_rows(const ConvGemmParams& p, int dtype) {
   return rows_max >= 1024 && gemm256_eligible(q, dtype) ? rows_max : 0;
 }
 static int run_gemm256(const ConvGemmParams& p, int dtype, hipStream_t stream) { return dtype == 2 ? launch_gemm256_x2(p, stream) : launch_gemm256(p, stream); }
-// which kernel launch_conv_gemm runs for p: 0 conv3x3_halo, 1 gemm256 (whole or in row slices), 2 conv_gemm_v2
+// which kernel launch_conv_gemm runs for p: 0 conv3x3_halo, 1 gemm256 (whole or in row slices), 2 conv_gemm_v2, 3 gconv3x3_x2 (two-limb grouped 3x3)
 int conv_gemm_route(const ConvGemmParams& p, int dtype) {
   if (conv3x3_halo_eligible(p, dtype)) return 0;
+  if (gconv3x3_x2_eligible(p, dtype)) return 3;
   if (gemm256_eligible(p, dtype) || gemm256_slice_rows(p, dtype)) return 1;
   return 2;
 }
 
 int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream) {
   if (conv3x3_halo_eligible(p, dtype)) return launch_conv3x3_halo(p, stream);
+  if (gconv3x3_x2_eligible(p, dtype)) return launch_gconv3x3_x2(p, stream);
   if (gemm256_eligible(p, dtype)) return run_gemm256(p, dtype, stream);
   // A plain 1x1 layer whose activation matrix is past gemm256's 32-bit DMA offsets (a 12 800-image ViT chunk: 2.5 M rows x 1536 columns)
   // runs as row slices of < 4 GB each, if a slice is eligible.

@@ -519,7 +519,7 @@ int tap(EngineBase* h, const std::string& name, const void* src, size_t bytes, b
 }
 
 // kernel ids reported by the profiler (names in fsvit_kernel_name)
-enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_QKVATTN = 15, KID_STEMCONV1 = 16 };
+enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_QKVATTN = 15, KID_STEMCONV1 = 16, KID_GCONV_X2 = 14 };
 
 
 // Runs one launch; in profiling mode brackets it with HIP events on the same stream.
@@ -542,7 +542,7 @@ int run_gemm(EngineBase* h, hipStream_t st, const char* layer, const Layer& L, c
   const double flops = 2.0 * (double)p.M * n_true * k_true * (double)p.groups;     // algorithmic: unpadded N and K
   static const int kid_of_cfg[4] = {KID_GEMM256, KID_GEMM64, KID_GEMM32, KID_GEMM128};
   const int route = K(conv_gemm_route)(p, kg(kdt));
-  const int kid = route == 0 ? KID_HALO : route == 1 ? KID_GEMM256 : kid_of_cfg[K(conv_gemm_v2_config)(p)];
+  const int kid = route == 0 ? KID_HALO : route == 1 ? KID_GEMM256 : route == 3 ? KID_GCONV_X2 : kid_of_cfg[K(conv_gemm_v2_config)(p)];
   return timed(h, st, layer, kid, flops, [&]() { return K(launch_conv_gemm)(p, kg(kdt), st); });
 }
 
@@ -1013,7 +1013,7 @@ extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
                                "patchify_kernel<_Float16>", "layernorm_kernel<_Float16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel"};
   static const char* x2n[] = {"gemm256_x2_kernel", "conv_gemm_v2_kernel<f32x2l,128,64,2,2,3>", "conv_gemm_v2_kernel<f32x2l,128,32,4,1,3>", "", "", "", "", "", "", "conv_gemm_v2_kernel<f32x2l,128,128,2,2,2>"};
   if (kernel_id < 0 || kernel_id > 16) return "?";
-  if (is_x2(dtype)) return (kernel_id == 0 || kernel_id == 1 || kernel_id == 2 || kernel_id == 9) ? x2n[kernel_id] : f32n[kernel_id];
+  if (is_x2(dtype)) return kernel_id == 14 ? "gconv3x3_x2_kernel" : (kernel_id == 0 || kernel_id == 1 || kernel_id == 2 || kernel_id == 9) ? x2n[kernel_id] : f32n[kernel_id];
   return dtype == FSVIT_F32 ? f32n[kernel_id] : dtype == FSVIT_F16 ? f16n[kernel_id] : bf16n[kernel_id];
 }
 

@@ -18,6 +18,7 @@
 //     into the PyTorch weight layout (deterministic, like the round-1 path).
 #include <stdlib.h>
 
+#include "conv_gemm.h"
 #include "fsvit_common.h"
 #include "kernels.h"
 
@@ -310,6 +311,137 @@ int launch_gconv3x3(const void* x, const void* w_packed, int Kw, void* y, int B,
   const int cpw = (n_chunks + wgs - 1) / wgs;
   wgs = (n_chunks + cpw - 1) / cpw;
   hipLaunchKernelGGL(gconv3x3_kernel, dim3(wgs), dim3(512), 0, s, (const bf16*)x, (const bf16*)w_packed, Kw, (bf16*)y, M, H, W, n_chunks, cpw);
+  return (int)hipGetLastError();
+}
+
+// ---- the same grouped conv in the two-limb numerics modes (`bf16x2` / `f16x2`, conv_gemm_v2.hip): fp32 activations in and out, weights as (hi, lo)
+// limb words [256][Kw].  On conv_gemm_v2's 128 x 32 two-limb tile this layer was the slowest of the mode (7.2 ms per block at 12800 images, 105
+// TFLOP/s: 16 MFMAs per staged K slice and wave).  Wave g = group g again: its 36 weight fragments (9 taps x 2 k-chunks of 16 channels x 2 channel
+// tiles) stay in 144 VGPRs.  The pixels live in a RING of 128 slots per 4-channel plane ([64 planes][128 pixels][16 B] = 128 KB of LDS, slot =
+// linear pixel index & 127), split into limb words ONCE while they are staged: consecutive 64-pixel chunks share 42 pixels of their windows, so a
+// chunk brings in only its 64 new pixels (8 x 16 B per thread in flight under the previous chunk's MFMAs - with the whole 106-pixel window in
+// registers the kernel spilled and the prefetch serialised).  A fragment read delivers 8 k-slots = 4 channels x (lo, hi), its half-swapped copy feeds
+// the cross terms: 18 reads + 72 MFMAs per 16 pixels.
+__global__ __launch_bounds__(512, 1) void gconv3x3_x2_kernel(const float* __restrict__ x, const unsigned* __restrict__ w, int Kw, float* __restrict__ y, int M, int H,
+                                                             int W, int n_chunks, int chunks_per_wg, int act) {
+  using namespace wg3;
+  constexpr int C = 256, NPL = C / 4, RING = 128, HALO = 21;              // 64 planes of 4 channels; the window of a chunk = its 64 pixels +- 21
+  constexpr int NPX = CH * NPL / 512;                                      // 8: 16-byte units per thread and batch of 64 pixels
+  static_assert(CH == 64 && CH + 2 * HALO + (CH - 2 * HALO) <= RING, "ring geometry");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];    // [64 planes][RING][16 B] + a zero slot
+  unsigned char* const ZERO = smem + NPL * RING * 16;
+  const int t = threadIdx.x, lane = t & 63, lrow = lane & 15, lq = lane >> 4;
+  const int g = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int q0 = blockIdx.x * chunks_per_wg;
+  int q1 = q0 + chunks_per_wg; q1 = q1 < n_chunks ? q1 : n_chunks;
+  if (t < 4) reinterpret_cast<unsigned*>(ZERO)[t] = 0u;
+
+  // this wave's weights: rows = output channels 16 nt + lrow of the group, limb words of channels 16 kc + 4 lq .. + 3 of tap tp
+  u32x4 wf[9][2][2];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) wf[tp][kc][nt] = *reinterpret_cast<const u32x4*>(w + (size_t)(g * 32 + nt * 16 + lrow) * Kw + tp * 32 + kc * 16 + lq * 4);
+
+  // a batch = 64 consecutive pixels starting at linear index P0 (may start before 0 / end past M: those are stored as zeros).  The loads are
+  // UNCONDITIONAL on a clamped pixel: a per-lane `ok ? load : 0` compiles to an exec-masked branch with its own vmcnt(0) per load.
+  u32x4 px[NPX];
+  unsigned pxok = 0;
+  auto gload = [&](long P0) {
+    pxok = 0;
+#pragma unroll
+    for (int u0 = 0; u0 < NPX; ++u0) {
+      const int u = t + 512 * u0, p = u / NPL, c4 = u % NPL;
+      const long m = P0 + p;
+      const bool ok = m >= 0 && m < M;
+      px[u0] = *reinterpret_cast<const u32x4*>(x + (size_t)(ok ? m : 0) * C + c4 * 4);
+      pxok |= ok ? (1u << u0) : 0u;
+    }
+  };
+  auto lstore = [&](long P0) {
+#pragma unroll
+    for (int u0 = 0; u0 < NPX; ++u0) {
+      const int u = t + 512 * u0, p = u / NPL, c4 = u % NPL;
+      u32x4 xs, xr;
+      x2_split(px[u0], xs, xr);
+      if (!((pxok >> u0) & 1u)) xs = u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(smem + c4 * (RING * 16) + (int)((P0 + p) & (RING - 1)) * 16) = xs;
+    }
+  };
+  const unsigned char* const plane = smem + (g * 8 + lq) * (RING * 16);     // k-chunk kc adds 4 planes
+  const int HW = H * W;
+
+  if (q0 < q1) {                           // the first window of this workgroup: pixels [64 q0 - 21, 64 q0 + 107) = the whole ring, in two batches
+    gload((long)q0 * CH - HALO);
+    lstore((long)q0 * CH - HALO);
+    gload((long)q0 * CH - HALO + CH);
+  }
+  for (int q = q0; q < q1; ++q) {
+    const long Pn = (long)q * CH - HALO + CH + (q == q0 ? 0 : CH - 2 * HALO);   // first pixel of the batch in px: second half of the first window, else the 64 new pixels
+    __syncthreads();                       // every wave is done with the previous chunk: its oldest 64 slots may be overwritten
+    lstore(q == q0 ? Pn : (long)q * CH + HALO + (CH - 2 * HALO));
+    __syncthreads();
+    if (q + 1 < q1) gload((long)(q + 1) * CH + HALO + (CH - 2 * HALO));          // the 64 pixels the next window adds: [64 (q+1) + 43, 64 (q+1) + 107)
+    const int m0 = q * CH;
+#pragma unroll 2
+    for (int mt = 0; mt < CH / 16; ++mt) {
+      const int m = m0 + mt * 16 + lrow;                              // this lane's pixel (B operand column)
+      const int rem = m % HW, oy = m < M ? rem / W : -4, ox = rem - (rem / W) * W;
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int dy = tp / 3 - 1, dx = tp % 3 - 1;
+        const bool ok = (unsigned)(oy + dy) < (unsigned)H && (unsigned)(ox + dx) < (unsigned)W;
+        const unsigned char* const src = ok ? plane + ((m + dy * W + dx) & (RING - 1)) * 16 : ZERO;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+          const u32x4 xf = *reinterpret_cast<const u32x4*>(ok ? src + kc * (4 * RING * 16) : ZERO);
+          u32x4 xr;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xr[e] = __builtin_amdgcn_alignbit(xf[e], xf[e], 16);
+          acc[0] = mma_chunk<bf16>(wf[tp][kc][0], xr, acc[0]);          // lo x hi + hi x lo   (the two accumulators alternate: no back-to-back dependence)
+          acc[1] = mma_chunk<bf16>(wf[tp][kc][1], xr, acc[1]);
+          acc[0] = mma_chunk<bf16>(wf[tp][kc][0], xf, acc[0]);          // hi x hi + lo x lo
+          acc[1] = mma_chunk<bf16>(wf[tp][kc][1], xf, acc[1]);
+        }
+      }
+      if (m < M) {                                                    // lane holds channels 32 g + 16 nt + 4 lq .. + 3 of pixel m
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          if (act == ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[nt][e] = gelu_erfc(acc[nt][e]);
+          }
+          *reinterpret_cast<f32x4*>(y + (size_t)m * C + g * 32 + nt * 16 + lq * 4) = acc[nt];
+        }
+      }
+    }
+  }
+}
+
+// p: a conv_gemm launch in the two-limb modes (dtype 2) that this kernel covers
+bool gconv3x3_x2_eligible(const ConvGemmParams& p, int dtype) {
+  static const bool off = [] { const char* e = getenv("FSVIT_GCONV3X3_X2"); return e && e[0] == '0'; }();
+  if (off || dtype != 2) return false;
+  if (p.groups != 8 || p.N != 32 || p.Cin != 32 || p.x_cstride != 256 || p.y_cstride != 256 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1) return false;
+  if (p.W > 20 || p.Kw < 288 || (p.Kw & 3) || p.bias || p.res || p.pos || p.x2 || p.K2 || p.pool2 || p.y_rpi || p.out_f32 || p.w_rstride || p.w_gstride) return false;
+  return (p.act == ACT_NONE || p.act == ACT_GELU) && (long)p.B * p.H * p.W < (1L << 31);
+}
+int launch_gconv3x3_x2(const ConvGemmParams& p, hipStream_t s) {
+  const int M = p.B * p.H * p.W, n_chunks = (M + wg3::CH - 1) / wg3::CH;
+  int wgs = n_chunks < 256 ? n_chunks : 256;              // one 8-wave workgroup per CU (128 KB of LDS, 2 waves per SIMD with 256 VGPRs)
+  const int cpw = (n_chunks + wgs - 1) / wgs;
+  wgs = (n_chunks + cpw - 1) / cpw;
+  const int lds = 64 * 128 * 16 + 16;                  // the pixel ring + the zero slot
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)gconv3x3_x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(gconv3x3_x2_kernel, dim3(wgs), dim3(512), lds, s, (const float*)p.x, (const unsigned*)p.w, p.Kw, (float*)p.y, M, p.H, p.W, n_chunks, cpw, p.act);
   return (int)hipGetLastError();
 }
 
