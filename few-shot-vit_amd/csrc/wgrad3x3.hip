@@ -317,7 +317,7 @@ int launch_gconv3x3(const void* x, const void* w_packed, int Kw, void* y, int B,
 // ---- the same grouped conv in the two-limb numerics modes (`bf16x2` / `f16x2`, conv_gemm_v2.hip): fp32 activations in and out, weights as (hi, lo)
 // limb words [256][Kw].  On conv_gemm_v2's 128 x 32 two-limb tile this layer was the slowest of the mode (7.2 ms per block at 12800 images, 105
 // TFLOP/s: 16 MFMAs per staged K slice and wave).  Wave g = group g again: its 36 weight fragments (9 taps x 2 k-chunks of 16 channels x 2 channel
-// tiles) stay in 144 VGPRs.  The pixels live in a RING of 128 slots per 4-channel plane ([64 planes][128 pixels][16 B] = 128 KB of LDS, slot =
+// tiles) stay in 144 VGPRs.  The pixels live in a RING of 128 slots per 4-channel plane ([64 planes][128 + 1 pixels][16 B] = 129 KB of LDS, slot =
 // linear pixel index & 127), split into limb words ONCE while they are staged: consecutive 64-pixel chunks share 42 pixels of their windows, so a
 // chunk brings in only its 64 new pixels (8 x 16 B per thread in flight under the previous chunk's MFMAs - with the whole 106-pixel window in
 // registers the kernel spilled and the prefetch serialised).  A fragment read delivers 8 k-slots = 4 channels x (lo, hi), its half-swapped copy feeds
@@ -327,9 +327,11 @@ __global__ __launch_bounds__(512, 1) void gconv3x3_x2_kernel(const float* __rest
   using namespace wg3;
   constexpr int C = 256, NPL = C / 4, RING = 128, HALO = 21;              // 64 planes of 4 channels; the window of a chunk = its 64 pixels +- 21
   constexpr int NPX = CH * NPL / 512;                                      // 8: 16-byte units per thread and batch of 64 pixels
+  constexpr int PLANE = (RING + 1) * 16;                                   // plane pitch: one slot of padding - the staging stores walk the planes (64 lanes = 64
+                                                                           // planes of one pixel) and a 2048-byte pitch put all of them on one bank group
   static_assert(CH == 64 && CH + 2 * HALO + (CH - 2 * HALO) <= RING, "ring geometry");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];    // [64 planes][RING][16 B] + a zero slot
-  unsigned char* const ZERO = smem + NPL * RING * 16;
+  unsigned char* const ZERO = smem + NPL * PLANE;
   const int t = threadIdx.x, lane = t & 63, lrow = lane & 15, lq = lane >> 4;
   const int g = __builtin_amdgcn_readfirstlane(t >> 6);
   const int q0 = blockIdx.x * chunks_per_wg;
@@ -367,10 +369,10 @@ __global__ __launch_bounds__(512, 1) void gconv3x3_x2_kernel(const float* __rest
       u32x4 xs, xr;
       x2_split(px[u0], xs, xr);
       if (!((pxok >> u0) & 1u)) xs = u32x4{0u, 0u, 0u, 0u};
-      *reinterpret_cast<u32x4*>(smem + c4 * (RING * 16) + (int)((P0 + p) & (RING - 1)) * 16) = xs;
+      *reinterpret_cast<u32x4*>(smem + c4 * PLANE + (int)((P0 + p) & (RING - 1)) * 16) = xs;
     }
   };
-  const unsigned char* const plane = smem + (g * 8 + lq) * (RING * 16);     // k-chunk kc adds 4 planes
+  const unsigned char* const plane = smem + (g * 8 + lq) * PLANE;           // k-chunk kc adds 4 planes
   const int HW = H * W;
 
   if (q0 < q1) {                           // the first window of this workgroup: pixels [64 q0 - 21, 64 q0 + 107) = the whole ring, in two batches
@@ -385,10 +387,21 @@ __global__ __launch_bounds__(512, 1) void gconv3x3_x2_kernel(const float* __rest
     __syncthreads();
     if (q + 1 < q1) gload((long)(q + 1) * CH + HALO + (CH - 2 * HALO));          // the 64 pixels the next window adds: [64 (q+1) + 43, 64 (q+1) + 107)
     const int m0 = q * CH;
+    // (oy, ox) of this lane's pixel: divided out once per chunk, then stepped by 16 pixels per tile (the three integer divisions per tile
+    // cost about as many VALU issues as the tile's 72 half-swaps)
+    int oyc, oxc;
+    {
+      const int mm = m0 + lrow, rem = mm % HW;
+      oyc = rem / W;
+      oxc = rem - oyc * W;
+    }
 #pragma unroll 2
     for (int mt = 0; mt < CH / 16; ++mt) {
       const int m = m0 + mt * 16 + lrow;                              // this lane's pixel (B operand column)
-      const int rem = m % HW, oy = m < M ? rem / W : -4, ox = rem - (rem / W) * W;
+      const int oy = m < M ? oyc : -4, ox = oxc;
+      oxc += 16;
+      while (oxc >= W) { oxc -= W; ++oyc; }
+      if (oyc >= H) oyc -= H;                                         // (H * W >= 16: at most one image boundary per step)
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp) {
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(512, 1) void gconv3x3_x2_kernel(const float* __rest
         const unsigned char* const src = ok ? plane + ((m + dy * W + dx) & (RING - 1)) * 16 : ZERO;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
-          const u32x4 xf = *reinterpret_cast<const u32x4*>(ok ? src + kc * (4 * RING * 16) : ZERO);
+          const u32x4 xf = *reinterpret_cast<const u32x4*>(ok ? src + kc * (4 * PLANE) : ZERO);
           u32x4 xr;
 #pragma unroll
           for (int e = 0; e < 4; ++e) xr[e] = __builtin_amdgcn_alignbit(xf[e], xf[e], 16);
@@ -427,14 +440,14 @@ bool gconv3x3_x2_eligible(const ConvGemmParams& p, int dtype) {
   if (off || dtype != 2) return false;
   if (p.groups != 8 || p.N != 32 || p.Cin != 32 || p.x_cstride != 256 || p.y_cstride != 256 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1) return false;
   if (p.W > 20 || p.Kw < 288 || (p.Kw & 3) || p.bias || p.res || p.pos || p.x2 || p.K2 || p.pool2 || p.y_rpi || p.out_f32 || p.w_rstride || p.w_gstride) return false;
-  return (p.act == ACT_NONE || p.act == ACT_GELU) && (long)p.B * p.H * p.W < (1L << 31);
+  return (p.act == ACT_NONE || p.act == ACT_GELU) && (long)p.B * p.H * p.W < (1L << 31) && p.H * p.W >= 16;
 }
 int launch_gconv3x3_x2(const ConvGemmParams& p, hipStream_t s) {
   const int M = p.B * p.H * p.W, n_chunks = (M + wg3::CH - 1) / wg3::CH;
   int wgs = n_chunks < 256 ? n_chunks : 256;              // one 8-wave workgroup per CU (128 KB of LDS, 2 waves per SIMD with 256 VGPRs)
   const int cpw = (n_chunks + wgs - 1) / wgs;
   wgs = (n_chunks + cpw - 1) / cpw;
-  const int lds = 64 * 128 * 16 + 16;                  // the pixel ring + the zero slot
+  const int lds = 64 * 129 * 16 + 16;                  // the pixel ring (planes padded by one slot) + the zero slot
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)gconv3x3_x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

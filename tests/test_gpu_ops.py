@@ -44,6 +44,7 @@ CASES = [
     ('1x1_gelu',        2, 20, 20, 128,    256, 1, 1, 0, 1, 1, False, 0, True, False),
     ('3x3_lrelu_res',   2, 40, 40, 64,     128, 3, 1, 1, 1, 2, True, 1, True, False),
     ('3x3_grouped',     3, 20, 20, 256,    256, 3, 1, 1, 8, 1, False, 0, False, False),
+    ('3x3_grouped_rag', 5, 7,  9,  256,    256, 3, 1, 1, 8, 0, False, 0, False, False),    # chunks straddling images, a ragged last chunk
     ('k2s2_pos',        2, 20, 20, 128,    256, 2, 2, 0, 1, 0, False, 0, True, True),
     ('1x1_tails',       1, 5,  5,  288,    96,  1, 1, 0, 1, 0, True, 0, False, False),
     ('1x1_qkv_like',    3, 10, 10, 256,    864, 1, 1, 0, 1, 0, False, 0, True, False),
@@ -101,7 +102,7 @@ def test_conv_gemm(case, dt):
     assert err <= _tol(dt, ref), (name, dt, err)
 
 
-X2_CASES = ['1x1_gelu', '3x3_lrelu_res', '3x3_grouped', 'k2s2_pos', '1x1_tails', '1x1_qkv_like', 'k32_im2col', '1x1_bigK', '3x3_small_n32',
+X2_CASES = ['1x1_gelu', '3x3_lrelu_res', '3x3_grouped', '3x3_grouped_rag', 'k2s2_pos', '1x1_tails', '1x1_qkv_like', 'k32_im2col', '1x1_bigK', '3x3_small_n32',
             # M >= 1024, N >= 192: gemm256_x2_kernel (256 x 256 two-limb tile): M / N tails, every epilogue
             'g256_fc1_gelu', 'g256_fc2_res', 'g256_qkv_tailN', 'g256_qkv_n864', 'g256_proj_k384', 'g256_k128', 'g256_bigK']
 
