@@ -37,7 +37,8 @@ template <int NC, int CC, int MAXW>
 __global__ __launch_bounds__(512) void wgrad3x3_kernel(const bf16* __restrict__ x, int xld, const bf16* __restrict__ dz, int zld, float* __restrict__ part,
                                                        int M, int H, int W, int n_chunks, int chunks_per_wg) {
   using namespace wg3;
-  constexpr int WINP = CH + 2 * (MAXW + 1) + 2;               // pixels of the x window (W <= MAXW), rounded up
+  constexpr int WINP = CH + 2 * (MAXW + 1) + 3;               // pixels of the x window (W <= MAXW), rounded up to an ODD count: the staging stores walk the
+                                                               // 16-column subtiles, and with an even pitch they met on 2 of the 16 bank groups
   constexpr int ZT_BYTES = (NC / 16) * CH * 32;
   constexpr int XW_BYTES = (CC / 16) * WINP * 32;
   constexpr int NPZ = (CH * NC / 8) / 512;                     // 16-byte units of dz per thread and chunk
@@ -206,7 +207,7 @@ int launch_wgrad3x3(const void* x, int xld, const void* dz, int zld, float* dw, 
   int splits, cpw, njobs;
   const int n_chunks = wgrad3x3_plan(O, Ig, groups, M, &splits, &cpw, &njobs);
   if (groups == 8) {
-    constexpr int WINP = wg3::CH + 2 * 21 + 2, lds = (256 / 16) * wg3::CH * 32 + (256 / 16) * WINP * 32 + WINP * 32 + 32;
+    constexpr int WINP = wg3::CH + 2 * 21 + 3, lds = (256 / 16) * wg3::CH * 32 + (256 / 16) * WINP * 32 + WINP * 32 + 32;
     static bool attr = false;
     if (!attr) {
       hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_kernel<256, 256, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -215,7 +216,7 @@ int launch_wgrad3x3(const void* x, int xld, const void* dz, int zld, float* dw, 
     }
     hipLaunchKernelGGL((wgrad3x3_kernel<256, 256, 20>), dim3(splits), dim3(512), lds, s, (const bf16*)x, xld, (const bf16*)dz, zld, scratch, M, H, W, n_chunks, cpw);
   } else {
-    constexpr int WINP = wg3::CH + 2 * 41 + 2, lds = (128 / 16) * wg3::CH * 32 + (64 / 16) * WINP * 32 + WINP * 32 + 32;
+    constexpr int WINP = wg3::CH + 2 * 41 + 3, lds = (128 / 16) * wg3::CH * 32 + (64 / 16) * WINP * 32 + WINP * 32 + 32;
     hipLaunchKernelGGL((wgrad3x3_kernel<128, 64, 40>), dim3(splits, Ig / 64), dim3(512), lds, s, (const bf16*)x, xld, (const bf16*)dz, zld, scratch, M, H, W, n_chunks, cpw);
   }
   int rc = (int)hipGetLastError();
@@ -234,7 +235,7 @@ int launch_wgrad3x3(const void* x, int xld, const void* dz, int zld, float* dw, 
 __global__ __launch_bounds__(512) void gconv3x3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, int Kw, bf16* __restrict__ y, int M, int H, int W,
                                                        int n_chunks, int chunks_per_wg) {
   using namespace wg3;
-  constexpr int C = 256, MAXW = 20, WINP = CH + 2 * (MAXW + 1) + 2;      // 108 pixels
+  constexpr int C = 256, MAXW = 20, WINP = CH + 2 * (MAXW + 1) + 3;      // 109 pixels (odd: the staging stores walk the planes)
   constexpr int NPX = (WINP * (C / 8) + 511) / 512;
   __shared__ __attribute__((aligned(16))) unsigned char smem[(C / 8) * WINP * 16 + 16];     // [32 channel chunks][pixel][16 B] + a zero slot
   unsigned char* const ZERO = smem + (C / 8) * WINP * 16;

@@ -1,2 +1,7 @@
-for c in 1600 3200 6400 12800; do python bench.py --chunk $c --no-cpu-baseline --no-modes --no-roofline --steps 10 --warmup 2 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('visformer chunk $c',round(d['value'],1),round(d['ms_per_step'],2))"; done
-for c in 400 800 1600 3200 12800; do python bench.py --model deit_small_patch16_224 --chunk $c --no-cpu-baseline --no-modes --no-roofline --steps 3 --warmup 1 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('deit chunk $c',round(d['value'],1),round(d['ms_per_step'],2))"; done
+R=$PWD
+timeout 900 python -m pytest tests/test_gpu_train.py -x -q -m gpu 2>&1 | tail -2
+for i in 1 2; do python bench.py --mode train --no-cpu-baseline 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('train ms',d['ms_per_step'])"; done
+cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/kprof
+rocprofv3 --kernel-trace -d /tmp/kprof -o p -- python3 $R/bench.py --mode train --no-cpu-baseline --steps 7 --warmup 0 > /dev/null 2>&1
+python3 $R/tools/rocpd_stats.py $(ls /tmp/kprof/*.db | head -1) 7 > $R/gpurun_out/r02_train12_kernel_stats.csv
+grep -E "wgrad3x3|gconv" $R/gpurun_out/r02_train12_kernel_stats.csv
