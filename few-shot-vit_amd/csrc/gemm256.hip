@@ -64,13 +64,17 @@ __device__ __forceinline__ void gemm256_body(const ConvGemmParams& p, const int 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  // 16-bit kernel: 2 x 4 waves of 128 (m) x 64 (n).  Two-limb kernel: 4 x 2 waves of 64 x 128 - an activation fragment is split into limbs by
+  // every wave that reads it, and this layout halves both the fragments a wave reads per K tile (8 instead of 16) and the waves sharing them.
+  constexpr int WM_ROWS = LIMBS ? 64 : 128, WN_COLS = LIMBS ? 128 : 64;
+  constexpr int TMH = WM_ROWS / 32, TNH = WN_COLS / 32;        // 16-row tiles per A half / 16-column tiles per B half of a wave
+  const int wm = LIMBS ? wave >> 1 : wave >> 2, wn = LIMBS ? wave & 1 : wave & 3;
   const int lrow = lane & 15, lq = lane >> 4;
   const unsigned lds0 = (unsigned)(size_t)(lptr256_t)smem;
 
   // LDS read bases of this lane (row part + the two swizzled 16-byte k-chunk slots of the 128-byte row)
   const unsigned sw0 = (unsigned)((lq ^ (lrow & 7)) << 4), sw1 = (unsigned)(((4 + lq) ^ (lrow & 7)) << 4);
-  const unsigned a_rd = (unsigned)((wm * 128 + lrow) * 128), b_rd = (unsigned)(G_BOFF + (wn * 64 + lrow) * 128);
+  const unsigned a_rd = (unsigned)((wm * WM_ROWS + lrow) * 128), b_rd = (unsigned)(G_BOFF + (wn * WN_COLS + lrow) * 128);
 
   // DMA geometry of this wave: half-tile h of A / B = 128 rows = 16 groups of 8 rows, this wave stages groups 2w, 2w+1
   const int srow = lane >> 3;                       // row inside the 8-row group
@@ -81,8 +85,10 @@ __device__ __forceinline__ void gemm256_body(const ConvGemmParams& p, const int 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int hr0 = (2 * wave + j) * 8;
-      rbA[h][j] = h == 0 ? (hr0 < 64 ? hr0 : hr0 + 64) : (hr0 < 64 ? hr0 + 64 : hr0 + 128);   // rows {0-63,128-191} | {64-127,192-255}
-      rbB[h][j] = (hr0 >> 5) * 64 + h * 32 + (hr0 & 31);                                       // each wave column's left | right 32
+      const int two = h == 0 ? (hr0 < 64 ? hr0 : hr0 + 64) : (hr0 < 64 ? hr0 + 64 : hr0 + 128);   // 2 wave rows / columns of 128: {0-63,128-191} | {64-127,192-255}
+      const int four = (hr0 >> 5) * 64 + h * 32 + (hr0 & 31);                                      // 4 wave rows / columns of 64: each one's first | second 32
+      rbA[h][j] = LIMBS ? four : two;
+      rbB[h][j] = LIMBS ? two : four;
     }
 
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, P = gridDim.x >> 3;
@@ -127,26 +133,26 @@ __device__ __forceinline__ void gemm256_body(const ConvGemmParams& p, const int 
     dma2(nx ? offBn[h][0] : offB[h][0], nx ? offBn[h][1] : offB[h][1], Wb + (size_t)(nx ? 0 : kt) * 128, d + rbB[h][0] * 128, d + rbB[h][1] * 128);
   };
 
-  f32x4 acc[8][4];
+  f32x4 acc[2 * TMH][2 * TNH];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 2 * TMH; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  u32x4 xa[4][2], wb[2][2];
+    for (int j = 0; j < 2 * TNH; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 xa[TMH][2], wb[TNH][2];
   bool xa_raw = false;                             // LIMBS: xa holds fp32 values not yet split into limb words
   auto readA = [&](int half, int stage) {          // rows wm*128 + half*64 + i*16 + lrow
-    const unsigned char* base = smem + stage * G_STAGE + a_rd + half * (64 * 128);
+    const unsigned char* base = smem + stage * G_STAGE + a_rd + half * (TMH * 16 * 128);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TMH; ++i) {
       xa[i][0] = *reinterpret_cast<const u32x4*>(base + i * 2048 + sw0);
       xa[i][1] = *reinterpret_cast<const u32x4*>(base + i * 2048 + sw1);
     }
     xa_raw = true;
   };
   auto readB = [&](int half, int stage) {          // weight rows wn*64 + half*32 + j*16 + lrow
-    const unsigned char* base = smem + stage * G_STAGE + b_rd + half * (32 * 128);
+    const unsigned char* base = smem + stage * G_STAGE + b_rd + half * (TNH * 16 * 128);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TNH; ++j) {
       wb[j][0] = *reinterpret_cast<const u32x4*>(base + j * 2048 + sw0);
       wb[j][1] = *reinterpret_cast<const u32x4*>(base + j * 2048 + sw1);
     }
@@ -155,7 +161,7 @@ __device__ __forceinline__ void gemm256_body(const ConvGemmParams& p, const int 
     if constexpr (LIMBS) {
       if (xa_raw) {                                // (after the phase's wait + barrier: the split sits next to the MFMAs that consume it)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TMH; ++i)
 #pragma unroll
           for (int kc = 0; kc < 2; ++kc) {
             u32x4 xs, xr;
@@ -164,17 +170,19 @@ __device__ __forceinline__ void gemm256_body(const ConvGemmParams& p, const int 
           }
         xa_raw = false;
       }
+      // the cross terms pair the weight words with the half-swapped activation words; the swap is redone per phase on the (fewer) activation
+      // fragments instead of kept in registers (254 VGPRs as it is)
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          u32x4 wr;
+        for (int i = 0; i < TMH; ++i) {
+          u32x4 xr;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) wr[e] = __builtin_amdgcn_alignbit(wb[j][kc][e], wb[j][kc][e], 16);
+          for (int e = 0; e < 4; ++e) xr[e] = __builtin_amdgcn_alignbit(xa[i][kc][e], xa[i][kc][e], 16);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            acc[ah * 4 + i][bh * 2 + j] = mma_chunk<bf16>(wr, xa[i][kc], acc[ah * 4 + i][bh * 2 + j]);          // lo x hi + hi x lo
-            acc[ah * 4 + i][bh * 2 + j] = mma_chunk<bf16>(wb[j][kc], xa[i][kc], acc[ah * 4 + i][bh * 2 + j]);   // hi x hi + lo x lo
+          for (int j = 0; j < TNH; ++j) {
+            acc[ah * TMH + i][bh * TNH + j] = mma_chunk<bf16>(wb[j][kc], xr, acc[ah * TMH + i][bh * TNH + j]);          // lo x hi + hi x lo
+            acc[ah * TMH + i][bh * TNH + j] = mma_chunk<bf16>(wb[j][kc], xa[i][kc], acc[ah * TMH + i][bh * TNH + j]);   // hi x hi + lo x lo
           }
         }
     } else {
@@ -232,12 +240,12 @@ __device__ __forceinline__ void gemm256_body(const ConvGemmParams& p, const int 
     // kernel is issue-bound - 32 dwordx2 stores per lane cost more than the whole K = 256 main loop)
     {
       const int mt = xcd + 8 * (it / tiles_n), nt = it % tiles_n;
-      const int mb = mt * G_BM + wm * 128 + lrow, nb = nt * G_BN + wn * 64 + lq * 8;
-      int ncl[2];
-      bool nok[2];
-      f32x4 bv[2][2];
+      const int mb = mt * G_BM + wm * WM_ROWS + lrow, nb = nt * G_BN + wn * WN_COLS + lq * 8;
+      int ncl[TNH];
+      bool nok[TNH];
+      f32x4 bv[TNH][2];
 #pragma unroll
-      for (int jp = 0; jp < 2; ++jp) {
+      for (int jp = 0; jp < TNH; ++jp) {
         const int n = nb + jp * 32;
         nok[jp] = n < p.N;                         // N % 8 == 0: a group of 8 is valid or not as a whole
         ncl[jp] = nok[jp] ? n : 0;
@@ -249,17 +257,17 @@ __device__ __forceinline__ void gemm256_body(const ConvGemmParams& p, const int 
           float* const Yf = reinterpret_cast<float*>(p.y);
           const float* const Rf = reinterpret_cast<const float*>(p.res);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
+          for (int i = 0; i < 2 * TMH; ++i) {
             const int m = mb + i * 16;
             const bool mok = m < p.M;
             const size_t rowoff = (size_t)(mok ? m : p.M - 1) * p.y_cstride;
-            f32x4 rf[2][2];
+            f32x4 rf[TNH][2];
 #pragma unroll
-            for (int jp = 0; jp < 2; ++jp)
+            for (int jp = 0; jp < TNH; ++jp)
 #pragma unroll
               for (int q = 0; q < 2; ++q) rf[jp][q] = Rf ? *reinterpret_cast<const f32x4*>(Rf + rowoff + ncl[jp] + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int jp = 0; jp < 2; ++jp)
+            for (int jp = 0; jp < TNH; ++jp)
 #pragma unroll
               for (int q = 0; q < 2; ++q) {
                 f32x4 v = acc[i][2 * jp + q] + bv[jp][q];
@@ -274,18 +282,17 @@ __device__ __forceinline__ void gemm256_body(const ConvGemmParams& p, const int 
                 if (mok && nok[jp]) *reinterpret_cast<f32x4*>(Yf + rowoff + ncl[jp] + 4 * q) = v;
               }
           }
-          return;
-        }
+        } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 2 * TMH; ++i) {
           const int m = mb + i * 16;
           const bool mok = m < p.M;
           const size_t rowoff = (size_t)(mok ? m : p.M - 1) * p.y_cstride;
-          u32x4 rv[2];
+          u32x4 rv[TNH];
 #pragma unroll
-          for (int jp = 0; jp < 2; ++jp) rv[jp] = R ? *reinterpret_cast<const u32x4*>(R + rowoff + ncl[jp]) : u32x4{0u, 0u, 0u, 0u};
+          for (int jp = 0; jp < TNH; ++jp) rv[jp] = R ? *reinterpret_cast<const u32x4*>(R + rowoff + ncl[jp]) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-          for (int jp = 0; jp < 2; ++jp) {
+          for (int jp = 0; jp < TNH; ++jp) {
             const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[jp]);
             bf16x8 o;
 #pragma unroll
@@ -303,6 +310,7 @@ __device__ __forceinline__ void gemm256_body(const ConvGemmParams& p, const int 
             }
             if (mok && nok[jp]) *reinterpret_cast<bf16x8*>(Y + rowoff + ncl[jp]) = o;
           }
+        }
         }
       };
       if (p.act == ACT_GELU) finish([](float x) { return LIMBS ? gelu_erfc(x) : gelu_sig(x); });
