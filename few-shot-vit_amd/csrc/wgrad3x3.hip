@@ -168,14 +168,26 @@ __global__ __launch_bounds__(512) void wgrad3x3_kernel(const bf16* __restrict__ 
 // grouped: o = 32 job + n, ig = c;  dense: job = (ig / 64) * 8 + (ig % 64 / 32) * 4 + o / 32
 __global__ __launch_bounds__(256) void wgrad3x3_finalize_kernel(const float* __restrict__ part, float* __restrict__ dw, int O, int Ig, int grouped, int njobs,
                                                                 int splits) {
+  // a thread owns 4 consecutive c (one 16-byte load per split slab) and keeps four slabs in flight: the one-element-per-thread loop with its
+  // dependent 4-byte loads ran at 0.3 TB/s over the 19 MB of slabs (60 us per layer)
   const int total = njobs * wg3::JOB;
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+  for (int i4 = blockIdx.x * 256 + threadIdx.x; i4 < total / 4; i4 += gridDim.x * 256) {
+    const int idx = i4 * 4;
     const int c = idx & 31, n = (idx >> 5) & 31, tp = (idx >> 10) % 9, job = idx / wg3::JOB;
-    float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += part[(size_t)sp * total + idx];
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int sp = 0;
+    for (; sp + 4 <= splits; sp += 4) {
+      s0 += *reinterpret_cast<const f32x4*>(part + (size_t)sp * total + idx);
+      s1 += *reinterpret_cast<const f32x4*>(part + (size_t)(sp + 1) * total + idx);
+      s2 += *reinterpret_cast<const f32x4*>(part + (size_t)(sp + 2) * total + idx);
+      s3 += *reinterpret_cast<const f32x4*>(part + (size_t)(sp + 3) * total + idx);
+    }
+    for (; sp < splits; ++sp) s0 += *reinterpret_cast<const f32x4*>(part + (size_t)sp * total + idx);
+    const f32x4 s = (s0 + s1) + (s2 + s3);
     const int o = grouped ? job * 32 + n : (job & 3) * 32 + n;
     const int ig = grouped ? c : (job >> 3) * 64 + ((job >> 2) & 1) * 32 + c;
-    dw[((size_t)o * Ig + ig) * 9 + tp] = s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dw[((size_t)o * Ig + ig + e) * 9 + tp] = s[e];
   }
 }
 
@@ -222,7 +234,7 @@ int launch_wgrad3x3(const void* x, int xld, const void* dz, int zld, float* dw, 
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   const int total = njobs * wg3::JOB;
-  hipLaunchKernelGGL(wgrad3x3_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, scratch, dw, O, Ig, groups == 8 ? 1 : 0, njobs, splits);
+  hipLaunchKernelGGL(wgrad3x3_finalize_kernel, dim3((total / 4 + 255) / 256), dim3(256), 0, s, scratch, dw, O, Ig, groups == 8 ? 1 : 0, njobs, splits);
   return (int)hipGetLastError();
 }
 
