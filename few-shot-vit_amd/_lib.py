@@ -66,6 +66,7 @@ SIGNATURES = {
     'fsvit_conv_gemm': (_i, [_vp, _vp, _fp, _vp, _fp, _vp] + [_i] * 15 + [_i, _vp]),
     'fsvit_conv_stem_tail': (_i, [_vp, _vp, _fp, _fp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'fsvit_stage1_block': (_i, [_vp, _vp, _vp, _fp, _vp, _vp, _i, _vp]),
+    'fsvit_stage1_block_hw': (_i, [_vp, _vp, _vp, _fp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'fsvit_visformer_last_tokens': (_i, [_vp, _vp, _sz, _i, _fp, _vp]),
     'fsvit_visformer_train_tokens': (_i, [_vp, _fp, _vp]),
     'fsvit_visformer_train_set_token_grad': (_i, [_vp, _fp]),

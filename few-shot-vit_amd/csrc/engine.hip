@@ -595,13 +595,21 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
   // stage 1: x += conv3(GELU(conv2_g(GELU(conv1(BN(x))))))
   const int Cg = h->hid1 / h->cfg.group;
   static const bool no_fuse = [] { const char* e = getenv("FSVIT_NO_FUSE"); return e && e[0] == '1'; }();
-  const bool fuse1 = !no_fuse && K(stage1_fused_supported)(dt, h->C1, h->hid1, h->cfg.group, h->H1);
+  // one LDS-resident kernel per block: the half-image kernel (20 x 20 tokens) or the ring kernel (any map up to 20 wide; FSVIT_STAGE1_RING=1: always)
+  const bool half1 = K(stage1_fused_supported)(dt, h->C1, h->hid1, h->cfg.group, h->H1) && h->s1.size() && h->s1[0].img;
+  const bool ring_ok = K(stage1_ring_supported)(dt, h->C1, h->hid1, h->cfg.group, h->H1) && h->s1.size() && h->s1[0].c2.Kw == 320;
+  const bool ring1 = !no_fuse && ring_ok && (!half1 || K(stage1_ring_preferred)());
+  const bool fuse1 = !no_fuse && (half1 || ring1);
   for (size_t i = 0; i < h->s1.size(); ++i) {
     const Block1& b = h->s1[i];
     if (fuse1) {   // one LDS-resident kernel per block, ping-pong between x1 and x1b
       const double fl = 2.0 * Bc * h->H1 * h->H1 * ((double)h->hid1 * h->C1 + (double)h->hid1 * 9 * Cg + (double)h->C1 * h->hid1);
-      RC_TRY(timed(h, st, "stage1.block", KID_STAGE1, fl,
-                   [&]() { return K(launch_stage1_block)(x1, x1b, b.img, b.c1.bias, Bc, st); }));
+      if (ring1)
+        RC_TRY(timed(h, st, "stage1.block", KID_STAGE1, fl,
+                     [&]() { return K(launch_stage1_ring)(x1, x1b, b.c1.w, b.c1.bias, b.c2.w, b.c3.w, Bc, h->H1, h->H1, st); }));
+      else
+        RC_TRY(timed(h, st, "stage1.block", KID_STAGE1, fl,
+                     [&]() { return K(launch_stage1_block)(x1, x1b, b.img, b.c1.bias, Bc, st); }));
       std::swap(x1, x1b);
     } else {
       RC_TRY(run_gemm(h, st, "stage1.mlp.conv1", b.c1, conv_params(b.c1, x1, ha, Bc, h->H1, h->H1, h->C1, h->C1, 1, 1, 1, 0, h->hid1, ACT_GELU, nullptr, 0, nullptr), h->hid1, h->C1));
@@ -819,11 +827,25 @@ extern "C" int fsvit_stage1_block(const void* x, void* y, const void* w1, const 
   hipStream_t st = (hipStream_t)stream;
   void* img = nullptr;
   HIP_TRY(hipMalloc(&img, K(stage1_image_bytes)()));
-  int rc = K(launch_stage1_pack)(w1, w2, w3, img, st);
-  if (rc == 0) rc = K(launch_stage1_block)(x, y, img, b1, B, st);
+  int rc;
+  if (K(stage1_ring_preferred)()) rc = K(launch_stage1_ring)(x, y, w1, b1, w2, w3, B, 20, 20, st);      // FSVIT_STAGE1_RING=1
+  else {
+    rc = K(launch_stage1_pack)(w1, w2, w3, img, st);
+    if (rc == 0) rc = K(launch_stage1_block)(x, y, img, b1, B, st);
+  }
   (void)hipStreamSynchronize(st);
   (void)hipFree(img);
   if (rc != 0) return hipfail((hipError_t)rc, "fsvit_stage1_block");
+  return 0;
+}
+
+extern "C" int fsvit_stage1_block_hw(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, int H, int W, int dtype,
+                                     void* stream) {
+  const int kdt = dtype;
+  if (!x || !y || !w1 || !b1 || !w2 || !w3 || x == y || B <= 0) return fail(FSVIT_ERR_ARG, "bad argument");
+  if (dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "fsvit_stage1_block_hw: 16-bit storage only (bf16 / f16)");
+  if (H != W || !K(stage1_ring_supported)(1, 128, 256, 8, W)) return fail(FSVIT_ERR_ARG, "fsvit_stage1_block_hw: square maps of 4 .. 20 tokens a side");
+  RC_TRY(K(launch_stage1_ring)(x, y, w1, b1, w2, w3, B, H, W, (hipStream_t)stream));
   return 0;
 }
 

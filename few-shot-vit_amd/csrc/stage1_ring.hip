@@ -1,0 +1,231 @@
+// Fused Visformer stage-1 block, second design ("ring"):   y = x + conv3( GELU( conv2_g8_3x3( GELU( conv1( BN(x) ) ) ) ) )
+// (test_phase/models/visformer.py:259-263 Block.forward with attn_disabled, Mlp :152-163; eval BatchNorm folded into conv1 by the packer).
+//
+// stage1_fused.hip owns a half image per workgroup and walks the 8 channel groups with all 16 waves in phase: per group interval the LDS
+// reads (2.9 k cycles), the MFMAs (1.8 k) and the GELUs (~2 k) queue up behind two barriers, every MFMA is fed by 1 .. 1.5 ds_read_b128 because
+// the weights come from LDS, and the MFMA pipe is busy 32 % of the time (profiles/r02_stage1_pmc.txt).  This kernel turns the decomposition
+// round - the same move that took the grouped conv of the training step from 213 to 91 us (wgrad3x3.hip gconv3x3_kernel):
+//   * WAVE g IS CHANNEL GROUP g for conv1 and conv2, and OUTPUT-CHANNEL TILE g for conv3; all of its weights live in registers for the whole
+//     launch: 8 fragments of W1 (32 hidden channels x 128), 18 of W2 (9 taps x 32 x 32), 8 of W3 (16 output channels x 256) = 136 VGPRs.  Only
+//     activations move through LDS: 0.6 fragment reads per MFMA;
+//   * the workgroup walks the batch as ONE sequence of pixels in chunks of 64 (any image geometry with W <= 20): x and the first hidden map h1
+//     live in RINGS of 128 pixel slots (slot = linear pixel index & 127, one plane per 8 channels, [plane][slot][16 B]).  A chunk stages only its
+//     64 NEW pixels of x, computes h1 for exactly those (conv1 is pointwise: no halo recomputation), then conv2 for its 64 pixels reads the 3x3
+//     neighbourhoods out of the h1 ring - a tap is an address, taps outside the image read a zero slot;
+//   * h1 is written and read by the SAME wave (its group's 4 planes): no barrier between conv1 and conv2.  h2 crosses waves once (conv3 contracts
+//     over all 256 hidden channels): [32 planes][64 pixels], one barrier.  The output tile goes through LDS for 16-byte coalesced stores;
+//   * per chunk and wave: 32 + 72 + 32 = 136 MFMAs (the algorithmic minimum), 64 GELUs per lane (packed pairs), 4 barriers; the next chunk's x
+//     batch (2 x 16 B per thread) is in flight under the MFMAs.
+// Numerics: as stage1_fused - h1 and h2 are rounded to the 16-bit storage type where they are stored, everything else fp32; a pixel's value does
+// not depend on its position in a chunk (batching never changes a result).
+#include <stdlib.h>
+
+#include "fsvit_common.h"
+#include "kernels.h"
+
+#ifndef S1R_UNROLL
+#define S1R_UNROLL 4
+#endif
+
+namespace FSVIT_NS {
+
+namespace s1r {
+constexpr int C1 = 128, HID = 256, G = 8, CH = 64, RING = 128, HALO = 21, KW2 = 320;
+constexpr int PITCH = (RING + 1) * 16;          // ring plane pitch (one pad slot: the staging stores walk the planes)
+constexpr int XR = 0;                            // x ring: 16 planes of 8 channels
+constexpr int H1R = XR + (C1 / 8) * PITCH;       // h1 ring: 32 planes
+constexpr int H2P = (CH + 1) * 16;               // h2 plane pitch
+constexpr int H2 = H1R + (HID / 8) * PITCH;      // h2 of the current chunk: 32 planes x 64 pixels
+constexpr int OROW = C1 * 2 + 16;                // output tile row pitch (272 B: conflict-free 8-byte column writes)
+constexpr int OUT = H2 + (HID / 8) * H2P;        // output tile [64 pixels][128 channels]
+constexpr int ZERO = OUT + CH * OROW;            // 16 zero bytes
+constexpr int LDS_BYTES = ZERO + 16;             // 149 776
+}  // namespace s1r
+
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_r;
+
+__device__ __forceinline__ u32x2_r s1r_pack4(f32x4 v) {
+  const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+  return __builtin_bit_cast(u32x2_r, o);
+}
+__device__ __forceinline__ f32x4 s1r_gelu4(f32x4 v) {
+  const f32x2 a = gelu_sig2(f32x2{v[0], v[1]}), b = gelu_sig2(f32x2{v[2], v[3]});
+  return f32x4{a[0], a[1], b[0], b[1]};
+}
+
+__global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const bf16* __restrict__ w1,
+                                                             const float* __restrict__ b1, const bf16* __restrict__ w2, const bf16* __restrict__ w3, int M,
+                                                             int H, int W, int n_chunks, int chunks_per_wg) {
+  using namespace s1r;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63, lrow = lane & 15, lq = lane >> 4;
+  const int g = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int q0 = blockIdx.x * chunks_per_wg;
+  int q1 = q0 + chunks_per_wg; q1 = q1 < n_chunks ? q1 : n_chunks;
+  if (q0 >= q1) return;
+  if (t < 4) reinterpret_cast<unsigned*>(smem + ZERO)[t] = 0u;
+
+  // ---- this wave's weights (A operands: row = output channel of the product, 8 consecutive k per lane)
+  u32x4 wf1[2][4], wf2[9][2], wf3[8];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) wf1[nt][kc] = *reinterpret_cast<const u32x4*>(w1 + (size_t)(g * 32 + nt * 16 + lrow) * C1 + kc * 32 + lq * 8);
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) wf2[tp][nt] = *reinterpret_cast<const u32x4*>(w2 + (size_t)(g * 32 + nt * 16 + lrow) * KW2 + tp * 32 + lq * 8);
+#pragma unroll
+  for (int kc = 0; kc < 8; ++kc) wf3[kc] = *reinterpret_cast<const u32x4*>(w3 + (size_t)(g * 16 + lrow) * HID + kc * 32 + lq * 8);
+  f32x4 bias1[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) bias1[nt] = *reinterpret_cast<const f32x4*>(b1 + g * 32 + nt * 16 + lq * 4);
+
+  // ---- x batches: 64 consecutive pixels from linear index P0 (pixels outside [0, M) are stored as zeros); 2 x 16 B per thread
+  u32x4 px[2];
+  unsigned pxok = 0;
+  auto gload = [&](long P0) {
+    pxok = 0;
+#pragma unroll
+    for (int u0 = 0; u0 < 2; ++u0) {
+      const int u = t + 512 * u0, p = u >> 4, c8 = u & 15;
+      const long m = P0 + p;
+      const bool ok = m >= 0 && m < M;
+      px[u0] = *reinterpret_cast<const u32x4*>(x + (size_t)(ok ? m : 0) * C1 + c8 * 8);      // unconditional, clamped (no exec-masked branch per load)
+      pxok |= ok ? (1u << u0) : 0u;
+    }
+  };
+  auto lstore = [&](long P0) {
+#pragma unroll
+    for (int u0 = 0; u0 < 2; ++u0) {
+      const int u = t + 512 * u0, p = u >> 4, c8 = u & 15;
+      const u32x4 v = ((pxok >> u0) & 1u) ? px[u0] : u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(smem + XR + c8 * PITCH + (int)((P0 + p) & (RING - 1)) * 16) = v;
+    }
+  };
+  // conv1 + bias + GELU for the 64 pixels from P0: wave g computes hidden channels 32 g .. 32 g + 31 into ITS planes of the h1 ring
+  const unsigned char* const xplane = smem + XR + lq * PITCH;                 // k-chunk kc adds 4 planes
+  unsigned char* const h1w = smem + H1R + (g * 4 + (lq >> 1)) * PITCH + (lq & 1) * 8;     // channel tile nt adds 2 planes
+  auto conv1 = [&](long P0) {
+#pragma unroll S1R_UNROLL
+    for (int mt = 0; mt < CH / 16; ++mt) {
+      const int slot = (int)((P0 + mt * 16 + lrow) & (RING - 1)) * 16;
+      f32x4 acc[2] = {bias1[0], bias1[1]};
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        const u32x4 xf = *reinterpret_cast<const u32x4*>(xplane + kc * (4 * PITCH) + slot);
+        acc[0] = mma_chunk<bf16>(wf1[0][kc], xf, acc[0]);
+        acc[1] = mma_chunk<bf16>(wf1[1][kc], xf, acc[1]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<u32x2_r*>(h1w + nt * (2 * PITCH) + slot) = s1r_pack4(s1r_gelu4(acc[nt]));
+    }
+  };
+
+  const unsigned char* const h1plane = smem + H1R + (g * 4 + lq) * PITCH;      // conv2 B operand: channels 32 g + 8 lq .. of a pixel
+  unsigned char* const h2w = smem + H2 + (g * 4 + (lq >> 1)) * H2P + (lq & 1) * 8;
+  const unsigned char* const h2plane = smem + H2 + lq * H2P;                   // conv3 B operand: k-chunk kc adds 4 planes
+  const unsigned char* const xres = smem + XR + (g * 2 + (lq >> 1)) * PITCH + (lq & 1) * 8;   // residual: channels 16 g + 4 lq .. of a pixel
+  unsigned char* const outw = smem + OUT + (g * 16 + lq * 4) * 2;
+  const int HW = H * W;
+
+  // ---- the first window: x pixels [64 q0 - 21, 64 q0 + 107) = the whole ring in two batches; h1 of the first batch here, of the second in the loop
+  gload((long)q0 * CH - HALO);
+  lstore((long)q0 * CH - HALO);
+  gload((long)q0 * CH - HALO + CH);
+  __syncthreads();
+  conv1((long)q0 * CH - HALO);
+
+  for (int q = q0; q < q1; ++q) {
+    const long Pn = (long)q * CH - HALO + CH;                       // the 64 pixels this chunk adds: [64 q + 43, 64 q + 107)
+    __syncthreads();                                                // A: the previous chunk's h2 / output tile / oldest ring slots are free
+    lstore(Pn);
+    __syncthreads();                                                // B: the new x pixels are visible
+    if (q + 1 < q1) gload(Pn + CH);
+    conv1(Pn);
+
+    // conv2 (grouped 3x3) + GELU for pixels [64 q, 64 q + 64): taps out of this wave's own h1 planes
+    const int m0 = q * CH;
+    int oyc, oxc;
+    {
+      const int mm = m0 + lrow, rem = mm % HW;
+      oyc = rem / W;
+      oxc = rem - oyc * W;
+    }
+#pragma unroll S1R_UNROLL
+    for (int mt = 0; mt < CH / 16; ++mt) {
+      const int m = m0 + mt * 16 + lrow;
+      const int oy = m < M ? oyc : -4, ox = oxc;
+      oxc += 16;
+      while (oxc >= W) { oxc -= W; ++oyc; }
+      if (oyc >= H) oyc -= H;
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int dy = tp / 3 - 1, dx = tp % 3 - 1;
+        const bool ok = (unsigned)(oy + dy) < (unsigned)H && (unsigned)(ox + dx) < (unsigned)W;
+        const u32x4 hf = *reinterpret_cast<const u32x4*>(ok ? h1plane + ((m + dy * W + dx) & (RING - 1)) * 16 : smem + ZERO);
+        acc[0] = mma_chunk<bf16>(wf2[tp][0], hf, acc[0]);
+        acc[1] = mma_chunk<bf16>(wf2[tp][1], hf, acc[1]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<u32x2_r*>(h2w + nt * (2 * H2P) + (mt * 16 + lrow) * 16) = s1r_pack4(s1r_gelu4(acc[nt]));
+    }
+    __syncthreads();                                                // C: h2 of all groups is complete
+
+    // conv3 + residual: wave g = output channels 16 g .. 16 g + 15
+#pragma unroll S1R_UNROLL
+    for (int mt = 0; mt < CH / 16; ++mt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accb = acc;       // two chains of four dependent MFMAs
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) {
+        acc = mma_chunk<bf16>(wf3[kc], *reinterpret_cast<const u32x4*>(h2plane + kc * (4 * H2P) + (mt * 16 + lrow) * 16), acc);
+        accb = mma_chunk<bf16>(wf3[kc + 4], *reinterpret_cast<const u32x4*>(h2plane + (kc + 4) * (4 * H2P) + (mt * 16 + lrow) * 16), accb);
+      }
+      acc += accb;
+      const int m = m0 + mt * 16 + lrow;
+      const bf16x4 r = __builtin_bit_cast(bf16x4, *reinterpret_cast<const u32x2_r*>(xres + (m & (RING - 1)) * 16));
+      acc += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+      *reinterpret_cast<u32x2_r*>(outw + (mt * 16 + lrow) * OROW) = s1r_pack4(acc);
+    }
+    __syncthreads();                                                // D: the output tile is complete
+#pragma unroll
+    for (int u0 = 0; u0 < 2; ++u0) {
+      const int u = t + 512 * u0, p = u >> 4, c8 = u & 15;
+      const long m = (long)m0 + p;
+      if (m < M) *reinterpret_cast<u32x4*>(y + (size_t)m * C1 + c8 * 8) = *reinterpret_cast<const u32x4*>(smem + OUT + p * OROW + c8 * 16);
+    }
+  }
+}
+
+bool stage1_ring_supported(int dtype, int C1, int hid, int group, int H1) {
+  return dtype == 1 && C1 == s1r::C1 && hid == s1r::HID && group == s1r::G && H1 >= 4 && H1 <= 20;
+}
+// FSVIT_STAGE1_RING=1: use this kernel also where stage1_fused.hip's half-image kernel applies (20 x 20 tokens; the two run at the same speed
+// there - both are bound by the 512 GELUs per token); other geometries take it by default
+bool stage1_ring_preferred() {
+  static const bool on = [] { const char* e = getenv("FSVIT_STAGE1_RING"); return e && e[0] == '1'; }();
+  return on;
+}
+
+// w1 [256][128], w2 [256][320] (columns (tap, c)), w3 [128][256]: the packed layers of the block (engine.hip pack_layer)
+int launch_stage1_ring(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, int H, int W, hipStream_t s) {
+  const long Ml = (long)B * H * W;
+  if (Ml <= 0) return 0;
+  if (Ml >= (1L << 31) - 256 || W > 20 || H * W < 16) return (int)hipErrorInvalidValue;
+  const int M = (int)Ml, n_chunks = (M + s1r::CH - 1) / s1r::CH;
+  int wgs = n_chunks < 256 ? n_chunks : 256;              // one 8-wave workgroup per CU (150 KB of LDS)
+  const int cpw = (n_chunks + wgs - 1) / wgs;
+  wgs = (n_chunks + cpw - 1) / cpw;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)stage1_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, s1r::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(stage1_ring_kernel, dim3(wgs), dim3(512), s1r::LDS_BYTES, s, (const bf16*)x, (bf16*)y, (const bf16*)w1, b1, (const bf16*)w2, (const bf16*)w3, M, H, W,
+                     n_chunks, cpw);
+  return (int)hipGetLastError();
+}
+
+}  // namespace FSVIT_NS

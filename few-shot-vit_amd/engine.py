@@ -463,6 +463,17 @@ class ops:
             _lib.check(lib.fsvit_stage1_block(_ptr(x), _ptr(y), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(w3), x.shape[0], _stream_ptr(x.device)))
         return y
 
+    @staticmethod
+    def stage1_block_hw(x, w1, b1, w2, w3):
+        """x NHWC [B,H,W,128] (bf16 / fp16), H = W in 4 .. 20: the ring kernel of the stage-1 block (fsvit_stage1_block_hw)."""
+        _require_cuda(x, w1, w2, w3, b1)
+        lib = _lib.load()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.fsvit_stage1_block_hw(_ptr(x), _ptr(y), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(w3), x.shape[0], x.shape[1], x.shape[2], ops._dt(x),
+                                                 _stream_ptr(x.device)))
+        return y
+
     # ---- distillation head (sun_meta_training/offline.py): fp32, token-major rows
     @staticmethod
     def linear(x, w, b=None):

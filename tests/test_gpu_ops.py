@@ -353,6 +353,40 @@ def test_stage1_fused_block_matches_unfused_math():
     assert border.mean().item() <= 3 * err.mean().item() + 1e-6
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('B,HW', [(5, 20), (3, 16), (7, 10), (2, 4), (130, 20)])
+def test_stage1_ring_block_matches_unfused_math(B, HW, dtype):
+    """fsvit_stage1_block_hw (stage1_ring.hip: wave = channel group, weights in registers, pixel rings) vs fp32 torch with the same 16-bit
+    roundings of x, the weights and the two hidden maps - several map sizes (chunks of 64 pixels straddle images and the batch end), and
+    against the half-image kernel at 20 x 20."""
+    from fewshot_vit_amd.engine import ops
+    g = torch.Generator().manual_seed(1000 * B + HW)
+    x = q(torch.randn(B, 128, HW, HW, generator=g), dtype)
+    w1 = q(torch.randn(256, 128, 1, 1, generator=g) / math.sqrt(128), dtype)
+    b1 = torch.randn(256, generator=g) * 0.2
+    w2 = q(torch.randn(256, 32, 3, 3, generator=g) / math.sqrt(288), dtype)
+    w3 = q(torch.randn(128, 256, 1, 1, generator=g) / math.sqrt(256), dtype)
+    h1 = q(F.gelu(F.conv2d(x, w1, b1)), dtype)
+    h2 = q(F.gelu(F.conv2d(h1, w2, padding=1, groups=8)), dtype)
+    ref = x + F.conv2d(h2, w3)
+    xd = x.permute(0, 2, 3, 1).contiguous().to('cuda', dtype)
+    args = (pack_w(w1, 1, dtype)[0].cuda(), b1.cuda(), pack_w(w2, 8, dtype).cuda(), pack_w(w3, 1, dtype)[0].cuda())
+    y = ops.stage1_block_hw(xd, *args)
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs()
+    print(f'stage1 ring B={B} {HW}x{HW} {dtype}: max err {err.max():.3e}, mean {err.mean():.3e}')
+    assert err.max().item() <= 3e-2 * max(1.0, float(ref.abs().max())), err.max().item()
+    assert err.mean().item() <= 2e-3
+    border = torch.cat([err[:, :, 0].flatten(), err[:, :, -1].flatten(), err[:, :, :, 0].flatten(), err[:, :, :, -1].flatten()])
+    assert border.mean().item() <= 3 * err.mean().item() + 1e-6
+    assert torch.equal(y, ops.stage1_block_hw(xd, *args))                                   # deterministic
+    if HW == 20 and dtype == torch.bfloat16:                                                 # the half-image kernel computes the same block
+        y0 = ops.stage1_block(xd, *args).float().cpu().permute(0, 3, 1, 2)
+        assert (y0 - got).abs().max().item() <= 3e-2 * max(1.0, float(ref.abs().max()))
+        assert (y0 - got).abs().mean().item() <= 1e-3
+
+
 @pytest.mark.parametrize('C', [256, 512])
 @pytest.mark.parametrize('M', [256, 1000, 70000 + 37])
 def test_mlp_rows_fused_matches_unfused_math(M, C):

@@ -311,3 +311,27 @@ def test_full_size_step_equals_small_launches(full_sd):
         small = torch.cat([m(xs[e:e + 8].cuda(), xq[e:e + 8].cuda()).cpu() for e in range(0, E, 8)])
     assert big.shape == (E, 75, 5) and torch.isfinite(big).all()
     assert torch.equal(big, small)
+
+
+def test_image_size_64_runs_the_ring_stage1_block():
+    """A 64 x 64 model (stage-1 map 16 x 16: the half-image kernel of stage1_fused.hip does not apply, the engine takes stage1_ring.hip; stage 2 has
+    64 tokens, stage 3 sixteen): parity features vs the oracle, bf16 features vs parity, launch-size invariance."""
+    from fewshot_vit_amd import synthetic
+    from fewshot_vit_amd.engine import VisformerEngine
+    from oracle import visformer_oracle as vo
+    ocfg = vo.VisformerCfg(img_size=64)
+    full = synthetic.synthetic_checkpoint_sd(vo.state_dict_shapes(ocfg, prefix='encoder.'))       # (the BN calibration is per channel: any image size)
+    sd = {k[len('encoder.'):]: v for k, v in full.items()}
+    cfg = dict(img_size=64, init_channels=64, embed_dim=256, depth=(4, 2, 3), num_heads=6, mlp_ratio=4.0, group=8)
+    x = synthetic.synthetic_episodes(5, 1, 3, 2, 1, img=64)            # 9 images
+    with torch.no_grad():
+        ref = vo.visformer_forward(sd, x, ocfg)
+    par = VisformerEngine(cfg, sd, numerics='parity').forward(x.cuda()).cpu()
+    eng = VisformerEngine(cfg, sd, numerics='bf16')
+    bf = eng.forward(x.cuda()).cpu()
+    one = torch.cat([eng.forward(x[i:i + 1].cuda()) for i in range(x.shape[0])]).cpu()
+    e_par, e_bf = (par - ref).abs().max().item(), (bf - par).abs().max().item()
+    print(f'64 x 64: parity vs oracle {e_par:.3e}, bf16 vs parity {e_bf:.3e} (max |feat| {ref.abs().max():.2f})')
+    assert e_par <= 1e-3
+    assert e_bf <= 0.05 * max(1.0, ref.abs().max().item())
+    assert torch.equal(bf, one)
