@@ -1,2 +1,5 @@
-timeout 900 python -m pytest tests/test_gpu_visformer.py -x -q -m gpu -k "image_size" -s 2>&1 | grep -E "64 x 64|passed|failed|Error" | tail -5
-FSVIT_STAGE1_RING=1 timeout 900 python -m pytest tests/test_gpu_visformer.py tests/test_gpu_soak.py tests/test_gpu_driver.py -x -q -m gpu 2>&1 | tail -2
+export FSVIT_STAGE1_RING=1
+python tools/bench_stage1.py 12800
+python tools/bench_stage1.py 12800 tools/probes/variants/libfsvit_nogelu.so
+python tools/bench_stage1.py 12800 tools/probes/variants/libfsvit_nomask.so
+python tools/bench_stage1.py 12800 tools/probes/variants/libfsvit_nogelumask.so

@@ -1,5 +1,5 @@
 """Times the fused stage-1 block (fsvit_stage1_block through ops.stage1_block is synchronous: this calls the launcher through the engine op in a loop
-with HIP events).  python tools/bench_stage1.py [images]      FSVIT_STAGE1_RING=0 selects the half-image kernel."""
+with HIP events).  python tools/bench_stage1.py [images [variant.so]]      FSVIT_STAGE1_RING=1 selects the ring kernel."""
 import math
 import sys
 import ctypes as C
@@ -21,6 +21,9 @@ w2[:, :288] = torch.randn(256, 288, generator=g) / math.sqrt(288)
 w2 = w2.to('cuda', bf)
 w3 = (torch.randn(128, 256, generator=g) / math.sqrt(256)).to('cuda', bf)
 y = torch.empty_like(x)
+import os
+if len(sys.argv) > 2:                    # a variant library (tools/build_variant.sh)
+    _lib.LIB_PATH = os.path.abspath(sys.argv[2])
 lib = _lib.load()
 st = _stream_ptr(x.device)
 for _ in range(2):
