@@ -5,16 +5,16 @@
 // reads (2.9 k cycles), the MFMAs (1.8 k) and the GELUs (~2 k) queue up behind two barriers, every MFMA is fed by 1 .. 1.5 ds_read_b128 because
 // the weights come from LDS, and the MFMA pipe is busy 32 % of the time (profiles/r02_stage1_pmc.txt).  This kernel turns the decomposition
 // round - the same move that took the grouped conv of the training step from 213 to 91 us (wgrad3x3.hip gconv3x3_kernel):
-//   * WAVE g IS CHANNEL GROUP g for conv1 and conv2, and OUTPUT-CHANNEL TILE g for conv3; all of its weights live in registers for the whole
-//     launch: 8 fragments of W1 (32 hidden channels x 128), 18 of W2 (9 taps x 32 x 32), 8 of W3 (16 output channels x 256) = 136 VGPRs.  Only
-//     activations move through LDS: 0.6 fragment reads per MFMA;
+//   * WAVE g IS CHANNEL GROUP g for conv1 and conv2, and a (32 output channels x 32 pixels) block for conv3; all of its weights live in registers
+//     for the whole launch: 8 fragments of W1 (32 hidden channels x 128), 18 of W2 (9 taps x 32 x 32), 16 of W3 (32 output channels x 256) = 168
+//     VGPRs.  Only activations move through LDS: 0.5 fragment reads per MFMA;
 //   * the workgroup walks the batch as ONE sequence of pixels in chunks of 64 (any image geometry with W <= 20): x and the first hidden map h1
 //     live in RINGS of 128 pixel slots (slot = linear pixel index & 127, one plane per 8 channels, [plane][slot][16 B]).  A chunk stages only its
 //     64 NEW pixels of x, computes h1 for exactly those (conv1 is pointwise: no halo recomputation), then conv2 for its 64 pixels reads the 3x3
 //     neighbourhoods out of the h1 ring - a tap is an address, taps outside the image read a zero slot;
 //   * h1 is written and read by the SAME wave (its group's 4 planes): no barrier between conv1 and conv2.  h2 crosses waves once (conv3 contracts
 //     over all 256 hidden channels): [32 planes][64 pixels], one barrier.  The output tile goes through LDS for 16-byte coalesced stores;
-//   * per chunk and wave: 32 + 72 + 32 = 136 MFMAs (the algorithmic minimum), 64 GELUs per lane (packed pairs), 4 barriers; the next chunk's x
+//   * per chunk and wave: 32 + 72 + 32 = 136 MFMAs (the algorithmic minimum) fed by 16 + 36 + 16 fragment reads, 64 GELUs per lane (packed pairs), 4 barriers; the next chunk's x
 //     batch (2 x 16 B per thread) is in flight under the MFMAs.
 // Numerics: as stage1_fused - h1 and h2 are rounded to the 16-bit storage type where they are stored, everything else fp32; a pixel's value does
 // not depend on its position in a chunk (batching never changes a result).
@@ -25,6 +25,12 @@
 
 #ifndef S1R_UNROLL
 #define S1R_UNROLL 4
+#endif
+
+#ifdef S1R_NO_BAR        // timing diagnostics only (races)
+#define S1R_SYNC() do { } while (0)
+#else
+#define S1R_SYNC() __syncthreads()
 #endif
 
 namespace FSVIT_NS {
@@ -69,7 +75,8 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restr
   if (t < 4) reinterpret_cast<unsigned*>(smem + ZERO)[t] = 0u;
 
   // ---- this wave's weights (A operands: row = output channel of the product, 8 consecutive k per lane)
-  u32x4 wf1[2][4], wf2[9][2], wf3[8];
+  u32x4 wf1[2][4], wf2[9][2], wf3[2][8];
+  const int np3 = g >> 1, ph3 = g & 1;          // conv3: this wave = output channels 32 np3 .. + 31 of the pixel tiles 2 ph3, 2 ph3 + 1
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -79,7 +86,9 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restr
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) wf2[tp][nt] = *reinterpret_cast<const u32x4*>(w2 + (size_t)(g * 32 + nt * 16 + lrow) * KW2 + tp * 32 + lq * 8);
 #pragma unroll
-  for (int kc = 0; kc < 8; ++kc) wf3[kc] = *reinterpret_cast<const u32x4*>(w3 + (size_t)(g * 16 + lrow) * HID + kc * 32 + lq * 8);
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) wf3[nt][kc] = *reinterpret_cast<const u32x4*>(w3 + (size_t)(np3 * 32 + nt * 16 + lrow) * HID + kc * 32 + lq * 8);
   f32x4 bias1[2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) bias1[nt] = *reinterpret_cast<const f32x4*>(b1 + g * 32 + nt * 16 + lq * 4);
@@ -128,8 +137,8 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restr
   const unsigned char* const h1plane = smem + H1R + (g * 4 + lq) * PITCH;      // conv2 B operand: channels 32 g + 8 lq .. of a pixel
   unsigned char* const h2w = smem + H2 + (g * 4 + (lq >> 1)) * H2P + (lq & 1) * 8;
   const unsigned char* const h2plane = smem + H2 + lq * H2P;                   // conv3 B operand: k-chunk kc adds 4 planes
-  const unsigned char* const xres = smem + XR + (g * 2 + (lq >> 1)) * PITCH + (lq & 1) * 8;   // residual: channels 16 g + 4 lq .. of a pixel
-  unsigned char* const outw = smem + OUT + (g * 16 + lq * 4) * 2;
+  const unsigned char* const xres = smem + XR + (np3 * 4 + (lq >> 1)) * PITCH + (lq & 1) * 8;   // residual: channels 32 np3 + 4 lq .. of a pixel (tile nt: + 2 planes)
+  unsigned char* const outw = smem + OUT + (np3 * 32 + lq * 4) * 2;
   const int HW = H * W;
 
   // ---- the first window: x pixels [64 q0 - 21, 64 q0 + 107) = the whole ring in two batches; h1 of the first batch here, of the second in the loop
@@ -141,9 +150,9 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restr
 
   for (int q = q0; q < q1; ++q) {
     const long Pn = (long)q * CH - HALO + CH;                       // the 64 pixels this chunk adds: [64 q + 43, 64 q + 107)
-    __syncthreads();                                                // A: the previous chunk's h2 / output tile / oldest ring slots are free
+    S1R_SYNC();                                                // A: the previous chunk's h2 / output tile / oldest ring slots are free
     lstore(Pn);
-    __syncthreads();                                                // B: the new x pixels are visible
+    S1R_SYNC();                                                // B: the new x pixels are visible
     if (q + 1 < q1) gload(Pn + CH);
     conv1(Pn);
 
@@ -178,24 +187,29 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restr
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<u32x2_r*>(h2w + nt * (2 * H2P) + (mt * 16 + lrow) * 16) = s1r_pack4(s1r_gelu4(acc[nt]));
     }
-    __syncthreads();                                                // C: h2 of all groups is complete
+    S1R_SYNC();                                                // C: h2 of all groups is complete
 
-    // conv3 + residual: wave g = output channels 16 g .. 16 g + 15
-#pragma unroll S1R_UNROLL
-    for (int mt = 0; mt < CH / 16; ++mt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accb = acc;       // two chains of four dependent MFMAs
+    // conv3 + residual: 32 output channels x 32 pixels per wave (an h2 fragment feeds two MFMAs: with 16 channels x 64 pixels per wave every
+    // fragment fed one, and the 8 waves read the whole h2 tile eight times instead of four)
 #pragma unroll
-      for (int kc = 0; kc < 4; ++kc) {
-        acc = mma_chunk<bf16>(wf3[kc], *reinterpret_cast<const u32x4*>(h2plane + kc * (4 * H2P) + (mt * 16 + lrow) * 16), acc);
-        accb = mma_chunk<bf16>(wf3[kc + 4], *reinterpret_cast<const u32x4*>(h2plane + (kc + 4) * (4 * H2P) + (mt * 16 + lrow) * 16), accb);
+    for (int mi = 0; mi < 2; ++mi) {
+      const int mt = ph3 * 2 + mi;
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) {
+        const u32x4 hf = *reinterpret_cast<const u32x4*>(h2plane + kc * (4 * H2P) + (mt * 16 + lrow) * 16);
+        acc[0] = mma_chunk<bf16>(wf3[0][kc], hf, acc[0]);
+        acc[1] = mma_chunk<bf16>(wf3[1][kc], hf, acc[1]);
       }
-      acc += accb;
       const int m = m0 + mt * 16 + lrow;
-      const bf16x4 r = __builtin_bit_cast(bf16x4, *reinterpret_cast<const u32x2_r*>(xres + (m & (RING - 1)) * 16));
-      acc += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
-      *reinterpret_cast<u32x2_r*>(outw + (mt * 16 + lrow) * OROW) = s1r_pack4(acc);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const bf16x4 r = __builtin_bit_cast(bf16x4, *reinterpret_cast<const u32x2_r*>(xres + nt * (2 * PITCH) + (m & (RING - 1)) * 16));
+        acc[nt] += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+        *reinterpret_cast<u32x2_r*>(outw + nt * 32 + (mt * 16 + lrow) * OROW) = s1r_pack4(acc[nt]);
+      }
     }
-    __syncthreads();                                                // D: the output tile is complete
+    S1R_SYNC();                                                // D: the output tile is complete
 #pragma unroll
     for (int u0 = 0; u0 < 2; ++u0) {
       const int u = t + 512 * u0, p = u >> 4, c8 = u & 15;
