@@ -519,7 +519,7 @@ int tap(EngineBase* h, const std::string& name, const void* src, size_t bytes, b
 }
 
 // kernel ids reported by the profiler (names in fsvit_kernel_name)
-enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_QKVATTN = 15, KID_STEMCONV1 = 16, KID_GCONV_X2 = 14 };
+enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_QKVATTN = 15, KID_STEMCONV1 = 16, KID_GCONV_X2 = 14, KID_STAGE1RING = 17 };
 
 
 // Runs one launch; in profiling mode brackets it with HIP events on the same stream.
@@ -595,7 +595,7 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
   // stage 1: x += conv3(GELU(conv2_g(GELU(conv1(BN(x))))))
   const int Cg = h->hid1 / h->cfg.group;
   static const bool no_fuse = [] { const char* e = getenv("FSVIT_NO_FUSE"); return e && e[0] == '1'; }();
-  // one LDS-resident kernel per block: the half-image kernel (20 x 20 tokens) or the ring kernel (any map up to 20 wide; FSVIT_STAGE1_RING=1: always)
+  // one LDS-resident kernel per block: the ring kernel (any map up to 20 wide), or under FSVIT_STAGE1_RING=0 the half-image kernel (20 x 20 tokens)
   const bool half1 = K(stage1_fused_supported)(dt, h->C1, h->hid1, h->cfg.group, h->H1) && h->s1.size() && h->s1[0].img;
   const bool ring_ok = K(stage1_ring_supported)(dt, h->C1, h->hid1, h->cfg.group, h->H1) && h->s1.size() && h->s1[0].c2.Kw == 320;
   const bool ring1 = !no_fuse && ring_ok && (!half1 || K(stage1_ring_preferred)());
@@ -605,7 +605,7 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
     if (fuse1) {   // one LDS-resident kernel per block, ping-pong between x1 and x1b
       const double fl = 2.0 * Bc * h->H1 * h->H1 * ((double)h->hid1 * h->C1 + (double)h->hid1 * 9 * Cg + (double)h->C1 * h->hid1);
       if (ring1)
-        RC_TRY(timed(h, st, "stage1.block", KID_STAGE1, fl,
+        RC_TRY(timed(h, st, "stage1.block", KID_STAGE1RING, fl,
                      [&]() { return K(launch_stage1_ring)(x1, x1b, b.c1.w, b.c1.bias, b.c2.w, b.c3.w, Bc, h->H1, h->H1, st); }));
       else
         RC_TRY(timed(h, st, "stage1.block", KID_STAGE1, fl,
@@ -828,7 +828,7 @@ extern "C" int fsvit_stage1_block(const void* x, void* y, const void* w1, const 
   void* img = nullptr;
   HIP_TRY(hipMalloc(&img, K(stage1_image_bytes)()));
   int rc;
-  if (K(stage1_ring_preferred)()) rc = K(launch_stage1_ring)(x, y, w1, b1, w2, w3, B, 20, 20, st);      // FSVIT_STAGE1_RING=1
+  if (K(stage1_ring_preferred)()) rc = K(launch_stage1_ring)(x, y, w1, b1, w2, w3, B, 20, 20, st);      // (FSVIT_STAGE1_RING=0: the half-image kernel)
   else {
     rc = K(launch_stage1_pack)(w1, w2, w3, img, st);
     if (rc == 0) rc = K(launch_stage1_block)(x, y, img, b1, B, st);
@@ -1026,15 +1026,15 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
   static const char* f32n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
                                "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<float,128,128,2,2,2>",
-                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel"};
+                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel"};
   static const char* bf16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
                                 "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<__bf16,128,128,2,2,2>",
-                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel"};
+                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel"};
   static const char* f16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<_Float16,128,64,2,2,3>", "conv_gemm_v2_kernel<_Float16,128,32,4,1,3>",
                                "im2col27_kernel<_Float16>", "maxpool2_pos_kernel<_Float16>", "attention_v2_kernel<_Float16,...>", "pool_affine_kernel<_Float16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<_Float16,128,128,2,2,2>",
-                               "patchify_kernel<_Float16>", "layernorm_kernel<_Float16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel"};
+                               "patchify_kernel<_Float16>", "layernorm_kernel<_Float16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel"};
   static const char* x2n[] = {"gemm256_x2_kernel", "conv_gemm_v2_kernel<f32x2l,128,64,2,2,3>", "conv_gemm_v2_kernel<f32x2l,128,32,4,1,3>", "", "", "", "", "", "", "conv_gemm_v2_kernel<f32x2l,128,128,2,2,2>"};
-  if (kernel_id < 0 || kernel_id > 16) return "?";
+  if (kernel_id < 0 || kernel_id > 17) return "?";
   if (is_x2(dtype)) return kernel_id == 14 ? "gconv3x3_x2_kernel" : (kernel_id == 0 || kernel_id == 1 || kernel_id == 2 || kernel_id == 9) ? x2n[kernel_id] : f32n[kernel_id];
   return dtype == FSVIT_F32 ? f32n[kernel_id] : dtype == FSVIT_F16 ? f16n[kernel_id] : bf16n[kernel_id];
 }

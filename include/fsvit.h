@@ -169,8 +169,8 @@ int fsvit_qkv_attention(const void* x_dev, const void* wqkv_dev, int kw, const f
 int fsvit_stage1_block(const void* x_dev, void* y_dev, const void* w1_dev, const float* b1_dev, const void* w2_dev,
                        const void* w3_dev, int B, void* stream);
 /* The same block for any square token map of 4 .. 20 a side (stage1_ring.hip: wave = channel group, weights in registers, x and the first hidden map in
- * pixel rings - no half-image geometry): x, y NHWC [B,H,W,128], dtype FSVIT_BF16 / FSVIT_F16; weights as above.  The engines use it for image sizes whose
- * stage-1 map is not 20 x 20 (and for 20 x 20 under FSVIT_STAGE1_RING=1). */
+ * pixel rings - no half-image geometry): x, y NHWC [B,H,W,128], dtype FSVIT_BF16 / FSVIT_F16; weights as above.  This is the kernel the engines run
+ * (FSVIT_STAGE1_RING=0 keeps the half-image kernel of fsvit_stage1_block for 20 x 20 maps). */
 int fsvit_stage1_block_hw(const void* x_dev, void* y_dev, const void* w1_dev, const float* b1_dev, const void* w2_dev, const void* w3_dev, int B, int H, int W,
                           int dtype, void* stream);
 /* Fused Mlp of a Visformer attention block (visformer.py:146-150 with spatial_conv=False, + the residual of :262):
