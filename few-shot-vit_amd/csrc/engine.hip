@@ -827,12 +827,8 @@ extern "C" int fsvit_stage1_block(const void* x, void* y, const void* w1, const 
   hipStream_t st = (hipStream_t)stream;
   void* img = nullptr;
   HIP_TRY(hipMalloc(&img, K(stage1_image_bytes)()));
-  int rc;
-  if (K(stage1_ring_preferred)()) rc = K(launch_stage1_ring)(x, y, w1, b1, w2, w3, B, 20, 20, st);      // (FSVIT_STAGE1_RING=0: the half-image kernel)
-  else {
-    rc = K(launch_stage1_pack)(w1, w2, w3, img, st);
-    if (rc == 0) rc = K(launch_stage1_block)(x, y, img, b1, B, st);
-  }
+  int rc = K(launch_stage1_pack)(w1, w2, w3, img, st);      // (always the half-image kernel of stage1_fused.hip; the ring kernel is fsvit_stage1_block_hw)
+  if (rc == 0) rc = K(launch_stage1_block)(x, y, img, b1, B, st);
   (void)hipStreamSynchronize(st);
   (void)hipFree(img);
   if (rc != 0) return hipfail((hipError_t)rc, "fsvit_stage1_block");

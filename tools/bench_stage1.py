@@ -1,5 +1,6 @@
-"""Times the fused stage-1 block (fsvit_stage1_block through ops.stage1_block is synchronous: this calls the launcher through the engine op in a loop
-with HIP events).  python tools/bench_stage1.py [images [variant.so]]      FSVIT_STAGE1_RING=1 selects the ring kernel."""
+"""Times the fused stage-1 block operators: fsvit_stage1_block_hw (stage1_ring.hip, the engines' kernel) or, with FSVIT_STAGE1_RING=0,
+fsvit_stage1_block (stage1_fused.hip, the half-image kernel; the op packs its weight image and synchronises per call).
+python tools/bench_stage1.py [images [variant.so]]"""
 import math
 import sys
 import ctypes as C
@@ -25,15 +26,25 @@ import os
 if len(sys.argv) > 2:                    # a variant library (tools/build_variant.sh)
     _lib.LIB_PATH = os.path.abspath(sys.argv[2])
 lib = _lib.load()
+RING = os.environ.get('FSVIT_STAGE1_RING', '1') != '0'
+
+
+def call():
+    if RING:
+        _lib.check(lib.fsvit_stage1_block_hw(_ptr(x), _ptr(y), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(w3), B, 20, 20, _lib.BF16, st))
+    else:
+        _lib.check(lib.fsvit_stage1_block(_ptr(x), _ptr(y), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(w3), B, st))
+
 st = _stream_ptr(x.device)
 for _ in range(2):
-    _lib.check(lib.fsvit_stage1_block(_ptr(x), _ptr(y), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(w3), B, st))
+    call()
 torch.cuda.synchronize()
 import time
 t0 = time.perf_counter()
 N = 10
 for _ in range(N):
-    _lib.check(lib.fsvit_stage1_block(_ptr(x), _ptr(y), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(w3), B, st))      # (the op synchronises the stream itself)
+    call()
+torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / N
 fl = 2.0 * B * 400 * (256 * 128 + 256 * 9 * 32 + 128 * 256)
-print(f'stage1 block, {B} images: {dt * 1e3:.3f} ms per call (incl. the weight-image pack + sync of the op), {fl / dt / 1e12:.1f} TFLOP/s')
+print(f'stage1 block ({"ring" if RING else "half-image"} kernel), {B} images: {dt * 1e3:.3f} ms per call, {fl / dt / 1e12:.1f} TFLOP/s')
