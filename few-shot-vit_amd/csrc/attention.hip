@@ -149,7 +149,8 @@ __global__ __launch_bounds__(NW * 64) void attention_v2_kernel(const T* __restri
   constexpr int EPC = Elem<T>::kPerChunk;
   constexpr int HDP = NDT * 16;
   constexpr int SKP = NKT * 16;
-  constexpr int QS = HDP * ES + 16;            // K row stride (bytes): odd multiple of 16 -> conflict-free b128 reads
+  constexpr int QS = HDP * ES + ((32 - (HDP * ES) % 64 + 64) % 64);      // K row stride (bytes), 32 mod 64: the conflict-free strides of ds_read_b128's four
+                                                                         // mixed 16-lane groups (an odd multiple of 16, as before, reads 2-way; qkv_attn.hip)
   constexpr int VS = SKP * ES + 16;            // V^T row stride
   constexpr int NKC = (HDP * ES + 63) / 64;    // 64-byte chunks along the head dim; a head dim of 48 bf16 (1.5 chunks) zero-fills the half chunk in registers
   constexpr bool HALF_TAIL = (HDP * ES) % 64 != 0;
@@ -296,7 +297,8 @@ __global__ __launch_bounds__(NW * 64) void attention_v2_kernel(const T* __restri
 template <typename T, int NKT, int NDT, int NW>
 static int launch_v2(const void* qkv, void* ctx, int B, int S, int heads, float scale, hipStream_t s) {
   constexpr int ES = sizeof(T);
-  const size_t lds = (size_t)NKT * 16 * (NDT * 16 * ES + 16) + (size_t)NDT * 16 * (NKT * 16 * ES + 16);
+  constexpr int QSB = NDT * 16 * ES + ((32 - (NDT * 16 * ES) % 64 + 64) % 64);      // the kernel's K row stride
+  const size_t lds = (size_t)NKT * 16 * QSB + (size_t)NDT * 16 * (NKT * 16 * ES + 16);
   auto kern = attention_v2_kernel<T, NKT, NDT, NW>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -38,7 +38,9 @@ constexpr int TOKK = 112, NKT = TOKK / 16;             // key rows held / key ti
 constexpr int FRAGS = NCT * NKS, SLOT = FRAGS * 1024;  // one (head, part) weight image: 24 KB
 constexpr int NST = 4, NIMG = HEADS * 3;
 constexpr int PPW = FRAGS / NW;                        // LDS-DMA pieces per wave and slot image
-constexpr int KS = 128 + 16;                           // K row stride (bytes): 64 k positions (48 real) + pad, odd multiple of 16
+constexpr int KS = 128 + 32;                           // K row stride (bytes): 64 k positions (48 real) + pad.  32 mod 64: a ds_read_b128 is serviced in four
+                                                       // 16-lane groups mixing the rows {0-3, 12-15} of one lq with {4-11} of the next (MI355X_MICROARCH.md, LDS):
+                                                       // strides of 32 mod 64 bytes are the conflict-free ones, an odd multiple of 16 (144 before) reads 2-way
 constexpr int VS = TOK * 2 + 16;                       // V^T row stride
 constexpr int OFF_K = NST * SLOT, OFF_V = OFF_K + IMGS * TOKK * KS, OFF_B = OFF_V + IMGS * HDP * VS;
 static_assert(OFF_B + 3 * HEADS * HDP * 4 <= 160 * 1024, "LDS budget");
