@@ -373,13 +373,14 @@ int launch_attention_bwd(const void* qkv, const void* dctx, void* dqkv, int B, i
       else if (ndt == 4) rc = launch_bwd_mfma<2, 4, 2>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
       else if (ndt == 6) rc = launch_bwd_mfma<2, 6, 2>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
       else if (ndt == 8) rc = launch_bwd_mfma<2, 8, 2>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
-    } else if (S <= 128) {
-      if (ndt == 2) rc = launch_bwd_mfma<8, 2, 8>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
-      else if (ndt == 4) rc = launch_bwd_mfma<8, 4, 8>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
-      else if (ndt == 6) rc = launch_bwd_mfma<8, 6, 8>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
+    } else if (S <= 128) {                              // (4 waves: with 8 the 512-thread bound left 256 registers per wave and the kernel spilled 228 ..
+                                                        //  928 bytes per lane; one wave per SIMD takes accumulators in AGPRs: 311 -> 249 us at S = 100)
+      if (ndt == 2) rc = launch_bwd_mfma<8, 2, 4>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
+      else if (ndt == 4) rc = launch_bwd_mfma<8, 4, 4>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
+      else if (ndt == 6) rc = launch_bwd_mfma<8, 6, 4>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
     } else {                                            // ViT: 196 patches + cls
-      if (ndt == 2) rc = launch_bwd_mfma<14, 2, 8>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
-      else if (ndt == 4) rc = launch_bwd_mfma<14, 4, 8>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
+      if (ndt == 2) rc = launch_bwd_mfma<14, 2, 4>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
+      else if (ndt == 4) rc = launch_bwd_mfma<14, 4, 4>(qkv, dctx, dqkv, B, S, heads, scale, s, &ran);
     }
     if (rc || ran) return rc;
   }
