@@ -330,7 +330,7 @@ int launch_gconv3x3(const void* x, const void* w_packed, int Kw, void* y, int B,
 // ---- the same grouped conv in the two-limb numerics modes (`bf16x2` / `f16x2`, conv_gemm_v2.hip): fp32 activations in and out, weights as (hi, lo)
 // limb words [256][Kw].  On conv_gemm_v2's 128 x 32 two-limb tile this layer was the slowest of the mode (7.2 ms per block at 12800 images, 105
 // TFLOP/s: 16 MFMAs per staged K slice and wave).  Wave g = group g again: its 36 weight fragments (9 taps x 2 k-chunks of 16 channels x 2 channel
-// tiles) stay in 144 VGPRs.  The pixels live in a RING of 128 slots per 4-channel plane ([64 planes][128 + 1 pixels][16 B] = 129 KB of LDS, slot =
+// tiles) stay in 144 VGPRs.  The pixels live in a RING of 128 slots per 4-channel plane ([64 planes][128 pixels][16 B] = 128 KB of LDS, slot =
 // linear pixel index & 127), split into limb words ONCE while they are staged: consecutive 64-pixel chunks share 42 pixels of their windows, so a
 // chunk brings in only its 64 new pixels (8 x 16 B per thread in flight under the previous chunk's MFMAs - with the whole 106-pixel window in
 // registers the kernel spilled and the prefetch serialised).  A fragment read delivers 8 k-slots = 4 channels x (lo, hi), its half-swapped copy feeds
@@ -340,8 +340,8 @@ __global__ __launch_bounds__(512, 1) void gconv3x3_x2_kernel(const float* __rest
   using namespace wg3;
   constexpr int C = 256, NPL = C / 4, RING = 128, HALO = 21;              // 64 planes of 4 channels; the window of a chunk = its 64 pixels +- 21
   constexpr int NPX = CH * NPL / 512;                                      // 8: 16-byte units per thread and batch of 64 pixels
-  constexpr int PLANE = (RING + 1) * 16;                                   // plane pitch: one slot of padding - the staging stores walk the planes (64 lanes = 64
-                                                                           // planes of one pixel) and a 2048-byte pitch put all of them on one bank group
+  constexpr int PLANE = RING * 16;                                         // plane pitch 0 mod 256 B: ds_read_b128's 16-lane groups mix the rows {0-3, 12-15} of one
+                                                                           // plane (lq) with {4-11} of the next - one pad slot per plane read 2-way
   static_assert(CH == 64 && CH + 2 * HALO + (CH - 2 * HALO) <= RING, "ring geometry");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];    // [64 planes][RING][16 B] + a zero slot
   unsigned char* const ZERO = smem + NPL * PLANE;
@@ -368,8 +368,8 @@ __global__ __launch_bounds__(512, 1) void gconv3x3_x2_kernel(const float* __rest
     pxok = 0;
 #pragma unroll
     for (int u0 = 0; u0 < NPX; ++u0) {
-      const int u = t + 512 * u0, p = u / NPL, c4 = u % NPL;
-      const long m = P0 + p;
+      const int u = t + 512 * u0, p = (u & 7) | ((u >> 9) << 3), c4 = (u >> 3) & (NPL - 1);      // 8 consecutive lanes = 8 consecutive pixels of one plane
+      const long m = P0 + p;                                                                       // (their 16-byte stores fill 128 contiguous LDS bytes)
       const bool ok = m >= 0 && m < M;
       px[u0] = *reinterpret_cast<const u32x4*>(x + (size_t)(ok ? m : 0) * C + c4 * 4);
       pxok |= ok ? (1u << u0) : 0u;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(512, 1) void gconv3x3_x2_kernel(const float* __rest
   auto lstore = [&](long P0) {
 #pragma unroll
     for (int u0 = 0; u0 < NPX; ++u0) {
-      const int u = t + 512 * u0, p = u / NPL, c4 = u % NPL;
+      const int u = t + 512 * u0, p = (u & 7) | ((u >> 9) << 3), c4 = (u >> 3) & (NPL - 1);
       u32x4 xs, xr;
       x2_split(px[u0], xs, xr);
       if (!((pxok >> u0) & 1u)) xs = u32x4{0u, 0u, 0u, 0u};
@@ -460,7 +460,7 @@ int launch_gconv3x3_x2(const ConvGemmParams& p, hipStream_t s) {
   int wgs = n_chunks < 256 ? n_chunks : 256;              // one 8-wave workgroup per CU (128 KB of LDS, 2 waves per SIMD with 256 VGPRs)
   const int cpw = (n_chunks + wgs - 1) / wgs;
   wgs = (n_chunks + cpw - 1) / cpw;
-  const int lds = 64 * 129 * 16 + 16;                  // the pixel ring (planes padded by one slot) + the zero slot
+  const int lds = 64 * 128 * 16 + 16;                  // the pixel ring + the zero slot
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)gconv3x3_x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
