@@ -913,6 +913,28 @@ extern "C" int fsvit_proj_mlp_rows(const void* x, void* y, const void* ctx, cons
   return 0;
 }
 
+// The ViT / DeiT block tail as one operator (deit.py:69-72): x1 = x + bp + wp ctx; y = x1 + b2 + W2 GELU(W1 LN(x1) + b1), LN without affine
+// (fold gamma / beta into w1 / b1: W1 diag(gamma), b1 + W1 beta - what the engine's packer does).  Packs the weights on every call.
+extern "C" int fsvit_vit_block_tail(const void* x, void* y, const void* ctx, const void* wp, int kpw, int KC, const float* bp, const void* w1, int k1w,
+                                    const float* b1, const void* w2, int k2w, const float* b2, int M, int C, int hid, float eps, void* stream) {
+  const int kdt = FSVIT_BF16;
+  if (!x || !y || !ctx || !wp || !bp || !w1 || !b1 || !w2 || !b2) return fail(FSVIT_ERR_ARG, "null argument");
+  if (!K(mlp_rows_ln_supported)(1, C, hid, KC)) return fail(FSVIT_ERR_ARG, "fsvit_vit_block_tail: only C = 384 / hidden = 1536 / KC = 384 (bf16) is built");
+  if (k1w < C || k2w < hid || kpw < KC) return fail(FSVIT_ERR_ARG, "weight rows shorter than K");
+  hipStream_t st = (hipStream_t)stream;
+  void *img = nullptr, *b1i = nullptr;
+  HIP_TRY(hipMalloc(&img, K(mlp_rows_image_bytes)(C, hid, KC)));
+  hipError_t e = hipMalloc(&b1i, (size_t)hid * 4);
+  if (e != hipSuccess) { (void)hipFree(img); return hipfail(e, "hipMalloc"); }
+  int rc = K(launch_mlp_pack)(w1, k1w, b1, w2, k2w, wp, kpw, KC, img, (float*)b1i, C, hid, st);
+  if (rc == 0) rc = K(launch_mlp_rows_ln)(x, y, img, (const float*)b1i, bp, b2, ctx, KC, M, C, hid, eps, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(img);
+  (void)hipFree(b1i);
+  if (rc != 0) return hipfail((hipError_t)rc, "fsvit_vit_block_tail");
+  return 0;
+}
+
 // ---- distillation head (sun_meta_training/offline.py, models/token_label.py, models/classifier.py)
 extern "C" int fsvit_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int N, int K, void* stream) {
   const int kdt = FSVIT_BF16;
@@ -1085,7 +1107,11 @@ extern "C" int fsvit_encoder_profile_end(void* hv, fsvit_prof_rec* out, int max_
 // ==================================================================================== ViT / DeiT encoder
 // test_phase/models/deit.py:139-218.  LayerNorm gains/shifts are folded into the following Linear
 // (W' = W diag(gamma), b' = b + W beta); the normalisation itself is a one-wave-per-token kernel.
-struct VitBlock { Layer qkv, proj, fc1, fc2; };
+struct VitBlock {
+  Layer qkv, proj, fc1, fc2;
+  void* mlp_img = nullptr;      // mlp_rows.hip: fragment-major image of proj | fc1 | fc2 (null: GEMM + LayerNorm launches)
+  float* mlp_b1 = nullptr;
+};
 
 struct fsvit_vit : EngineBase {
   fsvit_vit_cfg cfg;
@@ -1170,6 +1196,19 @@ int build_vit(fsvit_vit* h, const SD& sd) {
     RC_TRY(pack_layer(h, &h->blocks[i].proj, wp, D, heads * hd, 1, 1, 1, nullptr, nullptr, vbp, true, nullptr, 0, &colmap, heads * hdp));
     RC_TRY(pack_layer(h, &h->blocks[i].fc1, w1, h->hid, D, 1, 1, 1, nullptr, &s2, add_vec(prenorm_bias(w1, h->hid, D, t2), bf1, h->hid), true, nullptr, 0, nullptr, 0));
     RC_TRY(pack_layer(h, &h->blocks[i].fc2, w2, D, h->hid, 1, 1, 1, nullptr, nullptr, vb2, true, nullptr, 0, nullptr, 0));
+    const int kdt = h->dtype;
+    if (K(mlp_rows_ln_supported)(kd(kdt), D, h->hid, heads * hdp)) {      // proj + residual + norm2 + Mlp in one row-wise kernel
+      VitBlock& b = h->blocks[i];
+      void *img = nullptr, *b1i = nullptr;
+      HIP_TRY(hipMalloc(&img, K(mlp_rows_image_bytes)(D, h->hid, heads * hdp)));
+      h->allocs.push_back(img);
+      HIP_TRY(hipMalloc(&b1i, (size_t)h->hid * 4));
+      h->allocs.push_back(b1i);
+      RC_TRY(K(launch_mlp_pack)(b.fc1.w, b.fc1.Kw, b.fc1.bias, b.fc2.w, b.fc2.Kw, b.proj.w, b.proj.Kw, heads * hdp, img, (float*)b1i, D, h->hid, nullptr));
+      HIP_TRY(hipDeviceSynchronize());
+      b.mlp_img = img;
+      b.mlp_b1 = (float*)b1i;
+    }
   }
   return 0;
 }
@@ -1215,6 +1254,13 @@ int vit_forward_chunk(fsvit_vit* h, const float* x, int Bc, float* feat, unsigne
     RC_TRY(run_gemm(h, st, "blocks.attn.qkv", b.qkv, conv_params(b.qkv, xn, qkv, Bc, S, 1, D, D, 1, 1, 1, 0, 3 * heads * hdp, ACT_NONE, nullptr, 0, nullptr), 3.0 * D, D));
     RC_TRY(timed(h, st, "blocks.attn.core", KID_ATTN, 4.0 * Bc * heads * (double)S * S * h->hd,
                  [&]() { return K(launch_attention)(qkv, ctx, Bc, S, heads, hdp, scale, dt, st); }));
+    if (b.mlp_img) {
+      RC_TRY(timed(h, st, "blocks.proj+norm2+mlp", KID_MLPROWS, 2.0 * M * ((double)heads * h->hd * D + 2.0 * D * h->hid), [&]() {
+        return K(launch_mlp_rows_ln)(tokens, tokens, b.mlp_img, b.mlp_b1, b.proj.bias, b.fc2.bias, ctx, heads * hdp, M, D, h->hid, h->cfg.ln_eps, st);
+      }));
+      RC_TRY(tap(h, "blocks." + std::to_string(i), tokens, (size_t)M * D * es, first, st));
+      continue;
+    }
     RC_TRY(run_gemm(h, st, "blocks.attn.proj", b.proj, conv_params(b.proj, ctx, tokens, Bc, S, 1, heads * hdp, heads * hdp, 1, 1, 1, 0, D, ACT_NONE, tokens, 0, nullptr), D, D));
     RC_TRY(timed(h, st, "blocks.norm2", KID_LN, 0.0, [&]() { return K(launch_layernorm)(tokens, xn, M, D, h->cfg.ln_eps, dt, st); }));
     RC_TRY(run_gemm(h, st, "blocks.mlp.fc1", b.fc1, conv_params(b.fc1, xn, hid, Bc, S, 1, D, D, 1, 1, 1, 0, h->hid, ACT_GELU, nullptr, 0, nullptr), h->hid, D));

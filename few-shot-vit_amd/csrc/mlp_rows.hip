@@ -53,33 +53,53 @@ typedef __attribute__((address_space(3))) void* lptrm_t;
 namespace {
 
 constexpr int MR_NST = 4;                       // ring slots
-constexpr int MR_SLOT = 32768;                  // 32 fragments of 1 KiB
+// fragments of 1 KiB per ring slot: 32 (a whole chunk at C = 256, its W1 / W2 half at C = 512) or 24 (C = 384: W1 / W2 half of a chunk)
+constexpr int mr_slot_frags(int C) { return C == 384 ? 24 : 32; }
 constexpr int MR_NW = 4;                        // waves per workgroup (one per SIMD)
 constexpr int MR_FD = 6;                        // weight fragments read ahead of the MFMAs that consume them
 
-// This wave's share of one ring slot: 8 consecutive 1 KiB LDS-DMAs, source = sbase + voff + i * 1024, destination = lds + i * 1024.
+// This wave's share of one ring slot: PW = 8 (6) consecutive 1 KiB LDS-DMAs, source = sbase + voff + i * 1024, destination = lds + i * 1024.
 // The immediate offset of global_load_lds moves the LDS destination together with the global source (tools/probes/
 // ldsdma_offset.hip, measured on gfx950), so a linear copy needs no address arithmetic; the 13-bit offset field covers 4 pieces.
-__device__ __forceinline__ void mr_dma8(unsigned voff, const void* sbase, unsigned lds) {
+template <int PW> __device__ __forceinline__ void mr_dma(unsigned voff, const void* sbase, unsigned lds) {
+  static_assert(PW == 8 || PW == 6, "pieces per wave and slot");
   unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %4\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %3\n\t"
-      "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
-      "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
-      "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
-      "s_mov_b32 m0, %5\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %2, %3\n\t"
-      "global_load_lds_dwordx4 %2, %3 offset:1024\n\t"
-      "global_load_lds_dwordx4 %2, %3 offset:2048\n\t"
-      "global_load_lds_dwordx4 %2, %3 offset:3072\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "v"(voff + 4096u), "s"(sbase), "s"(lds), "s"(lds + 4096u)
-      : "memory");
+  if constexpr (PW == 8)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %3\n\t"
+        "global_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+        "global_load_lds_dwordx4 %2, %3 offset:2048\n\t"
+        "global_load_lds_dwordx4 %2, %3 offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "v"(voff + 4096u), "s"(sbase), "s"(lds), "s"(lds + 4096u)
+        : "memory");
+  else
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %3 offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, %3 offset:3072\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %3\n\t"
+        "global_load_lds_dwordx4 %2, %3 offset:1024\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "v"(voff + 4096u), "s"(sbase), "s"(lds), "s"(lds + 4096u)
+        : "memory");
 }
 // One 1 KiB piece.  A VMEM instruction of 64 x 16 bytes keeps the wave's issue stage for ~64 cycles; back to back they queue behind
 // each other and hold up the MFMAs that follow, so inside the chunk loop the refill goes out one piece at a time, pieces >= 4 MFMAs apart.
@@ -137,6 +157,9 @@ __device__ __forceinline__ void mfma32_a(u32x4 a, u32x4 b, f32x16& c) {
 __device__ __forceinline__ void mfma32_v_z(u32x4 a, u32x4 b, f32x16& d) {
   asm volatile(FSVIT_MFMA_32x32x16 " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
 }
+__device__ __forceinline__ void mfma32_a_z(u32x4 a, u32x4 b, f32x16& d) {
+  asm volatile(FSVIT_MFMA_32x32x16 " %0, %1, %2, 0" : "=a"(d) : "v"(a), "v"(b));
+}
 // accumulator := 0 without ever being a VGPR value (a C++ `= 0` makes the loop-carried accumulators VGPR-class and every asm use
 // a 16-register round trip through v_accvgpr_write / read)
 __device__ __forceinline__ void mfma32_a_zero(f32x16& c) {
@@ -150,26 +173,39 @@ __device__ __forceinline__ void mfma32_a_zero(f32x16& c) {
 //   x1 = x + Wp ctx  (ctx = attention output [M][KC], head dims zero-padded; Wp's fragments = the first KC/16 * C/32 fragments of the image)
 // accumulated in the output AGPRs, rounded to bf16 into the x registers (exactly what the separate proj launch stored), and the Mlp
 // continues from there: proj is HBM-bound as a GEMM of its own (K = 384 / 576, N = C, + residual read and write).
-template <int C, int HID, int RB, int KC>
+//
+// LN (the ViT / DeiT block, deit.py:69-72: x = x + proj(attn); x = x + mlp(norm2(x)), C = 384 / hidden = 1536 / KC = 384): the proj has a
+// bias (bp), and a LayerNorm sits between the residual stream and fc1.  It is row-local, and a token's row lives in the two lanes
+// (r, kh = 0 / 1) of the x registers: x1 = bf16(x + Wp ctx + bp) is moved into the output accumulators as the residual by two MFMAs per
+// channel tile against an identity fragment (exact: 1.0 x bf16 into fp32), then normalised in place - two in-lane passes and one lane
+// exchange each for mean and variance - so GEMM1 reads (x1 - mean) rstd while gamma / beta are already folded into W1 / b1 by the
+// engine's packer.  Replaces the proj GEMM, the LayerNorm launch and both Mlp GEMMs (with the 4C hidden tensor's round trip).
+template <int C, int HID, int RB, int KC, bool LN>
 __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
                                                           const float* __restrict__ b1img, const float* __restrict__ b2, const bf16* __restrict__ CTX,
-                                                          const int M, const int n_tiles) {
+                                                          const float* __restrict__ bproj, const float ln_eps, const int M, const int n_tiles) {
   constexpr int NCT = C / 32, NKS = C / 16, NCH = HID / 32;
+  constexpr int SLF = mr_slot_frags(C), MR_SLOT = SLF * 1024;      // ring slot: SLF fragments
+  constexpr int PW = SLF / MR_NW, WSH = PW * 1024;                 // LDS-DMA pieces per wave and slot; a wave's share of a slot image
+  constexpr int SL = RB * NKS;                                     // MFMA slots per group (GEMM1 or GEMM2 of one chunk): 32, or 24 at C = 384
   constexpr int PKS = KC / 16, PFR = PKS * NCT;          // proj: k-steps of 16 ctx channels, fragments in (k-step outer, c-tile inner) order
-  constexpr int PSLOTS = (PFR + 31) / 32;                // ring slots of 32 fragments, the last one padded (its tail is never read)
+  constexpr int PSLOTS = (PFR + SLF - 1) / SLF;          // ring slots of SLF fragments, the last one padded (its tail is never read)
   static_assert(KC % 16 == 0, "whole k-steps");
-  constexpr int PPC = 2 * NKS / 32;                      // ring slots per hidden chunk: 1 (W1 | W2) or 2 (W1, W2)
+  constexpr int PPC = 2 * NKS / SLF;                     // ring slots per hidden chunk: 1 (W1 | W2) or 2 (W1, W2)
   constexpr int BM = MR_NW * 32 * RB;                    // token rows per workgroup tile
   constexpr int FD = MR_FD;
-  static_assert(RB * NKS == 32 && (PPC == 1 || PPC == 2), "register budget: 128 x + 256 y VGPRs");
+  static_assert((SL == 32 || (SL == 24 && RB == 1)) && 2 * NKS == PPC * SLF && (PPC == 1 || PPC == 2), "register budget: <= 128 x + 256 y VGPRs");
+  static_assert(!LN || (KC > 0 && RB == 1), "the LayerNorm variant continues from the proj prologue");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* const b1tab = reinterpret_cast<float*>(smem + MR_NST * MR_SLOT);
+  float* const bptab = b1tab + HID;                      // LN: proj bias, fc2 bias (channel order)
+  float* const b2tab = bptab + C;
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int r = lane & 31, kh = lane >> 5;
   const unsigned lds0 = (unsigned)(size_t)(lptrm_t)smem;
-  const unsigned voff = (unsigned)(wave * 8192 + lane * 16);           // this lane's 16 bytes inside a slot image
+  const unsigned voff = (unsigned)(wave * WSH + lane * 16);            // this lane's 16 bytes inside a slot image
   if ((int)blockIdx.x >= n_tiles) return;
 #ifdef MR_PAD     // code-placement screen (tools/screen_mlp_rows.sh): shifts every later instruction by 4 * MR_PAD bytes
   asm volatile(".rept %0\n\ts_nop 0\n\t.endr" :: "n"(MR_PAD));
@@ -177,6 +213,8 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
 
   // bias table of conv1 (already in accumulator order) -> LDS
   for (int i = t; i < HID; i += MR_NW * 64) b1tab[i] = b1img[i];
+  if constexpr (LN)
+    for (int i = t; i < C; i += MR_NW * 64) { bptab[i] = bproj[i]; b2tab[i] = b2[i]; }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // table written before the first ring barrier publishes it
 
   // ring: slot image n (the weight image is a sequence of NCH * PPC slot images, repeated for every tile) is issued right after
@@ -187,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
   // code placement.  Barrier n also certifies that every wave has finished reading the slot refilled next.
   int issue_img = 0, issue_slot = 0;
   auto issue = [&]() {
-    mr_dma8(voff, wimg + (size_t)issue_img * MR_SLOT, lds0 + issue_slot * MR_SLOT + wave * 8192);
+    mr_dma<PW>(voff, wimg + (size_t)issue_img * MR_SLOT, lds0 + issue_slot * MR_SLOT + wave * WSH);
     issue_img = issue_img == PSLOTS + NCH * PPC - 1 ? 0 : issue_img + 1;
     issue_slot = issue_slot == MR_NST - 1 ? 0 : issue_slot + 1;
   };
@@ -196,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
   int slot = 0;
   bool first = true;
   auto ring_wait = [&]() {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // all but the newest slot image of this wave have landed: the image read after the NEXT barrier
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory");     // all but the newest slot image of this wave have landed: the image read after the NEXT barrier
 #if !(defined(MR_DIAG) && (MR_DIAG & 2))
     mr_bar();
 #endif
@@ -207,8 +245,8 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
   };
   // the same refill piece by piece (0..7 in order), each placed between MFMAs of the interval that follows ring_wait()
   auto issue1 = [&](int piece) {
-    mr_dma1(voff + piece * 1024, wimg + (size_t)issue_img * MR_SLOT, lds0 + issue_slot * MR_SLOT + wave * 8192 + piece * 1024);
-    if (piece == 7) {
+    mr_dma1(voff + piece * 1024, wimg + (size_t)issue_img * MR_SLOT, lds0 + issue_slot * MR_SLOT + wave * WSH + piece * 1024);
+    if (piece == PW - 1) {
       issue_img = issue_img == PSLOTS + NCH * PPC - 1 ? 0 : issue_img + 1;
       issue_slot = issue_slot == MR_NST - 1 ? 0 : issue_slot + 1;
     }
@@ -218,6 +256,15 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
 #ifdef MR_CLK
   const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_w0 = wall_clock64();
 #endif
+  u32x4 idf[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};      // LN: identity fragments of the two k-steps of a channel tile
+  if constexpr (LN) {
+    const int ch = 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        idf[q][e] = mr_pk2(ch == 16 * kh + 8 * q + 2 * e ? 1.0f : 0.0f, ch == 16 * kh + 8 * q + 2 * e + 1 ? 1.0f : 0.0f);
+  }
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     // ---- this wave's 32 RB token rows -> registers (tail rows re-read the last valid row; their results are never stored)
     bool mok[RB];
@@ -241,6 +288,19 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
       mr_wait_loads<RB * NKS>(&xr[0][0]);
     };
     f32x16 yacc[RB][NCT];
+    // wait states MFMA -> v_accvgpr_read, accumulators threaded through
+    auto yacc_settle = [&]() {
+      f32x16* yf = &yacc[0][0];
+      static_assert(RB * NCT == 16 || RB * NCT == 12, "operand list");
+      if constexpr (RB * NCT == 16)
+        asm volatile("s_nop 15\n\ts_nop 3"
+                     : "+a"(yf[0]), "+a"(yf[1]), "+a"(yf[2]), "+a"(yf[3]), "+a"(yf[4]), "+a"(yf[5]), "+a"(yf[6]), "+a"(yf[7]),
+                       "+a"(yf[8]), "+a"(yf[9]), "+a"(yf[10]), "+a"(yf[11]), "+a"(yf[12]), "+a"(yf[13]), "+a"(yf[14]), "+a"(yf[15]));
+      else
+        asm volatile("s_nop 15\n\ts_nop 3"
+                     : "+a"(yf[0]), "+a"(yf[1]), "+a"(yf[2]), "+a"(yf[3]), "+a"(yf[4]), "+a"(yf[5]), "+a"(yf[6]), "+a"(yf[7]),
+                       "+a"(yf[8]), "+a"(yf[9]), "+a"(yf[10]), "+a"(yf[11]));
+    };
     if constexpr (KC > 0) {
       u32x4 cr[RB][PKS];                                   // ctx rows as B operands: token r, channels 16 ks + 8 kh .. +7
 #pragma unroll
@@ -262,26 +322,20 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
         for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + i * 1024);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int fi = 0; fi < 32; ++fi) {
-          const int g = ps * 32 + fi, ks = g / NCT, ct = g % NCT;
+        for (int fi = 0; fi < SLF; ++fi) {
+          const int g = ps * SLF + fi, ks = g / NCT, ct = g % NCT;
           if (g < PFR) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) mfma32_a(fr[fi % FD], cr[rb][ks < PKS ? ks : 0], yacc[rb][ct]);
           }
-          if (fi + FD < 32 && g + FD < PFR) fr[fi % FD] = *reinterpret_cast<const u32x4*>(sp + (fi + FD) * 1024);
+          if (fi + FD < SLF && g + FD < PFR) fr[fi % FD] = *reinterpret_cast<const u32x4*>(sp + (fi + FD) * 1024);
           __builtin_amdgcn_sched_barrier(0);
         }
         next_slot();
       }
       // x1 = proj + x, rounded to bf16 into the x registers (accumulator channel order == x register order)
       load_x();
-      {
-        f32x16* yf = &yacc[0][0];
-        static_assert(RB * NCT == 16, "operand list");
-        asm volatile("s_nop 15\n\ts_nop 3"
-                     : "+a"(yf[0]), "+a"(yf[1]), "+a"(yf[2]), "+a"(yf[3]), "+a"(yf[4]), "+a"(yf[5]), "+a"(yf[6]), "+a"(yf[7]),
-                       "+a"(yf[8]), "+a"(yf[9]), "+a"(yf[10]), "+a"(yf[11]), "+a"(yf[12]), "+a"(yf[13]), "+a"(yf[14]), "+a"(yf[15]));
-      }
+      yacc_settle();
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -289,20 +343,77 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             const bf16x8 xv = __builtin_bit_cast(bf16x8, xr[rb][2 * ct + q]);
+            float pb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if constexpr (LN) {
+              const f32x4 b0 = *reinterpret_cast<const f32x4*>(bptab + 32 * ct + 16 * kh + 8 * q);
+              const f32x4 b1 = *reinterpret_cast<const f32x4*>(bptab + 32 * ct + 16 * kh + 8 * q + 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { pb[e] = b0[e]; pb[4 + e] = b1[e]; }
+            }
             u32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              o[e] = mr_pk2(yacc[rb][ct][8 * q + 2 * e] + (float)xv[2 * e], yacc[rb][ct][8 * q + 2 * e + 1] + (float)xv[2 * e + 1]);
+            for (int e = 0; e < 4; ++e) {
+              float a0 = yacc[rb][ct][8 * q + 2 * e] + (float)xv[2 * e], a1 = yacc[rb][ct][8 * q + 2 * e + 1] + (float)xv[2 * e + 1];
+              if constexpr (LN) { a0 += pb[2 * e]; a1 += pb[2 * e + 1]; }
+              o[e] = mr_pk2(a0, a1);
+            }
             xr[rb][2 * ct + q] = o;
           }
     } else {
       load_x();
       if (first) { mr_bar(); first = false; }             // one barrier between the drain above and the first reads of image 0
     }
+    if constexpr (LN) {
+      // residual: yacc := x1 through the identity fragments (accumulator row n of tile ct <-> channel 16 (n>>2 & 1) + 4 (n>>3) + (n & 3), the k slot
+      // (kh, e8) of step 2 ct + q <-> channel 16 kh + 8 q + e8).  Every x register is threaded through before the nops: VALU-written -> MFMA SrcB.
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
+      for (int o = 0; o + 4 < NKS; o += 4) asm volatile("" : "+v"(xr[0][o]), "+v"(xr[0][o + 1]), "+v"(xr[0][o + 2]), "+v"(xr[0][o + 3]) :: "memory");
+      // (the identity fragments too: the compiler may have parked them in AGPRs - a v_accvgpr_read right in front of the first MFMA is the same hazard)
+      asm volatile("s_nop 7" : "+v"(xr[0][NKS - 4]), "+v"(xr[0][NKS - 3]), "+v"(xr[0][NKS - 2]), "+v"(xr[0][NKS - 1]), "+v"(idf[0]), "+v"(idf[1]) :: "memory");
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) mfma32_a_zero(yacc[rb][ct]);
+      for (int ct = 0; ct < NCT; ++ct) {
+        mfma32_a_z(idf[0], xr[0][2 * ct], yacc[0][ct]);
+        mfma32_a(idf[1], xr[0][2 * ct + 1], yacc[0][ct]);
+      }
+      // LayerNorm of the row held by lanes (r, 0) and (r, 1): two passes (mean, then centred sum of squares), biased variance (nn.LayerNorm)
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+        const bf16x8 v = __builtin_bit_cast(bf16x8, xr[0][s]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s4[e & 3] += (float)v[e];
+      }
+      float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      sum += __shfl_xor(sum, 32);
+      const float mean = sum * (1.0f / C);
+      float q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+        const bf16x8 v = __builtin_bit_cast(bf16x8, xr[0][s]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = (float)v[e] - mean; q4[e & 3] = fmaf(d, d, q4[e & 3]); }
+      }
+      float sq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+      sq += __shfl_xor(sq, 32);
+      const float rstd = rsqrtf(sq * (1.0f / C) + ln_eps);
+      const float nmr = -mean * rstd;
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+        const bf16x8 v = __builtin_bit_cast(bf16x8, xr[0][s]);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = mr_pk2(fmaf((float)v[2 * e], rstd, nmr), fmaf((float)v[2 * e + 1], rstd, nmr));
+        xr[0][s] = o;
+      }
+#pragma unroll
+      for (int o = 0; o + 4 < NKS; o += 4) asm volatile("" : "+v"(xr[0][o]), "+v"(xr[0][o + 1]), "+v"(xr[0][o + 2]), "+v"(xr[0][o + 3]) :: "memory");
+      asm volatile("s_nop 7" : "+v"(xr[0][NKS - 4]), "+v"(xr[0][NKS - 3]), "+v"(xr[0][NKS - 2]), "+v"(xr[0][NKS - 1]) :: "memory");
+    } else {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) mfma32_a_zero(yacc[rb][ct]);
+    }
 
     // ---- hidden chunks, software-pipelined inside the wave.  One wave per SIMD issues in order and MFMA shares its issue port with
     // the VALU, so GEMM1 -> GELU -> GEMM2 run back to back left the matrix pipe idle through every GELU, every exposed LDS latency
@@ -339,7 +450,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
     // this group's share of the ring refill, called after every MFMA slot m (0..31) of a group: 4 (C = 256: half a slot image,
     // `half` was already flipped by begin_group) or 8 (C = 512) single pieces, 8 / 4 MFMAs apart
     auto refill = [&](int m) {
-      constexpr int EVERY = 32 / (4 * PPC);
+      constexpr int EVERY = SL / (PW / (PPC == 1 ? 2 : 1));
 #if !(defined(MR_DIAG) && (MR_DIAG & 4))
       if (m % EVERY == 1) issue1((PPC == 1 && !half ? 4 : 0) + m / EVERY);
 #endif
@@ -412,7 +523,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
     constexpr int CAD2 = RB == 2 ? 7 : 8;
     constexpr int O_A2 = 1, O_E = 2, O_BA = RB == 2 ? 4 : 3, O_BR = RB == 2 ? 5 : 4, O_C = RB == 2 ? 6 : 7;
     auto st = [](int q) { return q * CAD2 / 2; };
-    auto st_a1 = [&](int q) { const int lim = 45 - (NP - 1 - q); return RB == 2 && q >= 8 && st(q) > lim ? lim : st(q); };
+    auto st_a1 = [&](int q) { const int lim = (RB == 2 ? 45 : SL - 4) - (NP - 1 - q); return (RB == 1 || q >= 8) && st(q) > lim ? lim : st(q); };
     constexpr int G_LAST = (NP - 1) * CAD2 / 2 + O_C;     // slot of the last micro-stage
     auto gelu_slot = [&](int m, u32x4 (&hp)[RB][2]) {
 #pragma unroll
@@ -425,7 +536,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
         if (m == st(q) + O_C) gC(q, hp);
       }
     };
-    static_assert(G_LAST < 64, "the GELU fits in one body");
+    static_assert(G_LAST < 2 * SL, "the GELU fits in one body");
 
     // One body.  G2: slots 0..31 carry GEMM2 of the previous chunk (B operands hp_prev);  G1: slots 32..63 carry GEMM1 of chunk jn;
     // GE: the GELU of the chunk in hacc runs through the slots (-> hp_cur).
@@ -440,7 +551,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
         for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + foff2(i));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < 32; ++m) {
+        for (int m = 0; m < SL; ++m) {
           const int f = m / RB, rb = m % RB;
           mfma32_a(fr[f % FD], hp_prev[rb][f / NCT], yacc[rb][f % NCT]);
 #if !(defined(MR_DIAG) && (MR_DIAG & 8))
@@ -454,14 +565,14 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
             else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(hacc[0]));
           }
           if (GE) gelu_slot(m, hp_cur);
-          if (G1 && m == 28) bias_init(0, jn);              // after the GELU's last direct read of row block 0's accumulator              // after the GELU's last direct read of row block 0's accumulator
+          if (G1 && m == SL - 4) bias_init(0, jn);              // after the GELU's last direct read of row block 0's accumulator              // after the GELU's last direct read of row block 0's accumulator
           __builtin_amdgcn_sched_barrier(0);
         }
       } else if (GE) {                                     // body 0: the GELU of chunk 0 on its own
         if constexpr (RB == 2) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(hacc[0]), "+v"(hacc[RB - 1]));
         else asm volatile("s_nop 15\n\ts_nop 3" : "+v"(hacc[0]));
 #pragma unroll
-        for (int m = 0; m < 32; ++m) gelu_slot(m, hp_cur);
+        for (int m = 0; m < SL; ++m) gelu_slot(m, hp_cur);
         if (G1) bias_init(0, jn);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -471,20 +582,20 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
         for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + foff1(i));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < SL; ++i) {
           const int rb = RB == 2 ? i / NKS : 0, s = RB == 2 ? i % NKS : i;
           mfma32_v(fr[i % FD], xr[rb][s], hacc[rb]);
 #if !(defined(MR_DIAG) && (MR_DIAG & 8))
-          if (i + FD < 32) fr[i % FD] = *reinterpret_cast<const u32x4*>(sp + foff1(i + FD));
+          if (i + FD < SL) fr[i % FD] = *reinterpret_cast<const u32x4*>(sp + foff1(i + FD));
 #endif
           refill(i);
-          if (GE) gelu_slot(32 + i, hp_cur);
+          if (GE) gelu_slot(SL + i, hp_cur);
           if (RB == 2 && i == NKS - 2) bias_init(1, jn);        // after the last GELU read of row block 1's accumulator (slot 45)
           __builtin_amdgcn_sched_barrier(0);
         }
       } else if (GE) {                                     // last body: the tail of the GELU on its own
 #pragma unroll
-        for (int m = 32; m <= G_LAST; ++m) gelu_slot(m, hp_cur);
+        for (int m = SL; m <= G_LAST; ++m) gelu_slot(m, hp_cur);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -504,13 +615,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
     else asm volatile("s_nop 7" : "+v"(hpB[0][0]), "+v"(hpB[0][1]));
     body(yes_t{}, no_t{}, no_t{}, 0, hpB, hpB);            // GEMM2(NCH-1)
 
-    {   // wait states MFMA -> v_accvgpr_read, accumulators threaded through
-      f32x16* yf = &yacc[0][0];
-      static_assert(RB * NCT == 16, "operand list");
-      asm volatile("s_nop 15\n\ts_nop 3"
-                   : "+a"(yf[0]), "+a"(yf[1]), "+a"(yf[2]), "+a"(yf[3]), "+a"(yf[4]), "+a"(yf[5]), "+a"(yf[6]), "+a"(yf[7]),
-                     "+a"(yf[8]), "+a"(yf[9]), "+a"(yf[10]), "+a"(yf[11]), "+a"(yf[12]), "+a"(yf[13]), "+a"(yf[14]), "+a"(yf[15]));
-    }
+    yacc_settle();
     // ---- epilogue: + residual (the x registers), + optional bias of conv3, 2 x 16-byte stores per 32-channel tile
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -520,11 +625,18 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
         for (int q = 0; q < 2; ++q) {
           const bf16x8 xv = __builtin_bit_cast(bf16x8, xr[rb][2 * ct + q]);
           bf16x8 o;
+          if constexpr (LN) {         // the residual is already in the accumulator; fc2's bias from the LDS table
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(b2tab + 32 * ct + 16 * kh + 8 * q);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(b2tab + 32 * ct + 16 * kh + 8 * q + 4);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float v = yacc[rb][ct][8 * q + e] + (float)xv[e];
-            if (b2) v += b2[32 * ct + 16 * kh + 8 * q + e];
-            o[e] = (bf16)v;
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)(yacc[rb][ct][8 * q + e] + (e < 4 ? b0[e & 3] : b1[e & 3]));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float v = yacc[rb][ct][8 * q + e] + (float)xv[e];
+              if (b2) v += b2[32 * ct + 16 * kh + 8 * q + e];
+              o[e] = (bf16)v;
+            }
           }
           if (mok[rb]) *reinterpret_cast<bf16x8*>(Y + rowoff[rb] + 32 * ct + 8 * q) = o;
         }
@@ -547,7 +659,8 @@ __global__ void mlp_pack_kernel(const bf16* __restrict__ w1, int k1w, const floa
                                 const bf16* __restrict__ wp, int kpw, int KC, bf16* __restrict__ wimg, float* __restrict__ b1img, int C, int HID) {
   const int NCT = C / 32, NKS = C / 16, NCH = HID / 32;
   const int per_chunk = (NKS + 2 * NCT) * 512;
-  const long proj_elems = (long)(((KC / 16) * NCT + 31) / 32) * 32 * 512;      // whole slots; fragments past KC read wp's zero padding (kpw >= 16 * ceil)
+  const int slf = mr_slot_frags(C);
+  const long proj_elems = (long)(((KC / 16) * NCT + slf - 1) / slf) * slf * 512;      // whole slots; fragments past KC read wp's zero padding (kpw >= 16 * ceil)
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < HID) {
     const int j = (int)idx >> 5, w = (int)idx & 31, kh = w >> 4, i = w & 15;
@@ -585,6 +698,11 @@ __global__ void mlp_pack_kernel(const bf16* __restrict__ w1, int k1w, const floa
   wimg[idx] = v;
 }
 
+// the ViT / DeiT block (proj + bias + residual, LayerNorm, Mlp with biases): DeiT-S geometry; FSVIT_MLP_ROWS bit 3
+bool mlp_rows_ln_supported(int dtype, int C, int hid, int KC) {
+  static const int mode = [] { const char* e = getenv("FSVIT_MLP_ROWS"); return e ? atoi(e) : 15; }();
+  return dtype == 1 && (mode & 8) && C == 384 && hid == 1536 && KC == 384;
+}
 bool mlp_rows_supported(int dtype, int C, int hid) {
   static const int mode = [] { const char* e = getenv("FSVIT_MLP_ROWS"); return e ? atoi(e) : 7; }();      // bit 0: C = 256, bit 1: C = 512, bit 2: proj fusion
   if (dtype != 1) return false;
@@ -596,7 +714,8 @@ bool mlp_rows_proj_supported(int C, int hid, int KC) {
   return (mode & 4) && ((C == 256 && hid == 1024 && KC == 288) || (C == 512 && hid == 2048 && KC == 576));
 }
 size_t mlp_rows_image_bytes(int C, int hid, int KC) {
-  const size_t proj_frags = ((size_t)(KC / 16) * (C / 32) + 31) / 32 * 32;
+  const size_t slf = (size_t)mr_slot_frags(C);
+  const size_t proj_frags = ((size_t)(KC / 16) * (C / 32) + slf - 1) / slf * slf;
   return (proj_frags + (size_t)(hid / 32) * (C / 16 + 2 * (C / 32))) * 1024;
 }
 
@@ -608,10 +727,11 @@ int launch_mlp_pack(const void* w1, int k1w, const float* b1, const void* w2, in
   return (int)hipGetLastError();
 }
 
-template <int C, int HID, int RB, int KC>
-static int launch_mlp_rows_t(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, const void* ctx, int M, hipStream_t s) {
-  auto kern = mlp_rows_kernel<C, HID, RB, KC>;
-  const int lds = MR_NST * MR_SLOT + HID * 4;
+template <int C, int HID, int RB, int KC, bool LN = false>
+static int launch_mlp_rows_t(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, const void* ctx, const float* bproj, float eps,
+                             int M, hipStream_t s) {
+  auto kern = mlp_rows_kernel<C, HID, RB, KC, LN>;
+  const int lds = MR_NST * mr_slot_frags(C) * 1024 + HID * 4 + (LN ? 2 * C * 4 : 0);
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -621,8 +741,8 @@ static int launch_mlp_rows_t(const void* x, void* y, const void* wimg, const flo
   constexpr int BM = MR_NW * 32 * RB;
   const int n_tiles = (M + BM - 1) / BM;
   const int grid = n_tiles < 256 ? n_tiles : 256;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(MR_NW * 64), lds, s, (const bf16*)x, (bf16*)y, (const unsigned char*)wimg, b1img, b2, (const bf16*)ctx, M,
-                     n_tiles);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(MR_NW * 64), lds, s, (const bf16*)x, (bf16*)y, (const unsigned char*)wimg, b1img, b2, (const bf16*)ctx, bproj,
+                     eps, M, n_tiles);
   return (int)hipGetLastError();
 }
 
@@ -631,10 +751,19 @@ int launch_mlp_rows(const void* x, void* y, const void* wimg, const float* b1img
                     hipStream_t s) {
   if (M <= 0) return 0;
   if (!ctx) KC = 0;
-  if (C == 256 && hid == 1024 && KC == 0) return launch_mlp_rows_t<256, 1024, 2, 0>(x, y, wimg, b1img, b2, nullptr, M, s);
-  if (C == 512 && hid == 2048 && KC == 0) return launch_mlp_rows_t<512, 2048, 1, 0>(x, y, wimg, b1img, b2, nullptr, M, s);
-  if (C == 256 && hid == 1024 && KC == 288) return launch_mlp_rows_t<256, 1024, 2, 288>(x, y, wimg, b1img, b2, ctx, M, s);
-  if (C == 512 && hid == 2048 && KC == 576) return launch_mlp_rows_t<512, 2048, 1, 576>(x, y, wimg, b1img, b2, ctx, M, s);
+  if (C == 256 && hid == 1024 && KC == 0) return launch_mlp_rows_t<256, 1024, 2, 0>(x, y, wimg, b1img, b2, nullptr, nullptr, 0.f, M, s);
+  if (C == 512 && hid == 2048 && KC == 0) return launch_mlp_rows_t<512, 2048, 1, 0>(x, y, wimg, b1img, b2, nullptr, nullptr, 0.f, M, s);
+  if (C == 256 && hid == 1024 && KC == 288) return launch_mlp_rows_t<256, 1024, 2, 288>(x, y, wimg, b1img, b2, ctx, nullptr, 0.f, M, s);
+  if (C == 512 && hid == 2048 && KC == 576) return launch_mlp_rows_t<512, 2048, 1, 576>(x, y, wimg, b1img, b2, ctx, nullptr, 0.f, M, s);
+  return (int)hipErrorInvalidValue;
+}
+
+// y = x1 + b2 + W2 GELU(W1' LN(x1) + b1'),  x1 = x + bp + Wp ctx   (gamma / beta of the LayerNorm folded into W1' / b1' by the caller)
+int launch_mlp_rows_ln(const void* x, void* y, const void* wimg, const float* b1img, const float* bproj, const float* b2, const void* ctx, int KC, int M,
+                       int C, int hid, float eps, hipStream_t s) {
+  if (M <= 0) return 0;
+  if (!ctx || !bproj || !b2) return (int)hipErrorInvalidValue;
+  if (C == 384 && hid == 1536 && KC == 384) return launch_mlp_rows_t<384, 1536, 1, 384, true>(x, y, wimg, b1img, b2, ctx, bproj, eps, M, s);
   return (int)hipErrorInvalidValue;
 }
 

@@ -560,6 +560,19 @@ class ops:
         return y
 
     @staticmethod
+    def vit_block_tail(x, ctx, wp, bp, w1, b1, w2, b2, eps=1e-6):
+        """DeiT block tail (deit.py:69-72) on bf16 rows, (C, KC, hidden) = (384, 384, 1536): x1 = x + bp + ctx wp^T;
+        y = x1 + b2 + W2 GELU(W1 LN(x1) + b1), LN without affine (norm2's gamma / beta folded into w1 / b1 by the caller)."""
+        _require_cuda(x, ctx, wp, bp, w1, b1, w2, b2)
+        lib = _lib.load()
+        y = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.fsvit_vit_block_tail(_ptr(x), _ptr(y), _ptr(ctx), _ptr(wp), wp.shape[-1], ctx.shape[1], _ptr(bp), _ptr(w1), w1.shape[-1],
+                                                _ptr(b1), _ptr(w2), w2.shape[-1], _ptr(b2), x.shape[0], x.shape[1], w1.shape[0], float(eps),
+                                                _stream_ptr(x.device)))
+        return y
+
+    @staticmethod
     def mlp_rows(x, w1, b1, w2, b2=None):
         """x [M][C] bf16, C = 256 or 512; w1 [4C][K1w], w2 [C][K2w] packed K-major bf16; b1 [4C], b2 [C] fp32 or None.  y = x + W2 GELU(W1 x + b1) + b2."""
         _require_cuda(x, w1, w2)

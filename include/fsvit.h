@@ -185,6 +185,12 @@ int fsvit_mlp_rows(const void* x_dev, void* y_dev, const void* w1_dev, int k1w, 
  * (C, KC) = (256, 288) or (512, 576).  ctx == NULL: plain fsvit_mlp_rows. */
 int fsvit_proj_mlp_rows(const void* x_dev, void* y_dev, const void* ctx_dev, const void* wp_dev, int kpw, int KC, const void* w1_dev, int k1w,
                         const float* b1_dev, const void* w2_dev, int k2w, const float* b2_dev, int M, int C, int hid, void* stream);
+/* The ViT / DeiT block tail (test_phase/models/deit.py:69-72, `x = x + attn.proj(ctx); x = x + mlp(norm2(x))`) on token-major rows, bf16,
+ * (C, hidden, KC) = (384, 1536, 384):  x1 = x + bp + wp ctx;  y = x1 + b2 + W2 GELU(W1 LN(x1) + b1), LN = (x1 - mean) / sqrt(var + eps) without
+ * affine - the caller folds norm2's gamma / beta into w1 / b1 (W1 diag(gamma), b1 + W1 beta).  In place (y == x) allowed. */
+int fsvit_vit_block_tail(const void* x_dev, void* y_dev, const void* ctx_dev, const void* wp_dev, int kpw, int KC, const float* bp_dev,
+                         const void* w1_dev, int k1w, const float* b1_dev, const void* w2_dev, int k2w, const float* b2_dev, int M, int C, int hid,
+                         float eps, void* stream);
 /* ---------------------------------------------------------------- distillation head
  * Replaces, for sun_meta_training/offline.py: `LinearClassifier.forward` / its autograd (models/classifier.py:27-34) as used by
  * `TokenLabelOffline` (models/token_label.py:36-60) on the 25 tokens and on the pooled feature, `generate_softlabel`

@@ -450,6 +450,42 @@ def test_proj_mlp_rows_fused_matches_unfused_math(M, C, KC):
         assert torch.equal(ops.proj_mlp_rows(*args), y0)
 
 
+@pytest.mark.parametrize('M', [197, 128 * 40 + 77])
+def test_vit_block_tail_matches_unfused_math(M):
+    """mlp_rows at the DeiT-S geometry with proj + bias + residual, LayerNorm and both Mlp biases fused (deit.py:69-72) against fp32 torch
+    with the same bf16 roundings (x1, LN(x1), GELU output); 5 repeats bit-identical; in place."""
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    C, KC, HID, eps = 384, 384, 1536, 1e-6
+    g = torch.Generator().manual_seed(M)
+    x = q(torch.randn(M, C, generator=g) * 2.0 + 0.5, bf)
+    ctx = q(torch.randn(M, KC, generator=g), bf)
+    wp = q(torch.randn(C, KC, generator=g) / math.sqrt(KC), bf)
+    bp = torch.randn(C, generator=g) * 0.3
+    w1 = q(torch.randn(HID, C, generator=g) / math.sqrt(C), bf)
+    b1 = torch.randn(HID, generator=g) * 0.3
+    w2 = q(torch.randn(C, HID, generator=g) / math.sqrt(HID), bf)
+    b2 = torch.randn(C, generator=g) * 0.3
+    x1 = q(x + ctx @ wp.t() + bp, bf)
+    xn = q(F.layer_norm(x1, (C,), eps=eps), bf)
+    ref = x1 + q(F.gelu(xn @ w1.t() + b1), bf) @ w2.t() + b2
+    args = [x.to('cuda', bf), ctx.to('cuda', bf), wp.to('cuda', bf), bp.cuda(), w1.to('cuda', bf), b1.cuda(), w2.to('cuda', bf), b2.cuda()]
+    y0 = ops.vit_block_tail(*args, eps=eps)
+    torch.cuda.synchronize()
+    err = (y0.float().cpu() - ref).abs()
+    assert err.max().item() <= 4e-2 * max(1.0, float(ref.abs().max())), (M, err.max().item())
+    assert err.mean().item() <= 4e-3, (M, err.mean().item())
+    for _ in range(5):
+        assert torch.equal(ops.vit_block_tail(*args, eps=eps), y0)
+    from fewshot_vit_amd import _lib
+    from fewshot_vit_amd.engine import _ptr, _stream_ptr
+    yi = args[0].clone()
+    _lib.check(_lib.load().fsvit_vit_block_tail(_ptr(yi), _ptr(yi), _ptr(args[1]), _ptr(args[2]), KC, KC, _ptr(args[3]), _ptr(args[4]), C, _ptr(args[5]),
+                                                _ptr(args[6]), HID, _ptr(args[7]), M, C, HID, eps, _stream_ptr(yi.device)))
+    torch.cuda.synchronize()
+    assert torch.equal(yi, y0)
+
+
 def test_gemm256_large_shapes_repeatable_and_correct():
     """Race screen of the pipelined 256x256 kernel (counted-vmcnt LDS-DMA ring, cdna_hip_programming.md: a misplaced wait shows up as
     rare wrong tiles): several persistent items per workgroup, tails in M and N, 25 repeats must be bit-identical and match fp32."""
