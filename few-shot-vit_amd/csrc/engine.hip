@@ -935,6 +935,23 @@ extern "C" int fsvit_vit_block_tail(const void* x, void* y, const void* ctx, con
   return 0;
 }
 
+// LayerNorm + Linear on token rows as one operator (the DeiT block's norm1 + qkv, deit.py:40-47,:69): y [M][N] = b + W LN(x), LN without affine
+// (gamma / beta folded into w / b by the caller).  bf16, C = 384, N a multiple of 32.  Packs the weights on every call.
+extern "C" int fsvit_ln_linear_rows(const void* x, void* y, const void* w, int kw, const float* b, int M, int C, int N, float eps, void* stream) {
+  const int kdt = FSVIT_BF16;
+  if (!x || !y || !w || !b) return fail(FSVIT_ERR_ARG, "null argument");
+  if (!K(ln_gemm_rows_supported)(1, C, N) || kw < C) return fail(FSVIT_ERR_ARG, "fsvit_ln_linear_rows: C = 384, N a multiple of 32, rows of at least C weights (bf16)");
+  hipStream_t st = (hipStream_t)stream;
+  void* img = nullptr;
+  HIP_TRY(hipMalloc(&img, K(ln_gemm_rows_image_bytes)(C, N)));
+  int rc = K(launch_ln_gemm_pack)(w, kw, img, C, N, st);
+  if (rc == 0) rc = K(launch_ln_gemm_rows)(x, y, img, b, M, C, N, eps, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(img);
+  if (rc != 0) return hipfail((hipError_t)rc, "fsvit_ln_linear_rows");
+  return 0;
+}
+
 // ---- distillation head (sun_meta_training/offline.py, models/token_label.py, models/classifier.py)
 extern "C" int fsvit_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int N, int K, void* stream) {
   const int kdt = FSVIT_BF16;
@@ -1044,15 +1061,15 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
   static const char* f32n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
                                "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<float,128,128,2,2,2>",
-                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel"};
+                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel"};
   static const char* bf16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
                                 "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<__bf16,128,128,2,2,2>",
-                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel"};
+                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel"};
   static const char* f16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<_Float16,128,64,2,2,3>", "conv_gemm_v2_kernel<_Float16,128,32,4,1,3>",
                                "im2col27_kernel<_Float16>", "maxpool2_pos_kernel<_Float16>", "attention_v2_kernel<_Float16,...>", "pool_affine_kernel<_Float16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<_Float16,128,128,2,2,2>",
-                               "patchify_kernel<_Float16>", "layernorm_kernel<_Float16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel"};
+                               "patchify_kernel<_Float16>", "layernorm_kernel<_Float16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel"};
   static const char* x2n[] = {"gemm256_x2_kernel", "conv_gemm_v2_kernel<f32x2l,128,64,2,2,3>", "conv_gemm_v2_kernel<f32x2l,128,32,4,1,3>", "", "", "", "", "", "", "conv_gemm_v2_kernel<f32x2l,128,128,2,2,2>"};
-  if (kernel_id < 0 || kernel_id > 17) return "?";
+  if (kernel_id < 0 || kernel_id > 18) return "?";
   if (is_x2(dtype)) return kernel_id == 14 ? "gconv3x3_x2_kernel" : (kernel_id == 0 || kernel_id == 1 || kernel_id == 2 || kernel_id == 9) ? x2n[kernel_id] : f32n[kernel_id];
   return dtype == FSVIT_F32 ? f32n[kernel_id] : dtype == FSVIT_F16 ? f16n[kernel_id] : bf16n[kernel_id];
 }
@@ -1111,6 +1128,7 @@ struct VitBlock {
   Layer qkv, proj, fc1, fc2;
   void* mlp_img = nullptr;      // mlp_rows.hip: fragment-major image of proj | fc1 | fc2 (null: GEMM + LayerNorm launches)
   float* mlp_b1 = nullptr;
+  void* qkv_img = nullptr;      // mlp_rows.hip ln_gemm_rows: fragment-major image of the qkv Linear (null: LayerNorm launch + GEMM)
 };
 
 struct fsvit_vit : EngineBase {
@@ -1209,6 +1227,15 @@ int build_vit(fsvit_vit* h, const SD& sd) {
       b.mlp_img = img;
       b.mlp_b1 = (float*)b1i;
     }
+    if (K(ln_gemm_rows_supported)(kd(kdt), D, 3 * heads * hdp)) {         // norm1 + qkv in one row-wise kernel
+      VitBlock& b = h->blocks[i];
+      void* img = nullptr;
+      HIP_TRY(hipMalloc(&img, K(ln_gemm_rows_image_bytes)(D, 3 * heads * hdp)));
+      h->allocs.push_back(img);
+      RC_TRY(K(launch_ln_gemm_pack)(b.qkv.w, b.qkv.Kw, img, D, 3 * heads * hdp, nullptr));
+      HIP_TRY(hipDeviceSynchronize());
+      b.qkv_img = img;
+    }
   }
   return 0;
 }
@@ -1230,7 +1257,7 @@ VitPlan make_vit_plan(const fsvit_vit* h, size_t Bc) {
   return p;
 }
 
-enum { KID_PATCHIFY = 10, KID_LN = 11 };
+enum { KID_PATCHIFY = 10, KID_LN = 11, KID_LNGEMM = 18 };
 
 int vit_forward_chunk(fsvit_vit* h, const float* x, int Bc, float* feat, unsigned char* ws, bool first, hipStream_t st) {
   const VitPlan pl = make_vit_plan(h, Bc);
@@ -1250,8 +1277,14 @@ int vit_forward_chunk(fsvit_vit* h, const float* x, int Bc, float* feat, unsigne
   const float scale = 1.0f / std::sqrt((float)h->hd);
   for (size_t i = 0; i < h->blocks.size(); ++i) {
     const VitBlock& b = h->blocks[i];
-    RC_TRY(timed(h, st, "blocks.norm1", KID_LN, 0.0, [&]() { return K(launch_layernorm)(tokens, xn, M, D, h->cfg.ln_eps, dt, st); }));
-    RC_TRY(run_gemm(h, st, "blocks.attn.qkv", b.qkv, conv_params(b.qkv, xn, qkv, Bc, S, 1, D, D, 1, 1, 1, 0, 3 * heads * hdp, ACT_NONE, nullptr, 0, nullptr), 3.0 * D, D));
+    if (b.qkv_img) {
+      RC_TRY(timed(h, st, "blocks.norm1+qkv", KID_LNGEMM, 2.0 * M * 3.0 * D * D, [&]() {
+        return K(launch_ln_gemm_rows)(tokens, qkv, b.qkv_img, b.qkv.bias, M, D, 3 * heads * hdp, h->cfg.ln_eps, st);
+      }));
+    } else {
+      RC_TRY(timed(h, st, "blocks.norm1", KID_LN, 0.0, [&]() { return K(launch_layernorm)(tokens, xn, M, D, h->cfg.ln_eps, dt, st); }));
+      RC_TRY(run_gemm(h, st, "blocks.attn.qkv", b.qkv, conv_params(b.qkv, xn, qkv, Bc, S, 1, D, D, 1, 1, 1, 0, 3 * heads * hdp, ACT_NONE, nullptr, 0, nullptr), 3.0 * D, D));
+    }
     RC_TRY(timed(h, st, "blocks.attn.core", KID_ATTN, 4.0 * Bc * heads * (double)S * S * h->hd,
                  [&]() { return K(launch_attention)(qkv, ctx, Bc, S, heads, hdp, scale, dt, st); }));
     if (b.mlp_img) {

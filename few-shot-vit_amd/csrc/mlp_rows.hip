@@ -62,9 +62,21 @@ constexpr int MR_FD = 6;                        // weight fragments read ahead o
 // The immediate offset of global_load_lds moves the LDS destination together with the global source (tools/probes/
 // ldsdma_offset.hip, measured on gfx950), so a linear copy needs no address arithmetic; the 13-bit offset field covers 4 pieces.
 template <int PW> __device__ __forceinline__ void mr_dma(unsigned voff, const void* sbase, unsigned lds) {
-  static_assert(PW == 8 || PW == 6, "pieces per wave and slot");
+  static_assert(PW == 8 || PW == 6 || PW == 3, "pieces per wave and slot");
   unsigned keep;
-  if constexpr (PW == 8)
+  if constexpr (PW == 3)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds)
+        : "memory");
+  else if constexpr (PW == 8)
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %4\n\t"
@@ -165,6 +177,49 @@ __device__ __forceinline__ void mfma32_a_z(u32x4 a, u32x4 b, f32x16& d) {
 __device__ __forceinline__ void mfma32_a_zero(f32x16& c) {
   const u32x4 z = {0u, 0u, 0u, 0u};
   asm volatile("s_nop 7\n\t" FSVIT_MFMA_32x32x16 " %0, %1, %1, 0" : "=a"(c) : "v"(z));      // s_nop: VALU-written z -> MFMA SrcA/B
+}
+
+__device__ __forceinline__ void mr_gstore16(void* p, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(v) : "memory");
+}
+
+// LayerNorm (no affine) of token rows held as MFMA B operands: lane (r, kh) has half of token r's C channels in NKS 16-byte registers, the
+// other half sits in lane r of the other wave half.  Two passes (mean, then centred sum of squares; biased variance as nn.LayerNorm), one lane
+// exchange each; the rows are replaced by bf16((x - mean) rstd).  Ends with the wait states VALU write -> MFMA SrcB.
+template <int NKS, int C> __device__ __forceinline__ void mr_layernorm_rows(u32x4 (&xr)[NKS], const float eps) {
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) {
+    const bf16x8 v = __builtin_bit_cast(bf16x8, xr[s]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s4[e & 3] += (float)v[e];
+  }
+  float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  sum += __shfl_xor(sum, 32);
+  const float mean = sum * (1.0f / C);
+  float q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) {
+    const bf16x8 v = __builtin_bit_cast(bf16x8, xr[s]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = (float)v[e] - mean; q4[e & 3] = fmaf(d, d, q4[e & 3]); }
+  }
+  float sq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+  sq += __shfl_xor(sq, 32);
+  const float rstd = rsqrtf(sq * (1.0f / C) + eps);
+  const float nmr = -mean * rstd;
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) {
+    const bf16x8 v = __builtin_bit_cast(bf16x8, xr[s]);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = mr_pk2(fmaf((float)v[2 * e], rstd, nmr), fmaf((float)v[2 * e + 1], rstd, nmr));
+    xr[s] = o;
+  }
+  static_assert(NKS % 4 == 0, "groups of 4");
+#pragma unroll
+  for (int o = 0; o + 4 < NKS; o += 4) asm volatile("" : "+v"(xr[o]), "+v"(xr[o + 1]), "+v"(xr[o + 2]), "+v"(xr[o + 3]) :: "memory");
+  asm volatile("s_nop 7" : "+v"(xr[NKS - 4]), "+v"(xr[NKS - 3]), "+v"(xr[NKS - 2]), "+v"(xr[NKS - 1]) :: "memory");
 }
 
 }  // namespace
@@ -375,39 +430,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
         mfma32_a_z(idf[0], xr[0][2 * ct], yacc[0][ct]);
         mfma32_a(idf[1], xr[0][2 * ct + 1], yacc[0][ct]);
       }
-      // LayerNorm of the row held by lanes (r, 0) and (r, 1): two passes (mean, then centred sum of squares), biased variance (nn.LayerNorm)
-      float s4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) {
-        const bf16x8 v = __builtin_bit_cast(bf16x8, xr[0][s]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s4[e & 3] += (float)v[e];
-      }
-      float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-      sum += __shfl_xor(sum, 32);
-      const float mean = sum * (1.0f / C);
-      float q4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) {
-        const bf16x8 v = __builtin_bit_cast(bf16x8, xr[0][s]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = (float)v[e] - mean; q4[e & 3] = fmaf(d, d, q4[e & 3]); }
-      }
-      float sq = (q4[0] + q4[1]) + (q4[2] + q4[3]);
-      sq += __shfl_xor(sq, 32);
-      const float rstd = rsqrtf(sq * (1.0f / C) + ln_eps);
-      const float nmr = -mean * rstd;
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) {
-        const bf16x8 v = __builtin_bit_cast(bf16x8, xr[0][s]);
-        u32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = mr_pk2(fmaf((float)v[2 * e], rstd, nmr), fmaf((float)v[2 * e + 1], rstd, nmr));
-        xr[0][s] = o;
-      }
-#pragma unroll
-      for (int o = 0; o + 4 < NKS; o += 4) asm volatile("" : "+v"(xr[0][o]), "+v"(xr[0][o + 1]), "+v"(xr[0][o + 2]), "+v"(xr[0][o + 3]) :: "memory");
-      asm volatile("s_nop 7" : "+v"(xr[0][NKS - 4]), "+v"(xr[0][NKS - 3]), "+v"(xr[0][NKS - 2]), "+v"(xr[0][NKS - 1]) :: "memory");
+      mr_layernorm_rows<NKS, C>(xr[0], ln_eps);
     } else {
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb)
@@ -650,6 +673,146 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
            (w1 - clk_w0) / 100.0, dc / ((w1 - clk_w0) / 100.0));
   }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// LayerNorm + Linear on token rows (the DeiT block head, deit.py:69 `attn(norm1(x))` up to the qkv Linear, deit.py:40-47):
+//   Y[m][n] = bias[n] + sum_k W'[n][k] LN(x[m])[k],   C = 384, N a multiple of 32 (qkv: 1152), gamma / beta folded into W' / bias.
+// As a 256x256-tile GEMM this layer has 6 K tiles per output tile (720 TF/s) and needs the normalised rows written and re-read by a
+// LayerNorm launch.  Here a wave keeps its 32 token rows in registers (96 VGPRs), normalises them in place (mr_layernorm_rows) and walks the
+// N / 32 output chunks: 24 MFMAs per chunk against W' fragments streamed through the LDS ring (image = the chunks' fragments in
+// consumption order, 12 per 12 KB slot), then bias (the accumulator's initial value) -> bf16 -> two 16-byte stores per lane: the
+// fragment rows are permuted at pack time so that a lane's 16 accumulators are 16 consecutive output channels.  Nothing is software-
+// pipelined by hand: the kernel needs < 256 registers and 53 KB of LDS, so TWO workgroups share a CU and one's row load / LayerNorm /
+// stores run under the other's MFMAs.  The stores share the vmcnt queue with the ring's DMAs: loads complete in order among loads, so
+// "at most PW operations outstanding" still implies that every older slot image has landed (stores can only make the wait longer).
+template <int C>
+__global__ __launch_bounds__(256, 2) void ln_gemm_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
+                                                              const float* __restrict__ bias, const float ln_eps, const int M, const int N,
+                                                              const int n_tiles) {
+  constexpr int NKS = C / 16, SLF = 12, SPC = NKS / SLF;      // k-steps; fragments per ring slot; slots per chunk
+  constexpr int SLOT = SLF * 1024, PW = SLF / MR_NW, WSH = PW * 1024, NST = 4, FD = 4;
+  static_assert(NKS % SLF == 0 && SLF % MR_NW == 0, "whole slots");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const btab = reinterpret_cast<float*>(smem + NST * SLOT);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, kh = lane >> 5;
+  const unsigned lds0 = (unsigned)(size_t)(lptrm_t)smem;
+  const unsigned voff = (unsigned)(wave * WSH + lane * 16);
+  const int nch = N / 32, n_img = nch * SPC;
+  if ((int)blockIdx.x >= n_tiles) return;
+  for (int i = t; i < N; i += MR_NW * 64) btab[i] = bias[i];
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+  // the ring of mlp_rows_kernel: image n issued after barrier n-3, waited for before barrier n-1, first read after barrier n
+  int issue_img = 0, issue_slot = 0, slot = 0;
+  auto issue = [&]() {
+    mr_dma<PW>(voff, wimg + (size_t)issue_img * SLOT, lds0 + issue_slot * SLOT + wave * WSH);
+    issue_img = issue_img == n_img - 1 ? 0 : issue_img + 1;
+    issue_slot = issue_slot == NST - 1 ? 0 : issue_slot + 1;
+  };
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i) issue();
+  bool first = true;
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int m = tile * (MR_NW * 32) + wave * 32 + r;
+    const bool mok = m < M;
+    const size_t row = (size_t)(mok ? m : M - 1);
+    u32x4 xr[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) xr[s] = mr_gload16(X + row * C + 32 * (s >> 1) + 16 * kh + 8 * (s & 1));
+    mr_wait_loads<NKS>(&xr[0]);
+    if (first) { mr_bar(); first = false; }
+    mr_layernorm_rows<NKS, C>(xr, ln_eps);
+    bf16* const yrow = Y + row * N + 16 * kh;
+#pragma unroll 1
+    for (int j = 0; j < nch; ++j) {
+      f32x16 hacc;
+      {
+        const float* bp = btab + j * 32 + kh * 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 4 * g);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hacc[4 * g + e] = b[e];
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < SPC; ++h) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory");
+        mr_bar();
+        issue();
+        unsigned a = slot * SLOT + lane * 16;
+        asm volatile("" : "+v"(a));
+        const unsigned char* sp = smem + a;
+        slot = slot == NST - 1 ? 0 : slot + 1;
+        u32x4 fr[FD];
+#pragma unroll
+        for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < SLF; ++i) {
+          mfma32_v(fr[i % FD], xr[h * SLF + i], hacc);
+          if (i + FD < SLF) fr[i % FD] = *reinterpret_cast<const u32x4*>(sp + (i + FD) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      asm volatile("s_nop 15\n\ts_nop 3" : "+v"(hacc));          // wait states MFMA -> VALU read of the accumulator
+      u32x4 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o0[e] = mr_pk2(hacc[2 * e], hacc[2 * e + 1]);
+        o1[e] = mr_pk2(hacc[8 + 2 * e], hacc[8 + 2 * e + 1]);
+      }
+      if (mok) {
+        mr_gstore16(yrow + j * 32, o0);
+        mr_gstore16(yrow + j * 32 + 8, o1);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may be in flight into the LDS of a finished workgroup
+}
+
+// image for ln_gemm_rows_kernel from a standard packed layer w [N][kw] (K-contiguous rows): fragment (chunk j, k-step s), lane = 32 kh + r, e8:
+//   W[32 j + 16 (r>>2 & 1) + 4 (r>>3) + (r & 3)][32 (s>>1) + 16 kh + 8 (s&1) + e8]   (accumulator i of lane (token, kh) = channel 32 j + 16 kh + i)
+__global__ void ln_gemm_pack_kernel(const bf16* __restrict__ w, int kw, bf16* __restrict__ wimg, int C, int N) {
+  const int NKS = C / 16;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)(N / 32) * NKS * 512) return;
+  const int g = (int)(idx >> 9), lane = (int)(idx >> 3) & 63, e8 = (int)idx & 7;
+  const int j = g / NKS, s = g % NKS, kh = lane >> 5, r = lane & 31;
+  const int n = 32 * j + 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
+  wimg[idx] = w[(size_t)n * kw + 32 * (s >> 1) + 16 * kh + 8 * (s & 1) + e8];
+}
+
+bool ln_gemm_rows_supported(int dtype, int C, int N) {
+  static const bool on = [] { const char* e = getenv("FSVIT_LN_GEMM_ROWS"); return !e || e[0] != '0'; }();
+  return on && dtype == 1 && C == 384 && N >= 32 && N % 32 == 0;
+}
+size_t ln_gemm_rows_image_bytes(int C, int N) { return (size_t)(N / 32) * (C / 16) * 1024; }
+int launch_ln_gemm_pack(const void* w, int kw, void* wimg, int C, int N, hipStream_t s) {
+  const long n = (long)ln_gemm_rows_image_bytes(C, N) / 2;
+  hipLaunchKernelGGL(ln_gemm_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)w, kw, (bf16*)wimg, C, N);
+  return (int)hipGetLastError();
+}
+// y [M][N] = bias + W' LN(x [M][C])   (gamma / beta folded into W' / bias by the caller; image from launch_ln_gemm_pack)
+int launch_ln_gemm_rows(const void* x, void* y, const void* wimg, const float* bias, int M, int C, int N, float eps, hipStream_t s) {
+  if (M <= 0) return 0;
+  if (C != 384 || N % 32 || !bias) return (int)hipErrorInvalidValue;
+  auto kern = ln_gemm_rows_kernel<384>;
+  const int lds = 4 * 12 * 1024 + N * 4;
+  static int lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    lds_set = lds;
+  }
+  const int n_tiles = (M + MR_NW * 32 - 1) / (MR_NW * 32);
+  const int grid = n_tiles < 512 ? n_tiles : 512;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(MR_NW * 64), lds, s, (const bf16*)x, (bf16*)y, (const unsigned char*)wimg, bias, eps, M, N, n_tiles);
+  return (int)hipGetLastError();
 }
 
 // Builds the fragment-major weight image + bias table from the engine's standard packed layers (w1 [HID][k1w], w2 [C][k2w], optional

@@ -560,6 +560,17 @@ class ops:
         return y
 
     @staticmethod
+    def ln_linear_rows(x, w, b, eps=1e-6):
+        """y = b + LN(x) w^T on bf16 rows (x [M][384], w [N][>=384], N % 32 == 0): the DeiT block's norm1 + qkv (deit.py:40-47,:69), LN without
+        affine (gamma / beta folded into w / b by the caller)."""
+        _require_cuda(x, w, b)
+        y = torch.empty(x.shape[0], w.shape[0], device=x.device, dtype=x.dtype)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().fsvit_ln_linear_rows(_ptr(x), _ptr(y), _ptr(w), w.shape[-1], _ptr(b), x.shape[0], x.shape[1], w.shape[0], float(eps),
+                                                        _stream_ptr(x.device)))
+        return y
+
+    @staticmethod
     def vit_block_tail(x, ctx, wp, bp, w1, b1, w2, b2, eps=1e-6):
         """DeiT block tail (deit.py:69-72) on bf16 rows, (C, KC, hidden) = (384, 384, 1536): x1 = x + bp + ctx wp^T;
         y = x1 + b2 + W2 GELU(W1 LN(x1) + b1), LN without affine (norm2's gamma / beta folded into w1 / b1 by the caller)."""

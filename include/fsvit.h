@@ -191,6 +191,9 @@ int fsvit_proj_mlp_rows(const void* x_dev, void* y_dev, const void* ctx_dev, con
 int fsvit_vit_block_tail(const void* x_dev, void* y_dev, const void* ctx_dev, const void* wp_dev, int kpw, int KC, const float* bp_dev,
                          const void* w1_dev, int k1w, const float* b1_dev, const void* w2_dev, int k2w, const float* b2_dev, int M, int C, int hid,
                          float eps, void* stream);
+/* The ViT / DeiT block head up to the qkv Linear (deit.py:40-47,:69 `attn(norm1(x))`): y [M][N] = b + W LN(x [M][C]) on token-major bf16 rows,
+ * C = 384, N a multiple of 32, LN without affine (the caller folds norm1's gamma / beta into w [N][kw] / b). */
+int fsvit_ln_linear_rows(const void* x_dev, void* y_dev, const void* w_dev, int kw, const float* b_dev, int M, int C, int N, float eps, void* stream);
 /* ---------------------------------------------------------------- distillation head
  * Replaces, for sun_meta_training/offline.py: `LinearClassifier.forward` / its autograd (models/classifier.py:27-34) as used by
  * `TokenLabelOffline` (models/token_label.py:36-60) on the 25 tokens and on the pooled feature, `generate_softlabel`

@@ -486,6 +486,27 @@ def test_vit_block_tail_matches_unfused_math(M):
     assert torch.equal(yi, y0)
 
 
+@pytest.mark.parametrize('M,N', [(197, 1152), (128 * 70 + 5, 1152), (3000, 96)])
+def test_ln_linear_rows_matches_unfused_math(M, N):
+    """ln_gemm_rows (DeiT norm1 + qkv, deit.py:40-47,:69) against fp32 torch with the normalised rows rounded to bf16; repeats bit-identical."""
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    C, eps = 384, 1e-6
+    g = torch.Generator().manual_seed(M + N)
+    x = q(torch.randn(M, C, generator=g) * 2.0 + 0.5, bf)
+    w = q(torch.randn(N, C, generator=g) / math.sqrt(C), bf)
+    b = torch.randn(N, generator=g) * 0.3
+    ref = q(F.layer_norm(x, (C,), eps=eps), bf) @ w.t() + b
+    args = [x.to('cuda', bf), w.to('cuda', bf), b.cuda()]
+    y0 = ops.ln_linear_rows(*args, eps=eps)
+    torch.cuda.synchronize()
+    err = (y0.float().cpu() - ref).abs()
+    assert err.max().item() <= 4e-2 * max(1.0, float(ref.abs().max())), (M, N, err.max().item())
+    assert err.mean().item() <= 4e-3, (M, N, err.mean().item())
+    for _ in range(8):
+        assert torch.equal(ops.ln_linear_rows(*args, eps=eps), y0)
+
+
 def test_gemm256_large_shapes_repeatable_and_correct():
     """Race screen of the pipelined 256x256 kernel (counted-vmcnt LDS-DMA ring, cdna_hip_programming.md: a misplaced wait shows up as
     rare wrong tiles): several persistent items per workgroup, tails in M and N, 25 repeats must be bit-identical and match fp32."""
