@@ -132,6 +132,7 @@ struct BlockA {
   float* mlp_b1 = nullptr;
   int mlp_kc = 0;              // > 0: the image starts with the proj fragments and mlp_rows also computes x += proj(ctx)
   void* qa_img = nullptr;      // qkv_attn.hip: fragment-major image of the qkv conv (null: qkv GEMM + attention launches)
+  void* qr_img = nullptr;      // mlp_rows.hip gemm_rows: fragment-major image of the qkv conv (row-wise GEMM instead of the 256-tile one)
 };
 
 struct Tap { void* dst; size_t bytes; };
@@ -432,6 +433,13 @@ int build(fsvit_visformer* h, const SD& sd) {
         RC_TRY(K(launch_qkv_attn_pack)(blocks[i].qkv.w, blocks[i].qkv.Kw, img, nullptr));
         HIP_TRY(hipDeviceSynchronize());
         blocks[i].qa_img = img;
+      } else if (K(gemm_rows_supported)(kd(kdt), C, 3 * heads * hdp)) {      // stage 3: the qkv conv as a row-wise GEMM
+        void* img = nullptr;
+        HIP_TRY(hipMalloc(&img, K(ln_gemm_rows_image_bytes)(C, 3 * heads * hdp)));
+        h->allocs.push_back(img);
+        RC_TRY(K(launch_ln_gemm_pack)(blocks[i].qkv.w, blocks[i].qkv.Kw, img, C, 3 * heads * hdp, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        blocks[i].qr_img = img;
       }
     }
   }
@@ -519,7 +527,7 @@ int tap(EngineBase* h, const std::string& name, const void* src, size_t bytes, b
 }
 
 // kernel ids reported by the profiler (names in fsvit_kernel_name)
-enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_QKVATTN = 15, KID_STEMCONV1 = 16, KID_GCONV_X2 = 14, KID_STAGE1RING = 17 };
+enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_QKVATTN = 15, KID_STEMCONV1 = 16, KID_GCONV_X2 = 14, KID_STAGE1RING = 17, KID_LNGEMM = 18 };
 
 
 // Runs one launch; in profiling mode brackets it with HIP events on the same stream.
@@ -641,6 +649,10 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
         RC_TRY(timed(h, st, (sp + ".attn.qkv+core").c_str(), KID_QKVATTN, 2.0 * Bc * S * (3.0 * heads * hd) * C + 4.0 * Bc * heads * (double)S * S * hd,
                      [&]() { return K(launch_qkv_attn)(xs, ctx, b.qa_img, b.qkv.bias, Bc, S, scale, st); }));
       } else {
+      if (b.qr_img) {
+        RC_TRY(timed(h, st, (sp + ".attn.qkv").c_str(), KID_LNGEMM, 2.0 * Bc * S * (3.0 * heads * hd) * C,
+                     [&]() { return K(launch_gemm_rows)(xs, qkv, b.qr_img, b.qkv.bias, Bc * S, C, 3 * heads * hdp, st); }));
+      } else
       RC_TRY(run_gemm(h, st, (sp + ".attn.qkv").c_str(), b.qkv, conv_params(b.qkv, xs, qkv, Bc, Ho, Ho, C, C, 1, 1, 1, 0, 3 * heads * hdp, ACT_NONE, nullptr, 0, nullptr), 3.0 * heads * hd, C));
       RC_TRY(timed(h, st, (sp + ".attn.core").c_str(), KID_ATTN, 4.0 * Bc * heads * (double)S * S * hd,
                    [&]() { return K(launch_attention)(qkv, ctx, Bc, S, heads, hdp, scale, dt, st); }));
@@ -939,13 +951,15 @@ extern "C" int fsvit_vit_block_tail(const void* x, void* y, const void* ctx, con
 // (gamma / beta folded into w / b by the caller).  bf16, C = 384, N a multiple of 32.  Packs the weights on every call.
 extern "C" int fsvit_ln_linear_rows(const void* x, void* y, const void* w, int kw, const float* b, int M, int C, int N, float eps, void* stream) {
   const int kdt = FSVIT_BF16;
-  if (!x || !y || !w || !b) return fail(FSVIT_ERR_ARG, "null argument");
-  if (!K(ln_gemm_rows_supported)(1, C, N) || kw < C) return fail(FSVIT_ERR_ARG, "fsvit_ln_linear_rows: C = 384, N a multiple of 32, rows of at least C weights (bf16)");
+  if (!x || !y || !w || (!b && C != 512)) return fail(FSVIT_ERR_ARG, "null argument");
+  const bool plain = C == 512;      // the Visformer stage-3 geometry runs the same kernel without the LayerNorm (eps ignored)
+  if (!(plain ? K(gemm_rows_supported)(1, C, N) : K(ln_gemm_rows_supported)(1, C, N)) || kw < C)
+    return fail(FSVIT_ERR_ARG, "fsvit_ln_linear_rows: C = 384 (LayerNorm + Linear) or 512 (Linear only), N a multiple of 32, rows of at least C weights (bf16)");
   hipStream_t st = (hipStream_t)stream;
   void* img = nullptr;
   HIP_TRY(hipMalloc(&img, K(ln_gemm_rows_image_bytes)(C, N)));
   int rc = K(launch_ln_gemm_pack)(w, kw, img, C, N, st);
-  if (rc == 0) rc = K(launch_ln_gemm_rows)(x, y, img, b, M, C, N, eps, st);
+  if (rc == 0) rc = plain ? K(launch_gemm_rows)(x, y, img, b, M, C, N, st) : K(launch_ln_gemm_rows)(x, y, img, b, M, C, N, eps, st);
   (void)hipStreamSynchronize(st);
   (void)hipFree(img);
   if (rc != 0) return hipfail((hipError_t)rc, "fsvit_ln_linear_rows");
@@ -1257,7 +1271,7 @@ VitPlan make_vit_plan(const fsvit_vit* h, size_t Bc) {
   return p;
 }
 
-enum { KID_PATCHIFY = 10, KID_LN = 11, KID_LNGEMM = 18 };
+enum { KID_PATCHIFY = 10, KID_LN = 11 };
 
 int vit_forward_chunk(fsvit_vit* h, const float* x, int Bc, float* feat, unsigned char* ws, bool first, hipStream_t st) {
   const VitPlan pl = make_vit_plan(h, Bc);

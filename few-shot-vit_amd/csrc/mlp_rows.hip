@@ -62,9 +62,22 @@ constexpr int MR_FD = 6;                        // weight fragments read ahead o
 // The immediate offset of global_load_lds moves the LDS destination together with the global source (tools/probes/
 // ldsdma_offset.hip, measured on gfx950), so a linear copy needs no address arithmetic; the 13-bit offset field covers 4 pieces.
 template <int PW> __device__ __forceinline__ void mr_dma(unsigned voff, const void* sbase, unsigned lds) {
-  static_assert(PW == 8 || PW == 6 || PW == 3, "pieces per wave and slot");
+  static_assert(PW == 8 || PW == 6 || PW == 4 || PW == 3, "pieces per wave and slot");
   unsigned keep;
-  if constexpr (PW == 3)
+  if constexpr (PW == 4)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds)
+        : "memory");
+  else if constexpr (PW == 3)
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %3\n\t"
@@ -686,11 +699,13 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
 // pipelined by hand: the kernel needs < 256 registers and 53 KB of LDS, so TWO workgroups share a CU and one's row load / LayerNorm /
 // stores run under the other's MFMAs.  The stores share the vmcnt queue with the ring's DMAs: loads complete in order among loads, so
 // "at most PW operations outstanding" still implies that every older slot image has landed (stores can only make the wait longer).
-template <int C>
+// LN = false, C = 512: the plain row-wise Linear (the Visformer stage-3 qkv conv, visformer.py:175, eval BatchNorm folded: 7 x 7 tokens are past
+// what qkv_attn holds per image but the layer has the same 256-tile problem: K = 512 is 8 K tiles per epilogue, 753 TF/s).
+template <int C, bool LN>
 __global__ __launch_bounds__(256, 2) void ln_gemm_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
                                                               const float* __restrict__ bias, const float ln_eps, const int M, const int N,
                                                               const int n_tiles) {
-  constexpr int NKS = C / 16, SLF = 12, SPC = NKS / SLF;      // k-steps; fragments per ring slot; slots per chunk
+  constexpr int NKS = C / 16, SLF = NKS / 2, SPC = 2;         // k-steps; fragments per ring slot (12 / 16 KB); slots per chunk
   constexpr int SLOT = SLF * 1024, PW = SLF / MR_NW, WSH = PW * 1024, NST = 4, FD = 4;
   static_assert(NKS % SLF == 0 && SLF % MR_NW == 0, "whole slots");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -702,7 +717,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_rows_kernel(const bf16* __rest
   const unsigned voff = (unsigned)(wave * WSH + lane * 16);
   const int nch = N / 32, n_img = nch * SPC;
   if ((int)blockIdx.x >= n_tiles) return;
-  for (int i = t; i < N; i += MR_NW * 64) btab[i] = bias[i];
+  for (int i = t; i < N; i += MR_NW * 64) btab[i] = bias ? bias[i] : 0.0f;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
   // the ring of mlp_rows_kernel: image n issued after barrier n-3, waited for before barrier n-1, first read after barrier n
@@ -725,7 +740,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_rows_kernel(const bf16* __rest
     for (int s = 0; s < NKS; ++s) xr[s] = mr_gload16(X + row * C + 32 * (s >> 1) + 16 * kh + 8 * (s & 1));
     mr_wait_loads<NKS>(&xr[0]);
     if (first) { mr_bar(); first = false; }
-    mr_layernorm_rows<NKS, C>(xr, ln_eps);
+    if constexpr (LN) mr_layernorm_rows<NKS, C>(xr, ln_eps);
     bf16* const yrow = Y + row * N + 16 * kh;
 #pragma unroll 1
     for (int j = 0; j < nch; ++j) {
@@ -791,18 +806,21 @@ bool ln_gemm_rows_supported(int dtype, int C, int N) {
   static const bool on = [] { const char* e = getenv("FSVIT_LN_GEMM_ROWS"); return !e || e[0] != '0'; }();
   return on && dtype == 1 && C == 384 && N >= 32 && N % 32 == 0;
 }
+// the same kernel without the LayerNorm at C = 512 (Visformer stage-3 qkv); FSVIT_LN_GEMM_ROWS=0 turns both off
+bool gemm_rows_supported(int dtype, int C, int N) {
+  static const bool on = [] { const char* e = getenv("FSVIT_LN_GEMM_ROWS"); return !e || e[0] != '0'; }();
+  return on && dtype == 1 && C == 512 && N >= 32 && N % 32 == 0;
+}
 size_t ln_gemm_rows_image_bytes(int C, int N) { return (size_t)(N / 32) * (C / 16) * 1024; }
 int launch_ln_gemm_pack(const void* w, int kw, void* wimg, int C, int N, hipStream_t s) {
   const long n = (long)ln_gemm_rows_image_bytes(C, N) / 2;
   hipLaunchKernelGGL(ln_gemm_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)w, kw, (bf16*)wimg, C, N);
   return (int)hipGetLastError();
 }
-// y [M][N] = bias + W' LN(x [M][C])   (gamma / beta folded into W' / bias by the caller; image from launch_ln_gemm_pack)
-int launch_ln_gemm_rows(const void* x, void* y, const void* wimg, const float* bias, int M, int C, int N, float eps, hipStream_t s) {
-  if (M <= 0) return 0;
-  if (C != 384 || N % 32 || !bias) return (int)hipErrorInvalidValue;
-  auto kern = ln_gemm_rows_kernel<384>;
-  const int lds = 4 * 12 * 1024 + N * 4;
+template <int C, bool LN>
+static int launch_gemm_rows_t(const void* x, void* y, const void* wimg, const float* bias, int M, int N, float eps, hipStream_t s) {
+  auto kern = ln_gemm_rows_kernel<C, LN>;
+  const int lds = 4 * (C / 32) * 1024 + N * 4;
   static int lds_set = 0;
   if (lds > lds_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -813,6 +831,18 @@ int launch_ln_gemm_rows(const void* x, void* y, const void* wimg, const float* b
   const int grid = n_tiles < 512 ? n_tiles : 512;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(MR_NW * 64), lds, s, (const bf16*)x, (bf16*)y, (const unsigned char*)wimg, bias, eps, M, N, n_tiles);
   return (int)hipGetLastError();
+}
+// y [M][N] = bias + W' LN(x [M][C])   (gamma / beta folded into W' / bias by the caller; image from launch_ln_gemm_pack)
+int launch_ln_gemm_rows(const void* x, void* y, const void* wimg, const float* bias, int M, int C, int N, float eps, hipStream_t s) {
+  if (M <= 0) return 0;
+  if (C != 384 || N % 32) return (int)hipErrorInvalidValue;
+  return launch_gemm_rows_t<384, true>(x, y, wimg, bias, M, N, eps, s);
+}
+// y [M][N] = bias + W x [M][C]   (C = 512; bias may be null)
+int launch_gemm_rows(const void* x, void* y, const void* wimg, const float* bias, int M, int C, int N, hipStream_t s) {
+  if (M <= 0) return 0;
+  if (C != 512 || N % 32) return (int)hipErrorInvalidValue;
+  return launch_gemm_rows_t<512, false>(x, y, wimg, bias, M, N, 0.0f, s);
 }
 
 // Builds the fragment-major weight image + bias table from the engine's standard packed layers (w1 [HID][k1w], w2 [C][k2w], optional

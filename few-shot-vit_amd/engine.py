@@ -562,8 +562,9 @@ class ops:
     @staticmethod
     def ln_linear_rows(x, w, b, eps=1e-6):
         """y = b + LN(x) w^T on bf16 rows (x [M][384], w [N][>=384], N % 32 == 0): the DeiT block's norm1 + qkv (deit.py:40-47,:69), LN without
-        affine (gamma / beta folded into w / b by the caller)."""
-        _require_cuda(x, w, b)
+        affine (gamma / beta folded into w / b by the caller).  x [M][512]: the same row-wise kernel without the LayerNorm (Visformer stage-3
+        qkv, visformer.py:175), b may be None."""
+        _require_cuda(x, w)
         y = torch.empty(x.shape[0], w.shape[0], device=x.device, dtype=x.dtype)
         with torch.cuda.device(x.device):
             _lib.check(_lib.load().fsvit_ln_linear_rows(_ptr(x), _ptr(y), _ptr(w), w.shape[-1], _ptr(b), x.shape[0], x.shape[1], w.shape[0], float(eps),

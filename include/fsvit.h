@@ -192,7 +192,8 @@ int fsvit_vit_block_tail(const void* x_dev, void* y_dev, const void* ctx_dev, co
                          const void* w1_dev, int k1w, const float* b1_dev, const void* w2_dev, int k2w, const float* b2_dev, int M, int C, int hid,
                          float eps, void* stream);
 /* The ViT / DeiT block head up to the qkv Linear (deit.py:40-47,:69 `attn(norm1(x))`): y [M][N] = b + W LN(x [M][C]) on token-major bf16 rows,
- * C = 384, N a multiple of 32, LN without affine (the caller folds norm1's gamma / beta into w [N][kw] / b). */
+ * C = 384, N a multiple of 32, LN without affine (the caller folds norm1's gamma / beta into w [N][kw] / b).  C = 512: the same row-wise kernel
+ * WITHOUT the LayerNorm, y = b + W x (the Visformer stage-3 qkv conv with its eval BatchNorm folded, visformer.py:175; eps ignored, b may be NULL). */
 int fsvit_ln_linear_rows(const void* x_dev, void* y_dev, const void* w_dev, int kw, const float* b_dev, int M, int C, int N, float eps, void* stream);
 /* ---------------------------------------------------------------- distillation head
  * Replaces, for sun_meta_training/offline.py: `LinearClassifier.forward` / its autograd (models/classifier.py:27-34) as used by

@@ -507,6 +507,27 @@ def test_ln_linear_rows_matches_unfused_math(M, N):
         assert torch.equal(ops.ln_linear_rows(*args, eps=eps), y0)
 
 
+@pytest.mark.parametrize('M,N,bias', [(49 * 5, 1728, True), (128 * 90 + 33, 1728, False)])
+def test_linear_rows_c512_matches_fp32(M, N, bias):
+    """The row-wise GEMM without LayerNorm at the Visformer stage-3 qkv geometry (C = 512, N = 3 x 6 x 96) against fp32 torch."""
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    C = 512
+    g = torch.Generator().manual_seed(M + N)
+    x = q(torch.randn(M, C, generator=g), bf)
+    w = q(torch.randn(N, C, generator=g) / math.sqrt(C), bf)
+    b = torch.randn(N, generator=g) * 0.3 if bias else None
+    ref = x @ w.t() + (b if bias else 0.0)
+    args = [x.to('cuda', bf), w.to('cuda', bf), b.cuda() if bias else None]
+    y0 = ops.ln_linear_rows(*args)
+    torch.cuda.synchronize()
+    err = (y0.float().cpu() - ref).abs()
+    assert err.max().item() <= 2e-2 * max(1.0, float(ref.abs().max())), (M, N, err.max().item())
+    assert err.mean().item() <= 3e-3, (M, N, err.mean().item())
+    for _ in range(8):
+        assert torch.equal(ops.ln_linear_rows(*args), y0)
+
+
 def test_gemm256_large_shapes_repeatable_and_correct():
     """Race screen of the pipelined 256x256 kernel (counted-vmcnt LDS-DMA ring, cdna_hip_programming.md: a misplaced wait shows up as
     rare wrong tiles): several persistent items per workgroup, tails in M and N, 25 repeats must be bit-identical and match fp32."""
