@@ -62,9 +62,20 @@ constexpr int MR_FD = 6;                        // weight fragments read ahead o
 // The immediate offset of global_load_lds moves the LDS destination together with the global source (tools/probes/
 // ldsdma_offset.hip, measured on gfx950), so a linear copy needs no address arithmetic; the 13-bit offset field covers 4 pieces.
 template <int PW> __device__ __forceinline__ void mr_dma(unsigned voff, const void* sbase, unsigned lds) {
-  static_assert(PW == 8 || PW == 6 || PW == 4 || PW == 3, "pieces per wave and slot");
+  static_assert(PW == 8 || PW == 6 || PW == 4 || PW == 3 || PW == 2, "pieces per wave and slot");
   unsigned keep;
-  if constexpr (PW == 4)
+  if constexpr (PW == 2)
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds)
+        : "memory");
+  else if constexpr (PW == 4)
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %3\n\t"
@@ -192,8 +203,34 @@ __device__ __forceinline__ void mfma32_a_zero(f32x16& c) {
   asm volatile("s_nop 7\n\t" FSVIT_MFMA_32x32x16 " %0, %1, %1, 0" : "=a"(c) : "v"(z));      // s_nop: VALU-written z -> MFMA SrcA/B
 }
 
+// cache policy of the rows GEMM's streaming accesses (tools/build_variant.sh sweeps): 0 default, 1 nt, 2 sc0 sc1 nt, 3 sc1
+#ifndef LGR_ST_POL
+#define LGR_ST_POL 0
+#endif
+#ifndef LGR_LD_POL
+#define LGR_LD_POL 0
+#endif
+#if LGR_ST_POL == 1
+#define LGR_ST_MOD " nt"
+#elif LGR_ST_POL == 2
+#define LGR_ST_MOD " sc0 sc1 nt"
+#elif LGR_ST_POL == 3
+#define LGR_ST_MOD " sc1"
+#else
+#define LGR_ST_MOD ""
+#endif
+#if LGR_LD_POL == 1
+#define LGR_LD_MOD " nt"
+#else
+#define LGR_LD_MOD ""
+#endif
 __device__ __forceinline__ void mr_gstore16(void* p, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off" LGR_ST_MOD :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ u32x4 mr_gload16s(const void* p) {      // streaming row load of the rows GEMM
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" LGR_LD_MOD : "=v"(v) : "v"(p) : "memory");
+  return v;
 }
 
 // LayerNorm (no affine) of token rows held as MFMA B operands: lane (r, kh) has half of token r's C channels in NKS 16-byte registers, the
@@ -556,7 +593,10 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
     // Seven per MFMA already stretch the MFMA slot by ~20 % (mfma_valu_overlap probe); six cost ~10 %.  The stage that reads the
     // accumulator (A1) may not slip behind the restart of its chain (slot 28 for row block 0, 46 for row block 1): the last pairs of
     // row block 1 run A1 early and carry (x, u) in registers.
-    constexpr int CAD2 = RB == 2 ? 7 : 8;
+#ifndef MR_CAD384
+#define MR_CAD384 8
+#endif
+    constexpr int CAD2 = RB == 2 ? 7 : (SL == 24 ? MR_CAD384 : 8);
     constexpr int O_A2 = 1, O_E = 2, O_BA = RB == 2 ? 4 : 3, O_BR = RB == 2 ? 5 : 4, O_C = RB == 2 ? 6 : 7;
     auto st = [](int q) { return q * CAD2 / 2; };
     auto st_a1 = [&](int q) { const int lim = (RB == 2 ? 45 : SL - 4) - (NP - 1 - q); return (RB == 1 || q >= 8) && st(q) > lim ? lim : st(q); };
@@ -701,12 +741,18 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
 // "at most PW operations outstanding" still implies that every older slot image has landed (stores can only make the wait longer).
 // LN = false, C = 512: the plain row-wise Linear (the Visformer stage-3 qkv conv, visformer.py:175, eval BatchNorm folded: 7 x 7 tokens are past
 // what qkv_attn holds per image but the layer has the same 256-tile problem: K = 512 is 8 K tiles per epilogue, 753 TF/s).
-template <int C, bool LN>
+// Measured (tools/bench_rows_gemm.py under rocprofv3, -DLGR_DIAG variants; C = 384 / 512): 818 / 850 TFLOP/s.  Every MFMA reads a fresh 1 KB
+// fragment (one row block per wave), which is exactly the CU's 128 B/clk of LDS at the full MFMA rate - without the stores and the ring
+// traffic the loop reaches 1130 TF/s.  Dropping the stores gains 25 %, the ring refill 15 %, the barriers nothing.  What did NOT help the
+// store cost: a deeper ring (slots x depth 2 x 4 ... 3 x 9, so that a wait leaves up to three images and the store acknowledgements in flight),
+// whole 64-byte segments per store instruction (v_permlane16_swap of the two pieces between rows r and r + 16), even whole 128-byte lines
+// (wrong layout, same bytes: -4 %); `nt` / `sc1` stores are 1.5 ... 2 x slower (the partial lines are no longer merged in L2).
+template <int C, bool LN, int SPC, int NST>
 __global__ __launch_bounds__(256, 2) void ln_gemm_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
                                                               const float* __restrict__ bias, const float ln_eps, const int M, const int N,
                                                               const int n_tiles) {
-  constexpr int NKS = C / 16, SLF = NKS / 2, SPC = 2;         // k-steps; fragments per ring slot (12 / 16 KB); slots per chunk
-  constexpr int SLOT = SLF * 1024, PW = SLF / MR_NW, WSH = PW * 1024, NST = 4, FD = 4;
+  constexpr int NKS = C / 16, SLF = NKS / SPC;                // k-steps; fragments per ring slot; SPC slots per chunk
+  constexpr int SLOT = SLF * 1024, PW = SLF / MR_NW, WSH = PW * 1024, FD = 4, LAG = (NST - 3) * PW;
   static_assert(NKS % SLF == 0 && SLF % MR_NW == 0, "whole slots");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* const btab = reinterpret_cast<float*>(smem + NST * SLOT);
@@ -737,7 +783,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_rows_kernel(const bf16* __rest
     const size_t row = (size_t)(mok ? m : M - 1);
     u32x4 xr[NKS];
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) xr[s] = mr_gload16(X + row * C + 32 * (s >> 1) + 16 * kh + 8 * (s & 1));
+    for (int s = 0; s < NKS; ++s) xr[s] = mr_gload16s(X + row * C + 32 * (s >> 1) + 16 * kh + 8 * (s & 1));
     mr_wait_loads<NKS>(&xr[0]);
     if (first) { mr_bar(); first = false; }
     if constexpr (LN) mr_layernorm_rows<NKS, C>(xr, ln_eps);
@@ -756,9 +802,13 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_rows_kernel(const bf16* __rest
       }
 #pragma unroll
       for (int h = 0; h < SPC; ++h) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory");
+#if !(defined(LGR_DIAG) && (LGR_DIAG & 2))
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LAG) : "memory");
         mr_bar();
+#endif
+#if !(defined(LGR_DIAG) && (LGR_DIAG & 8))
         issue();
+#endif
         unsigned a = slot * SLOT + lane * 16;
         asm volatile("" : "+v"(a));
         const unsigned char* sp = smem + a;
@@ -781,7 +831,12 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_rows_kernel(const bf16* __rest
         o0[e] = mr_pk2(hacc[2 * e], hacc[2 * e + 1]);
         o1[e] = mr_pk2(hacc[8 + 2 * e], hacc[8 + 2 * e + 1]);
       }
-      if (mok) {
+#if defined(LGR_DIAG) && (LGR_DIAG & 1)
+      if (o0[0] == 0x12345678u)
+#else
+      if (mok)
+#endif
+      {
         mr_gstore16(yrow + j * 32, o0);
         mr_gstore16(yrow + j * 32 + 8, o1);
       }
@@ -817,10 +872,18 @@ int launch_ln_gemm_pack(const void* w, int kw, void* wimg, int C, int N, hipStre
   hipLaunchKernelGGL(ln_gemm_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)w, kw, (bf16*)wimg, C, N);
   return (int)hipGetLastError();
 }
-template <int C, bool LN>
+#ifndef LGR_SPC384     // ring geometry (tools/build_variant.sh sweeps)
+#define LGR_SPC384 2
+#define LGR_NST384 4
+#endif
+#ifndef LGR_SPC512
+#define LGR_SPC512 2
+#define LGR_NST512 4
+#endif
+template <int C, bool LN, int SPC, int NST>
 static int launch_gemm_rows_t(const void* x, void* y, const void* wimg, const float* bias, int M, int N, float eps, hipStream_t s) {
-  auto kern = ln_gemm_rows_kernel<C, LN>;
-  const int lds = 4 * (C / 32) * 1024 + N * 4;
+  auto kern = ln_gemm_rows_kernel<C, LN, SPC, NST>;
+  const int lds = NST * (C / 16 / SPC) * 1024 + N * 4;
   static int lds_set = 0;
   if (lds > lds_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -836,13 +899,13 @@ static int launch_gemm_rows_t(const void* x, void* y, const void* wimg, const fl
 int launch_ln_gemm_rows(const void* x, void* y, const void* wimg, const float* bias, int M, int C, int N, float eps, hipStream_t s) {
   if (M <= 0) return 0;
   if (C != 384 || N % 32) return (int)hipErrorInvalidValue;
-  return launch_gemm_rows_t<384, true>(x, y, wimg, bias, M, N, eps, s);
+  return launch_gemm_rows_t<384, true, LGR_SPC384, LGR_NST384>(x, y, wimg, bias, M, N, eps, s);
 }
 // y [M][N] = bias + W x [M][C]   (C = 512; bias may be null)
 int launch_gemm_rows(const void* x, void* y, const void* wimg, const float* bias, int M, int C, int N, hipStream_t s) {
   if (M <= 0) return 0;
   if (C != 512 || N % 32) return (int)hipErrorInvalidValue;
-  return launch_gemm_rows_t<512, false>(x, y, wimg, bias, M, N, 0.0f, s);
+  return launch_gemm_rows_t<512, false, LGR_SPC512, LGR_NST512>(x, y, wimg, bias, M, N, 0.0f, s);
 }
 
 // Builds the fragment-major weight image + bias table from the engine's standard packed layers (w1 [HID][k1w], w2 [C][k2w], optional

@@ -1,6 +1,6 @@
 """Stage-wise debug of the fused DeiT block tail (mlp_rows LN variant): zeroes parts of the problem to localise an error."""
-import math, sys, torch, torch.nn.functional as F
-sys.path.insert(0, '.')
+import math, os, sys, torch, torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fewshot_vit_amd.engine import ops
 bf = torch.bfloat16
 q = lambda t: t.to(bf).float()
