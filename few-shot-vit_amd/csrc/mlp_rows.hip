@@ -763,6 +763,9 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_rows_kernel(const bf16* __rest
   const unsigned voff = (unsigned)(wave * WSH + lane * 16);
   const int nch = N / 32, n_img = nch * SPC;
   if ((int)blockIdx.x >= n_tiles) return;
+#ifdef MR_PAD     // code-placement screen (tools/screen_mlp_rows.sh)
+  asm volatile(".rept %0\n\ts_nop 0\n\t.endr" :: "n"(MR_PAD));
+#endif
   for (int i = t; i < N; i += MR_NW * 64) btab[i] = bias ? bias[i] : 0.0f;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 

@@ -44,3 +44,30 @@ def test_qkv_attention_is_deterministic_at_bench_size():
     w = w.reshape(3 * heads * hdp, 256).to(bf)
     bias = rn(3 * heads * hdp) * 0.3
     assert _repeat(lambda: ops.qkv_attention(x, w, bias, B, S, heads, hdp, hd ** -0.5), 40) == 0
+
+
+def test_vit_block_tail_is_deterministic_at_bench_size():
+    """mlp_rows at C = 384 (24-fragment ring slots, LayerNorm variant): 30 bench-size launches bit-identical and finite."""
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    M, C, KC, HID = 3200 * 197, 384, 384, 1536
+    g = torch.Generator(device='cuda').manual_seed(11)
+    rn = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    x, ctx = rn(M, C).to(bf), rn(M, KC).to(bf)
+    wp = (rn(C, KC) / math.sqrt(KC)).to(bf)
+    w1, w2 = (rn(HID, C) / math.sqrt(C)).to(bf), (rn(C, HID) / math.sqrt(HID)).to(bf)
+    bp, b1, b2 = rn(C) * 0.3, rn(HID) * 0.3, rn(C) * 0.3
+    assert _repeat(lambda: ops.vit_block_tail(x, ctx, wp, bp, w1, b1, w2, b2), 30) == 0
+
+
+@pytest.mark.parametrize('C,N,M', [(384, 1152, 3200 * 197), (512, 1728, 12800 * 25)])
+def test_ln_linear_rows_is_deterministic_at_bench_size(C, N, M):
+    """ln_gemm_rows (two workgroups per CU on one LDS-DMA ring each): 40 bench-size launches bit-identical and finite."""
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    g = torch.Generator(device='cuda').manual_seed(C)
+    rn = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    x = rn(M, C).to(bf)
+    w = (rn(N, C) / math.sqrt(C)).to(bf)
+    b = rn(N) * 0.3
+    assert _repeat(lambda: ops.ln_linear_rows(x, w, b), 40) == 0
