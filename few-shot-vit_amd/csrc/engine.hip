@@ -133,6 +133,7 @@ struct BlockA {
   int mlp_kc = 0;              // > 0: the image starts with the proj fragments and mlp_rows also computes x += proj(ctx)
   void* qa_img = nullptr;      // qkv_attn.hip: fragment-major image of the qkv conv (null: qkv GEMM + attention launches)
   void* qr_img = nullptr;      // mlp_rows.hip gemm_rows: fragment-major image of the qkv conv (row-wise GEMM instead of the 256-tile one)
+  void* qar_img = nullptr;     // mlp_rows.hip qkv_attn_rows: head-major image of the qkv conv (qkv + attention in one launch, maps of <= 32 tokens)
 };
 
 struct Tap { void* dst; size_t bytes; };
@@ -433,6 +434,13 @@ int build(fsvit_visformer* h, const SD& sd) {
         RC_TRY(K(launch_qkv_attn_pack)(blocks[i].qkv.w, blocks[i].qkv.Kw, img, nullptr));
         HIP_TRY(hipDeviceSynchronize());
         blocks[i].qa_img = img;
+      } else if (K(qkv_attn_rows_supported)(kd(kdt), C, heads, hdp, (s == 2 ? h->H2 : h->H3) * (s == 2 ? h->H2 : h->H3))) {   // stage 3, <= 32 tokens
+        void* img = nullptr;
+        HIP_TRY(hipMalloc(&img, K(ln_gemm_rows_image_bytes)(C, 3 * heads * hdp)));
+        h->allocs.push_back(img);
+        RC_TRY(K(launch_qkv_attn_rows_pack)(blocks[i].qkv.w, blocks[i].qkv.Kw, img, C, heads, hdp, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        blocks[i].qar_img = img;
       } else if (K(gemm_rows_supported)(kd(kdt), C, 3 * heads * hdp)) {      // stage 3: the qkv conv as a row-wise GEMM
         void* img = nullptr;
         HIP_TRY(hipMalloc(&img, K(ln_gemm_rows_image_bytes)(C, 3 * heads * hdp)));
@@ -527,7 +535,7 @@ int tap(EngineBase* h, const std::string& name, const void* src, size_t bytes, b
 }
 
 // kernel ids reported by the profiler (names in fsvit_kernel_name)
-enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_QKVATTN = 15, KID_STEMCONV1 = 16, KID_GCONV_X2 = 14, KID_STAGE1RING = 17, KID_LNGEMM = 18 };
+enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_QKVATTN = 15, KID_STEMCONV1 = 16, KID_GCONV_X2 = 14, KID_STAGE1RING = 17, KID_LNGEMM = 18, KID_QKVATTNROWS = 19 };
 
 
 // Runs one launch; in profiling mode brackets it with HIP events on the same stream.
@@ -648,6 +656,9 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
       if (b.qa_img) {     // qkv conv + attention core in one launch: q / k / v never leave the chip
         RC_TRY(timed(h, st, (sp + ".attn.qkv+core").c_str(), KID_QKVATTN, 2.0 * Bc * S * (3.0 * heads * hd) * C + 4.0 * Bc * heads * (double)S * S * hd,
                      [&]() { return K(launch_qkv_attn)(xs, ctx, b.qa_img, b.qkv.bias, Bc, S, scale, st); }));
+      } else if (b.qar_img) {
+        RC_TRY(timed(h, st, (sp + ".attn.qkv+core").c_str(), KID_QKVATTNROWS, 2.0 * Bc * S * (3.0 * heads * hd) * C + 4.0 * Bc * heads * (double)S * S * hd,
+                     [&]() { return K(launch_qkv_attn_rows)(xs, ctx, b.qar_img, b.qkv.bias, Bc, S, C, heads, hdp, scale, st); }));
       } else {
       if (b.qr_img) {
         RC_TRY(timed(h, st, (sp + ".attn.qkv").c_str(), KID_LNGEMM, 2.0 * Bc * S * (3.0 * heads * hd) * C,
@@ -1016,10 +1027,21 @@ extern "C" int fsvit_qkv_attention(const void* x, const void* wqkv, int kw, cons
                                    float scale, void* stream) {
   const int kdt = FSVIT_BF16;
   if (!x || !wqkv || !ctx) return fail(FSVIT_ERR_ARG, "null argument");
-  if (!K(qkv_attn_supported)(1, C, heads, hdp, S) || kw < C)
-    return fail(FSVIT_ERR_ARG, "fsvit_qkv_attention: only C = 256, 6 heads x 48 (padded), S <= 112 (bf16) is built");
   hipStream_t st = (hipStream_t)stream;
   void* img = nullptr;
+  if (C == 512) {       // the rows kernel (stage-3 geometry: head dim padded to 96, maps of at most 32 tokens)
+    if (!K(qkv_attn_rows_supported)(1, C, heads, hdp, S) || kw < C)
+      return fail(FSVIT_ERR_ARG, "fsvit_qkv_attention: C = 512 needs head dim 96 (padded) and S <= 32 (bf16)");
+    HIP_TRY(hipMalloc(&img, K(ln_gemm_rows_image_bytes)(C, 3 * heads * hdp)));
+    int rc = K(launch_qkv_attn_rows_pack)(wqkv, kw, img, C, heads, hdp, st);
+    if (rc == 0) rc = K(launch_qkv_attn_rows)(x, ctx, img, bias, B, S, C, heads, hdp, scale, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(img);
+    if (rc != 0) return hipfail((hipError_t)rc, "fsvit_qkv_attention");
+    return 0;
+  }
+  if (!K(qkv_attn_supported)(1, C, heads, hdp, S) || kw < C)
+    return fail(FSVIT_ERR_ARG, "fsvit_qkv_attention: only C = 256, 6 heads x 48 (padded), S <= 112 (bf16) is built");
   HIP_TRY(hipMalloc(&img, K(qkv_attn_image_bytes)()));
   int rc = K(launch_qkv_attn_pack)(wqkv, kw, img, st);
   if (rc == 0) rc = K(launch_qkv_attn)(x, ctx, img, bias, B, S, scale, st);
@@ -1075,15 +1097,15 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
   static const char* f32n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
                                "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<float,128,128,2,2,2>",
-                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel"};
+                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel", "qkv_attn_rows_kernel"};
   static const char* bf16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
                                 "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<__bf16,128,128,2,2,2>",
-                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel"};
+                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel", "qkv_attn_rows_kernel"};
   static const char* f16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<_Float16,128,64,2,2,3>", "conv_gemm_v2_kernel<_Float16,128,32,4,1,3>",
                                "im2col27_kernel<_Float16>", "maxpool2_pos_kernel<_Float16>", "attention_v2_kernel<_Float16,...>", "pool_affine_kernel<_Float16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<_Float16,128,128,2,2,2>",
-                               "patchify_kernel<_Float16>", "layernorm_kernel<_Float16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel"};
+                               "patchify_kernel<_Float16>", "layernorm_kernel<_Float16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel", "qkv_attn_rows_kernel"};
   static const char* x2n[] = {"gemm256_x2_kernel", "conv_gemm_v2_kernel<f32x2l,128,64,2,2,3>", "conv_gemm_v2_kernel<f32x2l,128,32,4,1,3>", "", "", "", "", "", "", "conv_gemm_v2_kernel<f32x2l,128,128,2,2,2>"};
-  if (kernel_id < 0 || kernel_id > 18) return "?";
+  if (kernel_id < 0 || kernel_id > 19) return "?";
   if (is_x2(dtype)) return kernel_id == 14 ? "gconv3x3_x2_kernel" : (kernel_id == 0 || kernel_id == 1 || kernel_id == 2 || kernel_id == 9) ? x2n[kernel_id] : f32n[kernel_id];
   return dtype == FSVIT_F32 ? f32n[kernel_id] : dtype == FSVIT_F16 ? f16n[kernel_id] : bf16n[kernel_id];
 }

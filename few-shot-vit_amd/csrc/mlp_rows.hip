@@ -848,14 +848,198 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_rows_kernel(const bf16* __rest
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may be in flight into the LDS of a finished workgroup
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// qkv conv + attention core for token maps of at most 32 tokens (Visformer stage 3 at 80 x 80: 25 tokens, C = 512, 6 heads x 96 padded;
+// visformer.py:172-190) - the row-wise GEMM above with one image per wave, so that q, k and v of an image never leave its registers:
+//   * per head, the weight stream delivers the chunks K0..2, Q0..2, V0..2 (32 channels each; packed in that order).  A K / Q chunk is the
+//     usual D[channel][token] (A = W fragment, B = x rows): a lane (token, kh) holds 16 channels, which packed to bf16 are the two k-steps of
+//     an MFMA operand with the token as its row - K as A, Q as B of  S^T[key][query] += K Q^T  (the same trick as GEMM1 -> GEMM2 of mlp_rows);
+//   * S^T leaves a query's 32 keys in the 16 accumulators of its two lanes: mask (keys >= S), max / sum with one lane exchange each, exp2;
+//     the probabilities packed to bf16 are the B operand P[query][key] of the next product;
+//   * a V chunk is computed with the operands SWAPPED (A = x rows, B = W fragment - both are "32 rows x 8 k per lane", so the same registers
+//     serve either side): D[token][channel] = V^T with the keys in the accumulators of lane (channel, kh) in exactly the key order of S^T -
+//     packed, it is the A operand of  O^T[d][query] = V^T P^T  without any transpose through LDS; the fragment-row permutation of the image
+//     makes lane (query, kh) end up with 16 consecutive head channels = two 16-byte stores.
+// 7 of a wave's 32 rows are padding at S = 25 (masked as keys, never stored as queries): 28 % more MFMAs than the plain GEMM, in exchange
+// for the qkv tensor (2.2 GB per launch written and read back) and the attention launch.
+template <int C, int HDC>
+__global__ __launch_bounds__(256, 2) void qkv_attn_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ CTX, const unsigned char* __restrict__ wimg,
+                                                               const float* __restrict__ bias, const float scale_log2e, const int B, const int S,
+                                                               const int heads, const int n_tiles) {
+  constexpr int NKS = C / 16, SPC = 2, SLF = NKS / SPC, NST = 4, FD = 4;
+  constexpr int SLOT = SLF * 1024, PW = SLF / MR_NW, WSH = PW * 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const btab = reinterpret_cast<float*>(smem + NST * SLOT);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, kh = lane >> 5;
+  const unsigned lds0 = (unsigned)(size_t)(lptrm_t)smem;
+  const unsigned voff = (unsigned)(wave * WSH + lane * 16);
+  const int HD = HDC * 32, N = 3 * heads * HD, n_img = (N / 32) * SPC;
+  if ((int)blockIdx.x >= n_tiles) return;
+#ifdef MR_PAD     // code-placement screen (tools/screen_mlp_rows.sh)
+  asm volatile(".rept %0\n\ts_nop 0\n\t.endr" :: "n"(MR_PAD));
+#endif
+  for (int i = t; i < N; i += MR_NW * 64) btab[i] = bias ? bias[i] : 0.0f;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+  int issue_img = 0, issue_slot = 0, slot = 0;
+  auto issue = [&]() {
+    mr_dma<PW>(voff, wimg + (size_t)issue_img * SLOT, lds0 + issue_slot * SLOT + wave * WSH);
+    issue_img = issue_img == n_img - 1 ? 0 : issue_img + 1;
+    issue_slot = issue_slot == NST - 1 ? 0 : issue_slot + 1;
+  };
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i) issue();
+  bool first = true;
+  const int perm = 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);      // fragment row r <-> channel perm of its chunk (pack kernel)
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int img = tile * MR_NW + wave;
+    const bool ok = img < B && r < S;
+    const size_t row = (size_t)(img < B ? img : B - 1) * S + (r < S ? r : S - 1);
+    u32x4 xr[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) xr[s] = mr_gload16s(X + row * C + 32 * (s >> 1) + 16 * kh + 8 * (s & 1));
+    mr_wait_loads<NKS>(&xr[0]);
+    if (first) { mr_bar(); first = false; }
+    bf16* const crow = CTX + row * (size_t)(heads * HD) + 16 * kh;
+
+    // one chunk of 32 output channels: NKS MFMAs over the two ring slots of its fragments.  swapped: A = x rows, B = fragment -> D[token][channel]
+    auto chunk = [&](auto swapped_, f32x16& acc) {
+      constexpr bool SW = decltype(swapped_)::value;
+#pragma unroll
+      for (int h2 = 0; h2 < SPC; ++h2) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory");
+        mr_bar();
+        issue();
+        unsigned a = slot * SLOT + lane * 16;
+        asm volatile("" : "+v"(a));
+        const unsigned char* sp = smem + a;
+        slot = slot == NST - 1 ? 0 : slot + 1;
+        u32x4 fr[FD];
+#pragma unroll
+        for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < SLF; ++i) {
+          if constexpr (SW) mfma32_v(xr[h2 * SLF + i], fr[i % FD], acc);
+          else mfma32_v(fr[i % FD], xr[h2 * SLF + i], acc);
+          if (i + FD < SLF) fr[i % FD] = *reinterpret_cast<const u32x4*>(sp + (i + FD) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));          // wait states MFMA -> VALU read of the accumulator
+    };
+    auto bias_rows = [&](f32x16& acc, int src) {                 // D[channel][token]: lane (token, kh) holds channels 16 kh + i
+      const float* bp = btab + src * 32 + kh * 16;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bp + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = b[e];
+      }
+    };
+    auto pack2 = [&](const f32x16& acc, u32x4 (&o)[2]) {          // accumulators 8 t .. 8 t + 7 -> k-step t of an MFMA operand
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[tt][e] = mr_pk2(acc[8 * tt + 2 * e], acc[8 * tt + 2 * e + 1]);
+    };
+    using yes_t = std::integral_constant<bool, true>;
+    using no_t = std::integral_constant<bool, false>;
+
+#pragma unroll 1
+    for (int h = 0; h < heads; ++h) {
+      u32x4 kp[HDC][2];
+#pragma unroll
+      for (int c = 0; c < HDC; ++c) {
+        f32x16 acc;
+        bias_rows(acc, (heads + h) * HDC + c);
+        chunk(no_t{}, acc);
+        pack2(acc, kp[c]);
+      }
+      f32x16 sacc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sacc[i] = 0.0f;
+#pragma unroll
+      for (int c = 0; c < HDC; ++c) {
+        f32x16 acc;
+        bias_rows(acc, h * HDC + c);
+        chunk(no_t{}, acc);
+        u32x4 qp[2];
+        pack2(acc, qp);
+        asm volatile("s_nop 7" : "+v"(qp[0]), "+v"(qp[1]), "+v"(kp[c][0]), "+v"(kp[c][1]), "+v"(sacc));     // VALU-written operands -> MFMA
+        mfma32_v(kp[c][0], qp[0], sacc);
+        mfma32_v(kp[c][1], qp[1], sacc);
+      }
+      asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc));
+      // softmax over the 32 keys of this lane pair: accumulator i <-> key 8 (i >> 2) + 4 kh + (i & 3)
+      float pv[16], mx = -3.0e38f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        pv[i] = (8 * (i >> 2) + 4 * kh + (i & 3)) < S ? sacc[i] : -3.0e38f;
+        mx = fmaxf(mx, pv[i]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        pv[i] = __builtin_amdgcn_exp2f((pv[i] - mx) * scale_log2e);
+        sum += pv[i];
+      }
+      sum += __shfl_xor(sum, 32);
+      const float inv = __builtin_amdgcn_rcpf(sum);
+      u32x4 pp[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pp[tt][e] = mr_pk2(pv[8 * tt + 2 * e], pv[8 * tt + 2 * e + 1]);
+#pragma unroll
+      for (int c = 0; c < HDC; ++c) {
+        f32x16 acc;
+        const float bv = btab[((2 * heads + h) * HDC + c) * 32 + perm];       // D[token][channel]: lane = channel, every accumulator a token
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = bv;
+        chunk(yes_t{}, acc);
+        u32x4 vp[2];
+        pack2(acc, vp);
+        asm volatile("s_nop 7" : "+v"(vp[0]), "+v"(vp[1]), "+v"(pp[0]), "+v"(pp[1]));
+        f32x16 oacc;
+        mfma32_v_z(vp[0], pp[0], oacc);
+        mfma32_v(vp[1], pp[1], oacc);
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(oacc));
+        u32x4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o0[e] = mr_pk2(oacc[2 * e] * inv, oacc[2 * e + 1] * inv);
+          o1[e] = mr_pk2(oacc[8 + 2 * e] * inv, oacc[8 + 2 * e + 1] * inv);
+        }
+        if (ok) {
+          mr_gstore16(crow + h * HD + c * 32, o0);
+          mr_gstore16(crow + h * HD + c * 32 + 8, o1);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // image for ln_gemm_rows_kernel from a standard packed layer w [N][kw] (K-contiguous rows): fragment (chunk j, k-step s), lane = 32 kh + r, e8:
 //   W[32 j + 16 (r>>2 & 1) + 4 (r>>3) + (r & 3)][32 (s>>1) + 16 kh + 8 (s&1) + e8]   (accumulator i of lane (token, kh) = channel 32 j + 16 kh + i)
-__global__ void ln_gemm_pack_kernel(const bf16* __restrict__ w, int kw, bf16* __restrict__ wimg, int C, int N) {
+// heads > 0 (qkv_attn_rows_kernel; rows of w = (q | k | v, head, hdc chunks of 32)): image chunk (head h, part K | Q | V, c) = w's chunk
+// ((k, q, v)[part] * heads + h) * hdc + c
+__global__ void ln_gemm_pack_kernel(const bf16* __restrict__ w, int kw, bf16* __restrict__ wimg, int C, int N, int heads, int hdc) {
   const int NKS = C / 16;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)(N / 32) * NKS * 512) return;
   const int g = (int)(idx >> 9), lane = (int)(idx >> 3) & 63, e8 = (int)idx & 7;
-  const int j = g / NKS, s = g % NKS, kh = lane >> 5, r = lane & 31;
+  int j = g / NKS;
+  if (heads > 0) {
+    const int h = j / (3 * hdc), part = (j / hdc) % 3, c = j % hdc;
+    j = ((part == 0 ? 1 : part == 1 ? 0 : 2) * heads + h) * hdc + c;
+  }
+  const int s = g % NKS, kh = lane >> 5, r = lane & 31;
   const int n = 32 * j + 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
   wimg[idx] = w[(size_t)n * kw + 32 * (s >> 1) + 16 * kh + 8 * (s & 1) + e8];
 }
@@ -872,7 +1056,36 @@ bool gemm_rows_supported(int dtype, int C, int N) {
 size_t ln_gemm_rows_image_bytes(int C, int N) { return (size_t)(N / 32) * (C / 16) * 1024; }
 int launch_ln_gemm_pack(const void* w, int kw, void* wimg, int C, int N, hipStream_t s) {
   const long n = (long)ln_gemm_rows_image_bytes(C, N) / 2;
-  hipLaunchKernelGGL(ln_gemm_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)w, kw, (bf16*)wimg, C, N);
+  hipLaunchKernelGGL(ln_gemm_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)w, kw, (bf16*)wimg, C, N, 0, 0);
+  return (int)hipGetLastError();
+}
+// qkv conv + attention on the rows kernel: C = 512, head dim padded to 96, maps of at most 32 tokens; FSVIT_QKV_ATTN_ROWS=0 turns it off
+bool qkv_attn_rows_supported(int dtype, int C, int heads, int hdp, int S) {
+  static const bool on = [] { const char* e = getenv("FSVIT_QKV_ATTN_ROWS"); return !e || e[0] != '0'; }();
+  return on && dtype == 1 && C == 512 && hdp == 96 && heads >= 1 && S >= 1 && S <= 32;
+}
+int launch_qkv_attn_rows_pack(const void* w, int kw, void* wimg, int C, int heads, int hdp, hipStream_t s) {
+  const int N = 3 * heads * hdp;
+  const long n = (long)ln_gemm_rows_image_bytes(C, N) / 2;
+  hipLaunchKernelGGL(ln_gemm_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)w, kw, (bf16*)wimg, C, N, heads, hdp / 32);
+  return (int)hipGetLastError();
+}
+// ctx [B*S][heads*hdp] = softmax(scale q k^T) v per image and head, q | k | v = bias + W x   (image from launch_qkv_attn_rows_pack)
+int launch_qkv_attn_rows(const void* x, void* ctx, const void* wimg, const float* bias, int B, int S, int C, int heads, int hdp, float scale, hipStream_t s) {
+  if (B <= 0) return 0;
+  if (C != 512 || hdp != 96 || S < 1 || S > 32) return (int)hipErrorInvalidValue;
+  auto kern = qkv_attn_rows_kernel<512, 3>;
+  const int N = 3 * heads * hdp, lds = 4 * (512 / 32) * 1024 + N * 4;
+  static int lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    lds_set = lds;
+  }
+  const int n_tiles = (B + MR_NW - 1) / MR_NW;
+  const int grid = n_tiles < 512 ? n_tiles : 512;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(MR_NW * 64), lds, s, (const bf16*)x, (bf16*)ctx, (const unsigned char*)wimg, bias, scale * 1.4426950408889634f, B,
+                     S, heads, n_tiles);
   return (int)hipGetLastError();
 }
 #ifndef LGR_SPC384     // ring geometry (tools/build_variant.sh sweeps)

@@ -160,7 +160,8 @@ int fsvit_attention(const void* qkv_dev, void* ctx_dev, int B, int S, int heads,
 /* Fused qkv conv + attention core of a Visformer stage-2 Attention block (visformer.py:172-190; the eval BatchNorm folded into the
  * conv as column scale + bias by the caller), bf16, Visformer-S geometry only (C = 256, 6 heads, head dim padded to 48, S <= 112):
  * x rows [B*S][C] -> ctx rows [B*S][heads*hdp].  wqkv [3*heads*hdp][kw] K-major bf16, rows ordered (q|k|v, head, z); bias fp32
- * [3*heads*hdp] or NULL.  Equals fsvit_conv_gemm (1x1, N = 3*heads*hdp) followed by fsvit_attention without the qkv tensor. */
+ * [3*heads*hdp] or NULL.  Equals fsvit_conv_gemm (1x1, N = 3*heads*hdp) followed by fsvit_attention without the qkv tensor.
+ * Also the stage-3 geometry on the row-wise kernel: C = 512, head dim padded to 96, S <= 32 (one image per wave). */
 int fsvit_qkv_attention(const void* x_dev, const void* wqkv_dev, int kw, const float* bias_dev, void* ctx_dev, int B, int S, int C,
                         int heads, int hdp, float scale, void* stream);
 /* One fused Visformer stage-1 block (visformer.py:259-263 with attn_disabled + spatial_conv Mlp :152-163), bf16,

@@ -270,6 +270,42 @@ def test_qkv_attention_fused_matches_unfused_math(B, S, use_bias):
     assert d.max().item() <= 2e-2 * max(1.0, float(ref.abs().max())) and d.mean().item() <= 1e-3, (d.max().item(), d.mean().item())
 
 
+@pytest.mark.parametrize('B,S', [(3, 25), (1031, 25), (640, 16), (9, 32), (5, 1)])
+@pytest.mark.parametrize('use_bias', [True, False])
+def test_qkv_attention_rows_stage3_matches_unfused_math(B, S, use_bias):
+    """qkv_attn_rows (mlp_rows.hip: qkv conv + attention with one image per wave, V computed transposed by swapping the MFMA operands) at the
+    Visformer stage-3 geometry (C = 512, 6 heads x 85 padded to 96) against the unfused math with the same bf16 rounding points; partial last
+    workgroup, full 32-token maps, the single-token edge; repeats bit-identical."""
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    C, heads, hd, hdp = 512, 6, 85, 96
+    g = torch.Generator().manual_seed(B * 131 + S)
+    x = q(torch.randn(B * S, C, generator=g), bf)
+    w = torch.zeros(3, heads, hdp, C)
+    w[:, :, :hd] = torch.randn(3, heads, hd, C, generator=g) / math.sqrt(C)
+    w = q(w, bf).reshape(3 * heads * hdp, C)
+    bias = torch.zeros(3, heads, hdp)
+    if use_bias:
+        bias[:, :, :hd] = torch.randn(3, heads, hd, generator=g) * 0.3
+    bias = bias.reshape(-1)
+    scale = hd ** -0.5
+    qkv = q(x @ w.t() + bias, bf).reshape(B, S, 3, heads, hdp)
+    qq, kk, vv = [qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
+    p = ((qq @ kk.transpose(-1, -2)) * scale).softmax(-1)
+    ref = (p @ vv).permute(0, 2, 1, 3).reshape(B * S, heads * hdp)
+    args = (x.to('cuda', bf), w.to('cuda', bf), bias.cuda() if use_bias else None, B, S, heads, hdp, scale)
+    got_d = ops.qkv_attention(*args)
+    torch.cuda.synchronize()
+    got = got_d.float().cpu()
+    assert torch.isfinite(got).all()
+    assert got.reshape(B * S, heads, hdp)[..., hd:].abs().max().item() == 0.0       # padded head dims stay exactly 0
+    err = (got - ref).abs()
+    assert err.max().item() <= 3e-2 * max(1.0, float(ref.abs().max())), (B, S, err.max().item())
+    assert err.mean().item() <= 3e-3, (B, S, err.mean().item())
+    for _ in range(5):
+        assert torch.equal(ops.qkv_attention(*args), got_d)
+
+
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 def test_im2col_maxpool_pool(dt):
     from fewshot_vit_amd.engine import ops
