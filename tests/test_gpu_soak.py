@@ -71,3 +71,18 @@ def test_ln_linear_rows_is_deterministic_at_bench_size(C, N, M):
     w = (rn(N, C) / math.sqrt(C)).to(bf)
     b = rn(N) * 0.3
     assert _repeat(lambda: ops.ln_linear_rows(x, w, b), 40) == 0
+
+
+def test_qkv_attention_rows_is_deterministic_at_bench_size():
+    """qkv_attn_rows (stage-3 geometry, 12800 images of 25 tokens): 40 launches bit-identical and finite."""
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    B, S, C, heads, hd, hdp = 12800, 25, 512, 6, 85, 96
+    g = torch.Generator(device='cuda').manual_seed(9)
+    rn = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    x = rn(B * S, C).to(bf)
+    w = torch.zeros(3, heads, hdp, C, device='cuda')
+    w[:, :, :hd] = rn(3, heads, hd, C) / math.sqrt(C)
+    w = w.reshape(3 * heads * hdp, C).to(bf)
+    bias = rn(3 * heads * hdp) * 0.3
+    assert _repeat(lambda: ops.qkv_attention(x, w, bias, B, S, heads, hdp, hd ** -0.5), 40) == 0
