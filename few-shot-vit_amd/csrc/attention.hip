@@ -327,8 +327,14 @@ static int launch_attention_v2(const void* qkv, void* ctx, int B, int S, int hea
   const int ndt = hdp / 16;
   if (dtype == 0) {
     if (S <= 32) return dispatch_ndt<float, 2, 2>(ndt, qkv, ctx, B, S, heads, scale, s);
-    if (S <= 112) return dispatch_ndt<float, 7, 4>(ndt, qkv, ctx, B, S, heads, scale, s);
-    if (S <= 208) return dispatch_ndt<float, 13, 4>(ndt, qkv, ctx, B, S, heads, scale, s);   // ViT: 196 patches + cls
+#ifndef ATT_NWF112
+#define ATT_NWF112 4
+#endif
+#ifndef ATT_NWF208
+#define ATT_NWF208 7      // 13 query tiles: 4 waves 153 ms per DeiT-S step (two-limb mode), 7: 138, 8: 141; at 7 tiles (S <= 112) the wave count does not matter
+#endif
+    if (S <= 112) return dispatch_ndt<float, 7, ATT_NWF112>(ndt, qkv, ctx, B, S, heads, scale, s);
+    if (S <= 208) return dispatch_ndt<float, 13, ATT_NWF208>(ndt, qkv, ctx, B, S, heads, scale, s);   // ViT: 196 patches + cls
   } else {
     if (S <= 32) return dispatch_ndt<bf16, 2, 2>(ndt, qkv, ctx, B, S, heads, scale, s);
     if (S <= 128) return dispatch_ndt<bf16, 8, 4>(ndt, qkv, ctx, B, S, heads, scale, s);
