@@ -747,8 +747,11 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
 // store cost: a deeper ring (slots x depth 2 x 4 ... 3 x 9, so that a wait leaves up to three images and the store acknowledgements in flight),
 // whole 64-byte segments per store instruction (v_permlane16_swap of the two pieces between rows r and r + 16), even whole 128-byte lines
 // (wrong layout, same bytes: -4 %); `nt` / `sc1` stores are 1.5 ... 2 x slower (the partial lines are no longer merged in L2).
+#ifndef LGR_OCC
+#define LGR_OCC 2
+#endif
 template <int C, bool LN, int SPC, int NST>
-__global__ __launch_bounds__(256, 2) void ln_gemm_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
+__global__ __launch_bounds__(256, LGR_OCC) void ln_gemm_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
                                                               const float* __restrict__ bias, const float ln_eps, const int M, const int N,
                                                               const int n_tiles) {
   constexpr int NKS = C / 16, SLF = NKS / SPC;                // k-steps; fragments per ring slot; SPC slots per chunk
@@ -1107,7 +1110,7 @@ static int launch_gemm_rows_t(const void* x, void* y, const void* wimg, const fl
     lds_set = lds;
   }
   const int n_tiles = (M + MR_NW * 32 - 1) / (MR_NW * 32);
-  const int grid = n_tiles < 512 ? n_tiles : 512;
+  const int grid = n_tiles < 256 * LGR_OCC ? n_tiles : 256 * LGR_OCC;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(MR_NW * 64), lds, s, (const bf16*)x, (bf16*)y, (const unsigned char*)wimg, bias, eps, M, N, n_tiles);
   return (int)hipGetLastError();
 }
