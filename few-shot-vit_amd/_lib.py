@@ -79,6 +79,7 @@ SIGNATURES = {
     'fsvit_adamw_step': (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _i, _vp]),
     'fsvit_proj_mlp_rows': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _fp, _vp, _i, _fp, _i, _i, _i, _vp]),
     'fsvit_ln_linear_rows': (_i, [_vp, _vp, _vp, _i, _fp, _i, _i, _i, _f, _vp]),
+    'fsvit_patch_embed2x2': (_i, [_vp, _vp, _vp, _i, _fp, _fp, _i, _i, _i, _i, _vp]),
     'fsvit_vit_block_tail': (_i, [_vp, _vp, _vp, _vp, _i, _i, _fp, _vp, _i, _fp, _vp, _i, _fp, _i, _i, _i, _f, _vp]),
     'fsvit_mlp_rows': (_i, [_vp, _vp, _vp, _i, _fp, _vp, _i, _fp, _i, _i, _i, _vp]),
     'fsvit_attention': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),

@@ -161,6 +161,7 @@ struct fsvit_visformer : EngineBase {
   int hid1 = 0, hid2 = 0, hid3 = 0;
   int hd2 = 0, hdp2 = 0, hd3 = 0, hdp3 = 0;
   Layer conv1, down, conv2, conv3, conv3f, pe2, pe3;   // conv3f: conv3 + downsample folded in as a tail K slice
+  void* pe_img[2] = {nullptr, nullptr};                // mlp_rows.hip: fragment-major image of patch_embed2 / 3 for the row-wise kernel (null: conv_gemm)
   float *pos1 = nullptr, *pos2 = nullptr, *pos3 = nullptr;
   std::vector<Block1> s1;
   std::vector<BlockA> s2, s3;
@@ -385,6 +386,15 @@ int build(fsvit_visformer* h, const SD& sd) {
     std::vector<double> bias(Co);
     for (int o = 0; o < Co; ++o) bias[o] = bn.s[o] * (double)b[o] + bn.t[o];
     RC_TRY(pack_layer(h, s == 2 ? &h->pe2 : &h->pe3, w, Co, Ci, 2, 2, 1, &bn.s, nullptr, bias, true, nullptr, 0, nullptr, 0));
+    const Layer& pe = s == 2 ? h->pe2 : h->pe3;
+    if (K(patch_embed_rows_supported)(kd(kdt), Ci, s == 2 ? h->H1 : h->H2, Co) && pe.Kw == 4 * Ci) {
+      void* img = nullptr;
+      HIP_TRY(hipMalloc(&img, K(ln_gemm_rows_image_bytes)(4 * Ci, Co)));
+      h->allocs.push_back(img);
+      RC_TRY(K(launch_ln_gemm_pack)(pe.w, pe.Kw, img, 4 * Ci, Co, nullptr));
+      HIP_TRY(hipDeviceSynchronize());
+      h->pe_img[s - 2] = img;
+    }
   }
   // ---- stages 2, 3 (attention + MLP blocks; Attention :166-194, Block :259-263)
   for (int s = 2; s <= 3; ++s) {
@@ -646,6 +656,10 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
     const float* pos = s == 2 ? h->pos2 : h->pos3;
     const size_t xbytes = (size_t)Bc * Ho * Ho * C * es;
     const std::string sp = "stage" + std::to_string(s);
+    if (h->pe_img[s - 2]) {
+      RC_TRY(timed(h, st, s == 2 ? "patch_embed2" : "patch_embed3", KID_LNGEMM, 2.0 * Bc * Ho * Ho * 4.0 * Ci * C,
+                   [&]() { return K(launch_patch_embed_rows)(xin, xs, h->pe_img[s - 2], pe.bias, pos, Bc, Hi, Ci, C, st); }));
+    } else
     RC_TRY(run_gemm(h, st, s == 2 ? "patch_embed2" : "patch_embed3", pe, conv_params(pe, xin, xs, Bc, Hi, Hi, Ci, Ci, 2, 2, 2, 0, C, ACT_NONE, nullptr, 0, pos), C, 4.0 * Ci));
     RC_TRY(tap(h, "patch_embed" + std::to_string(s), xs, xbytes, first, st));
     const std::vector<BlockA>& blocks = s == 2 ? h->s2 : h->s3;
@@ -974,6 +988,25 @@ extern "C" int fsvit_ln_linear_rows(const void* x, void* y, const void* w, int k
   (void)hipStreamSynchronize(st);
   (void)hipFree(img);
   if (rc != 0) return hipfail((hipError_t)rc, "fsvit_ln_linear_rows");
+  return 0;
+}
+
+// PatchEmbed of the Visformer stages as one operator (visformer.py:266-288: conv k2 s2 -> BN, + pos_embed): x NHWC bf16 [B][H][H][Ci] with
+// 4 Ci = 512 (patch_embed2 of Visformer-S), w [N][kw >= 4 Ci] K-major in (ky, kx, c) order with the eval BatchNorm folded, bias [N] or NULL,
+// pos fp32 [(H/2)^2][N]; y [B (H/2)^2][N].  Packs the weights on every call.
+extern "C" int fsvit_patch_embed2x2(const void* x, void* y, const void* w, int kw, const float* bias, const float* pos, int B, int H, int Ci, int N,
+                                    void* stream) {
+  const int kdt = FSVIT_BF16;
+  if (!x || !y || !w || !pos) return fail(FSVIT_ERR_ARG, "null argument");
+  if (!K(patch_embed_rows_supported)(1, Ci, H, N) || kw < 4 * Ci) return fail(FSVIT_ERR_ARG, "fsvit_patch_embed2x2: 4 Ci = 512, even H, N a multiple of 32 (bf16)");
+  hipStream_t st = (hipStream_t)stream;
+  void* img = nullptr;
+  HIP_TRY(hipMalloc(&img, K(ln_gemm_rows_image_bytes)(4 * Ci, N)));
+  int rc = K(launch_ln_gemm_pack)(w, kw, img, 4 * Ci, N, st);
+  if (rc == 0) rc = K(launch_patch_embed_rows)(x, y, img, bias, pos, B, H, Ci, N, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(img);
+  if (rc != 0) return hipfail((hipError_t)rc, "fsvit_patch_embed2x2");
   return 0;
 }
 

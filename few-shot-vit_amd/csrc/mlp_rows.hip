@@ -750,10 +750,14 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
 #ifndef LGR_OCC
 #define LGR_OCC 2
 #endif
-template <int C, bool LN, int SPC, int NST>
+// GATHER (C = 4 Ci): the 2 x 2 / stride-2 patch-embedding conv (visformer.py:266-288, eval BatchNorm folded) - an output token's row is the
+// concatenation of its four input pixels (k = (ky, kx, c): each 16-byte register load stays inside one pixel), and pos_embed [OH*OW][N]
+// fp32 is added before the rounding: its 16 values per lane and chunk are loaded at the top of the chunk through asm (invisible to hipcc's
+// waitcnt pass) and are complete after the chunk's second ring wait - they are older than the DMAs that wait leaves in flight.
+template <int C, bool LN, int SPC, int NST, bool GATHER = false>
 __global__ __launch_bounds__(256, LGR_OCC) void ln_gemm_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ Y, const unsigned char* __restrict__ wimg,
                                                               const float* __restrict__ bias, const float ln_eps, const int M, const int N,
-                                                              const int n_tiles) {
+                                                              const int n_tiles, const int gH = 0, const float* __restrict__ pos = nullptr) {
   constexpr int NKS = C / 16, SLF = NKS / SPC;                // k-steps; fragments per ring slot; SPC slots per chunk
   constexpr int SLOT = SLF * 1024, PW = SLF / MR_NW, WSH = PW * 1024, FD = 4, LAG = (NST - 3) * PW;
   static_assert(NKS % SLF == 0 && SLF % MR_NW == 0, "whole slots");
@@ -788,8 +792,22 @@ __global__ __launch_bounds__(256, LGR_OCC) void ln_gemm_rows_kernel(const bf16* 
     const bool mok = m < M;
     const size_t row = (size_t)(mok ? m : M - 1);
     u32x4 xr[NKS];
+    const float* posrow = nullptr;
+    if constexpr (GATHER) {
+      constexpr int CI = C / 4, SPT = NKS / 4;                 // channels per input pixel; k-steps per tap
+      const int OH = gH >> 1, hw = OH * OH;
+      const int b = (int)row / hw, pp = (int)row - b * hw, oy = pp / OH, ox = pp - oy * OH;
+      const bf16* const px = X + ((size_t)(b * gH + 2 * oy) * gH + 2 * ox) * CI + 16 * kh;
+      posrow = pos + (size_t)pp * N + 16 * kh;
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) xr[s] = mr_gload16s(X + row * C + 32 * (s >> 1) + 16 * kh + 8 * (s & 1));
+      for (int s = 0; s < NKS; ++s) {
+        const int tap = s / SPT, ky = tap >> 1, kx = tap & 1;
+        xr[s] = mr_gload16s(px + (size_t)(ky * gH + kx) * CI + 32 * ((s % SPT) >> 1) + 8 * (s & 1));
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) xr[s] = mr_gload16s(X + row * C + 32 * (s >> 1) + 16 * kh + 8 * (s & 1));
+    }
     mr_wait_loads<NKS>(&xr[0]);
     if (first) { mr_bar(); first = false; }
     if constexpr (LN) mr_layernorm_rows<NKS, C>(xr, ln_eps);
@@ -797,6 +815,11 @@ __global__ __launch_bounds__(256, LGR_OCC) void ln_gemm_rows_kernel(const bf16* 
 #pragma unroll 1
     for (int j = 0; j < nch; ++j) {
       f32x16 hacc;
+      u32x4 posv[4];
+      if constexpr (GATHER) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) posv[g] = mr_gload16(posrow + j * 32 + 4 * g);
+      }
       {
         const float* bp = btab + j * 32 + kh * 16;
 #pragma unroll
@@ -831,6 +854,16 @@ __global__ __launch_bounds__(256, LGR_OCC) void ln_gemm_rows_kernel(const bf16* 
         }
       }
       asm volatile("s_nop 15\n\ts_nop 3" : "+v"(hacc));          // wait states MFMA -> VALU read of the accumulator
+      if constexpr (GATHER) {
+        static_assert(!GATHER || SPC == 2, "the pos loads are covered by the second ring wait of the chunk");
+        asm volatile("" : "+v"(posv[0]), "+v"(posv[1]), "+v"(posv[2]), "+v"(posv[3]));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 pf = __builtin_bit_cast(f32x4, posv[g]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hacc[4 * g + e] += pf[e];
+        }
+      }
       u32x4 o0, o1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -1099,9 +1132,10 @@ int launch_qkv_attn_rows(const void* x, void* ctx, const void* wimg, const float
 #define LGR_SPC512 2
 #define LGR_NST512 4
 #endif
-template <int C, bool LN, int SPC, int NST>
-static int launch_gemm_rows_t(const void* x, void* y, const void* wimg, const float* bias, int M, int N, float eps, hipStream_t s) {
-  auto kern = ln_gemm_rows_kernel<C, LN, SPC, NST>;
+template <int C, bool LN, int SPC, int NST, bool GATHER = false>
+static int launch_gemm_rows_t(const void* x, void* y, const void* wimg, const float* bias, int M, int N, float eps, hipStream_t s, int gH = 0,
+                              const float* pos = nullptr) {
+  auto kern = ln_gemm_rows_kernel<C, LN, SPC, NST, GATHER>;
   const int lds = NST * (C / 16 / SPC) * 1024 + N * 4;
   static int lds_set = 0;
   if (lds > lds_set) {
@@ -1111,8 +1145,18 @@ static int launch_gemm_rows_t(const void* x, void* y, const void* wimg, const fl
   }
   const int n_tiles = (M + MR_NW * 32 - 1) / (MR_NW * 32);
   const int grid = n_tiles < 256 * LGR_OCC ? n_tiles : 256 * LGR_OCC;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(MR_NW * 64), lds, s, (const bf16*)x, (bf16*)y, (const unsigned char*)wimg, bias, eps, M, N, n_tiles);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(MR_NW * 64), lds, s, (const bf16*)x, (bf16*)y, (const unsigned char*)wimg, bias, eps, M, N, n_tiles, gH, pos);
   return (int)hipGetLastError();
+}
+// 2 x 2 / stride-2 patch embedding on the rows kernel: x NHWC [B][H][H][Ci] with 4 Ci = 512, y [B (H/2)^2][N] = bias + W patches + pos
+bool patch_embed_rows_supported(int dtype, int Ci, int H, int N) {
+  static const bool on = [] { const char* e = getenv("FSVIT_LN_GEMM_ROWS"); return !e || e[0] != '0'; }();
+  return on && dtype == 1 && 4 * Ci == 512 && H >= 2 && H % 2 == 0 && N >= 32 && N % 32 == 0;
+}
+int launch_patch_embed_rows(const void* x, void* y, const void* wimg, const float* bias, const float* pos, int B, int H, int Ci, int N, hipStream_t s) {
+  if (B <= 0) return 0;
+  if (4 * Ci != 512 || (H & 1) || N % 32 || !pos) return (int)hipErrorInvalidValue;
+  return launch_gemm_rows_t<512, false, 2, 4, true>(x, y, wimg, bias, B * (H / 2) * (H / 2), N, 0.0f, s, H, pos);
 }
 // y [M][N] = bias + W' LN(x [M][C])   (gamma / beta folded into W' / bias by the caller; image from launch_ln_gemm_pack)
 int launch_ln_gemm_rows(const void* x, void* y, const void* wimg, const float* bias, int M, int C, int N, float eps, hipStream_t s) {

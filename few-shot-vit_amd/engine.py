@@ -572,6 +572,18 @@ class ops:
         return y
 
     @staticmethod
+    def patch_embed2x2(x, w, bias, pos):
+        """Visformer PatchEmbed (conv k2 s2 with folded BN, + pos_embed; visformer.py:266-288) on the row-wise kernel: x NHWC bf16 [B, H, H, Ci]
+        (4 Ci = 512), w [N, 4 Ci] in (ky, kx, c) order, bias [N] or None, pos fp32 [(H/2)^2, N] -> [B (H/2)^2, N]."""
+        _require_cuda(x, w, pos)
+        B, H, _, Ci = x.shape
+        y = torch.empty(B * (H // 2) * (H // 2), w.shape[0], device=x.device, dtype=x.dtype)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().fsvit_patch_embed2x2(_ptr(x), _ptr(y), _ptr(w), w.shape[-1], _ptr(bias), _ptr(pos), B, H, Ci, w.shape[0],
+                                                        _stream_ptr(x.device)))
+        return y
+
+    @staticmethod
     def vit_block_tail(x, ctx, wp, bp, w1, b1, w2, b2, eps=1e-6):
         """DeiT block tail (deit.py:69-72) on bf16 rows, (C, KC, hidden) = (384, 384, 1536): x1 = x + bp + ctx wp^T;
         y = x1 + b2 + W2 GELU(W1 LN(x1) + b1), LN without affine (norm2's gamma / beta folded into w1 / b1 by the caller)."""

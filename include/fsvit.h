@@ -196,6 +196,11 @@ int fsvit_vit_block_tail(const void* x_dev, void* y_dev, const void* ctx_dev, co
  * C = 384, N a multiple of 32, LN without affine (the caller folds norm1's gamma / beta into w [N][kw] / b).  C = 512: the same row-wise kernel
  * WITHOUT the LayerNorm, y = b + W x (the Visformer stage-3 qkv conv with its eval BatchNorm folded, visformer.py:175; eps ignored, b may be NULL). */
 int fsvit_ln_linear_rows(const void* x_dev, void* y_dev, const void* w_dev, int kw, const float* b_dev, int M, int C, int N, float eps, void* stream);
+/* PatchEmbed of a Visformer stage (test_phase/models/visformer.py:266-288: Conv2d k2 s2 -> BatchNorm, then `x + pos_embed`, :437-447) on the
+ * row-wise kernel: x NHWC bf16 [B][H][H][Ci], 4 Ci = 512; w [N][kw] K-major in (ky, kx, c) order with the eval BatchNorm folded in, bias fp32 [N]
+ * or NULL, pos fp32 [(H/2)^2][N]; y [B (H/2)^2][N] bf16. */
+int fsvit_patch_embed2x2(const void* x_dev, void* y_dev, const void* w_dev, int kw, const float* bias_dev, const float* pos_dev, int B, int H, int Ci,
+                         int N, void* stream);
 /* ---------------------------------------------------------------- distillation head
  * Replaces, for sun_meta_training/offline.py: `LinearClassifier.forward` / its autograd (models/classifier.py:27-34) as used by
  * `TokenLabelOffline` (models/token_label.py:36-60) on the 25 tokens and on the pooled feature, `generate_softlabel`

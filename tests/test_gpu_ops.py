@@ -564,6 +564,31 @@ def test_linear_rows_c512_matches_fp32(M, N, bias):
         assert torch.equal(ops.ln_linear_rows(*args), y0)
 
 
+@pytest.mark.parametrize('B,H,N', [(3, 20, 256), (411, 20, 256), (70, 12, 96)])
+def test_patch_embed2x2_rows_vs_conv2d(B, H, N):
+    """The 2 x 2 / stride-2 patch embedding + pos_embed on the rows kernel (visformer.py:266-288, :437-447) against torch conv2d in fp32 on the
+    same bf16 operands; partial last workgroup; repeats bit-identical."""
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    Ci = 128
+    g = torch.Generator().manual_seed(B + H + N)
+    x = q(torch.randn(B, Ci, H, H, generator=g), bf)
+    w = q(torch.randn(N, Ci, 2, 2, generator=g) / math.sqrt(4 * Ci), bf)
+    bias = torch.randn(N, generator=g) * 0.3
+    pos = torch.randn(N, H // 2, H // 2, generator=g) * 0.5
+    ref = (F.conv2d(x, w, bias, stride=2) + pos).permute(0, 2, 3, 1).reshape(-1, N)
+    xd = x.permute(0, 2, 3, 1).contiguous().to('cuda', bf)
+    wd = w.permute(0, 2, 3, 1).reshape(N, 4 * Ci).contiguous().to('cuda', bf)          # K order (ky, kx, c)
+    posd = pos.permute(1, 2, 0).reshape(-1, N).contiguous().cuda()
+    y0 = ops.patch_embed2x2(xd, wd, bias.cuda(), posd)
+    torch.cuda.synchronize()
+    err = (y0.float().cpu() - ref).abs()
+    assert err.max().item() <= 2e-2 * max(1.0, float(ref.abs().max())), (B, H, N, err.max().item())
+    assert err.mean().item() <= 3e-3, err.mean().item()
+    for _ in range(6):
+        assert torch.equal(ops.patch_embed2x2(xd, wd, bias.cuda(), posd), y0)
+
+
 def test_gemm256_large_shapes_repeatable_and_correct():
     """Race screen of the pipelined 256x256 kernel (counted-vmcnt LDS-DMA ring, cdna_hip_programming.md: a misplaced wait shows up as
     rare wrong tiles): several persistent items per workgroup, tails in M and N, 25 repeats must be bit-identical and match fp32."""
