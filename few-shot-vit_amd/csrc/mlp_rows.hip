@@ -741,14 +741,20 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
 // "at most PW operations outstanding" still implies that every older slot image has landed (stores can only make the wait longer).
 // LN = false, C = 512: the plain row-wise Linear (the Visformer stage-3 qkv conv, visformer.py:175, eval BatchNorm folded: 7 x 7 tokens are past
 // what qkv_attn holds per image but the layer has the same 256-tile problem: K = 512 is 8 K tiles per epilogue, 753 TF/s).
-// Measured (tools/bench_rows_gemm.py under rocprofv3, -DLGR_DIAG variants; C = 384 / 512): 818 / 850 TFLOP/s.  Every MFMA reads a fresh 1 KB
-// fragment (one row block per wave), which is exactly the CU's 128 B/clk of LDS at the full MFMA rate - without the stores and the ring
-// traffic the loop reaches 1130 TF/s.  Dropping the stores gains 25 %, the ring refill 15 %, the barriers nothing.  What did NOT help the
+// Measured (tools/bench_rows_gemm.py under rocprofv3, -DLGR_DIAG variants; C = 384 / 512): 818 / 850 TFLOP/s.  With stores, ring refill,
+// barriers AND fragment reads removed the MFMA loop runs at 1280 TF/s (the practical ceiling of every long MFMA stream measured in this
+// repository); dropping only the stores gains 25 %, only the ring refill 15 %, the barriers nothing, and - against the expectation that a
+// fresh 1 KB fragment per MFMA (= the CU's 128 B/clk of LDS at the full MFMA rate) is the limit - dropping the fragment READS nothing
+// either.  Spreading the VMEM instructions between the MFMAs (LGR_SPREAD: refill one piece at a time, stores deferred into the next chunk's
+// first slot; the mlp_rows recipe) is worth 1 ... 2 % with two workgroups per CU.  What did NOT help the
 // store cost: a deeper ring (slots x depth 2 x 4 ... 3 x 9, so that a wait leaves up to three images and the store acknowledgements in flight),
 // whole 64-byte segments per store instruction (v_permlane16_swap of the two pieces between rows r and r + 16), even whole 128-byte lines
 // (wrong layout, same bytes: -4 %); `nt` / `sc1` stores are 1.5 ... 2 x slower (the partial lines are no longer merged in L2).
 #ifndef LGR_OCC
 #define LGR_OCC 2
+#endif
+#ifndef LGR_SPREAD      // 1: ring refill and output stores issued one instruction at a time between the MFMAs
+#define LGR_SPREAD 1
 #endif
 // GATHER (C = 4 Ci): the 2 x 2 / stride-2 patch-embedding conv (visformer.py:266-288, eval BatchNorm folded) - an output token's row is the
 // concatenation of its four input pixels (k = (ky, kx, c): each 16-byte register load stays inside one pixel), and pos_embed [OH*OW][N]
@@ -812,6 +818,7 @@ __global__ __launch_bounds__(256, LGR_OCC) void ln_gemm_rows_kernel(const bf16* 
     if (first) { mr_bar(); first = false; }
     if constexpr (LN) mr_layernorm_rows<NKS, C>(xr, ln_eps);
     bf16* const yrow = Y + row * N + 16 * kh;
+    u32x4 po0 = {0u, 0u, 0u, 0u}, po1 = {0u, 0u, 0u, 0u};      // LGR_SPREAD: the previous chunk's output, stored between the MFMAs of this one
 #pragma unroll 1
     for (int j = 0; j < nch; ++j) {
       f32x16 hacc;
@@ -835,7 +842,14 @@ __global__ __launch_bounds__(256, LGR_OCC) void ln_gemm_rows_kernel(const bf16* 
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LAG) : "memory");
         mr_bar();
 #endif
-#if !(defined(LGR_DIAG) && (LGR_DIAG & 8))
+#if LGR_SPREAD
+        // A 1 KB VMEM instruction holds the wave's issue stage for ~64 cycles (mlp_rows): the refill of the slot freed by this barrier goes out one
+        // piece at a time, 4 MFMAs apart, and the previous chunk's two stores in the gaps of the chunk's first slot.
+        const unsigned char* const dsrc = wimg + (size_t)issue_img * SLOT;
+        const unsigned ddst = lds0 + issue_slot * SLOT + wave * WSH;
+        issue_img = issue_img == n_img - 1 ? 0 : issue_img + 1;
+        issue_slot = issue_slot == NST - 1 ? 0 : issue_slot + 1;
+#elif !(defined(LGR_DIAG) && (LGR_DIAG & 8))
         issue();
 #endif
         unsigned a = slot * SLOT + lane * 16;
@@ -849,7 +863,17 @@ __global__ __launch_bounds__(256, LGR_OCC) void ln_gemm_rows_kernel(const bf16* 
 #pragma unroll
         for (int i = 0; i < SLF; ++i) {
           mfma32_v(fr[i % FD], xr[h * SLF + i], hacc);
+#if !(defined(LGR_DIAG) && (LGR_DIAG & 32))      // diagnostic: the MFMAs without their fragment reads (wrong results)
           if (i + FD < SLF) fr[i % FD] = *reinterpret_cast<const u32x4*>(sp + (i + FD) * 1024);
+#endif
+#if LGR_SPREAD
+          constexpr int EVERY = SLF / PW;
+          if (i % EVERY == 1 && i / EVERY < PW) mr_dma1(voff + (i / EVERY) * 1024, dsrc, ddst + (i / EVERY) * 1024);
+          if (h == 0 && j > 0 && mok) {
+            if (i == 3) mr_gstore16(yrow + (j - 1) * 32, po0);
+            if (i == EVERY + 3) mr_gstore16(yrow + (j - 1) * 32 + 8, po1);
+          }
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -870,6 +894,15 @@ __global__ __launch_bounds__(256, LGR_OCC) void ln_gemm_rows_kernel(const bf16* 
         o0[e] = mr_pk2(hacc[2 * e], hacc[2 * e + 1]);
         o1[e] = mr_pk2(hacc[8 + 2 * e], hacc[8 + 2 * e + 1]);
       }
+#if LGR_SPREAD
+      po0 = o0;
+      po1 = o1;
+    }
+    if (mok) {
+      mr_gstore16(yrow + (nch - 1) * 32, po0);
+      mr_gstore16(yrow + (nch - 1) * 32 + 8, po1);
+    }
+#else
 #if defined(LGR_DIAG) && (LGR_DIAG & 1)
       if (o0[0] == 0x12345678u)
 #else
@@ -880,6 +913,7 @@ __global__ __launch_bounds__(256, LGR_OCC) void ln_gemm_rows_kernel(const bf16* 
         mr_gstore16(yrow + j * 32 + 8, o1);
       }
     }
+#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may be in flight into the LDS of a finished workgroup
 }
