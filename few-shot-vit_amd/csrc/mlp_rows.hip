@@ -247,6 +247,9 @@ template <int NKS, int C> __device__ __forceinline__ void mr_layernorm_rows(u32x
   float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
   sum += __shfl_xor(sum, 32);
   const float mean = sum * (1.0f / C);
+  // opaque between the passes: hipcc otherwise keeps all C / 2 converted values of a pass alive for the next one (247 VGPRs, AGPR copies)
+#pragma unroll
+  for (int o = 0; o < NKS; o += 4) asm volatile("" : "+v"(xr[o]), "+v"(xr[o + 1]), "+v"(xr[o + 2]), "+v"(xr[o + 3]));
   float q4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < NKS; ++s) {
@@ -258,6 +261,8 @@ template <int NKS, int C> __device__ __forceinline__ void mr_layernorm_rows(u32x
   sq += __shfl_xor(sq, 32);
   const float rstd = rsqrtf(sq * (1.0f / C) + eps);
   const float nmr = -mean * rstd;
+#pragma unroll
+  for (int o = 0; o < NKS; o += 4) asm volatile("" : "+v"(xr[o]), "+v"(xr[o + 1]), "+v"(xr[o + 2]), "+v"(xr[o + 3]));
 #pragma unroll
   for (int s = 0; s < NKS; ++s) {
     const bf16x8 v = __builtin_bit_cast(bf16x8, xr[s]);
