@@ -14,5 +14,5 @@ for n in 1 2 3 5 7 11; do
   if [ -f ../../tools/probes/pad/mr_pad$n.o ]; then cp ../../tools/probes/pad/mr_pad$n.o build/mlp_rows.o
   else /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -DMR_PAD=$n -c mlp_rows.hip -o build/mlp_rows.o; fi
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libfsvit.so build/*.o
-  echo "MR_PAD=$n: $(cd ../..; python -m pytest tests/test_gpu_ops.py tests/test_gpu_soak.py -q -k "mlp_rows or vit_block_tail or linear_rows or qkv_attention_rows" 2>&1 | tail -1)"
+  echo "MR_PAD=$n: $(cd ../..; python -m pytest tests/test_gpu_ops.py tests/test_gpu_soak.py -q -k "mlp_rows or vit_block_tail or linear_rows or qkv_attention_rows or patch_embed2x2" 2>&1 | tail -1)"
 done
