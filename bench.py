@@ -66,6 +66,7 @@ def parse(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-modes', action='store_true', help='skip the parity-mode leg and the agreement figures')
+    ap.add_argument('--no-legs', action='store_true', help="skip the other configurations' legs (train / deit / deit_train / end_to_end)")
     ap.add_argument('--cpu-episodes', type=int, default=12)
     ap.add_argument('--layers', action='store_true', help='print the per-layer timing table to stderr')
     ap.add_argument('--mode', default='eval', choices=['eval', 'train'],
@@ -73,6 +74,7 @@ def parse(argv=None):
                          "(train_meta_mini_visformer_5shot.yaml geometry: 8 episodes x 10-way (5 shot + 5 query) = 800 images)")
     ap.add_argument('--train-episodes', type=int, default=8, help='train mode: episodes per GPU per step (ep_per_batch)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='nccl == RCCL over xGMI; gloo only with --selftest-launcher')
+    ap.add_argument('--via-launcher', action='store_true', help='start the rank process(es) from a GPU-untouched parent even for --gpus 1 (the route --gpus N > 1 takes when invoked plainly)')
     ap.add_argument('--selftest-launcher', action='store_true',
                     help='exercise the rank launcher and the timing / statistics exchange on the CPU (gloo), no GPU work: tests/test_bench_launcher_cpu.py')
     return ap.parse_args(argv)
@@ -87,11 +89,37 @@ def _free_port():
     return port
 
 
+def count_gpus_without_hip():
+    """Number of GPUs a rank process will see, found WITHOUT any HIP / torch.cuda call in THIS process (it is about to start N children and
+    must never have initialised the runtime): a throw-away child counts them (whatever it initialises dies with it); if that child cannot be
+    started, the KFD topology in sysfs (nodes with SIMDs) clipped by the *_VISIBLE_DEVICES lists."""
+    try:
+        r = subprocess.run([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'], capture_output=True, text=True, timeout=300)
+        if r.returncode == 0:
+            return int(r.stdout.strip().splitlines()[-1])
+    except Exception:
+        pass
+    n = 0
+    root = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, 'properties')) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get('simd_count', 0)) > 0:
+                n += 1
+    except OSError:
+        return 0
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        if os.environ.get(var, '').strip():
+            n = min(n, len([x for x in os.environ[var].split(',') if x.strip()]))
+    return n
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start N rank processes from this (GPU-untouched) parent."""
     n = args.gpus
     if args.backend == 'nccl':
-        have = torch.cuda.device_count()          # counts devices without initialising HIP (never torch.cuda.is_available() here)
+        have = count_gpus_without_hip()
         if have < n:
             sys.stderr.write(f'bench.py --gpus {n}: only {have} GPU(s) visible on this node - one rank per GPU is required '
                              f'(run with --gpus <= {max(have, 1)})\n')
@@ -170,64 +198,109 @@ def _physical_cores():
         return os.cpu_count()
 
 
-def cpu_baseline(sd, xs_all, xq_all, gpu_logits, n_ep, model='visformer_micro_80'):
-    """The oracle on the host cores over the FIRST episodes of the GPU leg's pool (same tensors, copied to the host).  Thread count
-    and ep_per_batch are swept first (2 episodes per setting; the reference's own setting is ep_per_batch=1, test_few_shot.py:47-48),
-    then `n_ep` episodes are timed at the best setting.  Accuracy and logits of those episodes are compared with the GPU's."""
+def _oracle_runner(sd, model, img, shot):
     from oracle import visformer_oracle as vo
-    img = xs_all.shape[-1]
-    shot = xs_all.shape[2]
     if model == 'visformer_micro_80':
         cfg = vo.VisformerCfg()
+        return lambda xs, xq: vo.meta_baseline_forward(sd, xs, xq, cfg)
+    from oracle import deit_oracle as do
+    cfg = do.FACTORIES[model]
 
-        def run(xs, xq):
-            return vo.meta_baseline_forward(sd, xs, xq, cfg)
-    else:
-        from oracle import deit_oracle as do
-        cfg = do.FACTORIES[model]
+    def run(xs, xq):
+        E = xs.shape[0]
+        with torch.no_grad():
+            f = do.deit_forward(sd, torch.cat([xs.reshape(-1, 3, img, img), xq.reshape(-1, 3, img, img)]), cfg, prefix='encoder.')
+        n = E * xs.shape[1] * xs.shape[2]
+        return vo.meta_baseline_head(f[:n].reshape(E, 5, xs.shape[2], -1), f[n:].reshape(E, 75, -1), temp=10.0)
+    return run
 
-        def run(xs, xq):
-            E = xs.shape[0]
-            with torch.no_grad():
-                f = do.deit_forward(sd, torch.cat([xs.reshape(-1, 3, img, img), xq.reshape(-1, 3, img, img)]), cfg, prefix='encoder.')
-            n = E * xs.shape[1] * xs.shape[2]
-            return vo.meta_baseline_head(f[:n].reshape(E, 5, shot, -1), f[n:].reshape(E, 75, -1), temp=10.0)
 
-    def rate(threads, epb, n):
+def cpu_worker(argv):
+    """One worker process of the episode-parallel CPU baseline: `bench.py --cpu-worker <dir> <w> <W> <threads> <model>`.  Loads the sample the
+    parent wrote, warms up, reports ready, waits for the parent's go file, runs the oracle on episodes w::W (5-shot, then the same episodes
+    as 1-shot: the first shot image of every class) and writes its logits."""
+    d, w, W, threads, model = argv[0], int(argv[1]), int(argv[2]), int(argv[3]), argv[4]
+    torch.set_num_threads(threads)
+    blob = torch.load(os.path.join(d, 'sample.pt'))
+    xs, xq, sd = blob['xs'], blob['xq'], blob['sd']
+    run = _oracle_runner(sd, model, xs.shape[-1], xs.shape[2])
+    mine = list(range(w, xs.shape[0], W))
+    run(xs[:1], xq[:1])
+    open(os.path.join(d, 'ready.%d' % w), 'w').close()
+    while not os.path.exists(os.path.join(d, 'go')):
+        time.sleep(0.005)
+    t0 = time.time()
+    out5 = [run(xs[e:e + 1], xq[e:e + 1]) for e in mine]
+    t1 = time.time()
+    out1 = [run(xs[e:e + 1, :, :1], xq[e:e + 1]) for e in mine]
+    t2 = time.time()
+    torch.save({'episodes': mine, 'logits5': torch.cat(out5) if out5 else None, 'logits1': torch.cat(out1) if out1 else None, 't': (t0, t1, t2)},
+               os.path.join(d, 'out.%d.pt' % w))
+    return 0
+
+
+def cpu_baseline(sd, xs_all, xq_all, gpu_logits, n_ep, model='visformer_micro_80'):
+    """The oracle (the pinned port of the reference's CPU path) on the host cores over the FIRST episodes of the GPU leg's pool (same tensors,
+    copied to the host), BASELINE.md 3b: all physical cores.  One torch process does not scale past ~16 threads on this network (a short
+    thread sweep is reported), so the whole-host figure is EPISODE-PARALLEL: W = physical cores / T worker processes of T threads each, every
+    worker running whole episodes at ep_per_batch = 1 (the reference's test setting, test_few_shot.py:47-48); `value` = episodes of all workers /
+    wall time between the common go signal and the last worker's finish.  5-way 5-shot is `value`; the same episodes as 5-way 1-shot (first
+    shot image of each class) are reported next to it.  Accuracy and logits of the 5-shot episodes are compared with the GPU's."""
+    import shutil
+    import tempfile
+    img = xs_all.shape[-1]
+    shot = xs_all.shape[2]
+    run = _oracle_runner(sd, model, img, shot)
+
+    def rate(threads, n):
         torch.set_num_threads(threads)
-        run(xs_all[:epb], xq_all[:epb])                                     # warm-up at this setting
+        run(xs_all[:1], xq_all[:1])                                     # warm-up at this setting
         t0 = time.perf_counter()
-        for e in range(0, n, epb):
-            run(xs_all[e:e + epb], xq_all[e:e + epb])
+        for e in range(n):
+            run(xs_all[e:e + 1], xq_all[e:e + 1])
         return n / (time.perf_counter() - t0)
 
     logical, physical = os.cpu_count() or 1, _physical_cores() or 1
-    cand = sorted({t for t in (8, 16, 32, 64, 128, physical) if t <= logical} or {logical})
-    sweep = {}
-    for t in cand:
-        sweep['%dthr_epb1' % t] = rate(t, 1, 2)
-    best_t = max(cand, key=lambda t: sweep['%dthr_epb1' % t])
-    epb4 = 4 if xs_all.shape[0] >= 4 else 1
-    if epb4 > 1:
-        sweep['%dthr_epb%d' % (best_t, epb4)] = rate(best_t, epb4, epb4)
-    best_epb = epb4 if epb4 > 1 and sweep['%dthr_epb%d' % (best_t, epb4)] > sweep['%dthr_epb1' % best_t] else 1
-    torch.set_num_threads(best_t)
-    n_ep = max(best_epb, n_ep - n_ep % best_epb)
-    outs = []
-    t0 = time.perf_counter()
-    for e in range(0, n_ep, best_epb):
-        outs.append(run(xs_all[e:e + best_epb], xq_all[e:e + best_epb]))
-    dt = time.perf_counter() - t0
-    logits = torch.cat(outs)                                                  # [n_ep, 75, way]
+    sweep = {'%dthr' % t: rate(t, 2) for t in sorted({t for t in (8, 16, 32) if t <= logical} or {logical})}
+    best_t = int(max(sweep, key=sweep.get)[:-3])
+    W = max(1, physical // best_t)
+    n_ep = max(W, min(xs_all.shape[0], max(n_ep, 3 * W)))
+    d = tempfile.mkdtemp(prefix='fsvit_cpu_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    try:
+        torch.save({'xs': xs_all[:n_ep].contiguous(), 'xq': xq_all[:n_ep].contiguous(), 'sd': sd}, os.path.join(d, 'sample.pt'))
+        env = dict(os.environ, OMP_NUM_THREADS=str(best_t), MKL_NUM_THREADS=str(best_t))
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', d, str(w), str(W), str(best_t), model], env=env) for w in range(W)]
+        deadline = time.time() + 600
+        while not all(os.path.exists(os.path.join(d, 'ready.%d' % w)) for w in range(W)):
+            if time.time() > deadline or any(p.poll() not in (None, 0) for p in procs):
+                for p in procs:
+                    p.kill()
+                raise RuntimeError('cpu_baseline: a worker did not come up')
+            time.sleep(0.01)
+        open(os.path.join(d, 'go'), 'w').close()
+        for p in procs:
+            p.wait(timeout=900)
+        outs = [torch.load(os.path.join(d, 'out.%d.pt' % w)) for w in range(W)]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    t_go = min(o['t'][0] for o in outs)
+    dt5 = max(o['t'][1] for o in outs) - t_go
+    dt1 = max(o['t'][2] - o['t'][1] for o in outs)                    # workers start their 1-shot pass as they finish the 5-shot one
+    logits = torch.zeros(n_ep, *outs[0]['logits5'].shape[1:])
+    for o in outs:
+        logits[o['episodes']] = o['logits5']
     way, Q = logits.shape[-1], logits.shape[1]
     label = torch.arange(way).repeat_interleave(Q // way)
     acc_cpu = (logits.argmax(-1) == label).float().mean().item()
     g = gpu_logits[:n_ep].cpu()
     acc_gpu = (g.argmax(-1) == label).float().mean().item()
-    return {'value': n_ep / dt, 'unit': 'episodes/s', 'cores': best_t, 'kind': 'port',
-            'sample': f'{n_ep} episodes 5-way {shot}-shot ({way * (shot + Q // way)} images each) = the first {n_ep} episodes of the GPU leg, fp32 torch CPU oracle, '
-                      f'ep_per_batch={best_epb}, {best_t} threads (host: {physical} physical / {logical} logical cores), best of the sweep below, {dt:.1f} s',
-            'sweep_episodes_per_s': sweep, 'accuracy': acc_cpu, 'gpu_accuracy_same_episodes': acc_gpu,
+    return {'value': n_ep / dt5, 'unit': 'episodes/s', 'cores': W * best_t, 'kind': 'port',
+            'sample': f'{n_ep} episodes 5-way {shot}-shot ({way * (shot + Q // way)} images each) = the first {n_ep} episodes of the GPU leg, fp32 torch CPU '
+                      f'oracle, ep_per_batch=1, episode-parallel: {W} worker processes x {best_t} threads (host: {physical} physical / {logical} logical '
+                      f'cores), {dt5:.1f} s; then the same episodes as 1-shot, {dt1:.1f} s',
+            'one_shot': {'value': n_ep / dt1, 'unit': 'episodes/s', 'images_per_episode': way * (1 + Q // way)},
+            'single_process_thread_sweep_episodes_per_s': sweep, 'workers': W, 'threads_per_worker': best_t,
+            'accuracy': acc_cpu, 'gpu_accuracy_same_episodes': acc_gpu,
             'gpu_max_abs_dlogit_same_episodes': (g - logits).abs().max().item(),
             'gpu_argmax_agreement_same_episodes': (g.argmax(-1) == logits.argmax(-1)).float().mean().item()}
 
@@ -277,62 +350,159 @@ def _max_over_ranks(elapsed, world, dev):
     return elapsed
 
 
-def train_main(args, rank, world, dev):
-    """BASELINE configs[2]: one meta-tuning step = model.train() forward, CE, backward, (grad all-reduce), SGD step."""
+def train_leg(model_name, numerics, E, steps, warmup, rank, world, dev):
+    """`steps` timed meta-tuning steps of `model_name` (forward + CE + backward + (gradient all-reduce) + SGD) on E episodes per GPU of
+    10-way 5-shot 5-query; returns (whole-job episodes/s, ms per step, final loss, state dict)."""
     from fewshot_vit_amd import models, synthetic, utils, parallel
     from fewshot_vit_amd.utils import few_shot as fs
-    vis = args.model == 'visformer_micro_80'
-    flop_per_image, img = MODELS[args.model]
-    model = models.make('meta-baseline', encoder=args.model, encoder_args={'numerics': args.numerics, 'drop_path_rate': 0.5 if vis else 0.1})
+    vis = model_name == 'visformer_micro_80'
+    img = MODELS[model_name][1]
+    model = models.make('meta-baseline', encoder=model_name, encoder_args={'numerics': numerics, 'drop_path_rate': 0.5 if vis else 0.1})
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = synthetic.synthetic_checkpoint_sd(shapes, calib='visformer_micro_80' if vis else None)
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).train()
     opt, _ = utils.make_optimizer(model.parameters(), 'sgd', lr=0.001, weight_decay=5e-4)
-    way, shot, query, E = 10, 5, 5, args.train_episodes
+    way, shot, query = 10, 5, 5
     x_shot, x_query = device_episodes(999 + rank, E, way, shot, query, dev, img)
     label = fs.make_nk_label(way, query, E).to(dev)
+    reducer = parallel.GradBucket(model) if world > 1 else None
 
     def step():
         logits = model(x_shot, x_query).view(-1, way)
         loss = torch.nn.functional.cross_entropy(logits, label)
         opt.zero_grad()
         loss.backward()
-        if world > 1:
-            parallel.allreduce_mean_grads(model.parameters())
+        if reducer is not None:
+            reducer.allreduce_mean()
         opt.step()
         return loss
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     _barrier(world)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     _barrier(world)
     elapsed = _max_over_ranks(time.perf_counter() - t0, world, dev)
+    return world * E * steps / elapsed, 1e3 * elapsed / steps, float(loss), sd
+
+
+def train_workload(model_name):
+    vis = model_name == 'visformer_micro_80'
+    img = MODELS[model_name][1]
+    return ('BASELINE configs[2]: SUN-M train_meta.py meta-tuning step, Visformer-S (visformer_micro_80, drop_path 0.5), ep_per_batch episodes of '
+            '10-way 5-shot 5-query 80x80 (train_meta_mini_visformer_5shot.yaml), forward + CE + backward + SGD(0.9, wd 5e-4), episodes resident '
+            'in HBM') if vis else ('train_meta.py meta-tuning step with encoder %s (drop_path 0.1), episodes of 10-way 5-shot 5-query %dx%d, '
+                                   'forward + CE + backward + SGD(0.9, wd 5e-4), episodes resident in HBM' % (model_name, img, img))
+
+
+def train_main(args, rank, world, dev):
+    """BASELINE configs[2]: one meta-tuning step = model.train() forward, CE, backward, (grad all-reduce), SGD step."""
+    vis = args.model == 'visformer_micro_80'
+    E = args.train_episodes
+    eps, ms, loss, sd = train_leg(args.model, args.numerics, E, args.steps, args.warmup, rank, world, dev)
     if rank == 0:
-        imgs = way * (shot + query)
-        eps = world * E * args.steps / elapsed
-        flops_ep = 3.0 * flop_per_image * imgs          # forward + dgrad + wgrad
+        imgs = 100
+        flops_ep = 3.0 * MODELS[args.model][0] * imgs          # forward + dgrad + wgrad
         peak = MFMA_PEAK_TFLOPS[args.numerics]
         out = {'metric': 'train_episodes_per_sec_10way_5shot_%s' % ('visformer_s' if vis else args.model), 'value': eps, 'unit': 'episodes/s', 'n_gpus': world,
-               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE_NAME[args.numerics], 'data': 'synthetic',
-               'config': {'workload': ('BASELINE configs[2]: SUN-M train_meta.py meta-tuning step, Visformer-S (visformer_micro_80, '
-                                       'drop_path 0.5), ep_per_batch episodes of 10-way 5-shot 5-query 80x80 (train_meta_mini_visformer_5shot.yaml), '
-                                       'forward + CE + backward + SGD(0.9, wd 5e-4), episodes resident in HBM') if vis else
-                                      ('train_meta.py meta-tuning step with encoder %s (drop_path 0.1), episodes of 10-way 5-shot 5-query %dx%d, '
-                                       'forward + CE + backward + SGD(0.9, wd 5e-4), episodes resident in HBM' % (args.model, img, img)),
-                          'episodes_per_step_per_gpu': E, 'images_per_episode': imgs,
-                          'parallelism': 'episode axis sharded x%d, one all-reduce of the flattened gradients per step' % world},
+               'config': {'workload': train_workload(args.model), 'episodes_per_step_per_gpu': E, 'images_per_episode': imgs,
+                          'parallelism': 'episode axis sharded x%d, one all-reduce of the flat gradient bucket per step' % world},
                'whole_path_tflops': eps * flops_ep / 1e12, 'whole_path_mfma_frac': eps * flops_ep / 1e12 / peak,
                'roofline': {'bound': 'mfma', 'achieved': eps * flops_ep / 1e12, 'peak': peak, 'unit': 'TFLOP/s',
                             'frac': eps * flops_ep / 1e12 / peak, 'traffic': None, 'kernel': 'whole training step (forward + backward + SGD)'},
-               'final_loss': float(loss)}
+               'final_loss': loss}
         if world == 1 and not args.no_cpu_baseline and vis:
             out['cpu_baseline'] = cpu_train_baseline(sd)
         print(json.dumps(out), flush=True)
+
+
+def extra_legs(args, dev):
+    """The other single-GPU configurations of BASELINE.json on the same JSON line (rank 0, N = 1): configs[2] = the 800-image SUN-M meta-tuning
+    step (`train`), the DeiT-S/16 224 x 224 shape of configs[4] in eval (`deit`) and as a meta-tuning step (`deit_train`, 2 episodes = 200
+    images).  Each leg reports ms per step, whole-job episodes/s, algorithmic TFLOP/s and the fraction of the dense bf16 MFMA peak."""
+    legs = {}
+    peak = MFMA_PEAK_TFLOPS['bf16']
+
+    def free():
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    eps, ms, loss, _ = train_leg('visformer_micro_80', 'bf16', 8, 20, 3, 0, 1, dev)
+    tf = eps * 3.0 * MODELS['visformer_micro_80'][0] * 100 / 1e12
+    legs['train'] = {'value': eps, 'unit': 'train-episodes/s', 'ms_per_step': ms, 'steps': 20, 'warmup': 3, 'dtype': 'bf16', 'images_per_step': 800,
+                     'whole_path_tflops': tf, 'whole_path_mfma_frac': tf / peak, 'final_loss': loss, 'workload': train_workload('visformer_micro_80'),
+                     'note': 'FLOPs = 3 x forward (forward + data gradient + weight gradient), 4.87 TFLOP per step'}
+    free()
+    name = 'deit_small_patch16_224'
+    flop, img = MODELS[name]
+    from fewshot_vit_amd import models, synthetic
+    m = models.make('meta-baseline', encoder=name, encoder_args={'numerics': 'bf16'})
+    m.load_state_dict(synthetic.synthetic_checkpoint_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}), strict=True)
+    m = m.to(dev).eval()
+    eng = m.encoder.engine()
+    E, steps, warm = args.episodes, 5, 2
+    pool = [device_episodes(777 + i, E, 5, 5, 15, dev, img) for i in range(2)]
+    temp = float(m.temp.detach())
+    for i in range(warm):
+        eng.meta_baseline_forward(*pool[i % 2], temp, 'cos', want_stats=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        _, acc, _ = eng.meta_baseline_forward(*pool[i % 2], temp, 'cos', want_stats=True)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    eps = E * steps / el
+    tf = eps * (flop * 100 + HEAD_FLOP_PER_EPISODE) / 1e12
+    legs['deit'] = {'value': eps, 'unit': 'episodes/s', 'ms_per_step': 1e3 * el / steps, 'steps': steps, 'warmup': warm, 'dtype': 'bf16',
+                    'episodes_per_step': E, 'whole_path_tflops': tf, 'whole_path_mfma_frac': tf / peak, 'accuracy_last_step': float(acc.mean()),
+                    'workload': 'BASELINE configs[4] shape on one GPU: deit_small_patch16_224 (ViT-S/16), 224x224, 5-way 5-shot episodic eval, '
+                                '15 query/class, synthetic episodes resident in HBM, procedural weights'}
+    del pool, eng, m
+    free()
+    eps, ms, loss, _ = train_leg(name, 'bf16', 2, 5, 2, 0, 1, dev)
+    tf = eps * 3.0 * flop * 100 / 1e12
+    legs['deit_train'] = {'value': eps, 'unit': 'train-episodes/s', 'ms_per_step': ms, 'steps': 5, 'warmup': 2, 'dtype': 'bf16', 'images_per_step': 200,
+                          'whole_path_tflops': tf, 'whole_path_mfma_frac': tf / peak, 'final_loss': loss, 'workload': train_workload(name)}
+    free()
+    legs['end_to_end'] = end_to_end_leg(args, dev)
+    free()
+    return legs
+
+
+def end_to_end_leg(args, dev, n_images=12000, n_classes=20):
+    """The reference's own evaluation loop (test_phase/test_few_shot.py:45-56,79-94) end to end: a miniImageNet-FORMAT pickle (uint8
+    [12000, 84, 84, 3], 20 classes x 600 - the test split's shape, synthetic content) -> datasets.make('mini-imagenet') (one upload) ->
+    CategoriesSampler on the host (the reference's legacy-RNG stream) -> fsvit_image_transform_gather (Resize 88 / CenterCrop 80 / Normalize
+    on the GPU) -> fsvit_meta_baseline_forward -> acc +- CI over 2000 batches of one 5-way 5-shot episode."""
+    import pickle
+    import tempfile
+    import numpy as np
+    from fewshot_vit_amd import test_few_shot
+    rng = np.random.default_rng(12345)
+    per = n_images // n_classes
+    mu = rng.integers(64, 192, size=(n_classes, 1, 84, 84, 3)).astype(np.int16)
+    data = np.clip(mu + rng.integers(-64, 65, size=(n_classes, per, 84, 84, 3), dtype=np.int16), 0, 255).astype(np.uint8).reshape(-1, 84, 84, 3)
+    labels = np.repeat(np.arange(n_classes), per).tolist()
+    with tempfile.TemporaryDirectory() as root:
+        with open(os.path.join(root, 'miniImageNet_category_split_test.pickle'), 'wb') as f:
+            pickle.dump({'data': data, 'labels': labels}, f, protocol=4)
+        cfg = {'dataset': 'mini-imagenet', 'dataset_args': {'root_path': root, 'split': 'test'}, 'synthetic_checkpoint': 'visformer_micro_80'}
+        logs = []
+        test_few_shot.evaluate(cfg, shot=5, n_batch=256, launch_batches=args.episodes, numerics='bf16', device=dev, log=logs.append)     # warm-up
+        t0 = time.perf_counter()
+        r = test_few_shot.evaluate(cfg, shot=5, n_batch=2000, launch_batches=args.episodes, numerics='bf16', device=dev, log=logs.append)
+        wall = time.perf_counter() - t0
+    return {'value': 2000 / r['loop_seconds'], 'unit': 'episodes/s', 'episodes': 2000, 'loop_seconds': r['loop_seconds'], 'evaluate_call_seconds': wall,
+            'episodes_per_launch': args.episodes, 'accuracy': r['acc'], 'ci95': r['ci'], 'dtype': 'bf16',
+            'workload': 'test_few_shot.evaluate on a miniImageNet-format uint8 table (12000 x 84 x 84 x 3): host CategoriesSampler -> device gather + '
+                        'Resize(88) / CenterCrop(80) / Normalize -> encoder + cosine head -> acc +- CI; `value` = 2000 episodes / loop time (after model and '
+                        'dataset construction), `evaluate_call_seconds` = the whole call incl. pickle load, upload, weight packing'}
 
 
 def _committed_pmc(dom_kernel):
@@ -349,10 +519,17 @@ def _committed_pmc(dom_kernel):
     def pick(tj):
         return [k for k in tj if k == dom_kernel] or [k for k in tj if k.split('<')[0] == dom_kernel.split('<')[0]]
     traffic = busy = None
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('csrc_hash', os.path.join(REPO, 'tools', 'csrc_hash.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    now = mod.csrc_sha()
+    fresh = {}
     tf = newest('r*_hbm_traffic.json')
     if tf:
         with open(tf) as f:
             tj = json.load(f)
+        fresh[os.path.basename(tf)] = tj.get('_meta', {}).get('csrc_sha') == now
         cand = pick(tj)
         if cand:      # several template instantiations behind one kernel name (conv2 / conv3 of the stem): launch-weighted mean
             n = sum(tj[k].get('launches', 1) for k in cand)
@@ -361,11 +538,16 @@ def _committed_pmc(dom_kernel):
     if mf:
         with open(mf) as f:
             mj = json.load(f)
+        fresh[os.path.basename(mf)] = mj.get('_meta', {}).get('csrc_sha') == now
         cand = pick(mj)
         if cand:
             n = sum(mj[k].get('launches', 1) for k in cand)
             busy = sum(mj[k].get('launches', 1) * mj[k].get('mfma_busy', 0.0) for k in cand) / n
-    return traffic, busy
+    stale = sorted(k for k, ok in fresh.items() if not ok)
+    if stale:
+        sys.stderr.write('bench.py: WARNING - the committed PMC summaries quoted in roofline.traffic / roofline.mfma_busy (%s) were collected from other '
+                         'kernel sources than this tree (few-shot-vit_amd/csrc changed since): re-run tools/pmc_bench.sh and commit the summaries\n' % ', '.join(stale))
+    return traffic, busy, {'files': sorted(fresh), 'match_current_csrc': not stale}
 
 
 def eval_main(args, rank, world, dev):
@@ -455,11 +637,11 @@ def eval_main(args, rank, world, dev):
         d = bykern[dom]
         peak = MFMA_PEAK_TFLOPS[args.numerics]
         achieved = d['flops'] / (d['ms'] * 1e-3) / 1e12
-        traffic = busy = None
+        traffic = busy = pmc_src = None
         if args.model == 'visformer_micro_80' and args.numerics == 'bf16' and E == 128 and args.chunk == 12800:
-            traffic, busy = _committed_pmc(dom)
+            traffic, busy, pmc_src = _committed_pmc(dom)
         out['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                           'traffic': traffic, 'mfma_busy': busy, 'kernel': dom, 'launches': d['launches'],
+                           'traffic': traffic, 'mfma_busy': busy, 'pmc_source': pmc_src, 'kernel': dom, 'launches': d['launches'],
                            'avg_launch_us': 1e3 * d['ms'] / d['launches'],
                            'avg_launch_gflop': d['flops'] / d['launches'] / 1e9,
                            'share_of_gpu_time': d['ms'] / sum(k['ms'] for k in bykern.values())}
@@ -530,17 +712,25 @@ def eval_main(args, rank, world, dev):
                                           '(peak 2500 / 4 TFLOP/s); also meets the 1e-3 logit tolerance against the reference goldens '
                                           '(tests/test_gpu_visformer.py::test_logits_two_limb_modes_vs_reference_golden: 1.5e-4; f16x2: 2.2e-5)'}
         del plog, olog, xlog
+    cpu_sample = None
     if world == 1 and not args.no_cpu_baseline:
-        k = min(E, max(4, args.cpu_episodes))
-        out['cpu_baseline'] = cpu_baseline(sd, pool[0][0][:k].cpu(), pool[0][1][:k].cpu(), head_logits[:k], args.cpu_episodes, args.model)
+        k = min(E, 32)
+        cpu_sample = (pool[0][0][:k].cpu(), pool[0][1][:k].cpu(), head_logits[:k].cpu())
+    if world == 1 and not args.no_legs and args.model == 'visformer_micro_80' and args.numerics == 'bf16':
+        del pool, engine, model, head_logits
+        out['legs'] = extra_legs(args, dev)
+    if cpu_sample is not None:
+        out['cpu_baseline'] = cpu_baseline(sd, cpu_sample[0], cpu_sample[1], cpu_sample[2], args.cpu_episodes, args.model)
     print(json.dumps(out), flush=True)
 
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
+    if argv and argv[0] == '--cpu-worker':
+        return cpu_worker(argv[1:])
     args = parse(argv)
     in_launcher = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
-    if not in_launcher and args.gpus > 1:
+    if not in_launcher and (args.gpus > 1 or args.via_launcher):
         return launch_ranks(args, argv)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))

@@ -20,7 +20,9 @@ def _check_generation(ctx):
 
 
 class VisformerTrainFn(torch.autograd.Function):
-    """feat = encoder(x) in train mode.  `params` are passed as inputs so autograd routes their gradients."""
+    """feat = encoder(x) in train mode.  `params` are passed as inputs so autograd routes their gradients.  With a gradient sink
+    (`trainer.grad_sink`: name -> (parameter, view into parallel.GradBucket's flat buffer)) the trainer writes every gradient straight into
+    the bucket, `.grad` is pointed at the view and autograd is handed None for those inputs (overwrite semantics: one backward per step)."""
 
     @staticmethod
     def forward(ctx, x, trainer, names, buffers, drop_path_rate, masks, *params):
@@ -28,6 +30,7 @@ class VisformerTrainFn(torch.autograd.Function):
         tensors.update(buffers)
         feat = trainer.forward(tensors, x, drop_path_rate, masks)
         ctx.trainer, ctx.names, ctx.buffers, ctx.generation = trainer, names, buffers, trainer.generation
+        ctx.sink = getattr(trainer, 'grad_sink', None)
         ctx.save_for_backward(*params)
         return feat
 
@@ -36,6 +39,14 @@ class VisformerTrainFn(torch.autograd.Function):
         _check_generation(ctx)
         params = ctx.saved_tensors
         tensors = dict(zip(ctx.names, params))
+        sink = ctx.sink
+        if sink is not None and all(k in sink and sink[k][1].shape == tensors[k].shape for k in ctx.names):
+            grads = {k: sink[k][1] for k in ctx.names}
+            tensors.update(ctx.buffers)
+            ctx.trainer.backward(tensors, grads, dfeat)
+            for k in ctx.names:
+                sink[k][0].grad = sink[k][1]
+            return (None,) * (6 + len(ctx.names))
         grads = {k: torch.empty_like(v) for k, v in tensors.items()}
         tensors.update(ctx.buffers)
         ctx.trainer.backward(tensors, grads, dfeat)

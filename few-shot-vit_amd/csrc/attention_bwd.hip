@@ -364,7 +364,7 @@ static int launch_bwd_mfma(const void* qkv, const void* dctx, void* dqkv, int B,
 
 int launch_attention_bwd(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, int hd, int hdp, float scale, int dtype, hipStream_t s) {
   if (B <= 0) return 0;
-  if (dtype == 1 && hdp % 32 == 0 && S <= 224 && getenv("FSVIT_ATTN_BWD_VALU") == nullptr) {      // bf16: MFMA kernel
+  if (dtype == 1 && hdp % 32 == 0 && S <= 224) {      // bf16: MFMA kernel
     bool ran = false;
     int rc = 0;
     const int ndt = hdp / 16;

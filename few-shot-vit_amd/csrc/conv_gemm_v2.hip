@@ -416,8 +416,7 @@ static int launch_cfg(const ConvGemmParams& p, hipStream_t stream) {
 
 template <typename T>
 static int launch_v2_t(const ConvGemmParams& p, hipStream_t stream) {
-  static const int force = [] { const char* e = getenv("FSVIT_GEMM_TILE"); return e ? atoi(e) : 0; }();   // experiments only
-  if (p.N > 64 && force != 64) return launch_cfg<T, 128, 128, 2, 2, 2>(p, stream);
+  if (p.N > 64) return launch_cfg<T, 128, 128, 2, 2, 2>(p, stream);
   if (p.N > 32) return launch_cfg<T, 128, 64, 2, 2, 3>(p, stream);
   return launch_cfg<T, 128, 32, 4, 1, 3>(p, stream);
 }

@@ -342,13 +342,12 @@ bool gemm256_eligible(const ConvGemmParams& p, int dtype) {
   if (dtype == 2) {
     // two-limb mode: conv_gemm_v2's 128 x 128 tile stages 32 flop per byte and runs at 100 .. 270 TFLOP/s; every dense 1x1 layer wide enough for
     // the 256-wide tile comes here
-    static const bool x2off = [] { const char* e = getenv("FSVIT_GEMM256_X2"); return e && e[0] == '0'; }();
-    return !x2off;
+    return true;
   }
   // One 8-wave workgroup per CU cannot hide its epilogue behind another workgroup's MFMAs, so the HBM-bound layers
   // (few flops per streamed byte: the N = 256 / residual projections) stay on conv_gemm_v2 (2-3 workgroups per CU);
   // measured crossover ~200 flop/B (profiles/r01_gemm256_layers.txt); 190 keeps the stage-2 qkv layer with 48-wide heads (N = 864, 197.5 flop/B) here.
-  static const double min_ai = [] { const char* e = getenv("FSVIT_GEMM256_MIN_AI"); return e ? atof(e) : 190.0; }();
+  const double min_ai = 190.0;
   const double ai = (double)p.N * p.K / ((double)p.K + (double)p.N * (p.res ? 2.0 : 1.0));
   return ai >= min_ai;
 }

@@ -19,17 +19,27 @@ EVAL_ONLY = (_lib.F16, _lib.BF16X2, _lib.F16X2)
 
 
 # Packed eval engines cache BN-folded copies of the weights.  The HIP optimizers and the HIP trainer write parameters and running
-# statistics through raw device pointers, which torch's per-tensor `_version` never sees - so every such write bumps this
-# process-wide generation and the encoders' engine fingerprints include it (a stale engine would silently report old-weight accuracy).
-_weight_generation = [0]
+# statistics through raw device pointers, which torch's per-tensor `_version` never sees - so every such write bumps a generation
+# PER WRITTEN TENSOR (keyed by its data pointer) and the encoders' engine fingerprints include the generations of their own tensors
+# only: a frozen teacher keeps its packed engine while a student trains next to it (offline.py), a stale engine is still impossible.
+_tensor_generation = {}
 
 
-def bump_weight_generation() -> None:
-    _weight_generation[0] += 1
+def bump_weight_generation(tensors) -> None:
+    """`tensors`: the torch tensors a HIP kernel has just written behind torch's back."""
+    for t in tensors:
+        if t is not None:
+            p = t.data_ptr()
+            _tensor_generation[p] = _tensor_generation.get(p, 0) + 1
 
 
-def weight_generation() -> int:
-    return _weight_generation[0]
+def weight_generation(t) -> int:
+    return _tensor_generation.get(t.data_ptr(), 0)
+
+
+def weights_fingerprint(module) -> tuple:
+    """(data_ptr, torch version, HIP-side generation) of every parameter and buffer of `module`."""
+    return tuple((t.data_ptr(), t._version, _tensor_generation.get(t.data_ptr(), 0)) for t in list(module.parameters()) + list(module.buffers()))
 
 
 def default_numerics() -> str:
@@ -280,7 +290,8 @@ class VisformerTrainer:
                                                               self._ws.numel(), _stream_ptr(x.device)))
         self._keep = (x, masks)
         self.generation += 1
-        bump_weight_generation()          # BatchNorm running statistics were updated in place
+        # BatchNorm running statistics were updated in place
+        bump_weight_generation(v for k, v in tensors.items() if k.endswith(('running_mean', 'running_var')))
         return feat
 
     def tokens(self, B: int, tokens_per_image: int) -> torch.Tensor:
@@ -543,7 +554,7 @@ class ops:
     @staticmethod
     def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
         _require_cuda(p, g, m, v)
-        bump_weight_generation()
+        bump_weight_generation((p,))
         with torch.cuda.device(p.device):
             _lib.check(_lib.load().fsvit_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
                                                     float(weight_decay), int(step), _stream_ptr(p.device)))
@@ -732,7 +743,7 @@ class ops:
             return
         _require_cuda(*params)
         lib = _lib.load()
-        bump_weight_generation()
+        bump_weight_generation(params)
         dev = params[0].device
         table = torch.tensor([[p.data_ptr(), g.data_ptr(), b.data_ptr(), p.numel()] for p, g, b in zip(params, grads, bufs)], dtype=torch.int64)
         with torch.cuda.device(dev):
@@ -745,7 +756,7 @@ class ops:
     def sgd_step(param, grad, buf, lr, momentum, weight_decay, first_step):
         _require_cuda(param, grad, buf)
         lib = _lib.load()
-        bump_weight_generation()
+        bump_weight_generation((param,))
         with torch.cuda.device(param.device):
             _lib.check(lib.fsvit_sgd_step(_ptr(param), _ptr(grad), _ptr(buf), param.numel(), float(lr), float(momentum),
                                           float(weight_decay), int(bool(first_step)), _stream_ptr(param.device)))

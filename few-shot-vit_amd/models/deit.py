@@ -80,8 +80,8 @@ class VisionTransformer(nn.Module):
         dev = self.pos_embed.device
         if dev.type != 'cuda':
             raise RuntimeError('fsvit: the encoder lives on %s; the HIP engine needs an MI355X (no CPU fallback)' % dev)
-        from ..engine import weight_generation
-        key = (weight_generation(), tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers())), self.numerics, str(dev))
+        from ..engine import weights_fingerprint
+        key = (weights_fingerprint(self), self.numerics, str(dev))
         if self._engine is None or self._engine_key != key:
             self._engine = VitEngine(self.cfg, self.state_dict(), numerics=self.numerics, device=dev)
             self._engine_key = key
@@ -116,6 +116,7 @@ class VisionTransformer(nn.Module):
         named = [(k, p) for k, p in self.named_parameters()]
         names = tuple(k for k, _ in named)
         masks = droppath_masks if droppath_masks is not None else self.draw_droppath_masks(x.shape[0], x.device)
+        self.trainer().grad_sink = getattr(self, '_grad_sink', None)       # parallel.GradBucket: gradients land in the flat all-reduce buffer
         return VisformerTrainFn.apply(x, self.trainer(), names, {}, self.drop_path_rate, masks, *[p for _, p in named])
 
 

@@ -134,8 +134,8 @@ class Visformer(nn.Module):
 
     # ------------------------------------------------------------------ engine management
     def _fingerprint(self):
-        from ..engine import weight_generation
-        return (weight_generation(),) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        from ..engine import weights_fingerprint
+        return weights_fingerprint(self)
 
     def engine(self):
         """Packed HIP engine for the current weights (re-packed when any tensor changed)."""
@@ -198,6 +198,7 @@ class Visformer(nn.Module):
         names = tuple(k for k, _ in named)
         buffers = {k: b for k, b in self.named_buffers() if not k.endswith('num_batches_tracked')}
         masks = droppath_masks if droppath_masks is not None else self.draw_droppath_masks(x.shape[0], x.device)
+        self.trainer().grad_sink = getattr(self, '_grad_sink', None)       # parallel.GradBucket: gradients land in the flat all-reduce buffer
         if self.return_map:
             from ..autograd import VisformerTrainMapFn
             tok, feat = VisformerTrainMapFn.apply(x, self.trainer(), names, buffers, self.drop_path_rate, masks, hw * hw, *[p for _, p in named])

@@ -55,10 +55,76 @@ def allreduce_mean_stats(sum_acc: float, sum_sq: float, n: float, device) -> tup
     return mean, var, cnt
 
 
+class GradBucket:
+    """The one exchange of a data-parallel training step, in place: every rank holds the gradient of ITS episodes' mean loss in ONE
+    persistent flat fp32 buffer (50 MB for Visformer-S: large enough to run the xGMI ring at bandwidth, one collective instead of 150) and
+    `allreduce_mean()` is a single all-reduce over that buffer - no flatten (`cat`) before it and no scatter after it.
+
+    `params`: the model's parameters (an iterable, or an nn.Module).  Each parameter's `.grad` becomes a view into the bucket.  The HIP
+    trainer writes its gradients straight into those views (autograd.VisformerTrainFn, `trainer.grad_sink`): with one forward / backward
+    per step (train_meta.py:161-170: zero_grad, backward, step) no torch kernel touches the gradients between the backward and the
+    collective.  Gradients that reach a parameter through plain autograd (the head's `temp`, a zero_grad(set_to_none=True) in between) are
+    copied into their view by `allreduce_mean()` - correct either way, the sink only removes the copy."""
+
+    def __init__(self, params, bucket_dtype=None):
+        import torch.nn as nn
+        self.module = params if isinstance(params, nn.Module) else None
+        ps = list(params.parameters()) if self.module is not None else list(params)
+        self.params = [p for p in ps if p.requires_grad]
+        if not self.params:
+            raise ValueError('GradBucket: no trainable parameters')
+        dev = self.params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        self.wire_dtype = bucket_dtype               # e.g. torch.bfloat16: halves the bytes on the xGMI ring, gradients are rounded once
+        self.views, off = [], 0
+        for p in self.params:
+            n = p.numel()
+            self.views.append(self.flat[off:off + n].view(p.shape))
+            off += n
+        self.attach()
+
+    def attach(self):
+        """Point every `.grad` at its view and hand the encoder trainers their sink (name -> (parameter, view))."""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+        if self.module is not None:
+            by_id = {id(p): v for p, v in zip(self.params, self.views)}
+            for m in self.module.modules():
+                if hasattr(m, 'trainer') and callable(m.trainer) and hasattr(m, 'named_parameters'):
+                    m._grad_sink = {k: (p, by_id[id(p)]) for k, p in m.named_parameters() if id(p) in by_id}
+
+    def detach(self):
+        if self.module is not None:
+            for m in self.module.modules():
+                if hasattr(m, '_grad_sink'):
+                    m._grad_sink = None
+
+    def _collect(self):
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                v.copy_(g)
+            p.grad = v
+
+    def allreduce_mean(self) -> None:
+        self._collect()
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        world = dist.get_world_size()
+        if self.wire_dtype is not None and self.wire_dtype != torch.float32:
+            wire = self.flat.to(self.wire_dtype)
+            dist.all_reduce(wire)
+            self.flat.copy_(wire).div_(world)
+            return
+        dist.all_reduce(self.flat)
+        self.flat.div_(world)
+
+
 def allreduce_mean_grads(params) -> None:
-    """The one exchange of a data-parallel training step: every rank holds the gradient of ITS episodes' mean loss;
-    flatten all of them into one bucket, all-reduce (sum) once over RCCL, divide by the world size and scatter the views
-    back.  One 50 MB bucket for Visformer-S: large enough to run the xGMI ring at bandwidth, one launch instead of 150."""
+    """Gradient all-reduce (mean) for loops that do not keep a GradBucket (train_classifier.py, offline.py): flatten, ONE all-reduce over
+    RCCL, divide, scatter the views back."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return
     grads = [p.grad for p in params if p.grad is not None]

@@ -68,6 +68,9 @@ def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch
 
     np.random.seed(12345)                                  # fixes the episode stream (test_few_shot.py:76)
     out = None
+    import time
+    torch.cuda.synchronize(device)
+    t_loop = time.perf_counter()
     # the reference keeps ONE pair of averagers and ONE va_lst across epochs (test_few_shot.py:73-74 sit outside the epoch loop), so the
     # accuracy / CI printed for epoch e covers every batch of epochs 1..e
     aves_va, aves_vl, va_lst = utils.Averager(), utils.Averager(), []
@@ -110,6 +113,8 @@ def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch
                    loss=aves_vl.item(), n=len(va_lst), last_label=last_label, va_lst=list(va_lst))
         if collect_pred:
             out['pred'] = torch.cat(preds) if preds else torch.zeros(0, n_way * n_query, dtype=torch.uint8)
+        # sampler -> gather + transform -> encoder + head -> statistics exchange, everything after model / dataset construction (the gather above synchronised)
+        out['loop_seconds'] = time.perf_counter() - t_loop
         if rank == 0:
             log('test epoch {}: acc={:.2f} +- {:.2f} (%), loss={:.4f} (@{})'.format(
                 epoch, out['acc'] * 100, out['ci'] * 100, out['loss'], last_label))

@@ -58,15 +58,19 @@ def build_model(config):
     return model
 
 
-def train_step(model, optimizer, x_shot, x_query, label, n_way, world=1):
-    """train_meta.py:161-174: forward, CE, zero_grad, backward, (gradient all-reduce), step.  Returns (loss, acc)."""
+def train_step(model, optimizer, x_shot, x_query, label, n_way, world=1, bucket=None):
+    """train_meta.py:161-174: forward, CE, zero_grad, backward, (gradient all-reduce), step.  Returns (loss, acc).
+    `bucket`: the model's parallel.GradBucket (world > 1): the gradients already sit in its flat buffer, the exchange is one in-place all-reduce."""
     logits = model(x_shot, x_query).view(-1, n_way)
     loss = F.cross_entropy(logits, label)
     acc = utils.compute_acc(logits, label)
     optimizer.zero_grad()
     loss.backward()
     if world > 1:
-        parallel.allreduce_mean_grads(model.parameters())
+        if bucket is not None:
+            bucket.allreduce_mean()
+        else:
+            parallel.allreduce_mean_grads(model.parameters())
     optimizer.step()
     return loss.item(), acc
 
@@ -119,6 +123,7 @@ def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, sa
     else:
         optimizer, lr_scheduler = utils.make_optimizer(model.parameters(), config['optimizer'], **config['optimizer_args'])
 
+    bucket = parallel.GradBucket(model) if world > 1 else None      # gradients are written straight into the all-reduce buffer
     max_epoch, save_epoch = config['max_epoch'], config.get('save_epoch')
     max_va = 0.
     timer_used, timer_epoch = utils.Timer(), utils.Timer()
@@ -137,7 +142,7 @@ def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, sa
             data = _batch(train_dataset, idx, device)
             x_shot, x_query = fs.split_shot_query(data, n_train_way, n_train_shot, n_train_query, ep_per_batch=ep_local)
             label = fs.make_nk_label(n_train_way, n_train_query, ep_per_batch=ep_local).to(device)
-            loss, acc = train_step(model, optimizer, x_shot, x_query, label, n_train_way, world)
+            loss, acc = train_step(model, optimizer, x_shot, x_query, label, n_train_way, world, bucket)
             aves['tl'].add(loss)
             aves['ta'].add(acc)
 

@@ -262,3 +262,75 @@ def test_train_meta_driver_with_deit_encoder(tmp_path):
     ck = torch.load(os.path.join(str(tmp_path), 'd', 'epoch-last.pth'), map_location='cpu')
     m = models.load(ck)
     assert ck['model_args']['encoder'] == 'deit_nano_patch6_84' and m.encoder.out_dim == 224
+
+
+def test_deit_small_launch_size_invariance_12800_images():
+    """BASELINE configs[4] at the bench's launch size: the features of a 12 800-image (128-episode) DeiT-S/16 pass equal, bit for bit, the
+    features of the same images pushed through in 400-image launches - chunking, persistent-kernel tile tails and the fused row kernels'
+    partial last workgroups never change a value."""
+    from fewshot_vit_amd import models, synthetic
+    m = models.make('deit_small_patch16_224', numerics='bf16')
+    m.load_state_dict(synthetic.procedural_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}), strict=True)
+    m = m.cuda().eval()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(12800, 3, 224, 224, device='cuda', generator=g)
+    os.environ['FSVIT_CHUNK'] = '12800'
+    try:
+        m._engine = None
+        with torch.no_grad():
+            big = m(x).clone()
+    finally:
+        del os.environ['FSVIT_CHUNK']
+    m._engine = None                                  # default chunk (400 images)
+    picks = [0, 399, 400, 6399, 12400, 12799]
+    with torch.no_grad():
+        for lo in sorted({p // 400 * 400 for p in picks}):
+            small = m(x[lo:lo + 400])
+            assert torch.equal(small, big[lo:lo + 400]), lo
+    assert torch.isfinite(big).all() and float(big.std()) > 0
+
+
+def test_deit_small_train_step_200_images_equals_mean_of_single_episode_steps():
+    """DeiT-S/16 meta-tuning at 197 tokens x 200 images (2 episodes of 10-way 5-shot 5-query, the `deit_train` leg of bench.py): LayerNorm
+    networks have no cross-image coupling, so with fixed DropPath masks the two-episode gradient is the mean of the single-episode ones."""
+    from fewshot_vit_amd import models, synthetic
+    from fewshot_vit_amd.utils import few_shot as fs
+    E, way, shot, query = 2, 10, 5, 5
+    m = models.make('meta-baseline', encoder='deit_small_patch16_224', encoder_args={'numerics': 'bf16', 'drop_path_rate': 0.1})
+    m.load_state_dict(synthetic.procedural_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}), strict=True)
+    m = m.cuda().train()
+    g = torch.Generator(device='cuda').manual_seed(11)
+    mu = torch.randn(E, way, 1, 3, 224, 224, device='cuda', generator=g)
+    x = mu + torch.randn(E, way, shot + query, 3, 224, 224, device='cuda', generator=g)
+    xs, xq = x[:, :, :shot].contiguous(), x[:, :, shot:].contiguous().view(E, way * query, 3, 224, 224)
+    label = fs.make_nk_label(way, query, E).cuda()
+    n_shot = E * way * shot
+    gc = torch.Generator().manual_seed(3)
+    rates = [r for r in torch.linspace(0, 0.1, 12).tolist() if r > 0 for _ in range(2)]
+    masks = torch.stack([(1.0 - r + torch.rand(2 * n_shot, generator=gc)).floor() for r in rates]).cuda()
+
+    def run(xs_, xq_, label_, mk):
+        m.encoder.draw_droppath_masks = lambda n, dev: mk
+        m.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(m(xs_, xq_).view(-1, way), label_)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    loss_full, g_full = run(xs, xq, label, masks)
+    assert np.isfinite(loss_full) and all(torch.isfinite(v).all() for v in g_full.values())
+    per = way * shot
+    acc = {k: torch.zeros_like(v) for k, v in g_full.items()}
+    for e in range(E):
+        mk = torch.cat([masks[:, e * per:(e + 1) * per], masks[:, n_shot + e * way * query:n_shot + (e + 1) * way * query]], dim=1).contiguous()
+        _, ge = run(xs[e:e + 1], xq[e:e + 1], label[e * way * query:(e + 1) * way * query], mk)
+        for k in acc:
+            acc[k] += ge[k] / E
+    worst, wk = 0.0, None
+    for k, v in g_full.items():
+        n = float(acc[k].norm())
+        rel = float((v - acc[k]).norm()) / (n + 1e-12) if n > 1e-6 else 0.0
+        if rel > worst:
+            worst, wk = rel, k
+    print(f'DeiT-S/16 200-image step vs mean of 2 single-episode steps: worst gradient rel err {worst:.2e} ({wk}), loss {loss_full:.5f}')
+    assert worst <= 2e-5, (worst, wk)

@@ -74,3 +74,19 @@ def test_accuracy_agreement_bf16_vs_parity_2000_episodes():
     assert dmean <= p['ci']
     assert agree >= 0.98
     assert np.abs(va - vp).max() <= 5.5 / 75.0
+
+
+def test_bench_rank_launcher_route_on_a_gpu_box():
+    """`bench.py --gpus N` invoked plainly starts its ranks from a parent that never touches the GPU (device count by a throw-away child);
+    `--via-launcher` sends the 1-GPU run down that same child-spawn route, so it runs once where GPUs exist."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--via-launcher', '--steps', '3', '--warmup', '1', '--episodes', '16',
+                        '--chunk', '1600', '--no-modes', '--no-cpu-baseline', '--no-legs'], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['steps'] == 3 and line['value'] > 0 and line['roofline']['kernel']
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '64', '--steps', '1'], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 2 and 'GPU(s) visible' in r.stderr

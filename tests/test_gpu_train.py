@@ -477,3 +477,124 @@ def test_gconv3x3_vs_torch(shape, dtype):
     print(f'gconv3x3 {shape} {dtype}: forward {err:.3e}, data gradient {err_t:.3e} (max |y| {ref.abs().max():.2f})')
     tol = 1.2e-2 * max(1.0, ref.abs().max().item())       # the 16-bit rounding of the output
     assert err <= tol and err_t <= tol
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[2] at its own size
+def _full_size_batch(E=8, way=10, shot=5, query=5, seed=31):
+    from fewshot_vit_amd import synthetic
+    from fewshot_vit_amd.utils import few_shot as fs
+    x = synthetic.synthetic_episodes(seed, E, way, shot, query)
+    xs, xq = fs.split_shot_query(x, way, shot, query, E)
+    return xs.cuda(), xq.cuda(), fs.make_nk_label(way, query, E).cuda()
+
+
+@pytest.mark.parametrize('numerics', ['parity', 'bf16'])
+def test_full_size_800_image_step_equals_mean_of_single_episode_steps(numerics):
+    """The SUN-M step at the size train_meta_mini_visformer_5shot.yaml runs it (8 episodes x 10-way x (5 + 5) = 800 images, drop_path 0.5):
+    with frozen BatchNorm (train_meta.py:156-157) and fixed DropPath masks every image is independent, so the gradient of the 8-episode
+    step must equal the mean of the eight single-episode gradients - the full-size launch (split-slab weight gradients over 800 x 1600 rows,
+    the 800-image arenas, wgrad3x3 at full batch) against eight 100-image launches of the same kernels.  fp32 summation order is the only
+    difference in `parity`; in `bf16` the loss scale differs by 8 = 2^3, which is exact in bf16, so the same bound holds."""
+    from fewshot_vit_amd import models, synthetic, utils
+    E, way, shot, query = 8, 10, 5, 5
+    m = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={'numerics': numerics, 'drop_path_rate': 0.5})
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(synthetic.synthetic_checkpoint_sd(shapes), strict=True)
+    m = m.cuda().train()
+    utils.freeze_bn(m)
+    xs, xq, label = _full_size_batch(E, way, shot, query)
+    n_shot = E * way * shot
+    g = torch.Generator().manual_seed(7)
+    n_calls = m.encoder.trainer().n_droppath_calls(0.5)
+    rates = [r for b, r in enumerate(torch.linspace(0, 0.5, 9).tolist()) for _ in range(1 if b < 4 else 2) if r > 0]
+    assert len(rates) == n_calls
+    masks = torch.stack([(1.0 - r + torch.rand(2 * n_shot, generator=g)).floor() for r in rates]).cuda()
+
+    def run(xs_, xq_, label_, mk):
+        m.encoder.draw_droppath_masks = lambda n, dev: mk
+        m.zero_grad(set_to_none=True)
+        logits = m(xs_, xq_).view(-1, way)
+        loss = F.cross_entropy(logits, label_)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    loss_full, g_full = run(xs, xq, label, masks)
+    assert np.isfinite(loss_full) and all(torch.isfinite(v).all() for v in g_full.values())
+    per = way * shot
+    acc = {k: torch.zeros_like(v) for k, v in g_full.items()}
+    loss_sum = 0.0
+    for e in range(E):
+        mk = torch.cat([masks[:, e * per:(e + 1) * per], masks[:, n_shot + e * way * query:n_shot + (e + 1) * way * query]], dim=1).contiguous()
+        l, ge = run(xs[e:e + 1], xq[e:e + 1], label[e * way * query:(e + 1) * way * query], mk)
+        loss_sum += l
+        for k in acc:
+            acc[k] += ge[k] / E
+    assert abs(loss_full - loss_sum / E) <= 1e-5 * max(1.0, abs(loss_full))
+    worst, worst_k = 0.0, None
+    for k, v in g_full.items():
+        n = float(acc[k].norm())
+        if n <= 1e-6:
+            assert float(v.abs().max()) <= 1e-5, k
+            continue
+        rel = float((v - acc[k]).norm()) / n
+        if rel > worst:
+            worst, worst_k = rel, k
+    print(f'[{numerics}] 800-image step vs mean of 8 single-episode steps: worst gradient rel err {worst:.2e} ({worst_k}), loss {loss_full:.5f}')
+    assert worst <= 2e-5, (worst, worst_k)
+
+
+def test_full_size_800_image_step_live_batchnorm():
+    """The same 800-image step with live BatchNorm (batch statistics over all 800 x 1600 stem rows): everything finite, and the first
+    BatchNorm's running statistics after the step equal momentum-0.1 updates from torch's own statistics of conv1(x) over the batch."""
+    from fewshot_vit_amd import models, synthetic
+    E, way = 8, 10
+    m = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={'numerics': 'bf16', 'drop_path_rate': 0.5})
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = synthetic.synthetic_checkpoint_sd(shapes)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    xs, xq, label = _full_size_batch()
+    logits = m(xs, xq).view(-1, way)
+    loss = F.cross_entropy(logits, label)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss)) and torch.isfinite(logits).all()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    x = torch.cat([xs.reshape(-1, 3, 80, 80), xq.reshape(-1, 3, 80, 80)])
+    z = F.conv2d(x.double(), sd['encoder.stem.conv1.weight'].cuda().double(), stride=2, padding=1)
+    mean, var = z.mean(dim=(0, 2, 3)), z.var(dim=(0, 2, 3), unbiased=True)
+    rm = 0.9 * sd['encoder.stem.bn1.running_mean'].cuda().double() + 0.1 * mean
+    rv = 0.9 * sd['encoder.stem.bn1.running_var'].cuda().double() + 0.1 * var
+    torch.testing.assert_close(m.encoder.stem.bn1.running_mean.double(), rm, rtol=2e-2, atol=2e-3)      # bf16 operands of conv1
+    torch.testing.assert_close(m.encoder.stem.bn1.running_var.double(), rv, rtol=2e-2, atol=2e-3)
+    for k, v in m.state_dict().items():
+        if k.endswith(('running_mean', 'running_var')):
+            assert torch.isfinite(v).all() and not torch.equal(v.cpu(), sd[k]), k
+
+
+def test_frozen_teacher_keeps_its_engine_while_a_student_trains():
+    """raw-pointer writes invalidate the packed engines of the tensors they touch only - a student's train-mode forward and
+    optimizer step must not make a frozen teacher re-pack (offline.py runs both every iteration)."""
+    from fewshot_vit_amd import models, synthetic, utils
+    from fewshot_vit_amd.utils import few_shot as fs
+    teacher = models.make('visformer_micro_80', numerics='bf16').cuda().eval()
+    student = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={'numerics': 'bf16'}).cuda().train()
+    opt, _ = utils.make_optimizer(student.parameters(), 'sgd', lr=0.01, weight_decay=5e-4)
+    x = synthetic.synthetic_episodes(5, 1, 5, 1, 3).cuda()
+    xs, xq = fs.split_shot_query(x, 5, 1, 3, 1)
+    label = fs.make_nk_label(5, 3, 1).cuda()
+    with torch.no_grad():
+        teacher(x)
+    eng = teacher.engine()
+    for _ in range(2):
+        loss = F.cross_entropy(student(xs, xq).view(-1, 5), label)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            teacher(x)
+        assert teacher.engine() is eng
+    s_eng = student.encoder.engine()
+    loss = F.cross_entropy(student(xs, xq).view(-1, 5), label)           # running statistics written through raw pointers
+    assert student.encoder.engine() is not s_eng

@@ -63,7 +63,7 @@ def test_two_rank_gather_matches_single_process(n_batch):
         assert ci == pytest.approx(float(utils.mean_confidence_interval(ref[:, 0].tolist())), abs=1e-12)
 
 
-def _grad_worker(rank, world, port, q):
+def _grad_worker(rank, world, port, q, use_bucket=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -75,8 +75,17 @@ def _grad_worker(rank, world, port, q):
     np.random.seed(1)
     idx = next(iter(CategoriesSampler(label, 1, 5, 4, ep_per_batch=4)))              # same stream on every rank
     mine = parallel.shard_episode_axis(idx, 4, rank, world)
-    loss_fn(params, data[mine % len(data)].view(4 // world, -1, data.shape[1])).backward()
-    parallel.allreduce_mean_grads(params)
+    if use_bucket:                      # persistent flat buffer, `.grad` = views into it, ONE in-place all-reduce
+        bucket = parallel.GradBucket(params)
+        for it in range(2):             # second step: zero_grad(set_to_none) dropped the views, the bucket collects and re-attaches
+            for p in params:
+                p.grad = None if it else p.grad
+            loss_fn(params, data[mine % len(data)].view(4 // world, -1, data.shape[1])).backward()
+            bucket.allreduce_mean()
+            assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, bucket.views))
+    else:
+        loss_fn(params, data[mine % len(data)].view(4 // world, -1, data.shape[1])).backward()
+        parallel.allreduce_mean_grads(params)
     q.put((rank, [p.grad.numpy().copy() for p in params], mine.tolist()))
     dist.destroy_process_group()
 
@@ -91,7 +100,8 @@ def _toy_problem():
     return params, data, loss_fn
 
 
-def test_two_rank_gradient_allreduce_matches_single_process_step():
+@pytest.mark.parametrize('use_bucket', [False, True])
+def test_two_rank_gradient_allreduce_matches_single_process_step(use_bucket):
     """train_meta.py data parallelism: ranks keep slices of the batch's episode axis; the all-reduced mean of their
     gradients equals the gradient of the whole batch's mean loss."""
     from fewshot_vit_amd import parallel
@@ -107,7 +117,7 @@ def test_two_rank_gradient_allreduce_matches_single_process_step():
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q, use_bucket)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in procs]

@@ -19,6 +19,7 @@ import json
 import sqlite3
 import sys
 
+from csrc_hash import csrc_sha
 from rocpd_stats import short
 
 
@@ -42,7 +43,7 @@ def main():
     acc = {}
     for p in dbs:
         load(p, acc)
-    out = {'_meta': {'source': 'rocprofv3 --pmc SQ_* / GRBM_GUI_ACTIVE passes (kernels serialised by the profiler); ' + note,
+    out = {'_meta': {'csrc_sha': csrc_sha(), 'source': 'rocprofv3 --pmc SQ_* / GRBM_GUI_ACTIVE passes (kernels serialised by the profiler); ' + note,
                      'mfma_busy': 'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)'}}
     rows = []
     for k, d in acc.items():
