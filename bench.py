@@ -443,7 +443,7 @@ def extra_legs(args, dev):
     flop, img = MODELS[name]
     from fewshot_vit_amd import models, synthetic
     m = models.make('meta-baseline', encoder=name, encoder_args={'numerics': 'bf16'})
-    m.load_state_dict(synthetic.synthetic_checkpoint_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}), strict=True)
+    m.load_state_dict(synthetic.synthetic_checkpoint_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}, calib=None), strict=True)
     m = m.to(dev).eval()
     eng = m.encoder.engine()
     E, steps, warm = args.episodes, 5, 2

@@ -61,6 +61,7 @@ SIGNATURES = {
     'fsvit_encoder_profile_end': (_i, [_vp, C.POINTER(ProfRec), _i, C.POINTER(_i)]),
     'fsvit_kernel_name': (C.c_char_p, [_i, _i]),
     'fsvit_proto_head': (_i, [_fp, _fp, _i, _i, _i, _i, _i, _f, _i, _fp, _fp, _fp, _vp]),
+    'fsvit_proto_head_devtemp': (_i, [_fp, _fp, _i, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _vp]),
     'fsvit_meta_baseline_forward': (_i, [_vp, _fp, _fp, _i, _i, _i, _i, _i, _i, _f, _i, _fp, _fp, _fp, _fp,
                                          _vp, _sz, _vp]),
     'fsvit_conv_gemm': (_i, [_vp, _vp, _fp, _vp, _fp, _vp] + [_i] * 15 + [_i, _vp]),
@@ -101,6 +102,7 @@ SIGNATURES = {
     'fsvit_vit_train_backward': (_i, [_vp, C.POINTER(Param), _i, _fp, _vp]),
     'fsvit_proto_head_backward': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _fp, _fp, _vp]),
     'fsvit_proto_head_backward_sqr': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _fp, _fp, _vp]),
+    'fsvit_proto_head_backward_devtemp': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _vp]),
     'fsvit_visformer_trainer_set_freeze_bn': (_i, [_vp, _i]),
     'fsvit_sgd_step_multi': (_i, [_vp, _i, _sz, _f, _f, _f, _i, _vp]),
     'fsvit_sgd_step': (_i, [_fp, _fp, _fp, _sz, _f, _f, _f, _i, _vp]),

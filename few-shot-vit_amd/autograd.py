@@ -86,7 +86,7 @@ class ProtoHeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat_shot, feat_query, temp, method='cos'):
         feat_shot, feat_query = feat_shot.contiguous(), feat_query.contiguous()
-        logits, _, _ = ops.proto_head(feat_shot, feat_query, float(temp), method)
+        logits, _, _ = ops.proto_head(feat_shot, feat_query, temp if temp.is_cuda else float(temp), method)
         ctx.save_for_backward(feat_shot, feat_query, temp)
         ctx.method = method
         return logits
@@ -94,7 +94,7 @@ class ProtoHeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         feat_shot, feat_query, temp = ctx.saved_tensors
-        ds, dq, dt = ops.proto_head_backward(feat_shot, feat_query, dlogits, float(temp), ctx.method)
+        ds, dq, dt = ops.proto_head_backward(feat_shot, feat_query, dlogits, temp if temp.is_cuda else float(temp), ctx.method)
         return ds, dq, dt.reshape(temp.shape), None
 
 

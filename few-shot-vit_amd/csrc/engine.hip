@@ -790,7 +790,16 @@ extern "C" int fsvit_proto_head(const float* fs, const float* fq, int E, int way
   const int kdt = FSVIT_BF16;
   if (!fs || !fq || !logits) return fail(FSVIT_ERR_ARG, "null argument");
   if (method != FSVIT_HEAD_COS && method != FSVIT_HEAD_SQR && method != FSVIT_HEAD_DOT) return fail(FSVIT_ERR_ARG, "unknown head method %d", method);
-  RC_TRY(K(launch_proto_head)(fs, fq, E, way, shot, Q, D, temp, method, logits, acc, loss, (hipStream_t)stream));
+  RC_TRY(K(launch_proto_head)(fs, fq, E, way, shot, Q, D, temp, method, logits, acc, loss, (hipStream_t)stream, nullptr));
+  return 0;
+}
+
+extern "C" int fsvit_proto_head_devtemp(const float* fs, const float* fq, int E, int way, int shot, int Q, int D, const float* temp_dev,
+                                        int method, float* logits, float* acc, float* loss, void* stream) {
+  const int kdt = FSVIT_BF16;
+  if (!fs || !fq || !logits || !temp_dev) return fail(FSVIT_ERR_ARG, "null argument");
+  if (method != FSVIT_HEAD_COS && method != FSVIT_HEAD_SQR && method != FSVIT_HEAD_DOT) return fail(FSVIT_ERR_ARG, "unknown head method %d", method);
+  RC_TRY(K(launch_proto_head)(fs, fq, E, way, shot, Q, D, 0.f, method, logits, acc, loss, (hipStream_t)stream, temp_dev));
   return 0;
 }
 
@@ -890,7 +899,7 @@ extern "C" int fsvit_conv3x3_wgrad(const void* x, const void* dz, float* dw, int
   hipStream_t st = (hipStream_t)stream;
   void* scratch = nullptr;
   HIP_TRY(hipMalloc(&scratch, K(wgrad3x3_scratch_bytes)(O, Ig, groups, B * H * W)));
-  int rc = K(launch_wgrad3x3)(x, groups * Ig, dz, O, dw, (float*)scratch, B, H, W, O, Ig, groups, st);
+  int rc = K(launch_wgrad3x3)(x, groups * Ig, dz, O, dw, (float*)scratch, B, H, W, O, Ig, groups, st, nullptr);
   (void)hipStreamSynchronize(st);
   (void)hipFree(scratch);
   if (rc != 0) return hipfail((hipError_t)rc, "fsvit_conv3x3_wgrad");

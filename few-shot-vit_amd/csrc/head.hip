@@ -41,8 +41,10 @@ int launch_pool_affine(const void* x, const float* scale, const float* shift, fl
 template <int NT>
 __global__ __launch_bounds__(NT) void proto_head_kernel(const float* __restrict__ feat_shot, const float* __restrict__ feat_query,
                                                          int way, int shot, int Q, int D, float temp, int method,
-                                                         float* __restrict__ logits, float* __restrict__ acc, float* __restrict__ loss) {
+                                                         float* __restrict__ logits, float* __restrict__ acc, float* __restrict__ loss,
+                                                         const float* __restrict__ temp_dev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (temp_dev) temp = *temp_dev;                             // the learnable temperature read where it lives (no host round trip per step)
   float* proto = reinterpret_cast<float*>(smem);              // [way][D]
   float* qstat = proto + (size_t)way * D;                     // [Q][2]: correct flag, nll
   const int e = blockIdx.x;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(NT) void proto_head_kernel(const float* __restrict_
 }
 
 int launch_proto_head(const float* feat_shot, const float* feat_query, int E, int way, int shot, int Q, int D,
-                      float temp, int method, float* logits, float* acc, float* loss, hipStream_t s) {
+                      float temp, int method, float* logits, float* acc, float* loss, hipStream_t s, const float* temp_dev) {
   if (E <= 0) return 0;
   const size_t lds = ((size_t)way * D + (size_t)Q * 2) * sizeof(float);
   if (lds > 160 * 1024 || way < 1 || shot < 1 || Q < 1) return (int)hipErrorInvalidValue;
@@ -121,7 +123,7 @@ int launch_proto_head(const float* feat_shot, const float* feat_query, int E, in
   hipError_t e = hipFuncSetAttribute((const void*)proto_head_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(proto_head_kernel<1024>, dim3(E), dim3(1024), lds, s, feat_shot, feat_query, way, shot, Q, D, temp, method,
-                     logits, acc, loss);
+                     logits, acc, loss, temp_dev);
   return (int)hipGetLastError();
 }
 
@@ -131,8 +133,10 @@ int launch_proto_head(const float* feat_shot, const float* feat_query, int E, in
 constexpr int HB_NT = 1024;
 __global__ __launch_bounds__(HB_NT) void proto_head_bwd_kernel(const float* __restrict__ feat_shot, const float* __restrict__ feat_query,
                                                              const float* __restrict__ dlogits, int way, int shot, int Q, int D, float temp,
-                                                             float* __restrict__ dfeat_shot, float* __restrict__ dfeat_query, float* __restrict__ dtemp) {
+                                                             float* __restrict__ dfeat_shot, float* __restrict__ dfeat_query, float* __restrict__ dtemp,
+                                                             const float* __restrict__ temp_dev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (temp_dev) temp = *temp_dev;
   float* proto = reinterpret_cast<float*>(smem);            // [way][D] normalised prototypes
   float* dproto = proto + (size_t)way * D;                    // [way][D] gradient w.r.t. the normalised prototypes
   float* pinv = dproto + (size_t)way * D;                     // [way] 1 / |p_c|
@@ -209,8 +213,10 @@ __global__ __launch_bounds__(HB_NT) void proto_head_bwd_kernel(const float* __re
 // p_c = mean_s f_shot[c][s].  dq = -2 temp sum_c dl (q - p_c);  dp_c = 2 temp sum_q dl (q - p_c);  dtemp = -sum dl |q - p_c|^2.
 __global__ __launch_bounds__(256) void proto_head_sqr_bwd_kernel(const float* __restrict__ feat_shot, const float* __restrict__ feat_query,
                                                                  const float* __restrict__ dlogits, int way, int shot, int Q, int D, float temp,
-                                                                 float* __restrict__ dfeat_shot, float* __restrict__ dfeat_query, float* __restrict__ dtemp) {
+                                                                 float* __restrict__ dfeat_shot, float* __restrict__ dfeat_query, float* __restrict__ dtemp,
+                                                                 const float* __restrict__ temp_dev) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (temp_dev) temp = *temp_dev;
   float* proto = reinterpret_cast<float*>(smem);            // [way][D]
   float* red = proto + (size_t)way * D;                       // [4]
   const int e = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -251,24 +257,24 @@ __global__ __launch_bounds__(256) void proto_head_sqr_bwd_kernel(const float* __
 }
 
 int launch_proto_head_sqr_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
-                              float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s) {
+                              float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s, const float* temp_dev) {
   if (E <= 0) return 0;
   const size_t lds = ((size_t)way * D + 4) * sizeof(float);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute((const void*)proto_head_sqr_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(proto_head_sqr_bwd_kernel, dim3(E), dim3(256), lds, s, feat_shot, feat_query, dlogits, way, shot, Q, D, temp, dfeat_shot, dfeat_query, dtemp);
+  hipLaunchKernelGGL(proto_head_sqr_bwd_kernel, dim3(E), dim3(256), lds, s, feat_shot, feat_query, dlogits, way, shot, Q, D, temp, dfeat_shot, dfeat_query, dtemp, temp_dev);
   return (int)hipGetLastError();
 }
 
 int launch_proto_head_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
-                          float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s) {
+                          float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s, const float* temp_dev) {
   if (E <= 0) return 0;
   const size_t lds = ((size_t)2 * way * D + way + Q + HB_NT / 64) * sizeof(float);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute((const void*)proto_head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(proto_head_bwd_kernel, dim3(E), dim3(HB_NT), lds, s, feat_shot, feat_query, dlogits, way, shot, Q, D, temp, dfeat_shot, dfeat_query, dtemp);
+  hipLaunchKernelGGL(proto_head_bwd_kernel, dim3(E), dim3(HB_NT), lds, s, feat_shot, feat_query, dlogits, way, shot, Q, D, temp, dfeat_shot, dfeat_query, dtemp, temp_dev);
   return (int)hipGetLastError();
 }
 

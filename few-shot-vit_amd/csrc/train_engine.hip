@@ -101,6 +101,9 @@ struct fsvit_visformer_trainer {
   void* xnf = nullptr;
   float* scales = nullptr;                // [n_calls][B] = mask / keep
   const float* dtokens = nullptr;         // optional gradient of the post-norm token map for the next backward (distillation head)
+  // weight-gradient split slabs of a backward pass stay in the `save` arena and are summed by ONE table-driven launch at the end of the pass
+  std::vector<FinJob> fin;
+  size_t save_after_forward = 0;
 };
 
 namespace {
@@ -217,23 +220,22 @@ int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W
   const int Kc_pad = c.via_patches ? 32 : round_up(c.KH * c.KW * Cin_tot, 4);
   if (!c.via_patches && c.KH == 3 && c.KW == 3 && c.stride == 1 && c.pad == 1 && wgrad3x3_supported(t->dtype, c.O, c.Ig, c.groups, W)) {
     // direct kernel: no transposed copies of dz / im2col(x) (wgrad3x3.hip)
-    const size_t tmp_mark = t->tmp.off;
-    float* scratch = (float*)t->tmp.take(wgrad3x3_scratch_bytes(c.O, c.Ig, c.groups, M));
+    float* scratch = (float*)t->save.take(wgrad3x3_scratch_bytes(c.O, c.Ig, c.groups, M));
     if (!scratch) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (wgrad3x3)");
-    T_RUN(launch_wgrad3x3(x, Cin_tot, dz, rows, w->grad, scratch, B, H, W, c.O, c.Ig, c.groups, t->st));
-    t->tmp.off = tmp_mark;
+    int d[2] = {0, 0};
+    T_RUN(launch_wgrad3x3(x, Cin_tot, dz, rows, w->grad, scratch, B, H, W, c.O, c.Ig, c.groups, t->st, d));
+    if (!t->save.dry) t->fin.push_back(FinJob{scratch, w->grad, 3, 0, c.Ig, 3, 3, c.groups == 8 ? 1 : 0, d[1], d[0], 1, 1, 1, 1});
     return 0;
   }
   if ((c.via_patches || (c.KH == 1 && c.KW == 1 && c.stride == 1 && c.groups == 1)) && wgrad1x1_supported(t->dtype, rows, Cin_tot)) {
     // direct kernel on the row-major operands (x [M][Cin_tot] - or the 32-wide patch rows - and dz [M][rows]); the finalize pass is the round-1 one
-    const size_t tmp_mark = t->tmp.off;
     const int splits = wgrad1x1_splits(rows, Cin_tot, M);
-    float* ysp = (float*)t->tmp.take((size_t)round_up(rows, 4) * splits * Kc_pad * 4);
+    float* ysp = (float*)t->save.take((size_t)round_up(rows, 4) * splits * Kc_pad * 4);
     if (!ysp) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (wgrad1x1)");
     T_RUN(launch_wgrad1x1(x, Cin_tot, Cin_tot, dz, rows, rows, ysp, M, Kc_pad, t->st));
     const int KHf = c.via_patches ? 3 : c.KH, KWf = c.via_patches ? 3 : c.KW;
-    T_RUN(launch_wgrad_finalize(ysp, w->grad, c.O, c.Ig, KHf, KWf, 0, splits, Kc_pad, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols, t->st));
-    t->tmp.off = tmp_mark;
+    const bool fast = KHf == 1 && KWf == 1 && c.hd_rows == c.hdp_rows && c.hd_cols == c.hdp_cols && (c.Ig & 3) == 0 && (Kc_pad & 3) == 0;
+    if (!t->save.dry) t->fin.push_back(FinJob{ysp, w->grad, fast ? 1 : 0, c.O, c.Ig, KHf, KWf, 0, splits, Kc_pad, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols});
     return 0;
   }
   const int tiles = ((rows + 127) / 128) * ((Kc_pad + 127) / 128);
@@ -242,10 +244,10 @@ int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W
   if (splits > M / 512) splits = M / 512;
   if (splits < 1) splits = 1;
   const int Ks = round_up((M + splits - 1) / splits, 64), Mpad = splits * Ks;
+  float* ysp = (float*)t->save.take((size_t)round_up(rows, 4) * splits * Kc_pad * 4);
   const size_t tmp_mark = t->tmp.off;
   void* dzt = t->tmp.take((size_t)rows * Mpad * t->es);
   void* xct = t->tmp.take((size_t)Kc_pad * Mpad * t->es);
-  float* ysp = (float*)t->tmp.take((size_t)round_up(rows, 4) * splits * Kc_pad * 4);
   if (!dzt || !xct || !ysp) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (wgrad)");
   T_RUN(launch_transpose_cols(dz, dzt, M, rows, 0, rows, Mpad, t->dtype, t->st));
   if (c.via_patches) T_RUN(launch_transpose_cols(x, xct, M, 32, 0, 32, Mpad, t->dtype, t->st));
@@ -254,13 +256,23 @@ int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W
   ConvGemmParams p = gemm_params(dzt, xct, ysp, 1, rows, 1, Ks, Mpad, 1, 1, 1, 0, Kc_pad, splits * Kc_pad, Ks, Ks, splits);
   p.w_gstride = Ks; p.w_rstride = Mpad; p.out_f32 = 1;
   T_RUN(launch_conv_gemm(p, t->dtype, t->st));
-  if (c.groups > 1)
-    T_RUN(launch_wgrad_finalize_dense(ysp, w->grad, c.O / c.groups, c.Ig, c.KH, c.KW, c.groups, splits, Kc_pad, t->st));
-  else {
-    const int KHf = c.via_patches ? 3 : c.KH, KWf = c.via_patches ? 3 : c.KW;
-    T_RUN(launch_wgrad_finalize(ysp, w->grad, c.O, c.Ig, KHf, KWf, 0, splits, Kc_pad, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols, t->st));
+  if (!t->save.dry) {
+    if (c.groups > 1) t->fin.push_back(FinJob{ysp, w->grad, 2, c.O / c.groups, c.Ig, c.KH, c.KW, c.groups, splits, Kc_pad, 1, 1, 1, 1});
+    else {
+      const int KHf = c.via_patches ? 3 : c.KH, KWf = c.via_patches ? 3 : c.KW;
+      const bool fast = KHf == 1 && KWf == 1 && c.hd_rows == c.hdp_rows && c.hd_cols == c.hdp_cols && (c.Ig & 3) == 0 && (Kc_pad & 3) == 0;
+      t->fin.push_back(FinJob{ysp, w->grad, fast ? 1 : 0, c.O, c.Ig, KHf, KWf, 0, splits, Kc_pad, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols});
+    }
   }
   t->tmp.off = tmp_mark;
+  return 0;
+}
+
+// every deferred split-slab finalize of this backward pass (one or two launches)
+int run_finalizes(TR* t) {
+  if (t->save.dry || t->fin.empty()) return 0;
+  T_RUN(launch_wgrad_finalize_multi(t->fin.data(), (int)t->fin.size(), t->st));
+  t->fin.clear();
   return 0;
 }
 
@@ -287,14 +299,15 @@ int bn_fwd(TR* t, const std::string& name, const void* z, int M, int C, int act,
     T_RUN(launch_bn_fwd_finalize(partial, M, C, t->cfg.bn_eps, 0.1f, g->data, b->data, rm->data, rv->data, sv->mean, sv->invstd, sv->sa, sv->sb, t->st));
   }
   if (add) *add = PendingAdd{};
-  T_RUN(launch_bn_apply(z, sv->sa, sv->sb, res, y, (size_t)M, C, act, t->dtype, t->st));
+  if (y) T_RUN(launch_bn_apply(z, sv->sa, sv->sb, res, y, (size_t)M, C, act, t->dtype, t->st));     // (y == nullptr: the caller applies sa / sb in a fused pass)
   return 0;
 }
 
 // dy: gradient w.r.t. the BN output (after undoing the activation) -> dz; writes dgamma / dbeta
 // acc / scale2 / out2 / rows_per_img: the fused tail of launch_bn_bwd_apply (dz = acc + ..., out2 = scale2[image] * dz)
+// act: dy is the gradient BEHIND the LeakyReLU that followed this BatchNorm (no residual); the slope is applied inside the reduce and apply passes
 int bn_bwd(TR* t, const std::string& name, const BnSave& sv, const void* dy, void* dz, const void* acc = nullptr, const float* scale2 = nullptr,
-           void* out2 = nullptr, size_t rows_per_img = 0) {
+           void* out2 = nullptr, size_t rows_per_img = 0, bool act = false) {
   const fsvit_param *g = getp(t, name + ".weight"), *b = getp(t, name + ".bias");
   if (!g || !b) return FSVIT_ERR_KEY;
   const size_t mark = t->tmp.off;
@@ -303,9 +316,10 @@ int bn_bwd(TR* t, const std::string& name, const BnSave& sv, const void* dy, voi
   if (!partial || !coef) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (bn bwd)");
   float* dgamma = g->grad ? g->grad : coef + 3 * sv.C;
   float* dbeta = b->grad ? b->grad : coef + 4 * sv.C;
-  T_RUN(launch_bn_reduce(dy, sv.z, sv.mean, sv.invstd, partial, sv.M, sv.C, 1, t->dtype, t->st));
+  T_RUN(launch_bn_reduce(dy, sv.z, sv.mean, sv.invstd, partial, sv.M, sv.C, 1, t->dtype, t->st, nullptr, nullptr, nullptr, 0, act ? sv.sa : nullptr, act ? sv.sb : nullptr));
   T_RUN(launch_bn_bwd_finalize(partial, sv.M, sv.C, g->data, sv.invstd, dgamma, dbeta, coef, coef + sv.C, coef + 2 * sv.C, t->freeze_bn ? 1 : 0, t->st));
-  T_RUN(launch_bn_bwd_apply(dy, sv.z, sv.mean, sv.invstd, coef, coef + sv.C, coef + 2 * sv.C, dz, (size_t)sv.M, sv.C, t->dtype, t->st, acc, scale2, out2, rows_per_img));
+  T_RUN(launch_bn_bwd_apply(dy, sv.z, sv.mean, sv.invstd, coef, coef + sv.C, coef + 2 * sv.C, dz, (size_t)sv.M, sv.C, t->dtype, t->st, acc, scale2, out2, rows_per_img,
+                            act ? sv.sa : nullptr, act ? sv.sb : nullptr));
   t->tmp.off = mark;
   return 0;
 }
@@ -374,7 +388,7 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
   auto& S = t->stem;
   NEED(S.patches = take_act(t, M0 * 32)); NEED(S.z1 = take_act(t, M0 * t->C0)); NEED(S.a1 = take_act(t, M0 * t->C0));
   NEED(S.zd = take_act(t, M0 * t->C1)); NEED(S.ad = take_act(t, M0 * t->C1)); NEED(S.z2 = take_act(t, M0 * t->C1)); NEED(S.a2 = take_act(t, M0 * t->C1));
-  NEED(S.z3 = take_act(t, M0 * t->C1)); NEED(S.a3 = take_act(t, M0 * t->C1)); NEED(S.arg = (unsigned char*)t->save.take(M1 * t->C1)); NEED(S.x1 = take_act(t, M1 * t->C1));
+  NEED(S.z3 = take_act(t, M0 * t->C1)); S.a3 = nullptr; NEED(S.arg = (unsigned char*)t->save.take(M1 * t->C1)); NEED(S.x1 = take_act(t, M1 * t->C1));
   T_RUN(launch_im2col27(x, S.patches, B, img, img, H0, H0, dt, st));
   T_TRY(conv_fwd(t, sp.conv1, S.patches, B, H0, H0, S.z1, nullptr));
   T_TRY(bn_fwd(t, "stem.bn1", S.z1, (int)M0, t->C0, ACT_LRELU, nullptr, S.a1, &S.b1));
@@ -383,7 +397,7 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
   T_TRY(conv_fwd(t, sp.conv2, S.a1, B, H0, H0, S.z2, nullptr));
   T_TRY(bn_fwd(t, "stem.bn2", S.z2, (int)M0, t->C1, ACT_LRELU, nullptr, S.a2, &S.b2));
   T_TRY(conv_fwd(t, sp.conv3, S.a2, B, H0, H0, S.z3, nullptr));
-  T_TRY(bn_fwd(t, "stem.bn3", S.z3, (int)M0, t->C1, ACT_LRELU, S.ad, S.a3, &S.b3));
+  T_TRY(bn_fwd(t, "stem.bn3", S.z3, (int)M0, t->C1, ACT_LRELU, S.ad, nullptr, &S.b3));      // statistics only: applied inside the pooling pass below
   {
     const fsvit_param* pos = getp(t, "pos_embed1");
     if (!pos) return FSVIT_ERR_KEY;
@@ -391,7 +405,7 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
     float* pt = (float*)t->tmp.take((size_t)H1 * H1 * t->C1 * 4);
     NEED(pt);
     T_RUN(launch_transpose_cols(pos->data, pt, t->C1, H1 * H1, 0, H1 * H1, t->C1, 0, st));   // in [C][HW] -> out [HW][C]
-    T_RUN(launch_maxpool2_idx(S.a3, pt, S.x1, S.arg, B, H1, H1, t->C1, dt, st));
+    T_RUN(launch_bn_pool_fwd(S.z3, S.b3.sa, S.b3.sb, S.ad, pt, S.x1, S.arg, B, H1, H1, t->C1, dt, st));      // LeakyReLU(bn3 + identity) -> MaxPool -> + pos
   }
   void* xcur = S.x1;
   // residual adds in front of a BatchNorm are queued here and computed by that BatchNorm's reduce pass (bn_fwd); flush_add() launches a queued
@@ -622,9 +636,8 @@ int train_backward_impl(TR* t, const float* dfeat) {
       T_RUN(launch_transpose_cols(ps, pos->grad, H1 * H1, t->C1, 0, t->C1, H1 * H1, 0, st));
     }
     void* da3 = take_tmp(t, M0 * t->C1); NEED(da3);
-    T_RUN(launch_maxpool2_bwd(dx, S.arg, da3, B, H1, H1, t->C1, dt, st));
     void* g3 = take_tmp(t, M0 * t->C1); NEED(g3);
-    T_RUN(launch_bn_act_bwd(da3, S.z3, S.b3.sa, S.b3.sb, S.ad, g3, M0, t->C1, dt, st));       // gradient at (bn3(z3) + identity)
+    T_RUN(launch_pool_act_bwd(dx, S.arg, g3, B, H1, H1, t->C1, dt, st));                      // gradient at (bn3(z3) + identity): max-pool routing x LeakyReLU slope
     T_TRY(bn_bwd(t, "stem.bn3", S.b3, g3, da3));                                              // da3 := dz3
     T_TRY(conv_bwd_weight(t, sp.conv3, S.a2, B, H0, H0, da3));
     void* da2 = take_tmp(t, M0 * t->C1); NEED(da2);
@@ -632,17 +645,15 @@ int train_backward_impl(TR* t, const float* dfeat) {
     // identity path: ad = bn_d(zd)
     T_TRY(bn_bwd(t, "stem.downsample.1", S.bd, g3, da3));                                     // da3 := dzd
     T_TRY(conv_bwd_weight(t, sp.down, S.patches, B, H0, H0, da3));
-    T_RUN(launch_bn_act_bwd(da2, S.z2, S.b2.sa, S.b2.sb, nullptr, g3, M0, t->C1, dt, st));
-    T_TRY(bn_bwd(t, "stem.bn2", S.b2, g3, da2));                                              // da2 := dz2
+    // bn2 / bn1 are followed by a LeakyReLU: its slope rides in the BatchNorm backward's two passes (no bn_act_bwd pass, no 328 MB map)
+    T_TRY(bn_bwd(t, "stem.bn2", S.b2, da2, da2, nullptr, nullptr, nullptr, 0, true));         // da2 := dz2 (in place)
     T_TRY(conv_bwd_weight(t, sp.conv2, S.a1, B, H0, H0, da2));
     void* da1 = take_tmp(t, M0 * t->C0); NEED(da1);
     T_TRY(conv_bwd_data(t, sp.conv2, da2, B, H0, H0, da1));
-    void* g1 = take_tmp(t, M0 * t->C0); NEED(g1);
-    T_RUN(launch_bn_act_bwd(da1, S.z1, S.b1.sa, S.b1.sb, nullptr, g1, M0, t->C0, dt, st));
-    T_TRY(bn_bwd(t, "stem.bn1", S.b1, g1, da1));                                              // da1 := dz1
+    T_TRY(bn_bwd(t, "stem.bn1", S.b1, da1, da1, nullptr, nullptr, nullptr, 0, true));         // da1 := dz1 (in place)
     T_TRY(conv_bwd_weight(t, sp.conv1, S.patches, B, H0, H0, da1));
   }
-  return 0;
+  return run_finalizes(t);
 }
 
 }  // namespace
@@ -868,7 +879,7 @@ int vit_backward_impl(VT* t, const float* dfeat) {
     T_TRY(conv_bwd_weight(t, sp.pe, t->patches, (int)Mp, 1, 1, dzpe));
     T_TRY(bias_grad(t, peb, dzpe, (int)Mp, D, 1, 1));
   }
-  return 0;
+  return run_finalizes(t);
 }
 
 int vit_droppath_calls(const VT* t, float rate, std::vector<float>* keep) {
@@ -946,11 +957,12 @@ extern "C" int fsvit_vit_train_forward(fsvit_vit_trainer* t, const fsvit_param* 
     const int ncalls = vit_droppath_calls(t, drop_path_rate, &keep);
     t->scales = (float*)t->save.take((size_t)ncalls * n_img * 4);
     if (!t->scales) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small");
-    for (int k = 0; k < ncalls; ++k)
-      T_RUN(launch_scale_copy(masks_dev + (size_t)k * n_img, t->scales + (size_t)k * n_img, n_img, 1.0f / keep[k], t->st));
+    T_RUN(launch_droppath_scales(masks_dev, t->scales, ncalls, n_img, keep.data(), t->st));
   }
   T_TRY(run_packs(t));
-  return vit_forward_impl(t, x_nchw_dev, feat_dev);
+  const int rc_f = vit_forward_impl(t, x_nchw_dev, feat_dev);
+  t->save_after_forward = t->save.off;
+  return rc_f;
 }
 
 extern "C" int fsvit_vit_train_backward(fsvit_vit_trainer* t, const fsvit_param* params, int n_params, const float* dfeat_dev, void* stream) {
@@ -960,6 +972,8 @@ extern "C" int fsvit_vit_train_backward(fsvit_vit_trainer* t, const fsvit_param*
   for (int i = 0; i < n_params; ++i) t->P[params[i].name] = &params[i];
   t->st = (hipStream_t)stream;
   t->tmp.off = 0;
+  t->save.off = t->save_after_forward;            // the pass's weight-gradient slabs are appended to the saved activations
+  t->fin.clear();
   return vit_backward_impl(t, dfeat_dev);
 }
 
@@ -1050,11 +1064,12 @@ extern "C" int fsvit_visformer_train_forward(fsvit_visformer_trainer* t, const f
     const int ncalls = droppath_calls(t, drop_path_rate, &keep);
     t->scales = (float*)t->save.take((size_t)ncalls * n_img * 4);
     if (!t->scales) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small");
-    for (int k = 0; k < ncalls; ++k)
-      T_RUN(launch_scale_copy(masks_dev + (size_t)k * n_img, t->scales + (size_t)k * n_img, n_img, 1.0f / keep[k], t->st));
+    T_RUN(launch_droppath_scales(masks_dev, t->scales, ncalls, n_img, keep.data(), t->st));
   }
   T_TRY(run_packs(t));                              // every weight pack of this step (forward + data-gradient layouts) in one or two launches
-  return train_forward_impl(t, x_nchw_dev, feat_dev);
+  const int rc_f = train_forward_impl(t, x_nchw_dev, feat_dev);
+  t->save_after_forward = t->save.off;
+  return rc_f;
 }
 
 extern "C" int fsvit_visformer_train_backward(fsvit_visformer_trainer* t, const fsvit_param* params, int n_params, const float* dfeat_dev, void* stream) {
@@ -1063,6 +1078,8 @@ extern "C" int fsvit_visformer_train_backward(fsvit_visformer_trainer* t, const 
   bind_params(t, params, n_params);
   t->st = (hipStream_t)stream;
   t->tmp.off = 0;
+  t->save.off = t->save_after_forward;            // the pass's weight-gradient slabs are appended to the saved activations
+  t->fin.clear();
   return train_backward_impl(t, dfeat_dev);
 }
 
@@ -1078,6 +1095,16 @@ extern "C" int fsvit_proto_head_backward_sqr(const float* feat_shot, const float
   if (!feat_shot || !feat_query || !dlogits || !dfeat_shot || !dfeat_query) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
   int rc = launch_proto_head_sqr_bwd(feat_shot, feat_query, dlogits, E, way, shot, Q, D, temp, dfeat_shot, dfeat_query, dtemp_per_episode, (hipStream_t)stream);
   return rc ? fsvit_set_error(rc, "proto_head_sqr_bwd") : 0;
+}
+
+extern "C" int fsvit_proto_head_backward_devtemp(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D,
+                                                 const float* temp_dev, int method, float* dfeat_shot, float* dfeat_query, float* dtemp_per_episode, void* stream) {
+  if (!feat_shot || !feat_query || !dlogits || !dfeat_shot || !dfeat_query || !temp_dev) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
+  if (method != FSVIT_HEAD_COS && method != FSVIT_HEAD_SQR) return fsvit_set_error(FSVIT_ERR_ARG, "head backward: method 'cos' or 'sqr'");
+  int rc = method == FSVIT_HEAD_COS
+               ? launch_proto_head_bwd(feat_shot, feat_query, dlogits, E, way, shot, Q, D, 0.f, dfeat_shot, dfeat_query, dtemp_per_episode, (hipStream_t)stream, temp_dev)
+               : launch_proto_head_sqr_bwd(feat_shot, feat_query, dlogits, E, way, shot, Q, D, 0.f, dfeat_shot, dfeat_query, dtemp_per_episode, (hipStream_t)stream, temp_dev);
+  return rc ? fsvit_set_error(rc, "proto_head_bwd") : 0;
 }
 
 extern "C" int fsvit_attention_backward(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, int hd, int hdp, float scale, int dtype,

@@ -11,6 +11,15 @@ struct PackJobs { static constexpr int MAX = 40; PackJob job[MAX]; };
 int launch_pack_weight_multi(const PackJob* jobs, int n, int dtype, hipStream_t s);
 int launch_pack_weight(const float* w, void* out, int O, int Ig, int KH, int KW, int groups, int mode, int rows_pad, int Kw, int hd_rows, int hdp_rows,
                        int hd_cols, int hdp_cols, int dtype, hipStream_t s);
+// Deferred split-slab finalizes of a whole backward pass in one or two launches (the 38 per-layer finalize launches of a step were 10 .. 25 us
+// of latency each): kind 0 = wgrad_finalize_kernel, 1 = its 1x1 fast path, 2 = dense grouped, 3 = wgrad3x3_finalize_kernel (a = grouped flag,
+// b = njobs); the job table travels as a kernel argument, blockIdx.y = job
+struct FinJob { const float* y; float* dw; int kind, Ng, Ig, KH, KW, g, splits, Kc_pad, hd_rows, hdp_rows, hd_cols, hdp_cols; };
+struct FinJobs { static constexpr int MAX = 48; FinJob job[MAX]; };
+int launch_wgrad_finalize_multi(const FinJob* jobs, int n, hipStream_t s);
+// DropPath scales of all calls of a step in one launch: scales[k][b] = masks[k][b] / keep[k]
+struct DropKeep { static constexpr int MAX = 64; float inv[MAX]; };
+int launch_droppath_scales(const float* masks, float* scales, int ncalls, int n_img, const float* keep, hipStream_t s);
 int launch_wgrad_finalize(const float* y, float* dw, int Ng, int Ig, int KH, int KW, int g, int splits, int Kc_pad, int hd_rows, int hdp_rows, int hd_cols,
                           int hdp_cols, hipStream_t s);
 // grouped conv via one dense GEMM: keeps the diagonal (same-group) blocks
@@ -21,7 +30,8 @@ int launch_im2col_t(const void* x, void* out, int B, int H, int W, int ld, int c
 int launch_unpatch2(const void* g, void* dx, int B, int OH, int OW, int C, int dtype, hipStream_t s);
 int bn_reduce_blocks(int M);
 int launch_bn_reduce(const void* a, const void* z, const float* mean, const float* invstd, float* partial, int M, int C, int bwd, int dtype, hipStream_t s,
-                     const void* add_a = nullptr, const void* add_b = nullptr, const float* add_scale = nullptr, int rows_per_img = 0);
+                     const void* add_a = nullptr, const void* add_b = nullptr, const float* add_scale = nullptr, int rows_per_img = 0,
+                     const float* act_sa = nullptr, const float* act_sb = nullptr);
 int launch_bn_fwd_finalize(const float* partial, int M, int C, float eps, float momentum, const float* gamma, const float* beta, float* rmean, float* rvar,
                            float* mean, float* invstd, float* sa, float* sb, hipStream_t s);
 int launch_bn_bwd_finalize(const float* partial, int M, int C, const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* ca, float* cb,
@@ -32,7 +42,11 @@ int launch_bn_apply(const void* z, const float* sa, const float* sb, const void*
 int launch_bn_act_bwd(const void* dout, const void* z, const float* sa, const float* sb, const void* res, void* g, size_t M, int C, int dtype, hipStream_t s);
 int launch_bn_bwd_apply(const void* dy, const void* z, const float* mean, const float* invstd, const float* ca, const float* cb, const float* cc, void* dz,
                         size_t M, int C, int dtype, hipStream_t s, const void* acc = nullptr, const float* scale2 = nullptr, void* out2 = nullptr,
-                        size_t rows_per_img = 0);
+                        size_t rows_per_img = 0, const float* act_sa = nullptr, const float* act_sb = nullptr);
+// stem tail: LeakyReLU(sa * z + sb + res) -> MaxPool2d(2) -> + pos in one pass (arg = window position | 4 if the maximum is positive), and its backward
+int launch_bn_pool_fwd(const void* z, const float* sa, const float* sb, const void* res, const float* pos, void* out, unsigned char* arg, int B, int OH, int OW,
+                       int C, int dtype, hipStream_t s);
+int launch_pool_act_bwd(const void* dout, const unsigned char* arg, void* g, int B, int OH, int OW, int C, int dtype, hipStream_t s);
 int launch_gelu_fwd(const void* z, void* h, size_t n, int dtype, hipStream_t s);
 int launch_gelu_bwd(const void* dh, const void* z, void* dz, size_t n, int dtype, hipStream_t s);
 int launch_add_scaled(const void* a, const void* br, const float* scale, void* out, size_t n, size_t per_img, int dtype, hipStream_t s);
@@ -51,9 +65,9 @@ int launch_sgd(float* p, const float* g, float* buf, size_t n, float lr, float m
 int launch_attention_bwd(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, int hd, int hdp, float scale, int dtype, hipStream_t s);
 // prototype head backward (head.hip): dlogits [E,Q,way] -> dfeat_shot [E,way,shot,D], dfeat_query [E,Q,D], dtemp[E] (cos method)
 int launch_proto_head_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
-                          float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s);
+                          float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s, const float* temp_dev = nullptr);
 int launch_proto_head_sqr_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
-                          float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s);
+                          float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s, const float* temp_dev = nullptr);
 
 // ---- ViT / DeiT training (deit.py): LayerNorm with kept row statistics, token assembly, the final norm on the cls row
 int launch_ln_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M, int D, float eps, int dtype, hipStream_t s);

@@ -164,6 +164,98 @@ __global__ __launch_bounds__(256) void wgrad_finalize_dense_kernel(const float* 
   }
 }
 
+// All deferred finalizes of a backward pass: blockIdx.y = job, grid-stride over x inside the job (same arithmetic, same summation order as the
+// per-layer kernels above and wgrad3x3_finalize_kernel)
+__global__ __launch_bounds__(256) void wgrad_finalize_multi_kernel(const FinJobs jobs) {
+  const FinJob j = jobs.job[blockIdx.y];
+  const float* __restrict__ y = j.y;
+  float* __restrict__ dw = j.dw;
+  const int splits = j.splits, Kc_pad = j.Kc_pad;
+  const size_t gstep = (size_t)gridDim.x * 256, g0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j.kind == 1) {
+    const int i4n = j.Ig / 4;
+    const size_t total = (size_t)j.Ng * i4n;
+    for (size_t idx = g0; idx < total; idx += gstep) {
+      const int i = (int)(idx % i4n) * 4, n = (int)(idx / i4n);
+      const float* src = y + (size_t)n * splits * Kc_pad + i;
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+      int sp = 0;
+      for (; sp + 4 <= splits; sp += 4) {
+        s0 += *reinterpret_cast<const f32x4*>(src + (size_t)sp * Kc_pad);
+        s1 += *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 1) * Kc_pad);
+        s2 += *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 2) * Kc_pad);
+        s3 += *reinterpret_cast<const f32x4*>(src + (size_t)(sp + 3) * Kc_pad);
+      }
+      for (; sp < splits; ++sp) s0 += *reinterpret_cast<const f32x4*>(src + (size_t)sp * Kc_pad);
+      *reinterpret_cast<f32x4*>(dw + (size_t)n * j.Ig + i) = (s0 + s1) + (s2 + s3);
+    }
+  } else if (j.kind == 0) {
+    const size_t total = (size_t)j.Ng * j.Ig * j.KH * j.KW;
+    for (size_t idx = g0; idx < total; idx += gstep) {
+      const int kx = (int)(idx % j.KW);
+      size_t t2 = idx / j.KW;
+      const int ky = (int)(t2 % j.KH); t2 /= j.KH;
+      const int i = (int)(t2 % j.Ig);
+      const int n = (int)(t2 / j.Ig);
+      int k = (ky * j.KW + kx) * j.Ig + i;
+      if (j.hdp_cols != j.hd_cols) k = (k / j.hd_cols) * j.hdp_cols + k % j.hd_cols;
+      int r = n;
+      if (j.hdp_rows != j.hd_rows) r = (n / j.hd_rows) * j.hdp_rows + n % j.hd_rows;
+      const float* src = y + (size_t)r * splits * Kc_pad + k;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int sp = 0;
+      for (; sp + 4 <= splits; sp += 4) {
+        s0 += src[(size_t)sp * Kc_pad];
+        s1 += src[(size_t)(sp + 1) * Kc_pad];
+        s2 += src[(size_t)(sp + 2) * Kc_pad];
+        s3 += src[(size_t)(sp + 3) * Kc_pad];
+      }
+      for (; sp < splits; ++sp) s0 += src[(size_t)sp * Kc_pad];
+      dw[(((size_t)(j.g * j.Ng + n) * j.Ig + i) * j.KH + ky) * j.KW + kx] = (s0 + s1) + (s2 + s3);
+    }
+  } else if (j.kind == 2) {
+    const int groups = j.g;
+    const size_t total = (size_t)groups * j.Ng * j.Ig * j.KH * j.KW;
+    for (size_t idx = g0; idx < total; idx += gstep) {
+      const int kx = (int)(idx % j.KW);
+      size_t t2 = idx / j.KW;
+      const int ky = (int)(t2 % j.KH); t2 /= j.KH;
+      const int i = (int)(t2 % j.Ig);
+      const int o = (int)(t2 / j.Ig), g = o / j.Ng;
+      const int k = (ky * j.KW + kx) * (groups * j.Ig) + g * j.Ig + i;
+      float s = 0.f;
+      for (int sp = 0; sp < splits; ++sp) s += y[(size_t)o * splits * Kc_pad + (size_t)sp * Kc_pad + k];
+      dw[idx] = s;
+    }
+  } else {                                                   // wgrad3x3 partials [split][job][tap][32][32]
+    constexpr int JOB = 9 * 32 * 32;
+    const int grouped = j.g, njobs = j.Kc_pad, Ig = j.Ig, total = njobs * JOB;
+    for (size_t i4 = g0; i4 < (size_t)(total / 4); i4 += gstep) {
+      const int idx = (int)i4 * 4;
+      const int c = idx & 31, n = (idx >> 5) & 31, tp = (idx >> 10) % 9, job = idx / JOB;
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+      int sp = 0;
+      for (; sp + 4 <= splits; sp += 4) {
+        s0 += *reinterpret_cast<const f32x4*>(y + (size_t)sp * total + idx);
+        s1 += *reinterpret_cast<const f32x4*>(y + (size_t)(sp + 1) * total + idx);
+        s2 += *reinterpret_cast<const f32x4*>(y + (size_t)(sp + 2) * total + idx);
+        s3 += *reinterpret_cast<const f32x4*>(y + (size_t)(sp + 3) * total + idx);
+      }
+      for (; sp < splits; ++sp) s0 += *reinterpret_cast<const f32x4*>(y + (size_t)sp * total + idx);
+      const f32x4 sv = (s0 + s1) + (s2 + s3);
+      const int o = grouped ? job * 32 + n : (job & 3) * 32 + n;
+      const int ig = grouped ? c : (job >> 3) * 64 + ((job >> 2) & 1) * 32 + c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dw[((size_t)o * Ig + ig + e) * 9 + tp] = sv[e];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void droppath_scales_kernel(const float* __restrict__ masks, float* __restrict__ scales, int n_img, const DropKeep keep) {
+  const float inv = keep.inv[blockIdx.y];
+  for (int b = blockIdx.x * 256 + threadIdx.x; b < n_img; b += gridDim.x * 256) scales[(size_t)blockIdx.y * n_img + b] = masks[(size_t)blockIdx.y * n_img + b] * inv;
+}
+
 // ------------------------------------------------------------------------------------------------ transposes for wgrad
 // in [M][ld] (columns c0 .. c0+ncols) -> out [ncols][Mpad], zero for m >= M.  32x32 LDS tile transpose.
 template <typename T>
@@ -286,7 +378,8 @@ template <typename T, bool BWD, int V>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* a, const T* __restrict__ z, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd, float* __restrict__ partial, int M, int C,
                                                         const T* __restrict__ add_a = nullptr, const T* __restrict__ add_b = nullptr,
-                                                        const float* __restrict__ add_scale = nullptr, int rows_per_img = 1) {
+                                                        const float* __restrict__ add_scale = nullptr, int rows_per_img = 1,
+                                                        const float* __restrict__ act_sa = nullptr, const float* __restrict__ act_sb = nullptr) {
   constexpr int Q = V / 4;                               // V channels per lane (16 / sizeof(T), or 4 when C is not a multiple of that) = Q f32x4 groups
   __shared__ f32x4 red[2][Q][256];
   const int lanesC = C / V;
@@ -303,12 +396,21 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* a, const T* __r
   };
   for (int cv = cl; cv < lanesC; cv += LC) {            // (one pass for C <= 2048)
     const int c = cv * V;
-    f32x4 s0[Q], s1[Q], mu[Q], is[Q];
+    // Backward form with act_sa != nullptr: `a` is the gradient BEHIND a LeakyReLU(0.1) that followed this BatchNorm (y = act_sa * z + act_sb);
+    // the gradient at the BatchNorm output, dy = a * lrelu'(y), is formed on the fly (the stem's bn_act_bwd pass and its 328 MB map are gone)
+    f32x4 s0[Q], s1[Q], mu[Q], is[Q], asa[Q], asb[Q];
+    const bool act = BWD && act_sa != nullptr;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      s0[q] = s1[q] = mu[q] = is[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s0[q] = s1[q] = mu[q] = is[q] = asa[q] = asb[q] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (BWD) { mu[q] = *reinterpret_cast<const f32x4*>(mean + c + 4 * q); is[q] = *reinterpret_cast<const f32x4*>(invstd + c + 4 * q); }
+      if (act) { asa[q] = *reinterpret_cast<const f32x4*>(act_sa + c + 4 * q); asb[q] = *reinterpret_cast<const f32x4*>(act_sb + c + 4 * q); }
     }
+    auto lrelu_grad = [&](f32x4& d, const f32x4& zz, int q) {
+      const f32x4 yv = zz * asa[q] + asb[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = yv[e] > 0.f ? d[e] : 0.1f * d[e];
+    };
     if (live) {
       const size_t step = (size_t)gridDim.x * R;
       size_t m = (size_t)blockIdx.x * R + rl;
@@ -350,6 +452,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* a, const T* __r
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int q = 0; q < Q; ++q) {
+            if (act) lrelu_grad(va[u][q], vz[u][q], q);
             s0[q] += va[u][q];
             if (BWD) s1[q] += va[u][q] * (vz[u][q] - mu[q]) * is[q];
             else s1[q] += va[u][q] * va[u][q];
@@ -361,6 +464,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const T* a, const T* __r
         if (BWD) ld(z + m * C + c, vz);
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
+          if (act) lrelu_grad(va[q], vz[q], q);
           s0[q] += va[q];
           if (BWD) s1[q] += va[q] * (vz[q] - mu[q]) * is[q];
           else s1[q] += va[q] * va[q];
@@ -489,14 +593,21 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, const T* __restrict__ z, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ ca, const float* __restrict__ cb,
                                                            const float* __restrict__ cc, T* dz, size_t M, int C, const T* acc, const float* __restrict__ scale2,
-                                                           T* out2, size_t rows_per_img) {
+                                                           T* out2, size_t rows_per_img, const float* __restrict__ act_sa, const float* __restrict__ act_sb) {
   const int c4n = C / 4;
   const size_t total = M * c4n;
   GS_LOOP(idx, total) {
     const int c = (int)(idx % c4n) * 4;
     const size_t row = idx / c4n, off = row * C + c;
-    const f32x4 xh = (load4<T>(z + off) - *reinterpret_cast<const f32x4*>(mean + c)) * *reinterpret_cast<const f32x4*>(invstd + c);
-    f32x4 v = *reinterpret_cast<const f32x4*>(ca + c) * load4<T>(dy + off) + *reinterpret_cast<const f32x4*>(cb + c) +
+    const f32x4 zv = load4<T>(z + off);
+    const f32x4 xh = (zv - *reinterpret_cast<const f32x4*>(mean + c)) * *reinterpret_cast<const f32x4*>(invstd + c);
+    f32x4 d = load4<T>(dy + off);
+    if (act_sa) {                                     // dy = gradient behind the LeakyReLU(0.1) that followed this BatchNorm (see bn_reduce_kernel)
+      const f32x4 yv = zv * *reinterpret_cast<const f32x4*>(act_sa + c) + *reinterpret_cast<const f32x4*>(act_sb + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = yv[e] > 0.f ? d[e] : 0.1f * d[e];
+    }
+    f32x4 v = *reinterpret_cast<const f32x4*>(ca + c) * d + *reinterpret_cast<const f32x4*>(cb + c) +
               *reinterpret_cast<const f32x4*>(cc + c) * xh;
     if (acc) v += load4<T>(acc + off);
     store4<T>(dz + off, v);
@@ -591,6 +702,89 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
     p[C] = a == 1 ? d : z;
     p[(size_t)W * C] = a == 2 ? d : z;
     p[(size_t)W * C + C] = a == 3 ? d : z;
+  }
+}
+
+// Stem tail in one pass (visformer.py:224-237): y = LeakyReLU(sa * z + sb + res), MaxPool2d(2), + pos_embed1.  The activated map is never stored
+// (the separate bn_apply + maxpool pair wrote and re-read its 328 MB at 800 images).  arg = window position of the maximum (first of equals,
+// compared in fp32) | 4 when the maximum is positive - all the backward needs (LeakyReLU slope of the routed gradient).  V channels per thread.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_pool_fwd_kernel(const T* __restrict__ z, const float* __restrict__ sa, const float* __restrict__ sb,
+                                                          const T* __restrict__ res, const float* __restrict__ pos, T* __restrict__ out,
+                                                          unsigned char* __restrict__ arg, int B, int OH, int OW, int C) {
+  const int cvn = C / V, W = OW * 2;
+  const size_t total = (size_t)B * OH * OW * cvn;
+  GS_LOOP(idx, total) {
+    const int c = (int)(idx % cvn) * V;
+    const size_t pix = idx / cvn;
+    const int ox = (int)(pix % OW);
+    const size_t t2 = pix / OW;
+    const int oy = (int)(t2 % OH);
+    const size_t b = t2 / OH;
+    const size_t base = ((b * OH * 2 + oy * 2) * W + ox * 2) * C + c;
+    float best[V];
+    int bi[V];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t off = base + ((size_t)(k >> 1) * W + (k & 1)) * C;
+#pragma unroll
+      for (int q = 0; q < V / 4; ++q) {
+        f32x4 v = load4<T>(z + off + 4 * q) * *reinterpret_cast<const f32x4*>(sa + c + 4 * q) + *reinterpret_cast<const f32x4*>(sb + c + 4 * q);
+        if (res) v += load4<T>(res + off + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float y = v[e] > 0.f ? v[e] : 0.1f * v[e];
+          if (k == 0 || y > best[4 * q + e]) { best[4 * q + e] = y; bi[4 * q + e] = k; }
+        }
+      }
+    }
+    const size_t o = pix * C + c;
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+      f32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        r[e] = best[4 * q + e] + (pos ? pos[(size_t)(oy * OW + ox) * C + c + 4 * q + e] : 0.f);
+        arg[o + 4 * q + e] = (unsigned char)(bi[4 * q + e] | (best[4 * q + e] > 0.f ? 4 : 0));
+      }
+      store4<T>(out + o + 4 * q, r);
+    }
+  }
+}
+// Its backward: the pooled gradient is routed to the arg-max position with the LeakyReLU slope of that value, zeros elsewhere
+// (= maxpool2_bwd + bn_act_bwd of the unfused path, from 123 MB of inputs instead of 1.1 GB)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void pool_act_bwd_kernel(const T* __restrict__ dout, const unsigned char* __restrict__ arg, T* __restrict__ g,
+                                                           int B, int OH, int OW, int C) {
+  const int cvn = C / V, W = OW * 2;
+  const size_t total = (size_t)B * OH * OW * cvn;
+  GS_LOOP(idx, total) {
+    const int c = (int)(idx % cvn) * V;
+    const size_t pix = idx / cvn;
+    const int ox = (int)(pix % OW);
+    const size_t t2 = pix / OW;
+    const int oy = (int)(t2 % OH);
+    const size_t b = t2 / OH;
+    const size_t base = ((b * OH * 2 + oy * 2) * W + ox * 2) * C + c, o = pix * C + c;
+    float d[V];
+    int a[V];
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+      const f32x4 v = load4<T>(dout + o + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[4 * q + e] = arg[o + 4 * q + e]; d[4 * q + e] = (a[4 * q + e] & 4) ? v[e] : 0.1f * v[e]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t off = base + ((size_t)(k >> 1) * W + (k & 1)) * C;
+#pragma unroll
+      for (int q = 0; q < V / 4; ++q) {
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = (a[4 * q + e] & 3) == k ? d[4 * q + e] : 0.f;
+        store4<T>(g + off + 4 * q, r);
+      }
+    }
   }
 }
 
@@ -849,6 +1043,36 @@ int launch_pack_weight_multi(const PackJob* jobs, int n, int dtype, hipStream_t 
   }
   return 0;
 }
+int launch_wgrad_finalize_multi(const FinJob* jobs, int n, hipStream_t s) {
+  for (int i0 = 0; i0 < n; i0 += FinJobs::MAX) {
+    FinJobs fj;
+    const int m = n - i0 < FinJobs::MAX ? n - i0 : FinJobs::MAX;
+    size_t biggest = 0;
+    for (int i = 0; i < m; ++i) {
+      const FinJob& j = fj.job[i] = jobs[i0 + i];
+      size_t tot = j.kind == 1 ? (size_t)j.Ng * (j.Ig / 4) : j.kind == 0 ? (size_t)j.Ng * j.Ig * j.KH * j.KW
+                   : j.kind == 2 ? (size_t)j.g * j.Ng * j.Ig * j.KH * j.KW : (size_t)j.Kc_pad * 9 * 32 * 32 / 4;
+      if (tot > biggest) biggest = tot;
+    }
+    unsigned gx = (unsigned)((biggest + 255) / 256);
+    if (gx > 64) gx = 64;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(wgrad_finalize_multi_kernel, dim3(gx, (unsigned)m), dim3(256), 0, s, fj);
+    const int rc = (int)hipGetLastError();
+    if (rc) return rc;
+  }
+  return 0;
+}
+int launch_droppath_scales(const float* masks, float* scales, int ncalls, int n_img, const float* keep, hipStream_t s) {
+  if (ncalls <= 0) return 0;
+  if (ncalls > DropKeep::MAX) return (int)hipErrorInvalidValue;
+  DropKeep k;
+  for (int i = 0; i < ncalls; ++i) k.inv[i] = 1.0f / keep[i];
+  unsigned gx = (unsigned)((n_img + 255) / 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(droppath_scales_kernel, dim3(gx, (unsigned)ncalls), dim3(256), 0, s, masks, scales, n_img, k);
+  return (int)hipGetLastError();
+}
 int launch_wgrad_finalize(const float* y, float* dw, int Ng, int Ig, int KH, int KW, int g, int splits, int Kc_pad, int hd_rows, int hdp_rows, int hd_cols,
                           int hdp_cols, hipStream_t s) {
   const size_t total = (size_t)Ng * Ig * KH * KW;
@@ -897,13 +1121,13 @@ int launch_unpatch2(const void* g, void* dx, int B, int OH, int OW, int C, int d
 }
 int bn_reduce_blocks(int M) { int nb = (M + 63) / 64; return nb > 512 ? 512 : nb; }
 int launch_bn_reduce(const void* a, const void* z, const float* mean, const float* invstd, float* partial, int M, int C, int bwd, int dtype, hipStream_t s,
-                     const void* add_a, const void* add_b, const float* add_scale, int rows_per_img) {
+                     const void* add_a, const void* add_b, const float* add_scale, int rows_per_img, const float* act_sa, const float* act_sb) {
   const int nb = bn_reduce_blocks(M);
   if (!rows_per_img) rows_per_img = 1;
 #define FSVIT_BNR(T, V) do { if (bwd) hipLaunchKernelGGL((bn_reduce_kernel<T, true, V>), dim3(nb), dim3(256), 0, s, (const T*)a, (const T*)z, mean, invstd, partial, M, C, \
-                                                         (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, 1); \
+                                                         (const T*)nullptr, (const T*)nullptr, (const float*)nullptr, 1, act_sa, act_sb); \
                              else hipLaunchKernelGGL((bn_reduce_kernel<T, false, V>), dim3(nb), dim3(256), 0, s, (const T*)a, (const T*)z, mean, invstd, partial, M, C, \
-                                                     (const T*)add_a, (const T*)add_b, add_scale, rows_per_img); } while (0)
+                                                     (const T*)add_a, (const T*)add_b, add_scale, rows_per_img, (const float*)nullptr, (const float*)nullptr); } while (0)
   if (dtype == 0) FSVIT_BNR(float, 4);
   else if (C % 8 == 0) FSVIT_BNR(bf16, 8);
   else FSVIT_BNR(bf16, 4);
@@ -938,13 +1162,29 @@ int launch_bn_act_bwd(const void* dout, const void* z, const float* sa, const fl
   return (int)hipGetLastError();
 }
 int launch_bn_bwd_apply(const void* dy, const void* z, const float* mean, const float* invstd, const float* ca, const float* cb, const float* cc, void* dz,
-                        size_t M, int C, int dtype, hipStream_t s, const void* acc, const float* scale2, void* out2, size_t rows_per_img) {
+                        size_t M, int C, int dtype, hipStream_t s, const void* acc, const float* scale2, void* out2, size_t rows_per_img, const float* act_sa,
+                        const float* act_sb) {
   const size_t total = M * (C / 4);
   if (!rows_per_img) rows_per_img = 1;
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, (const float*)dy, (const float*)z, mean, invstd, ca, cb, cc, (float*)dz, M, C,
-                                       (const float*)acc, scale2, (float*)out2, rows_per_img),
+                                       (const float*)acc, scale2, (float*)out2, rows_per_img, act_sa, act_sb),
              hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, (const bf16*)dy, (const bf16*)z, mean, invstd, ca, cb, cc, (bf16*)dz, M, C,
-                                (const bf16*)acc, scale2, (bf16*)out2, rows_per_img));
+                                (const bf16*)acc, scale2, (bf16*)out2, rows_per_img, act_sa, act_sb));
+  return (int)hipGetLastError();
+}
+int launch_bn_pool_fwd(const void* z, const float* sa, const float* sb, const void* res, const float* pos, void* out, unsigned char* arg, int B, int OH, int OW,
+                       int C, int dtype, hipStream_t s) {
+  if (C % 8) return (int)hipErrorInvalidValue;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((bn_pool_fwd_kernel<float, 4>), dim3(gs_grid((size_t)B * OH * OW * (C / 4))), dim3(256), 0, s, (const float*)z, sa, sb, (const float*)res, pos,
+                                       (float*)out, arg, B, OH, OW, C),
+             hipLaunchKernelGGL((bn_pool_fwd_kernel<bf16, 8>), dim3(gs_grid((size_t)B * OH * OW * (C / 8))), dim3(256), 0, s, (const bf16*)z, sa, sb, (const bf16*)res, pos,
+                                (bf16*)out, arg, B, OH, OW, C));
+  return (int)hipGetLastError();
+}
+int launch_pool_act_bwd(const void* dout, const unsigned char* arg, void* g, int B, int OH, int OW, int C, int dtype, hipStream_t s) {
+  if (C % 8) return (int)hipErrorInvalidValue;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((pool_act_bwd_kernel<float, 4>), dim3(gs_grid((size_t)B * OH * OW * (C / 4))), dim3(256), 0, s, (const float*)dout, arg, (float*)g, B, OH, OW, C),
+             hipLaunchKernelGGL((pool_act_bwd_kernel<bf16, 8>), dim3(gs_grid((size_t)B * OH * OW * (C / 8))), dim3(256), 0, s, (const bf16*)dout, arg, (bf16*)g, B, OH, OW, C));
   return (int)hipGetLastError();
 }
 int launch_gelu_fwd(const void* z, void* h, size_t n, int dtype, hipStream_t s) {

@@ -214,7 +214,10 @@ size_t wgrad3x3_scratch_bytes(int O, int Ig, int groups, int M) {
   wgrad3x3_plan(O, Ig, groups, M, &splits, &cpw, &njobs);
   return (size_t)splits * njobs * wg3::JOB * sizeof(float);
 }
-int launch_wgrad3x3(const void* x, int xld, const void* dz, int zld, float* dw, float* scratch, int B, int H, int W, int O, int Ig, int groups, hipStream_t s) {
+// defer != nullptr: the split slabs are left in `scratch` for a later batched finalize (train_kernels.hip wgrad_finalize_multi, kind 3) and
+// defer[0..1] = {njobs, splits}
+int launch_wgrad3x3(const void* x, int xld, const void* dz, int zld, float* dw, float* scratch, int B, int H, int W, int O, int Ig, int groups, hipStream_t s,
+                    int* defer) {
   const int M = B * H * W;
   int splits, cpw, njobs;
   const int n_chunks = wgrad3x3_plan(O, Ig, groups, M, &splits, &cpw, &njobs);
@@ -233,6 +236,7 @@ int launch_wgrad3x3(const void* x, int xld, const void* dz, int zld, float* dw, 
   }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
+  if (defer) { defer[0] = njobs; defer[1] = splits; return 0; }
   const int total = njobs * wg3::JOB;
   hipLaunchKernelGGL(wgrad3x3_finalize_kernel, dim3((total / 4 + 255) / 256), dim3(256), 0, s, scratch, dw, O, Ig, groups == 8 ? 1 : 0, njobs, splits);
   return (int)hipGetLastError();

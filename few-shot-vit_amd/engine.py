@@ -402,6 +402,7 @@ class VitEngine(_EncoderEngine):
 
 class ops:
     """Operator-level entry points (storage dtype follows the input tensors: fp32 or bf16)."""
+    _sgd_tables = {}
 
     @staticmethod
     def _dt(t):
@@ -703,9 +704,14 @@ class ops:
         ds, dq = torch.empty_like(feat_shot), torch.empty_like(feat_query)
         dt = torch.empty(E, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            fn = lib.fsvit_proto_head_backward if method == 'cos' else lib.fsvit_proto_head_backward_sqr
-            _lib.check(fn(_ptr(feat_shot), _ptr(feat_query), _ptr(dlogits.contiguous().float()), E, way, shot, Q, D, float(temp), _ptr(ds), _ptr(dq), _ptr(dt),
-                          _stream_ptr(dev)))
+            if isinstance(temp, torch.Tensor) and temp.is_cuda:
+                _lib.check(lib.fsvit_proto_head_backward_devtemp(_ptr(feat_shot), _ptr(feat_query), _ptr(dlogits.contiguous().float()), E, way, shot, Q, D,
+                                                                 _ptr(temp.detach().float().contiguous()), _lib.HEAD_COS if method == 'cos' else _lib.HEAD_SQR,
+                                                                 _ptr(ds), _ptr(dq), _ptr(dt), _stream_ptr(dev)))
+            else:
+                fn = lib.fsvit_proto_head_backward if method == 'cos' else lib.fsvit_proto_head_backward_sqr
+                _lib.check(fn(_ptr(feat_shot), _ptr(feat_query), _ptr(dlogits.contiguous().float()), E, way, shot, Q, D, float(temp), _ptr(ds), _ptr(dq), _ptr(dt),
+                              _stream_ptr(dev)))
         return ds, dq, dt.sum()
 
     @staticmethod
@@ -745,12 +751,19 @@ class ops:
         lib = _lib.load()
         bump_weight_generation(params)
         dev = params[0].device
-        table = torch.tensor([[p.data_ptr(), g.data_ptr(), b.data_ptr(), p.numel()] for p, g, b in zip(params, grads, bufs)], dtype=torch.int64)
+        rows = tuple((p.data_ptr(), g.data_ptr(), b.data_ptr(), p.numel()) for p, g, b in zip(params, grads, bufs))
+        cached = ops._sgd_tables.get(dev)
+        if cached is None or cached[0] != rows:
+            # (pinned allocation + upload only when a pointer changed: with parallel.GradBucket or zero_grad(set_to_none=False) the gradients keep
+            # their addresses and a step uploads nothing; hipHostMalloc per step stalled the host behind the whole backward)
+            table = torch.tensor(rows, dtype=torch.int64).pin_memory()
+            with torch.cuda.device(dev):
+                cached = (rows, table.to(dev, non_blocking=True), table)
+            ops._sgd_tables[dev] = cached
         with torch.cuda.device(dev):
-            table_dev = table.pin_memory().to(dev, non_blocking=True)
-            _lib.check(lib.fsvit_sgd_step_multi(_ptr(table_dev), len(params), max(p.numel() for p in params), float(lr), float(momentum),
+            _lib.check(lib.fsvit_sgd_step_multi(_ptr(cached[1]), len(params), max(r[3] for r in rows), float(lr), float(momentum),
                                                 float(weight_decay), int(bool(first_step)), _stream_ptr(dev)))
-        return table_dev          # keep alive until the caller's next synchronisation point (the allocator is stream-ordered anyway)
+        return cached[1]
 
     @staticmethod
     def sgd_step(param, grad, buf, lr, momentum, weight_decay, first_step):
@@ -774,6 +787,11 @@ class ops:
         loss = torch.empty(E, dtype=torch.float32, device=dev)
         m = {'cos': _lib.HEAD_COS, 'sqr': _lib.HEAD_SQR, 'dot': _lib.HEAD_DOT}[method]
         with torch.cuda.device(dev):
-            _lib.check(lib.fsvit_proto_head(_ptr(feat_shot.contiguous().float()), _ptr(feat_query.contiguous().float()), E, way,
-                                            shot, Q, D, float(temp), m, _ptr(logits), _ptr(acc), _ptr(loss), _stream_ptr(dev)))
+            if isinstance(temp, torch.Tensor) and temp.is_cuda:      # the learnable temperature stays on the device: no .item() synchronisation per step
+                _lib.check(lib.fsvit_proto_head_devtemp(_ptr(feat_shot.contiguous().float()), _ptr(feat_query.contiguous().float()), E, way,
+                                                        shot, Q, D, _ptr(temp.detach().float().contiguous()), m, _ptr(logits), _ptr(acc), _ptr(loss),
+                                                        _stream_ptr(dev)))
+            else:
+                _lib.check(lib.fsvit_proto_head(_ptr(feat_shot.contiguous().float()), _ptr(feat_query.contiguous().float()), E, way,
+                                                shot, Q, D, float(temp), m, _ptr(logits), _ptr(acc), _ptr(loss), _stream_ptr(dev)))
         return logits, acc, loss

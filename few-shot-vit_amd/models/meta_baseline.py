@@ -46,7 +46,7 @@ class MetaBaseline(nn.Module):
         n_shot = E * way * shot
         f_shot = x_tot[:n_shot].view(E, way, shot, -1)
         f_query = x_tot[n_shot:].view(E, Q, -1)
-        temp = self.temp if isinstance(self.temp, torch.Tensor) else torch.tensor(float(self.temp), device=x_tot.device)
+        temp = self.temp if isinstance(self.temp, torch.Tensor) else torch.tensor(float(self.temp))      # (a host scalar: passed by value)
         return ProtoHeadFn.apply(f_shot, f_query, temp, self.method)
 
     def _forward_eval(self, x_shot, x_query):

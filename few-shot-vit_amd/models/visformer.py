@@ -165,15 +165,15 @@ class Visformer(nn.Module):
         if n == 0:
             return None
         depth = self.cfg['depth']
-        rates = torch.linspace(0, self.drop_path_rate, sum(depth)).tolist()
-        draws, keep = [], []
-        for b, r in enumerate(rates):
-            if r > 0:
-                for _ in range(1 if b < depth[0] else 2):
-                    draws.append(torch.rand(n_img, device=device))      # one generator call per DropPath call, as the reference makes them
-                    keep.append(1.0 - r)
+        key = (str(device), self.drop_path_rate)
+        if getattr(self, '_keep_key', None) != key:          # keep-probabilities per DropPath call, uploaded once (an upload per step is a stream synchronisation)
+            rates = torch.linspace(0, self.drop_path_rate, sum(depth)).tolist()
+            keep = [1.0 - r for b, r in enumerate(rates) if r > 0 for _ in range(1 if b < depth[0] else 2)]
+            self._keep_dev = torch.tensor(keep, dtype=torch.float32).to(device).unsqueeze(1)
+            self._keep_key = key
+        draws = [torch.rand(n_img, device=device) for _ in range(n)]     # one generator call per DropPath call, as the reference makes them
         # floor(keep_prob + rand) for all calls in one pass (same fp32 values as per-call arithmetic, a third of the launches)
-        return torch.stack(draws).add_(torch.tensor(keep, dtype=torch.float32, device=device).unsqueeze(1)).floor_()
+        return torch.stack(draws).add_(self._keep_dev).floor_()
 
     def forward(self, x, droppath_masks=None):
         """[B,3,img,img] fp32 -> [B,out_dim] pooled features (visformer.py:424-462).

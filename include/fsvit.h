@@ -134,6 +134,11 @@ int fsvit_vit_forward(fsvit_vit* h, const float* x_nchw_dev, int n_img, int img_
 int fsvit_proto_head(const float* feat_shot_dev, const float* feat_query_dev, int E, int way, int shot, int Q, int D,
                      float temp, int method, float* logits_dev, float* acc_dev, float* loss_dev, void* stream);
 
+/* The same with the temperature read from DEVICE memory (`self.temp` is an nn.Parameter the optimizer updates on the GPU, meta_baseline.py:20-21):
+ * the meta-tuning step never brings it to the host, so the step issues no stream synchronisation. */
+int fsvit_proto_head_devtemp(const float* feat_shot_dev, const float* feat_query_dev, int E, int way, int shot, int Q, int D,
+                             const float* temp_dev, int method, float* logits_dev, float* acc_dev, float* loss_dev, void* stream);
+
 /* Whole `MetaBaseline.forward(x_shot, x_query)` (meta_baseline.py:24-47) in eval mode:
  * x_shot_dev [E,way,shot,3,H,W], x_query_dev [E,Q,3,H,W] fp32 -> logits_dev [E,Q,way].
  * feat_dev: scratch [(E*way*shot + E*Q), out_dim] fp32. */
@@ -306,6 +311,10 @@ int fsvit_proto_head_backward(const float* feat_shot_dev, const float* feat_quer
 int fsvit_proto_head_backward_sqr(const float* feat_shot_dev, const float* feat_query_dev, const float* dlogits_dev, int E, int way,
                                   int shot, int Q, int D, float temp, float* dfeat_shot_dev, float* dfeat_query_dev,
                                   float* dtemp_per_episode_dev, void* stream);
+/* Both backward forms with the temperature read from device memory (method FSVIT_HEAD_COS or FSVIT_HEAD_SQR). */
+int fsvit_proto_head_backward_devtemp(const float* feat_shot_dev, const float* feat_query_dev, const float* dlogits_dev, int E, int way,
+                                      int shot, int Q, int D, const float* temp_dev, int method, float* dfeat_shot_dev,
+                                      float* dfeat_query_dev, float* dtemp_per_episode_dev, void* stream);
 /* The same update for a table of tensors in one launch.  items_dev: DEVICE array of n_items records {float* param; const float* grad;
  * float* momentum_buf; size_t numel} (4 x 8 bytes each); max_numel = the largest numel.  All tensors share lr / momentum / weight_decay /
  * first_step (one param_group of torch.optim.SGD, meta_tuning_sun_m/utils/__init__.py:128-139). */

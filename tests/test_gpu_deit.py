@@ -315,7 +315,7 @@ def test_deit_small_train_step_200_images_equals_mean_of_single_episode_steps():
         loss = torch.nn.functional.cross_entropy(m(xs_, xq_).view(-1, way), label_)
         loss.backward()
         torch.cuda.synchronize()
-        return float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        return float(loss.detach()), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
 
     loss_full, g_full = run(xs, xq, label, masks)
     assert np.isfinite(loss_full) and all(torch.isfinite(v).all() for v in g_full.values())

@@ -517,7 +517,7 @@ def test_full_size_800_image_step_equals_mean_of_single_episode_steps(numerics):
         loss = F.cross_entropy(logits, label_)
         loss.backward()
         torch.cuda.synchronize()
-        return float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        return float(loss.detach()), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
 
     loss_full, g_full = run(xs, xq, label, masks)
     assert np.isfinite(loss_full) and all(torch.isfinite(v).all() for v in g_full.values())
