@@ -198,6 +198,43 @@ def _physical_cores():
         return os.cpu_count()
 
 
+def _usable_cores():
+    """Physical cores this process may actually use: the host's physical core count clipped by the scheduler affinity mask and by a cgroup
+    CPU quota (a container limited to 16 CPUs of a 128-core host gains nothing from 128 threads - the sweeps of rounds 1 / 2 that peaked at
+    16 threads are what such a quota looks like).  Returns (usable, dict of what was found)."""
+    logical, physical = os.cpu_count() or 1, _physical_cores() or 1
+    info = {'logical': logical, 'physical': physical}
+    usable = physical
+    try:
+        aff = len(os.sched_getaffinity(0))
+        info['affinity_cpus'] = aff
+        if aff < logical:
+            usable = min(usable, max(1, aff * physical // logical))
+    except Exception:
+        pass
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:                     # cgroup v2
+            q, per = f.read().split()[:2]
+            if q != 'max':
+                quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:    # cgroup v1
+                q = float(f.read())
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        info['cgroup_cpu_quota'] = quota
+        usable = min(usable, max(1, int(quota)))
+    info['usable'] = usable
+    return usable, info
+
+
 def _oracle_runner(sd, model, img, shot):
     from oracle import visformer_oracle as vo
     if model == 'visformer_micro_80':
@@ -261,9 +298,10 @@ def cpu_baseline(sd, xs_all, xq_all, gpu_logits, n_ep, model='visformer_micro_80
         return n / (time.perf_counter() - t0)
 
     logical, physical = os.cpu_count() or 1, _physical_cores() or 1
+    usable, core_info = _usable_cores()
     sweep = {'%dthr' % t: rate(t, 2) for t in sorted({t for t in (8, 16, 32) if t <= logical} or {logical})}
     best_t = int(max(sweep, key=sweep.get)[:-3])
-    W = max(1, physical // best_t)
+    W = max(1, usable // best_t)
     n_ep = max(W, min(xs_all.shape[0], max(n_ep, 3 * W)))
     d = tempfile.mkdtemp(prefix='fsvit_cpu_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
     try:
@@ -297,9 +335,9 @@ def cpu_baseline(sd, xs_all, xq_all, gpu_logits, n_ep, model='visformer_micro_80
     return {'value': n_ep / dt5, 'unit': 'episodes/s', 'cores': W * best_t, 'kind': 'port',
             'sample': f'{n_ep} episodes 5-way {shot}-shot ({way * (shot + Q // way)} images each) = the first {n_ep} episodes of the GPU leg, fp32 torch CPU '
                       f'oracle, ep_per_batch=1, episode-parallel: {W} worker processes x {best_t} threads (host: {physical} physical / {logical} logical '
-                      f'cores), {dt5:.1f} s; then the same episodes as 1-shot, {dt1:.1f} s',
+                      f'cores, {usable} usable by this process), {dt5:.1f} s; then the same episodes as 1-shot, {dt1:.1f} s',
             'one_shot': {'value': n_ep / dt1, 'unit': 'episodes/s', 'images_per_episode': way * (1 + Q // way)},
-            'single_process_thread_sweep_episodes_per_s': sweep, 'workers': W, 'threads_per_worker': best_t,
+            'single_process_thread_sweep_episodes_per_s': sweep, 'workers': W, 'threads_per_worker': best_t, 'host_cores': core_info,
             'accuracy': acc_cpu, 'gpu_accuracy_same_episodes': acc_gpu,
             'gpu_max_abs_dlogit_same_episodes': (g - logits).abs().max().item(),
             'gpu_argmax_agreement_same_episodes': (g.argmax(-1) == logits.argmax(-1)).float().mean().item()}

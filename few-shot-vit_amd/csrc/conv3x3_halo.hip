@@ -462,7 +462,7 @@ bool conv3x3_halo_eligible(const ConvGemmParams& p, int dtype) {
   if (off || dtype != 1) return false;
   if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1 || p.groups != 1) return false;
   if (p.N != 128 || p.y_cstride != 128 || p.W != halo::TW || (p.H % halo::TR) || p.OH != p.H || p.OW != p.W) return false;
-  if (p.res || p.y_rpi || p.out_f32 || p.w_rstride || p.w_gstride) return false;
+  if (p.res || p.y2 || p.act == ACT_MUL || p.y_rpi || p.out_f32 || p.w_rstride || p.w_gstride) return false;
   if (p.Cin != p.x_cstride || p.K != 9 * p.Cin) return false;
   if (p.pool2) return p.Cin == 128 && p.x2 && p.K2 == 32 && p.x2_cstride >= 32 && p.pos && p.Kw == p.K + 64;
   return (p.Cin == 64 || p.Cin == 128) && !p.x2 && !p.pos && p.Kw == p.K;

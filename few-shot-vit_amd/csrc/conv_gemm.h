@@ -15,7 +15,8 @@
 namespace fsvit_types {
 
 
-enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_LRELU = 2 };
+// ACT_MUL (training, data gradients): y = (acc + bias) * res - `res` is a MULTIPLIER, not an addend (the saved GELU derivative of the layer in front)
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_LRELU = 2, ACT_MUL = 3 };
 
 struct ConvGemmParams {
   const void* x;       // activations NHWC [B, H, W, x_cstride]
@@ -56,6 +57,10 @@ struct ConvGemmParams {
   // the packed default g*N*Kw + n*Kw), and the output can be stored as fp32 whatever the storage dtype.
   long w_gstride, w_rstride;
   int out_f32;
+  // Training forward: with act == ACT_GELU and y2 != nullptr the epilogue also stores the GELU's DERIVATIVE at the pre-activation, y2[m][n]
+  // (same layout and dtype as y) - the backward multiplies by it inside the data-gradient GEMM's epilogue (ACT_MUL) instead of keeping the
+  // pre-activation map for a separate elementwise pass in each direction.
+  void* y2;
 };
 
 }  // namespace fsvit_types

@@ -17,6 +17,8 @@
 #include <stdlib.h>
 
 #include "conv_gemm.h"
+#include <type_traits>
+
 #include "fsvit_common.h"
 
 namespace FSVIT_NS {
@@ -300,7 +302,8 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
       for (int jn = 0; jn < TN; ++jn) bv[jn] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     constexpr int HB = TM > 2 ? 2 : TM;
-    auto batch = [&](int i0, auto actf) {
+    auto batch = [&](int i0, auto actf, auto mode) {
+      constexpr int MODE = decltype(mode)::value;          // 0: plain, 1: also store the GELU derivative (y2), 2: ACT_MUL (res multiplies)
       f32x4 rv[HB][TN];
       size_t rowoff[HB];
       bool mk_[HB];
@@ -324,7 +327,12 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
 #pragma unroll
           for (int jn = 0; jn < TN; ++jn) rv[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      if (p.res_first) {
+      if (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < HB; ++i)
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn) { acc[i0 + i][jn] = (acc[i0 + i][jn] + bv[jn]) * rv[i][jn] - bv[jn]; rv[i][jn] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      } else if (p.res_first) {
 #pragma unroll
         for (int i = 0; i < HB; ++i)
 #pragma unroll
@@ -345,8 +353,14 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
         for (int jn = 0; jn < TN; ++jn) {
           f32x4 v = acc[i0 + i][jn] + bv[jn];
           acc[i0 + i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+          f32x4 dv = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (MODE == 1) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = actf(v[e]);
+            for (int e = 0; e < 4; ++e) { float d; v[e] = sizeof(T) == 2 ? gelu_sig_d(v[e], d) : gelu_erf_d(v[e], d); dv[e] = d; }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = actf(v[e]);
+          }
           if (p.pool2) {                   // the window's 4 pixels sit in lanes lrow = 4j .. 4j+3 of the same lq
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -358,17 +372,23 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
           if (mk_[i] && nk_[jn] && (!p.pool2 || (lrow & 3) == 0)) {
             if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + rowoff[i] + ncl[jn]) = v;
             else store4<T>(Y + rowoff[i] + ncl[jn], v);
+            if constexpr (MODE == 1) store4<T>(reinterpret_cast<T*>(p.y2) + rowoff[i] + ncl[jn], dv);
           }
         }
       }
     };
-    auto finish = [&](auto actf) {
+    auto finish = [&](auto actf, auto mode) {
 #pragma unroll
-      for (int i0 = 0; i0 < TM; i0 += HB) batch(i0, actf);
+      for (int i0 = 0; i0 < TM; i0 += HB) batch(i0, actf, mode);
     };
-    if (p.act == ACT_GELU) finish([](float x) { return sizeof(T) == 2 ? gelu_sig(x) : (LIMBS ? gelu_erfc(x) : gelu_erf(x)); });
-    else if (p.act == ACT_LRELU) finish([](float x) { return x > 0.0f ? x : 0.1f * x; });
-    else finish([](float x) { return x; });
+    typedef std::integral_constant<int, 0> M0_t;
+    typedef std::integral_constant<int, 1> M1_t;
+    typedef std::integral_constant<int, 2> M2_t;
+    if (p.act == ACT_GELU && p.y2 && !LIMBS) finish([](float x) { return x; }, M1_t{});
+    else if (p.act == ACT_GELU) finish([](float x) { return sizeof(T) == 2 ? gelu_sig(x) : (LIMBS ? gelu_erfc(x) : gelu_erf(x)); }, M0_t{});
+    else if (p.act == ACT_LRELU) finish([](float x) { return x > 0.0f ? x : 0.1f * x; }, M0_t{});
+    else if (p.act == ACT_MUL) finish([](float x) { return x; }, M2_t{});
+    else finish([](float x) { return x; }, M0_t{});
   };
 
   // ---- one software pipeline over the flattened (item, k-slice) sequence.  The inner k-loop holds
@@ -469,6 +489,7 @@ int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream) {
       q.x = (const unsigned char*)p.x + (size_t)m0 * p.x_cstride * es;
       q.y = (unsigned char*)p.y + (size_t)m0 * p.y_cstride * es;
       q.res = p.res ? (const unsigned char*)p.res + (size_t)m0 * p.y_cstride * es : nullptr;
+      q.y2 = p.y2 ? (unsigned char*)p.y2 + (size_t)m0 * p.y_cstride * es : nullptr;
       const int rc = gemm256_eligible(q, dtype) ? run_gemm256(q, dtype, stream) : launch_conv_gemm_v2(q, dtype, stream);
       if (rc) return rc;
     }

@@ -531,7 +531,7 @@ ConvGemmParams conv_params(const Layer& L, const void* x, void* y, int B, int H,
   p.N = L.N; p.y_cstride = y_cstride; p.K = L.K; p.Kw = L.Kw; p.M = B * p.OH * p.OW;
   p.groups = L.groups; p.act = act; p.res_first = res_first; p.log2Cin = ilog2(Cin);
   p.x2 = nullptr; p.x2_cstride = 0; p.K2 = 0; p.pool2 = 0; p.y_rpi = 0; p.y_row0 = 0;
-  p.w_gstride = 0; p.w_rstride = 0; p.out_f32 = 0;
+  p.w_gstride = 0; p.w_rstride = 0; p.out_f32 = 0; p.y2 = nullptr;
   return p;
 }
 
@@ -911,7 +911,7 @@ extern "C" int fsvit_gconv3x3(const void* x, const void* w_packed, int Kw, void*
   if (!x || !w_packed || !y || B <= 0) return fail(FSVIT_ERR_ARG, "bad argument");
   if (dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "fsvit_gconv3x3: 16-bit storage only (bf16 / f16)");
   if (!K(gconv3x3_supported)(1, 256, 32, 8, 3, 3, 1, 1, W) || Kw < 288 || (Kw & 7)) return fail(FSVIT_ERR_ARG, "fsvit_gconv3x3: 8 groups of 32 -> 32 channels, W <= 20, Kw >= 288");
-  RC_TRY(K(launch_gconv3x3)(x, w_packed, Kw, y, B, H, W, (hipStream_t)stream));
+  RC_TRY(K(launch_gconv3x3)(x, w_packed, Kw, y, B, H, W, (hipStream_t)stream, nullptr, nullptr));
   return 0;
 }
 

@@ -95,6 +95,26 @@ __device__ __forceinline__ float gelu_sig(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// gelu_sig and its derivative d/dx [x s(x)], s = sigmoid(x * poly(x^2)):  s * (1 + x * (1 - s) * q(x^2)),  q(u) = c0 + 3 c1 u + 5 c2 u^2
+// (= d/dx [x poly(x^2)]; beyond the clamp of u the sigmoid has saturated and s (1 - s) vanishes).  Training forward epilogues store it next
+// to the activation (conv_gemm.h y2).
+__device__ __forceinline__ float gelu_sig_d(float x, float& d) {
+  const float u = fminf(x * x, 64.0f);
+  float p = fmaf(1.0153755e-3f, u, -1.0678257e-1f);
+  p = fmaf(p, u, -2.3011138f);
+  const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
+  float q = fmaf(5.0f * 1.0153755e-3f, u, 3.0f * -1.0678257e-1f);
+  q = fmaf(q, u, -2.3011138f) * -0.69314718055994530942f;      // the coefficients carry -log2(e)
+  d = s * fmaf(x * (1.0f - s), q, 1.0f);
+  return x * s;
+}
+// exact erf form and its derivative Phi(x) + x phi(x) (fp32 / parity mode)
+__device__ __forceinline__ float gelu_erf_d(float x, float& d) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  d = cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+  return x * cdf;
+}
+
 // Two GELUs at once on packed fp32 (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 process a register pair per issue; exp2, rcp and
 // min stay scalar): 14 VALU issues per pair instead of 18.  The GELU-heavy kernels (stage-1 block: 256 hidden channels x 2
 // GELUs per token, fused Mlp) spend more issue slots on GELU than on MFMA, so this is an end-to-end lever there.

@@ -24,6 +24,8 @@
 #include <stdlib.h>
 
 #include "conv_gemm.h"
+#include <type_traits>
+
 #include "fsvit_common.h"
 
 namespace FSVIT_NS {
@@ -252,7 +254,8 @@ __device__ __forceinline__ void gemm256_body(const ConvGemmParams& p, const int 
 #pragma unroll
         for (int q = 0; q < 2; ++q) bv[jp][q] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + ncl[jp] + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      auto finish = [&](auto actf) {
+      auto finish = [&](auto actf, auto mode) {
+        constexpr int MODE = decltype(mode)::value;        // 0: plain, 1: also store the GELU derivative (p.y2), 2: ACT_MUL (res multiplies) - conv_gemm.h
         if constexpr (LIMBS) {                     // fp32 rows: the lane's 8 consecutive channels = two 16-byte accesses
           float* const Yf = reinterpret_cast<float*>(p.y);
           const float* const Rf = reinterpret_cast<const float*>(p.res);
@@ -294,7 +297,7 @@ __device__ __forceinline__ void gemm256_body(const ConvGemmParams& p, const int 
 #pragma unroll
           for (int jp = 0; jp < TNH; ++jp) {
             const bf16x8 r8 = __builtin_bit_cast(bf16x8, rv[jp]);
-            bf16x8 o;
+            bf16x8 o, o2;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
               f32x4 v = acc[i][2 * jp + q] + bv[jp][q];
@@ -302,20 +305,32 @@ __device__ __forceinline__ void gemm256_body(const ConvGemmParams& p, const int 
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 const float r = (float)r8[4 * q + e];
-                float x = p.res_first ? v[e] + r : v[e];
-                x = actf(x);
-                if (!p.res_first) x += r;
-                o[4 * q + e] = (bf16)x;
+                if constexpr (MODE == 2) o[4 * q + e] = (bf16)(v[e] * r);
+                else if constexpr (MODE == 1) { float d; o[4 * q + e] = (bf16)gelu_sig_d(v[e], d); o2[4 * q + e] = (bf16)d; }
+                else {
+                  float x = p.res_first ? v[e] + r : v[e];
+                  x = actf(x);
+                  if (!p.res_first) x += r;
+                  o[4 * q + e] = (bf16)x;
+                }
               }
             }
-            if (mok && nok[jp]) *reinterpret_cast<bf16x8*>(Y + rowoff + ncl[jp]) = o;
+            if (mok && nok[jp]) {
+              *reinterpret_cast<bf16x8*>(Y + rowoff + ncl[jp]) = o;
+              if constexpr (MODE == 1) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.y2) + rowoff + ncl[jp]) = o2;
+            }
           }
         }
         }
       };
-      if (p.act == ACT_GELU) finish([](float x) { return LIMBS ? gelu_erfc(x) : gelu_sig(x); });
-      else if (p.act == ACT_LRELU) finish([](float x) { return x > 0.0f ? x : 0.1f * x; });
-      else finish([](float x) { return x; });
+      typedef std::integral_constant<int, 0> M0_t;
+      typedef std::integral_constant<int, 1> M1_t;
+      typedef std::integral_constant<int, 2> M2_t;
+      if (p.act == ACT_GELU && p.y2 && !LIMBS) finish([](float x) { return x; }, M1_t{});
+      else if (p.act == ACT_GELU) finish([](float x) { return LIMBS ? gelu_erfc(x) : gelu_sig(x); }, M0_t{});
+      else if (p.act == ACT_LRELU) finish([](float x) { return x > 0.0f ? x : 0.1f * x; }, M0_t{});
+      else if (p.act == ACT_MUL && !LIMBS) finish([](float x) { return x; }, M2_t{});
+      else finish([](float x) { return x; }, M0_t{});
     }
     if (!has_next) break;
     it = itn;
@@ -339,6 +354,7 @@ bool gemm256_eligible(const ConvGemmParams& p, int dtype) {
   if (p.N < 192 || p.M < 1024 || (p.N & 7) || (p.y_cstride & 7)) return false;   // 16-byte epilogue accesses
   if (p.K != p.Kw || (p.Kw % bke) || p.Kw < 2 * bke) return false;            // whole 128-byte K tiles on both operands
   if ((size_t)p.M * p.x_cstride * es >= (1ull << 32) || (size_t)p.N * p.Kw * es >= (1ull << 32)) return false;   // 32-bit DMA offsets
+  if (dtype == 2 && (p.y2 || p.act == ACT_MUL)) return false;
   if (dtype == 2) {
     // two-limb mode: conv_gemm_v2's 128 x 128 tile stages 32 flop per byte and runs at 100 .. 270 TFLOP/s; every dense 1x1 layer wide enough for
     // the 256-wide tile comes here
@@ -348,7 +364,7 @@ bool gemm256_eligible(const ConvGemmParams& p, int dtype) {
   // (few flops per streamed byte: the N = 256 / residual projections) stay on conv_gemm_v2 (2-3 workgroups per CU);
   // measured crossover ~200 flop/B (profiles/r01_gemm256_layers.txt); 190 keeps the stage-2 qkv layer with 48-wide heads (N = 864, 197.5 flop/B) here.
   const double min_ai = 190.0;
-  const double ai = (double)p.N * p.K / ((double)p.K + (double)p.N * (p.res ? 2.0 : 1.0));
+  const double ai = (double)p.N * p.K / ((double)p.K + (double)p.N * ((p.res && p.act != ACT_MUL) ? 2.0 : 1.0));
   return ai >= min_ai;
 }
 

@@ -166,7 +166,8 @@ int run_packs(TR* t) {
 }
 
 // ---------------------------------------------------------------- conv forward: z = conv(x) (+ bias)
-int conv_fwd(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, void* z, const float* bias) {
+// gp != nullptr: z = GELU(conv(x) + bias) and gp = the GELU's derivative at the pre-activation, both written by the GEMM's epilogue (conv_gemm.h y2)
+int conv_fwd(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, void* z, const float* bias, void* gp = nullptr) {
   const fsvit_param* w = getp(t, c.wname);
   if (!w) return FSVIT_ERR_KEY;
   const int bke = 128 / t->es, Ng = c.rows_fwd(), K = c.kpad_cols(), Kw = round_up(K, bke);
@@ -174,19 +175,21 @@ int conv_fwd(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, void*
   T_TRY(packed_weight(t, PackJob{w->data, nullptr, c.O, c.Ig, c.KH, c.KW, c.groups, 0, Ng, Kw, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols},
                       (size_t)c.groups * Ng * Kw * t->es, &pk));
   if (!bias && !c.via_patches && gconv3x3_supported(t->dtype, c.O, c.Ig, c.groups, c.KH, c.KW, c.stride, c.pad, W)) {
-    T_RUN(launch_gconv3x3(x, pk, Kw, z, B, H, W, t->st));          // wave = group, weights in registers (wgrad3x3.hip)
+    T_RUN(launch_gconv3x3(x, pk, Kw, z, B, H, W, t->st, gp));      // wave = group, weights in registers (wgrad3x3.hip)
     return 0;
   }
   ConvGemmParams p;
   if (c.via_patches) p = gemm_params(x, pk, z, B, H, W, 32, 32, 1, 1, 1, 0, Ng, Ng, 32, Kw, 1);
   else p = gemm_params(x, pk, z, B, H, W, K / (c.KH * c.KW), c.groups * (K / (c.KH * c.KW)), c.KH, c.KW, c.stride, c.pad, Ng, c.groups * Ng, K, Kw, c.groups);
   p.bias = bias;
+  if (gp) { p.act = ACT_GELU; p.y2 = gp; }
   T_RUN(launch_conv_gemm(p, t->dtype, t->st));
   return 0;
 }
 
 // ---------------------------------------------------------------- data gradient: dx = conv^T(dz)   (stride-1 convs and 1x1)
-int conv_bwd_data(TR* t, const ConvSpec& c, const void* dz, int B, int OH, int OW, void* dx) {
+// mul != nullptr: dx = conv^T(dz) * mul (the saved GELU derivative of the layer in front: its backward rides in this epilogue)
+int conv_bwd_data(TR* t, const ConvSpec& c, const void* dz, int B, int OH, int OW, void* dx, const void* mul = nullptr) {
   const fsvit_param* w = getp(t, c.wname);
   if (!w) return FSVIT_ERR_KEY;
   const int bke = 128 / t->es;
@@ -198,10 +201,11 @@ int conv_bwd_data(TR* t, const ConvSpec& c, const void* dz, int B, int OH, int O
   T_TRY(packed_weight(t, PackJob{w->data, nullptr, c.O, c.Ig, c.KH, c.KW, c.groups, 1, Ig_pad, Kw, c.hd_cols, c.hdp_cols, c.hd_rows, c.hdp_rows},
                       (size_t)c.groups * Ig_pad * Kw * t->es, &pk));
   if (gconv3x3_supported(t->dtype, c.O, c.Ig, c.groups, c.KH, c.KW, c.stride, c.pad, OW) && Ng_pad == 32 && Ig_pad == 32) {
-    T_RUN(launch_gconv3x3(dz, pk, Kw, dx, B, OH, OW, t->st));      // the same kernel on the transposed, tap-flipped pack
+    T_RUN(launch_gconv3x3(dz, pk, Kw, dx, B, OH, OW, t->st, nullptr, mul));      // the same kernel on the transposed, tap-flipped pack
     return 0;
   }
   ConvGemmParams p = gemm_params(dz, pk, dx, B, OH, OW, Ng_pad, c.groups * Ng_pad, c.KH, c.KW, 1, c.pad, Ig_pad, c.groups * Ig_pad, K, Kw, c.groups);
+  if (mul) { p.act = ACT_MUL; p.res = mul; }
   T_RUN(launch_conv_gemm(p, t->dtype, t->st));
   return 0;
 }
@@ -428,10 +432,9 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
     const size_t mark = t->tmp.off;
     void* z3 = take_tmp(t, M1 * t->C1); NEED(z3);
     T_TRY(bn_fwd(t, p + "norm2.bn", b.x, (int)M1, t->C1, ACT_NONE, nullptr, b.xn, &b.bn, &pend));
-    T_TRY(conv_fwd(t, sp.s1c1[i], b.xn, B, H1, H1, b.z1, nullptr));
-    T_RUN(launch_gelu_fwd(b.z1, b.h1, M1 * t->hid1, dt, st));
-    T_TRY(conv_fwd(t, sp.s1c2[i], b.h1, B, H1, H1, b.z2, nullptr));
-    T_RUN(launch_gelu_fwd(b.z2, b.h2, M1 * t->hid1, dt, st));
+    // (z1 / z2 hold the GELU DERIVATIVES at the pre-activations, written next to h1 / h2 by the conv epilogues)
+    T_TRY(conv_fwd(t, sp.s1c1[i], b.xn, B, H1, H1, b.h1, nullptr, b.z1));
+    T_TRY(conv_fwd(t, sp.s1c2[i], b.h1, B, H1, H1, b.h2, nullptr, b.z2));
     T_TRY(conv_fwd(t, sp.s1c3[i], b.h2, B, H1, H1, z3, nullptr));
     b.scale = dp_scale(t, dp_call, blk, nblk);
     if (t->dp_rate * blk > 0.f) ++dp_call;
@@ -486,8 +489,7 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
       if (t->dp_rate * blk > 0.f) ++dp_call;
       pend = PendingAdd{b.x, zp, b.s1, b.xa, M * C, (size_t)Ho * Ho * C};                       // b.xa = b.x + s1 * zp inside norm2's reduce pass
       T_TRY(bn_fwd(t, p + "norm2.bn", b.xa, (int)M, C, ACT_NONE, nullptr, b.xn2, &b.bn2, &pend));
-      T_TRY(conv_fwd(t, cs.fc1, b.xn2, B, Ho, Ho, b.z1, nullptr));
-      T_RUN(launch_gelu_fwd(b.z1, b.h, M * hid, dt, st));
+      T_TRY(conv_fwd(t, cs.fc1, b.xn2, B, Ho, Ho, b.h, nullptr, b.z1));                        // b.z1 = GELU'(fc1(xn2))
       T_TRY(conv_fwd(t, cs.fc2, b.h, B, Ho, Ho, zp, nullptr));
       b.s2 = dp_scale(t, dp_call, blk, nblk);
       if (t->dp_rate * blk > 0.f) ++dp_call;
@@ -548,8 +550,7 @@ int train_backward_impl(TR* t, const float* dfeat) {
       if (i == (int)blocks.size() - 1) T_RUN(launch_add_scaled(nullptr, dx, b.s2, dz2, M * C, (size_t)Ho * Ho * C, dt, st));
       T_TRY(conv_bwd_weight(t, cs.fc2, b.h, B, Ho, Ho, dz2));
       void* dh = take_tmp(t, M * hid); NEED(dh);
-      T_TRY(conv_bwd_data(t, cs.fc2, dz2, B, Ho, Ho, dh));
-      T_RUN(launch_gelu_bwd(dh, b.z1, dh, M * hid, dt, st));                                   // dh := dz1 (in place)
+      T_TRY(conv_bwd_data(t, cs.fc2, dz2, B, Ho, Ho, dh, b.z1));                               // dh := dz1 (x GELU' in the epilogue)
       T_TRY(conv_bwd_weight(t, cs.fc1, b.xn2, B, Ho, Ho, dh));
       void* dxn2 = take_tmp(t, M * C); NEED(dxn2);
       T_TRY(conv_bwd_data(t, cs.fc1, dh, B, Ho, Ho, dxn2));
@@ -612,12 +613,10 @@ int train_backward_impl(TR* t, const float* dfeat) {
     if (i == (int)t->s1.size() - 1) T_RUN(launch_add_scaled(nullptr, dx, b.scale, dz3, M1 * t->C1, (size_t)H1 * H1 * t->C1, dt, st));
     T_TRY(conv_bwd_weight(t, sp.s1c3[i], b.h2, B, H1, H1, dz3));
     void* dh2 = take_tmp(t, M1 * t->hid1); NEED(dh2);
-    T_TRY(conv_bwd_data(t, sp.s1c3[i], dz3, B, H1, H1, dh2));
-    T_RUN(launch_gelu_bwd(dh2, b.z2, dh2, M1 * t->hid1, dt, st));
+    T_TRY(conv_bwd_data(t, sp.s1c3[i], dz3, B, H1, H1, dh2, b.z2));                           // x GELU'(z2) in the epilogue
     T_TRY(conv_bwd_weight(t, sp.s1c2[i], b.h1, B, H1, H1, dh2));
     void* dh1 = take_tmp(t, M1 * t->hid1); NEED(dh1);
-    T_TRY(conv_bwd_data(t, sp.s1c2[i], dh2, B, H1, H1, dh1));
-    T_RUN(launch_gelu_bwd(dh1, b.z1, dh1, M1 * t->hid1, dt, st));
+    T_TRY(conv_bwd_data(t, sp.s1c2[i], dh2, B, H1, H1, dh1, b.z1));                           // x GELU'(z1) in the epilogue
     T_TRY(conv_bwd_weight(t, sp.s1c1[i], b.xn, B, H1, H1, dh1));
     T_TRY(conv_bwd_data(t, sp.s1c1[i], dh1, B, H1, H1, dz3));                                  // dz3 := d(xn)
     // dx += norm2 backward (read from dz3); the next block's dz3 = scale' * dx goes to the same buffer (in place over the BatchNorm's dy)
@@ -795,8 +794,7 @@ int vit_forward_impl(VT* t, const float* x, float* feat) {
     if (t->dp_rate * i > 0.f) ++dp_call;
     T_RUN(launch_add_scaled(b.x, zp, b.s1, b.x1, M * D, (size_t)S * D, dt, st));
     T_TRY(vit_ln_fwd(t, p + "norm2", b.x1, b.xn2, &b.m2, &b.r2, (int)M));
-    T_TRY(conv_fwd(t, sp.fc1[i], b.xn2, B, S, 1, b.z1, b1->data));
-    T_RUN(launch_gelu_fwd(b.z1, b.h, M * hid, dt, st));
+    T_TRY(conv_fwd(t, sp.fc1[i], b.xn2, B, S, 1, b.h, b1->data, b.z1));                       // b.z1 = GELU'(fc1(xn2) + b1)
     T_TRY(conv_fwd(t, sp.fc2[i], b.h, B, S, 1, zp, b2->data));
     b.s2 = vit_dp_scale(t, dp_call, i);
     if (t->dp_rate * i > 0.f) ++dp_call;
@@ -841,8 +839,7 @@ int vit_backward_impl(VT* t, const float* dfeat) {
     T_TRY(conv_bwd_weight(t, sp.fc2[i], b.h, B, S, 1, dz2));
     T_TRY(bias_grad(t, b2, dz2, (int)M, D, 1, 1));
     void* dh = take_tmp(t, M * hid); NEED(dh);
-    T_TRY(conv_bwd_data(t, sp.fc2[i], dz2, B, S, 1, dh));
-    T_RUN(launch_gelu_bwd(dh, b.z1, dh, M * hid, dt, st));
+    T_TRY(conv_bwd_data(t, sp.fc2[i], dz2, B, S, 1, dh, b.z1));
     T_TRY(conv_bwd_weight(t, sp.fc1[i], b.xn2, B, S, 1, dh));
     T_TRY(bias_grad(t, b1, dh, (int)M, hid, 1, 1));
     void* dxn = take_tmp(t, M * D); NEED(dxn);

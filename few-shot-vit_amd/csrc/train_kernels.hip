@@ -1054,8 +1054,8 @@ int launch_wgrad_finalize_multi(const FinJob* jobs, int n, hipStream_t s) {
                    : j.kind == 2 ? (size_t)j.g * j.Ng * j.Ig * j.KH * j.KW : (size_t)j.Kc_pad * 9 * 32 * 32 / 4;
       if (tot > biggest) biggest = tot;
     }
-    unsigned gx = (unsigned)((biggest + 255) / 256);
-    if (gx > 64) gx = 64;
+    unsigned gx = (unsigned)((biggest + 255) / 256);          // blocks per job: the largest layer gets one pass, smaller jobs' surplus blocks exit at once
+    if (gx > 1024) gx = 1024;
     if (gx < 1) gx = 1;
     hipLaunchKernelGGL(wgrad_finalize_multi_kernel, dim3(gx, (unsigned)m), dim3(256), 0, s, fj);
     const int rc = (int)hipGetLastError();

@@ -248,8 +248,10 @@ int launch_wgrad3x3(const void* x, int xld, const void* dz, int zld, float* dw, 
 // whole launch, the activations go through the same staged pixel window as in wgrad3x3 (planes of 8 channels, a tap = an address, invalid taps
 // read a zero slot): per 16 pixels 9 fragment reads feed 18 MFMAs.
 //   y[m][32 g + n] = sum_{tap, c} x[pix(m) + tap][32 g + c] * w[32 g + n][tap * 32 + c]        w = the trainer's packed layer ([256][Kw], K order (ky, kx, c))
+// Training epilogues (conv_gemm.h): y2 != nullptr - y = GELU(conv), y2 = the GELU's derivative at the pre-activation (forward); mul != nullptr -
+// y = conv * mul (data gradient times the saved derivative of the layer in front)
 __global__ __launch_bounds__(512) void gconv3x3_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, int Kw, bf16* __restrict__ y, int M, int H, int W,
-                                                       int n_chunks, int chunks_per_wg) {
+                                                       int n_chunks, int chunks_per_wg, bf16* __restrict__ y2, const bf16* __restrict__ mul) {
   using namespace wg3;
   constexpr int C = 256, MAXW = 20, WINP = CH + 2 * (MAXW + 1) + 3;      // 109 pixels (odd: the staging stores walk the planes)
   constexpr int NPX = (WINP * (C / 8) + 511) / 512;
@@ -311,8 +313,21 @@ __global__ __launch_bounds__(512) void gconv3x3_kernel(const bf16* __restrict__ 
         acc[1] = mma_chunk<bf16>(wf[tp][1], xf, acc[1]);
       }
       if (m < M) {                                                    // lane holds channels 32 g + 16 nt + 4 lq .. + 3 of pixel m
-        store4<bf16>(y + (size_t)m * C + g * 32 + lq * 4, acc[0]);
-        store4<bf16>(y + (size_t)m * C + g * 32 + 16 + lq * 4, acc[1]);
+        const size_t o0 = (size_t)m * C + g * 32 + lq * 4;
+        if (y2) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            f32x4 dv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float d; acc[nt][e] = gelu_sig_d(acc[nt][e], d); dv[e] = d; }
+            store4<bf16>(y2 + o0 + 16 * nt, dv);
+          }
+        } else if (mul) {
+          acc[0] = acc[0] * load4<bf16>(mul + o0);
+          acc[1] = acc[1] * load4<bf16>(mul + o0 + 16);
+        }
+        store4<bf16>(y + o0, acc[0]);
+        store4<bf16>(y + o0 + 16, acc[1]);
       }
     }
   }
@@ -322,12 +337,13 @@ bool gconv3x3_supported(int dtype, int O, int Ig, int groups, int KH, int KW, in
   static const bool off = [] { const char* e = getenv("FSVIT_GCONV3X3"); return e && e[0] == '0'; }();
   return !off && dtype == 1 && O == 256 && Ig == 32 && groups == 8 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && W <= 20;
 }
-int launch_gconv3x3(const void* x, const void* w_packed, int Kw, void* y, int B, int H, int W, hipStream_t s) {
+int launch_gconv3x3(const void* x, const void* w_packed, int Kw, void* y, int B, int H, int W, hipStream_t s, void* y2, const void* mul) {
   const int M = B * H * W, n_chunks = (M + wg3::CH - 1) / wg3::CH;
   int wgs = n_chunks < 512 ? n_chunks : 512;
   const int cpw = (n_chunks + wgs - 1) / wgs;
   wgs = (n_chunks + cpw - 1) / cpw;
-  hipLaunchKernelGGL(gconv3x3_kernel, dim3(wgs), dim3(512), 0, s, (const bf16*)x, (const bf16*)w_packed, Kw, (bf16*)y, M, H, W, n_chunks, cpw);
+  hipLaunchKernelGGL(gconv3x3_kernel, dim3(wgs), dim3(512), 0, s, (const bf16*)x, (const bf16*)w_packed, Kw, (bf16*)y, M, H, W, n_chunks, cpw,
+                     (bf16*)y2, (const bf16*)mul);
   return (int)hipGetLastError();
 }
 

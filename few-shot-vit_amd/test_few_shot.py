@@ -81,14 +81,19 @@ def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch
         def flush():
             if not pending:
                 return
+            G = len(pending)
             if hasattr(dataset, 'gather'):                  # device-resident dataset: gather + transform on the GPU
-                data = dataset.gather(torch.cat(list(pending)))
-                data = data.view(len(pending), -1, *data.shape[1:])
+                # the index list is permuted on the host so that the transform writes all shot images, then all query images: x_shot / x_query
+                # are views of its output (fs.split_shot_query on the class-major batch would copy 1 GB per 128-episode launch)
+                idx = torch.stack(list(pending)).view(G * ep_per_batch, n_way, shot + n_query)
+                n_s = G * ep_per_batch * n_way * shot
+                data = dataset.gather(torch.cat([idx[:, :, :shot].reshape(-1), idx[:, :, shot:].reshape(-1)]))
+                x_shot = data[:n_s].view(G * ep_per_batch, n_way, shot, *data.shape[1:])
+                x_query = data[n_s:].view(G * ep_per_batch, n_way * n_query, *data.shape[1:])
             else:
                 data = torch.stack([torch.stack([dataset[int(i)][0] for i in idx]) for idx in pending])   # [G, E*way*(S+Q), 3,H,W]
-            G = data.shape[0]
-            data = data.view(G * ep_per_batch * n_way * (shot + n_query), *data.shape[2:]).to(device, non_blocking=True)
-            x_shot, x_query = fs.split_shot_query(data, n_way, shot, n_query, ep_per_batch=G * ep_per_batch)
+                data = data.view(G * ep_per_batch * n_way * (shot + n_query), *data.shape[2:]).to(device, non_blocking=True)
+                x_shot, x_query = fs.split_shot_query(data, n_way, shot, n_query, ep_per_batch=G * ep_per_batch)
             logits, acc, loss = engine.meta_baseline_forward(x_shot, x_query, temp, model.method, want_stats=True)
             if collect_pred:                                         # per-query arg-max of every episode (agreement tests between numerics modes)
                 preds.append(logits.argmax(-1).to(torch.uint8).cpu())
@@ -96,11 +101,16 @@ def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch
             losses.append(loss.view(G, ep_per_batch).mean(dim=1))
             pending.clear()
 
+        # the first launches are small so that the GPU starts while the host is still drawing the stream (a full first launch leaves it idle
+        # for launch_batches x ~100 us of sampling); from then on the sampler runs under the previous launch
+        ramp = [n for n in (8, 16, 32, 64) if n < launch_batches]
         for idx in sampler:
             pending.append(idx)
             last_label = dataset.label[int(idx[-1])]
-            if len(pending) == launch_batches:
+            if len(pending) == (ramp[0] if ramp else launch_batches):
                 flush()
+                if ramp:
+                    ramp.pop(0)
         flush()
         mine = torch.stack([torch.cat(accs), torch.cat(losses)], dim=1).double() if accs else torch.zeros(0, 2, dtype=torch.float64, device=device)
         allv = parallel.gather_in_stream_order(mine, n_batch, rank, world).cpu().numpy()     # the one exchange
