@@ -40,8 +40,16 @@ def _make(encoder_kwargs, sd, numerics, drop_path_rate):
     return m.cuda().train()
 
 
-def _grad_check(named_grads, ref, rel_tol, what, noise_tol=1e-5):
+def _layer_group(k):
+    for tag in ('stem', 'stage1', 'patch_embed2', 'stage2', 'patch_embed3', 'stage3', 'pos_embed', 'norm'):
+        if ('encoder.' + tag) in k or k.startswith(tag):
+            return tag
+    return 'other'
+
+
+def _grad_check(named_grads, ref, rel_tol, what, noise_tol=1e-5, group_tol=None):
     worst = 0.0
+    groups = {}
     for k, g in named_grads.items():
         r = ref[k]
         scale = float(r.norm())
@@ -54,7 +62,11 @@ def _grad_check(named_grads, ref, rel_tol, what, noise_tol=1e-5):
             assert float(g.abs().max()) <= noise_tol, f'{what}: grad of {k} should vanish, max {float(g.abs().max()):.3e}'
         else:
             worst = max(worst, rel)
-            assert rel <= rel_tol, f'{what}: grad of {k}: rel err {rel:.3e} (norm {scale:.3e})'
+            grp = _layer_group(k)
+            groups[grp] = max(groups.get(grp, 0.0), rel)
+            tol = rel_tol if group_tol is None else group_tol.get(grp, rel_tol)
+            assert rel <= tol, f'{what}: grad of {k}: rel err {rel:.3e} (norm {scale:.3e}, gate {tol:.3e})'
+    print(f'{what}: worst gradient rel err per layer group: ' + ', '.join(f'{g} {v:.2e}' for g, v in groups.items()))
     return worst
 
 
@@ -154,7 +166,11 @@ def test_micro_train_step_vs_oracle_autograd(numerics, drop, freeze):
     assert set(grads) == set(ref_grads)
     # parity: max-pool argmax / LeakyReLU sign decisions flip at rounding-level ties (6M stem activations), so the stem's
     # gradients carry a few discrete differences: 5e-3 of the norm; every other layer is at the 1e-5 level (printed)
-    worst = _grad_check(grads, ref_grads, 5e-3 if par else 0.15, numerics, 1e-5 if par else 2e-3)
+    # bf16 gates per layer group = 1.5 x the measured worst (round 3: stem 1.4e-1 - 30 images through batch-statistics BatchNorm, max-pool /
+    # LeakyReLU decisions on bf16 activations - every other group 2.3e-2 ... 5.0e-2, the temperature 7.8e-3)
+    bf16_gates = {'stem': 0.22, 'stage1': 0.075, 'patch_embed2': 0.07, 'stage2': 0.07, 'patch_embed3': 0.065, 'stage3': 0.07, 'pos_embed': 0.065,
+                  'norm': 0.065, 'other': 0.012}
+    worst = _grad_check(grads, ref_grads, 5e-3 if par else 0.22, numerics, 1e-5 if par else 2e-3, None if par else bf16_gates)
     print(f'[{numerics} drop={drop} freeze_bn={freeze}] micro train step: max|dlogit| = {dl:.3e}, |dloss| = {abs(float(loss) - float(ref_loss)):.3e}, '
           f'worst grad rel err = {worst:.3e}')
     assert dl <= (1e-3 if par else 0.3)
@@ -598,3 +614,66 @@ def test_frozen_teacher_keeps_its_engine_while_a_student_trains():
     s_eng = student.encoder.engine()
     loss = F.cross_entropy(student(xs, xq).view(-1, 5), label)           # running statistics written through raw pointers
     assert student.encoder.engine() is not s_eng
+
+
+def _tune_and_eval(numerics, steps, lr, eval_numerics='parity'):
+    """Meta-tune `steps` SUN-M steps (8 episodes x 10-way x (5 + 5), drop_path 0.5, train_meta.py:161-177) on a seeded synthetic stream, then
+    evaluate on 500 held-out 5-way 5-shot episodes.  Seeds fix the episode stream, the DropPath draws and the data, so two numerics modes see
+    the same training run up to their own rounding."""
+    from fewshot_vit_amd import datasets, models, synthetic, utils
+    from fewshot_vit_amd.datasets.samplers import CategoriesSampler
+    from fewshot_vit_amd.utils import few_shot as fs
+    m = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={'numerics': numerics, 'drop_path_rate': 0.5})
+    m.load_state_dict(synthetic.synthetic_checkpoint_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}), strict=True)
+    m = m.cuda()
+    train = datasets.make('synthetic-episodes', split='train', n_classes=40, n_per_class=20, noise=1.0, seed=1)
+    test = datasets.make('synthetic-episodes', split='test', n_classes=20, n_per_class=40, noise=1.0, seed=0)
+    opt, _ = utils.make_optimizer(m.parameters(), 'sgd', lr=lr, weight_decay=5e-4)
+    E, way, shot, query = 8, 10, 5, 5
+    label = fs.make_nk_label(way, query, E).cuda()
+    torch.manual_seed(4321)
+    torch.cuda.manual_seed_all(4321)
+    np.random.seed(4321)
+    m.train()
+    losses = []
+    for idx in CategoriesSampler(train.label, steps, way, shot + query, ep_per_batch=E):
+        xs, xq = fs.split_shot_query(train.gather(idx), way, shot, query, ep_per_batch=E)
+        loss = F.cross_entropy(m(xs, xq).view(-1, way), label)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+    losses = torch.stack(losses).cpu()
+    assert torch.isfinite(losses).all()
+    m.eval()
+    m.encoder.numerics = eval_numerics               # both tuned models are scored by the same (exact-fp32) evaluator
+    m.encoder._engine = None
+    np.random.seed(99)
+    accs = []
+    lab = fs.make_nk_label(5, 15, 1).cuda()
+    with torch.no_grad():
+        batch = []
+        for idx in CategoriesSampler(test.label, 500, 5, 5 + 15, ep_per_batch=1):
+            batch.append(idx)
+            if len(batch) == 50:
+                xs, xq = fs.split_shot_query(test.gather(torch.cat(batch)), 5, 5, 15, ep_per_batch=50)
+                lg = m(xs, xq)
+                accs.append((lg.argmax(-1) == lab.view(1, -1)).float().mean(dim=1))
+                batch = []
+    accs = torch.cat(accs).double().cpu()
+    ci = 1.96 * float(accs.std(unbiased=True)) / len(accs) ** 0.5
+    return float(accs.mean()), ci, float(losses[:10].mean()), float(losses[-10:].mean())
+
+
+def test_bf16_meta_tuning_reaches_the_parity_tuned_accuracy():
+    """the bf16 trainer must earn its place - 100 SUN-M steps at the configs[2] geometry (800 images per step) on the same seeded
+    stream in `bf16` and in `parity` (exact fp32), both scored on the same 500 held-out episodes by the exact-fp32 evaluator: the accuracies
+    must agree within the evaluation's own 95 % CI, and tuning must have moved the model (the loss falls) so the comparison is not vacuous."""
+    steps, lr = 100, 0.01
+    acc_b, ci_b, l0_b, l1_b = _tune_and_eval('bf16', steps, lr)
+    acc_p, ci_p, l0_p, l1_p = _tune_and_eval('parity', steps, lr)
+    print(f'meta-tuned {steps} steps (lr {lr}): bf16 acc {100 * acc_b:.2f} +- {100 * ci_b:.2f} %, loss {l0_b:.4f} -> {l1_b:.4f}; '
+          f'parity acc {100 * acc_p:.2f} +- {100 * ci_p:.2f} %, loss {l0_p:.4f} -> {l1_p:.4f}; |delta acc| = {100 * abs(acc_b - acc_p):.2f} %')
+    assert l1_b < l0_b and l1_p < l0_p
+    assert abs(l1_b - l1_p) <= 0.05 * max(l1_p, 1e-3) + 0.02
+    assert abs(acc_b - acc_p) <= max(ci_b, ci_p)

@@ -46,5 +46,21 @@ for _ in range(N):
     call()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / N
+if len(sys.argv) > 2 and RING:           # variant: results must equal the shipped library's (same arithmetic, different schedule)
+    base = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), 'libfsvit.so'))
+    base.fsvit_stage1_block_hw.restype = C.c_int
+    base.fsvit_stage1_block_hw.argtypes = lib.fsvit_stage1_block_hw.argtypes
+    y0 = torch.empty_like(x)
+    assert base.fsvit_stage1_block_hw(_ptr(x), _ptr(y0), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(w3), B, 20, 20, _lib.BF16, st) == 0
+    torch.cuda.synchronize()
+    d = (y.float() - y0.float()).abs().max().item()
+    print(f'variant vs shipped library: max |dy| = {d:.3e} ({"bit-identical" if torch.equal(y, y0) else "DIFFERENT"})')
+    for hw, bb in ((16, 7), (10, 33), (4, 5)):
+        xs = torch.randn(bb, hw, hw, 128, generator=g).to('cuda', bf)
+        ya, yb = torch.empty_like(xs), torch.empty_like(xs)
+        assert lib.fsvit_stage1_block_hw(_ptr(xs), _ptr(ya), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(w3), bb, hw, hw, _lib.BF16, st) == 0
+        assert base.fsvit_stage1_block_hw(_ptr(xs), _ptr(yb), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(w3), bb, hw, hw, _lib.BF16, st) == 0
+        torch.cuda.synchronize()
+        print(f'  {bb} x {hw} x {hw}: {"bit-identical" if torch.equal(ya, yb) else "DIFFERENT max %.3e" % (ya.float() - yb.float()).abs().max().item()}')
 fl = 2.0 * B * 400 * (256 * 128 + 256 * 9 * 32 + 128 * 256)
 print(f'stage1 block ({"ring" if RING else "half-image"} kernel), {B} images: {dt * 1e3:.3f} ms per call, {fl / dt / 1e12:.1f} TFLOP/s')
