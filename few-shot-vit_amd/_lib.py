@@ -85,6 +85,7 @@ SIGNATURES = {
     'fsvit_mlp_rows': (_i, [_vp, _vp, _vp, _i, _fp, _vp, _i, _fp, _i, _i, _i, _vp]),
     'fsvit_attention': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     'fsvit_qkv_attention': (_i, [_vp, _vp, _i, _fp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    'fsvit_vit_ln_qkv_attention': (_i, [_vp, _vp, _i, _fp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp]),
     'fsvit_im2col27': (_i, [_fp, _vp, _i, _i, _i, _i, _vp]),
     'fsvit_stem_conv1': (_i, [_fp, _vp, _i, _fp, _vp, _vp, _i, _i, _i, _vp]),
     'fsvit_maxpool2_pos': (_i, [_vp, _fp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -545,7 +545,7 @@ int tap(EngineBase* h, const std::string& name, const void* src, size_t bytes, b
 }
 
 // kernel ids reported by the profiler (names in fsvit_kernel_name)
-enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_QKVATTN = 15, KID_STEMCONV1 = 16, KID_GCONV_X2 = 14, KID_STAGE1RING = 17, KID_LNGEMM = 18, KID_QKVATTNROWS = 19 };
+enum { KID_GEMM256 = 0, KID_GEMM64 = 1, KID_GEMM32 = 2, KID_IM2COL = 3, KID_MAXPOOL = 4, KID_ATTN = 5, KID_POOL = 6, KID_HEAD = 7, KID_STAGE1 = 8, KID_GEMM128 = 9, KID_HALO = 12, KID_MLPROWS = 13, KID_QKVATTN = 15, KID_STEMCONV1 = 16, KID_GCONV_X2 = 14, KID_STAGE1RING = 17, KID_LNGEMM = 18, KID_QKVATTNROWS = 19, KID_VITATTNROWS = 20 };
 
 
 // Runs one launch; in profiling mode brackets it with HIP events on the same stream.
@@ -1093,6 +1093,23 @@ extern "C" int fsvit_qkv_attention(const void* x, const void* wqkv, int kw, cons
   return 0;
 }
 
+extern "C" int fsvit_vit_ln_qkv_attention(const void* x, const void* wqkv, int kw, const float* bias, void* ctx, int B, int S, int C, int heads, int hdp,
+                                          float eps, float scale, void* stream) {
+  const int kdt = FSVIT_BF16;
+  if (!x || !wqkv || !ctx) return fail(FSVIT_ERR_ARG, "null argument");
+  if (!K(vit_attn_rows_supported)(1, C, heads, hdp, S) || kw < C)
+    return fail(FSVIT_ERR_ARG, "fsvit_vit_ln_qkv_attention: built for C = 384, head dim 64, S <= 256 (bf16)");
+  hipStream_t st = (hipStream_t)stream;
+  void* img = nullptr;
+  HIP_TRY(hipMalloc(&img, K(ln_gemm_rows_image_bytes)(C, 3 * heads * hdp)));
+  int rc = K(launch_qkv_attn_rows_pack)(wqkv, kw, img, C, heads, hdp, st);
+  if (rc == 0) rc = K(launch_vit_attn_rows)(x, ctx, img, bias, B, S, C, heads, hdp, eps, scale, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(img);
+  if (rc != 0) return hipfail((hipError_t)rc, "fsvit_vit_ln_qkv_attention");
+  return 0;
+}
+
 extern "C" int fsvit_attention(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, void* stream) {
   const int kdt = dtype;
   if (!known_dtype(dtype)) return fail(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
@@ -1139,15 +1156,15 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
   static const char* f32n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
                                "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<float,128,128,2,2,2>",
-                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel", "qkv_attn_rows_kernel"};
+                               "patchify_kernel<float>", "layernorm_kernel<float>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel", "qkv_attn_rows_kernel", "vit_attn_rows_kernel"};
   static const char* bf16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<__bf16,128,64,2,2,3>", "conv_gemm_v2_kernel<__bf16,128,32,4,1,3>",
                                 "im2col27_kernel<__bf16>", "maxpool2_pos_kernel<__bf16>", "attention_v2_kernel<__bf16,...>", "pool_affine_kernel<__bf16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<__bf16,128,128,2,2,2>",
-                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel", "qkv_attn_rows_kernel"};
+                                "patchify_kernel<__bf16>", "layernorm_kernel<__bf16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel", "qkv_attn_rows_kernel", "vit_attn_rows_kernel"};
   static const char* f16n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<_Float16,128,64,2,2,3>", "conv_gemm_v2_kernel<_Float16,128,32,4,1,3>",
                                "im2col27_kernel<_Float16>", "maxpool2_pos_kernel<_Float16>", "attention_v2_kernel<_Float16,...>", "pool_affine_kernel<_Float16>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<_Float16,128,128,2,2,2>",
-                               "patchify_kernel<_Float16>", "layernorm_kernel<_Float16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel", "qkv_attn_rows_kernel"};
+                               "patchify_kernel<_Float16>", "layernorm_kernel<_Float16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel", "qkv_attn_rows_kernel", "vit_attn_rows_kernel"};
   static const char* x2n[] = {"gemm256_x2_kernel", "conv_gemm_v2_kernel<f32x2l,128,64,2,2,3>", "conv_gemm_v2_kernel<f32x2l,128,32,4,1,3>", "", "", "", "", "", "", "conv_gemm_v2_kernel<f32x2l,128,128,2,2,2>"};
-  if (kernel_id < 0 || kernel_id > 19) return "?";
+  if (kernel_id < 0 || kernel_id > 20) return "?";
   if (is_x2(dtype)) return kernel_id == 14 ? "gconv3x3_x2_kernel" : (kernel_id == 0 || kernel_id == 1 || kernel_id == 2 || kernel_id == 9) ? x2n[kernel_id] : f32n[kernel_id];
   return dtype == FSVIT_F32 ? f32n[kernel_id] : dtype == FSVIT_F16 ? f16n[kernel_id] : bf16n[kernel_id];
 }
@@ -1207,6 +1224,7 @@ struct VitBlock {
   void* mlp_img = nullptr;      // mlp_rows.hip: fragment-major image of proj | fc1 | fc2 (null: GEMM + LayerNorm launches)
   float* mlp_b1 = nullptr;
   void* qkv_img = nullptr;      // mlp_rows.hip ln_gemm_rows: fragment-major image of the qkv Linear (null: LayerNorm launch + GEMM)
+  void* attn_img = nullptr;     // mlp_rows.hip vit_attn_rows: head-major image of the qkv Linear (norm1 + qkv + attention in one launch)
 };
 
 struct fsvit_vit : EngineBase {
@@ -1314,6 +1332,15 @@ int build_vit(fsvit_vit* h, const SD& sd) {
       HIP_TRY(hipDeviceSynchronize());
       b.qkv_img = img;
     }
+    if (K(vit_attn_rows_supported)(kd(kdt), D, heads, hdp, h->S)) {       // norm1 + qkv + attention core in one launch: the qkv tensor never reaches HBM
+      VitBlock& b = h->blocks[i];
+      void* img = nullptr;
+      HIP_TRY(hipMalloc(&img, K(ln_gemm_rows_image_bytes)(D, 3 * heads * hdp)));
+      h->allocs.push_back(img);
+      RC_TRY(K(launch_qkv_attn_rows_pack)(b.qkv.w, b.qkv.Kw, img, D, heads, hdp, nullptr));
+      HIP_TRY(hipDeviceSynchronize());
+      b.attn_img = img;
+    }
   }
   return 0;
 }
@@ -1355,6 +1382,11 @@ int vit_forward_chunk(fsvit_vit* h, const float* x, int Bc, float* feat, unsigne
   const float scale = 1.0f / std::sqrt((float)h->hd);
   for (size_t i = 0; i < h->blocks.size(); ++i) {
     const VitBlock& b = h->blocks[i];
+    if (b.attn_img) {
+      RC_TRY(timed(h, st, "blocks.norm1+qkv+attn", KID_VITATTNROWS, 2.0 * M * 3.0 * D * D + 4.0 * Bc * heads * (double)S * S * h->hd, [&]() {
+        return K(launch_vit_attn_rows)(tokens, ctx, b.attn_img, b.qkv.bias, Bc, S, D, heads, hdp, h->cfg.ln_eps, scale, st);
+      }));
+    } else {
     if (b.qkv_img) {
       RC_TRY(timed(h, st, "blocks.norm1+qkv", KID_LNGEMM, 2.0 * M * 3.0 * D * D, [&]() {
         return K(launch_ln_gemm_rows)(tokens, qkv, b.qkv_img, b.qkv.bias, M, D, 3 * heads * hdp, h->cfg.ln_eps, st);
@@ -1365,6 +1397,7 @@ int vit_forward_chunk(fsvit_vit* h, const float* x, int Bc, float* feat, unsigne
     }
     RC_TRY(timed(h, st, "blocks.attn.core", KID_ATTN, 4.0 * Bc * heads * (double)S * S * h->hd,
                  [&]() { return K(launch_attention)(qkv, ctx, Bc, S, heads, hdp, scale, dt, st); }));
+    }
     if (b.mlp_img) {
       RC_TRY(timed(h, st, "blocks.proj+norm2+mlp", KID_MLPROWS, 2.0 * M * ((double)heads * h->hd * D + 2.0 * D * h->hid), [&]() {
         return K(launch_mlp_rows_ln)(tokens, tokens, b.mlp_img, b.mlp_b1, b.proj.bias, b.fc2.bias, ctx, heads * hdp, M, D, h->hid, h->cfg.ln_eps, st);

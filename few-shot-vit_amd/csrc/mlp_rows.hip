@@ -1100,6 +1100,251 @@ __global__ __launch_bounds__(256, 2) void qkv_attn_rows_kernel(const bf16* __res
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// norm1 + qkv Linear + attention core of a ViT / DeiT block in ONE launch (deit.py:40-58,:69; DeiT-S: C = 384, 6 heads x 64, S = 197 tokens):
+// the qkv tensor - 5.8 GB per block written by ln_gemm_rows and read back by attention_v2 at 12 800 images - never exists.
+// qkv_attn_rows_kernel above keeps an image in ONE wave (<= 32 tokens).  Here an image is NB = ceil(S / 32) <= 8 row blocks and a workgroup of
+// 8 waves owns it: wave w = row block w (its 32 token rows normalised in registers, as in ln_gemm_rows).  Per head the weight stream delivers
+// K0 K1 | Q0 Q1 | V0 V1 (the image of launch_qkv_attn_rows_pack); every wave computes ITS rows' K / Q / V chunks exactly as above, but
+//   * the packed K fragments (A operands of S^T = K Q^T, row = key) and the packed V^T fragments (A operands of O^T = V^T P^T, computed with
+//     swapped operands) are written to LDS - 2 x 2 KB per row block and chunk, lane-linear: the reader's register image IS the writer's - and
+//     every wave reads all NB blocks back: 64 KB of LDS for both;
+//   * the attention runs flash-style over the key blocks: S^T_kb (4 MFMAs) -> masked online softmax in the lane pair of a query (running max
+//     and sum, O rescaled by exp2 of the max's change) -> O^T += V^T_kb P_kb (4 MFMAs); registers hold one key block's scores at a time.
+// Synchronisation rides on the weight ring: every chunk passes the ring barrier, so K (written before the Q chunks) is visible when the first
+// score is formed, V needs one barrier of its own, and the next head's first ring barrier guarantees that all waves have left this head's K / V.
+// Rows beyond S (27 of 224 at S = 197) and the waves beyond NB compute on clamped rows and store nothing (12 % of the MFMAs).
+template <int C, int HDC>
+__global__ __launch_bounds__(512, 1) void vit_attn_rows_kernel(const bf16* __restrict__ X, bf16* __restrict__ CTX, const unsigned char* __restrict__ wimg,
+                                                               const float* __restrict__ bias, const float eps, const float scale_log2e, const int B,
+                                                               const int S, const int heads) {
+  constexpr int NWV = 8, NKS = C / 16, SLF = NKS, NST = 3, FD = 4;
+  constexpr int SLOT = SLF * 1024, PW = SLF / NWV, WSH = PW * 1024;
+  constexpr int KV1 = HDC * 2 * 1024;                               // one row block's packed K (or V^T) fragments of a head
+  static_assert(SLF % NWV == 0 && (PW == 3 || PW == 4 || PW == 2), "pieces per wave");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const kx = smem + NST * SLOT;
+  unsigned char* const vx = kx + NWV * KV1;
+  float* const btab = reinterpret_cast<float*>(vx + NWV * KV1);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 31, kh = lane >> 5;
+  const unsigned lds0 = (unsigned)(size_t)(lptrm_t)smem;
+  const unsigned voff = (unsigned)(wave * WSH + lane * 16);
+  const int HD = HDC * 32, N = 3 * heads * HD, n_img = N / 32;
+  const int NB = (S + 31) >> 5;
+  if ((int)blockIdx.x >= B) return;
+  for (int i = t; i < N; i += NWV * 64) btab[i] = bias ? bias[i] : 0.0f;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+  int issue_img = 0, issue_slot = 0, slot = 0;
+  auto issue = [&]() {
+    mr_dma<PW>(voff, wimg + (size_t)issue_img * SLOT, lds0 + issue_slot * SLOT + wave * WSH);
+    issue_img = issue_img == n_img - 1 ? 0 : issue_img + 1;
+    issue_slot = issue_slot == NST - 1 ? 0 : issue_slot + 1;
+  };
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i) issue();
+  bool first = true;
+  const int perm = 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);      // fragment row r <-> channel perm of its chunk (pack kernel)
+  unsigned char* const kmine = kx + wave * KV1 + lane * 16;
+  unsigned char* const vmine = vx + wave * KV1 + lane * 16;
+
+  const int tok = wave * 32 + r;
+  const bool ok = tok < S;
+  u32x4 xr[NKS];
+  auto load_rows = [&](int img) {                                    // this wave's 32 token rows of image `img` (clamped), in flight
+    const size_t row = (size_t)img * S + (ok ? tok : S - 1);
+#pragma unroll
+    for (int s2 = 0; s2 < NKS; ++s2) xr[s2] = mr_gload16s(X + row * C + 32 * (s2 >> 1) + 16 * kh + 8 * (s2 & 1));
+  };
+  load_rows(blockIdx.x);
+  for (int img = blockIdx.x; img < B; img += gridDim.x) {
+    const size_t row = (size_t)img * S + (ok ? tok : S - 1);
+    mr_wait_loads<NKS>(&xr[0]);
+    mr_layernorm_rows<NKS, C>(xr, eps);
+    if (first) { mr_bar(); first = false; }
+    bf16* const crow = CTX + row * (size_t)(heads * HD) + 16 * kh;
+
+    auto chunk = [&](auto swapped_, f32x16& acc) {
+      constexpr bool SW = decltype(swapped_)::value;
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(PW) : "memory");      // (lgkmcnt: this wave's K / V fragment stores are in LDS before the barrier)
+      mr_bar();
+      issue();
+      unsigned a = slot * SLOT + lane * 16;
+      asm volatile("" : "+v"(a));
+      const unsigned char* sp = smem + a;
+      slot = slot == NST - 1 ? 0 : slot + 1;
+      u32x4 fr[FD];
+#pragma unroll
+      for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + i * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < SLF; ++i) {
+        if constexpr (SW) mfma32_v(xr[i], fr[i % FD], acc);
+        else mfma32_v(fr[i % FD], xr[i], acc);
+        if (i + FD < SLF) fr[i % FD] = *reinterpret_cast<const u32x4*>(sp + (i + FD) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));          // wait states MFMA -> VALU read of the accumulator
+    };
+    auto bias_rows = [&](f32x16& acc, int src) {                 // D[channel][token]: lane (token, kh) holds channels 16 kh + i
+      const float* bp = btab + src * 32 + kh * 16;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * g + e] = b4[e];
+      }
+    };
+    auto pack2 = [&](const f32x16& acc, u32x4 (&o)[2]) {          // accumulators 8 t .. 8 t + 7 -> k-step t of an MFMA operand
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[tt][e] = mr_pk2(acc[8 * tt + 2 * e], acc[8 * tt + 2 * e + 1]);
+    };
+    using yes_t = std::integral_constant<bool, true>;
+    using no_t = std::integral_constant<bool, false>;
+
+#pragma unroll 1
+    for (int h = 0; h < heads; ++h) {
+      // ---- K chunks of this wave's rows -> LDS
+#pragma unroll
+      for (int c = 0; c < HDC; ++c) {
+        f32x16 acc;
+        bias_rows(acc, (heads + h) * HDC + c);
+        chunk(no_t{}, acc);
+        u32x4 kp[2];
+        pack2(acc, kp);
+        *reinterpret_cast<u32x4*>(kmine + (c * 2 + 0) * 1024) = kp[0];
+        *reinterpret_cast<u32x4*>(kmine + (c * 2 + 1) * 1024) = kp[1];
+      }
+      // ---- Q chunks stay in registers (B operands of the scores)
+      u32x4 qp[HDC][2];
+#pragma unroll
+      for (int c = 0; c < HDC; ++c) {
+        f32x16 acc;
+        bias_rows(acc, h * HDC + c);
+        chunk(no_t{}, acc);
+        pack2(acc, qp[c]);
+      }
+      // ---- V chunks, transposed by swapping the MFMA operands -> LDS
+#pragma unroll
+      for (int c = 0; c < HDC; ++c) {
+        f32x16 acc;
+        const float bv = btab[((2 * heads + h) * HDC + c) * 32 + perm];       // D[token][channel]: lane = channel, every accumulator a token
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = bv;
+        chunk(yes_t{}, acc);
+        u32x4 vp[2];
+        pack2(acc, vp);
+        *reinterpret_cast<u32x4*>(vmine + (c * 2 + 0) * 1024) = vp[0];
+        *reinterpret_cast<u32x4*>(vmine + (c * 2 + 1) * 1024) = vp[1];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      mr_bar();                                                   // every row block's V^T (and, since the Q chunks, K) is in LDS
+      if (h == heads - 1 && img + (int)gridDim.x < B) load_rows(img + gridDim.x);     // the rows are dead from here on: the next image's arrive under this head's attention
+
+      // ---- attention over the key blocks (flash-style, one block's scores in registers at a time)
+      f32x16 oacc[HDC];
+#pragma unroll
+      for (int c = 0; c < HDC; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[c][i] = 0.0f;
+      float mrun = -3.0e38f, lrun = 0.0f;
+      auto kv_load = [&](int kb, u32x4 (&kf)[HDC][2], u32x4 (&vf)[HDC][2]) {
+        const unsigned char* const kb_k = kx + kb * KV1 + lane * 16;
+        const unsigned char* const kb_v = vx + kb * KV1 + lane * 16;
+#pragma unroll
+        for (int c = 0; c < HDC; ++c)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            kf[c][tt] = *reinterpret_cast<const u32x4*>(kb_k + (c * 2 + tt) * 1024);
+            vf[c][tt] = *reinterpret_cast<const u32x4*>(kb_v + (c * 2 + tt) * 1024);
+          }
+      };
+      auto kv_step = [&](int kb, u32x4 (&kf)[HDC][2], u32x4 (&vf)[HDC][2]) {
+        f32x16 sacc;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(qp[0][0]), "+v"(qp[0][1]) :: "memory");
+        mfma32_v_z(kf[0][0], qp[0][0], sacc);
+        mfma32_v(kf[0][1], qp[0][1], sacc);
+#pragma unroll
+        for (int c = 1; c < HDC; ++c) {
+          mfma32_v(kf[c][0], qp[c][0], sacc);
+          mfma32_v(kf[c][1], qp[c][1], sacc);
+        }
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(sacc));
+        // softmax over this block's 32 keys of the lane pair's query: accumulator i <-> key 32 kb + 8 (i >> 2) + 4 kh + (i & 3)
+        float pv[16], mx = -3.0e38f;
+        if (kb == NB - 1) {                                           // (wave-uniform: only the last block has keys beyond S)
+          const int key0 = 32 * kb + 4 * kh;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) pv[i] = (key0 + 8 * (i >> 2) + (i & 3)) < S ? sacc[i] : -3.0e38f;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) pv[i] = sacc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, pv[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * scale_log2e);
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          pv[i] = __builtin_amdgcn_exp2f((pv[i] - mnew) * scale_log2e);
+          sum += pv[i];
+        }
+        sum += __shfl_xor(sum, 32);
+        lrun = lrun * alpha + sum;
+        mrun = mnew;
+        u32x4 pp[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) pp[tt][e] = mr_pk2(pv[8 * tt + 2 * e], pv[8 * tt + 2 * e + 1]);
+#pragma unroll
+        for (int c = 0; c < HDC; ++c)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) oacc[c][i] *= alpha;
+        asm volatile("s_nop 7" : "+v"(pp[0]), "+v"(pp[1]), "+v"(oacc[0]), "+v"(oacc[HDC - 1]), "+v"(vf[0][0]), "+v"(vf[0][1]));     // VALU-written operands -> MFMA
+#pragma unroll
+        for (int c = 0; c < HDC; ++c) {
+          mfma32_v(vf[c][0], pp[0], oacc[c]);
+          mfma32_v(vf[c][1], pp[1], oacc[c]);
+        }
+      };
+      {                                                            // two fragment sets: block kb + 1 is read from LDS under block kb's work
+        u32x4 kfa[HDC][2], vfa[HDC][2], kfb[HDC][2], vfb[HDC][2];
+        kv_load(0, kfa, vfa);
+#pragma unroll 1
+        for (int kb = 0; kb < NB; kb += 2) {
+          if (kb + 1 < NB) kv_load(kb + 1, kfb, vfb);
+          kv_step(kb, kfa, vfa);
+          if (kb + 2 < NB) kv_load(kb + 2, kfa, vfa);
+          if (kb + 1 < NB) kv_step(kb + 1, kfb, vfb);
+        }
+      }
+      asm volatile("s_nop 15\n\ts_nop 3" : "+v"(oacc[0]), "+v"(oacc[HDC - 1]));
+      const float inv = __builtin_amdgcn_rcpf(lrun);
+#pragma unroll
+      for (int c = 0; c < HDC; ++c) {
+        u32x4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o0[e] = mr_pk2(oacc[c][2 * e] * inv, oacc[c][2 * e + 1] * inv);
+          o1[e] = mr_pk2(oacc[c][8 + 2 * e] * inv, oacc[c][8 + 2 * e + 1] * inv);
+        }
+        if (ok) {
+          mr_gstore16(crow + h * HD + c * 32, o0);
+          mr_gstore16(crow + h * HD + c * 32 + 8, o1);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // image for ln_gemm_rows_kernel from a standard packed layer w [N][kw] (K-contiguous rows): fragment (chunk j, k-step s), lane = 32 kh + r, e8:
 //   W[32 j + 16 (r>>2 & 1) + 4 (r>>3) + (r & 3)][32 (s>>1) + 16 kh + 8 (s&1) + e8]   (accumulator i of lane (token, kh) = channel 32 j + 16 kh + i)
 // heads > 0 (qkv_attn_rows_kernel; rows of w = (q | k | v, head, hdc chunks of 32)): image chunk (head h, part K | Q | V, c) = w's chunk
@@ -1161,6 +1406,28 @@ int launch_qkv_attn_rows(const void* x, void* ctx, const void* wimg, const float
   const int grid = n_tiles < 512 ? n_tiles : 512;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(MR_NW * 64), lds, s, (const bf16*)x, (bf16*)ctx, (const unsigned char*)wimg, bias, scale * 1.4426950408889634f, B,
                      S, heads, n_tiles);
+  return (int)hipGetLastError();
+}
+// norm1 + qkv + attention of a ViT block in one launch (vit_attn_rows_kernel): C = 384, head dim 64, up to 256 tokens; FSVIT_VIT_ATTN_ROWS=0 turns it off
+bool vit_attn_rows_supported(int dtype, int C, int heads, int hdp, int S) {
+  static const bool on = [] { const char* e = getenv("FSVIT_VIT_ATTN_ROWS"); return !e || e[0] != '0'; }();
+  return on && dtype == 1 && C == 384 && hdp == 64 && heads >= 1 && S >= 1 && S <= 256;
+}
+// ctx [B*S][heads*64] = softmax(scale q k^T) v per image and head, q | k | v = bias + W' LN(x)   (image from launch_qkv_attn_rows_pack with C = 384)
+int launch_vit_attn_rows(const void* x, void* ctx, const void* wimg, const float* bias, int B, int S, int C, int heads, int hdp, float eps, float scale,
+                         hipStream_t s) {
+  if (B <= 0) return 0;
+  if (C != 384 || hdp != 64 || S < 1 || S > 256) return (int)hipErrorInvalidValue;
+  auto kern = vit_attn_rows_kernel<384, 2>;
+  const int N = 3 * heads * hdp, lds = 3 * (384 / 16) * 1024 + 2 * 8 * (2 * 2 * 1024) + N * 4;
+  static int lds_set = 0;
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    lds_set = lds;
+  }
+  const int grid = B < 256 ? B : 256;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, (const bf16*)x, (bf16*)ctx, (const unsigned char*)wimg, bias, eps, scale * 1.4426950408889634f, B, S, heads);
   return (int)hipGetLastError();
 }
 #ifndef LGR_SPC384     // ring geometry (tools/build_variant.sh sweeps)

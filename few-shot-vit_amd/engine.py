@@ -640,6 +640,17 @@ class ops:
         return ctx
 
     @staticmethod
+    def vit_ln_qkv_attention(x, wqkv, bias, B, S, heads, hdp, scale, eps=1e-6):
+        """norm1 + qkv Linear + attention core of a ViT block in one launch (mlp_rows.hip vit_attn_rows): x [B*S, 384] bf16, wqkv [3*heads*64, kw]
+        bf16 (LayerNorm affine folded in by the caller) -> ctx [B*S, heads*64]."""
+        _require_cuda(x, wqkv)
+        ctx = torch.empty(B * S, heads * hdp, dtype=x.dtype, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().fsvit_vit_ln_qkv_attention(_ptr(x), _ptr(wqkv), wqkv.shape[-1], _ptr(bias), _ptr(ctx), B, S, x.shape[1], heads, hdp,
+                                                              float(eps), float(scale), _stream_ptr(x.device)))
+        return ctx
+
+    @staticmethod
     def im2col27(x, dtype):
         _require_cuda(x)
         lib = _lib.load()

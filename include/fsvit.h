@@ -169,6 +169,12 @@ int fsvit_attention(const void* qkv_dev, void* ctx_dev, int B, int S, int heads,
  * Also the stage-3 geometry on the row-wise kernel: C = 512, head dim padded to 96, S <= 32 (one image per wave). */
 int fsvit_qkv_attention(const void* x_dev, const void* wqkv_dev, int kw, const float* bias_dev, void* ctx_dev, int B, int S, int C,
                         int heads, int hdp, float scale, void* stream);
+/* norm1 + qkv Linear + attention core of a ViT / DeiT block in one launch (deit.py:40-58 Attention.forward, :69 `x + attn(norm1(x))` without the
+ * proj): x rows [B*S][C] bf16 -> ctx rows [B*S][heads*hdp]; LayerNorm without affine (gamma / beta folded into wqkv / bias by the caller),
+ * wqkv [3*heads*hdp][kw] K-major bf16 rows ordered (q|k|v, head, z), bias fp32 or NULL.  Built for C = 384, head dim 64, S <= 256
+ * (DeiT-S/16: 197 tokens).  Equals fsvit_ln_linear_rows followed by fsvit_attention without the qkv tensor in HBM. */
+int fsvit_vit_ln_qkv_attention(const void* x_dev, const void* wqkv_dev, int kw, const float* bias_dev, void* ctx_dev, int B, int S, int C,
+                               int heads, int hdp, float eps, float scale, void* stream);
 /* One fused Visformer stage-1 block (visformer.py:259-263 with attn_disabled + spatial_conv Mlp :152-163), bf16,
  * Visformer-S geometry only (20x20 tokens, 128 channels, 256 hidden, 8 groups): y = x + conv3(GELU(conv2_g(GELU(conv1(x)+b1)))).
  * x, y NHWC [B,20,20,128] bf16 (distinct buffers); w1 [256][128], w2 [8][32][320], w3 [128][256] packed K-major bf16. */

@@ -610,3 +610,36 @@ def test_gemm256_large_shapes_repeatable_and_correct():
         ref = x[rows].float() @ w.float().t()
         err = (first[rows.cuda()].float().cpu() - ref).abs().max().item()
         assert err <= 2e-2 * max(1.0, ref.abs().max().item()), (M, N, K, err)
+
+
+@pytest.mark.parametrize('B,S', [(3, 197), (2, 64), (1, 33), (5, 224), (2, 1)])
+def test_vit_ln_qkv_attention_rows_matches_unfused_math(B, S):
+    """vit_attn_rows (mlp_rows.hip): norm1 + qkv Linear + attention core of a DeiT-S block in one launch - a workgroup of 8 waves owns an image,
+    wave = 32-token row block, K and V^T fragments exchanged through LDS, flash-style loop over the key blocks - against the unfused math with
+    the same bf16 rounding points (LayerNorm output, q / k / v, probabilities); token counts that end inside / at a row block, the 197 tokens
+    of DeiT-S/16, a single token; repeats bit-identical."""
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    C, heads, hd = 384, 6, 64
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    x = q(torch.randn(B * S, C, generator=g) * 1.5 + 0.3, bf)
+    w = q(torch.randn(3 * heads * hd, C, generator=g) / math.sqrt(C), bf)
+    bias = torch.randn(3 * heads * hd, generator=g) * 0.3
+    scale = hd ** -0.5
+    mu, var = x.mean(-1, keepdim=True), x.var(-1, unbiased=False, keepdim=True)
+    xn = q((x - mu) * torch.rsqrt(var + 1e-6), bf)
+    qkv = q(xn @ w.t() + bias, bf).reshape(B, S, 3, heads, hd)
+    qq, kk, vv = [qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
+    p = ((qq @ kk.transpose(-1, -2)) * scale).softmax(-1)
+    ref = (p @ vv).permute(0, 2, 1, 3).reshape(B * S, heads * hd)
+    args = (x.to('cuda', bf), w.to('cuda', bf), bias.cuda(), B, S, heads, hd, scale)
+    got_d = ops.vit_ln_qkv_attention(*args)
+    torch.cuda.synchronize()
+    got = got_d.float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    print(f'vit_ln_qkv_attention B={B} S={S}: max err {err.max().item():.3e}, mean {err.mean().item():.3e} (max |ref| {ref.abs().max().item():.2f})')
+    assert err.max().item() <= 3e-2 * max(1.0, float(ref.abs().max())), (B, S, err.max().item())
+    assert err.mean().item() <= 3e-3, (B, S, err.mean().item())
+    for _ in range(3):
+        assert torch.equal(ops.vit_ln_qkv_attention(*args), got_d)
