@@ -233,6 +233,24 @@ __device__ __forceinline__ u32x4 mr_gload16s(const void* p) {      // streaming 
   return v;
 }
 
+// max / sum of a value with its partner in the other wave half (lane ^ 32): one v_permlane32_swap_b32 instead of a trip through the LDS crossbar.
+// Issued from inline asm on two copies: hipcc 7.2 treats both results of __builtin_amdgcn_permlane32_swap as interchangeable and folded
+// max(r0, r1) -> r0 and r0 + r1 -> 2 r0 (v_fmac 2.0 in the ISA), although the instruction returns [lo | lo] and [hi | hi]
+// (tools/probes/permlane32_swap_probe.hip).  s_nop 1: VALU write -> permlane read.
+__device__ __forceinline__ void xhalf_swap(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float xhalf_max(float v) {
+  float a = v, b = v;
+  xhalf_swap(a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  float a = v, b = v;
+  xhalf_swap(a, b);
+  return a + b;
+}
+
 // LayerNorm (no affine) of token rows held as MFMA B operands: lane (r, kh) has half of token r's C channels in NKS 16-byte registers, the
 // other half sits in lane r of the other wave half.  Two passes (mean, then centred sum of squares; biased variance as nn.LayerNorm), one lane
 // exchange each; the rows are replaced by bf16((x - mean) rstd).  Ends with the wait states VALU write -> MFMA SrcB.
@@ -1181,8 +1199,12 @@ __global__ __launch_bounds__(512, 1) void vit_attn_rows_kernel(const bf16* __res
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < SLF; ++i) {
+#if !(defined(VAR_DIAG) && (VAR_DIAG & 2))
         if constexpr (SW) mfma32_v(xr[i], fr[i % FD], acc);
         else mfma32_v(fr[i % FD], xr[i], acc);
+#else
+        if (i < 2) { if constexpr (SW) mfma32_v(xr[i], fr[i % FD], acc); else mfma32_v(fr[i % FD], xr[i], acc); }
+#endif
         if (i + FD < SLF) fr[i % FD] = *reinterpret_cast<const u32x4*>(sp + (i + FD) * 1024);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1286,27 +1308,34 @@ __global__ __launch_bounds__(512, 1) void vit_attn_rows_kernel(const bf16* __res
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, pv[i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mnew = fmaxf(mrun, mx);
-        const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * scale_log2e);
+        mx = xhalf_max(mx);                                           // the query's other 16 keys sit in the lane 32 away (v_permlane32_swap, no LDS trip)
+        // Deferred rescale: the running maximum only moves when a block's maximum exceeds it by more than 2^DEFER in the exponent (wave-uniform
+        // decision) - in between, the probabilities are taken against the stale maximum (at most 2^DEFER too large, fp32 / bf16 range is ample)
+        // and the 32 accumulator multiplies of the rescale are skipped; exact in the end because O and the sum carry the same factor.
+        constexpr float DEFER = 6.0f;
+        if (__builtin_amdgcn_ballot_w64((mx - mrun) * scale_log2e > DEFER) != 0) {
+          const float mnew = fmaxf(mrun, mx);
+          const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * scale_log2e);
+          lrun *= alpha;
+          mrun = mnew;
+#pragma unroll
+          for (int c = 0; c < HDC; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[c][i] *= alpha;
+        }
+        const float nm = -mrun * scale_log2e;
         float sum = 0.0f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          pv[i] = __builtin_amdgcn_exp2f((pv[i] - mnew) * scale_log2e);
+          pv[i] = __builtin_amdgcn_exp2f(fmaf(pv[i], scale_log2e, nm));
           sum += pv[i];
         }
-        sum += __shfl_xor(sum, 32);
-        lrun = lrun * alpha + sum;
-        mrun = mnew;
+        lrun += xhalf_sum(sum);
         u32x4 pp[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
           for (int e = 0; e < 4; ++e) pp[tt][e] = mr_pk2(pv[8 * tt + 2 * e], pv[8 * tt + 2 * e + 1]);
-#pragma unroll
-        for (int c = 0; c < HDC; ++c)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) oacc[c][i] *= alpha;
         asm volatile("s_nop 7" : "+v"(pp[0]), "+v"(pp[1]), "+v"(oacc[0]), "+v"(oacc[HDC - 1]), "+v"(vf[0][0]), "+v"(vf[0][1]));     // VALU-written operands -> MFMA
 #pragma unroll
         for (int c = 0; c < HDC; ++c) {
@@ -1314,6 +1343,7 @@ __global__ __launch_bounds__(512, 1) void vit_attn_rows_kernel(const bf16* __res
           mfma32_v(vf[c][1], pp[1], oacc[c]);
         }
       };
+#if !(defined(VAR_DIAG) && (VAR_DIAG & 1))                       // (timing diagnostics: -DVAR_DIAG=1 drops the attention phase, 2 the GEMM MFMAs - wrong results)
       {                                                            // two fragment sets: block kb + 1 is read from LDS under block kb's work
         u32x4 kfa[HDC][2], vfa[HDC][2], kfb[HDC][2], vfb[HDC][2];
         kv_load(0, kfa, vfa);
@@ -1325,6 +1355,7 @@ __global__ __launch_bounds__(512, 1) void vit_attn_rows_kernel(const bf16* __res
           if (kb + 1 < NB) kv_step(kb + 1, kfb, vfb);
         }
       }
+#endif
       asm volatile("s_nop 15\n\ts_nop 3" : "+v"(oacc[0]), "+v"(oacc[HDC - 1]));
       const float inv = __builtin_amdgcn_rcpf(lrun);
 #pragma unroll
