@@ -369,26 +369,23 @@ bool gemm256_eligible(const ConvGemmParams& p, int dtype) {
 }
 
 template <typename KernT>
-static int launch_gemm256_t(KernT kern, bool& attr, const ConvGemmParams& p, hipStream_t stream) {
+static int launch_gemm256_t(KernT kern, const ConvGemmParams& p, hipStream_t stream) {
   const int tiles_m = (p.M + G_BM - 1) / G_BM, tiles_n = (p.N + G_BN - 1) / G_BN;
   const long items = (long)tiles_m * tiles_n;
   long grid = 256;                                  // persistent: one 8-wave workgroup per CU
   if (items < grid) grid = (items + 7) / 8 * 8;
-  if (!attr) {
+  {    // per launch: the attribute is per device
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_STAGE);
     if (e != hipSuccess) return (int)e;
-    attr = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), 2 * G_STAGE, stream, p, tiles_m, tiles_n);
   return (int)hipGetLastError();
 }
 int launch_gemm256(const ConvGemmParams& p, hipStream_t stream) {
-  static bool attr = false;
-  return launch_gemm256_t(gemm256_kernel, attr, p, stream);
+  return launch_gemm256_t(gemm256_kernel, p, stream);
 }
 int launch_gemm256_x2(const ConvGemmParams& p, hipStream_t stream) {
-  static bool attr = false;
-  return launch_gemm256_t(gemm256_x2_kernel, attr, p, stream);
+  return launch_gemm256_t(gemm256_x2_kernel, p, stream);
 }
 
 }  // namespace FSVIT_NS

@@ -1427,11 +1427,9 @@ int launch_qkv_attn_rows(const void* x, void* ctx, const void* wimg, const float
   if (C != 512 || hdp != 96 || S < 1 || S > 32) return (int)hipErrorInvalidValue;
   auto kern = qkv_attn_rows_kernel<512, 3>;
   const int N = 3 * heads * hdp, lds = 4 * (512 / 32) * 1024 + N * 4;
-  static int lds_set = 0;
-  if (lds > lds_set) {
+  {    // per launch: the attribute is per device
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    lds_set = lds;
   }
   const int n_tiles = (B + MR_NW - 1) / MR_NW;
   const int grid = n_tiles < 512 ? n_tiles : 512;
@@ -1451,11 +1449,9 @@ int launch_vit_attn_rows(const void* x, void* ctx, const void* wimg, const float
   if (C != 384 || hdp != 64 || S < 1 || S > 256) return (int)hipErrorInvalidValue;
   auto kern = vit_attn_rows_kernel<384, 2>;
   const int N = 3 * heads * hdp, lds = 3 * (384 / 16) * 1024 + 2 * 8 * (2 * 2 * 1024) + N * 4;
-  static int lds_set = 0;
-  if (lds > lds_set) {
+  {    // per launch: the attribute is per device
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    lds_set = lds;
   }
   const int grid = B < 256 ? B : 256;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, (const bf16*)x, (bf16*)ctx, (const unsigned char*)wimg, bias, eps, scale * 1.4426950408889634f, B, S, heads);
@@ -1474,11 +1470,9 @@ static int launch_gemm_rows_t(const void* x, void* y, const void* wimg, const fl
                               const float* pos = nullptr) {
   auto kern = ln_gemm_rows_kernel<C, LN, SPC, NST, GATHER>;
   const int lds = NST * (C / 16 / SPC) * 1024 + N * 4;
-  static int lds_set = 0;
-  if (lds > lds_set) {
+  {    // per launch: the attribute is per device
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    lds_set = lds;
   }
   const int n_tiles = (M + MR_NW * 32 - 1) / (MR_NW * 32);
   const int grid = n_tiles < 256 * LGR_OCC ? n_tiles : 256 * LGR_OCC;
@@ -1588,11 +1582,9 @@ static int launch_mlp_rows_t(const void* x, void* y, const void* wimg, const flo
                              int M, hipStream_t s) {
   auto kern = mlp_rows_kernel<C, HID, RB, KC, LN>;
   const int lds = MR_NST * mr_slot_frags(C) * 1024 + HID * 4 + (LN ? 2 * C * 4 : 0);
-  static bool attr = false;
-  if (!attr) {
+  {    // per launch: the attribute is per DEVICE (a process-wide "done" flag skipped it on a second GPU), and the call is cheap
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr = true;
   }
   constexpr int BM = MR_NW * 32 * RB;
   const int n_tiles = (M + BM - 1) / BM;

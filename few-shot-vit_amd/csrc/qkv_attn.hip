@@ -350,11 +350,9 @@ int launch_qkv_attn_pack(const void* w, int kw, void* img, hipStream_t s) {
 
 int launch_qkv_attn(const void* x, void* ctx, const void* wimg, const float* bias, int B, int S, float scale, hipStream_t s) {
   if (B <= 0) return 0;
-  static bool attr = false;
-  if (!attr) {
+  {    // per launch: the attribute is per DEVICE (a process-wide "done" flag skipped it on a second GPU), and the call is cheap
     hipError_t e = hipFuncSetAttribute((const void*)qkv_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, qa::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr = true;
   }
   const int n_pass = (B + qa::IMGS - 1) / qa::IMGS;
   const int grid = n_pass < 256 ? n_pass : 256;

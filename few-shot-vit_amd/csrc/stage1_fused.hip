@@ -402,11 +402,9 @@ int launch_stage1_pack(const void* w1, const void* w2, const void* w3, void* wim
 
 int launch_stage1_block(const void* x, void* y, const void* wimg, const float* b1, int B, hipStream_t s) {
   if (B <= 0) return 0;
-  static bool attr_set = false;
-  if (!attr_set) {
+  {    // per launch: the attribute is per DEVICE (a process-wide "done" flag skipped it on a second GPU), and the call is cheap
     hipError_t e = hipFuncSetAttribute((const void*)stage1_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, s1::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   const int grid = 2 * B < 256 ? 2 * B : 256;            // persistent: one workgroup per CU, a fixed image half each
   hipLaunchKernelGGL(stage1_block_kernel, dim3(grid), dim3(s1::NW * 64), s1::LDS_BYTES, s, (const bf16*)x, (bf16*)y, (const unsigned char*)wimg, b1, B);

@@ -242,11 +242,9 @@ int launch_stage1_ring(const void* x, void* y, const void* w1, const float* b1, 
   int wgs = n_chunks < 256 ? n_chunks : 256;              // one 8-wave workgroup per CU (150 KB of LDS)
   const int cpw = (n_chunks + wgs - 1) / wgs;
   wgs = (n_chunks + cpw - 1) / cpw;
-  static bool attr = false;
-  if (!attr) {
+  {    // per launch: the attribute is per DEVICE (a process-wide "done" flag skipped it on a second GPU), and the call is cheap
     hipError_t e = hipFuncSetAttribute((const void*)stage1_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, s1r::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr = true;
   }
   hipLaunchKernelGGL(stage1_ring_kernel, dim3(wgs), dim3(512), s1r::LDS_BYTES, s, (const bf16*)x, (bf16*)y, (const bf16*)w1, b1, (const bf16*)w2, (const bf16*)w3, M, H, W,
                      n_chunks, cpw);

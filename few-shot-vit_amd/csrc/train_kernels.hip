@@ -900,8 +900,8 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const T* __restrict__
 // gridDim.x blocks of 4 waves, block b owns rows b*R .. (R = rows per block), each wave every 4th of them.
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, const float* __restrict__ gamma, const T* __restrict__ add,
-                                                     T* __restrict__ dx, float* __restrict__ partial, int M, int D, int rows_per_blk) {
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma, const T* add,
+                                                     T* dx, float* __restrict__ partial, int M, int D, int rows_per_blk) {      // (add may be dx: no restrict)
   extern __shared__ float red[];                       // [4 waves][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* mine = red + (size_t)wave * 2 * D;

@@ -223,11 +223,9 @@ int launch_wgrad3x3(const void* x, int xld, const void* dz, int zld, float* dw, 
   const int n_chunks = wgrad3x3_plan(O, Ig, groups, M, &splits, &cpw, &njobs);
   if (groups == 8) {
     constexpr int WINP = wg3::CH + 2 * 21 + 3, lds = (256 / 16) * wg3::CH * 32 + (256 / 16) * WINP * 32 + WINP * 32 + 32;
-    static bool attr = false;
-    if (!attr) {
+    {    // per launch: the attribute is per DEVICE (a process-wide "done" flag skipped it on a second GPU), and the call is cheap
       hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_kernel<256, 256, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) return (int)e;
-      attr = true;
     }
     hipLaunchKernelGGL((wgrad3x3_kernel<256, 256, 20>), dim3(splits), dim3(512), lds, s, (const bf16*)x, xld, (const bf16*)dz, zld, scratch, M, H, W, n_chunks, cpw);
   } else {
@@ -480,11 +478,9 @@ int launch_gconv3x3_x2(const ConvGemmParams& p, hipStream_t s) {
   const int cpw = (n_chunks + wgs - 1) / wgs;
   wgs = (n_chunks + cpw - 1) / cpw;
   const int lds = 64 * 128 * 16 + 16;                  // the pixel ring + the zero slot
-  static bool attr = false;
-  if (!attr) {
+  {    // per launch: the attribute is per DEVICE (a process-wide "done" flag skipped it on a second GPU), and the call is cheap
     hipError_t e = hipFuncSetAttribute((const void*)gconv3x3_x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    attr = true;
   }
   hipLaunchKernelGGL(gconv3x3_x2_kernel, dim3(wgs), dim3(512), lds, s, (const float*)p.x, (const unsigned*)p.w, p.Kw, (float*)p.y, M, p.H, p.W, n_chunks, cpw, p.act);
   return (int)hipGetLastError();

@@ -83,7 +83,12 @@ class ImageFolder:
                 self.label.append(i)
         self.n_classes = max(self.label) + 1
         self.device = torch.device(device if device is not None else ('cuda' if torch.cuda.is_available() else 'cpu'))
-        self._cache = {}
+        # decoded-image cache, bounded in bytes (LRU): a tieredImageNet-sized split at 224 px is 150 KB per image - 30 ... 67 GB if every
+        # image ever touched stayed resident, per rank.  `cache_bytes` (default 8 GiB; 0 disables) caps it.
+        from collections import OrderedDict
+        self._cache = OrderedDict()
+        self._cache_bytes = 0
+        self._cache_limit = int(kwargs.get('cache_bytes', 8 << 30))
         self._mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
         self._std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
 
@@ -96,6 +101,7 @@ class ImageFolder:
         i = int(i)
         hit = self._cache.get(i)
         if hit is not None:
+            self._cache.move_to_end(i)
             return hit
         from PIL import Image
         im = _open_rgb(self.filepaths[i])
@@ -112,7 +118,12 @@ class ImageFolder:
             im, (w, h) = canvas, canvas.size
         top, left = int(round((h - S) / 2.0)), int(round((w - S) / 2.0))
         t = torch.from_numpy(np.asarray(im.crop((left, top, left + S, top + S)), dtype=np.uint8).copy())
-        self._cache[i] = t
+        if self._cache_limit > 0:
+            self._cache[i] = t
+            self._cache_bytes += t.numel()
+            while self._cache_bytes > self._cache_limit and len(self._cache) > 1:
+                _, old = self._cache.popitem(last=False)
+                self._cache_bytes -= old.numel()
         return t
 
     def _normalise(self, u8: torch.Tensor) -> torch.Tensor:

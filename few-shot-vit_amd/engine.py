@@ -90,6 +90,10 @@ class _EncoderEngine:
             if k.endswith('num_batches_tracked'):
                 continue
             a = np.ascontiguousarray(v.detach().to('cpu', torch.float32).numpy())
+            if self.dtype in (_lib.F16, _lib.F16X2) and a.size and not np.all(np.abs(a) < 65504.0):
+                # fp16 limbs top out at 65504 (hi = inf, lo = NaN beyond) and go subnormal below 6e-5: the 'f16' / 'f16x2' modes assume
+                # BatchNorm / LayerNorm-scaled networks (weights O(1)); anything else belongs in 'bf16x2' (8-bit exponent, no range limit)
+                raise ValueError(f"fsvit: {k} holds values outside the fp16 range; use numerics='bf16x2' (or 'parity') for this checkpoint")
             keep.append(a)
             arr[n].name = k.encode()
             arr[n].data = a.ctypes.data_as(C.POINTER(C.c_float))
@@ -422,6 +426,8 @@ class ops:
         w = w.float()
         hi = w.to(t16)
         lo = (w - hi.float()).to(t16)
+        if not (torch.isfinite(hi.float()).all() and torch.isfinite(lo.float()).all()):
+            raise ValueError("x2_limbs: values outside the 16-bit type's range (fp16 limbs: |w| < 65504); use 'bf16x2'")
         words = (hi.view(torch.int16).to(torch.int32) << 16) | (lo.view(torch.int16).to(torch.int32) & 0xffff)
         return words.view(torch.float32)
 

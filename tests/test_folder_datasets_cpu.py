@@ -69,3 +69,22 @@ def test_cifar_fs_loads_split_and_keeps_uint8_images(tmp_path):
         datasets.make('cifar-fs', root_path=root, split='test', augment='resize', device='cpu')
     with pytest.raises(RuntimeError):
         ds.gather(torch.tensor([0]))                                       # the transform itself runs on the GPU: no CPU fallback
+
+
+def test_image_folder_cache_is_bounded_lru(tmp_path):
+    """the decoded-image cache is capped in bytes (least recently used images are evicted), results unchanged."""
+    from PIL import Image
+    from fewshot_vit_amd import datasets
+    root = tmp_path / 'imgs'
+    rng = np.random.default_rng(0)
+    for c in range(2):
+        (root / f'c{c}').mkdir(parents=True)
+        for i in range(4):
+            Image.fromarray(rng.integers(0, 256, size=(40, 48, 3), dtype=np.uint8)).save(root / f'c{c}' / f'{i}.png')
+    ds = datasets.make('image-folder', root_path=str(root), image_size=32, box_size=36, device='cpu', cache_bytes=3 * 32 * 32 * 3)
+    first = ds._load_u8(0).clone()
+    for i in range(8):
+        ds._load_u8(i)
+    assert len(ds._cache) == 3 and ds._cache_bytes <= 3 * 32 * 32 * 3
+    assert 0 not in ds._cache and 7 in ds._cache
+    assert torch.equal(ds._load_u8(0), first)
