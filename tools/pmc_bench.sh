@@ -6,7 +6,7 @@
 tag=${1:-r02}; shift
 R=$PWD; out=$R/gpurun_out/$tag; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
-B="python3 $R/bench.py --no-cpu-baseline --no-roofline --no-modes --steps 3 --warmup 1 $*"
+B="python3 $R/bench.py --no-cpu-baseline --no-roofline --no-modes --no-legs --steps 3 --warmup 1 $*"
 rm -rf /tmp/pb_*
 rocprofv3 --kernel-trace --stats -d /tmp/pb_kt -o kt -- $B > $out/kt_bench.json 2> $out/kt.err
 python3 $R/tools/rocpd_stats.py $(ls /tmp/pb_kt/*.db | head -1) 4 > $out/kernel_stats.csv   # 1 warm-up + 3 timed steps
