@@ -496,9 +496,12 @@ __global__ __launch_bounds__(512) void wgrad1x1_kernel(const bf16* __restrict__ 
   using namespace wg3;
   constexpr int WN = NT / 4, WC = CT / 2;                          // a wave's block: 4 x 2 waves
   constexpr int TN = WN / 16, TC = WC / 16;
-  constexpr int ZT_BYTES = (NT / 16) * CH * 32, XT_BYTES = (CT / 16) * CH * 32;
+  // subtile pitch 2048 + 32 bytes: the staging stores of a lane group hit 4 .. 8 DIFFERENT 16-column subtiles at the same row - with a pitch
+  // of 0 mod 256 bytes they all landed on the same banks (SQ_LDS_BANK_CONFLICT 54 % of this kernel's LDS cycles, profiles/r03_train_mfma_pmc.txt)
+  constexpr int SUB = CH * 32 + 32;
+  constexpr int ZT_BYTES = (NT / 16) * SUB, XT_BYTES = (CT / 16) * SUB;
   constexpr int NPZ = (CH * NT / 8) / 512, NPX = (CH * CT / 8) / 512;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[ZT_BYTES + XT_BYTES];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const ZT = smem;
   unsigned char* const XT = smem + ZT_BYTES;
   const int t = threadIdx.x, lane = t & 63, i = lane & 15, lq = lane >> 4;
@@ -528,20 +531,20 @@ __global__ __launch_bounds__(512) void wgrad1x1_kernel(const bf16* __restrict__ 
 #pragma unroll
     for (int u0 = 0; u0 < NPZ; ++u0) {
       const int u = t + 512 * u0, r = u / (NT / 8), c8 = u % (NT / 8);
-      *reinterpret_cast<u32x4*>(ZT + (c8 >> 1) * (CH * 32) + r * 32 + (c8 & 1) * 16) = pz[u0];
+      *reinterpret_cast<u32x4*>(ZT + (c8 >> 1) * SUB + r * 32 + (c8 & 1) * 16) = pz[u0];
     }
 #pragma unroll
     for (int u0 = 0; u0 < NPX; ++u0) {
       const int u = t + 512 * u0, r = u / (CT / 8), c8 = u % (CT / 8);
-      *reinterpret_cast<u32x4*>(XT + (c8 >> 1) * (CH * 32) + r * 32 + (c8 & 1) * 16) = px[u0];
+      *reinterpret_cast<u32x4*>(XT + (c8 >> 1) * SUB + r * 32 + (c8 & 1) * 16) = px[u0];
     }
   };
   f32x4 acc[TN][TC];
 #pragma unroll
   for (int a = 0; a < TN * TC; ++a) acc[a / TC][a % TC] = f32x4{0.f, 0.f, 0.f, 0.f};
   const unsigned lane_off = (lq * 4 + (i >> 2)) * 32 + (i & 3) * 8;
-  const unsigned zt_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ZT + (wn * TN) * (CH * 32) + lane_off;
-  const unsigned xt_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)XT + (wc * TC) * (CH * 32) + lane_off;
+  const unsigned zt_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ZT + (wn * TN) * SUB + lane_off;
+  const unsigned xt_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)XT + (wc * TC) * SUB + lane_off;
   auto tr = [&](unsigned addr) -> u32x2 {
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(size_t)addr));
   };
@@ -557,12 +560,12 @@ __global__ __launch_bounds__(512) void wgrad1x1_kernel(const bf16* __restrict__ 
       u32x4 af[TN];
 #pragma unroll
       for (int k4 = 0; k4 < TN; ++k4) {
-        const u32x2 a1 = tr(zt_lane + k4 * (CH * 32) + ks * 1024), a2 = tr(zt_lane + k4 * (CH * 32) + ks * 1024 + 512);
+        const u32x2 a1 = tr(zt_lane + k4 * SUB + ks * 1024), a2 = tr(zt_lane + k4 * SUB + ks * 1024 + 512);
         af[k4] = u32x4{a1[0], a1[1], a2[0], a2[1]};
       }
 #pragma unroll
       for (int ct = 0; ct < TC; ++ct) {
-        const u32x2 b1 = tr(xt_lane + ct * (CH * 32) + ks * 1024), b2 = tr(xt_lane + ct * (CH * 32) + ks * 1024 + 512);
+        const u32x2 b1 = tr(xt_lane + ct * SUB + ks * 1024), b2 = tr(xt_lane + ct * SUB + ks * 1024 + 512);
         const u32x4 bf = {b1[0], b1[1], b2[0], b2[1]};
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) acc[nt][ct] = mma_chunk<bf16>(af[nt], bf, acc[nt][ct]);
@@ -611,7 +614,10 @@ int launch_wgrad1x1(const void* x, int xld, int C, const void* dz, int zld, int 
   const int splits = wgrad1x1_splits(N, C, M);
   const int cpw = (n_chunks + splits - 1) / splits;
   const dim3 grid(splits, (N + NT - 1) / NT, (C + CT - 1) / CT);
-#define WG1_LAUNCH(A, B) hipLaunchKernelGGL((wgrad1x1_kernel<A, B>), grid, dim3(512), 0, s, (const bf16*)x, xld, C, (const bf16*)dz, zld, N, y, M, n_chunks, cpw, splits, Kc_pad)
+#define WG1_LAUNCH(A, B) do { const int lds = ((A) / 16 + (B) / 16) * (wg3::CH * 32 + 32);                                                                  \
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad1x1_kernel<A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                            \
+    if (e != hipSuccess) return (int)e;                                                                                                                  \
+    hipLaunchKernelGGL((wgrad1x1_kernel<A, B>), grid, dim3(512), lds, s, (const bf16*)x, xld, C, (const bf16*)dz, zld, N, y, M, n_chunks, cpw, splits, Kc_pad); } while (0)
   if (NT == 256 && CT == 256) WG1_LAUNCH(256, 256);
   else if (NT == 256) WG1_LAUNCH(256, 128);
   else if (CT == 256) WG1_LAUNCH(128, 256);

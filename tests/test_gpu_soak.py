@@ -86,3 +86,17 @@ def test_qkv_attention_rows_is_deterministic_at_bench_size():
     w = w.reshape(3 * heads * hdp, C).to(bf)
     bias = rn(3 * heads * hdp) * 0.3
     assert _repeat(lambda: ops.qkv_attention(x, w, bias, B, S, heads, hdp, hd ** -0.5), 40) == 0
+
+
+def test_vit_ln_qkv_attention_rows_is_deterministic_at_bench_size():
+    """vit_attn_rows (DeiT-S/16 geometry, 3200 images of 197 tokens: 8 waves per image, K / V^T fragments through LDS behind the ring barriers, the
+    next image's rows in flight under the last head): 30 launches bit-identical and finite - a missed barrier or wait shows up as a flicker."""
+    from fewshot_vit_amd.engine import ops
+    bf = torch.bfloat16
+    B, S, C, heads, hd = 3200, 197, 384, 6, 64
+    g = torch.Generator(device='cuda').manual_seed(11)
+    rn = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    x = (rn(B * S, C) * 1.5 + 0.3).to(bf)
+    w = (rn(3 * heads * hd, C) / math.sqrt(C)).to(bf)
+    bias = rn(3 * heads * hd) * 0.3
+    assert _repeat(lambda: ops.vit_ln_qkv_attention(x, w, bias, B, S, heads, hd, hd ** -0.5), 30) == 0
