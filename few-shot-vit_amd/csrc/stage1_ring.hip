@@ -58,6 +58,10 @@ __device__ __forceinline__ u32x2_r s1r_pack4(f32x4 v) {
   const bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
   return __builtin_bit_cast(u32x2_r, o);
 }
+__device__ __forceinline__ u32x4 s1r_pack8(f32x4 a, f32x4 b) {
+  const bf16x8 o = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+  return __builtin_bit_cast(u32x4, o);
+}
 __device__ __forceinline__ f32x4 s1r_gelu4(f32x4 v) {
 #ifdef S1R_NO_GELU      // timing diagnostics only (wrong results)
   return v;
@@ -81,21 +85,26 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restr
   // ---- this wave's weights (A operands: row = output channel of the product, 8 consecutive k per lane)
   u32x4 wf1[2][4], wf2[9][2], wf3[2][8];
   const int np3 = g >> 1, ph3 = g & 1;          // conv3: this wave = output channels 32 np3 .. + 31 of the pixel tiles 2 ph3, 2 ph3 + 1
+  // Which channel of a 32-channel block sits in which MFMA row is the loader's choice: row R of tile nt carries channel 8 (R >> 2) + 4 nt + (R & 3),
+  // so the 4 + 4 accumulators a lane holds of the tile pair are 8 CONSECUTIVE channels 8 lq .. 8 lq + 7 of its pixel = one 16-byte slot of plane lq:
+  // h1 / h2 / the output tile are written with ds_write_b128 (8 lanes = 128 contiguous bytes, conflict-free) instead of two 8-byte stores whose
+  // 16-lane groups met 2-way on the banks (28.6 % of the kernel's LDS cycles, profiles/r02_stage1_pmc.txt), and the residual is one 16-byte read.
+  const int prow = 8 * (lrow >> 2) + (lrow & 3);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) wf1[nt][kc] = *reinterpret_cast<const u32x4*>(w1 + (size_t)(g * 32 + nt * 16 + lrow) * C1 + kc * 32 + lq * 8);
+    for (int kc = 0; kc < 4; ++kc) wf1[nt][kc] = *reinterpret_cast<const u32x4*>(w1 + (size_t)(g * 32 + prow + 4 * nt) * C1 + kc * 32 + lq * 8);
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) wf2[tp][nt] = *reinterpret_cast<const u32x4*>(w2 + (size_t)(g * 32 + nt * 16 + lrow) * KW2 + tp * 32 + lq * 8);
+    for (int nt = 0; nt < 2; ++nt) wf2[tp][nt] = *reinterpret_cast<const u32x4*>(w2 + (size_t)(g * 32 + prow + 4 * nt) * KW2 + tp * 32 + lq * 8);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int kc = 0; kc < 8; ++kc) wf3[nt][kc] = *reinterpret_cast<const u32x4*>(w3 + (size_t)(np3 * 32 + nt * 16 + lrow) * HID + kc * 32 + lq * 8);
+    for (int kc = 0; kc < 8; ++kc) wf3[nt][kc] = *reinterpret_cast<const u32x4*>(w3 + (size_t)(np3 * 32 + prow + 4 * nt) * HID + kc * 32 + lq * 8);
   f32x4 bias1[2];
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) bias1[nt] = *reinterpret_cast<const f32x4*>(b1 + g * 32 + nt * 16 + lq * 4);
+  for (int nt = 0; nt < 2; ++nt) bias1[nt] = *reinterpret_cast<const f32x4*>(b1 + g * 32 + lq * 8 + nt * 4);
 
   // ---- x batches: 64 consecutive pixels from linear index P0 (pixels outside [0, M) are stored as zeros); 2 x 16 B per thread
   u32x4 px[2];
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restr
   };
   // conv1 + bias + GELU for the 64 pixels from P0: wave g computes hidden channels 32 g .. 32 g + 31 into ITS planes of the h1 ring
   const unsigned char* const xplane = smem + XR + lq * PITCH;                 // k-chunk kc adds 4 planes
-  unsigned char* const h1w = smem + H1R + (g * 4 + (lq >> 1)) * PITCH + (lq & 1) * 8;     // channel tile nt adds 2 planes
+  unsigned char* const h1w = smem + H1R + (g * 4 + lq) * PITCH;                           // this lane's 8 channels = plane lq of the group
   auto conv1 = [&](long P0) {
 #pragma unroll S1R_UNROLL
     for (int mt = 0; mt < CH / 16; ++mt) {
@@ -133,16 +142,15 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restr
         acc[0] = mma_chunk<bf16>(wf1[0][kc], xf, acc[0]);
         acc[1] = mma_chunk<bf16>(wf1[1][kc], xf, acc[1]);
       }
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<u32x2_r*>(h1w + nt * (2 * PITCH) + slot) = s1r_pack4(s1r_gelu4(acc[nt]));
+      *reinterpret_cast<u32x4*>(h1w + slot) = s1r_pack8(s1r_gelu4(acc[0]), s1r_gelu4(acc[1]));
     }
   };
 
   const unsigned char* const h1plane = smem + H1R + (g * 4 + lq) * PITCH;      // conv2 B operand: channels 32 g + 8 lq .. of a pixel
-  unsigned char* const h2w = smem + H2 + (g * 4 + (lq >> 1)) * H2P + (lq & 1) * 8;
+  unsigned char* const h2w = smem + H2 + (g * 4 + lq) * H2P;
   const unsigned char* const h2plane = smem + H2 + lq * H2P;                   // conv3 B operand: k-chunk kc adds 4 planes
-  const unsigned char* const xres = smem + XR + (np3 * 4 + (lq >> 1)) * PITCH + (lq & 1) * 8;   // residual: channels 32 np3 + 4 lq .. of a pixel (tile nt: + 2 planes)
-  unsigned char* const outw = smem + OUT + (np3 * 32 + lq * 4) * 2;
+  const unsigned char* const xres = smem + XR + (np3 * 4 + lq) * PITCH;          // residual: channels 32 np3 + 8 lq .. + 7 of a pixel
+  unsigned char* const outw = smem + OUT + (np3 * 32 + lq * 8) * 2;
   const int HW = H * W;
 
   // ---- the first window: x pixels [64 q0 - 21, 64 q0 + 107) = the whole ring in two batches; h1 of the first batch here, of the second in the loop
@@ -188,8 +196,7 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restr
         acc[0] = mma_chunk<bf16>(wf2[tp][0], hf, acc[0]);
         acc[1] = mma_chunk<bf16>(wf2[tp][1], hf, acc[1]);
       }
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) *reinterpret_cast<u32x2_r*>(h2w + nt * (2 * H2P) + (mt * 16 + lrow) * 16) = s1r_pack4(s1r_gelu4(acc[nt]));
+      *reinterpret_cast<u32x4*>(h2w + (mt * 16 + lrow) * 16) = s1r_pack8(s1r_gelu4(acc[0]), s1r_gelu4(acc[1]));
     }
     S1R_SYNC();                                                // C: h2 of all groups is complete
 
@@ -206,12 +213,10 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restr
         acc[1] = mma_chunk<bf16>(wf3[1][kc], hf, acc[1]);
       }
       const int m = m0 + mt * 16 + lrow;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const bf16x4 r = __builtin_bit_cast(bf16x4, *reinterpret_cast<const u32x2_r*>(xres + nt * (2 * PITCH) + (m & (RING - 1)) * 16));
-        acc[nt] += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
-        *reinterpret_cast<u32x2_r*>(outw + nt * 32 + (mt * 16 + lrow) * OROW) = s1r_pack4(acc[nt]);
-      }
+      const bf16x8 r = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xres + (m & (RING - 1)) * 16));
+      acc[0] += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+      acc[1] += f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+      *reinterpret_cast<u32x4*>(outw + (mt * 16 + lrow) * OROW) = s1r_pack8(acc[0], acc[1]);
     }
     S1R_SYNC();                                                // D: the output tile is complete
 #pragma unroll
