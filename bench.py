@@ -503,9 +503,9 @@ def extra_legs(args, dev):
                                 '15 query/class, synthetic episodes resident in HBM, procedural weights'}
     del pool, eng, m
     free()
-    eps, ms, loss, _ = train_leg(name, 'bf16', 2, 5, 2, 0, 1, dev)
+    eps, ms, loss, _ = train_leg(name, 'bf16', 2, 10, 3, 0, 1, dev)
     tf = eps * 3.0 * flop * 100 / 1e12
-    legs['deit_train'] = {'value': eps, 'unit': 'train-episodes/s', 'ms_per_step': ms, 'steps': 5, 'warmup': 2, 'dtype': 'bf16', 'images_per_step': 200,
+    legs['deit_train'] = {'value': eps, 'unit': 'train-episodes/s', 'ms_per_step': ms, 'steps': 10, 'warmup': 3, 'dtype': 'bf16', 'images_per_step': 200,
                           'whole_path_tflops': tf, 'whole_path_mfma_frac': tf / peak, 'final_loss': loss, 'workload': train_workload(name)}
     free()
     legs['end_to_end'] = end_to_end_leg(args, dev)
@@ -550,7 +550,8 @@ def _committed_pmc(dom_kernel):
     import re
 
     def newest(pattern):
-        fs_ = sorted(glob.glob(os.path.join(REPO, 'profiles', pattern)),
+        # rNN_<what>.json only (the eval bench's own summaries; rNN_train_* etc. belong to other commands)
+        fs_ = sorted((p for p in glob.glob(os.path.join(REPO, 'profiles', pattern)) if re.fullmatch(r'r\d+_(hbm_traffic|mfma_pmc)\.json', os.path.basename(p))),
                      key=lambda p: [int(x) if x.isdigit() else x for x in re.split(r'(\d+)', os.path.basename(p))])
         return fs_[-1] if fs_ else None
 
