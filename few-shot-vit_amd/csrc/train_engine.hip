@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -104,6 +105,23 @@ struct fsvit_visformer_trainer {
   // weight-gradient split slabs of a backward pass stay in the `save` arena and are summed by ONE table-driven launch at the end of the pass
   std::vector<FinJob> fin;
   size_t save_after_forward = 0;
+  // Side stream of the backward pass: the direct weight-gradient kernels (wgrad3x3 / wgrad1x1) have no consumer before the end of the pass, so they
+  // run on a second HIP stream next to the data-gradient / BatchNorm chain (launch tails and HBM-bound elementwise passes overlap with them).
+  // `pend` = the byte ranges pending side launches still READ; a main-stream launch that writes into one of them first waits for the side stream.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_a = nullptr;
+  std::vector<hipEvent_t> ev_done;        // one per side launch of a pass (recorded behind it; the side stream runs in order)
+  int side_seq = 0;                       // side launches of this pass so far
+  // default: on for the ViT / DeiT trainer (GEMM-heavy: 19.2 -> 17.6 ms per 200-image DeiT-S step), off for the Visformer trainer (its 800-image step is
+  // HBM-bound in every kernel, overlap buys nothing: 16.55 vs 16.67 ms); FSVIT_WGRAD_SIDE_STREAM=0 / 1 forces it
+  bool side_on = false;
+  struct Range { const unsigned char *lo, *hi; int seq; };
+  std::vector<Range> pend;
+  ~fsvit_visformer_trainer() {
+    if (ev_a) (void)hipEventDestroy(ev_a);
+    for (hipEvent_t e : ev_done) (void)hipEventDestroy(e);
+    if (side) (void)hipStreamDestroy(side);
+  }
 };
 
 namespace {
@@ -188,6 +206,7 @@ int conv_fwd(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, void*
 }
 
 // ---------------------------------------------------------------- data gradient: dx = conv^T(dz)   (stride-1 convs and 1x1)
+int side_guard(TR* t, const void* p, size_t bytes);       // (side stream of the backward pass, below)
 // mul != nullptr: dx = conv^T(dz) * mul (the saved GELU derivative of the layer in front: its backward rides in this epilogue)
 int conv_bwd_data(TR* t, const ConvSpec& c, const void* dz, int B, int OH, int OW, void* dx, const void* mul = nullptr) {
   const fsvit_param* w = getp(t, c.wname);
@@ -200,6 +219,7 @@ int conv_bwd_data(TR* t, const ConvSpec& c, const void* dz, int B, int OH, int O
   void* pk = nullptr;
   T_TRY(packed_weight(t, PackJob{w->data, nullptr, c.O, c.Ig, c.KH, c.KW, c.groups, 1, Ig_pad, Kw, c.hd_cols, c.hdp_cols, c.hd_rows, c.hdp_rows},
                       (size_t)c.groups * Ig_pad * Kw * t->es, &pk));
+  T_TRY(side_guard(t, dx, (size_t)B * OH * OW * c.groups * Ig_pad * t->es));
   if (gconv3x3_supported(t->dtype, c.O, c.Ig, c.groups, c.KH, c.KW, c.stride, c.pad, OW) && Ng_pad == 32 && Ig_pad == 32) {
     T_RUN(launch_gconv3x3(dz, pk, Kw, dx, B, OH, OW, t->st, nullptr, mul));      // the same kernel on the transposed, tap-flipped pack
     return 0;
@@ -208,6 +228,53 @@ int conv_bwd_data(TR* t, const ConvSpec& c, const void* dz, int B, int OH, int O
   if (mul) { p.act = ACT_MUL; p.res = mul; }
   T_RUN(launch_conv_gemm(p, t->dtype, t->st));
   return 0;
+}
+
+// ---------------------------------------------------------------- side stream of the backward pass
+int side_begin(TR* t) {                       // the side stream may start once everything queued on the main stream so far is done
+  if (!t->side) {
+    T_TRY((int)hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+    T_TRY((int)hipEventCreateWithFlags(&t->ev_a, hipEventDisableTiming));
+  }
+  T_TRY((int)hipEventRecord(t->ev_a, t->st));
+  T_TRY((int)hipStreamWaitEvent(t->side, t->ev_a, 0));
+  return 0;
+}
+// behind a side launch: its completion event, and the byte ranges it reads
+int side_end(TR* t, const void* p0, size_t b0, const void* p1, size_t b1) {
+  if ((int)t->ev_done.size() <= t->side_seq) {
+    hipEvent_t e = nullptr;
+    T_TRY((int)hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    t->ev_done.push_back(e);
+  }
+  T_TRY((int)hipEventRecord(t->ev_done[t->side_seq], t->side));
+  t->pend.push_back(TR::Range{(const unsigned char*)p0, (const unsigned char*)p0 + b0, t->side_seq});
+  t->pend.push_back(TR::Range{(const unsigned char*)p1, (const unsigned char*)p1 + b1, t->side_seq});
+  ++t->side_seq;
+  return 0;
+}
+// the main stream waits for the side launches up to `seq` (the side stream is in order) and forgets their ranges
+int side_wait(TR* t, int seq) {
+  T_TRY((int)hipStreamWaitEvent(t->st, t->ev_done[seq], 0));
+  size_t k = 0;
+  for (size_t i = 0; i < t->pend.size(); ++i)
+    if (t->pend[i].seq > seq) t->pend[k++] = t->pend[i];
+  t->pend.resize(k);
+  return 0;
+}
+int side_sync(TR* t) {                        // ... for every side launch so far
+  if (t->save.dry || t->side_seq == 0) { t->pend.clear(); return 0; }
+  T_TRY(side_wait(t, t->side_seq - 1));
+  t->pend.clear();
+  return 0;
+}
+// call before a main-stream launch that WRITES [p, p + bytes): waits for the youngest pending side launch that still reads any of it
+int side_guard(TR* t, const void* p, size_t bytes) {
+  const unsigned char *lo = (const unsigned char*)p, *hi = lo + bytes;
+  int seq = -1;
+  for (const TR::Range& r : t->pend)
+    if (lo < r.hi && r.lo < hi && r.seq > seq) seq = r.seq;
+  return seq >= 0 ? side_wait(t, seq) : 0;
 }
 
 // ---------------------------------------------------------------- weight gradient: dW = sum_m dz[m] (x) xcol[m]   (split-K GEMM over transposed operands)
@@ -227,7 +294,10 @@ int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W
     float* scratch = (float*)t->save.take(wgrad3x3_scratch_bytes(c.O, c.Ig, c.groups, M));
     if (!scratch) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (wgrad3x3)");
     int d[2] = {0, 0};
-    T_RUN(launch_wgrad3x3(x, Cin_tot, dz, rows, w->grad, scratch, B, H, W, c.O, c.Ig, c.groups, t->st, d));
+    const bool on_side = t->side_on && !t->save.dry;
+    if (on_side) T_TRY(side_begin(t));
+    T_RUN(launch_wgrad3x3(x, Cin_tot, dz, rows, w->grad, scratch, B, H, W, c.O, c.Ig, c.groups, on_side ? t->side : t->st, d));
+    if (on_side) T_TRY(side_end(t, x, (size_t)M * Cin_tot * t->es, dz, (size_t)M * rows * t->es));
     if (!t->save.dry) t->fin.push_back(FinJob{scratch, w->grad, 3, 0, c.Ig, 3, 3, c.groups == 8 ? 1 : 0, d[1], d[0], 1, 1, 1, 1});
     return 0;
   }
@@ -236,7 +306,10 @@ int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W
     const int splits = wgrad1x1_splits(rows, Cin_tot, M);
     float* ysp = (float*)t->save.take((size_t)round_up(rows, 4) * splits * Kc_pad * 4);
     if (!ysp) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (wgrad1x1)");
-    T_RUN(launch_wgrad1x1(x, Cin_tot, Cin_tot, dz, rows, rows, ysp, M, Kc_pad, t->st));
+    const bool on_side = t->side_on && !t->save.dry;
+    if (on_side) T_TRY(side_begin(t));
+    T_RUN(launch_wgrad1x1(x, Cin_tot, Cin_tot, dz, rows, rows, ysp, M, Kc_pad, on_side ? t->side : t->st));
+    if (on_side) T_TRY(side_end(t, x, (size_t)M * Cin_tot * t->es, dz, (size_t)M * rows * t->es));
     const int KHf = c.via_patches ? 3 : c.KH, KWf = c.via_patches ? 3 : c.KW;
     const bool fast = KHf == 1 && KWf == 1 && c.hd_rows == c.hdp_rows && c.hd_cols == c.hdp_cols && (c.Ig & 3) == 0 && (Kc_pad & 3) == 0;
     if (!t->save.dry) t->fin.push_back(FinJob{ysp, w->grad, fast ? 1 : 0, c.O, c.Ig, KHf, KWf, 0, splits, Kc_pad, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols});
@@ -253,6 +326,8 @@ int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W
   void* dzt = t->tmp.take((size_t)rows * Mpad * t->es);
   void* xct = t->tmp.take((size_t)Kc_pad * Mpad * t->es);
   if (!dzt || !xct || !ysp) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (wgrad)");
+  T_TRY(side_guard(t, dzt, (size_t)rows * Mpad * t->es));
+  T_TRY(side_guard(t, xct, (size_t)Kc_pad * Mpad * t->es));
   T_RUN(launch_transpose_cols(dz, dzt, M, rows, 0, rows, Mpad, t->dtype, t->st));
   if (c.via_patches) T_RUN(launch_transpose_cols(x, xct, M, 32, 0, 32, Mpad, t->dtype, t->st));
   else T_RUN(launch_im2col_t(x, xct, B, H, W, Cin_tot, 0, Cin_tot, c.KH, c.KW, c.stride, c.pad, OH, OW, Mpad, t->dtype, t->st));
@@ -274,6 +349,7 @@ int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W
 
 // every deferred split-slab finalize of this backward pass (one or two launches)
 int run_finalizes(TR* t) {
+  T_TRY(side_sync(t));
   if (t->save.dry || t->fin.empty()) return 0;
   T_RUN(launch_wgrad_finalize_multi(t->fin.data(), (int)t->fin.size(), t->st));
   t->fin.clear();
@@ -322,6 +398,8 @@ int bn_bwd(TR* t, const std::string& name, const BnSave& sv, const void* dy, voi
   float* dbeta = b->grad ? b->grad : coef + 4 * sv.C;
   T_RUN(launch_bn_reduce(dy, sv.z, sv.mean, sv.invstd, partial, sv.M, sv.C, 1, t->dtype, t->st, nullptr, nullptr, nullptr, 0, act ? sv.sa : nullptr, act ? sv.sb : nullptr));
   T_RUN(launch_bn_bwd_finalize(partial, sv.M, sv.C, g->data, sv.invstd, dgamma, dbeta, coef, coef + sv.C, coef + 2 * sv.C, t->freeze_bn ? 1 : 0, t->st));
+  T_TRY(side_guard(t, dz, (size_t)sv.M * sv.C * t->es));
+  if (out2) T_TRY(side_guard(t, out2, (size_t)sv.M * sv.C * t->es));
   T_RUN(launch_bn_bwd_apply(dy, sv.z, sv.mean, sv.invstd, coef, coef + sv.C, coef + 2 * sv.C, dz, (size_t)sv.M, sv.C, t->dtype, t->st, acc, scale2, out2, rows_per_img,
                             act ? sv.sa : nullptr, act ? sv.sb : nullptr));
   t->tmp.off = mark;
@@ -547,7 +625,7 @@ int train_backward_impl(TR* t, const float* dfeat) {
       // (dz2 sits at the same tmp offset in every block of the stage: the drop-path-scaled copy of dx each branch starts from is written by
       // the fused tail of the preceding BatchNorm backward, only the stage's first block launches the copy itself)
       void* dz2 = take_tmp(t, M * C); NEED(dz2);
-      if (i == (int)blocks.size() - 1) T_RUN(launch_add_scaled(nullptr, dx, b.s2, dz2, M * C, (size_t)Ho * Ho * C, dt, st));
+      if (i == (int)blocks.size() - 1) { T_TRY(side_guard(t, dz2, M * C * t->es)); T_RUN(launch_add_scaled(nullptr, dx, b.s2, dz2, M * C, (size_t)Ho * Ho * C, dt, st)); }
       T_TRY(conv_bwd_weight(t, cs.fc2, b.h, B, Ho, Ho, dz2));
       void* dh = take_tmp(t, M * hid); NEED(dh);
       T_TRY(conv_bwd_data(t, cs.fc2, dz2, B, Ho, Ho, dh, b.z1));                               // dh := dz1 (x GELU' in the epilogue)
@@ -560,6 +638,7 @@ int train_backward_impl(TR* t, const float* dfeat) {
       void* dctx = take_tmp(t, M * heads * hdp); NEED(dctx);
       T_TRY(conv_bwd_data(t, cs.proj, dz2, B, Ho, Ho, dctx));
       void* dqkv = take_tmp(t, M * 3 * heads * hdp); NEED(dqkv);
+      T_TRY(side_guard(t, dqkv, M * 3 * heads * hdp * t->es));
       T_RUN(launch_attention_bwd(b.qkv, dctx, dqkv, B, Ho * Ho, heads, hd, hdp, scale, dt, st));
       T_TRY(conv_bwd_weight(t, cs.qkv, b.xn1, B, Ho, Ho, dqkv));
       T_TRY(conv_bwd_data(t, cs.qkv, dqkv, B, Ho, Ho, dxn2));                                 // dxn2 := d(xn1)
@@ -578,6 +657,7 @@ int train_backward_impl(TR* t, const float* dfeat) {
       if (!bias || !pos) return FSVIT_ERR_KEY;
       if (pos->grad || t->save.dry) {
         float* ps = (float*)t->tmp.take((size_t)Ho * Ho * C * 4); NEED(ps);
+        T_TRY(side_guard(t, ps, (size_t)Ho * Ho * C * 4));
         T_RUN(launch_batch_sum(dx, ps, B, (size_t)Ho * Ho * C, dt, st));
         T_RUN(launch_transpose_cols(ps, pos->grad, Ho * Ho, C, 0, C, Ho * Ho, 0, st));         // [HW][C] -> [C][HW]
       }
@@ -585,6 +665,7 @@ int train_backward_impl(TR* t, const float* dfeat) {
       T_TRY(bn_bwd(t, pn + "norm.bn", pe.bn, dx, dz));
       if (bias->grad || t->save.dry) {
         float* partial = (float*)t->tmp.take((size_t)bn_reduce_blocks((int)M) * 2 * C * 4); NEED(partial);
+        T_TRY(side_guard(t, partial, (size_t)bn_reduce_blocks((int)M) * 2 * C * 4));
         T_RUN(launch_colsum(dz, partial, bias->grad, (int)M, C, dt, st));
       }
       T_TRY(conv_bwd_weight(t, pc, pe.xin, B, Hi, Hi, dz));
@@ -595,12 +676,15 @@ int train_backward_impl(TR* t, const float* dfeat) {
       T_TRY(packed_weight(t, PackJob{w->data, nullptr, C, Ci, 2, 2, 1, 2, 4 * Ci, Kw, 1, 1, 1, 1}, (size_t)4 * Ci * Kw * t->es, &pk));
       void* G = take_tmp(t, M * 4 * Ci); NEED(G);
       ConvGemmParams p = gemm_params(dz, pk, G, B, Ho, Ho, C, C, 1, 1, 1, 0, 4 * Ci, 4 * Ci, C, Kw, 1);
+      T_TRY(side_guard(t, G, M * 4 * Ci * t->es));
       T_RUN(launch_conv_gemm(p, dt, st));
       void* dxi = take_tmp(t, Mi * Ci); NEED(dxi);
+      T_TRY(side_guard(t, dxi, Mi * Ci * t->es));
       T_RUN(launch_unpatch2(G, dxi, B, Ho, Ho, Ci, dt, st));
       // the new residual-stream gradient lives at the start of tmp: move it there
       t->tmp.off = 0;
       dx = take_tmp(t, Mi * Ci);
+      T_TRY(side_sync(t));                    // (the start of tmp held this stage's gradient buffers)
       T_RUN((int)hipMemcpyAsync(dx, dxi, Mi * Ci * t->es, hipMemcpyDeviceToDevice, st));
     }
   }
@@ -610,7 +694,7 @@ int train_backward_impl(TR* t, const float* dfeat) {
     const std::string p = "stage1." + std::to_string(i) + ".";
     const size_t mark = t->tmp.off;
     void* dz3 = take_tmp(t, M1 * t->C1); NEED(dz3);
-    if (i == (int)t->s1.size() - 1) T_RUN(launch_add_scaled(nullptr, dx, b.scale, dz3, M1 * t->C1, (size_t)H1 * H1 * t->C1, dt, st));
+    if (i == (int)t->s1.size() - 1) { T_TRY(side_guard(t, dz3, M1 * t->C1 * t->es)); T_RUN(launch_add_scaled(nullptr, dx, b.scale, dz3, M1 * t->C1, (size_t)H1 * H1 * t->C1, dt, st)); }
     T_TRY(conv_bwd_weight(t, sp.s1c3[i], b.h2, B, H1, H1, dz3));
     void* dh2 = take_tmp(t, M1 * t->hid1); NEED(dh2);
     T_TRY(conv_bwd_data(t, sp.s1c3[i], dz3, B, H1, H1, dh2, b.z2));                           // x GELU'(z2) in the epilogue
@@ -631,11 +715,13 @@ int train_backward_impl(TR* t, const float* dfeat) {
     if (!pos) return FSVIT_ERR_KEY;
     if (pos->grad || t->save.dry) {
       float* ps = (float*)t->tmp.take((size_t)H1 * H1 * t->C1 * 4); NEED(ps);
+      T_TRY(side_guard(t, ps, (size_t)H1 * H1 * t->C1 * 4));
       T_RUN(launch_batch_sum(dx, ps, B, (size_t)H1 * H1 * t->C1, dt, st));
       T_RUN(launch_transpose_cols(ps, pos->grad, H1 * H1, t->C1, 0, t->C1, H1 * H1, 0, st));
     }
     void* da3 = take_tmp(t, M0 * t->C1); NEED(da3);
     void* g3 = take_tmp(t, M0 * t->C1); NEED(g3);
+    T_TRY(side_guard(t, g3, M0 * t->C1 * t->es));
     T_RUN(launch_pool_act_bwd(dx, S.arg, g3, B, H1, H1, t->C1, dt, st));                      // gradient at (bn3(z3) + identity): max-pool routing x LeakyReLU slope
     T_TRY(bn_bwd(t, "stem.bn3", S.b3, g3, da3));                                              // da3 := dz3
     T_TRY(conv_bwd_weight(t, sp.conv3, S.a2, B, H0, H0, da3));
@@ -835,6 +921,7 @@ int vit_backward_impl(VT* t, const float* dfeat) {
     const size_t mark = t->tmp.off;
     // mlp branch: out = x1 + s2 * fc2(gelu(fc1(norm2(x1))))
     void* dz2 = take_tmp(t, M * D); NEED(dz2);
+    T_TRY(side_guard(t, dz2, M * D * t->es));
     T_RUN(launch_add_scaled(nullptr, dx, b.s2, dz2, M * D, (size_t)S * D, dt, st));
     T_TRY(conv_bwd_weight(t, sp.fc2[i], b.h, B, S, 1, dz2));
     T_TRY(bias_grad(t, b2, dz2, (int)M, D, 1, 1));
@@ -846,12 +933,14 @@ int vit_backward_impl(VT* t, const float* dfeat) {
     T_TRY(conv_bwd_data(t, sp.fc1[i], dh, B, S, 1, dxn));
     T_TRY(vit_ln_bwd(t, p + "norm2", dxn, b.x1, b.m2, b.r2, dx, dx, (int)M));                // dx := d(x1) total
     // attention branch: x1 = x + s1 * proj(attn(qkv(norm1(x))))
+    T_TRY(side_guard(t, dz2, M * D * t->es));
     T_RUN(launch_add_scaled(nullptr, dx, b.s1, dz2, M * D, (size_t)S * D, dt, st));
     T_TRY(conv_bwd_weight(t, sp.proj[i], b.ctx, B, S, 1, dz2));
     T_TRY(bias_grad(t, bp, dz2, (int)M, D, 1, 1));
     void* dctx = take_tmp(t, M * heads * hdp); NEED(dctx);
     T_TRY(conv_bwd_data(t, sp.proj[i], dz2, B, S, 1, dctx));
     void* dqkv = take_tmp(t, M * 3 * heads * hdp); NEED(dqkv);
+    T_TRY(side_guard(t, dqkv, M * 3 * heads * hdp * t->es));
     T_RUN(launch_attention_bwd(b.qkv, dctx, dqkv, B, S, heads, t->hd, hdp, scale, dt, st));
     T_TRY(conv_bwd_weight(t, sp.qkv[i], b.xn1, B, S, 1, dqkv));
     T_TRY(bias_grad(t, bq, dqkv, (int)M, 3 * heads * t->hd, t->hd, hdp));
@@ -872,6 +961,7 @@ int vit_backward_impl(VT* t, const float* dfeat) {
       if (e != hipSuccess) return fsvit_set_error((int)e, "pos / cls gradient");
     }
     void* dzpe = take_tmp(t, Mp * D); NEED(dzpe);
+    T_TRY(side_sync(t));
     T_RUN(launch_vit_patch_rows(dx, dzpe, B, S, D, dt, st));
     T_TRY(conv_bwd_weight(t, sp.pe, t->patches, (int)Mp, 1, 1, dzpe));
     T_TRY(bias_grad(t, peb, dzpe, (int)Mp, D, 1, 1));
@@ -909,6 +999,7 @@ int vit_size_workspace(VT* t, int n_img, float rate, size_t* save_bytes, size_t*
 
 }  // namespace
 
+static bool side_stream_default(bool dflt);
 extern "C" int fsvit_vit_trainer_create(const fsvit_vit_cfg* cfg, int dtype, fsvit_vit_trainer** out) {
   if (!cfg || !out) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
   if (dtype != FSVIT_F32 && dtype != FSVIT_BF16) return fsvit_set_error(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
@@ -919,6 +1010,7 @@ extern "C" int fsvit_vit_trainer_create(const fsvit_vit_cfg* cfg, int dtype, fsv
   t->D = cfg->embed_dim; t->npw = cfg->img_size / cfg->patch_size; t->np = t->npw * t->npw; t->S = t->np + 1;
   t->K = 3 * cfg->patch_size * cfg->patch_size; t->Kp = round_up(t->K, 128 / t->es);
   t->hidv = (int)(cfg->embed_dim * cfg->mlp_ratio); t->heads = cfg->num_heads; t->hd = cfg->embed_dim / cfg->num_heads; t->hdp = round_up(t->hd, kch);
+  t->side_on = side_stream_default(true);
   *out = t;
   return 0;
 }
@@ -971,6 +1063,7 @@ extern "C" int fsvit_vit_train_backward(fsvit_vit_trainer* t, const fsvit_param*
   t->tmp.off = 0;
   t->save.off = t->save_after_forward;            // the pass's weight-gradient slabs are appended to the saved activations
   t->fin.clear();
+  t->side_seq = 0; t->pend.clear();
   return vit_backward_impl(t, dfeat_dev);
 }
 
@@ -987,10 +1080,15 @@ extern "C" int fsvit_visformer_trainer_create(const fsvit_visformer_cfg* cfg, in
   t->hd2 = t->C2 / cfg->num_heads; t->hd3 = t->C3 / cfg->num_heads;
   t->hdp2 = round_up(t->hd2, kch); t->hdp3 = round_up(t->hd3, kch);
   t->Cg = t->hid1 / cfg->group;
+  t->side_on = side_stream_default(false);
   *out = t;
   return 0;
 }
 
+static bool side_stream_default(bool dflt) {
+  const char* e = getenv("FSVIT_WGRAD_SIDE_STREAM");
+  return e ? e[0] != '0' : dflt;
+}
 extern "C" void fsvit_visformer_trainer_destroy(fsvit_visformer_trainer* t) { delete t; }
 
 static void bind_params(TR* t, const fsvit_param* params, int n) {
@@ -1077,6 +1175,7 @@ extern "C" int fsvit_visformer_train_backward(fsvit_visformer_trainer* t, const 
   t->tmp.off = 0;
   t->save.off = t->save_after_forward;            // the pass's weight-gradient slabs are appended to the saved activations
   t->fin.clear();
+  t->side_seq = 0; t->pend.clear();
   return train_backward_impl(t, dfeat_dev);
 }
 
