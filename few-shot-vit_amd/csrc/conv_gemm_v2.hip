@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
     typedef std::integral_constant<int, 0> M0_t;
     typedef std::integral_constant<int, 1> M1_t;
     typedef std::integral_constant<int, 2> M2_t;
-    if (p.act == ACT_GELU && p.y2 && !LIMBS) finish([](float x) { return x; }, M1_t{});
+    if (p.act == ACT_GELU && p.y2) finish([](float x) { return x; }, M1_t{});
     else if (p.act == ACT_GELU) finish([](float x) { return sizeof(T) == 2 ? gelu_sig(x) : (LIMBS ? gelu_erfc(x) : gelu_erf(x)); }, M0_t{});
     else if (p.act == ACT_LRELU) finish([](float x) { return x > 0.0f ? x : 0.1f * x; }, M0_t{});
     else if (p.act == ACT_MUL) finish([](float x) { return x; }, M2_t{});

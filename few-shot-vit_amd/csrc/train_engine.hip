@@ -74,7 +74,8 @@ struct BnSave { void* z; float *mean, *invstd, *sa, *sb; int M, C; };
 
 struct fsvit_visformer_trainer {
   fsvit_visformer_cfg cfg;
-  int dtype = 0, es = 4;
+  int dtype = 0, es = 4;          // storage type of activations / activation gradients (FSVIT_F32 | FSVIT_BF16) and its element size
+  int gdt = 0;                    // GEMM kernel type (conv_gemm.h): = dtype, or 2 for FSVIT_BF16X2 (fp32 storage, every GEMM as two-limb 16-bit MFMAs on limb-packed weights)
   int C0, C1, C2, C3, H0, H1, H2, H3, hid1, hid2, hid3, hd2, hdp2, hd3, hdp3, Cg;
   // ---- per-call state
   std::map<std::string, const fsvit_param*> P;
@@ -166,7 +167,7 @@ int packed_weight(TR* t, const PackJob& job, size_t bytes, void** out) {
   void* pk = t->tmp.take(bytes);
   if (!pk) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (weights)");
   T_RUN(launch_pack_weight(job.w, pk, job.O, job.Ig, job.KH, job.KW, job.groups, job.mode, job.rows_pad, job.Kw, job.hd_rows, job.hdp_rows, job.hd_cols, job.hdp_cols,
-                           t->dtype, t->st));
+                           t->gdt, t->st));
   *out = pk;
   return 0;
 }
@@ -178,7 +179,7 @@ int run_packs(TR* t) {
   if (!base) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (packed weights)");
   std::vector<PackJob> js = t->jobs;
   for (size_t i = 0; i < js.size(); ++i) js[i].out = base + t->job_off[i];
-  T_RUN(launch_pack_weight_multi(js.data(), (int)js.size(), t->dtype, t->st));
+  T_RUN(launch_pack_weight_multi(js.data(), (int)js.size(), t->gdt, t->st));
   t->pack_base = base;
   return 0;
 }
@@ -201,7 +202,7 @@ int conv_fwd(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, void*
   else p = gemm_params(x, pk, z, B, H, W, K / (c.KH * c.KW), c.groups * (K / (c.KH * c.KW)), c.KH, c.KW, c.stride, c.pad, Ng, c.groups * Ng, K, Kw, c.groups);
   p.bias = bias;
   if (gp) { p.act = ACT_GELU; p.y2 = gp; }
-  T_RUN(launch_conv_gemm(p, t->dtype, t->st));
+  T_RUN(launch_conv_gemm(p, t->gdt, t->st));
   return 0;
 }
 
@@ -226,7 +227,7 @@ int conv_bwd_data(TR* t, const ConvSpec& c, const void* dz, int B, int OH, int O
   }
   ConvGemmParams p = gemm_params(dz, pk, dx, B, OH, OW, Ng_pad, c.groups * Ng_pad, c.KH, c.KW, 1, c.pad, Ig_pad, c.groups * Ig_pad, K, Kw, c.groups);
   if (mul) { p.act = ACT_MUL; p.res = mul; }
-  T_RUN(launch_conv_gemm(p, t->dtype, t->st));
+  T_RUN(launch_conv_gemm(p, t->gdt, t->st));
   return 0;
 }
 
@@ -329,12 +330,12 @@ int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W
   T_TRY(side_guard(t, dzt, (size_t)rows * Mpad * t->es));
   T_TRY(side_guard(t, xct, (size_t)Kc_pad * Mpad * t->es));
   T_RUN(launch_transpose_cols(dz, dzt, M, rows, 0, rows, Mpad, t->dtype, t->st));
-  if (c.via_patches) T_RUN(launch_transpose_cols(x, xct, M, 32, 0, 32, Mpad, t->dtype, t->st));
-  else T_RUN(launch_im2col_t(x, xct, B, H, W, Cin_tot, 0, Cin_tot, c.KH, c.KW, c.stride, c.pad, OH, OW, Mpad, t->dtype, t->st));
+  if (c.via_patches) T_RUN(launch_transpose_cols(x, xct, M, 32, 0, 32, Mpad, t->gdt, t->st));           // (the GEMM's weight-side operand: limb words under bf16x2)
+  else T_RUN(launch_im2col_t(x, xct, B, H, W, Cin_tot, 0, Cin_tot, c.KH, c.KW, c.stride, c.pad, OH, OW, Mpad, t->gdt, t->st));
   // Y[n][s*Kc_pad + k] = sum_{m in split s} dzt[n][m] * xct[k][m]
   ConvGemmParams p = gemm_params(dzt, xct, ysp, 1, rows, 1, Ks, Mpad, 1, 1, 1, 0, Kc_pad, splits * Kc_pad, Ks, Ks, splits);
   p.w_gstride = Ks; p.w_rstride = Mpad; p.out_f32 = 1;
-  T_RUN(launch_conv_gemm(p, t->dtype, t->st));
+  T_RUN(launch_conv_gemm(p, t->gdt, t->st));
   if (!t->save.dry) {
     if (c.groups > 1) t->fin.push_back(FinJob{ysp, w->grad, 2, c.O / c.groups, c.Ig, c.KH, c.KW, c.groups, splits, Kc_pad, 1, 1, 1, 1});
     else {
@@ -677,7 +678,7 @@ int train_backward_impl(TR* t, const float* dfeat) {
       void* G = take_tmp(t, M * 4 * Ci); NEED(G);
       ConvGemmParams p = gemm_params(dz, pk, G, B, Ho, Ho, C, C, 1, 1, 1, 0, 4 * Ci, 4 * Ci, C, Kw, 1);
       T_TRY(side_guard(t, G, M * 4 * Ci * t->es));
-      T_RUN(launch_conv_gemm(p, dt, st));
+      T_RUN(launch_conv_gemm(p, t->gdt, st));
       void* dxi = take_tmp(t, Mi * Ci); NEED(dxi);
       T_TRY(side_guard(t, dxi, Mi * Ci * t->es));
       T_RUN(launch_unpatch2(G, dxi, B, Ho, Ho, Ci, dt, st));
@@ -1002,10 +1003,10 @@ int vit_size_workspace(VT* t, int n_img, float rate, size_t* save_bytes, size_t*
 static bool side_stream_default(bool dflt);
 extern "C" int fsvit_vit_trainer_create(const fsvit_vit_cfg* cfg, int dtype, fsvit_vit_trainer** out) {
   if (!cfg || !out) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
-  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16) return fsvit_set_error(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_BF16X2) return fsvit_set_error(FSVIT_ERR_ARG, "trainer dtype %d (FSVIT_F32 | FSVIT_BF16 | FSVIT_BF16X2)", dtype);
   if (cfg->embed_dim % cfg->num_heads || cfg->img_size % cfg->patch_size || cfg->embed_dim % 8) return fsvit_set_error(FSVIT_ERR_ARG, "bad ViT configuration");
   VT* t = new VT();
-  t->vcfg = *cfg; t->dtype = dtype; t->es = dtype == FSVIT_F32 ? 4 : 2;
+  t->vcfg = *cfg; t->gdt = dtype == FSVIT_BF16X2 ? 2 : dtype; t->dtype = dtype == FSVIT_BF16X2 ? FSVIT_F32 : dtype; t->es = t->dtype == FSVIT_F32 ? 4 : 2;
   const int kch = 64 / t->es;
   t->D = cfg->embed_dim; t->npw = cfg->img_size / cfg->patch_size; t->np = t->npw * t->npw; t->S = t->np + 1;
   t->K = 3 * cfg->patch_size * cfg->patch_size; t->Kp = round_up(t->K, 128 / t->es);
@@ -1070,9 +1071,9 @@ extern "C" int fsvit_vit_train_backward(fsvit_vit_trainer* t, const fsvit_param*
 // ================================================================ C ABI
 extern "C" int fsvit_visformer_trainer_create(const fsvit_visformer_cfg* cfg, int dtype, fsvit_visformer_trainer** out) {
   if (!cfg || !out) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
-  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16) return fsvit_set_error(FSVIT_ERR_ARG, "unknown dtype %d", dtype);
+  if (dtype != FSVIT_F32 && dtype != FSVIT_BF16 && dtype != FSVIT_BF16X2) return fsvit_set_error(FSVIT_ERR_ARG, "trainer dtype %d (FSVIT_F32 | FSVIT_BF16 | FSVIT_BF16X2)", dtype);
   TR* t = new TR();
-  t->cfg = *cfg; t->dtype = dtype; t->es = dtype == FSVIT_F32 ? 4 : 2;
+  t->cfg = *cfg; t->gdt = dtype == FSVIT_BF16X2 ? 2 : dtype; t->dtype = dtype == FSVIT_BF16X2 ? FSVIT_F32 : dtype; t->es = t->dtype == FSVIT_F32 ? 4 : 2;
   const int D = cfg->embed_dim, kch = 64 / t->es;
   t->C0 = cfg->init_channels; t->C1 = D / 2; t->C2 = D; t->C3 = D * 2;
   t->H0 = cfg->img_size / 2; t->H1 = cfg->img_size / 4; t->H2 = cfg->img_size / 8; t->H3 = cfg->img_size / 16;

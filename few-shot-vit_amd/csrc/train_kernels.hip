@@ -12,6 +12,20 @@ static inline unsigned gs_grid(size_t total, int per_block = 256) {
   size_t nb = (total + per_block - 1) / per_block;
   return (unsigned)(nb > 32768 ? 32768 : (nb < 1 ? 1 : nb));
 }
+// a two-limb weight word of the `bf16x2` GEMMs (conv_gemm_v2.hip x2_split / engine.py ops.x2_limbs): upper half hi = the value rounded to bf16,
+// lower half lo = (value - hi) rounded to bf16.  As an output type of the pack / transpose kernels below (training in the two-limb mode packs
+// its weights - and the activation operand of the split-K weight-gradient GEMM - on the device every step).
+struct limbw { unsigned w; };
+template <> __device__ __forceinline__ limbw from_f32<limbw>(float v) {
+  const bf16 h = (bf16)v;
+  const bf16 l = (bf16)(v - (float)h);
+  return limbw{((unsigned)__builtin_bit_cast(unsigned short, h) << 16) | (unsigned)__builtin_bit_cast(unsigned short, l)};
+}
+template <> __device__ __forceinline__ void store4<limbw>(limbw* p, f32x4 v) {
+  const u32x4 o = {from_f32<limbw>(v[0]).w, from_f32<limbw>(v[1]).w, from_f32<limbw>(v[2]).w, from_f32<limbw>(v[3]).w};
+  *reinterpret_cast<u32x4*>(p) = o;
+}
+
 #define GS_LOOP(idx, total) for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (total); idx += (size_t)gridDim.x * blockDim.x)
 
 // ------------------------------------------------------------------------------------------------ weights
@@ -258,8 +272,8 @@ __global__ __launch_bounds__(256) void droppath_scales_kernel(const float* __res
 
 // ------------------------------------------------------------------------------------------------ transposes for wgrad
 // in [M][ld] (columns c0 .. c0+ncols) -> out [ncols][Mpad], zero for m >= M.  32x32 LDS tile transpose.
-template <typename T>
-__global__ __launch_bounds__(256) void transpose_cols_kernel(const T* __restrict__ in, T* __restrict__ out, int M, int ld, int c0, int ncols, int Mpad) {
+template <typename T, typename TO = T>
+__global__ __launch_bounds__(256) void transpose_cols_kernel(const T* __restrict__ in, TO* __restrict__ out, int M, int ld, int c0, int ncols, int Mpad) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
   const int mt = blockIdx.x * 32, ct = blockIdx.y * 32;
@@ -272,13 +286,13 @@ __global__ __launch_bounds__(256) void transpose_cols_kernel(const T* __restrict
 #pragma unroll
   for (int r = 0; r < 32; r += 8) {
     const int c = ct + ty + r, m = mt + tx;
-    if (c < ncols && m < Mpad) out[(size_t)c * Mpad + m] = from_f32<T>(tile[tx][ty + r]);
+    if (c < ncols && m < Mpad) out[(size_t)c * Mpad + m] = from_f32<TO>(tile[tx][ty + r]);
   }
 }
 
 // x NHWC [B,H,W,ld] (channels c0 .. c0+C) -> out [(ky*KW+kx)*C + c][Mpad], m = (b, oy, ox); zero outside the image / m >= M
-template <typename T>
-__global__ __launch_bounds__(256) void im2col_t_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int ld, int c0, int C,
+template <typename T, typename TO = T>
+__global__ __launch_bounds__(256) void im2col_t_kernel(const T* __restrict__ x, TO* __restrict__ out, int B, int H, int W, int ld, int c0, int C,
                                                        int KH, int KW, int stride, int pad, int OH, int OW, int Mpad) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -300,14 +314,14 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(const T* __restrict__ x, 
 #pragma unroll
   for (int r = 0; r < 32; r += 8) {
     const int c = ct + ty + r, m = mt + tx;
-    if (c < C && m < Mpad) out[(size_t)(tap * C + c) * Mpad + m] = from_f32<T>(tile[tx][ty + r]);
+    if (c < C && m < Mpad) out[(size_t)(tap * C + c) * Mpad + m] = from_f32<TO>(tile[tx][ty + r]);
   }
 }
 
 // Vectorised 64 x 64 tile transposes (8/16-byte accesses on both sides): require ld, c0, ncols, Mpad % 4 == 0.
 // `row_src(m)` gives the source row of output column m (or -1 for zero fill).
-template <typename T, typename RowFn>
-__device__ __forceinline__ void transpose_tile64(const T* __restrict__ in, T* __restrict__ out, int ld, int c0, int ncols, int Mpad, size_t out_row0,
+template <typename T, typename TO, typename RowFn>
+__device__ __forceinline__ void transpose_tile64(const T* __restrict__ in, TO* __restrict__ out, int ld, int c0, int ncols, int Mpad, size_t out_row0,
                                                  int mt, int ct, RowFn row_src) {
   __shared__ float tile[64][65];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // 16 channel quads x 16 rows
@@ -328,22 +342,22 @@ __device__ __forceinline__ void transpose_tile64(const T* __restrict__ in, T* __
     const int c = ct + ty + r, m = mt + tx * 4;
     if (c < ncols && m < Mpad) {
       const f32x4 v = {tile[ty + r][tx * 4], tile[ty + r][tx * 4 + 1], tile[ty + r][tx * 4 + 2], tile[ty + r][tx * 4 + 3]};
-      store4<T>(out + (out_row0 + c) * (size_t)Mpad + m, v);
+      store4<TO>(out + (out_row0 + c) * (size_t)Mpad + m, v);
     }
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void transpose_cols_v4_kernel(const T* __restrict__ in, T* __restrict__ out, int M, int ld, int c0, int ncols, int Mpad) {
-  transpose_tile64<T>(in, out, ld, c0, ncols, Mpad, 0, blockIdx.x * 64, blockIdx.y * 64, [&](int m) -> long { return m < M ? m : -1; });
+template <typename T, typename TO = T>
+__global__ __launch_bounds__(256) void transpose_cols_v4_kernel(const T* __restrict__ in, TO* __restrict__ out, int M, int ld, int c0, int ncols, int Mpad) {
+  transpose_tile64<T, TO>(in, out, ld, c0, ncols, Mpad, 0, blockIdx.x * 64, blockIdx.y * 64, [&](int m) -> long { return m < M ? m : -1; });
 }
 
 // x NHWC [B,H,W,ld] (channels c0 .. c0+C) -> out [(ky*KW+kx)*C + c][Mpad], m = (b, oy, ox); zero outside the image / m >= M
-template <typename T>
-__global__ __launch_bounds__(256) void im2col_t_v4_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int ld, int c0, int C,
+template <typename T, typename TO = T>
+__global__ __launch_bounds__(256) void im2col_t_v4_kernel(const T* __restrict__ x, TO* __restrict__ out, int B, int H, int W, int ld, int c0, int C,
                                                           int KH, int KW, int stride, int pad, int OH, int OW, int Mpad) {
   const int tap = blockIdx.z, ky = tap / KW, kx = tap % KW, M = B * OH * OW;
-  transpose_tile64<T>(x, out, ld, c0, C, Mpad, (size_t)tap * C, blockIdx.x * 64, blockIdx.y * 64, [&](int m) -> long {
+  transpose_tile64<T, TO>(x, out, ld, c0, C, Mpad, (size_t)tap * C, blockIdx.x * 64, blockIdx.y * 64, [&](int m) -> long {
     if (m >= M) return -1;
     const int b = m / (OH * OW), rem = m % (OH * OW), oy = rem / OW, ox = rem % OW;
     const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
@@ -1019,6 +1033,10 @@ __global__ __launch_bounds__(64) void vit_cls_ln_bwd_kernel(const float* __restr
 int launch_pack_weight(const float* w, void* out, int O, int Ig, int KH, int KW, int groups, int mode, int rows_pad, int Kw, int hd_rows, int hdp_rows,
                        int hd_cols, int hdp_cols, int dtype, hipStream_t s) {
   const size_t total = (size_t)groups * rows_pad * Kw;
+  if (dtype == 2) {      // two-limb words (fp32 storage, 16-bit MFMA arithmetic)
+    hipLaunchKernelGGL(pack_weight_kernel<limbw>, dim3(gs_grid(total)), dim3(256), 0, s, w, (limbw*)out, O, Ig, KH, KW, groups, mode, rows_pad, Kw, hd_rows, hdp_rows, hd_cols, hdp_cols);
+    return (int)hipGetLastError();
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, w, (float*)out, O, Ig, KH, KW, groups, mode, rows_pad, Kw, hd_rows, hdp_rows, hd_cols, hdp_cols),
              hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, w, (bf16*)out, O, Ig, KH, KW, groups, mode, rows_pad, Kw, hd_rows, hdp_rows, hd_cols, hdp_cols));
   return (int)hipGetLastError();
@@ -1036,8 +1054,10 @@ int launch_pack_weight_multi(const PackJob* jobs, int n, int dtype, hipStream_t 
     unsigned gx = (unsigned)((biggest + 1023) / 1024);
     if (gx > 128) gx = 128;
     if (gx < 1) gx = 1;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3(gx, (unsigned)m), dim3(256), 0, s, pj),
-               hipLaunchKernelGGL(pack_weight_multi_kernel<bf16>, dim3(gx, (unsigned)m), dim3(256), 0, s, pj));
+    if (dtype == 2) hipLaunchKernelGGL(pack_weight_multi_kernel<limbw>, dim3(gx, (unsigned)m), dim3(256), 0, s, pj);
+    else
+      DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3(gx, (unsigned)m), dim3(256), 0, s, pj),
+                 hipLaunchKernelGGL(pack_weight_multi_kernel<bf16>, dim3(gx, (unsigned)m), dim3(256), 0, s, pj));
     const int rc = (int)hipGetLastError();
     if (rc) return rc;
   }
@@ -1088,7 +1108,16 @@ int launch_wgrad_finalize_dense(const float* y, float* dw, int Ng, int Ig, int K
   hipLaunchKernelGGL(wgrad_finalize_dense_kernel, dim3(gs_grid(total)), dim3(256), 0, s, y, dw, Ng, Ig, KH, KW, groups, splits, Kc_pad);
   return (int)hipGetLastError();
 }
+// dtype 2: fp32 in, two-limb words out (the weight-side operand of a `bf16x2` GEMM)
 int launch_transpose_cols(const void* in, void* out, int M, int ld, int c0, int ncols, int Mpad, int dtype, hipStream_t s) {
+  if (dtype == 2) {
+    if (((ld | c0 | ncols | Mpad) & 3) == 0) {
+      hipLaunchKernelGGL((transpose_cols_v4_kernel<float, limbw>), dim3((Mpad + 63) / 64, (ncols + 63) / 64), dim3(256), 0, s, (const float*)in, (limbw*)out, M, ld, c0, ncols, Mpad);
+    } else {
+      hipLaunchKernelGGL((transpose_cols_kernel<float, limbw>), dim3((Mpad + 31) / 32, (ncols + 31) / 32), dim3(256), 0, s, (const float*)in, (limbw*)out, M, ld, c0, ncols, Mpad);
+    }
+    return (int)hipGetLastError();
+  }
   if (((ld | c0 | ncols | Mpad) & 3) == 0) {
     dim3 g4((Mpad + 63) / 64, (ncols + 63) / 64);
     DISPATCH_T(dtype, hipLaunchKernelGGL(transpose_cols_v4_kernel<float>, g4, dim3(256), 0, s, (const float*)in, (float*)out, M, ld, c0, ncols, Mpad),
@@ -1102,6 +1131,16 @@ int launch_transpose_cols(const void* in, void* out, int M, int ld, int c0, int 
 }
 int launch_im2col_t(const void* x, void* out, int B, int H, int W, int ld, int c0, int C, int KH, int KW, int stride, int pad, int OH, int OW, int Mpad,
                     int dtype, hipStream_t s) {
+  if (dtype == 2) {
+    if (((ld | c0 | C | Mpad) & 3) == 0) {
+      hipLaunchKernelGGL((im2col_t_v4_kernel<float, limbw>), dim3((Mpad + 63) / 64, (C + 63) / 64, KH * KW), dim3(256), 0, s, (const float*)x, (limbw*)out, B, H, W, ld, c0, C, KH, KW,
+                         stride, pad, OH, OW, Mpad);
+    } else {
+      hipLaunchKernelGGL((im2col_t_kernel<float, limbw>), dim3((Mpad + 31) / 32, (C + 31) / 32, KH * KW), dim3(256), 0, s, (const float*)x, (limbw*)out, B, H, W, ld, c0, C, KH, KW, stride,
+                         pad, OH, OW, Mpad);
+    }
+    return (int)hipGetLastError();
+  }
   if (((ld | c0 | C | Mpad) & 3) == 0) {
     dim3 g4((Mpad + 63) / 64, (C + 63) / 64, KH * KW);
     DISPATCH_T(dtype, hipLaunchKernelGGL(im2col_t_v4_kernel<float>, g4, dim3(256), 0, s, (const float*)x, (float*)out, B, H, W, ld, c0, C, KH, KW, stride, pad, OH, OW, Mpad),

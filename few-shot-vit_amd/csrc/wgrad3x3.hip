@@ -469,7 +469,7 @@ __global__ __launch_bounds__(512, 1) void gconv3x3_x2_kernel(const float* __rest
 bool gconv3x3_x2_eligible(const ConvGemmParams& p, int dtype) {
   if (dtype != 2) return false;
   if (p.groups != 8 || p.N != 32 || p.Cin != 32 || p.x_cstride != 256 || p.y_cstride != 256 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad != 1) return false;
-  if (p.W > 20 || p.Kw < 288 || (p.Kw & 3) || p.bias || p.res || p.pos || p.x2 || p.K2 || p.pool2 || p.y_rpi || p.out_f32 || p.w_rstride || p.w_gstride) return false;
+  if (p.W > 20 || p.Kw < 288 || (p.Kw & 3) || p.bias || p.res || p.y2 || p.pos || p.x2 || p.K2 || p.pool2 || p.y_rpi || p.out_f32 || p.w_rstride || p.w_gstride) return false;
   return (p.act == ACT_NONE || p.act == ACT_GELU) && (long)p.B * p.H * p.W < (1L << 31) && p.H * p.W >= 16;
 }
 int launch_gconv3x3_x2(const ConvGemmParams& p, hipStream_t s) {

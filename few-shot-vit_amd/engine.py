@@ -15,7 +15,7 @@ from . import _lib
 DTYPES = {'f32': _lib.F32, 'parity': _lib.F32, 'fp32': _lib.F32, 'bf16': _lib.BF16, 'f16': _lib.F16, 'fp16': _lib.F16,
           'bf16x2': _lib.BF16X2, 'f16x2': _lib.F16X2}
 TORCH_DTYPE = {_lib.F32: torch.float32, _lib.BF16: torch.bfloat16, _lib.F16: torch.float16, _lib.BF16X2: torch.float32, _lib.F16X2: torch.float32}
-EVAL_ONLY = (_lib.F16, _lib.BF16X2, _lib.F16X2)
+EVAL_ONLY = (_lib.F16, _lib.F16X2)        # 'bf16x2' trains too (fp32 storage, every forward / dgrad / wgrad GEMM on two-limb bf16 MFMAs)
 
 
 # Packed eval engines cache BN-folded copies of the weights.  The HIP optimizers and the HIP trainer write parameters and running
@@ -45,7 +45,7 @@ def weights_fingerprint(module) -> tuple:
 def default_numerics() -> str:
     """'bf16' (throughput mode) unless FSVIT_NUMERICS selects another one: 'f16' (fp16 storage + MFMA: same kernels and rate, 8 x smaller
     logit deviation than bf16, eval only), 'bf16x2' / 'f16x2' (fp32 storage, every GEMM on the 16-bit MFMA with two-limb operands: meets the
-    1e-3 logit tolerance at several times the fp32-MFMA rate, eval only) or 'parity' / 'f32' (exact-fp32 MFMA)."""
+    1e-3 logit tolerance at several times the fp32-MFMA rate; 'bf16x2' also trains, 'f16x2' is eval only) or 'parity' / 'f32' (exact-fp32 MFMA)."""
     return os.environ.get('FSVIT_NUMERICS', 'bf16')
 
 
@@ -218,7 +218,7 @@ class VisformerTrainer:
         if numerics not in DTYPES:
             raise ValueError(f'unknown numerics mode {numerics!r} (bf16 | parity)')
         if DTYPES[numerics] in EVAL_ONLY:
-            raise NotImplementedError(f"fsvit: the {numerics!r} numerics mode is an eval mode; train in 'bf16' or 'parity'")
+            raise NotImplementedError(f"fsvit: the {numerics!r} numerics mode is an eval mode; train in 'bf16', 'bf16x2' or 'parity'")
         self.dtype = DTYPES[numerics]
         self.device = torch.device(device if device is not None else 'cuda')
         if self.device.type != 'cuda':
@@ -331,7 +331,7 @@ class VitTrainer:
         if numerics not in DTYPES:
             raise ValueError(f'unknown numerics mode {numerics!r} (bf16 | parity)')
         if DTYPES[numerics] in EVAL_ONLY:
-            raise NotImplementedError(f"fsvit: the {numerics!r} numerics mode is an eval mode; train in 'bf16' or 'parity'")
+            raise NotImplementedError(f"fsvit: the {numerics!r} numerics mode is an eval mode; train in 'bf16', 'bf16x2' or 'parity'")
         self.dtype = DTYPES[numerics]
         self.device = torch.device(device if device is not None else 'cuda')
         if self.device.type != 'cuda':

@@ -14,8 +14,9 @@
  *   - `dtype` selects storage + MFMA arithmetic of activations/weights: FSVIT_F32 = exact fp32
  *     MFMA (v_mfma_f32_16x16x4_f32, the parity mode), FSVIT_BF16 = bf16 MFMA with fp32 accumulate, FSVIT_F16 = fp16 MFMA with
  *     fp32 accumulate (eval engines only: same kernels, same rate, 3 more mantissa bits than bf16; |activations| must stay
- *     below 65504, which BatchNorm / LayerNorm networks do with a wide margin).  FSVIT_BF16X2 / FSVIT_F16X2 (eval engines and
- *     fsvit_conv_gemm): fp32 storage as FSVIT_F32, but every GEMM runs on the 16-bit MFMA with both operands split into two 16-bit
+ *     below 65504, which BatchNorm / LayerNorm networks do with a wide margin).  FSVIT_BF16X2 / FSVIT_F16X2 (eval engines,
+ *     fsvit_conv_gemm and - FSVIT_BF16X2 only - the two trainers, which pack the limb words of the weights and of the weight-gradient
+ *     GEMM's activation operand on the device every step): fp32 storage as FSVIT_F32, but every GEMM runs on the 16-bit MFMA with both operands split into two 16-bit
  *     limbs (hi + lo; two MFMAs per K chunk = all four limb products, fp32 accumulate): 16 (bf16 limbs) / 22 (fp16 limbs) significand
  *     bits per operand at 1/4 of the 16-bit MFMA rate = 4 x the fp32-MFMA rate.  Weights given to fsvit_conv_gemm in these modes are
  *     4-byte limb pairs (upper half hi, lower half lo).
