@@ -20,10 +20,12 @@ template <int CLS> __device__ __forceinline__ void valu(f32x2& v, float c) {
   if (CLS == 4) { unsigned o; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o) : "v"(v[0]), "v"(v[1])); v[0] = __builtin_bit_cast(float, o); }
 }
 
-template <int CLS, int A, int B, int STAGGER>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int CLS, int A, int B, int STAGGER, int M32 = 0>
 __global__ __launch_bounds__(1024, 1) void probe(float* out, long long* clk, int iters, float c) {
   f32x4 acc[A > 0 ? A : 1];
-  for (int i = 0; i < (A > 0 ? A : 1); ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x16 acc32[A > 0 ? A : 1];
+  for (int i = 0; i < (A > 0 ? A : 1); ++i) { acc[i] = f32x4{0.f, 0.f, 0.f, 0.f}; for (int e = 0; e < 16; ++e) acc32[i][e] = 0.f; }
   u32x4 a = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, b = a;
   f32x2 v[8];
   for (int i = 0; i < 8; ++i) v[i] = f32x2{c * (threadIdx.x + i), c};
@@ -37,26 +39,29 @@ __global__ __launch_bounds__(1024, 1) void probe(float* out, long long* clk, int
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < A; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+    for (int i = 0; i < A; ++i) {
+      if (M32) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc32[i]) : "v"(a), "v"(b));
+      else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+    }
 #pragma unroll
     for (int k = 0; k < B; ++k) valu<CLS>(v[k & 7], c);
   }
   const long long t1 = __builtin_readcyclecounter();
   float s = 0.f;
-  for (int i = 0; i < (A > 0 ? A : 1); ++i) s += acc[i][0] + acc[i][3];
+  for (int i = 0; i < (A > 0 ? A : 1); ++i) s += acc[i][0] + acc[i][3] + acc32[i][0] + acc32[i][15];
   for (int i = 0; i < 8; ++i) s += v[i][0] + v[i][1];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (threadIdx.x == 0 && blockIdx.x == 0) clk[0] = t1 - t0;
 }
 
-template <int CLS, int A, int B, int STAGGER> void run(const char* name, int W, float* out, long long* clk) {
+template <int CLS, int A, int B, int STAGGER, int M32 = 0> void run(const char* name, int W, float* out, long long* clk) {
   const int iters = 2000;
-  probe<CLS, A, B, STAGGER><<<256, 256 * W>>>(out, clk, iters, 1.0001f);
+  probe<CLS, A, B, STAGGER, M32><<<256, 256 * W>>>(out, clk, iters, 1.0001f);
   hipDeviceSynchronize();
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  probe<CLS, A, B, STAGGER><<<256, 256 * W>>>(out, clk, iters, 1.0001f);
+  probe<CLS, A, B, STAGGER, M32><<<256, 256 * W>>>(out, clk, iters, 1.0001f);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -72,6 +77,12 @@ int main() {
   run<CLS, 0, 32, 0>(NAME " valu only", 1, out, clk); run<CLS, 0, 32, 0>(NAME " valu only", 2, out, clk);    \
   run<CLS, 8, 32, 0>(NAME, 1, out, clk); run<CLS, 8, 32, 0>(NAME, 2, out, clk); run<CLS, 8, 32, 1>(NAME, 2, out, clk); \
   run<CLS, 8, 32, 0>(NAME, 4, out, clk); run<CLS, 8, 32, 1>(NAME, 4, out, clk);
+  // 32x32x16 MFMAs (32 cycles each): 4 per iteration = the same 128 matrix cycles
+  run<3, 4, 0, 0, 1>("max m32 mfma only", 1, out, clk); run<3, 4, 0, 0, 1>("max m32 mfma only", 2, out, clk);
+  run<3, 4, 32, 0, 1>("max m32", 1, out, clk); run<3, 4, 32, 0, 1>("max m32", 2, out, clk); run<3, 4, 32, 0, 1>("max m32", 4, out, clk);
+  run<3, 4, 64, 0, 1>("max m32 B64", 1, out, clk); run<3, 4, 64, 0, 1>("max m32 B64", 2, out, clk);
+  run<3, 8, 64, 0, 0>("max m16 B64", 1, out, clk); run<3, 8, 64, 0, 0>("max m16 B64", 2, out, clk);
+  run<2, 4, 32, 0, 1>("exp m32", 2, out, clk); run<1, 4, 32, 0, 1>("pk_fma m32", 2, out, clk);
   SET(0, "fma")
   SET(1, "pk_fma")
   SET(2, "exp")
