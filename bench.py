@@ -424,7 +424,7 @@ def train_leg(model_name, numerics, E, steps, warmup, rank, world, dev):
         loss = step()
     _barrier(world)
     elapsed = _max_over_ranks(time.perf_counter() - t0, world, dev)
-    return world * E * steps / elapsed, 1e3 * elapsed / steps, float(loss), sd
+    return world * E * steps / elapsed, 1e3 * elapsed / steps, float(loss.detach()), sd
 
 
 def train_workload(model_name):
