@@ -173,6 +173,12 @@ def test_vit_train_step_197_tokens_parity():
     _vit_train_check(dict(img_size=84, patch_size=6, embed_dim=224, depth=3, num_heads=4), 4, 'parity', 0.2, 2e-5, 2e-5)
 
 
+def test_vit_train_step_deit_tokens_two_limb():
+    """The DeiT-S layer shape (197 tokens, 6 heads of 64, patch 16) in the two-limb training mode: limb-packed Linears forward / backward, the split-K
+    weight gradients on limb-transposed activations, the tiled fp32 attention backward; 2 blocks keep the fp32 oracle quick."""
+    _vit_train_check(dict(img_size=224, patch_size=16, embed_dim=384, depth=2, num_heads=6), 4, 'bf16x2', 0.1, 2e-4, 2e-4)
+
+
 def test_vit_train_step_deit_tokens_bf16():
     """A DeiT-shaped layer stack (197 tokens, head dim 64, patch 16) in the bf16 training mode: the MFMA attention backward with 224 resident keys
     and the direct weight-gradient kernels; 2 blocks keep the fp32 oracle quick."""
