@@ -154,179 +154,168 @@ __global__ __launch_bounds__(256) void attention_bwd_tiled_f32_kernel(const floa
 
 // ---------------------------------------------------------------------------------------------------------------
 // fp32 MFMA version (round 3; the `parity` and `bf16x2` trainers, Visformer shapes): exact fp32 products on v_mfma_f32_16x16x4_f32 instead of the FMA
-// loops above (7.9 of the 66 ms of a two-limb training step).  One workgroup of 4 waves per (image, head); Q, K, V, dO resident in LDS as
-// [KT * 16 rows][DT * 16 + 1] fp32 (rows >= S and columns >= hd zero).  A 16x16x4 MFMA takes ONE float per lane and operand - A[i = lane & 15][k = lane >> 4],
-// B[k = lane >> 4][j = lane & 15] - so either orientation of a row-major LDS array is a plain ds_read_b32 (no transposed copies), and the result
-// D[4 (lane >> 4) + r][lane & 15] puts 4 consecutive A-rows of one B-row in a lane.
-// Wave w owns the query blocks w, w + 4, ... of 16 queries.  Per block: S^T and dP^T tiles over all keys (A = K / V rows, B = Q / dO rows: a lane
-// holds 4 keys of ITS query), the softmax statistics inside the 4 lanes of a query (two shuffles), P -> wave-private LDS [query][key],
-// dV^T += dO^T P (A = dO used transposed, B = P), dS over P, dK^T += Q^T dS, dQ^T = K^T dS^T (A = K used transposed, B = dS rows) -> global.
-// dK / dV accumulate in registers over the wave's blocks; the four waves' partial sums meet in LDS in FIXED order (bit-reproducible).
+// loops above (7.9 of the 66 ms of a two-limb training step).  One workgroup per (image, head), one wave per block of 16 tokens; Q, K, V, dO resident
+// in LDS as [KT * 16 rows][DT * 16 + 1] fp32 (rows >= S and columns >= hd zero) plus ONE [query][key] matrix that holds P, then dS.
+// A 16x16x4 MFMA takes one float per lane and operand - A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15] - so either orientation of a
+// row-major LDS array is a plain ds_read_b32 (no transposed copies), and the result D[4 (lane >> 4) + r][lane & 15] puts 4 consecutive A-rows of one
+// B-row in a lane.  Four phases, three barriers, no cross-wave reduction (every output element has ONE owner: bit-reproducible):
+//   A  wave = query block: S^T and dP^T over all keys (A = K / V rows, B = Q / dO rows: a lane holds 4 keys of ITS query), softmax statistics inside the
+//      4 lanes of a query (two shuffles), P -> LDS;            B  wave = key block: dV^T = dO^T P over all queries -> global;
+//   C  wave = query block: dS = scale P (dP - sum_j P dP) from the registers of phase A -> LDS over P;
+//   D  wave = key block: dK^T = Q^T dS -> global; wave = query block: dQ^T = K^T dS^T -> global.
 template <int KT, int DT>
-__global__ __launch_bounds__(256) void attention_bwd_f32mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx, float* __restrict__ dqkv,
-                                                                    int S, int heads, int hd, int hdp, float scale) {
-  constexpr int SP = KT * 16, HD = DT * 16, LD = HD + 1, PP = SP + 4;
+__global__ __launch_bounds__(KT * 64) void attention_bwd_f32mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx, float* __restrict__ dqkv,
+                                                                        int S, int heads, int hd, int hdp, float scale) {
+  constexpr int SP = KT * 16, HD = DT * 16, LD = HD + 1, PP = SP + 4, NT = KT * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* Q = reinterpret_cast<float*>(smem);
   float* K = Q + SP * LD;
   float* V = K + SP * LD;
   float* dO = V + SP * LD;
-  float* PSall = dO + SP * LD;                          // [4 waves][16][PP]
+  float* PS = dO + SP * LD;                             // [SP queries][PP]: P, then dS
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lrow = lane & 15, lq = lane >> 4;
-  float* PS = PSall + wave * 16 * PP;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
   const int rowlen = 3 * heads * hdp;
   const float* base = qkv + (size_t)b * S * rowlen + h * hdp;
   const float* dob = dctx + (size_t)b * S * heads * hdp + h * hdp;
   float* dq = dqkv + (size_t)b * S * rowlen + h * hdp;
-  for (int idx = t; idx < SP * HD; idx += 256) {
-    const int i = idx / HD, d = idx - i * HD;
-    const bool ok = i < S && d < hd;
-    const float* r = base + (size_t)(ok ? i : 0) * rowlen + (ok ? d : 0);
-    Q[i * LD + d] = ok ? r[0] : 0.f;
-    K[i * LD + d] = ok ? r[heads * hdp] : 0.f;
-    V[i * LD + d] = ok ? r[2 * heads * hdp] : 0.f;
-    dO[i * LD + d] = ok ? dob[(size_t)i * heads * hdp + d] : 0.f;
+  for (int idx = t; idx < SP * (HD / 4); idx += NT) {            // 16-byte global loads (hdp % 4 == 0: the launcher checks)
+    const int i = idx / (HD / 4), d = (idx - i * (HD / 4)) * 4;
+    f32x4 vq = {0.f, 0.f, 0.f, 0.f}, vk = vq, vv = vq, vo = vq;
+    if (i < S && d < hdp) {
+      const float* r = base + (size_t)i * rowlen + d;
+      vq = *reinterpret_cast<const f32x4*>(r);
+      vk = *reinterpret_cast<const f32x4*>(r + heads * hdp);
+      vv = *reinterpret_cast<const f32x4*>(r + 2 * heads * hdp);
+      vo = *reinterpret_cast<const f32x4*>(dob + (size_t)i * heads * hdp + d);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool ok = d + e < hd;
+      Q[i * LD + d + e] = ok ? vq[e] : 0.f;
+      K[i * LD + d + e] = ok ? vk[e] : 0.f;
+      V[i * LD + d + e] = ok ? vv[e] : 0.f;
+      dO[i * LD + d + e] = ok ? vo[e] : 0.f;
+    }
   }
   __syncthreads();
-  f32x4 accV[KT][DT], accK[KT][DT];
+  const int qb = wave, kb = wave;                       // this wave's query block and key block
+  const float* Qb = Q + (qb * 16) * LD;
+  const float* Ob = dO + (qb * 16) * LD;
+  // ---- A: S^T / dP^T (lane = query qb*16 + lrow, keys kt*16 + 4 lq + r); k outermost: 2 KT independent accumulators per step
+  f32x4 sc[KT], dp[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) sc[kt] = dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k0 = 0; k0 < HD; k0 += 4) {
+    const float bq = Qb[lrow * LD + k0 + lq], bo = Ob[lrow * LD + k0 + lq];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(K[(kt * 16 + lrow) * LD + k0 + lq], bq, sc[kt], 0, 0, 0);
+      dp[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[(kt * 16 + lrow) * LD + k0 + lq], bo, dp[kt], 0, 0, 0);
+    }
+  }
+  float m = -INFINITY;
 #pragma unroll
   for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) accV[kt][dt] = accK[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  for (int qb = wave; qb < KT; qb += 4) {
-    const float* Qb = Q + (qb * 16) * LD;
-    const float* Ob = dO + (qb * 16) * LD;
-    // ---- S^T / dP^T: lane = query qb*16 + lrow, keys kt*16 + 4 lq + r
-    f32x4 sc[KT], dp[KT];
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int k0 = 0; k0 < HD; k0 += 4) {
-        const float bq = Qb[lrow * LD + k0 + lq], bo = Ob[lrow * LD + k0 + lq];
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(K[(kt * 16 + lrow) * LD + k0 + lq], bq, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(V[(kt * 16 + lrow) * LD + k0 + lq], bo, a1, 0, 0, 0);
-      }
-      sc[kt] = a0; dp[kt] = a1;
+    for (int r = 0; r < 4; ++r) {
+      const float v = kt * 16 + 4 * lq + r < S ? sc[kt][r] * scale : -INFINITY;
+      sc[kt][r] = v;
+      m = fmaxf(m, v);
     }
-    // ---- softmax over the keys of this lane's query (4 lanes lq = 0..3 share it), P and the row term sum_j P dP
-    float m = -INFINITY;
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+  for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = kt * 16 + 4 * lq + r < S ? sc[kt][r] * scale : -INFINITY;
-        sc[kt][r] = v;
-        m = fmaxf(m, v);
-      }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
+    for (int r = 0; r < 4; ++r) { const float e = expf(sc[kt][r] - m); sc[kt][r] = e; sum += e; }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  float dot = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+  for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const float e = expf(sc[kt][r] - m); sc[kt][r] = e; sum += e; }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    float dot = 0.f;
+    for (int r = 0; r < 4; ++r) { const float pr = sc[kt][r] * inv; sc[kt][r] = pr; dot += pr * dp[kt][r]; }
+  dot += __shfl_xor(dot, 16, 64);
+  dot += __shfl_xor(dot, 32, 64);
+  float* PSq = PS + (qb * 16 + lrow) * PP;
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
+  for (int kt = 0; kt < KT; ++kt) *reinterpret_cast<f32x4*>(PSq + kt * 16 + 4 * lq) = sc[kt];
+  __syncthreads();
+  // ---- B: dV^T[d][key] = sum_q dO[q][d] P[q][key] for this wave's key block -> global (lane: key kb*16 + lrow, d = dt*16 + 4 lq + r)
+  auto key_block_product = [&](const float* X, int which) {      // X = dO (-> dV, which = 2) or Q (-> dK, which = 1)
+    f32x4 acc[DT];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const float pr = sc[kt][r] * inv; sc[kt][r] = pr; dot += pr * dp[kt][r]; }
-    dot += __shfl_xor(dot, 16, 64);
-    dot += __shfl_xor(dot, 32, 64);
-    // ---- P -> LDS [query][key]; dV^T[d][key] += sum_q dO[q][d] P[q][key]
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) *reinterpret_cast<f32x4*>(PS + lrow * PP + kt * 16 + 4 * lq) = sc[kt];
-#pragma unroll
-    for (int k0 = 0; k0 < 16; k0 += 4) {
-      float av[DT];
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) av[dt] = Ob[(k0 + lq) * LD + dt * 16 + lrow];
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        const float bp = PS[(k0 + lq) * PP + kt * 16 + lrow];
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) accV[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[dt], bp, accV[kt][dt], 0, 0, 0);
-      }
-    }
-    // ---- dS = scale P (dP - dot) over P in LDS; dK^T[d][key] += sum_q Q[q][d] dS[q][key]
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      f32x4 ds;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ds[r] = scale * sc[kt][r] * (dp[kt][r] - dot);
-      *reinterpret_cast<f32x4*>(PS + lrow * PP + kt * 16 + 4 * lq) = ds;
-    }
-#pragma unroll
-    for (int k0 = 0; k0 < 16; k0 += 4) {
-      float aq[DT];
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) aq[dt] = Qb[(k0 + lq) * LD + dt * 16 + lrow];
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt) {
-        const float bs = PS[(k0 + lq) * PP + kt * 16 + lrow];
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) accK[kt][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[dt], bs, accK[kt][dt], 0, 0, 0);
-      }
-    }
-    // ---- dQ^T[d][q] = sum_key K[key][d] dS[q][key]  -> global (lane: query lrow, d = dt*16 + 4 lq + r)
-    f32x4 accQ[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) accQ[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int k0 = 0; k0 < SP; k0 += 4) {
-      const float bs = PS[lrow * PP + k0 + lq];
+      const float bp = PS[(k0 + lq) * PP + kb * 16 + lrow];
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) accQ[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(K[(k0 + lq) * LD + dt * 16 + lrow], bs, accQ[dt], 0, 0, 0);
+      for (int dt = 0; dt < DT; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(X[(k0 + lq) * LD + dt * 16 + lrow], bp, acc[dt], 0, 0, 0);
+    }
+    const int key = kb * 16 + lrow;
+    if (key < S) {
+      float* r0 = dq + (size_t)key * rowlen + which * heads * hdp;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = dt * 16 + 4 * lq;
+        if (d + 3 < hdp) *reinterpret_cast<f32x4*>(r0 + d) = acc[dt];         // (columns hd .. hdp: the operand is zero there -> exact zeros)
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (d + r < hdp) r0[d + r] = acc[dt][r];
+      }
+    }
+  };
+  key_block_product(dO, 2);
+  __syncthreads();
+  // ---- C: dS over P
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    f32x4 ds;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ds[r] = scale * sc[kt][r] * (dp[kt][r] - dot);
+    *reinterpret_cast<f32x4*>(PSq + kt * 16 + 4 * lq) = ds;
+  }
+  __syncthreads();
+  // ---- D: dK^T for the key block; dQ^T[d][q] = sum_key K[key][d] dS[q][key] for the query block (lane: query lrow, d = dt*16 + 4 lq + r)
+  key_block_product(Q, 1);
+  {
+    f32x4 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k0 = 0; k0 < SP; k0 += 4) {
+      const float bs = PSq[k0 + lq];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(K[(k0 + lq) * LD + dt * 16 + lrow], bs, acc[dt], 0, 0, 0);
     }
     const int qrow = qb * 16 + lrow;
     if (qrow < S) {
+      float* r0 = dq + (size_t)qrow * rowlen;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = dt * 16 + 4 * lq;
+        if (d + 3 < hdp) *reinterpret_cast<f32x4*>(r0 + d) = acc[dt];
+        else
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int d = dt * 16 + 4 * lq + r;
-          if (d < hdp) dq[(size_t)qrow * rowlen + d] = accQ[dt][r];          // (columns hd .. hdp: K is zero there -> exact zeros)
-        }
+          for (int r = 0; r < 4; ++r) if (d + r < hdp) r0[d + r] = acc[dt][r];
+      }
     }
-  }
-  // ---- dK / dV: the four waves' partial sums, added in wave order through LDS (RK over Q, RV over dO: [key][d])
-  __syncthreads();
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int o = (kt * 16 + lrow) * LD + dt * 16 + 4 * lq + r;
-            if (w == 0) { Q[o] = accK[kt][dt][r]; dO[o] = accV[kt][dt][r]; }
-            else { Q[o] += accK[kt][dt][r]; dO[o] += accV[kt][dt][r]; }
-          }
-    }
-    __syncthreads();
-  }
-  for (int idx = t; idx < S * hdp; idx += 256) {
-    const int i = idx / hdp, d = idx - i * hdp;
-    float* r = dq + (size_t)i * rowlen + d;
-    r[heads * hdp] = d < hd ? Q[i * LD + d] : 0.f;
-    r[2 * heads * hdp] = d < hd ? dO[i * LD + d] : 0.f;
   }
 }
 
 template <int KT, int DT>
 static int launch_bwd_f32mfma(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, int hd, int hdp, float scale, hipStream_t s) {
   constexpr int SP = KT * 16, LD = DT * 16 + 1, PP = SP + 4;
-  const size_t lds = ((size_t)4 * SP * LD + (size_t)4 * 16 * PP) * sizeof(float);
+  const size_t lds = ((size_t)4 * SP * LD + (size_t)SP * PP) * sizeof(float);
+  if ((hdp & 3) || hdp > DT * 16) return (int)hipErrorInvalidValue;
   auto kern = attention_bwd_f32mfma_kernel<KT, DT>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(kern, dim3(B * heads), dim3(256), lds, s, (const float*)qkv, (const float*)dctx, (float*)dqkv, S, heads, hd, hdp, scale);
+  hipLaunchKernelGGL(kern, dim3(B * heads), dim3(KT * 64), lds, s, (const float*)qkv, (const float*)dctx, (float*)dqkv, S, heads, hd, hdp, scale);
   return (int)hipGetLastError();
 }
 
@@ -564,11 +553,11 @@ int launch_attention_bwd(const void* qkv, const void* dctx, void* dqkv, int B, i
   }
   if (dtype == 0) {                                     // exact-fp32 MFMA kernel where the head fits the LDS (Visformer stages: 100 x 42, 25 x 85)
     static const bool off = [] { const char* e = getenv("FSVIT_ATTN_BWD_F32_MFMA"); return e && e[0] == '0'; }();
-    if (!off) {
-      if (S <= 32 && hd <= 48) return launch_bwd_f32mfma<2, 3>(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, s);
-      if (S <= 32 && hd <= 96) return launch_bwd_f32mfma<2, 6>(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, s);
-      if (S <= 48 && hd <= 64) return launch_bwd_f32mfma<3, 4>(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, s);
-      if (S <= 112 && hd <= 48) return launch_bwd_f32mfma<7, 3>(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, s);
+    if (!off && (hdp & 3) == 0) {
+      if (S <= 32 && hdp <= 48) return launch_bwd_f32mfma<2, 3>(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, s);
+      if (S <= 32 && hdp <= 96) return launch_bwd_f32mfma<2, 6>(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, s);
+      if (S <= 48 && hdp <= 64) return launch_bwd_f32mfma<3, 4>(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, s);
+      if (S <= 112 && hdp <= 48) return launch_bwd_f32mfma<7, 3>(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, s);
     }
   }
   const size_t lds = ((size_t)4 * S * (hd + 1) + (size_t)2 * S * (S + 1)) * sizeof(float);
