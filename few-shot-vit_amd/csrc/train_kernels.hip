@@ -3,6 +3,8 @@
 // layout kernels except attention backward; the GEMM-shaped work (forward convs, dgrad, split-K wgrad)
 // reuses conv_gemm_v2.  T = storage dtype of activations and activation gradients (fp32 or bf16);
 // parameters, parameter gradients, BN statistics and reductions are fp32.
+#include <stdlib.h>
+
 #include "fsvit_common.h"
 #include "train_kernels.h"
 
@@ -636,6 +638,120 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* dy, const T*
   }
 }
 
+// ---- row-walking forms of bn_apply / bn_bwd_apply (round 3): a thread owns V = 16 / sizeof(T) channels (16-byte accesses) of the rows blk * R + rl,
+// += gridDim * R; its per-channel coefficients are loaded ONCE, there is no index division in the loop, and U rows' loads are issued back to back.
+// (The element-indexed kernels above did a 64-bit div / mod per 8-byte access and reached 3 TB/s on the 164 ... 328 MB maps of the stem and stage 1.)
+template <typename T, int V>
+__device__ __forceinline__ void ldv(const T* p, float (&o)[V]) {
+  if constexpr (sizeof(T) == 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = v[e];
+  } else {
+    const bf16x8 h = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(p));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)h[e];
+  }
+}
+template <typename T, int V>
+__device__ __forceinline__ void stv(T* p, const float (&v)[V]) {
+  if constexpr (sizeof(T) == 4) *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  else {
+    const bf16x8 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+    *reinterpret_cast<u32x4*>(p) = __builtin_bit_cast(u32x4, h);
+  }
+}
+template <int V>
+__device__ __forceinline__ void ldc(const float* p, float (&o)[V]) {
+#pragma unroll
+  for (int e = 0; e < V; e += 4) { const f32x4 v = *reinterpret_cast<const f32x4*>(p + e); o[e] = v[0]; o[e + 1] = v[1]; o[e + 2] = v[2]; o[e + 3] = v[3]; }
+}
+
+template <typename T, int V, int U>
+__global__ __launch_bounds__(256) void bn_apply_rows_kernel(const T* __restrict__ z, const float* __restrict__ sa, const float* __restrict__ sb,
+                                                            const T* __restrict__ res, T* __restrict__ y, size_t M, int C, int act) {
+  const int lanesC = C / V, R = 256 / lanesC;
+  const int cl = threadIdx.x % lanesC, rl = threadIdx.x / lanesC, c = cl * V;
+  float a[V], bsh[V];
+  ldc<V>(sa + c, a);
+  ldc<V>(sb + c, bsh);
+  const size_t step = (size_t)gridDim.x * R;
+  for (size_t m = (size_t)blockIdx.x * R + rl; m < M; m += U * step) {
+    float zv[U][V], rv[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t mm = m + u * step;
+      if (mm < M) { ldv<T, V>(z + mm * C + c, zv[u]); if (res) ldv<T, V>(res + mm * C + c, rv[u]); }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t mm = m + u * step;
+      if (mm < M) {
+        float o[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          float v = zv[u][e] * a[e] + bsh[e];
+          if (res) v += rv[u][e];
+          if (act == ACT_LRELU) v = v > 0.f ? v : 0.1f * v;
+          o[e] = v;
+        }
+        stv<T, V>(y + mm * C + c, o);
+      }
+    }
+  }
+}
+
+template <typename T, int V, int U>
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const T* dy, const T* __restrict__ z, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const float* __restrict__ ca, const float* __restrict__ cb,
+                                                                const float* __restrict__ cc, T* dz, size_t M, int C, const T* acc, const float* __restrict__ scale2,
+                                                                T* out2, size_t rows_per_img, const float* __restrict__ act_sa, const float* __restrict__ act_sb) {
+  const int lanesC = C / V, R = 256 / lanesC;
+  const int cl = threadIdx.x % lanesC, rl = threadIdx.x / lanesC, c = cl * V;
+  float A[V], MU[V], IS[V], B0[V], C0[V], asa[V], asb[V];      // the same expression, in the same order, as bn_bwd_apply_kernel
+  ldc<V>(ca + c, A); ldc<V>(mean + c, MU); ldc<V>(invstd + c, IS); ldc<V>(cb + c, B0); ldc<V>(cc + c, C0);
+#pragma unroll
+  for (int e = 0; e < V; ++e) asa[e] = asb[e] = 0.f;
+  if (act_sa) { ldc<V>(act_sa + c, asa); ldc<V>(act_sb + c, asb); }
+  const size_t step = (size_t)gridDim.x * R;
+  for (size_t m = (size_t)blockIdx.x * R + rl; m < M; m += U * step) {
+    float zv[U][V], dv[U][V], av[U][V];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t mm = m + u * step;
+      if (mm < M) { ldv<T, V>(z + mm * C + c, zv[u]); ldv<T, V>(dy + mm * C + c, dv[u]); if (acc) ldv<T, V>(acc + mm * C + c, av[u]); }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t mm = m + u * step;
+      if (mm < M) {
+        float o[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          float d = dv[u][e];
+          if (act_sa) d = zv[u][e] * asa[e] + asb[e] > 0.f ? d : 0.1f * d;
+          float v = A[e] * d + B0[e] + C0[e] * ((zv[u][e] - MU[e]) * IS[e]);
+          if (acc) v += av[u][e];
+          o[e] = v;
+        }
+        stv<T, V>(dz + mm * C + c, o);
+        if (out2) {                       // the copy scales what the NEXT kernels will read back from dz, i.e. the value rounded to the storage type
+          const float sc = scale2 ? scale2[mm / rows_per_img] : 1.0f;
+#pragma unroll
+          for (int e = 0; e < V; ++e) o[e] = to_f32<T>(from_f32<T>(o[e])) * sc;
+          stv<T, V>(out2 + mm * C + c, o);
+        }
+      }
+    }
+  }
+}
+static inline bool rows_form_ok(int C, int V) { const int lanesC = C / V; return C % V == 0 && lanesC >= 1 && lanesC <= 256 && 256 % lanesC == 0; }
+static inline unsigned rows_grid(size_t M, int C, int V, int U) {
+  const size_t R = 256 / (C / V);
+  size_t nb = (M + R * U - 1) / (R * U);
+  return (unsigned)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb));
+}
+
 // ------------------------------------------------------------------------------------------------ elementwise
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ z, T* __restrict__ h, size_t n4) {
@@ -1189,6 +1305,12 @@ int launch_bn_frozen_coeffs(int C, float eps, const float* gamma, const float* b
   return (int)hipGetLastError();
 }
 int launch_bn_apply(const void* z, const float* sa, const float* sb, const void* res, void* y, size_t M, int C, int act, int dtype, hipStream_t s) {
+  static const bool rows_off = [] { const char* e = getenv("FSVIT_BN_ROWS"); return e && e[0] == '0'; }();
+  if (!rows_off && rows_form_ok(C, dtype == 0 ? 4 : 8)) {
+    if (dtype == 0) hipLaunchKernelGGL((bn_apply_rows_kernel<float, 4, 4>), dim3(rows_grid(M, C, 4, 4)), dim3(256), 0, s, (const float*)z, sa, sb, (const float*)res, (float*)y, M, C, act);
+    else hipLaunchKernelGGL((bn_apply_rows_kernel<bf16, 8, 4>), dim3(rows_grid(M, C, 8, 4)), dim3(256), 0, s, (const bf16*)z, sa, sb, (const bf16*)res, (bf16*)y, M, C, act);
+    return (int)hipGetLastError();
+  }
   const size_t total = M * (C / 4);
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, (const float*)z, sa, sb, (const float*)res, (float*)y, M, C, act),
              hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, (const bf16*)z, sa, sb, (const bf16*)res, (bf16*)y, M, C, act));
@@ -1205,6 +1327,16 @@ int launch_bn_bwd_apply(const void* dy, const void* z, const float* mean, const 
                         const float* act_sb) {
   const size_t total = M * (C / 4);
   if (!rows_per_img) rows_per_img = 1;
+  static const bool rows_off = [] { const char* e = getenv("FSVIT_BN_ROWS"); return e && e[0] == '0'; }();
+  if (!rows_off && rows_form_ok(C, dtype == 0 ? 4 : 8)) {
+    if (dtype == 0)
+      hipLaunchKernelGGL((bn_bwd_apply_rows_kernel<float, 4, 2>), dim3(rows_grid(M, C, 4, 2)), dim3(256), 0, s, (const float*)dy, (const float*)z, mean, invstd, ca, cb, cc, (float*)dz, M, C,
+                         (const float*)acc, scale2, (float*)out2, rows_per_img, act_sa, act_sb);
+    else
+      hipLaunchKernelGGL((bn_bwd_apply_rows_kernel<bf16, 8, 2>), dim3(rows_grid(M, C, 8, 2)), dim3(256), 0, s, (const bf16*)dy, (const bf16*)z, mean, invstd, ca, cb, cc, (bf16*)dz, M, C,
+                         (const bf16*)acc, scale2, (bf16*)out2, rows_per_img, act_sa, act_sb);
+    return (int)hipGetLastError();
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(gs_grid(total)), dim3(256), 0, s, (const float*)dy, (const float*)z, mean, invstd, ca, cb, cc, (float*)dz, M, C,
                                        (const float*)acc, scale2, (float*)out2, rows_per_img, act_sa, act_sb),
              hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, dim3(gs_grid(total)), dim3(256), 0, s, (const bf16*)dy, (const bf16*)z, mean, invstd, ca, cb, cc, (bf16*)dz, M, C,
