@@ -136,6 +136,27 @@ __device__ __forceinline__ f32x2 gelu_sig2(f32x2 x) {
   return x * r;
 }
 
+// gelu_sig2 with the derivative of gelu_sig_d, packed (the training variant of the stage-1 ring kernel stores both)
+__device__ __forceinline__ f32x2 gelu_sig2_d(f32x2 x, f32x2& d) {
+  f32x2 u = x * x;
+  u[0] = fminf(u[0], 64.0f);
+  u[1] = fminf(u[1], 64.0f);
+  f32x2 p = u * f32x2{1.0153755e-3f, 1.0153755e-3f} + f32x2{-1.0678257e-1f, -1.0678257e-1f};
+  p = p * u + f32x2{-2.3011138f, -2.3011138f};
+  const f32x2 z = x * p;
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(z[0]);
+  e[1] = __builtin_amdgcn_exp2f(z[1]);
+  e = e + f32x2{1.0f, 1.0f};
+  f32x2 s;
+  s[0] = __builtin_amdgcn_rcpf(e[0]);
+  s[1] = __builtin_amdgcn_rcpf(e[1]);
+  f32x2 q = u * f32x2{5.0f * 1.0153755e-3f, 5.0f * 1.0153755e-3f} + f32x2{3.0f * -1.0678257e-1f, 3.0f * -1.0678257e-1f};
+  q = (q * u + f32x2{-2.3011138f, -2.3011138f}) * f32x2{-0.69314718055994530942f, -0.69314718055994530942f};
+  d = s * ((x * (f32x2{1.0f, 1.0f} - s)) * q + f32x2{1.0f, 1.0f});
+  return x * s;
+}
+
 // FAST selects gelu_sig (bf16 storage); the fp32 parity path keeps the exact erff form.
 template <bool FAST>
 __device__ __forceinline__ float apply_act(float v, int act) {

@@ -70,9 +70,22 @@ __device__ __forceinline__ f32x4 s1r_gelu4(f32x4 v) {
   return f32x4{a[0], a[1], b[0], b[1]};
 }
 
-__global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const bf16* __restrict__ w1,
-                                                             const float* __restrict__ b1, const bf16* __restrict__ w2, const bf16* __restrict__ w3, int M,
-                                                             int H, int W, int n_chunks, int chunks_per_wg) {
+// TRAIN (the meta-tuning step's forward, train_engine.hip): x = the block's NORMALISED input (the BatchNorm statistics are a pass of their own), no
+// bias, no residual (the scaled residual add rides in the next BatchNorm's reduce pass): y = conv3(h2), and the hidden maps h1 / h2 with the GELU
+// derivatives g1 / g2 at their pre-activations go to HBM for the backward pass ([M][256] each) - the three GEMM launches of a block and their
+// hidden-map round trips in one kernel.
+struct S1Train { bf16 *h1, *g1, *h2, *g2; };
+__device__ __forceinline__ void s1r_gelu4_d(f32x4 v, f32x4& h, f32x4& d) {
+  f32x2 da, db;
+  const f32x2 a = gelu_sig2_d(f32x2{v[0], v[1]}, da), b = gelu_sig2_d(f32x2{v[2], v[3]}, db);
+  h = f32x4{a[0], a[1], b[0], b[1]};
+  d = f32x4{da[0], da[1], db[0], db[1]};
+}
+
+template <bool TRAIN>
+__device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf16* __restrict__ y, const bf16* __restrict__ w1,
+                                                 const float* __restrict__ b1, const bf16* __restrict__ w2, const bf16* __restrict__ w3, int M,
+                                                 int H, int W, int n_chunks, int chunks_per_wg, const S1Train tr) {
   using namespace s1r;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, lrow = lane & 15, lq = lane >> 4;
@@ -102,9 +115,13 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restr
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) wf3[nt][kc] = *reinterpret_cast<const u32x4*>(w3 + (size_t)(np3 * 32 + prow + 4 * nt) * HID + kc * 32 + lq * 8);
-  f32x4 bias1[2];
+  f32x4 bias1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if constexpr (!TRAIN) {
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) bias1[nt] = *reinterpret_cast<const f32x4*>(b1 + g * 32 + lq * 8 + nt * 4);
+    for (int nt = 0; nt < 2; ++nt) bias1[nt] = *reinterpret_cast<const f32x4*>(b1 + g * 32 + lq * 8 + nt * 4);
+  }
+  const long own_lo = (long)q0 * CH;                                   // TRAIN: this workgroup stores h1 / g1 of its OWN pixels only (the halo is recomputed by the neighbours)
+  long own_hi = (long)q1 * CH; own_hi = own_hi < M ? own_hi : M;
 
   // ---- x batches: 64 consecutive pixels from linear index P0 (pixels outside [0, M) are stored as zeros); 2 x 16 B per thread
   u32x4 px[2];
@@ -142,7 +159,21 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restr
         acc[0] = mma_chunk<bf16>(wf1[0][kc], xf, acc[0]);
         acc[1] = mma_chunk<bf16>(wf1[1][kc], xf, acc[1]);
       }
-      *reinterpret_cast<u32x4*>(h1w + slot) = s1r_pack8(s1r_gelu4(acc[0]), s1r_gelu4(acc[1]));
+      if constexpr (TRAIN) {
+        f32x4 h0, h1v, d0, d1;
+        s1r_gelu4_d(acc[0], h0, d0);
+        s1r_gelu4_d(acc[1], h1v, d1);
+        const u32x4 hp = s1r_pack8(h0, h1v);
+        *reinterpret_cast<u32x4*>(h1w + slot) = hp;
+        const long pp = P0 + mt * 16 + lrow;
+        if (pp >= own_lo && pp < own_hi) {
+          const size_t o = (size_t)pp * HID + g * 32 + lq * 8;
+          *reinterpret_cast<u32x4*>(tr.h1 + o) = hp;
+          *reinterpret_cast<u32x4*>(tr.g1 + o) = s1r_pack8(d0, d1);
+        }
+      } else {
+        *reinterpret_cast<u32x4*>(h1w + slot) = s1r_pack8(s1r_gelu4(acc[0]), s1r_gelu4(acc[1]));
+      }
     }
   };
 
@@ -196,7 +227,20 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restr
         acc[0] = mma_chunk<bf16>(wf2[tp][0], hf, acc[0]);
         acc[1] = mma_chunk<bf16>(wf2[tp][1], hf, acc[1]);
       }
-      *reinterpret_cast<u32x4*>(h2w + (mt * 16 + lrow) * 16) = s1r_pack8(s1r_gelu4(acc[0]), s1r_gelu4(acc[1]));
+      if constexpr (TRAIN) {
+        f32x4 h0, h1v, d0, d1;
+        s1r_gelu4_d(acc[0], h0, d0);
+        s1r_gelu4_d(acc[1], h1v, d1);
+        const u32x4 hp = s1r_pack8(h0, h1v);
+        *reinterpret_cast<u32x4*>(h2w + (mt * 16 + lrow) * 16) = hp;
+        if (m < M) {
+          const size_t o = (size_t)m * HID + g * 32 + lq * 8;
+          *reinterpret_cast<u32x4*>(tr.h2 + o) = hp;
+          *reinterpret_cast<u32x4*>(tr.g2 + o) = s1r_pack8(d0, d1);
+        }
+      } else {
+        *reinterpret_cast<u32x4*>(h2w + (mt * 16 + lrow) * 16) = s1r_pack8(s1r_gelu4(acc[0]), s1r_gelu4(acc[1]));
+      }
     }
     S1R_SYNC();                                                // C: h2 of all groups is complete
 
@@ -212,10 +256,12 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restr
         acc[0] = mma_chunk<bf16>(wf3[0][kc], hf, acc[0]);
         acc[1] = mma_chunk<bf16>(wf3[1][kc], hf, acc[1]);
       }
-      const int m = m0 + mt * 16 + lrow;
-      const bf16x8 r = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xres + (m & (RING - 1)) * 16));
-      acc[0] += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
-      acc[1] += f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+      if constexpr (!TRAIN) {
+        const int m = m0 + mt * 16 + lrow;
+        const bf16x8 r = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xres + (m & (RING - 1)) * 16));
+        acc[0] += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+        acc[1] += f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+      }
       *reinterpret_cast<u32x4*>(outw + (mt * 16 + lrow) * OROW) = s1r_pack8(acc[0], acc[1]);
     }
     S1R_SYNC();                                                // D: the output tile is complete
@@ -226,6 +272,17 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restr
       if (m < M) *reinterpret_cast<u32x4*>(y + (size_t)m * C1 + c8 * 8) = *reinterpret_cast<const u32x4*>(smem + OUT + p * OROW + c8 * 16);
     }
   }
+}
+
+__global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const bf16* __restrict__ w1,
+                                                             const float* __restrict__ b1, const bf16* __restrict__ w2, const bf16* __restrict__ w3, int M,
+                                                             int H, int W, int n_chunks, int chunks_per_wg) {
+  stage1_ring_body<false>(x, y, w1, b1, w2, w3, M, H, W, n_chunks, chunks_per_wg, S1Train{nullptr, nullptr, nullptr, nullptr});
+}
+__global__ __launch_bounds__(512, 1) void stage1_ring_train_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const bf16* __restrict__ w1,
+                                                                   const bf16* __restrict__ w2, const bf16* __restrict__ w3, int M, int H, int W, int n_chunks,
+                                                                   int chunks_per_wg, const S1Train tr) {
+  stage1_ring_body<true>(x, y, w1, nullptr, w2, w3, M, H, W, n_chunks, chunks_per_wg, tr);
 }
 
 bool stage1_ring_supported(int dtype, int C1, int hid, int group, int H1) {
@@ -253,6 +310,23 @@ int launch_stage1_ring(const void* x, void* y, const void* w1, const float* b1, 
   }
   hipLaunchKernelGGL(stage1_ring_kernel, dim3(wgs), dim3(512), s1r::LDS_BYTES, s, (const bf16*)x, (bf16*)y, (const bf16*)w1, b1, (const bf16*)w2, (const bf16*)w3, M, H, W,
                      n_chunks, cpw);
+  return (int)hipGetLastError();
+}
+
+// training forward of a stage-1 Mlp: xn [M][128] normalised input -> z3 [M][128], h1 / g1 / h2 / g2 [M][256] (see stage1_ring_body<true>)
+int launch_stage1_ring_train(const void* xn, void* z3, const void* w1, const void* w2, const void* w3, void* h1, void* g1, void* h2, void* g2, int B, int H,
+                             int W, hipStream_t s) {
+  const long Ml = (long)B * H * W;
+  if (Ml <= 0) return 0;
+  if (Ml >= (1L << 31) - 256 || W > 20 || H * W < 16) return (int)hipErrorInvalidValue;
+  const int M = (int)Ml, n_chunks = (M + s1r::CH - 1) / s1r::CH;
+  int wgs = n_chunks < 256 ? n_chunks : 256;
+  const int cpw = (n_chunks + wgs - 1) / wgs;
+  wgs = (n_chunks + cpw - 1) / cpw;
+  hipError_t e = hipFuncSetAttribute((const void*)stage1_ring_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, s1r::LDS_BYTES);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(stage1_ring_train_kernel, dim3(wgs), dim3(512), s1r::LDS_BYTES, s, (const bf16*)xn, (bf16*)z3, (const bf16*)w1, (const bf16*)w2, (const bf16*)w3, M, H, W,
+                     n_chunks, cpw, S1Train{(bf16*)h1, (bf16*)g1, (bf16*)h2, (bf16*)g2});
   return (int)hipGetLastError();
 }
 

@@ -186,6 +186,15 @@ int run_packs(TR* t) {
 
 // ---------------------------------------------------------------- conv forward: z = conv(x) (+ bias)
 // gp != nullptr: z = GELU(conv(x) + bias) and gp = the GELU's derivative at the pre-activation, both written by the GEMM's epilogue (conv_gemm.h y2)
+// the forward pack of a layer: [groups][rows_fwd][Kw], row n = output channel, k = (tap, input channel)
+int conv_pack_fwd(TR* t, const ConvSpec& c, void** pk, int* Kw_out = nullptr) {
+  const fsvit_param* w = getp(t, c.wname);
+  if (!w) return FSVIT_ERR_KEY;
+  const int bke = 128 / t->es, Ng = c.rows_fwd(), K = c.kpad_cols(), Kw = round_up(K, bke);
+  if (Kw_out) *Kw_out = Kw;
+  return packed_weight(t, PackJob{w->data, nullptr, c.O, c.Ig, c.KH, c.KW, c.groups, 0, Ng, Kw, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols},
+                       (size_t)c.groups * Ng * Kw * t->es, pk);
+}
 int conv_fwd(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, void* z, const float* bias, void* gp = nullptr) {
   const fsvit_param* w = getp(t, c.wname);
   if (!w) return FSVIT_ERR_KEY;
@@ -512,9 +521,21 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
     void* z3 = take_tmp(t, M1 * t->C1); NEED(z3);
     T_TRY(bn_fwd(t, p + "norm2.bn", b.x, (int)M1, t->C1, ACT_NONE, nullptr, b.xn, &b.bn, &pend));
     // (z1 / z2 hold the GELU DERIVATIVES at the pre-activations, written next to h1 / h2 by the conv epilogues)
-    T_TRY(conv_fwd(t, sp.s1c1[i], b.xn, B, H1, H1, b.h1, nullptr, b.z1));
-    T_TRY(conv_fwd(t, sp.s1c2[i], b.h1, B, H1, H1, b.h2, nullptr, b.z2));
-    T_TRY(conv_fwd(t, sp.s1c3[i], b.h2, B, H1, H1, z3, nullptr));
+    static const bool fused_off = [] { const char* e = getenv("FSVIT_STAGE1_TRAIN_FUSED"); return e && e[0] == '0'; }();
+    if (!fused_off && stage1_ring_supported(t->gdt, t->C1, t->hid1, t->cfg.group, H1)) {
+      // the three GEMM launches of the Mlp and the round trips of its hidden maps in ONE kernel (stage1_ring.hip, training variant)
+      void *pk1 = nullptr, *pk2 = nullptr, *pk3 = nullptr;
+      int kw2 = 0;
+      T_TRY(conv_pack_fwd(t, sp.s1c1[i], &pk1));
+      T_TRY(conv_pack_fwd(t, sp.s1c2[i], &pk2, &kw2));
+      T_TRY(conv_pack_fwd(t, sp.s1c3[i], &pk3));
+      if (kw2 != 320) return fsvit_set_error(FSVIT_ERR_ARG, "stage-1 grouped conv pack: Kw %d", kw2);
+      T_RUN(launch_stage1_ring_train(b.xn, z3, pk1, pk2, pk3, b.h1, b.z1, b.h2, b.z2, B, H1, H1, st));
+    } else {
+      T_TRY(conv_fwd(t, sp.s1c1[i], b.xn, B, H1, H1, b.h1, nullptr, b.z1));
+      T_TRY(conv_fwd(t, sp.s1c2[i], b.h1, B, H1, H1, b.h2, nullptr, b.z2));
+      T_TRY(conv_fwd(t, sp.s1c3[i], b.h2, B, H1, H1, z3, nullptr));
+    }
     b.scale = dp_scale(t, dp_call, blk, nblk);
     if (t->dp_rate * blk > 0.f) ++dp_call;
     // b.out = b.x + scale * z3: queued for the next block's BatchNorm reduce pass (z3 must outlive this block's tmp scope: it is the first

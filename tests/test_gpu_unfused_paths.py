@@ -89,8 +89,16 @@ def test_every_training_dispatch_switch_agrees_with_the_default_path(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         return torch.load(out)
     base = run({}, 'base')
-    for i, env in enumerate([{'FSVIT_WGRAD3X3': '0'}, {'FSVIT_WGRAD1X1': '0'}, {'FSVIT_GCONV3X3': '0'}, {'FSVIT_WGRAD_SIDE_STREAM': '1'}, {'FSVIT_BN_ROWS': '0'}]):
+    for i, env in enumerate([{'FSVIT_WGRAD3X3': '0'}, {'FSVIT_WGRAD1X1': '0'}, {'FSVIT_GCONV3X3': '0'}, {'FSVIT_WGRAD_SIDE_STREAM': '1'}, {'FSVIT_BN_ROWS': '0'}, {'FSVIT_STAGE1_TRAIN_FUSED': '0'}]):
         other = run(env, f'tr{i}')
         worst = max(float((other[k] - v).norm() / (v.norm() + 1e-12)) for k, v in base.items() if float(v.norm()) > 1e-5)
         print(f'{env}: worst gradient rel difference to the default path = {worst:.3e}')
         assert worst <= 0.05, env
+
+
+def test_fp32_attention_backward_fallback_switch():
+    """FSVIT_ATTN_BWD_F32_MFMA=0 keeps the FMA-loop attention backward for the Visformer head shapes (the kernel the fp32 MFMA one replaced in
+    round 3): the same operator tests must pass through it."""
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_train.py'), '-q', '-x', '-k', 'attention_backward_vs_torch'],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, FSVIT_ATTN_BWD_F32_MFMA='0'), cwd=ROOT)
+    assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
