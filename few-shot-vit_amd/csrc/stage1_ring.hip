@@ -82,11 +82,15 @@ __device__ __forceinline__ void s1r_gelu4_d(f32x4 v, f32x4& h, f32x4& d) {
   d = f32x4{da[0], da[1], db[0], db[1]};
 }
 
-template <bool TRAIN>
+// MODE 2 (the block's data-gradient chain, train_engine.hip): the SAME ring walk over the transposed packs - x = dz3, "conv1" = W3^T (128 -> 256)
+// times g2' -> dz2, "conv2" = the grouped 3x3 with flipped taps times g1' -> dz1, "conv3" = W1^T (256 -> 128) -> d(xn); the multipliers come from HBM
+// ([M][256], the derivatives the forward variant stored), dz2 / dz1 go to HBM for the weight gradients (tr.h1 = dz2, tr.h2 = dz1; tr.g1 = g2', tr.g2 = g1').
+template <int MODE>
 __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf16* __restrict__ y, const bf16* __restrict__ w1,
                                                  const float* __restrict__ b1, const bf16* __restrict__ w2, const bf16* __restrict__ w3, int M,
                                                  int H, int W, int n_chunks, int chunks_per_wg, const S1Train tr) {
   using namespace s1r;
+  constexpr bool TRAIN = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, lrow = lane & 15, lq = lane >> 4;
   const int g = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -116,7 +120,7 @@ __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf1
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) wf3[nt][kc] = *reinterpret_cast<const u32x4*>(w3 + (size_t)(np3 * 32 + prow + 4 * nt) * HID + kc * 32 + lq * 8);
   f32x4 bias1[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  if constexpr (!TRAIN) {
+  if constexpr (MODE == 0) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) bias1[nt] = *reinterpret_cast<const f32x4*>(b1 + g * 32 + lq * 8 + nt * 4);
   }
@@ -159,7 +163,16 @@ __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf1
         acc[0] = mma_chunk<bf16>(wf1[0][kc], xf, acc[0]);
         acc[1] = mma_chunk<bf16>(wf1[1][kc], xf, acc[1]);
       }
-      if constexpr (TRAIN) {
+      if constexpr (MODE == 2) {
+        const long pp = P0 + mt * 16 + lrow;
+        const bool inr = pp >= 0 && pp < M;
+        const size_t o = (size_t)(inr ? pp : 0) * HID + g * 32 + lq * 8;
+        const bf16x8 mg = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tr.g1 + o));
+        const u32x4 hp = s1r_pack8(acc[0] * f32x4{(float)mg[0], (float)mg[1], (float)mg[2], (float)mg[3]},
+                                   acc[1] * f32x4{(float)mg[4], (float)mg[5], (float)mg[6], (float)mg[7]});
+        *reinterpret_cast<u32x4*>(h1w + slot) = hp;
+        if (pp >= own_lo && pp < own_hi) *reinterpret_cast<u32x4*>(tr.h1 + o) = hp;
+      } else if constexpr (TRAIN) {
         f32x4 h0, h1v, d0, d1;
         s1r_gelu4_d(acc[0], h0, d0);
         s1r_gelu4_d(acc[1], h1v, d1);
@@ -227,7 +240,14 @@ __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf1
         acc[0] = mma_chunk<bf16>(wf2[tp][0], hf, acc[0]);
         acc[1] = mma_chunk<bf16>(wf2[tp][1], hf, acc[1]);
       }
-      if constexpr (TRAIN) {
+      if constexpr (MODE == 2) {
+        const size_t o = (size_t)(m < M ? m : 0) * HID + g * 32 + lq * 8;
+        const bf16x8 mg = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tr.g2 + o));
+        const u32x4 hp = s1r_pack8(acc[0] * f32x4{(float)mg[0], (float)mg[1], (float)mg[2], (float)mg[3]},
+                                   acc[1] * f32x4{(float)mg[4], (float)mg[5], (float)mg[6], (float)mg[7]});
+        *reinterpret_cast<u32x4*>(h2w + (mt * 16 + lrow) * 16) = hp;
+        if (m < M) *reinterpret_cast<u32x4*>(tr.h2 + o) = hp;
+      } else if constexpr (TRAIN) {
         f32x4 h0, h1v, d0, d1;
         s1r_gelu4_d(acc[0], h0, d0);
         s1r_gelu4_d(acc[1], h1v, d1);
@@ -256,7 +276,7 @@ __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf1
         acc[0] = mma_chunk<bf16>(wf3[0][kc], hf, acc[0]);
         acc[1] = mma_chunk<bf16>(wf3[1][kc], hf, acc[1]);
       }
-      if constexpr (!TRAIN) {
+      if constexpr (MODE == 0) {
         const int m = m0 + mt * 16 + lrow;
         const bf16x8 r = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xres + (m & (RING - 1)) * 16));
         acc[0] += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
@@ -277,12 +297,17 @@ __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf1
 __global__ __launch_bounds__(512, 1) void stage1_ring_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const bf16* __restrict__ w1,
                                                              const float* __restrict__ b1, const bf16* __restrict__ w2, const bf16* __restrict__ w3, int M,
                                                              int H, int W, int n_chunks, int chunks_per_wg) {
-  stage1_ring_body<false>(x, y, w1, b1, w2, w3, M, H, W, n_chunks, chunks_per_wg, S1Train{nullptr, nullptr, nullptr, nullptr});
+  stage1_ring_body<0>(x, y, w1, b1, w2, w3, M, H, W, n_chunks, chunks_per_wg, S1Train{nullptr, nullptr, nullptr, nullptr});
 }
 __global__ __launch_bounds__(512, 1) void stage1_ring_train_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const bf16* __restrict__ w1,
                                                                    const bf16* __restrict__ w2, const bf16* __restrict__ w3, int M, int H, int W, int n_chunks,
                                                                    int chunks_per_wg, const S1Train tr) {
-  stage1_ring_body<true>(x, y, w1, nullptr, w2, w3, M, H, W, n_chunks, chunks_per_wg, tr);
+  stage1_ring_body<1>(x, y, w1, nullptr, w2, w3, M, H, W, n_chunks, chunks_per_wg, tr);
+}
+__global__ __launch_bounds__(512, 1) void stage1_ring_dgrad_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const bf16* __restrict__ w1,
+                                                                   const bf16* __restrict__ w2, const bf16* __restrict__ w3, int M, int H, int W, int n_chunks,
+                                                                   int chunks_per_wg, const S1Train tr) {
+  stage1_ring_body<2>(x, y, w1, nullptr, w2, w3, M, H, W, n_chunks, chunks_per_wg, tr);
 }
 
 bool stage1_ring_supported(int dtype, int C1, int hid, int group, int H1) {
@@ -327,6 +352,23 @@ int launch_stage1_ring_train(const void* xn, void* z3, const void* w1, const voi
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(stage1_ring_train_kernel, dim3(wgs), dim3(512), s1r::LDS_BYTES, s, (const bf16*)xn, (bf16*)z3, (const bf16*)w1, (const bf16*)w2, (const bf16*)w3, M, H, W,
                      n_chunks, cpw, S1Train{(bf16*)h1, (bf16*)g1, (bf16*)h2, (bf16*)g2});
+  return (int)hipGetLastError();
+}
+// data-gradient chain of the block: dz3 [M][128] -> dz2 = (dz3 W3) * g2', dz1 = (grouped conv^T of dz2) * g1', dxn = dz1 W1  (w3t / w2t / w1t: the transposed
+// ("dgrad") packs [256][128], [256][320] tap-flipped, [128][256]); dxn must not alias dz3
+int launch_stage1_ring_dgrad(const void* dz3, void* dxn, const void* w3t, const void* w2t, const void* w1t, const void* g2, const void* g1, void* dz2, void* dz1,
+                             int B, int H, int W, hipStream_t s) {
+  const long Ml = (long)B * H * W;
+  if (Ml <= 0) return 0;
+  if (Ml >= (1L << 31) - 256 || W > 20 || H * W < 16 || dz3 == dxn) return (int)hipErrorInvalidValue;
+  const int M = (int)Ml, n_chunks = (M + s1r::CH - 1) / s1r::CH;
+  int wgs = n_chunks < 256 ? n_chunks : 256;
+  const int cpw = (n_chunks + wgs - 1) / wgs;
+  wgs = (n_chunks + cpw - 1) / cpw;
+  hipError_t e = hipFuncSetAttribute((const void*)stage1_ring_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, s1r::LDS_BYTES);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(stage1_ring_dgrad_kernel, dim3(wgs), dim3(512), s1r::LDS_BYTES, s, (const bf16*)dz3, (bf16*)dxn, (const bf16*)w3t, (const bf16*)w2t, (const bf16*)w1t, M, H,
+                     W, n_chunks, cpw, S1Train{(bf16*)dz2, (bf16*)g2, (bf16*)dz1, (bf16*)g1});
   return (int)hipGetLastError();
 }
 

@@ -218,6 +218,16 @@ int conv_fwd(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, void*
 // ---------------------------------------------------------------- data gradient: dx = conv^T(dz)   (stride-1 convs and 1x1)
 int side_guard(TR* t, const void* p, size_t bytes);       // (side stream of the backward pass, below)
 // mul != nullptr: dx = conv^T(dz) * mul (the saved GELU derivative of the layer in front: its backward rides in this epilogue)
+// the transposed ("dgrad") pack of a layer: [groups][Ig_pad rows][Kw], row = input channel, k = (flipped tap, output channel)
+int conv_pack_bwd(TR* t, const ConvSpec& c, void** pk, int* Kw_out = nullptr) {
+  const fsvit_param* w = getp(t, c.wname);
+  if (!w) return FSVIT_ERR_KEY;
+  const int bke = 128 / t->es, Ng_pad = c.rows_fwd(), Ig_pad = c.Ig / c.hd_cols * c.hdp_cols;
+  const int K = c.KH * c.KW * Ng_pad, Kw = round_up(K, bke);
+  if (Kw_out) *Kw_out = Kw;
+  return packed_weight(t, PackJob{w->data, nullptr, c.O, c.Ig, c.KH, c.KW, c.groups, 1, Ig_pad, Kw, c.hd_cols, c.hdp_cols, c.hd_rows, c.hdp_rows},
+                       (size_t)c.groups * Ig_pad * Kw * t->es, pk);
+}
 int conv_bwd_data(TR* t, const ConvSpec& c, const void* dz, int B, int OH, int OW, void* dx, const void* mul = nullptr) {
   const fsvit_param* w = getp(t, c.wname);
   if (!w) return FSVIT_ERR_KEY;
@@ -717,17 +727,39 @@ int train_backward_impl(TR* t, const float* dfeat) {
     const size_t mark = t->tmp.off;
     void* dz3 = take_tmp(t, M1 * t->C1); NEED(dz3);
     if (i == (int)t->s1.size() - 1) { T_TRY(side_guard(t, dz3, M1 * t->C1 * t->es)); T_RUN(launch_add_scaled(nullptr, dx, b.scale, dz3, M1 * t->C1, (size_t)H1 * H1 * t->C1, dt, st)); }
-    T_TRY(conv_bwd_weight(t, sp.s1c3[i], b.h2, B, H1, H1, dz3));
-    void* dh2 = take_tmp(t, M1 * t->hid1); NEED(dh2);
-    T_TRY(conv_bwd_data(t, sp.s1c3[i], dz3, B, H1, H1, dh2, b.z2));                           // x GELU'(z2) in the epilogue
-    T_TRY(conv_bwd_weight(t, sp.s1c2[i], b.h1, B, H1, H1, dh2));
-    void* dh1 = take_tmp(t, M1 * t->hid1); NEED(dh1);
-    T_TRY(conv_bwd_data(t, sp.s1c2[i], dh2, B, H1, H1, dh1, b.z1));                           // x GELU'(z1) in the epilogue
-    T_TRY(conv_bwd_weight(t, sp.s1c1[i], b.xn, B, H1, H1, dh1));
-    T_TRY(conv_bwd_data(t, sp.s1c1[i], dh1, B, H1, H1, dz3));                                  // dz3 := d(xn)
-    // dx += norm2 backward (read from dz3); the next block's dz3 = scale' * dx goes to the same buffer (in place over the BatchNorm's dy)
-    if (i > 0) T_TRY(bn_bwd(t, p + "norm2.bn", b.bn, dz3, dx, dx, t->s1[i - 1].scale, dz3, (size_t)H1 * H1));
-    else T_TRY(bn_bwd(t, p + "norm2.bn", b.bn, dz3, dx, dx));
+    static const bool fused_off = [] { const char* e = getenv("FSVIT_STAGE1_TRAIN_FUSED"); return e && e[0] == '0'; }();
+    void* dxn = dz3;                                                                           // d(xn): in place over dz3 on the three-launch route
+    if (!fused_off && stage1_ring_supported(t->gdt, t->C1, t->hid1, t->cfg.group, H1)) {
+      // the block's data-gradient chain dz3 -> dz2 -> dz1 -> d(xn) in ONE kernel (stage1_ring.hip MODE 2), then the three weight gradients
+      void *pk3 = nullptr, *pk2 = nullptr, *pk1 = nullptr;
+      int kw2 = 0;
+      T_TRY(conv_pack_bwd(t, sp.s1c3[i], &pk3));
+      T_TRY(conv_pack_bwd(t, sp.s1c2[i], &pk2, &kw2));
+      T_TRY(conv_pack_bwd(t, sp.s1c1[i], &pk1));
+      if (kw2 != 320) return fsvit_set_error(FSVIT_ERR_ARG, "stage-1 grouped conv dgrad pack: Kw %d", kw2);
+      void* dh2 = take_tmp(t, M1 * t->hid1); NEED(dh2);
+      void* dh1 = take_tmp(t, M1 * t->hid1); NEED(dh1);
+      dxn = take_tmp(t, M1 * t->C1); NEED(dxn);
+      T_TRY(side_guard(t, dh2, M1 * t->hid1 * t->es));
+      T_TRY(side_guard(t, dh1, M1 * t->hid1 * t->es));
+      T_TRY(side_guard(t, dxn, M1 * t->C1 * t->es));
+      T_RUN(launch_stage1_ring_dgrad(dz3, dxn, pk3, pk2, pk1, b.z2, b.z1, dh2, dh1, B, H1, H1, st));
+      T_TRY(conv_bwd_weight(t, sp.s1c3[i], b.h2, B, H1, H1, dz3));
+      T_TRY(conv_bwd_weight(t, sp.s1c2[i], b.h1, B, H1, H1, dh2));
+      T_TRY(conv_bwd_weight(t, sp.s1c1[i], b.xn, B, H1, H1, dh1));
+    } else {
+      T_TRY(conv_bwd_weight(t, sp.s1c3[i], b.h2, B, H1, H1, dz3));
+      void* dh2 = take_tmp(t, M1 * t->hid1); NEED(dh2);
+      T_TRY(conv_bwd_data(t, sp.s1c3[i], dz3, B, H1, H1, dh2, b.z2));                           // x GELU'(z2) in the epilogue
+      T_TRY(conv_bwd_weight(t, sp.s1c2[i], b.h1, B, H1, H1, dh2));
+      void* dh1 = take_tmp(t, M1 * t->hid1); NEED(dh1);
+      T_TRY(conv_bwd_data(t, sp.s1c2[i], dh2, B, H1, H1, dh1, b.z1));                           // x GELU'(z1) in the epilogue
+      T_TRY(conv_bwd_weight(t, sp.s1c1[i], b.xn, B, H1, H1, dh1));
+      T_TRY(conv_bwd_data(t, sp.s1c1[i], dh1, B, H1, H1, dz3));                                  // dz3 := d(xn)
+    }
+    // dx += norm2 backward (read from d(xn)); the next block's dz3 = scale' * dx goes to dz3's buffer
+    if (i > 0) T_TRY(bn_bwd(t, p + "norm2.bn", b.bn, dxn, dx, dx, t->s1[i - 1].scale, dz3, (size_t)H1 * H1));
+    else T_TRY(bn_bwd(t, p + "norm2.bn", b.bn, dxn, dx, dx));
     t->tmp.off = mark;
   }
   // ---- stem
