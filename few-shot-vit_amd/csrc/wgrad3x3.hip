@@ -59,31 +59,38 @@ __global__ __launch_bounds__(512) void wgrad3x3_kernel(const bf16* __restrict__ 
   if (t < 8) { reinterpret_cast<unsigned*>(ZERO)[t] = 0u; reinterpret_cast<unsigned*>(ZERO + WINP * 32)[t] = 0u; }   // one zero row (32 B) each
 
   u32x4 pz[NPZ], px[NPX];
+  unsigned okm = 0;                                            // validity bits of pz / px (rows past the end / outside the window read a clamped row)
   auto gload = [&](int q) {                                    // chunk q -> registers
     const long m0 = (long)q * CH;
+    // UNCONDITIONAL loads on clamped rows, the validity kept as a bit and applied by lstore(): a per-lane `ok ? load : 0` compiles to an exec-masked
+    // branch (or a select right behind the load) with its own vmcnt wait, i.e. the chunk's 11 loads went out one latency after the other
+    okm = 0;
 #pragma unroll
     for (int u0 = 0; u0 < NPZ; ++u0) {
       const int u = t + 512 * u0, r = u / (NC / 8), c8 = u % (NC / 8);
       const long m = m0 + r;
-      pz[u0] = m < M ? *reinterpret_cast<const u32x4*>(dz + (size_t)m * zld + c8 * 8) : u32x4{0u, 0u, 0u, 0u};
+      pz[u0] = *reinterpret_cast<const u32x4*>(dz + (size_t)(m < M ? m : M - 1) * zld + c8 * 8);
+      okm |= m < M ? 1u << u0 : 0u;
     }
 #pragma unroll
     for (int u0 = 0; u0 < NPX; ++u0) {
       const int u = t + 512 * u0, p = u / (CC / 8), c8 = u % (CC / 8);
       const long m = m0 - halo + p;
-      px[u0] = (p < winp && m >= 0 && m < M) ? *reinterpret_cast<const u32x4*>(x + (size_t)m * xld + xc0 + c8 * 8) : u32x4{0u, 0u, 0u, 0u};
+      const bool ok = p < winp && m >= 0 && m < M;
+      px[u0] = *reinterpret_cast<const u32x4*>(x + (size_t)(ok ? m : 0) * xld + xc0 + c8 * 8);
+      okm |= ok ? 1u << (NPZ + u0) : 0u;
     }
   };
   auto lstore = [&]() {                                        // registers -> the subtile images
 #pragma unroll
     for (int u0 = 0; u0 < NPZ; ++u0) {
       const int u = t + 512 * u0, r = u / (NC / 8), c8 = u % (NC / 8);
-      *reinterpret_cast<u32x4*>(ZT + (c8 >> 1) * (CH * 32) + r * 32 + (c8 & 1) * 16) = pz[u0];
+      *reinterpret_cast<u32x4*>(ZT + (c8 >> 1) * (CH * 32) + r * 32 + (c8 & 1) * 16) = (okm >> u0) & 1u ? pz[u0] : u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
     for (int u0 = 0; u0 < NPX; ++u0) {
       const int u = t + 512 * u0, p = u / (CC / 8), c8 = u % (CC / 8);
-      if (p < WINP) *reinterpret_cast<u32x4*>(XW + (c8 >> 1) * (WINP * 32) + p * 32 + (c8 & 1) * 16) = px[u0];
+      if (p < WINP) *reinterpret_cast<u32x4*>(XW + (c8 >> 1) * (WINP * 32) + p * 32 + (c8 & 1) * 16) = (okm >> (NPZ + u0)) & 1u ? px[u0] : u32x4{0u, 0u, 0u, 0u};
     }
   };
 
@@ -129,6 +136,7 @@ __global__ __launch_bounds__(512) void wgrad3x3_kernel(const bf16* __restrict__ 
         if (m >= M) oy[h] = -4;                                 // rows past the end: every tap invalid (their dz rows are zero anyway)
         rowa[h] = xw_lane + (rr + halo) * 32;
       }
+      // per tap: its 4 transposing reads first, then its 4 MFMAs (hipcc had put every MFMA PAIR behind its own two reads and an lgkmcnt(0))
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp) {
         const int dy = tp / 3 - 1, dx = tp % 3 - 1;
@@ -139,12 +147,16 @@ __global__ __launch_bounds__(512) void wgrad3x3_kernel(const bf16* __restrict__ 
           const bool ok = (unsigned)(oy[h] + dy) < (unsigned)H && (unsigned)(ox[h] + dx) < (unsigned)W;
           ad[h] = ok ? rowa[h] + shift : zero_lane;
         }
+        u32x4 bf[2];
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
           const u32x2 r1 = tr(ad[0] + ct * (WINP * 32)), r2 = tr(ad[1] + ct * (WINP * 32));
-          const u32x4 bf = {r1[0], r1[1], r2[0], r2[1]};
-          acc[tp][0][ct] = mma_chunk<bf16>(af[0], bf, acc[tp][0][ct]);
-          acc[tp][1][ct] = mma_chunk<bf16>(af[1], bf, acc[tp][1][ct]);
+          bf[ct] = u32x4{r1[0], r1[1], r2[0], r2[1]};
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          acc[tp][0][ct] = mma_chunk<bf16>(af[0], bf[ct], acc[tp][0][ct]);
+          acc[tp][1][ct] = mma_chunk<bf16>(af[1], bf[ct], acc[tp][1][ct]);
         }
       }
     }
