@@ -179,23 +179,32 @@ __global__ __launch_bounds__(KT * 64) void attention_bwd_f32mfma_kernel(const fl
   const float* base = qkv + (size_t)b * S * rowlen + h * hdp;
   const float* dob = dctx + (size_t)b * S * heads * hdp + h * hdp;
   float* dq = dqkv + (size_t)b * S * rowlen + h * hdp;
-  for (int idx = t; idx < SP * (HD / 4); idx += NT) {            // 16-byte global loads (hdp % 4 == 0: the launcher checks)
-    const int i = idx / (HD / 4), d = (idx - i * (HD / 4)) * 4;
-    f32x4 vq = {0.f, 0.f, 0.f, 0.f}, vk = vq, vv = vq, vo = vq;
-    if (i < S && d < hdp) {
-      const float* r = base + (size_t)i * rowlen + d;
-      vq = *reinterpret_cast<const f32x4*>(r);
-      vk = *reinterpret_cast<const f32x4*>(r + heads * hdp);
-      vv = *reinterpret_cast<const f32x4*>(r + 2 * heads * hdp);
-      vo = *reinterpret_cast<const f32x4*>(dob + (size_t)i * heads * hdp + d);
+  {   // 16-byte global loads (hdp % 4 == 0: the launcher checks), ALL in flight before the first LDS store: unconditional on clamped coordinates
+    constexpr int NIT = (SP * (HD / 4) + NT - 1) / NT;
+    f32x4 vq[NIT], vk[NIT], vv[NIT], vo[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = t + it * NT, i = idx / (HD / 4), d = (idx - i * (HD / 4)) * 4;
+      const bool in = i < S && d < hdp;
+      const float* r = base + (size_t)(in ? i : 0) * rowlen + (in ? d : 0);
+      vq[it] = *reinterpret_cast<const f32x4*>(r);
+      vk[it] = *reinterpret_cast<const f32x4*>(r + heads * hdp);
+      vv[it] = *reinterpret_cast<const f32x4*>(r + 2 * heads * hdp);
+      vo[it] = *reinterpret_cast<const f32x4*>(dob + (size_t)(in ? i : 0) * heads * hdp + (in ? d : 0));
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const bool ok = d + e < hd;
-      Q[i * LD + d + e] = ok ? vq[e] : 0.f;
-      K[i * LD + d + e] = ok ? vk[e] : 0.f;
-      V[i * LD + d + e] = ok ? vv[e] : 0.f;
-      dO[i * LD + d + e] = ok ? vo[e] : 0.f;
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = t + it * NT, i = idx / (HD / 4), d = (idx - i * (HD / 4)) * 4;
+      if (idx < SP * (HD / 4)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = i < S && d + e < hd;
+          Q[i * LD + d + e] = ok ? vq[it][e] : 0.f;
+          K[i * LD + d + e] = ok ? vk[it][e] : 0.f;
+          V[i * LD + d + e] = ok ? vv[it][e] : 0.f;
+          dO[i * LD + d + e] = ok ? vo[it][e] : 0.f;
+        }
+      }
     }
   }
   __syncthreads();
@@ -355,20 +364,31 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_mfma_kernel(const bf16*
   bf16* dbase = dqkv + (size_t)b * S * rowlen + h * HDP;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
-  for (int idx = t; idx < SKP * CPR; idx += NW * 64) {
-    const int row = idx / CPR, ch = idx - row * CPR;
-    u32x4 q = zero4, k = zero4, v = zero4, o = zero4;
-    if (row < S) {
-      const bf16* src = base + (size_t)row * rowlen + ch * 8;
-      q = *reinterpret_cast<const u32x4*>(src);
-      k = *reinterpret_cast<const u32x4*>(src + heads * HDP);
-      v = *reinterpret_cast<const u32x4*>(src + 2 * heads * HDP);
-      o = *reinterpret_cast<const u32x4*>(dob + (size_t)row * heads * HDP + ch * 8);
+  {   // all staging loads of the head in flight at once: UNCONDITIONAL on clamped rows (rows >= S are zeroed at the LDS store).  The loop form - `if (row
+      // < S) { 4 loads }`, 4 stores, next iteration - waited for each iteration's loads before issuing the next ones: 4 HBM latencies per head.
+    constexpr int NIT = (SKP * CPR + NW * 64 - 1) / (NW * 64);
+    u32x4 q[NIT], k[NIT], v[NIT], o[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = t + it * NW * 64, row = idx / CPR, ch = idx - row * CPR;
+      const int rc = row < S ? row : S - 1;
+      const bf16* src = base + (size_t)rc * rowlen + ch * 8;
+      q[it] = *reinterpret_cast<const u32x4*>(src);
+      k[it] = *reinterpret_cast<const u32x4*>(src + heads * HDP);
+      v[it] = *reinterpret_cast<const u32x4*>(src + 2 * heads * HDP);
+      o[it] = *reinterpret_cast<const u32x4*>(dob + (size_t)rc * heads * HDP + ch * 8);
     }
-    *reinterpret_cast<u32x4*>(Qr + row * RS + ch * 16) = q;
-    *reinterpret_cast<u32x4*>(Kr + row * RS + ch * 16) = k;
-    *reinterpret_cast<u32x4*>(Vr + row * RS + ch * 16) = v;
-    *reinterpret_cast<u32x4*>(Or + row * RS + ch * 16) = o;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = t + it * NW * 64, row = idx / CPR, ch = idx - row * CPR;
+      if (idx < SKP * CPR) {
+        const bool ok = row < S;
+        *reinterpret_cast<u32x4*>(Qr + row * RS + ch * 16) = ok ? q[it] : zero4;
+        *reinterpret_cast<u32x4*>(Kr + row * RS + ch * 16) = ok ? k[it] : zero4;
+        *reinterpret_cast<u32x4*>(Vr + row * RS + ch * 16) = ok ? v[it] : zero4;
+        *reinterpret_cast<u32x4*>(Or + row * RS + ch * 16) = ok ? o[it] : zero4;
+      }
+    }
   }
   __syncthreads();
 
