@@ -1067,6 +1067,87 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     partial[(size_t)blockIdx.x * 2 * D + d] = red[d] + red[2 * D + d] + red[4 * D + d] + red[6 * D + d];
 }
 
+// ln_bwd_kernel with the row in registers (round 3): a lane owns the channels 4 lane + 256 g .. + 3 (g < NG = ceil(D / 256)); dy / x are read ONCE per
+// row (the kernel above read them for the row statistics and again for dx), the dgamma / dbeta sums live in registers until the end (it did a
+// read-modify-write of LDS per element and row), two rows per wave are in flight.  76 -> ~35 us on the [39 400 x 384] maps of a 200-image DeiT-S step.
+template <typename T, int NG>
+__global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ gamma, const T* add,
+                                                          T* dx, float* __restrict__ partial, int M, int D, int rows_per_blk) {      // (add may be dx: no restrict)
+  extern __shared__ float red[];                       // [4 waves][2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 gam[NG], accb[NG], accg[NG];
+  bool act[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int d = lane * 4 + 256 * g;
+    act[g] = d < D;
+    gam[g] = act[g] ? *reinterpret_cast<const f32x4*>(gamma + d) : f32x4{0.f, 0.f, 0.f, 0.f};
+    accb[g] = accg[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const long r0 = (long)blockIdx.x * rows_per_blk;
+  long rend = r0 + rows_per_blk; rend = rend < M ? rend : M;
+  const float invD = 1.0f / D;
+  for (long row = r0 + wave; row < rend; row += 8) {
+    f32x4 dyv[2][NG], xv[2][NG], av[2][NG];
+    float mu[2], rs[2];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long rr = row + 4 * u;
+      ok[u] = rr < rend;
+      const long rc = ok[u] ? rr : row;
+      mu[u] = mean[rc]; rs[u] = rstd[rc];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int d = act[g] ? lane * 4 + 256 * g : 0;
+        dyv[u][g] = load4<T>(dy + (size_t)rc * D + d);
+        xv[u][g] = load4<T>(x + (size_t)rc * D + d);
+        if (add) av[u][g] = load4<T>(add + (size_t)rc * D + d);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float c1 = 0.f, c2 = 0.f;
+      f32x4 gg[NG], xh[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        xh[g] = (xv[u][g] - mu[u]) * rs[u];
+        gg[g] = dyv[u][g] * gam[g];
+        if (act[g]) {
+          c1 += gg[g][0] + gg[g][1] + gg[g][2] + gg[g][3];
+          c2 += gg[g][0] * xh[g][0] + gg[g][1] * xh[g][1] + gg[g][2] * xh[g][2] + gg[g][3] * xh[g][3];
+        }
+      }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); }
+      c1 *= invD; c2 *= invD;
+      if (ok[u]) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+          if (act[g]) {
+            f32x4 v = (gg[g] - c1 - xh[g] * c2) * rs[u];
+            if (add) v += av[u][g];
+            store4<T>(dx + (size_t)(row + 4 * u) * D + lane * 4 + 256 * g, v);
+            accb[g] += dyv[u][g];
+            accg[g] += dyv[u][g] * xh[g];
+          }
+      }
+    }
+  }
+  float* mine = red + (size_t)wave * 2 * D;
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+    if (act[g]) {
+      const int d = lane * 4 + 256 * g;
+      *reinterpret_cast<f32x4*>(mine + d) = accb[g];
+      *reinterpret_cast<f32x4*>(mine + D + d) = accg[g];
+    }
+  __syncthreads();
+  for (int d = threadIdx.x; d < 2 * D; d += 256)
+    partial[(size_t)blockIdx.x * 2 * D + d] = red[d] + red[2 * D + d] + red[4 * D + d] + red[6 * D + d];
+}
+
 // dbeta[d] = sum_blk partial[blk][0][d], dgamma[d] = sum_blk partial[blk][1][d]  (fp64 accumulation, one wave per channel)
 __global__ __launch_bounds__(256) void ln_param_grad_kernel(const float* __restrict__ partial, int nblk, int D, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), sub = threadIdx.x & 63;
@@ -1446,6 +1527,14 @@ int launch_ln_bwd(const void* dy, const void* x, const float* mean, const float*
   if (D % 4 || (size_t)8 * D * 4 > 64 * 1024) return (int)hipErrorInvalidValue;
   const int nb = ln_bwd_blocks(M), rpb = (M + nb - 1) / nb;
   const size_t lds = (size_t)8 * D * sizeof(float);
+  static const bool rows_off = [] { const char* e = getenv("FSVIT_LN_BWD_ROWS"); return e && e[0] == '0'; }();
+  const int ng = (D + 255) / 256;
+  if (!rows_off && ng <= 4) {
+#define FSVIT_LNB(T, NG) hipLaunchKernelGGL((ln_bwd_rows_kernel<T, NG>), dim3(nb), dim3(256), lds, s, (const T*)dy, (const T*)x, mean, rstd, gamma, (const T*)add, (T*)dx, partial, M, D, rpb)
+    if (dtype == 0) { if (ng == 1) FSVIT_LNB(float, 1); else if (ng == 2) FSVIT_LNB(float, 2); else if (ng == 3) FSVIT_LNB(float, 3); else FSVIT_LNB(float, 4); }
+    else { if (ng == 1) FSVIT_LNB(bf16, 1); else if (ng == 2) FSVIT_LNB(bf16, 2); else if (ng == 3) FSVIT_LNB(bf16, 3); else FSVIT_LNB(bf16, 4); }
+#undef FSVIT_LNB
+  } else
   DISPATCH_T(dtype, hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nb), dim3(256), lds, s, (const float*)dy, (const float*)x, mean, rstd, gamma, (const float*)add, (float*)dx, partial, M, D, rpb),
              hipLaunchKernelGGL(ln_bwd_kernel<bf16>, dim3(nb), dim3(256), lds, s, (const bf16*)dy, (const bf16*)x, mean, rstd, gamma, (const bf16*)add, (bf16*)dx, partial, M, D, rpb));
   hipLaunchKernelGGL(ln_param_grad_kernel, dim3((D + 3) / 4), dim3(256), 0, s, partial, nb, D, dgamma, dbeta);

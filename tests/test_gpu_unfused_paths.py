@@ -102,3 +102,11 @@ def test_fp32_attention_backward_fallback_switch():
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_train.py'), '-q', '-x', '-k', 'attention_backward_vs_torch'],
                        capture_output=True, text=True, timeout=900, env=dict(os.environ, FSVIT_ATTN_BWD_F32_MFMA='0'), cwd=ROOT)
     assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_layernorm_backward_fallback_switch():
+    """FSVIT_LN_BWD_ROWS=0 keeps the two-pass LayerNorm backward kernel (the register-resident one replaced it in round 3): the ViT training-step
+    tests must pass through it as well."""
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_deit.py'), '-q', '-x', '-k', 'vit_train_step_vs_oracle_autograd_small'],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, FSVIT_LN_BWD_ROWS='0'), cwd=ROOT)
+    assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
