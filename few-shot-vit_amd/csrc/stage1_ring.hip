@@ -153,6 +153,16 @@ __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf1
   const unsigned char* const xplane = smem + XR + lq * PITCH;                 // k-chunk kc adds 4 planes
   unsigned char* const h1w = smem + H1R + (g * 4 + lq) * PITCH;                           // this lane's 8 channels = plane lq of the group
   auto conv1 = [&](long P0) {
+    // MODE 2: the multipliers of the batch's four tiles are requested up front (a load issued in a tile's epilogue right before its use exposed one
+    // HBM latency per tile)
+    u32x4 mgp[MODE == 2 ? CH / 16 : 1];
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int mt = 0; mt < CH / 16; ++mt) {
+        const long pp = P0 + mt * 16 + lrow;
+        mgp[mt] = *reinterpret_cast<const u32x4*>(tr.g1 + (size_t)(pp >= 0 && pp < M ? pp : 0) * HID + g * 32 + lq * 8);
+      }
+    }
 #pragma unroll S1R_UNROLL
     for (int mt = 0; mt < CH / 16; ++mt) {
       const int slot = (int)((P0 + mt * 16 + lrow) & (RING - 1)) * 16;
@@ -167,7 +177,7 @@ __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf1
         const long pp = P0 + mt * 16 + lrow;
         const bool inr = pp >= 0 && pp < M;
         const size_t o = (size_t)(inr ? pp : 0) * HID + g * 32 + lq * 8;
-        const bf16x8 mg = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tr.g1 + o));
+        const bf16x8 mg = __builtin_bit_cast(bf16x8, mgp[mt]);
         const u32x4 hp = s1r_pack8(acc[0] * f32x4{(float)mg[0], (float)mg[1], (float)mg[2], (float)mg[3]},
                                    acc[1] * f32x4{(float)mg[4], (float)mg[5], (float)mg[6], (float)mg[7]});
         *reinterpret_cast<u32x4*>(h1w + slot) = hp;
@@ -220,6 +230,14 @@ __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf1
       oyc = rem / W;
       oxc = rem - oyc * W;
     }
+    u32x4 mgq[MODE == 2 ? CH / 16 : 1];                              // MODE 2: the chunk's g1' multipliers, requested before the tap loops
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int mt = 0; mt < CH / 16; ++mt) {
+        const int mm = m0 + mt * 16 + lrow;
+        mgq[mt] = *reinterpret_cast<const u32x4*>(tr.g2 + (size_t)(mm < M ? mm : 0) * HID + g * 32 + lq * 8);
+      }
+    }
 #pragma unroll S1R_UNROLL
     for (int mt = 0; mt < CH / 16; ++mt) {
       const int m = m0 + mt * 16 + lrow;
@@ -242,7 +260,7 @@ __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf1
       }
       if constexpr (MODE == 2) {
         const size_t o = (size_t)(m < M ? m : 0) * HID + g * 32 + lq * 8;
-        const bf16x8 mg = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(tr.g2 + o));
+        const bf16x8 mg = __builtin_bit_cast(bf16x8, mgq[mt]);
         const u32x4 hp = s1r_pack8(acc[0] * f32x4{(float)mg[0], (float)mg[1], (float)mg[2], (float)mg[3]},
                                    acc[1] * f32x4{(float)mg[4], (float)mg[5], (float)mg[6], (float)mg[7]});
         *reinterpret_cast<u32x4*>(h2w + (mt * 16 + lrow) * 16) = hp;
