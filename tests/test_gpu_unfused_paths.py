@@ -47,6 +47,15 @@ def test_general_path_agrees_with_row_kernels(tmp_path, name, img, B, tol):
     assert 0.0 < d <= tol        # different kernels (not bit-identical), same mathematics
 
 
+def test_deit_unfused_attention_switch(tmp_path):
+    """FSVIT_VIT_ATTN_ROWS=0: LayerNorm + qkv (`ln_gemm_rows`) and `attention_v2` as two launches instead of `vit_attn_rows`."""
+    fused = _run(tmp_path, 'deit_small_patch16_224', 224, 3, {}, 'fused')
+    two = _run(tmp_path, 'deit_small_patch16_224', 224, 3, {'FSVIT_VIT_ATTN_ROWS': '0'}, 'two')
+    d = (fused - two).abs().max().item() / max(1.0, float(two.abs().max()))
+    print(f'deit_small_patch16_224: max rel |vit_attn_rows - two launches| = {d:.3e}')
+    assert torch.isfinite(two).all() and d <= 0.04
+
+
 # Every dispatch switch the shipped library still reads (VERDICT r02 weak #12: each one is a product configuration).  The experiment-only knobs
 # (FSVIT_GEMM_TILE, FSVIT_GEMM256_X2, FSVIT_GEMM256_MIN_AI, FSVIT_ATTN_BWD_VALU) were removed; the ones below select a general kernel instead
 # of a fused one and must give the same features within the bf16 mode's own noise.
@@ -89,7 +98,8 @@ def test_every_training_dispatch_switch_agrees_with_the_default_path(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         return torch.load(out)
     base = run({}, 'base')
-    for i, env in enumerate([{'FSVIT_WGRAD3X3': '0'}, {'FSVIT_WGRAD1X1': '0'}, {'FSVIT_GCONV3X3': '0'}, {'FSVIT_WGRAD_SIDE_STREAM': '1'}, {'FSVIT_BN_ROWS': '0'}, {'FSVIT_STAGE1_TRAIN_FUSED': '0'}]):
+    for i, env in enumerate([{'FSVIT_WGRAD3X3': '0'}, {'FSVIT_WGRAD1X1': '0'}, {'FSVIT_GCONV3X3': '0'}, {'FSVIT_WGRAD_SIDE_STREAM': '1'}, {'FSVIT_BN_ROWS': '0'}, {'FSVIT_STAGE1_TRAIN_FUSED': '0'},
+                             {'FSVIT_STAGE1_TRAIN_FUSED': '0', 'FSVIT_GCONV3X3': '0'}]):      # (the grouped-conv kernel only runs on the three-launch route)
         other = run(env, f'tr{i}')
         worst = max(float((other[k] - v).norm() / (v.norm() + 1e-12)) for k, v in base.items() if float(v.norm()) > 1e-5)
         print(f'{env}: worst gradient rel difference to the default path = {worst:.3e}')
