@@ -146,6 +146,9 @@ __global__ __launch_bounds__(NW * 64) void attention_v2_kernel(const T* __restri
                                                                int S, int heads, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int ES = sizeof(T);
+  constexpr bool LIMBS = sizeof(T) == 4 && !__is_same(T, float);      // T = f32x2l (the two-limb modes): fp32 rows in HBM, K / V^T held in LDS as [hi | lo]
+                                                                      // limb words (split once at staging), Q and P split once in registers, every product
+                                                                      // as two 16-bit MFMAs (all four limb products) instead of four exact-fp32 ones
   constexpr int EPC = Elem<T>::kPerChunk;
   constexpr int HDP = NDT * 16;
   constexpr int SKP = NKT * 16;
@@ -196,7 +199,12 @@ __global__ __launch_bounds__(NW * 64) void attention_v2_kernel(const T* __restri
     const int idx = t + it * NW * 64;
     const int row = idx / CPR, ch = idx - row * CPR;
     if (idx >= SKP * CPR) break;
-    const u32x4 k = row < S ? kreg[it] : zero4, v = row < S ? vreg[it] : zero4;
+    u32x4 k = row < S ? kreg[it] : zero4, v = row < S ? vreg[it] : zero4;
+    if constexpr (LIMBS) {
+      u32x4 r_;
+      x2_split(k, k, r_);
+      x2_split(v, v, r_);
+    }
     *reinterpret_cast<u32x4*>(Ks + row * QS + ch * 16) = k;
     if constexpr (ES == 2) {
       // 16-bit storage: V stays ROW-major, as [16-column subtile][key][32 B]; the PV step reads its A fragments (8 keys of one head-dim column
@@ -218,9 +226,12 @@ __global__ __launch_bounds__(NW * 64) void attention_v2_kernel(const T* __restri
     if (qt >= nqt) break;
     const int q = qt * 16 + lrow;
     // Q fragments (row q, 16-byte chunk kc*4 + lq): fetched with the K / V loads above
-    u32x4 qf[NKC];
+    u32x4 qf[NKC], qr[LIMBS ? NKC : 1];
 #pragma unroll
-    for (int kc = 0; kc < NKC; ++kc) qf[kc] = qpre[qi][kc];
+    for (int kc = 0; kc < NKC; ++kc) {
+      qf[kc] = qpre[qi][kc];
+      if constexpr (LIMBS) x2_split(qf[kc], qf[kc], qr[kc]);
+    }
     f32x4 sc[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -230,6 +241,10 @@ __global__ __launch_bounds__(NW * 64) void attention_v2_kernel(const T* __restri
       for (int kc = 0; kc < NKC; ++kc) {
         u32x4 kf = *reinterpret_cast<const u32x4*>(ka + kc * 64);
         if (HALF_TAIL && kc + 1 == NKC && lq >= 2) kf = zero4;                   // beyond the row: the LDS bytes there belong to the pad / the next row
+        if constexpr (LIMBS) {
+          acc = mma_chunk<bf16>(kf, qr[kc], acc);          // lo x hi + hi x lo
+          acc = mma_chunk<bf16>(kf, qf[kc], acc);          // hi x hi + lo x lo
+        } else
         acc = mma_chunk<T>(kf, qf[kc], acc);
       }
       sc[kt] = acc;                      // keys kt*16 + lq*4 + r  x  query lrow
@@ -264,11 +279,23 @@ __global__ __launch_bounds__(NW * 64) void attention_v2_kernel(const T* __restri
     const float inv = 1.0f / sum;
 
     // ctx^T[d][q] = sum_key V^T[d][key] * P[q][key]
+    u32x4 ps[LIMBS ? NKT : 1], pr[LIMBS ? NKT : 1];          // two-limb modes: the (unnormalised) probabilities as limb words, split once per query tile
+    if constexpr (LIMBS) {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) x2_split(__builtin_bit_cast(u32x4, sc[kt]), ps[kt], pr[kt]);
+    }
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       const unsigned char* va = Vt + (dt * 16 + lrow) * VS;
-      if constexpr (ES == 4) {
+      if constexpr (LIMBS) {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+          const u32x4 vf = *reinterpret_cast<const u32x4*>(va + kt * 64 + lq * 16);
+          acc = mma_chunk<bf16>(vf, pr[kt], acc);
+          acc = mma_chunk<bf16>(vf, ps[kt], acc);
+        }
+      } else if constexpr (ES == 4) {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
           const u32x4 vf = *reinterpret_cast<const u32x4*>(va + kt * 64 + lq * 16);
@@ -325,6 +352,12 @@ static int dispatch_ndt(int ndt, const void* qkv, void* ctx, int B, int S, int h
 
 static int launch_attention_v2(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, hipStream_t s) {
   const int ndt = hdp / 16;
+  if (dtype == 2) {                        // two-limb modes (fp32 storage): the float kernel's shapes on the 16-bit MFMA
+    if (S <= 32) return dispatch_ndt<f32x2l, 2, 2>(ndt, qkv, ctx, B, S, heads, scale, s);
+    if (S <= 112) return dispatch_ndt<f32x2l, 7, 4>(ndt, qkv, ctx, B, S, heads, scale, s);
+    if (S <= 208) return dispatch_ndt<f32x2l, 13, 7>(ndt, qkv, ctx, B, S, heads, scale, s);
+    return -1;
+  }
   if (dtype == 0) {
     if (S <= 32) return dispatch_ndt<float, 2, 2>(ndt, qkv, ctx, B, S, heads, scale, s);
 #ifndef ATT_NWF112
@@ -360,6 +393,11 @@ int attention_padded_head_dim(int hd, int S, int dtype) {
 
 int launch_attention(const void* qkv, void* ctx, int B, int S, int heads, int hdp, float scale, int dtype, hipStream_t s) {
   if (B <= 0) return 0;
+  if (dtype == 2) {                        // no two-limb instantiation for this shape: the exact-fp32 kernels take it
+    const int rc = launch_attention_v2(qkv, ctx, B, S, heads, hdp, scale, 2, s);
+    if (rc != -1) return rc;
+    dtype = 0;
+  }
 
   if (S < 1 || hdp % 16 != 0) return (int)hipErrorInvalidValue;
   {

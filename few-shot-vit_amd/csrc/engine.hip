@@ -680,7 +680,7 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
       } else
       RC_TRY(run_gemm(h, st, (sp + ".attn.qkv").c_str(), b.qkv, conv_params(b.qkv, xs, qkv, Bc, Ho, Ho, C, C, 1, 1, 1, 0, 3 * heads * hdp, ACT_NONE, nullptr, 0, nullptr), 3.0 * heads * hd, C));
       RC_TRY(timed(h, st, (sp + ".attn.core").c_str(), KID_ATTN, 4.0 * Bc * heads * (double)S * S * hd,
-                   [&]() { return K(launch_attention)(qkv, ctx, Bc, S, heads, hdp, scale, dt, st); }));
+                   [&]() { return K(launch_attention)(qkv, ctx, Bc, S, heads, hdp, scale, is_x2(h->dtype) ? 2 : dt, st); }));
       }
       if (b.mlp_img && b.mlp_kc) {   // proj + residual + conv1 + GELU + conv3 + residual in one launch
         RC_TRY(timed(h, st, (sp + ".proj+mlp").c_str(), KID_MLPROWS, 2.0 * Bc * S * ((double)C * heads * hd + 2.0 * hidc * C),
@@ -1396,7 +1396,7 @@ int vit_forward_chunk(fsvit_vit* h, const float* x, int Bc, float* feat, unsigne
       RC_TRY(run_gemm(h, st, "blocks.attn.qkv", b.qkv, conv_params(b.qkv, xn, qkv, Bc, S, 1, D, D, 1, 1, 1, 0, 3 * heads * hdp, ACT_NONE, nullptr, 0, nullptr), 3.0 * D, D));
     }
     RC_TRY(timed(h, st, "blocks.attn.core", KID_ATTN, 4.0 * Bc * heads * (double)S * S * h->hd,
-                 [&]() { return K(launch_attention)(qkv, ctx, Bc, S, heads, hdp, scale, dt, st); }));
+                 [&]() { return K(launch_attention)(qkv, ctx, Bc, S, heads, hdp, scale, is_x2(h->dtype) ? 2 : dt, st); }));
     }
     if (b.mlp_img) {
       RC_TRY(timed(h, st, "blocks.proj+norm2+mlp", KID_MLPROWS, 2.0 * M * ((double)heads * h->hd * D + 2.0 * D * h->hid), [&]() {
