@@ -593,7 +593,7 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
       void* zp = take_tmp(t, M * C); NEED(zp);
       T_TRY(bn_fwd(t, p + "norm1.bn", b.x, (int)M, C, ACT_NONE, nullptr, b.xn1, &b.bn1, &pend));
       T_TRY(conv_fwd(t, cs.qkv, b.xn1, B, Ho, Ho, b.qkv, nullptr));
-      T_RUN(launch_attention(b.qkv, b.ctx, B, Ho * Ho, heads, hdp, scale, dt, st));
+      T_RUN(launch_attention(b.qkv, b.ctx, B, Ho * Ho, heads, hdp, scale, t->gdt == 2 ? 2 : dt, st));
       T_TRY(conv_fwd(t, cs.proj, b.ctx, B, Ho, Ho, zp, nullptr));
       b.s1 = dp_scale(t, dp_call, blk, nblk);
       if (t->dp_rate * blk > 0.f) ++dp_call;
@@ -928,7 +928,7 @@ int vit_forward_impl(VT* t, const float* x, float* feat) {
     const float* bqp = nullptr;
     T_TRY(padded_bias(t, bq, 3 * heads * t->hd, t->hd, hdp, &bqp));
     T_TRY(conv_fwd(t, sp.qkv[i], b.xn1, B, S, 1, b.qkv, bqp));
-    T_RUN(launch_attention(b.qkv, b.ctx, B, S, heads, hdp, scale, dt, st));
+    T_RUN(launch_attention(b.qkv, b.ctx, B, S, heads, hdp, scale, t->gdt == 2 ? 2 : dt, st));
     T_TRY(conv_fwd(t, sp.proj[i], b.ctx, B, S, 1, zp, bp->data));
     b.s1 = vit_dp_scale(t, dp_call, i);
     if (t->dp_rate * i > 0.f) ++dp_call;
