@@ -329,6 +329,208 @@ static int launch_bwd_f32mfma(const void* qkv, const void* dctx, void* dqkv, int
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// fp32 MFMA, long sequences (ViT / DeiT: 197 tokens x 64; the `parity` and `bf16x2` ViT trainers): Q, K, V, dO do not fit the LDS together (216 KB),
+// so the head is walked twice, flash-style, with TWO of the four matrices resident at a time (111 KB) and the other two entering as per-lane B operands
+// straight from global memory (16 floats per lane and matrix).  attention_bwd_tiled_f32_kernel (FMA loops) took 9.6 ms per DeiT-S launch = 73 % of a
+// two-limb training step.
+//   pass 1 (K, V resident; a wave owns query blocks): S^T / dP^T over all keys (lane = query lrow, keys 4 lq + r), the softmax statistics
+//          (max, 1 / sum, sum_j P dP) -> LDS, dS in registers, dQ^T = K^T dS^T -> global;
+//   pass 2 (Q, dO resident; a wave owns key blocks): per query block S / dP recomputed in the OTHER orientation (lane = key lrow, queries 4 lq + r),
+//          P and dS from the stored statistics, dV^T += dO^T P, dK^T += Q^T dS -> global.
+// No matrix is ever transposed or staged for the second product of a chain: a 16x16x4 step may sum ANY four k indices as long as both operands agree,
+// so step (tile, r) takes k = lane >> 4 -> index 16 tile + 4 (lane >> 4) + r: the B operand is the lane's own result register [r] of the previous product.
+template <int KT, int DT, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_bwd_f32mfma_long_kernel(const float* __restrict__ qkv, const float* __restrict__ dctx, float* __restrict__ dqkv,
+                                                                             int S, int heads, int hd, int hdp, float scale) {
+  constexpr int SP = KT * 16, HD = DT * 16, LD = HD + 1, NT = NW * 64, KS = HD / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* A0 = reinterpret_cast<float*>(smem);          // pass 1: K, pass 2: Q        [SP][LD]
+  float* A1 = A0 + SP * LD;                            // pass 1: V, pass 2: dO
+  float* st_m = A1 + SP * LD;                          // per query: row maximum (scaled scores), 1 / sum, sum_j P dP
+  float* st_i = st_m + SP;
+  float* st_d = st_i + SP;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lrow = lane & 15, lq = lane >> 4;
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const int rowlen = 3 * heads * hdp;
+  const float* base = qkv + (size_t)b * S * rowlen + h * hdp;
+  const float* dob = dctx + (size_t)b * S * heads * hdp + h * hdp;
+  const size_t dorow = (size_t)heads * hdp;
+  float* dq = dqkv + (size_t)b * S * rowlen + h * hdp;
+  // two matrices ([S][hd], row strides sa / sb floats) -> A0 / A1, zero padded; all loads in flight before the first LDS store
+  auto stage2 = [&](const float* pa, size_t sa, const float* pb, size_t sb) {
+    constexpr int NIT = (SP * (HD / 4) + NT - 1) / NT;
+    f32x4 va[NIT], vb[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = t + it * NT, i = idx / (HD / 4), d = (idx - i * (HD / 4)) * 4;
+      const bool in = i < S && d < hdp;
+      va[it] = *reinterpret_cast<const f32x4*>(pa + (size_t)(in ? i : 0) * sa + (in ? d : 0));
+      vb[it] = *reinterpret_cast<const f32x4*>(pb + (size_t)(in ? i : 0) * sb + (in ? d : 0));
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = t + it * NT, i = idx / (HD / 4), d = (idx - i * (HD / 4)) * 4;
+      if (idx < SP * (HD / 4)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = i < S && d + e < hd;
+          A0[i * LD + d + e] = ok ? va[it][e] : 0.f;
+          A1[i * LD + d + e] = ok ? vb[it][e] : 0.f;
+        }
+      }
+    }
+  };
+  // the rows blk * 16 + lrow of a matrix as B operands: element [k = 4 s + lq] for the KS steps (zero past the row / the head dim)
+  auto rows_b = [&](const float* pm, size_t stride, int blk, float (&o)[KS]) {
+    const int row = blk * 16 + lrow;
+#pragma unroll
+    for (int s0 = 0; s0 < KS; ++s0) {
+      const int d = 4 * s0 + lq;
+      const bool in = row < S && d < hd;
+      const float v = pm[(size_t)(in ? row : 0) * stride + (in ? d : 0)];
+      o[s0] = in ? v : 0.f;
+    }
+  };
+
+  // ---------------- pass 1
+  stage2(base + heads * hdp, rowlen, base + 2 * heads * hdp, rowlen);          // K, V
+  __syncthreads();
+  for (int qb = wave; qb < KT; qb += NW) {
+    float bq[KS], bo[KS];
+    rows_b(base, rowlen, qb, bq);
+    rows_b(dob, dorow, qb, bo);
+    f32x4 sc[KT], dp[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) sc[kt] = dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s0 = 0; s0 < KS; ++s0) {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        sc[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[(kt * 16 + lrow) * LD + 4 * s0 + lq], bq[s0], sc[kt], 0, 0, 0);
+        dp[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[(kt * 16 + lrow) * LD + 4 * s0 + lq], bo[s0], dp[kt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);               // (keeps hipcc from hoisting every fragment read of the 416-MFMA block to its top: 98 spilled VGPRs)
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = kt * 16 + 4 * lq + r < S ? sc[kt][r] * scale : -INFINITY;
+        sc[kt][r] = v;
+        m = fmaxf(m, v);
+      }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float e = expf(sc[kt][r] - m); sc[kt][r] = e; sum += e; }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    float dot = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float pr = sc[kt][r] * inv; sc[kt][r] = pr; dot += pr * dp[kt][r]; }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    const int qrow = qb * 16 + lrow;
+    if (lq == 0) { st_m[qrow] = m; st_i[qrow] = qrow < S ? inv : 0.f; st_d[qrow] = dot; }      // (queries past the end: P = 0 in pass 2)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sc[kt][r] = scale * sc[kt][r] * (dp[kt][r] - dot);           // dS
+    // dQ^T[d][q] = sum_key K[key][d] dS[q][key]: step (kt, r) sums the keys 16 kt + 4 lq + r
+    f32x4 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[(kt * 16 + 4 * lq + r) * LD + dt * 16 + lrow], sc[kt][r], acc[dt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (qrow < S) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = dt * 16 + 4 * lq;
+        if (d + 3 < hdp) *reinterpret_cast<f32x4*>(dq + (size_t)qrow * rowlen + d) = acc[dt];   // (columns hd .. hdp: K is zero there -> exact zeros)
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (d + r < hdp) dq[(size_t)qrow * rowlen + d + r] = acc[dt][r];
+      }
+    }
+  }
+  __syncthreads();
+  // ---------------- pass 2
+  stage2(base, rowlen, dob, dorow);                                            // Q, dO
+  __syncthreads();
+  for (int kb = wave; kb < KT; kb += NW) {
+    float bk[KS], bv[KS];
+    rows_b(base + heads * hdp, rowlen, kb, bk);
+    rows_b(base + 2 * heads * hdp, rowlen, kb, bv);
+    const bool key_ok = kb * 16 + lrow < S;
+    f32x4 accV[DT], accK[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) accV[dt] = accK[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int qb = 0; qb < KT; ++qb) {
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, p4 = s4;          // lane = key lrow, queries qb*16 + 4 lq + r
+#pragma unroll
+      for (int s0 = 0; s0 < KS; ++s0) {
+        s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[(qb * 16 + lrow) * LD + 4 * s0 + lq], bk[s0], s4, 0, 0, 0);
+        p4 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[(qb * 16 + lrow) * LD + 4 * s0 + lq], bv[s0], p4, 0, 0, 0);
+      }
+      const f32x4 m4 = *reinterpret_cast<const f32x4*>(st_m + qb * 16 + 4 * lq), i4 = *reinterpret_cast<const f32x4*>(st_i + qb * 16 + 4 * lq),
+                  d4 = *reinterpret_cast<const f32x4*>(st_d + qb * 16 + 4 * lq);
+      f32x4 P, dS;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pr = key_ok ? expf(s4[r] * scale - m4[r]) * i4[r] : 0.f;
+        P[r] = pr;
+        dS[r] = scale * pr * (p4[r] - d4[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          accV[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[(qb * 16 + 4 * lq + r) * LD + dt * 16 + lrow], P[r], accV[dt], 0, 0, 0);
+          accK[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[(qb * 16 + 4 * lq + r) * LD + dt * 16 + lrow], dS[r], accK[dt], 0, 0, 0);
+        }
+    }
+    const int key = kb * 16 + lrow;
+    if (key < S) {
+      float* rk = dq + (size_t)key * rowlen + heads * hdp;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = dt * 16 + 4 * lq;
+        if (d + 3 < hdp) { *reinterpret_cast<f32x4*>(rk + d) = accK[dt]; *reinterpret_cast<f32x4*>(rk + heads * hdp + d) = accV[dt]; }
+        else
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (d + r < hdp) { rk[d + r] = accK[dt][r]; rk[heads * hdp + d + r] = accV[dt][r]; }
+      }
+    }
+  }
+}
+
+template <int KT, int DT, int NW>
+static int launch_bwd_f32mfma_long(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, int hd, int hdp, float scale, hipStream_t s) {
+  constexpr int SP = KT * 16, LD = DT * 16 + 1;
+  const size_t lds = ((size_t)2 * SP * LD + (size_t)3 * SP) * sizeof(float);
+  if ((hdp & 3) || hdp > DT * 16) return (int)hipErrorInvalidValue;
+  auto kern = attention_bwd_f32mfma_long_kernel<KT, DT, NW>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kern, dim3(B * heads), dim3(NW * 64), lds, s, (const float*)qkv, (const float*)dctx, (float*)dqkv, S, heads, hd, hdp, scale);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // bf16 MFMA version.  One workgroup per (image, head); S <= 224 keys, everything of the head lives in LDS, ROW-major only:
 //   Q, K, V, dO  [SKP][HDP]   score-type products read 16-byte k-chunks of a row; the three products that contract over keys / queries take
 //   their A operand (8 consecutive rows of one column) from the same images with ds_read_b64_tr_b16 (tools/probes/tr_read_probe.hip) -
@@ -578,6 +780,7 @@ int launch_attention_bwd(const void* qkv, const void* dctx, void* dqkv, int B, i
       if (S <= 32 && hdp <= 96) return launch_bwd_f32mfma<2, 6>(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, s);
       if (S <= 48 && hdp <= 64) return launch_bwd_f32mfma<3, 4>(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, s);
       if (S <= 112 && hdp <= 48) return launch_bwd_f32mfma<7, 3>(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, s);
+      if (S <= 208 && hdp <= 64) return launch_bwd_f32mfma_long<13, 4, 7>(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, s);      // ViT / DeiT: 196 patches + cls
     }
   }
   const size_t lds = ((size_t)4 * S * (hd + 1) + (size_t)2 * S * (S + 1)) * sizeof(float);
