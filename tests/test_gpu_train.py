@@ -694,3 +694,29 @@ def test_bf16_meta_tuning_reaches_the_parity_tuned_accuracy():
     assert l1_b < l0_b and l1_p < l0_p
     assert abs(l1_b - l1_p) <= 0.05 * max(l1_p, 1e-3) + 0.02
     assert abs(acc_b - acc_p) <= max(ci_b, ci_p)
+
+
+@pytest.mark.parametrize('numerics', ['bf16', 'parity', 'bf16x2'])
+def test_training_step_is_bit_reproducible(numerics):
+    """No atomics on the training path: split-K slabs are summed in fixed order, the attention backward kernels give every output element ONE owner, the
+    BatchNorm partials are reduced in block order - the same step twice gives the same bits (logits and every gradient)."""
+    from fewshot_vit_amd import models, synthetic
+    m = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={'numerics': numerics, 'drop_path_rate': 0.5})
+    m.load_state_dict(synthetic.synthetic_checkpoint_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}), strict=True)
+    m = m.cuda().train()
+    E, way, shot, query = 2, 5, 2, 3
+    xs, xq, label = _full_size_batch(E, way, shot, query)
+    masks = (torch.rand(m.encoder.trainer().n_droppath_calls(0.5), E * way * (shot + query), generator=torch.Generator().manual_seed(3)) > 0.3).float().cuda()
+    m.encoder.draw_droppath_masks = lambda n, dev: masks
+    runs = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+        logits = m(xs, xq).view(-1, way)
+        F.cross_entropy(logits, label).backward()
+        torch.cuda.synchronize()
+        runs.append((logits.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+        m.load_state_dict(sd0)                      # (running statistics back to where they were)
+    assert torch.equal(runs[0][0], runs[1][0])
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
