@@ -22,7 +22,10 @@ def _check_generation(ctx):
 class VisformerTrainFn(torch.autograd.Function):
     """feat = encoder(x) in train mode.  `params` are passed as inputs so autograd routes their gradients.  With a gradient sink
     (`trainer.grad_sink`: name -> (parameter, view into parallel.GradBucket's flat buffer)) the trainer writes every gradient straight into
-    the bucket, `.grad` is pointed at the view and autograd is handed None for those inputs (overwrite semantics: one backward per step)."""
+    the bucket, `.grad` is pointed at the view and autograd is handed None for those inputs.  That overwrites, so it is only taken when
+    every `.grad` is None (the state `optimizer.zero_grad()` leaves: train_meta.py:168-170 zero_grad / backward / step); with a gradient
+    already in place (a second backward before the step, a second train-mode encoder call in one graph, zero_grad(set_to_none=False)) the
+    gradients are returned to autograd, which ACCUMULATES them - into the bucket views when `.grad` is one - exactly as without a sink."""
 
     @staticmethod
     def forward(ctx, x, trainer, names, buffers, drop_path_rate, masks, *params):
@@ -40,7 +43,7 @@ class VisformerTrainFn(torch.autograd.Function):
         params = ctx.saved_tensors
         tensors = dict(zip(ctx.names, params))
         sink = ctx.sink
-        if sink is not None and all(k in sink and sink[k][1].shape == tensors[k].shape for k in ctx.names):
+        if sink is not None and all(k in sink and sink[k][1].shape == tensors[k].shape and sink[k][0].grad is None for k in ctx.names):
             grads = {k: sink[k][1] for k in ctx.names}
             tensors.update(ctx.buffers)
             ctx.trainer.backward(tensors, grads, dfeat)

@@ -50,7 +50,6 @@ int fsvit_set_error(int code, const char* fmt, ...) {      // shared with train_
   va_end(ap);
   return code;
 }
-extern "C" int fsvit_set_error_public(int code, const char* msg) { return fsvit_set_error(code, "%s", msg); }   // transform.hip
 static int hipfail(hipError_t e, const char* what) {
   return fail((int)e, "%s: %s", what, hipGetErrorString(e));
 }
@@ -231,32 +230,98 @@ int upload(EngineBase* h, const std::vector<float>& src, bool as_storage, void**
   return 0;
 }
 
+// ---- weight-rounding bias correction of the 16-bit modes (restated by oracle/visformer_emul.py operand_means / _corr)
+// Rounding a folded weight W'[n][k] to the 16-bit type is the same perturbation dW for every token of every image, so its mean effect
+// sum_k dW[n][k] E[a_k] survives the average pooling.  E[a_k] is in the checkpoint: the running mean of the BatchNorm that sees the operand
+// (pre-norm 1x1 convs: exact), 0 for the normalised image, and elsewhere the mean of the activation of a Gaussian pre-activation whose
+// moments follow from the preceding BatchNorm's (beta, gamma) under channel independence.  The correction is folded into the fp32 bias at
+// pack time: no run-time cost.  Bias-free convs that feed the residual stream (conv3 / proj of a block) hand their correction on as a
+// per-channel constant of the stream (`cst`), which is folded into the bias of every later consumer (W' cst) and into the pooled feature.
+struct WRound {
+  bool on = false, f16 = false;
+  std::vector<double> cst;                       // deferred constant of the residual stream
+  double rounded(double v) const {               // the value the 16-bit weight image holds for v
+    const float f = (float)v;
+    if (f16) return (double)f16_to_f32(f32_to_f16(f));
+    uint32_t u = (uint32_t)f32_to_bf16(f) << 16;
+    float r; memcpy(&r, &u, 4);
+    return (double)r;
+  }
+};
+
+// fraction of the output positions of a k x k conv (stride, zero padding pad) on an H x H map whose tap (ky, kx) lies inside the map
+std::vector<double> tap_fraction(int H, int stride, int k, int pad) {
+  const int Ho = (H + 2 * pad - k) / stride + 1;
+  std::vector<double> f1(k), f((size_t)k * k);
+  for (int t = 0; t < k; ++t) {
+    int in = 0;
+    for (int o = 0; o < Ho; ++o) { const int pos = o * stride - pad + t; in += (pos >= 0 && pos < H); }
+    f1[t] = (double)in / Ho;
+  }
+  for (int y = 0; y < k; ++y) for (int x = 0; x < k; ++x) f[(size_t)y * k + x] = f1[y] * f1[x];
+  return f;
+}
+
+inline double gelu_exact(double z) { return 0.5 * z * (1.0 + std::erf(z * 0.7071067811865476)); }
+
+// E[GELU(y)] and Var[GELU(y)] for y ~ N(mu, sig^2): trapezoid rule on z in [-8, 8], 257 nodes
+void gauss_moments_gelu(double mu, double sig, double* mean, double* var) {
+  double sw = 0, s1 = 0, s2 = 0;
+  for (int j = 0; j <= 256; ++j) {
+    const double z = -8.0 + j / 16.0, w = std::exp(-0.5 * z * z), v = gelu_exact(mu + sig * z);
+    sw += w; s1 += w * v; s2 += w * v * v;
+  }
+  *mean = s1 / sw;
+  *var = std::max(0.0, s2 / sw - (s1 / sw) * (s1 / sw));
+}
+
+// E[LeakyReLU_0.1(N(mu, sig^2))] = mu (0.1 + 0.9 Phi(mu / sig)) + 0.9 sig phi(mu / sig)
+double lrelu_mean(double mu, double sig) {
+  if (sig <= 0) return mu > 0 ? mu : 0.1 * mu;
+  const double t = mu / sig;
+  return mu * (0.1 + 0.9 * 0.5 * (1.0 + std::erf(t * 0.7071067811865476))) + 0.9 * sig * std::exp(-0.5 * t * t) * 0.3989422804014327;
+}
+
 // Pack a conv weight W[O][Ig][KH][KW] (O = groups*N) into [groups][N][Kw], k = (ky*KW+kx)*Ig + c,
 // with optional per-output-channel scale (BN after the conv) and per-input-channel scale (BN before
 // a 1x1 conv).  `rowmap`/`colmap` (optional) scatter rows / K columns (head-dim padding).
+// Weight-rounding correction (wr != null and on): `in_mean` [groups*Ig] = E[operand channel], `tapf` [KH*KW] = tap_fraction or null;
+// the correction -sum_k dW f_tap E[a] and (`use_cst`) the stream constant's image sum_k W' cst go into the bias; a bias-free layer
+// returns its correction in `corr_out` [O] instead.
 int pack_layer(EngineBase* h, Layer* L, const float* W, int O, int Ig, int KH, int KW, int groups,
                const std::vector<double>* out_scale, const std::vector<double>* in_scale,
                const std::vector<double>& bias, bool has_bias,
-               const std::vector<int>* rowmap, int Npad, const std::vector<int>* colmap, int Kpad) {
+               const std::vector<int>* rowmap, int Npad, const std::vector<int>* colmap, int Kpad,
+               const WRound* wr = nullptr, const std::vector<double>* in_mean = nullptr, const double* tapf = nullptr,
+               bool use_cst = false, std::vector<double>* corr_out = nullptr) {
   const int bke = 128 / h->es;
   const int N = (rowmap ? Npad : O) / groups;
   const int K = colmap ? Kpad : KH * KW * Ig;
   const int Kw = round_up(K, bke);
+  const bool fix = wr && wr->on && in_mean;
+  const bool cst = wr && wr->on && use_cst && !wr->cst.empty();
+  if (corr_out) corr_out->assign(O, 0.0);
   std::vector<float> pk((size_t)groups * N * Kw, 0.0f);
   std::vector<float> pb((size_t)groups * N, 0.0f);
   for (int o = 0; o < O; ++o) {
     const int row = rowmap ? (*rowmap)[o] : o;
     const double so = out_scale ? (*out_scale)[o] : 1.0;
+    const int g0 = (o / (O / groups)) * Ig;
+    double corr = 0.0, wc = 0.0;
     for (int c = 0; c < Ig; ++c) {
       const double si = in_scale ? (*in_scale)[c] : 1.0;
       for (int ky = 0; ky < KH; ++ky)
         for (int kx = 0; kx < KW; ++kx) {
           int k = (ky * KW + kx) * Ig + c;
           if (colmap) k = (*colmap)[k];
-          pk[(size_t)row * Kw + k] = (float)((double)W[(((size_t)o * Ig + c) * KH + ky) * KW + kx] * so * si);
+          const double v = (double)W[(((size_t)o * Ig + c) * KH + ky) * KW + kx] * so * si;
+          pk[(size_t)row * Kw + k] = (float)v;
+          if (fix) corr -= (wr->rounded(v) - v) * (tapf ? tapf[ky * KW + kx] : 1.0) * (*in_mean)[g0 + c];
+          if (cst) wc += v * wr->cst[g0 + c];
         }
     }
-    if (has_bias) pb[row] = (float)bias[o];
+    if (has_bias) pb[row] = (float)(bias[o] + corr + wc);
+    else if (corr_out) (*corr_out)[o] = corr;
   }
   L->N = N; L->K = K; L->Kw = Kw; L->groups = groups;
   RC_TRY(upload(h, pk, true, &L->w));
@@ -312,6 +377,15 @@ int build(fsvit_visformer* h, const SD& sd) {
   if (h->H2 * h->H2 > 128) return fail(FSVIT_ERR_ARG, "attention supports at most 128 tokens (img_size <= 88)");
 
   std::vector<double> nob;
+  WRound wr;                                    // weight-rounding bias correction: the 16-bit modes only (the two-limb modes carry 16+ bits)
+  wr.on = kdt == FSVIT_BF16 || kdt == FSVIT_F16;
+  wr.f16 = kdt == FSVIT_F16;
+  auto vec = [&](const std::string& name, int C, bool absolute) {      // a [C] state-dict entry as doubles (checked by bn_affine before)
+    const float* p = sd.get(name, {C});
+    std::vector<double> v(C, 0.0);
+    for (int c = 0; p && c < C; ++c) v[c] = absolute ? std::fabs((double)p[c]) : (double)p[c];
+    return v;
+  };
   // ---- stem (visformer.py:202-239): conv -> BN folded as per-output-channel scale + shift
   {
     const float* w1 = sd.get("stem.conv1.weight", {h->C0, 3, 3, 3});
@@ -324,21 +398,34 @@ int build(fsvit_visformer* h, const SD& sd) {
     // conv1 / downsample consume the 32-wide im2col rows: K columns 0..26 = (ky,kx,c), 27..31 = 0
     std::vector<int> cm(27);
     for (int k = 0; k < 27; ++k) cm[k] = k;
+    // operand means: the normalised image 0 (no correction for conv1 / downsample); conv2 / conv3 read LeakyReLU(BN(z)), z_c ~ N(beta_c, gamma_c^2)
+    std::vector<double> m2(h->C0), m3(h->C1);
+    {
+      const std::vector<double> be1 = vec("stem.bn1.bias", h->C0, false), ga1 = vec("stem.bn1.weight", h->C0, true);
+      const std::vector<double> be2 = vec("stem.bn2.bias", h->C1, false), ga2 = vec("stem.bn2.weight", h->C1, true);
+      for (int c = 0; c < h->C0; ++c) m2[c] = lrelu_mean(be1[c], ga1[c]);
+      for (int c = 0; c < h->C1; ++c) m3[c] = lrelu_mean(be2[c], ga2[c]);
+    }
+    const std::vector<double> tf0 = tap_fraction(h->H0, 1, 3, 1);
     RC_TRY(pack_layer(h, &h->conv1, w1, h->C0, 3, 3, 3, 1, &b1.s, nullptr, b1.t, true, nullptr, 0, &cm, 32));
     RC_TRY(pack_layer(h, &h->down, wd, h->C1, 3, 3, 3, 1, &bd.s, nullptr, bd.t, true, nullptr, 0, &cm, 32));
-    RC_TRY(pack_layer(h, &h->conv2, w2, h->C1, h->C0, 3, 3, 1, &b2.s, nullptr, b2.t, true, nullptr, 0, nullptr, 0));
-    RC_TRY(pack_layer(h, &h->conv3, w3, h->C1, h->C1, 3, 3, 1, &b3.s, nullptr, b3.t, true, nullptr, 0, nullptr, 0));
+    RC_TRY(pack_layer(h, &h->conv2, w2, h->C1, h->C0, 3, 3, 1, &b2.s, nullptr, b2.t, true, nullptr, 0, nullptr, 0, &wr, &m2, tf0.data()));
+    RC_TRY(pack_layer(h, &h->conv3, w3, h->C1, h->C1, 3, 3, 1, &b3.s, nullptr, b3.t, true, nullptr, 0, nullptr, 0, &wr, &m3, tf0.data()));
     {  // conv3f rows = [ bn3-scaled conv3 (K = 9*C1, padded to the K slice) | one tail slice: bn_d-scaled downsample taps ]
       const int bke = 128 / h->es, K = 9 * h->C1, Kmain = round_up(K, bke), Kw = Kmain + bke;
       std::vector<float> pk((size_t)h->C1 * Kw, 0.0f), pb(h->C1);
       for (int o = 0; o < h->C1; ++o) {
+        double corr = 0.0;
         for (int c = 0; c < h->C1; ++c)
-          for (int t9 = 0; t9 < 9; ++t9)
-            pk[(size_t)o * Kw + t9 * h->C1 + c] = (float)((double)w3[((size_t)o * h->C1 + c) * 9 + t9] * b3.s[o]);
+          for (int t9 = 0; t9 < 9; ++t9) {
+            const double v = (double)w3[((size_t)o * h->C1 + c) * 9 + t9] * b3.s[o];
+            pk[(size_t)o * Kw + t9 * h->C1 + c] = (float)v;
+            if (wr.on) corr -= (wr.rounded(v) - v) * tf0[t9] * m3[c];
+          }
         for (int c = 0; c < 3; ++c)
           for (int t9 = 0; t9 < 9; ++t9)
             pk[(size_t)o * Kw + Kmain + t9 * 3 + c] = (float)((double)wd[((size_t)o * 3 + c) * 9 + t9] * bd.s[o]);
-        pb[o] = (float)(b3.t[o] + bd.t[o]);
+        pb[o] = (float)(b3.t[o] + bd.t[o] + corr);
       }
       h->conv3f.N = h->C1; h->conv3f.K = K; h->conv3f.Kw = Kw; h->conv3f.groups = 1;
       RC_TRY(upload(h, pk, true, &h->conv3f.w));
@@ -355,6 +442,7 @@ int build(fsvit_visformer* h, const SD& sd) {
     RC_TRY(pack_pos(h, p3, h->C3, h->H3 * h->H3, &h->pos3));
   }
   // ---- stage 1 (Block with attn_disabled, spatial_conv; visformer.py:241-263, Mlp :127-163)
+  std::vector<double> x_mean;                   // WRound: estimated mean of the residual stream where the next PatchEmbed reads it
   h->s1.resize(cf.depth[0]);
   for (int i = 0; i < cf.depth[0]; ++i) {
     const std::string p = "stage1." + std::to_string(i) + ".";
@@ -363,9 +451,44 @@ int build(fsvit_visformer* h, const SD& sd) {
     const float* w2 = sd.get(p + "mlp.conv2.weight", {h->hid1, Cg, 3, 3});
     const float* w3 = sd.get(p + "mlp.conv3.weight", {h->C1, h->hid1, 1, 1});
     if (!n2.ok || !w1 || !w2 || !w3) return FSVIT_ERR_KEY;
-    RC_TRY(pack_layer(h, &h->s1[i].c1, w1, h->hid1, h->C1, 1, 1, 1, nullptr, &n2.s, prenorm_bias(w1, h->hid1, h->C1, n2.t), true, nullptr, 0, nullptr, 0));
+    // operand means: conv1 reads the stream the BatchNorm saw (running mean); conv3 reads h2 = GELU(conv2(h1)), h1 = GELU(conv1(BN(x))) with
+    // Gaussian pre-activations; the grouped conv2 has no bias and a GELU behind it: not corrected
+    const std::vector<double> rm = vec(p + "norm2.bn.running_mean", h->C1, false);
+    std::vector<double> mh2(h->hid1, 0.0), corr3;
+    if (wr.on) {
+      if (wr.cst.empty()) wr.cst.assign(h->C1, 0.0);
+      const std::vector<double> be = vec(p + "norm2.bn.bias", h->C1, false), ga = vec(p + "norm2.bn.weight", h->C1, true);
+      const std::vector<double> tf1 = tap_fraction(h->H1, 1, 3, 1);
+      std::vector<double> mh1(h->hid1), vh1(h->hid1);
+      for (int n = 0; n < h->hid1; ++n) {
+        double mu = 0, var = 0;
+        for (int c = 0; c < h->C1; ++c) { const double w = w1[(size_t)n * h->C1 + c]; mu += w * be[c]; var += w * w * ga[c] * ga[c]; }
+        gauss_moments_gelu(mu, std::sqrt(var), &mh1[n], &vh1[n]);
+      }
+      for (int n = 0; n < h->hid1; ++n) {
+        const int g0 = (n / (h->hid1 / cf.group)) * Cg;
+        double mu = 0, var = 0, dummy;
+        for (int c = 0; c < Cg; ++c)
+          for (int t9 = 0; t9 < 9; ++t9) {
+            const double w = w2[((size_t)n * Cg + c) * 9 + t9];
+            mu += w * tf1[t9] * mh1[g0 + c]; var += w * w * tf1[t9] * vh1[g0 + c];
+          }
+        gauss_moments_gelu(mu, std::sqrt(var), &mh2[n], &dummy);
+      }
+    }
+    RC_TRY(pack_layer(h, &h->s1[i].c1, w1, h->hid1, h->C1, 1, 1, 1, nullptr, &n2.s, prenorm_bias(w1, h->hid1, h->C1, n2.t), true, nullptr, 0, nullptr, 0,
+                      &wr, &rm, nullptr, true));
     RC_TRY(pack_layer(h, &h->s1[i].c2, w2, h->hid1, Cg, 3, 3, cf.group, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
-    RC_TRY(pack_layer(h, &h->s1[i].c3, w3, h->C1, h->hid1, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
+    RC_TRY(pack_layer(h, &h->s1[i].c3, w3, h->C1, h->hid1, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0, &wr, &mh2, nullptr, false, &corr3));
+    if (wr.on) {
+      x_mean.assign(h->C1, 0.0);                  // E[x] behind this block = running mean + conv3 E[h2]: the next PatchEmbed's operand mean
+      for (int o = 0; o < h->C1; ++o) {
+        double a = rm[o];
+        for (int c = 0; c < h->hid1; ++c) a += (double)w3[(size_t)o * h->hid1 + c] * mh2[c];
+        x_mean[o] = a;
+        wr.cst[o] += corr3[o];
+      }
+    }
     if (K(stage1_fused_supported)(kd(kdt), h->C1, h->hid1, cf.group, h->H1)) {
       void* img = nullptr;
       HIP_TRY(hipMalloc(&img, K(stage1_image_bytes)()));
@@ -375,8 +498,10 @@ int build(fsvit_visformer* h, const SD& sd) {
       h->s1[i].img = img;
     }
   }
-  // ---- patch embeds (visformer.py:266-288): conv k2 s2 + bias -> BN ; pos_embed added in the epilogue
+  // ---- per stage s = 2, 3: PatchEmbed (visformer.py:266-288: conv k2 s2 + bias -> BN ; pos_embed added in the epilogue), then its
+  // attention + MLP blocks (Attention :166-194, Block :259-263)
   for (int s = 2; s <= 3; ++s) {
+   {
     const int Ci = s == 2 ? h->C1 : h->C2, Co = s == 2 ? h->C2 : h->C3;
     const std::string p = "patch_embed" + std::to_string(s) + ".";
     const float* w = sd.get(p + "proj.weight", {Co, Ci, 2, 2});
@@ -385,7 +510,9 @@ int build(fsvit_visformer* h, const SD& sd) {
     if (!w || !b || !bn.ok) return FSVIT_ERR_KEY;
     std::vector<double> bias(Co);
     for (int o = 0; o < Co; ++o) bias[o] = bn.s[o] * (double)b[o] + bn.t[o];
-    RC_TRY(pack_layer(h, s == 2 ? &h->pe2 : &h->pe3, w, Co, Ci, 2, 2, 1, &bn.s, nullptr, bias, true, nullptr, 0, nullptr, 0));
+    // WRound: the operand is the residual stream leaving the previous stage (estimated mean x_mean); its deferred constant ends here
+    RC_TRY(pack_layer(h, s == 2 ? &h->pe2 : &h->pe3, w, Co, Ci, 2, 2, 1, &bn.s, nullptr, bias, true, nullptr, 0, nullptr, 0, &wr, &x_mean, nullptr, true));
+    if (wr.on) wr.cst.assign(Co, 0.0);
     const Layer& pe = s == 2 ? h->pe2 : h->pe3;
     if (K(patch_embed_rows_supported)(kd(kdt), Ci, s == 2 ? h->H1 : h->H2, Co) && pe.Kw == 4 * Ci) {
       void* img = nullptr;
@@ -395,9 +522,7 @@ int build(fsvit_visformer* h, const SD& sd) {
       HIP_TRY(hipDeviceSynchronize());
       h->pe_img[s - 2] = img;
     }
-  }
-  // ---- stages 2, 3 (attention + MLP blocks; Attention :166-194, Block :259-263)
-  for (int s = 2; s <= 3; ++s) {
+   }
     const int C = s == 2 ? h->C2 : h->C3, hid = s == 2 ? h->hid2 : h->hid3;
     const int hd = s == 2 ? h->hd2 : h->hd3, hdp = s == 2 ? h->hdp2 : h->hdp3;
     const int heads = cf.num_heads;
@@ -419,10 +544,39 @@ int build(fsvit_visformer* h, const SD& sd) {
       const float* w1 = sd.get(p + "mlp.conv1.weight", {hid, C, 1, 1});
       const float* w3 = sd.get(p + "mlp.conv3.weight", {C, hid, 1, 1});
       if (!n1.ok || !n2.ok || !wq || !wp || !w1 || !w3) return FSVIT_ERR_KEY;
-      RC_TRY(pack_layer(h, &blocks[i].qkv, wq, 3 * heads * hd, C, 1, 1, 1, nullptr, &n1.s, prenorm_bias(wq, 3 * heads * hd, C, n1.t), true, &rowmap, 3 * heads * hdp, nullptr, 0));
-      RC_TRY(pack_layer(h, &blocks[i].proj, wp, C, heads * hd, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, &colmap, heads * hdp));
-      RC_TRY(pack_layer(h, &blocks[i].fc1, w1, hid, C, 1, 1, 1, nullptr, &n2.s, prenorm_bias(w1, hid, C, n2.t), true, nullptr, 0, nullptr, 0));
-      RC_TRY(pack_layer(h, &blocks[i].fc2, w3, C, hid, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
+      // WRound operand means: qkv / conv1 read the stream their BatchNorm saw (running means); proj reads ctx, E[ctx] ~ E[v] = W_v beta_1
+      // (softmax rows sum to 1); conv3 reads GELU of a Gaussian pre-activation N(W1 beta_2, W1^2 gamma_2^2)
+      const std::vector<double> rm1 = vec(p + "norm1.bn.running_mean", C, false), rm2 = vec(p + "norm2.bn.running_mean", C, false);
+      std::vector<double> mctx(heads * hd, 0.0), mh(hid, 0.0), corr_p, corr_3;
+      if (wr.on) {
+        const std::vector<double> be1 = vec(p + "norm1.bn.bias", C, false);
+        const std::vector<double> be2 = vec(p + "norm2.bn.bias", C, false), ga2 = vec(p + "norm2.bn.weight", C, true);
+        for (int n = 0; n < heads * hd; ++n) {
+          double a = 0;
+          for (int c = 0; c < C; ++c) a += (double)wq[((size_t)2 * heads * hd + n) * C + c] * be1[c];
+          mctx[n] = a;
+        }
+        for (int n = 0; n < hid; ++n) {
+          double mu = 0, var = 0, dummy;
+          for (int c = 0; c < C; ++c) { const double w = w1[(size_t)n * C + c]; mu += w * be2[c]; var += w * w * ga2[c] * ga2[c]; }
+          gauss_moments_gelu(mu, std::sqrt(var), &mh[n], &dummy);
+        }
+      }
+      RC_TRY(pack_layer(h, &blocks[i].qkv, wq, 3 * heads * hd, C, 1, 1, 1, nullptr, &n1.s, prenorm_bias(wq, 3 * heads * hd, C, n1.t), true, &rowmap, 3 * heads * hdp, nullptr, 0,
+                        &wr, &rm1, nullptr, true));
+      RC_TRY(pack_layer(h, &blocks[i].proj, wp, C, heads * hd, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, &colmap, heads * hdp, &wr, &mctx, nullptr, false, &corr_p));
+      if (wr.on) for (int o = 0; o < C; ++o) wr.cst[o] += corr_p[o];
+      RC_TRY(pack_layer(h, &blocks[i].fc1, w1, hid, C, 1, 1, 1, nullptr, &n2.s, prenorm_bias(w1, hid, C, n2.t), true, nullptr, 0, nullptr, 0, &wr, &rm2, nullptr, true));
+      RC_TRY(pack_layer(h, &blocks[i].fc2, w3, C, hid, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0, &wr, &mh, nullptr, false, &corr_3));
+      if (wr.on) {
+        x_mean.assign(C, 0.0);
+        for (int o = 0; o < C; ++o) {
+          double a = rm2[o];
+          for (int c = 0; c < hid; ++c) a += (double)w3[(size_t)o * hid + c] * mh[c];
+          x_mean[o] = a;
+          wr.cst[o] += corr_3[o];
+        }
+      }
       if (K(mlp_rows_supported)(kd(kdt), C, hid)) {                // fused row-wise Mlp: re-pack [proj,] fc1, fc2 as the MFMA fragment stream
         const int kc = K(mlp_rows_proj_supported)(C, hid, heads * hdp) ? heads * hdp : 0;
         void *img = nullptr, *b1i = nullptr;
@@ -466,7 +620,7 @@ int build(fsvit_visformer* h, const SD& sd) {
     Affine bn = bn_affine(sd, "norm.bn", h->C3, eps);
     if (!bn.ok) return FSVIT_ERR_KEY;
     std::vector<float> s(h->C3), t(h->C3);
-    for (int c = 0; c < h->C3; ++c) { s[c] = (float)bn.s[c]; t[c] = (float)bn.t[c]; }
+    for (int c = 0; c < h->C3; ++c) { s[c] = (float)bn.s[c]; t[c] = (float)(bn.t[c] + (wr.on ? bn.s[c] * wr.cst[c] : 0.0)); }
     void* d; RC_TRY(upload(h, s, false, &d)); h->fscale = (float*)d;
     RC_TRY(upload(h, t, false, &d)); h->fshift = (float*)d;
   }

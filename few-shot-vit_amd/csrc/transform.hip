@@ -80,16 +80,16 @@ int launch_transform_gather(const TransformParams& p, int B, hipStream_t s) {
 
 }  // namespace fsvit
 
-extern "C" int fsvit_set_error_public(int code, const char* msg);
+int fsvit_set_error(int code, const char* fmt, ...);      // engine.hip (library-internal, C++ linkage)
 
 extern "C" int fsvit_image_transform_gather(const uint8_t* images_dev, int H, int W, const int64_t* index_dev, int B, const int32_t* xmin_h,
                                             const int32_t* cnt_h, const int32_t* coef_h, int ksize_h, const int32_t* xmin_v,
                                             const int32_t* cnt_v, const int32_t* coef_v, int ksize_v, int crop_y0, int crop_x0, int OH, int OW,
                                             const float* mean3_host, const float* std3_host, float* out_dev, void* stream) {
   if (!images_dev || !index_dev || !xmin_h || !cnt_h || !coef_h || !xmin_v || !cnt_v || !coef_v || !mean3_host || !std3_host || !out_dev)
-    return fsvit_set_error_public(-1, "fsvit_image_transform_gather: null argument");
+    return fsvit_set_error(-1, "%s", "fsvit_image_transform_gather: null argument");
   if (H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || ksize_h <= 0 || ksize_v <= 0 || crop_y0 < 0 || crop_x0 < 0)
-    return fsvit_set_error_public(-1, "fsvit_image_transform_gather: bad geometry");
+    return fsvit_set_error(-1, "%s", "fsvit_image_transform_gather: bad geometry");
   fsvit::TransformParams p;
   p.images = images_dev; p.index = index_dev;
   p.xmin_h = xmin_h; p.cnt_h = cnt_h; p.coef_h = coef_h;
@@ -99,6 +99,6 @@ extern "C" int fsvit_image_transform_gather(const uint8_t* images_dev, int H, in
   for (int c = 0; c < 3; ++c) { p.mean[c] = mean3_host[c]; p.stdv[c] = std3_host[c]; }
   p.inv255 = 1.0f / 255.0f;
   int rc = fsvit::launch_transform_gather(p, B, (hipStream_t)stream);
-  if (rc) return fsvit_set_error_public(rc, "fsvit_image_transform_gather: launch failed (image too large for LDS?)");
+  if (rc) return fsvit_set_error(rc, "%s", "fsvit_image_transform_gather: launch failed (image too large for LDS?)");
   return 0;
 }

@@ -36,12 +36,15 @@ def gather_in_stream_order(values: torch.Tensor, n_total: int, rank: int, world:
         return values
     per = (n_total + world - 1) // world
     shape = (per,) + tuple(values.shape[1:])
+    dev = values.device
+    if values.is_cuda and dist.get_backend() == 'gloo':   # gloo ranks that compute on a GPU (tests: two ranks on one device): gather on the host
+        values = values.cpu()
     pad = torch.zeros(shape, dtype=values.dtype, device=values.device)
     pad[:values.shape[0]] = values
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
     stacked = torch.stack(out, dim=1)                     # [per, world, ...]: row-major == global order
-    return stacked.reshape((per * world,) + tuple(values.shape[1:]))[:n_total]
+    return stacked.reshape((per * world,) + tuple(values.shape[1:]))[:n_total].to(dev)
 
 
 def allreduce_mean_stats(sum_acc: float, sum_sq: float, n: float, device) -> tuple:
@@ -100,26 +103,34 @@ class GradBucket:
                     m._grad_sink = None
 
     def _collect(self):
+        """Every gradient into its view.  Returns the parameters that HAVE no gradient (unused in this graph; every rank runs the same
+        graph): their views are zeroed for the collective, and allreduce_mean() hands them back as `.grad = None`, so that the optimizer
+        skips them (no momentum buffer, no weight decay) exactly as it does in a single-process run."""
+        unused = []
         for p, v in zip(self.params, self.views):
             g = p.grad
             if g is None:
                 v.zero_()
-            elif g.data_ptr() != v.data_ptr():
+                unused.append(p)
+                continue
+            if g.data_ptr() != v.data_ptr():
                 v.copy_(g)
             p.grad = v
+        return unused
 
     def allreduce_mean(self) -> None:
-        self._collect()
-        if not (dist.is_initialized() and dist.get_world_size() > 1):
-            return
-        world = dist.get_world_size()
-        if self.wire_dtype is not None and self.wire_dtype != torch.float32:
-            wire = self.flat.to(self.wire_dtype)
-            dist.all_reduce(wire)
-            self.flat.copy_(wire).div_(world)
-            return
-        dist.all_reduce(self.flat)
-        self.flat.div_(world)
+        unused = self._collect()
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            world = dist.get_world_size()
+            if self.wire_dtype is not None and self.wire_dtype != torch.float32:
+                wire = self.flat.to(self.wire_dtype)
+                dist.all_reduce(wire)
+                self.flat.copy_(wire).div_(world)
+            else:
+                dist.all_reduce(self.flat)
+                self.flat.div_(world)
+        for p in unused:
+            p.grad = None
 
 
 def allreduce_mean_grads(params) -> None:

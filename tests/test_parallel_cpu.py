@@ -127,3 +127,21 @@ def test_two_rank_gradient_allreduce_matches_single_process_step(use_bucket):
     for rank, grads, mine in results:
         for g, p in zip(grads, params):
             np.testing.assert_allclose(g, p.grad.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_grad_bucket_hands_unused_parameters_back_without_a_gradient():
+    """a parameter that received no gradient must stay `.grad = None` after the bucket's exchange, so that the optimizer skips it
+    (no momentum buffer, no weight decay) exactly as in a single-process run; the bucket only zeroes its slice for the collective."""
+    from fewshot_vit_amd import parallel
+    used, unused = torch.nn.Parameter(torch.ones(4)), torch.nn.Parameter(torch.ones(3))
+    bucket = parallel.GradBucket([used, unused])
+    for p in (used, unused):
+        p.grad = None                                     # optimizer.zero_grad()
+    (used * 2.0).sum().backward()
+    bucket.flat[4:] = 7.0                                 # stale bytes in the unused slice must not reach the collective
+    bucket.allreduce_mean()
+    assert unused.grad is None and torch.equal(bucket.flat[4:], torch.zeros(3))
+    assert used.grad.data_ptr() == bucket.views[0].data_ptr() and torch.equal(used.grad, torch.full((4,), 2.0))
+    opt = torch.optim.SGD([used, unused], lr=0.1, momentum=0.9, weight_decay=0.1)
+    opt.step()
+    assert torch.equal(unused.detach(), torch.ones(3)) and len(opt.state[unused]) == 0
