@@ -31,11 +31,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _train_config():
+def _train_config(numerics='bf16'):
     return dict(train_dataset='synthetic-episodes', train_dataset_args=dict(split='train', n_classes=12, n_per_class=30, noise=1.0, seed=1),
                 tval_dataset='synthetic-episodes', tval_dataset_args=dict(split='test', n_classes=6, n_per_class=30, noise=1.0, seed=0),
                 val_dataset='synthetic-episodes', val_dataset_args=dict(split='val', n_classes=6, n_per_class=30, noise=1.0, seed=2),
-                model='meta-baseline', model_args=dict(encoder='visformer_micro_80', encoder_args=dict(drop_path_rate=0.0, numerics='bf16')),
+                model='meta-baseline', model_args=dict(encoder='visformer_micro_80', encoder_args=dict(drop_path_rate=0.0, numerics=numerics)),
                 synthetic_checkpoint='visformer_micro_80', n_train_way=5, n_train_shot=5, n_train_query=5, n_way=5, n_shot=5, n_query=15,
                 train_batches=3, eval_batches=3, ep_per_batch=4, max_epoch=1, freeze_bn=True, optimizer='sgd',
                 optimizer_args=dict(lr=0.01, weight_decay=5e-4), save_epoch=1)
@@ -105,11 +105,15 @@ def test_evaluate_world2_on_one_gpu_equals_single_process(tmp_path):
     assert two['acc'] == one['acc'] and two['ci'] == one['ci'] and two['loss'] == pytest.approx(one['loss'], abs=1e-12)
 
 
-def test_train_meta_world2_on_one_gpu_matches_world1(tmp_path):
-    """3 SUN-M steps of 4 episodes (world 1) vs 2 ranks x 2 episodes: same parameters to fp32 summation order.  Drives GradBucket + the trainer's
-    gradient sink + FsvitSGD's pointer table on bucket views through the HIP trainer."""
+@pytest.mark.parametrize('numerics,tol', [('parity', 1.5e-3), ('bf16', 5e-2)])
+def test_train_meta_world2_on_one_gpu_matches_world1(tmp_path, numerics, tol):
+    """3 SUN-M steps of 4 episodes (world 1) vs 2 ranks x 2 episodes: same parameters to fp32 summation order in the exact-fp32 mode (measured 4e-4 of the update on the stem
+    weights, whose gradients pass the max-pool / LeakyReLU decisions at rounding-level ties; 1e-5 elsewhere).  In `bf16`
+    the first step agrees to summation order too, but a weight that differs in its last fp32 bit can round to the other bf16 neighbour in the
+    next step's pack (measured 1.5e-2 of the update after three steps).  Drives GradBucket + the trainer's gradient sink + FsvitSGD's pointer
+    table on bucket views through the HIP trainer."""
     from fewshot_vit_amd import train_meta
-    config = _train_config()
+    config = _train_config(numerics)
     train_meta.main(config, name='w1', device=torch.device('cuda', 0), log=lambda s: None, save_root=str(tmp_path / 'one'))
     out = str(tmp_path / 'train.json')
     json.dump(config, open(out + '.config.json', 'w'))
@@ -122,7 +126,7 @@ def test_train_meta_world2_on_one_gpu_matches_world1(tmp_path):
     from fewshot_vit_amd import models, synthetic
     m0 = models.make(config['model'], **config['model_args'])
     init = synthetic.synthetic_checkpoint_sd({k: tuple(v.shape) for k, v in m0.state_dict().items()}, calib='visformer_micro_80')
-    worst, moved = 0.0, 0
+    worst, moved, rel = 0.0, 0, {}
     for k, va in a['model_sd'].items():
         vb = b['model_sd'][k]
         if not va.dtype.is_floating_point:
@@ -134,11 +138,13 @@ def test_train_meta_world2_on_one_gpu_matches_world1(tmp_path):
             continue
         assert step > 0, k                                                       # every parameter was updated in both runs
         moved += 1
-        worst = max(worst, (va - vb).float().norm().item() / step)
-    print(f'[world 2 vs world 1] {moved} tensors, worst |dparam| / |update| = {worst:.3e}')
-    assert worst <= 2e-3
+        rel[k] = (va - vb).float().norm().item() / step
+        worst = max(worst, rel[k])
+    top = sorted(rel.items(), key=lambda kv: -kv[1])[:3]
+    print(f'[world 2 vs world 1, {numerics}] {moved} tensors, worst |dparam| / |update| = {worst:.3e}; top: ' + ', '.join(f'{k} {v:.2e}' for k, v in top))
+    assert worst <= tol
     la, lb = torch.load(os.path.join(str(tmp_path / 'one'), 'w1', 'trlog.pth')), two
-    assert lb['tl'][0] == pytest.approx(la['tl'][0], rel=1e-4) and lb['va'][0] == pytest.approx(la['va'][0], abs=0.02)
+    assert lb['tl'][0] == pytest.approx(la['tl'][0], rel=1e-3) and lb['va'][0] == pytest.approx(la['va'][0], abs=0.02)
     ma, mb = a['training']['optimizer_sd']['state'], b['training']['optimizer_sd']['state']
     assert len(ma) == len(mb) > 0                                                # same set of momentum buffers: no parameter skipped or added
 

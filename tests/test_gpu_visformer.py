@@ -14,10 +14,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 LOGIT_TOL_PARITY = 1e-3        # BASELINE.json north_star
-# bf16 throughput mode against the fp32 reference golden: 1.5 x the measured 1.07e-1 (round 1) / 9.2e-2 .. 9.6e-2 (round 2).  This deviation is
-# the bf16 rounding of the (BN-folded) WEIGHTS - a fixed perturbation of the model that does not average out over tokens - not of
-# the stored activations or the residual stream (ablation on the rounding-point emulator: DESIGN.md 2, tools/emul_ablation.py).
-LOGIT_TOL_BF16 = 0.16
+# bf16 throughput mode against the fp32 reference golden: 1.5 x the measured 4.2e-2 (5-shot) / 5.7e-2 (1-shot) of round 4.  Rounds 1-3 measured
+# 9.0e-2 .. 1.07e-1: the bf16 rounding of the (BN-folded) WEIGHTS - a fixed perturbation of the model that does not average out over tokens
+# (ablation on the rounding-point emulator: DESIGN.md 2, tools/emul_ablation.py).  Its MEAN effect is now folded into the fp32 biases at pack
+# time from the checkpoint's own BatchNorm statistics (engine.hip `WRound`); what is left is the per-image part and the activation rounding.
+LOGIT_TOL_BF16 = 0.086
 # ... and against the oracle that rounds where the kernels round (oracle/visformer_emul.py): only accumulation order and the
 # softmax / GELU instruction sequences differ - one-ulp flips of stored bf16 activations (2^-8 relative) that then propagate.
 # 1.5 x the measured 3.1e-2 / 3.5e-2 (logits, mean 7e-3) and 1.2e-2 (taps, relative to the tap's max).
@@ -95,7 +96,7 @@ def test_logits_bf16_mode_vs_reference_golden(full_sd, golden_dir, name, seed, s
 
 # f16 mode (fp16 storage + MFMA, same kernels compiled for _Float16): the rounding-point oracle predicts 1.3e-2 / 9e-3 against the fp32
 # reference for these two episodes; set from the GPU measurement (1.5 x).
-LOGIT_TOL_F16 = 1.8e-2          # 1.5 x the measured 1.18e-2 (5-shot) / 9.4e-3 (1-shot)
+LOGIT_TOL_F16 = 1.1e-2          # 1.5 x the measured 7.2e-3 (5-shot) / 6.4e-3 (1-shot) with the weight-rounding correction (round 3: 1.18e-2 / 9.4e-3)
 LOGIT_TOL_F16_EMUL = 7.5e-3     # 1.5 x the measured 4.9e-3 / 4.4e-3
 
 
