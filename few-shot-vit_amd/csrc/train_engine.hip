@@ -68,7 +68,7 @@ struct ConvSpec {                         // one nn.Conv2d of the model (PyTorch
   int kpad_cols() const { return via_patches ? 32 : kreal() / hd_cols * hdp_cols; }         // padded K (elements)
 };
 
-struct BnSave { void* z; float *mean, *invstd, *sa, *sb; int M, C; };
+struct BnSave { void* z = nullptr; float *mean = nullptr, *invstd = nullptr, *sa = nullptr, *sb = nullptr; int M = 0, C = 0; };
 
 }  // namespace
 
@@ -100,7 +100,6 @@ struct fsvit_visformer_trainer {
   std::vector<SA> s2, s3;
   PE pe2, pe3;
   BnSave bnf;
-  void* xnf = nullptr;
   float* scales = nullptr;                // [n_calls][B] = mask / keep
   const float* dtokens = nullptr;         // optional gradient of the post-norm token map for the next backward (distillation head)
   // weight-gradient split slabs of a backward pass stay in the `save` arena and are summed by ONE table-driven launch at the end of the pass
@@ -489,17 +488,17 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
   // ---- stem (visformer.py:219-239)
   auto& S = t->stem;
   NEED(S.patches = take_act(t, M0 * 32)); NEED(S.z1 = take_act(t, M0 * t->C0)); NEED(S.a1 = take_act(t, M0 * t->C0));
-  NEED(S.zd = take_act(t, M0 * t->C1)); NEED(S.ad = take_act(t, M0 * t->C1)); NEED(S.z2 = take_act(t, M0 * t->C1)); NEED(S.a2 = take_act(t, M0 * t->C1));
+  NEED(S.zd = take_act(t, M0 * t->C1)); S.ad = nullptr; NEED(S.z2 = take_act(t, M0 * t->C1)); NEED(S.a2 = take_act(t, M0 * t->C1));
   NEED(S.z3 = take_act(t, M0 * t->C1)); S.a3 = nullptr; NEED(S.arg = (unsigned char*)t->save.take(M1 * t->C1)); NEED(S.x1 = take_act(t, M1 * t->C1));
   T_RUN(launch_im2col27(x, S.patches, B, img, img, H0, H0, dt, st));
   T_TRY(conv_fwd(t, sp.conv1, S.patches, B, H0, H0, S.z1, nullptr));
   T_TRY(bn_fwd(t, "stem.bn1", S.z1, (int)M0, t->C0, ACT_LRELU, nullptr, S.a1, &S.b1));
   T_TRY(conv_fwd(t, sp.down, S.patches, B, H0, H0, S.zd, nullptr));
-  T_TRY(bn_fwd(t, "stem.downsample.1", S.zd, (int)M0, t->C1, ACT_NONE, nullptr, S.ad, &S.bd));
+  T_TRY(bn_fwd(t, "stem.downsample.1", S.zd, (int)M0, t->C1, ACT_NONE, nullptr, nullptr, &S.bd));      // statistics only: applied inside the pooling pass
   T_TRY(conv_fwd(t, sp.conv2, S.a1, B, H0, H0, S.z2, nullptr));
   T_TRY(bn_fwd(t, "stem.bn2", S.z2, (int)M0, t->C1, ACT_LRELU, nullptr, S.a2, &S.b2));
   T_TRY(conv_fwd(t, sp.conv3, S.a2, B, H0, H0, S.z3, nullptr));
-  T_TRY(bn_fwd(t, "stem.bn3", S.z3, (int)M0, t->C1, ACT_LRELU, S.ad, nullptr, &S.b3));      // statistics only: applied inside the pooling pass below
+  T_TRY(bn_fwd(t, "stem.bn3", S.z3, (int)M0, t->C1, ACT_LRELU, nullptr, nullptr, &S.b3));      // statistics only: applied inside the pooling pass below
   {
     const fsvit_param* pos = getp(t, "pos_embed1");
     if (!pos) return FSVIT_ERR_KEY;
@@ -507,7 +506,7 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
     float* pt = (float*)t->tmp.take((size_t)H1 * H1 * t->C1 * 4);
     NEED(pt);
     T_RUN(launch_transpose_cols(pos->data, pt, t->C1, H1 * H1, 0, H1 * H1, t->C1, 0, st));   // in [C][HW] -> out [HW][C]
-    T_RUN(launch_bn_pool_fwd(S.z3, S.b3.sa, S.b3.sb, S.ad, pt, S.x1, S.arg, B, H1, H1, t->C1, dt, st));      // LeakyReLU(bn3 + identity) -> MaxPool -> + pos
+    T_RUN(launch_bn_pool_fwd(S.z3, S.b3.sa, S.b3.sb, S.zd, pt, S.x1, S.arg, B, H1, H1, t->C1, dt, st, S.bd.sa, S.bd.sb));      // LeakyReLU(bn3(z3) + bn_d(zd)) -> MaxPool -> + pos
   }
   void* xcur = S.x1;
   // residual adds in front of a BatchNorm are queued here and computed by that BatchNorm's reduce pass (bn_fwd); flush_add() launches a queued
@@ -613,14 +612,9 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
   }
   // ---- final norm + pool (visformer.py:455-462)
   const size_t M3 = (size_t)B * t->H3 * t->H3;
-  NEED(t->xnf = take_act(t, M3 * t->C3));
-  T_TRY(bn_fwd(t, "norm.bn", xcur, (int)M3, t->C3, ACT_NONE, nullptr, t->xnf, &t->bnf));
-  {
-    float* ones = (float*)t->tmp.take((size_t)2 * t->C3 * 4); NEED(ones);
-    T_RUN(launch_fill_f32(ones, 1.0f, t->C3, st));
-    T_RUN(launch_fill_f32(ones + t->C3, 0.0f, t->C3, st));
-    T_RUN(launch_pool_affine(t->xnf, ones, ones + t->C3, feat, B, t->H3 * t->H3, t->C3, dt, st));
-  }
+  // the normalised map is only ever averaged: feat = sa * mean_hw(x) + sb in the pooling pass (no apply pass, no stored map)
+  T_TRY(bn_fwd(t, "norm.bn", xcur, (int)M3, t->C3, ACT_NONE, nullptr, nullptr, &t->bnf));
+  T_RUN(launch_pool_affine(xcur, t->bnf.sa, t->bnf.sb, feat, B, t->H3 * t->H3, t->C3, dt, st));
   return 0;
 }
 
@@ -775,15 +769,38 @@ int train_backward_impl(TR* t, const float* dfeat) {
     }
     void* da3 = take_tmp(t, M0 * t->C1); NEED(da3);
     void* g3 = take_tmp(t, M0 * t->C1); NEED(g3);
+    T_TRY(side_guard(t, da3, M0 * t->C1 * t->es));
     T_TRY(side_guard(t, g3, M0 * t->C1 * t->es));
-    T_RUN(launch_pool_act_bwd(dx, S.arg, g3, B, H1, H1, t->C1, dt, st));                      // gradient at (bn3(z3) + identity): max-pool routing x LeakyReLU slope
-    T_TRY(bn_bwd(t, "stem.bn3", S.b3, g3, da3));                                              // da3 := dz3
-    T_TRY(conv_bwd_weight(t, sp.conv3, S.a2, B, H0, H0, da3));
-    void* da2 = take_tmp(t, M0 * t->C1); NEED(da2);
-    T_TRY(conv_bwd_data(t, sp.conv3, da3, B, H0, H0, da2));
-    // identity path: ad = bn_d(zd)
-    T_TRY(bn_bwd(t, "stem.downsample.1", S.bd, g3, da3));                                     // da3 := dzd
-    T_TRY(conv_bwd_weight(t, sp.down, S.patches, B, H0, H0, da3));
+    void* da2 = nullptr;
+    if (pool_bn_bwd_supported(t->C1, dt)) {
+      // bn3 and the identity path's BatchNorm see the same gradient - the pooled gradient routed to each window's arg-max with the LeakyReLU slope;
+      // their reductions and apply passes are formed from the pooled gradient itself (train_kernels.hip pool_bn_bwd_*): da3 := dz3, g3 := dzd
+      const fsvit_param *g3w = getp(t, "stem.bn3.weight"), *b3w = getp(t, "stem.bn3.bias"), *gdw = getp(t, "stem.downsample.1.weight"), *bdw = getp(t, "stem.downsample.1.bias");
+      if (!g3w || !b3w || !gdw || !bdw) return FSVIT_ERR_KEY;
+      const int C = t->C1, nb = pool_bn_bwd_blocks(B, H1, H1, C, dt);
+      float* part = (float*)t->tmp.take((size_t)nb * 4 * C * 4); NEED(part);
+      float* coef = (float*)t->tmp.take((size_t)10 * C * 4); NEED(coef);
+      float *coef3 = coef, *coefd = coef + 3 * C, *scr = coef + 6 * C;
+      T_RUN(launch_pool_bn_bwd_reduce(dx, S.arg, S.z3, S.zd, S.b3.mean, S.b3.invstd, S.bd.mean, S.bd.invstd, part, part + (size_t)nb * 2 * C, B, H1, H1, C, dt, st));
+      T_RUN(launch_bn_bwd_finalize_nblk(part, nb, (int)M0, C, g3w->data, S.b3.invstd, g3w->grad ? g3w->grad : scr, b3w->grad ? b3w->grad : scr + C, coef3, coef3 + C,
+                                        coef3 + 2 * C, t->freeze_bn ? 1 : 0, st));
+      T_RUN(launch_bn_bwd_finalize_nblk(part + (size_t)nb * 2 * C, nb, (int)M0, C, gdw->data, S.bd.invstd, gdw->grad ? gdw->grad : scr + 2 * C, bdw->grad ? bdw->grad : scr + 3 * C,
+                                        coefd, coefd + C, coefd + 2 * C, t->freeze_bn ? 1 : 0, st));
+      T_RUN(launch_pool_bn_bwd_apply(dx, S.arg, S.z3, S.zd, S.b3.mean, S.b3.invstd, S.bd.mean, S.bd.invstd, coef3, coefd, da3, g3, B, H1, H1, C, dt, st));
+      T_TRY(conv_bwd_weight(t, sp.conv3, S.a2, B, H0, H0, da3));
+      da2 = take_tmp(t, M0 * t->C1); NEED(da2);
+      T_TRY(conv_bwd_data(t, sp.conv3, da3, B, H0, H0, da2));
+      T_TRY(conv_bwd_weight(t, sp.down, S.patches, B, H0, H0, g3));
+    } else {
+      T_RUN(launch_pool_act_bwd(dx, S.arg, g3, B, H1, H1, t->C1, dt, st));                      // gradient at (bn3(z3) + identity): max-pool routing x LeakyReLU slope
+      T_TRY(bn_bwd(t, "stem.bn3", S.b3, g3, da3));                                              // da3 := dz3
+      T_TRY(conv_bwd_weight(t, sp.conv3, S.a2, B, H0, H0, da3));
+      da2 = take_tmp(t, M0 * t->C1); NEED(da2);
+      T_TRY(conv_bwd_data(t, sp.conv3, da3, B, H0, H0, da2));
+      // identity path: ad = bn_d(zd)
+      T_TRY(bn_bwd(t, "stem.downsample.1", S.bd, g3, da3));                                     // da3 := dzd
+      T_TRY(conv_bwd_weight(t, sp.down, S.patches, B, H0, H0, da3));
+    }
     // bn2 / bn1 are followed by a LeakyReLU: its slope rides in the BatchNorm backward's two passes (no bn_act_bwd pass, no 328 MB map)
     T_TRY(bn_bwd(t, "stem.bn2", S.b2, da2, da2, nullptr, nullptr, nullptr, 0, true));         // da2 := dz2 (in place)
     T_TRY(conv_bwd_weight(t, sp.conv2, S.a1, B, H0, H0, da2));
@@ -1287,9 +1304,10 @@ extern "C" int fsvit_sgd_step(float* param, const float* grad, float* momentum_b
 // ---- post-norm token map of the last train_forward (the `x` of `return x, pooled`, sun_meta_training/models/visformer.py:464) and its gradient
 extern "C" int fsvit_visformer_train_tokens(fsvit_visformer_trainer* t, float* tokens_dev, void* stream) {
   if (!t || !tokens_dev) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
-  if (!t->xnf || !t->save.base || t->save.dry) return fsvit_set_error(FSVIT_ERR_ARG, "train_tokens called without a preceding train_forward");
+  if (!t->bnf.z || !t->save.base || t->save.dry) return fsvit_set_error(FSVIT_ERR_ARG, "train_tokens called without a preceding train_forward");
   const size_t n = (size_t)t->B * t->H3 * t->H3 * t->C3;
-  int rc = fsvit::launch_tokens_to_f32(t->xnf, nullptr, nullptr, tokens_dev, n, t->C3, t->dtype, (hipStream_t)stream);
+  // (the final BatchNorm's scale / shift are applied here: the training forward keeps no normalised copy of the stage-3 map)
+  int rc = fsvit::launch_tokens_to_f32(t->bnf.z, t->bnf.sa, t->bnf.sb, tokens_dev, n, t->C3, t->dtype, (hipStream_t)stream);
   if (rc != 0) return fsvit_set_error(FSVIT_ERR_ARG, "launch failed: %d", rc);
   return 0;
 }

@@ -44,8 +44,19 @@ int launch_bn_bwd_apply(const void* dy, const void* z, const float* mean, const 
                         size_t M, int C, int dtype, hipStream_t s, const void* acc = nullptr, const float* scale2 = nullptr, void* out2 = nullptr,
                         size_t rows_per_img = 0, const float* act_sa = nullptr, const float* act_sb = nullptr);
 // stem tail: LeakyReLU(sa * z + sb + res) -> MaxPool2d(2) -> + pos in one pass (arg = window position | 4 if the maximum is positive), and its backward
+// (rsa / rsb: `res` is the identity path's PRE-normalisation map, its BatchNorm scale / shift are applied in the same pass)
 int launch_bn_pool_fwd(const void* z, const float* sa, const float* sb, const void* res, const float* pos, void* out, unsigned char* arg, int B, int OH, int OW,
-                       int C, int dtype, hipStream_t s);
+                       int C, int dtype, hipStream_t s, const float* rsa = nullptr, const float* rsb = nullptr);
+// both BatchNorm backwards behind that tail (bn3 on z3, the identity path's on zd) straight from the pooled gradient + arg: the routed 2 x 2 gradient
+// map is never stored.  partial3 / partiald: pool_bn_bwd_blocks() * 2 * C floats each; coef3 / coefd: [3][C] = ca | cb | cc of launch_bn_bwd_finalize
+bool pool_bn_bwd_supported(int C, int dtype);
+int pool_bn_bwd_blocks(int B, int OH, int OW, int C, int dtype);
+int launch_pool_bn_bwd_reduce(const void* dout, const unsigned char* arg, const void* z3, const void* zd, const float* mean3, const float* is3, const float* meand,
+                              const float* isd, float* partial3, float* partiald, int B, int OH, int OW, int C, int dtype, hipStream_t s);
+int launch_pool_bn_bwd_apply(const void* dout, const unsigned char* arg, const void* z3, const void* zd, const float* mean3, const float* is3, const float* meand,
+                             const float* isd, const float* coef3, const float* coefd, void* dz3, void* dzd, int B, int OH, int OW, int C, int dtype, hipStream_t s);
+int launch_bn_bwd_finalize_nblk(const float* partial, int nblk, int M, int C, const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* ca, float* cb,
+                                float* cc, int frozen, hipStream_t s);
 int launch_pool_act_bwd(const void* dout, const unsigned char* arg, void* g, int B, int OH, int OW, int C, int dtype, hipStream_t s);
 int launch_gelu_fwd(const void* z, void* h, size_t n, int dtype, hipStream_t s);
 int launch_gelu_bwd(const void* dh, const void* z, void* dz, size_t n, int dtype, hipStream_t s);

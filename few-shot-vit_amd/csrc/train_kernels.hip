@@ -838,10 +838,13 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const T* __restrict__
 // Stem tail in one pass (visformer.py:224-237): y = LeakyReLU(sa * z + sb + res), MaxPool2d(2), + pos_embed1.  The activated map is never stored
 // (the separate bn_apply + maxpool pair wrote and re-read its 328 MB at 800 images).  arg = window position of the maximum (first of equals,
 // compared in fp32) | 4 when the maximum is positive - all the backward needs (LeakyReLU slope of the routed gradient).  V channels per thread.
+// rsa != nullptr: `res` is the PRE-normalisation map of the identity path and its BatchNorm is applied here too (res * rsa + rsb): the normalised
+// identity map (328 MB written and read back at 800 images) is never stored either.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void bn_pool_fwd_kernel(const T* __restrict__ z, const float* __restrict__ sa, const float* __restrict__ sb,
                                                           const T* __restrict__ res, const float* __restrict__ pos, T* __restrict__ out,
-                                                          unsigned char* __restrict__ arg, int B, int OH, int OW, int C) {
+                                                          unsigned char* __restrict__ arg, int B, int OH, int OW, int C,
+                                                          const float* __restrict__ rsa, const float* __restrict__ rsb) {
   const int cvn = C / V, W = OW * 2;
   const size_t total = (size_t)B * OH * OW * cvn;
   GS_LOOP(idx, total) {
@@ -860,7 +863,15 @@ __global__ __launch_bounds__(256) void bn_pool_fwd_kernel(const T* __restrict__ 
 #pragma unroll
       for (int q = 0; q < V / 4; ++q) {
         f32x4 v = load4<T>(z + off + 4 * q) * *reinterpret_cast<const f32x4*>(sa + c + 4 * q) + *reinterpret_cast<const f32x4*>(sb + c + 4 * q);
-        if (res) v += load4<T>(res + off + 4 * q);
+        if (res) {
+          f32x4 r = load4<T>(res + off + 4 * q);
+          if (rsa) {      // the normalised identity value as the separate apply pass stored it: rounded to the storage type
+            r = r * *reinterpret_cast<const f32x4*>(rsa + c + 4 * q) + *reinterpret_cast<const f32x4*>(rsb + c + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = to_f32<T>(from_f32<T>(r[e]));
+          }
+          v += r;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float y = v[e] > 0.f ? v[e] : 0.1f * v[e];
@@ -914,6 +925,114 @@ __global__ __launch_bounds__(256) void pool_act_bwd_kernel(const T* __restrict__
         for (int e = 0; e < 4; ++e) r[e] = (a[4 * q + e] & 3) == k ? d[4 * q + e] : 0.f;
         store4<T>(g + off + 4 * q, r);
       }
+    }
+  }
+}
+
+// ---- Stem tail backward without the routed gradient map (round 4).  g = the pooled gradient routed to its window's arg-max position with the
+// LeakyReLU slope (pool_act_bwd_kernel's output) has ONE non-zero per 2 x 2 window and feeds TWO BatchNorm backwards (bn3 on z3, the identity
+// path's BatchNorm on zd).  Their reductions  sum g, sum g xhat3, sum g xhatd  and their apply passes  dz = ca g + cb + cc xhat  are formed straight
+// from the pooled gradient + arg: pool_act_bwd's 328 MB write and the four reads of that map are gone (2.7 GB -> 1.6 GB at 800 images).
+// Row-walking form: a thread owns V channels and walks pooled pixels; partial3 / partiald are [blocks][2][C] like bn_reduce_kernel's.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(const T* __restrict__ dout, const unsigned char* __restrict__ arg, const T* __restrict__ z3,
+                                                                 const T* __restrict__ zd, const float* __restrict__ mean3, const float* __restrict__ is3,
+                                                                 const float* __restrict__ meand, const float* __restrict__ isd, float* __restrict__ partial3,
+                                                                 float* __restrict__ partiald, int B, int OH, int OW, int C) {
+  __shared__ float red[3][V][256];
+  const int lanesC = C / V, R = 256 / lanesC, W = OW * 2;
+  const int cl = threadIdx.x % lanesC, rl = threadIdx.x / lanesC, c = cl * V;
+  float M3[V], I3[V], MD[V], ID[V], s0[V], s1[V], s2[V];
+  ldc<V>(mean3 + c, M3); ldc<V>(is3 + c, I3); ldc<V>(meand + c, MD); ldc<V>(isd + c, ID);
+#pragma unroll
+  for (int e = 0; e < V; ++e) s0[e] = s1[e] = s2[e] = 0.f;
+  const size_t npix = (size_t)B * OH * OW, step = (size_t)gridDim.x * R;
+  for (size_t pix = (size_t)blockIdx.x * R + rl; pix < npix; pix += step) {
+    const int ox = (int)(pix % OW);
+    const size_t t2 = pix / OW;
+    const int oy = (int)(t2 % OH);
+    const size_t b = t2 / OH;
+    const size_t base = ((b * OH * 2 + oy * 2) * W + ox * 2) * C + c, o = pix * C + c;
+    float d[V], zv[4][V], dv[4][V];
+    ldv<T, V>(dout + o, d);
+    unsigned char a[V];
+    if constexpr (V == 8) *reinterpret_cast<uint2*>(a) = *reinterpret_cast<const uint2*>(arg + o);
+    else *reinterpret_cast<unsigned*>(a) = *reinterpret_cast<const unsigned*>(arg + o);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t off = base + ((size_t)(k >> 1) * W + (k & 1)) * C;
+      ldv<T, V>(z3 + off, zv[k]);
+      ldv<T, V>(zd + off, dv[k]);
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float g = to_f32<T>(from_f32<T>((a[e] & 4) ? d[e] : 0.1f * d[e]));      // the routed gradient as pool_act_bwd_kernel stored it
+      const int k = a[e] & 3;
+      const float x3 = k == 0 ? zv[0][e] : k == 1 ? zv[1][e] : k == 2 ? zv[2][e] : zv[3][e];
+      const float xd = k == 0 ? dv[0][e] : k == 1 ? dv[1][e] : k == 2 ? dv[2][e] : dv[3][e];
+      s0[e] += g;
+      s1[e] += g * ((x3 - M3[e]) * I3[e]);
+      s2[e] += g * ((xd - MD[e]) * ID[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < V; ++e) { red[0][e][threadIdx.x] = s0[e]; red[1][e][threadIdx.x] = s1[e]; red[2][e][threadIdx.x] = s2[e]; }
+  __syncthreads();
+  if (rl == 0) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      for (int r = 1; r < R; ++r) { s0[e] += red[0][e][r * lanesC + cl]; s1[e] += red[1][e][r * lanesC + cl]; s2[e] += red[2][e][r * lanesC + cl]; }
+      partial3[((size_t)blockIdx.x * 2 + 0) * C + c + e] = s0[e];
+      partial3[((size_t)blockIdx.x * 2 + 1) * C + c + e] = s1[e];
+      partiald[((size_t)blockIdx.x * 2 + 0) * C + c + e] = s0[e];
+      partiald[((size_t)blockIdx.x * 2 + 1) * C + c + e] = s2[e];
+    }
+  }
+}
+// coef3 / coefd: [3][C] = ca | cb | cc of bn_bwd_finalize_kernel
+template <typename T, int V>
+__global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const T* __restrict__ dout, const unsigned char* __restrict__ arg, const T* __restrict__ z3,
+                                                                const T* __restrict__ zd, const float* __restrict__ mean3, const float* __restrict__ is3,
+                                                                const float* __restrict__ meand, const float* __restrict__ isd, const float* __restrict__ coef3,
+                                                                const float* __restrict__ coefd, T* __restrict__ dz3, T* __restrict__ dzd, int B, int OH, int OW, int C) {
+  const int lanesC = C / V, R = 256 / lanesC, W = OW * 2;
+  const int cl = threadIdx.x % lanesC, rl = threadIdx.x / lanesC, c = cl * V;
+  float M3[V], I3[V], MD[V], ID[V], A3[V], B3[V], C3[V], AD[V], BD[V], CD[V];
+  ldc<V>(mean3 + c, M3); ldc<V>(is3 + c, I3); ldc<V>(meand + c, MD); ldc<V>(isd + c, ID);
+  ldc<V>(coef3 + c, A3); ldc<V>(coef3 + C + c, B3); ldc<V>(coef3 + 2 * C + c, C3);
+  ldc<V>(coefd + c, AD); ldc<V>(coefd + C + c, BD); ldc<V>(coefd + 2 * C + c, CD);
+  const size_t npix = (size_t)B * OH * OW, step = (size_t)gridDim.x * R;
+  for (size_t pix = (size_t)blockIdx.x * R + rl; pix < npix; pix += step) {
+    const int ox = (int)(pix % OW);
+    const size_t t2 = pix / OW;
+    const int oy = (int)(t2 % OH);
+    const size_t b = t2 / OH;
+    const size_t base = ((b * OH * 2 + oy * 2) * W + ox * 2) * C + c, o = pix * C + c;
+    float d[V], zv[4][V], dv[4][V];
+    ldv<T, V>(dout + o, d);
+    unsigned char a[V];
+    if constexpr (V == 8) *reinterpret_cast<uint2*>(a) = *reinterpret_cast<const uint2*>(arg + o);
+    else *reinterpret_cast<unsigned*>(a) = *reinterpret_cast<const unsigned*>(arg + o);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t off = base + ((size_t)(k >> 1) * W + (k & 1)) * C;
+      ldv<T, V>(z3 + off, zv[k]);
+      ldv<T, V>(zd + off, dv[k]);
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) d[e] = to_f32<T>(from_f32<T>((a[e] & 4) ? d[e] : 0.1f * d[e]));      // the routed gradient as pool_act_bwd_kernel stored it
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const size_t off = base + ((size_t)(k >> 1) * W + (k & 1)) * C;
+      float o3[V], od[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float g = (a[e] & 3) == k ? d[e] : 0.f;
+        o3[e] = A3[e] * g + B3[e] + C3[e] * ((zv[k][e] - M3[e]) * I3[e]);
+        od[e] = AD[e] * g + BD[e] + CD[e] * ((dv[k][e] - MD[e]) * ID[e]);
+      }
+      stv<T, V>(dz3 + off, o3);
+      stv<T, V>(dzd + off, od);
     }
   }
 }
@@ -1375,6 +1494,11 @@ int launch_bn_fwd_finalize(const float* partial, int M, int C, float eps, float 
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, bn_reduce_blocks(M), M, C, eps, momentum, gamma, beta, rmean, rvar, mean, invstd, sa, sb);
   return (int)hipGetLastError();
 }
+int launch_bn_bwd_finalize_nblk(const float* partial, int nblk, int M, int C, const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* ca, float* cb,
+                                float* cc, int frozen, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, nblk, M, C, gamma, invstd, dgamma, dbeta, ca, cb, cc, frozen);
+  return (int)hipGetLastError();
+}
 int launch_bn_bwd_finalize(const float* partial, int M, int C, const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* ca, float* cb,
                            float* cc, int frozen, hipStream_t s) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, bn_reduce_blocks(M), M, C, gamma, invstd, dgamma, dbeta, ca, cb, cc, frozen);
@@ -1425,12 +1549,42 @@ int launch_bn_bwd_apply(const void* dy, const void* z, const float* mean, const 
   return (int)hipGetLastError();
 }
 int launch_bn_pool_fwd(const void* z, const float* sa, const float* sb, const void* res, const float* pos, void* out, unsigned char* arg, int B, int OH, int OW,
-                       int C, int dtype, hipStream_t s) {
+                       int C, int dtype, hipStream_t s, const float* rsa, const float* rsb) {
   if (C % 8) return (int)hipErrorInvalidValue;
   DISPATCH_T(dtype, hipLaunchKernelGGL((bn_pool_fwd_kernel<float, 4>), dim3(gs_grid((size_t)B * OH * OW * (C / 4))), dim3(256), 0, s, (const float*)z, sa, sb, (const float*)res, pos,
-                                       (float*)out, arg, B, OH, OW, C),
+                                       (float*)out, arg, B, OH, OW, C, rsa, rsb),
              hipLaunchKernelGGL((bn_pool_fwd_kernel<bf16, 8>), dim3(gs_grid((size_t)B * OH * OW * (C / 8))), dim3(256), 0, s, (const bf16*)z, sa, sb, (const bf16*)res, pos,
-                                (bf16*)out, arg, B, OH, OW, C));
+                                (bf16*)out, arg, B, OH, OW, C, rsa, rsb));
+  return (int)hipGetLastError();
+}
+// the two BatchNorm backwards behind the stem's pooled tail, from the pooled gradient (pool_bn_bwd_*_kernel)
+bool pool_bn_bwd_supported(int C, int dtype) { return rows_form_ok(C, dtype == 0 ? 4 : 8); }
+static inline unsigned pool_rows_grid(size_t npix, int C, int V) {
+  const size_t R = 256 / (C / V);
+  size_t nb = (npix + R - 1) / R;
+  return (unsigned)(nb > 512 ? 512 : (nb < 1 ? 1 : nb));
+}
+int pool_bn_bwd_blocks(int B, int OH, int OW, int C, int dtype) { return (int)pool_rows_grid((size_t)B * OH * OW, C, dtype == 0 ? 4 : 8); }
+int launch_pool_bn_bwd_reduce(const void* dout, const unsigned char* arg, const void* z3, const void* zd, const float* mean3, const float* is3, const float* meand,
+                              const float* isd, float* partial3, float* partiald, int B, int OH, int OW, int C, int dtype, hipStream_t s) {
+  const unsigned nb = pool_rows_grid((size_t)B * OH * OW, C, dtype == 0 ? 4 : 8);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((pool_bn_bwd_reduce_kernel<float, 4>), dim3(nb), dim3(256), 0, s, (const float*)dout, arg, (const float*)z3, (const float*)zd, mean3, is3,
+                                       meand, isd, partial3, partiald, B, OH, OW, C),
+             hipLaunchKernelGGL((pool_bn_bwd_reduce_kernel<bf16, 8>), dim3(nb), dim3(256), 0, s, (const bf16*)dout, arg, (const bf16*)z3, (const bf16*)zd, mean3, is3, meand,
+                                isd, partial3, partiald, B, OH, OW, C));
+  return (int)hipGetLastError();
+}
+int launch_pool_bn_bwd_apply(const void* dout, const unsigned char* arg, const void* z3, const void* zd, const float* mean3, const float* is3, const float* meand,
+                             const float* isd, const float* coef3, const float* coefd, void* dz3, void* dzd, int B, int OH, int OW, int C, int dtype, hipStream_t s) {
+  const size_t npix = (size_t)B * OH * OW;
+  const int V = dtype == 0 ? 4 : 8;
+  const size_t R = 256 / (C / V);
+  size_t nb = (npix + R - 1) / R;
+  if (nb > 8192) nb = 8192;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((pool_bn_bwd_apply_kernel<float, 4>), dim3((unsigned)nb), dim3(256), 0, s, (const float*)dout, arg, (const float*)z3, (const float*)zd, mean3,
+                                       is3, meand, isd, coef3, coefd, (float*)dz3, (float*)dzd, B, OH, OW, C),
+             hipLaunchKernelGGL((pool_bn_bwd_apply_kernel<bf16, 8>), dim3((unsigned)nb), dim3(256), 0, s, (const bf16*)dout, arg, (const bf16*)z3, (const bf16*)zd, mean3, is3,
+                                meand, isd, coef3, coefd, (bf16*)dz3, (bf16*)dzd, B, OH, OW, C));
   return (int)hipGetLastError();
 }
 int launch_pool_act_bwd(const void* dout, const unsigned char* arg, void* g, int B, int OH, int OW, int C, int dtype, hipStream_t s) {
