@@ -102,7 +102,7 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f)); }
 
-template <int CIN, bool FUSE_TAIL>
+template <int CIN, bool FUSE_TAIL, bool STATS = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvGemmParams p, const int n_tiles) {
   using namespace halo;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -126,6 +126,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvGemmPara
   const int fr = ((lrow >> 3) & 1) * 2 + ((lrow >> 1) & 1), fc = ((lrow >> 2) & 1) * 2 + (lrow & 1);
   auto blk_r = [&](int i) { return (wm * MT + i) / (TW / 4); };
   auto blk_c = [&](int i) { return (wm * MT + i) % (TW / 4); };
+  f32x4 st0[STATS ? NT : 1], st1[STATS ? NT : 1];      // STATS: sum / sum of squares of this lane's 4 x 4 output channels over all its pixels
+#pragma unroll
+  for (int j = 0; j < (STATS ? NT : 1); ++j) st0[j] = st1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   unsigned xb[MT];                         // LDS byte offset of the tap-(0,0) halo pixel in plane lq of the CURRENT halo buffer
 #pragma unroll
   for (int i = 0; i < MT; ++i) xb[i] = (unsigned)(((blk_r(i) * 4 + fr) * HP + blk_c(i) * 4 + fc) * 16 + lq * PLANE);
@@ -367,6 +370,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvGemmPara
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         bv[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + wn * 64 + (j >> 1) * 32 + lq_e * 8 + (j & 1) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (STATS) {               // BatchNorm statistics of the stored map (training forward): per-lane running sums over every tile of this workgroup
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const f32x4 v = acc[i][j] + bv[j];
+            st0[j] += v;
+            st1[j] += v * v;
+          }
+      }
       auto finish = [&](auto actf) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -455,6 +468,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvGemmPara
            (int)blockIdx.x, my_tiles, __builtin_readcyclecounter() - ck0, ckP, ckA, ckV, ckW, ckB, ckT, ckE);
 #endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no DMA (dummy pieces) may be in flight into the LDS of a finished workgroup
+  if constexpr (STATS) {
+    // workgroup partial: the 16 pixel lanes of a channel quad (shuffles), then the 4 waves that share the 64-channel half, in fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);             // [8 waves][2][64 channels]
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = st0[j][e], q = st1[j][e];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+        if (lrow == 0) {
+          const int cl = (j >> 1) * 32 + lq * 8 + (j & 1) * 4 + e;     // channel inside the wave's 64 (the epilogue's 16-byte order)
+          red[(wave * 2 + 0) * 64 + cl] = a;
+          red[(wave * 2 + 1) * 64 + cl] = q;
+        }
+      }
+    __syncthreads();
+    if (t < 256) {
+      const int which = t >> 7, c = t & 127, h = c >> 6, cl = c & 63;
+      float a = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) a += red[((m * 2 + h) * 2 + which) * 64 + cl];      // waves (wm = m, wn = h)
+      p.stats[((size_t)blockIdx.x * 2 + which) * p.y_cstride + c] = a;
+    }
+  }
 }
 
 bool conv3x3_halo_eligible(const ConvGemmParams& p, int dtype) {
@@ -464,14 +503,24 @@ bool conv3x3_halo_eligible(const ConvGemmParams& p, int dtype) {
   if (p.N != 128 || p.y_cstride != 128 || p.W != halo::TW || (p.H % halo::TR) || p.OH != p.H || p.OW != p.W) return false;
   if (p.res || p.y2 || p.act == ACT_MUL || p.y_rpi || p.out_f32 || p.w_rstride || p.w_gstride) return false;
   if (p.Cin != p.x_cstride || p.K != 9 * p.Cin) return false;
+  if (p.stats && (p.pool2 || p.act != ACT_NONE)) return false;
   if (p.pool2) return p.Cin == 128 && p.x2 && p.K2 == 32 && p.x2_cstride >= 32 && p.pos && p.Kw == p.K + 64;
   return (p.Cin == 64 || p.Cin == 128) && !p.x2 && !p.pos && p.Kw == p.K;
 }
 
-template <int CIN, bool FUSE_TAIL>
+static inline int halo_grid(const ConvGemmParams& p) { const int n_tiles = p.B * (p.H / halo::TR); return n_tiles < 256 ? n_tiles : 256; }
+// (the statistics rows = the persistent grid: one partial per workgroup)
+int conv3x3_halo_stats_rows(const ConvGemmParams& p, int dtype) {
+  ConvGemmParams q = p;
+  float dummy;
+  q.stats = &dummy;
+  return conv3x3_halo_eligible(q, dtype) ? halo_grid(p) : 0;
+}
+
+template <int CIN, bool FUSE_TAIL, bool STATS = false>
 static int launch_halo_t(const ConvGemmParams& p, hipStream_t stream) {
   const int n_tiles = p.B * (p.H / halo::TR);
-  auto kern = conv3x3_halo_kernel<CIN, FUSE_TAIL>;
+  auto kern = conv3x3_halo_kernel<CIN, FUSE_TAIL, STATS>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, halo::LDS_BYTES);
   if (e != hipSuccess) return (int)e;
   const int grid = n_tiles < 256 ? n_tiles : 256;
@@ -481,6 +530,7 @@ static int launch_halo_t(const ConvGemmParams& p, hipStream_t stream) {
 
 int launch_conv3x3_halo(const ConvGemmParams& p, hipStream_t stream) {
   if (p.pool2) return launch_halo_t<128, true>(p, stream);
+  if (p.stats) return p.Cin == 64 ? launch_halo_t<64, false, true>(p, stream) : launch_halo_t<128, false, true>(p, stream);
   return p.Cin == 64 ? launch_halo_t<64, false>(p, stream) : launch_halo_t<128, false>(p, stream);
 }
 

@@ -61,6 +61,12 @@ struct ConvGemmParams {
   // (same layout and dtype as y) - the backward multiplies by it inside the data-gradient GEMM's epilogue (ACT_MUL) instead of keeping the
   // pre-activation map for a separate elementwise pass in each direction.
   void* y2;
+  // Training forward, BatchNorm statistics from the producer (round 4): stats != nullptr -> the kernel also writes per-workgroup partial sums of the
+  // values it stores, stats[(wg * 2 + 0) * y_cstride + n] = sum over the workgroup's output rows of y[m][n], [(wg * 2 + 1) ...] = sum of y^2
+  // (fp32, of the accumulators before the rounding to the storage type; fixed summation order: bit-reproducible).  The number of partial
+  // rows is conv_stats_rows(p, dtype) (0: this layer's kernel does not produce them); bn_fwd_finalize sums them - the separate reduce pass
+  // over the stored map is gone.  conv3x3_halo only so far.
+  float* stats;
 };
 
 }  // namespace fsvit_types
@@ -80,6 +86,8 @@ struct ConvGemmParams {
   /* conv3x3_halo.hip: 3x3 / stride 1 conv with the input tile + halo resident in LDS (stem conv2 / conv3 geometry) */      \
   bool conv3x3_halo_eligible(const ConvGemmParams& p, int dtype);                                                          \
   int launch_conv3x3_halo(const ConvGemmParams& p, hipStream_t stream);                                                    \
+  int conv_stats_rows(const ConvGemmParams& p, int dtype); /* partial rows `stats` receives from this layer's kernel, 0 = none */ \
+  int conv3x3_halo_stats_rows(const ConvGemmParams& p, int dtype);                                                           \
   int conv_gemm_v2_config(const ConvGemmParams& p); /* which tile configuration launch_conv_gemm_v2 picks */               \
   /* wgrad3x3.hip: the grouped 3x3 conv of the stage-1 Mlp in the two-limb modes (wave = group, weights in registers) */     \
   bool gconv3x3_x2_eligible(const ConvGemmParams& p, int dtype);                                                           \

@@ -95,7 +95,10 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 // with bf16 limbs, 22 with fp16 limbs.  The weights arrive pre-split (engine.hip upload()); the activations stay plain fp32
 // in HBM - every other kernel of the fp32 path is shared - and are split on their way into LDS (stash() in the kernel): x2_split() returns
 // the chunk in both slot orders.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int MINB>
+// STATS (training forward, ConvGemmParams::stats): per-lane running sums of the stored values and their squares over every item of the
+// workgroup, reduced to ONE partial row per workgroup at the end - the BatchNorm behind the layer needs no reduce pass.  A workgroup's items
+// j = slot, slot + P, ... all have the same n-tile when P % tiles_n == 0 (the launcher checks), so the sums stay per channel.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int MINB, bool STATS = false>
 __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmParams p, const int tiles_m, const int tiles_n) {
   constexpr int EPC = Elem<T>::kPerChunk;
   constexpr int BKE = Elem<T>::kBK;
@@ -122,7 +125,12 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, P = gridDim.x >> 3;
   const int MG = p.groups * tiles_m;                            // (group, m-tile) pairs, dealt round-robin to XCDs
   const int cnt = MG > xcd ? ((MG - xcd + 7) / 8) * tiles_n : 0;   // items owned by this XCD
-  if (slot >= cnt) return;
+  if (slot >= cnt) {
+    if constexpr (STATS) {                                        // an idle workgroup still owns a partial row
+      for (int i = t; i < 2 * p.y_cstride; i += 256) p.stats[(size_t)blockIdx.x * 2 * p.y_cstride + i] = 0.f;
+    }
+    return;
+  }
 
   const int ohw = p.OH * p.OW;
   const int nk_main = p.Kw / BKE - (p.K2 > 0 ? 1 : 0);   // K slices of the main operand
@@ -237,6 +245,9 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 st0[STATS ? TN : 1], st1[STATS ? TN : 1];
+#pragma unroll
+  for (int j = 0; j < (STATS ? TN : 1); ++j) st0[j] = st1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto compute = [&](int buf) {
     const unsigned char* a = ldsA0 + buf * (BM * 128) + (wm * TM * 16 + lrow) * 128;
@@ -353,6 +364,11 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
         for (int jn = 0; jn < TN; ++jn) {
           f32x4 v = acc[i0 + i][jn] + bv[jn];
           acc[i0 + i][jn] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (STATS) {
+            const float mk = mk_[i] ? 1.0f : 0.0f;                 // rows past M are computed on clamped coordinates: not part of the map
+            st0[jn] += v * mk;
+            st1[jn] += v * v * mk;
+          }
           f32x4 dv = {0.f, 0.f, 0.f, 0.f};
           if constexpr (MODE == 1) {
 #pragma unroll
@@ -422,15 +438,63 @@ __global__ __launch_bounds__(256, MINB) void conv_gemm_v2_kernel(const ConvGemmP
     __syncthreads();
     buf ^= 1;
   }
+  if constexpr (STATS) {
+    // the 16 pixel lanes of a channel quad (shuffles), then the WAVES_M waves that share the channels, in fixed order (bit-reproducible)
+    float* red = reinterpret_cast<float*>(smem);                 // [4 waves][2][TN * 16 channels]
+    constexpr int CW = TN * 16;
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = st0[jn][e], q = st1[jn][e];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+        if (lrow == 0) {
+          red[(wave * 2 + 0) * CW + jn * 16 + lq * 4 + e] = a;
+          red[(wave * 2 + 1) * CW + jn * 16 + lq * 4 + e] = q;
+        }
+      }
+    __syncthreads();
+    const int nt0 = (slot % tiles_n) * BN;                       // this workgroup's n-tile; the other channels of its partial row are zero
+    for (int i = t; i < 2 * p.y_cstride; i += 256) {
+      const int which = i / p.y_cstride, n = i % p.y_cstride, nl = n - nt0;
+      float a = 0.f;
+      if (nl >= 0 && nl < BN) {
+        const int w_n = nl / CW, cl = nl % CW;
+#pragma unroll
+        for (int m = 0; m < WAVES_M; ++m) a += red[((m * WAVES_N + w_n) * 2 + which) * CW + cl];
+      }
+      p.stats[((size_t)blockIdx.x * 2 + which) * p.y_cstride + n] = a;
+    }
+  }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int MINB>
-static int launch_cfg(const ConvGemmParams& p, hipStream_t stream) {
+template <int BM, int BN, int MINB>
+static long v2_grid(const ConvGemmParams& p) {
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const long items = (long)p.groups * tiles_m * tiles_n;
   long grid = 256L * MINB;                       // persistent: MINB workgroups per CU
   if (items < grid) grid = (items + 7) / 8 * 8;
+  return grid;
+}
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int MINB>
+static int launch_cfg(const ConvGemmParams& p, hipStream_t stream) {
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const long grid = v2_grid<BM, BN, MINB>(p);
   hipLaunchKernelGGL((conv_gemm_v2_kernel<T, BM, BN, WAVES_M, WAVES_N, MINB>), dim3((unsigned)grid), dim3(256), 0, stream, p, tiles_m, tiles_n);
+  return (int)hipGetLastError();
+}
+// The statistics variant: 16-bit, 128 x 64 tile at two workgroups per CU (the running sums need 16 more registers than the three-per-CU budget has;
+// the 128 x 128 tile has none to spare).  Partial rows it writes into ConvGemmParams::stats, 0 = not produced for this layer.
+int conv_gemm_v2_stats_rows(const ConvGemmParams& p, int dtype) {
+  if (dtype != 1 || p.groups != 1 || p.pool2 || p.act != ACT_NONE || p.res || p.pos || p.y_rpi || p.out_f32 || p.y2 || (p.N % 64) || p.N > 128 || p.N != p.y_cstride || p.M <= 0) return 0;
+  const long grid = v2_grid<128, 64, 2>(p);
+  return (grid / 8) % (p.N / 64) == 0 ? (int)grid : 0;
+}
+static int launch_v2_stats(const ConvGemmParams& p, hipStream_t stream) {
+  const int tiles_m = (p.M + 127) / 128, tiles_n = p.N / 64;
+  const long grid = v2_grid<128, 64, 2>(p);
+  hipLaunchKernelGGL((conv_gemm_v2_kernel<bf16, 128, 64, 2, 2, 2, true>), dim3((unsigned)grid), dim3(256), 0, stream, p, tiles_m, tiles_n);
   return (int)hipGetLastError();
 }
 
@@ -449,6 +513,7 @@ int launch_conv_gemm_v2(const ConvGemmParams& p, int dtype, hipStream_t stream) 
   if (p.M <= 0) return 0;
   if (p.pool2 && (p.res || p.y_rpi || (p.OH & 1) || (p.OW & 1) || p.stride != 1)) return (int)hipErrorInvalidValue;
   if (dtype == 2) return launch_v2_t<f32x2l>(p, stream);      // fp32 storage, two-limb 16-bit MFMA arithmetic
+  if (p.stats) return conv_gemm_v2_stats_rows(p, dtype) ? launch_v2_stats(p, stream) : (int)hipErrorInvalidValue;
   return dtype == 0 ? launch_v2_t<float>(p, stream) : launch_v2_t<bf16>(p, stream);
 }
 
@@ -472,6 +537,17 @@ int conv_gemm_route(const ConvGemmParams& p, int dtype) {
   if (gconv3x3_x2_eligible(p, dtype)) return 3;
   if (gemm256_eligible(p, dtype) || gemm256_slice_rows(p, dtype)) return 1;
   return 2;
+}
+
+// partial rows ConvGemmParams::stats receives when launch_conv_gemm runs p with stats set (follows the routing below); 0: the layer's kernel has no
+// statistics epilogue and the caller must not set `stats`
+int conv_stats_rows(const ConvGemmParams& p, int dtype) {
+  ConvGemmParams q = p;
+  float dummy;
+  q.stats = &dummy;
+  if (conv3x3_halo_eligible(q, dtype)) return conv3x3_halo_stats_rows(p, dtype);
+  if (gconv3x3_x2_eligible(q, dtype) || gemm256_eligible(q, dtype) || gemm256_slice_rows(q, dtype)) return 0;
+  return conv_gemm_v2_stats_rows(p, dtype);
 }
 
 int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream) {

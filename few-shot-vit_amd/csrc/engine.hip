@@ -685,7 +685,7 @@ ConvGemmParams conv_params(const Layer& L, const void* x, void* y, int B, int H,
   p.N = L.N; p.y_cstride = y_cstride; p.K = L.K; p.Kw = L.Kw; p.M = B * p.OH * p.OW;
   p.groups = L.groups; p.act = act; p.res_first = res_first; p.log2Cin = ilog2(Cin);
   p.x2 = nullptr; p.x2_cstride = 0; p.K2 = 0; p.pool2 = 0; p.y_rpi = 0; p.y_row0 = 0;
-  p.w_gstride = 0; p.w_rstride = 0; p.out_f32 = 0; p.y2 = nullptr;
+  p.w_gstride = 0; p.w_rstride = 0; p.out_f32 = 0; p.y2 = nullptr; p.stats = nullptr;
   return p;
 }
 

@@ -194,7 +194,11 @@ int conv_pack_fwd(TR* t, const ConvSpec& c, void** pk, int* Kw_out = nullptr) {
   return packed_weight(t, PackJob{w->data, nullptr, c.O, c.Ig, c.KH, c.KW, c.groups, 0, Ng, Kw, c.hd_rows, c.hdp_rows, c.hd_cols, c.hdp_cols},
                        (size_t)c.groups * Ng * Kw * t->es, pk);
 }
-int conv_fwd(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, void* z, const float* bias, void* gp = nullptr) {
+// st_rows != nullptr: ask the layer's kernel for the BatchNorm statistics of z (ConvGemmParams::stats); *st_partial / *st_rows receive the partial
+// sums (tmp arena) and their row count, 0 rows = this layer's kernel does not produce them (the caller runs the reduce pass)
+int conv_fwd(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, void* z, const float* bias, void* gp = nullptr, float** st_partial = nullptr,
+             int* st_rows = nullptr) {
+  if (st_rows) *st_rows = 0;
   const fsvit_param* w = getp(t, c.wname);
   if (!w) return FSVIT_ERR_KEY;
   const int bke = 128 / t->es, Ng = c.rows_fwd(), K = c.kpad_cols(), Kw = round_up(K, bke);
@@ -210,6 +214,15 @@ int conv_fwd(TR* t, const ConvSpec& c, const void* x, int B, int H, int W, void*
   else p = gemm_params(x, pk, z, B, H, W, K / (c.KH * c.KW), c.groups * (K / (c.KH * c.KW)), c.KH, c.KW, c.stride, c.pad, Ng, c.groups * Ng, K, Kw, c.groups);
   p.bias = bias;
   if (gp) { p.act = ACT_GELU; p.y2 = gp; }
+  if (st_rows) {
+    static const bool off = [] { const char* e = getenv("FSVIT_BN_PRODUCER_STATS"); return e && e[0] == '0'; }();
+    *st_rows = (off || t->freeze_bn) ? 0 : conv_stats_rows(p, t->gdt);
+    if (*st_rows > 0) {
+      *st_partial = (float*)t->tmp.take((size_t)*st_rows * 2 * p.y_cstride * 4);
+      if (!*st_partial) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (producer statistics)");
+      p.stats = *st_partial;
+    }
+  }
   T_RUN(launch_conv_gemm(p, t->gdt, t->st));
   return 0;
 }
@@ -378,7 +391,9 @@ int run_finalizes(TR* t) {
 // ---------------------------------------------------------------- BatchNorm (train)
 // A residual add queued by the block that produced z (z = add.a + add.scale[image] * add.b, not yet computed) rides in the reduce pass.
 struct PendingAdd { const void* a = nullptr; const void* b = nullptr; const float* scale = nullptr; void* out = nullptr; size_t n = 0, per_img = 0; };
-int bn_fwd(TR* t, const std::string& name, const void* z, int M, int C, int act, const void* res, void* y, BnSave* sv, PendingAdd* add = nullptr) {
+// pre / pre_rows: partial sums of z that the producing kernel already wrote (conv_fwd's st_partial / st_rows): no reduce pass
+int bn_fwd(TR* t, const std::string& name, const void* z, int M, int C, int act, const void* res, void* y, BnSave* sv, PendingAdd* add = nullptr,
+           const float* pre = nullptr, int pre_rows = 0) {
   const fsvit_param *g = getp(t, name + ".weight"), *b = getp(t, name + ".bias"), *rm = getp(t, name + ".running_mean"), *rv = getp(t, name + ".running_var");
   if (!g || !b || !rm || !rv) return FSVIT_ERR_KEY;
   float* stats = (float*)t->save.take((size_t)4 * C * 4);
@@ -393,9 +408,13 @@ int bn_fwd(TR* t, const std::string& name, const void* z, int M, int C, int act,
   if (t->freeze_bn) {
     T_RUN(launch_bn_frozen_coeffs(C, t->cfg.bn_eps, g->data, b->data, rm->data, rv->data, sv->mean, sv->invstd, sv->sa, sv->sb, t->st));
   } else {
-    if (fuse_add) T_RUN(launch_bn_reduce(z, nullptr, nullptr, nullptr, partial, M, C, 0, t->dtype, t->st, add->a, add->b, add->scale, (int)(add->per_img / C)));
-    else T_RUN(launch_bn_reduce(z, nullptr, nullptr, nullptr, partial, M, C, 0, t->dtype, t->st));
-    T_RUN(launch_bn_fwd_finalize(partial, M, C, t->cfg.bn_eps, 0.1f, g->data, b->data, rm->data, rv->data, sv->mean, sv->invstd, sv->sa, sv->sb, t->st));
+    if (pre && pre_rows > 0 && !fuse_add) {
+      T_RUN(launch_bn_fwd_finalize_nblk(pre, pre_rows, M, C, t->cfg.bn_eps, 0.1f, g->data, b->data, rm->data, rv->data, sv->mean, sv->invstd, sv->sa, sv->sb, t->st));
+    } else {
+      if (fuse_add) T_RUN(launch_bn_reduce(z, nullptr, nullptr, nullptr, partial, M, C, 0, t->dtype, t->st, add->a, add->b, add->scale, (int)(add->per_img / C)));
+      else T_RUN(launch_bn_reduce(z, nullptr, nullptr, nullptr, partial, M, C, 0, t->dtype, t->st));
+      T_RUN(launch_bn_fwd_finalize(partial, M, C, t->cfg.bn_eps, 0.1f, g->data, b->data, rm->data, rv->data, sv->mean, sv->invstd, sv->sa, sv->sb, t->st));
+    }
   }
   if (add) *add = PendingAdd{};
   if (y) T_RUN(launch_bn_apply(z, sv->sa, sv->sb, res, y, (size_t)M, C, act, t->dtype, t->st));     // (y == nullptr: the caller applies sa / sb in a fused pass)
@@ -491,14 +510,30 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
   NEED(S.zd = take_act(t, M0 * t->C1)); S.ad = nullptr; NEED(S.z2 = take_act(t, M0 * t->C1)); NEED(S.a2 = take_act(t, M0 * t->C1));
   NEED(S.z3 = take_act(t, M0 * t->C1)); S.a3 = nullptr; NEED(S.arg = (unsigned char*)t->save.take(M1 * t->C1)); NEED(S.x1 = take_act(t, M1 * t->C1));
   T_RUN(launch_im2col27(x, S.patches, B, img, img, H0, H0, dt, st));
-  T_TRY(conv_fwd(t, sp.conv1, S.patches, B, H0, H0, S.z1, nullptr));
-  T_TRY(bn_fwd(t, "stem.bn1", S.z1, (int)M0, t->C0, ACT_LRELU, nullptr, S.a1, &S.b1));
-  T_TRY(conv_fwd(t, sp.down, S.patches, B, H0, H0, S.zd, nullptr));
-  T_TRY(bn_fwd(t, "stem.downsample.1", S.zd, (int)M0, t->C1, ACT_NONE, nullptr, nullptr, &S.bd));      // statistics only: applied inside the pooling pass
-  T_TRY(conv_fwd(t, sp.conv2, S.a1, B, H0, H0, S.z2, nullptr));
-  T_TRY(bn_fwd(t, "stem.bn2", S.z2, (int)M0, t->C1, ACT_LRELU, nullptr, S.a2, &S.b2));
-  T_TRY(conv_fwd(t, sp.conv3, S.a2, B, H0, H0, S.z3, nullptr));
-  T_TRY(bn_fwd(t, "stem.bn3", S.z3, (int)M0, t->C1, ACT_LRELU, nullptr, nullptr, &S.b3));      // statistics only: applied inside the pooling pass below
+  {
+    // (the producing GEMMs hand the BatchNorm statistics of the maps they store to the finalize: no reduce pass, ConvGemmParams::stats)
+    const size_t mark = t->tmp.off;
+    float* stp = nullptr;
+    int str = 0;
+    T_TRY(conv_fwd(t, sp.conv1, S.patches, B, H0, H0, S.z1, nullptr, nullptr, &stp, &str));
+    T_TRY(bn_fwd(t, "stem.bn1", S.z1, (int)M0, t->C0, ACT_LRELU, nullptr, S.a1, &S.b1, nullptr, stp, str));
+    t->tmp.off = mark;
+    T_TRY(conv_fwd(t, sp.down, S.patches, B, H0, H0, S.zd, nullptr, nullptr, &stp, &str));
+    T_TRY(bn_fwd(t, "stem.downsample.1", S.zd, (int)M0, t->C1, ACT_NONE, nullptr, nullptr, &S.bd, nullptr, stp, str));      // statistics only: applied inside the pooling pass
+    t->tmp.off = mark;
+  }
+  {
+    // conv2 / conv3 (conv3x3_halo) hand their BatchNorm the statistics of the map they store: no reduce pass over 328 MB
+    const size_t mark = t->tmp.off;
+    float* stp = nullptr;
+    int str = 0;
+    T_TRY(conv_fwd(t, sp.conv2, S.a1, B, H0, H0, S.z2, nullptr, nullptr, &stp, &str));
+    T_TRY(bn_fwd(t, "stem.bn2", S.z2, (int)M0, t->C1, ACT_LRELU, nullptr, S.a2, &S.b2, nullptr, stp, str));
+    t->tmp.off = mark;
+    T_TRY(conv_fwd(t, sp.conv3, S.a2, B, H0, H0, S.z3, nullptr, nullptr, &stp, &str));
+    T_TRY(bn_fwd(t, "stem.bn3", S.z3, (int)M0, t->C1, ACT_LRELU, nullptr, nullptr, &S.b3, nullptr, stp, str));      // statistics only: applied inside the pooling pass below
+    t->tmp.off = mark;
+  }
   {
     const fsvit_param* pos = getp(t, "pos_embed1");
     if (!pos) return FSVIT_ERR_KEY;

@@ -1489,6 +1489,11 @@ int launch_bn_reduce(const void* a, const void* z, const float* mean, const floa
 #undef FSVIT_BNR
   return (int)hipGetLastError();
 }
+int launch_bn_fwd_finalize_nblk(const float* partial, int nblk, int M, int C, float eps, float momentum, const float* gamma, const float* beta, float* rmean, float* rvar,
+                                float* mean, float* invstd, float* sa, float* sb, hipStream_t s) {
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, nblk, M, C, eps, momentum, gamma, beta, rmean, rvar, mean, invstd, sa, sb);
+  return (int)hipGetLastError();
+}
 int launch_bn_fwd_finalize(const float* partial, int M, int C, float eps, float momentum, const float* gamma, const float* beta, float* rmean, float* rvar,
                            float* mean, float* invstd, float* sa, float* sb, hipStream_t s) {
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, partial, bn_reduce_blocks(M), M, C, eps, momentum, gamma, beta, rmean, rvar, mean, invstd, sa, sb);
