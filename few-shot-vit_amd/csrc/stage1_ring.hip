@@ -49,7 +49,8 @@ constexpr int H2 = H1R + (HID / 8) * PITCH;      // h2 of the current chunk: 32 
 constexpr int OROW = C1 * 2 + 16;                // output tile row pitch (272 B: conflict-free 8-byte column writes)
 constexpr int OUT = H2 + (HID / 8) * H2P;        // output tile [64 pixels][128 channels]
 constexpr int ZERO = OUT + CH * OROW;            // 16 zero bytes
-constexpr int LDS_BYTES = ZERO + 16;             // 148 496
+constexpr int BIAS = ZERO + 16;                  // MODE 3: conv1's folded bias [256] fp32 (8 VGPRs the training variant does not have)
+constexpr int LDS_BYTES = BIAS + HID * 4;        // 149 520
 }  // namespace s1r
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_r;
@@ -75,6 +76,12 @@ __device__ __forceinline__ f32x4 s1r_gelu4(f32x4 v) {
 // derivatives g1 / g2 at their pre-activations go to HBM for the backward pass ([M][256] each) - the three GEMM launches of a block and their
 // hidden-map round trips in one kernel.
 struct S1Train { bf16 *h1, *g1, *h2, *g2; };
+// MODE 3 (round 4: the training forward of a whole stage-1 BLOCK): x = the block's RAW input, the batch-statistics BatchNorm folded into conv1 exactly
+// as the eval engine folds the running statistics (w1 = W1 diag(sa) rounded once, b1 = W1 sb; fold_prenorm_kernel makes them after the BatchNorm's
+// finalize), the residual from the x ring with the block's DropPath scale per image: y = x + scale[image] * conv3(h2).  Also written: h1 / g1 / h2 / g2
+// as in MODE 1, the normalised input xn = sa x + sb of the workgroup's own pixels (the backward's weight-gradient operand), and the per-workgroup
+// partial sums of y and y^2 - the statistics of the NEXT block's BatchNorm.  Replaces bn_apply + stage1_ring_train + the residual add / reduce pass.
+struct S1Fused { bf16* xn; const float *sa, *sb, *scale; float* stats; };
 __device__ __forceinline__ void s1r_gelu4_d(f32x4 v, f32x4& h, f32x4& d) {
   f32x2 da, db;
   const f32x2 a = gelu_sig2_d(f32x2{v[0], v[1]}, da), b = gelu_sig2_d(f32x2{v[2], v[3]}, db);
@@ -88,9 +95,11 @@ __device__ __forceinline__ void s1r_gelu4_d(f32x4 v, f32x4& h, f32x4& d) {
 template <int MODE>
 __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf16* __restrict__ y, const bf16* __restrict__ w1,
                                                  const float* __restrict__ b1, const bf16* __restrict__ w2, const bf16* __restrict__ w3, int M,
-                                                 int H, int W, int n_chunks, int chunks_per_wg, const S1Train tr) {
+                                                 int H, int W, int n_chunks, int chunks_per_wg, const S1Train tr, const S1Fused fu = S1Fused{}) {
   using namespace s1r;
-  constexpr bool TRAIN = MODE == 1;
+  constexpr bool TRAIN = MODE == 1 || MODE == 3;
+  constexpr bool FUSED = MODE == 3 || MODE == 4;
+  constexpr bool FSTATS = MODE == 4;                                // (the statistics epilogue costs 16 VGPRs the kernel does not have: 25 spills, +95 us - kept for reference, not launched)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, lrow = lane & 15, lq = lane >> 4;
   const int g = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -124,6 +133,12 @@ __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf1
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) bias1[nt] = *reinterpret_cast<const f32x4*>(b1 + g * 32 + lq * 8 + nt * 4);
   }
+  if constexpr (FUSED) {
+    if (t < HID) reinterpret_cast<float*>(smem + BIAS)[t] = b1[t];      // (visible after the first barrier below)
+  }
+  f32x4 st0[FSTATS ? 2 : 1], st1[FSTATS ? 2 : 1];                         // FUSED: running sums of this lane's 8 output channels (y, y^2) over all its pixels
+#pragma unroll
+  for (int nt = 0; nt < (FSTATS ? 2 : 1); ++nt) st0[nt] = st1[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   const long own_lo = (long)q0 * CH;                                   // TRAIN: this workgroup stores h1 / g1 of its OWN pixels only (the halo is recomputed by the neighbours)
   long own_hi = (long)q1 * CH; own_hi = own_hi < M ? own_hi : M;
 
@@ -147,6 +162,16 @@ __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf1
       const int u = t + 512 * u0, p = (u & 7) + 8 * (u >> 7), c8 = (u >> 3) & 15;
       const u32x4 v = ((pxok >> u0) & 1u) ? px[u0] : u32x4{0u, 0u, 0u, 0u};
       *reinterpret_cast<u32x4*>(smem + XR + c8 * PITCH + (int)((P0 + p) & (RING - 1)) * 16) = v;
+      if constexpr (FUSED) {             // the normalised input of the workgroup's own pixels, for the backward pass (c8 is the same for both u0)
+        const long m = P0 + p;
+        if (m >= own_lo && m < own_hi) {
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(fu.sa + c8 * 8), a1 = *reinterpret_cast<const f32x4*>(fu.sa + c8 * 8 + 4);
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(fu.sb + c8 * 8), s1 = *reinterpret_cast<const f32x4*>(fu.sb + c8 * 8 + 4);
+          const bf16x8 r = __builtin_bit_cast(bf16x8, v);
+          *reinterpret_cast<u32x4*>(fu.xn + (size_t)m * C1 + c8 * 8) =
+              s1r_pack8(f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]} * a0 + s0, f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]} * a1 + s1);
+        }
+      }
     }
   };
   // conv1 + bias + GELU for the 64 pixels from P0: wave g computes hidden channels 32 g .. 32 g + 31 into ITS planes of the h1 ring
@@ -167,6 +192,10 @@ __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf1
     for (int mt = 0; mt < CH / 16; ++mt) {
       const int slot = (int)((P0 + mt * 16 + lrow) & (RING - 1)) * 16;
       f32x4 acc[2] = {bias1[0], bias1[1]};
+      if constexpr (FUSED) {
+        acc[0] = *reinterpret_cast<const f32x4*>(smem + BIAS + (g * 32 + lq * 8) * 4);
+        acc[1] = *reinterpret_cast<const f32x4*>(smem + BIAS + (g * 32 + lq * 8 + 4) * 4);
+      }
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) {
         const u32x4 xf = *reinterpret_cast<const u32x4*>(xplane + kc * (4 * PITCH) + slot);
@@ -300,6 +329,19 @@ __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf1
         acc[0] += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
         acc[1] += f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
       }
+      if constexpr (FUSED) {
+        const int m = m0 + mt * 16 + lrow;
+        const bool inr = m < M;
+        const float sc = fu.scale ? fu.scale[(inr ? m : 0) / HW] : 1.0f;
+        const bf16x8 r = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xres + (m & (RING - 1)) * 16));
+        acc[0] = acc[0] * sc + f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+        acc[1] = acc[1] * sc + f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+        if constexpr (FSTATS) {
+          const float mk = inr ? 1.0f : 0.0f;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) { st0[nt] += acc[nt] * mk; st1[nt] += acc[nt] * acc[nt] * mk; }
+        }
+      }
       *reinterpret_cast<u32x4*>(outw + (mt * 16 + lrow) * OROW) = s1r_pack8(acc[0], acc[1]);
     }
     S1R_SYNC();                                                // D: the output tile is complete
@@ -308,6 +350,29 @@ __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf1
       const int u = t + 512 * u0, p = u >> 4, c8 = u & 15;
       const long m = (long)m0 + p;
       if (m < M) *reinterpret_cast<u32x4*>(y + (size_t)m * C1 + c8 * 8) = *reinterpret_cast<const u32x4*>(smem + OUT + p * OROW + c8 * 16);
+    }
+  }
+  if constexpr (FSTATS) {
+    // workgroup partial of the output statistics: the 16 pixel lanes of a channel octet (shuffles), then the two waves (ph3 = 0, 1) that share the
+    // 32 channels, in fixed order (bit-reproducible); stats[(wg * 2 + which) * 128 + channel]
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);               // [8 waves][2][32 channels]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = st0[nt][e], q = st1[nt][e];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+        if (lrow == 0) {
+          red[(g * 2 + 0) * 32 + lq * 8 + nt * 4 + e] = a;
+          red[(g * 2 + 1) * 32 + lq * 8 + nt * 4 + e] = q;
+        }
+      }
+    __syncthreads();
+    if (t < 256) {
+      const int which = t >> 7, c = t & 127, np = c >> 5, cl = c & 31;
+      fu.stats[((size_t)blockIdx.x * 2 + which) * C1 + c] = red[((np * 2 + 0) * 2 + which) * 32 + cl] + red[((np * 2 + 1) * 2 + which) * 32 + cl];
     }
   }
 }
@@ -326,6 +391,12 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_dgrad_kernel(const bf16* _
                                                                    const bf16* __restrict__ w2, const bf16* __restrict__ w3, int M, int H, int W, int n_chunks,
                                                                    int chunks_per_wg, const S1Train tr) {
   stage1_ring_body<2>(x, y, w1, nullptr, w2, w3, M, H, W, n_chunks, chunks_per_wg, tr);
+}
+
+__global__ __launch_bounds__(512, 1) void stage1_ring_block_train_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const bf16* __restrict__ w1,
+                                                                         const float* __restrict__ b1, const bf16* __restrict__ w2, const bf16* __restrict__ w3, int M,
+                                                                         int H, int W, int n_chunks, int chunks_per_wg, const S1Train tr, const S1Fused fu) {
+  stage1_ring_body<3>(x, y, w1, b1, w2, w3, M, H, W, n_chunks, chunks_per_wg, tr, fu);
 }
 
 bool stage1_ring_supported(int dtype, int C1, int hid, int group, int H1) {
@@ -370,6 +441,34 @@ int launch_stage1_ring_train(const void* xn, void* z3, const void* w1, const voi
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(stage1_ring_train_kernel, dim3(wgs), dim3(512), s1r::LDS_BYTES, s, (const bf16*)xn, (bf16*)z3, (const bf16*)w1, (const bf16*)w2, (const bf16*)w3, M, H, W,
                      n_chunks, cpw, S1Train{(bf16*)h1, (bf16*)g1, (bf16*)h2, (bf16*)g2});
+  return (int)hipGetLastError();
+}
+// Training forward of a whole stage-1 block (MODE 3, see S1Fused): x [M][128] raw block input, w1f / b1f = conv1 with the batch-statistics BatchNorm folded
+// (fold_prenorm), scale = DropPath scale per image or NULL, out = x + scale * conv3(...), xn = sa x + sb, stats = partial sums of out / out^2:
+// stage1_ring_block_train_rows(M) rows of 2 x 128 floats.
+static inline void s1r_grid(int M, int* wgs, int* cpw) {
+  const int n_chunks = (M + s1r::CH - 1) / s1r::CH;
+  int w = n_chunks < 256 ? n_chunks : 256;
+  *cpw = (n_chunks + w - 1) / w;
+  *wgs = (n_chunks + *cpw - 1) / *cpw;
+}
+int stage1_ring_block_train_rows(int B, int H, int W) {
+  int wgs, cpw;
+  s1r_grid(B * H * W, &wgs, &cpw);
+  return wgs;
+}
+int launch_stage1_ring_block_train(const void* x, void* out, const void* w1f, const float* b1f, const void* w2, const void* w3, void* h1, void* g1, void* h2, void* g2,
+                                   void* xn, const float* sa, const float* sb, const float* scale, float* stats, int B, int H, int W, hipStream_t s) {
+  const long Ml = (long)B * H * W;
+  if (Ml <= 0) return 0;
+  if (Ml >= (1L << 31) - 256 || W > 20 || H * W < 16 || x == out) return (int)hipErrorInvalidValue;
+  const int M = (int)Ml, n_chunks = (M + s1r::CH - 1) / s1r::CH;
+  int wgs, cpw;
+  s1r_grid(M, &wgs, &cpw);
+  hipError_t e = hipFuncSetAttribute((const void*)stage1_ring_block_train_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, s1r::LDS_BYTES);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(stage1_ring_block_train_kernel, dim3(wgs), dim3(512), s1r::LDS_BYTES, s, (const bf16*)x, (bf16*)out, (const bf16*)w1f, b1f, (const bf16*)w2, (const bf16*)w3,
+                     M, H, W, n_chunks, cpw, S1Train{(bf16*)h1, (bf16*)g1, (bf16*)h2, (bf16*)g2}, S1Fused{(bf16*)xn, sa, sb, scale, stats});
   return (int)hipGetLastError();
 }
 // data-gradient chain of the block: dz3 [M][128] -> dz2 = (dz3 W3) * g2', dz1 = (grouped conv^T of dz2) * g1', dxn = dz1 W1  (w3t / w2t / w1t: the transposed

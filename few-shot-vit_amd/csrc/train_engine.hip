@@ -112,8 +112,8 @@ struct fsvit_visformer_trainer {
   hipEvent_t ev_a = nullptr;
   std::vector<hipEvent_t> ev_done;        // one per side launch of a pass (recorded behind it; the side stream runs in order)
   int side_seq = 0;                       // side launches of this pass so far
-  // default: on for the ViT / DeiT trainer (GEMM-heavy: 19.2 -> 17.6 ms per 200-image DeiT-S step), off for the Visformer trainer (its 800-image step is
-  // HBM-bound in every kernel, overlap buys nothing: 16.55 vs 16.67 ms); FSVIT_WGRAD_SIDE_STREAM=0 / 1 forces it
+  // default: on (ViT / DeiT trainer: 19.2 -> 17.6 ms per 200-image DeiT-S step; Visformer trainer: nothing in round 3 - 16.55 vs 16.67 ms -, 14.26 -> 14.15 ms
+  // once round 4 had taken HBM-bound passes out of the main stream); FSVIT_WGRAD_SIDE_STREAM=0 / 1 forces it
   bool side_on = false;
   struct Range { const unsigned char *lo, *hi; int seq; };
   std::vector<Range> pend;
@@ -555,6 +555,14 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
 
   // ---- stage 1 (Block with attn_disabled: x + DropPath(mlp(norm2(x))), visformer.py:259-263)
   t->s1.resize(t->cfg.depth[0]);
+  // Round 4: a block is ONE launch behind its BatchNorm's statistics (stage1_ring.hip MODE 3): the batch statistics are folded into conv1 as the eval
+  // engine folds the running statistics (fold_prenorm), the residual with the DropPath scale is added in the same kernel - no apply pass, and the
+  // reduce pass reads one finished map instead of adding two and storing a third.  (The statistics of the block's output from the same kernel were
+  // built and measured: 16 more VGPRs than the kernel has, 25 spills, +95 us per launch.)  FSVIT_STAGE1_BLOCK_FUSED=0: the round-3 route.
+  static const bool block_off = [] { const char* e = getenv("FSVIT_STAGE1_BLOCK_FUSED"); return e && e[0] == '0'; }();
+  static const bool fused_off = [] { const char* e = getenv("FSVIT_STAGE1_TRAIN_FUSED"); return e && e[0] == '0'; }();
+  const bool block_fused = !block_off && !fused_off && stage1_ring_supported(t->gdt, t->C1, t->hid1, t->cfg.group, H1);
+  const size_t s1_mark = t->tmp.off;
   for (int i = 0; i < t->cfg.depth[0]; ++i, ++blk) {
     auto& b = t->s1[i];
     const std::string p = "stage1." + std::to_string(i) + ".";
@@ -562,10 +570,28 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
     NEED(b.xn = take_act(t, M1 * t->C1)); NEED(b.z1 = take_act(t, M1 * t->hid1)); NEED(b.h1 = take_act(t, M1 * t->hid1));
     NEED(b.z2 = take_act(t, M1 * t->hid1)); NEED(b.h2 = take_act(t, M1 * t->hid1)); NEED(b.out = take_act(t, M1 * t->C1));
     const size_t mark = t->tmp.off;
+    if (block_fused) {
+      T_TRY(bn_fwd(t, p + "norm2.bn", b.x, (int)M1, t->C1, ACT_NONE, nullptr, nullptr, &b.bn));   // statistics only
+      const fsvit_param* w1 = getp(t, sp.s1c1[i].wname);
+      if (!w1) return FSVIT_ERR_KEY;
+      void* w1f = t->tmp.take((size_t)t->hid1 * t->C1 * t->es); NEED(w1f);
+      float* b1f = (float*)t->tmp.take((size_t)t->hid1 * 4); NEED(b1f);
+      T_RUN(launch_fold_prenorm(w1->data, b.bn.sa, b.bn.sb, w1f, b1f, t->hid1, t->C1, t->C1, dt, st));
+      void *pk2 = nullptr, *pk3 = nullptr;
+      int kw2 = 0;
+      T_TRY(conv_pack_fwd(t, sp.s1c2[i], &pk2, &kw2));
+      T_TRY(conv_pack_fwd(t, sp.s1c3[i], &pk3));
+      if (kw2 != 320) return fsvit_set_error(FSVIT_ERR_ARG, "stage-1 grouped conv pack: Kw %d", kw2);
+      b.scale = dp_scale(t, dp_call, blk, nblk);
+      if (t->dp_rate * blk > 0.f) ++dp_call;
+      T_RUN(launch_stage1_ring_block_train(b.x, b.out, w1f, b1f, pk2, pk3, b.h1, b.z1, b.h2, b.z2, b.xn, b.bn.sa, b.bn.sb, b.scale, nullptr, B, H1, H1, st));
+      t->tmp.off = mark;
+      xcur = b.out;
+      continue;
+    }
     void* z3 = take_tmp(t, M1 * t->C1); NEED(z3);
     T_TRY(bn_fwd(t, p + "norm2.bn", b.x, (int)M1, t->C1, ACT_NONE, nullptr, b.xn, &b.bn, &pend));
     // (z1 / z2 hold the GELU DERIVATIVES at the pre-activations, written next to h1 / h2 by the conv epilogues)
-    static const bool fused_off = [] { const char* e = getenv("FSVIT_STAGE1_TRAIN_FUSED"); return e && e[0] == '0'; }();
     if (!fused_off && stage1_ring_supported(t->gdt, t->C1, t->hid1, t->cfg.group, H1)) {
       // the three GEMM launches of the Mlp and the round trips of its hidden maps in ONE kernel (stage1_ring.hip, training variant)
       void *pk1 = nullptr, *pk2 = nullptr, *pk3 = nullptr;
@@ -589,6 +615,7 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
     t->tmp.off = mark;
     xcur = b.out;
   }
+  t->tmp.off = s1_mark;
 
   // ---- stages 2, 3
   for (int sg = 2; sg <= 3; ++sg) {
@@ -1186,7 +1213,7 @@ extern "C" int fsvit_visformer_trainer_create(const fsvit_visformer_cfg* cfg, in
   t->hd2 = t->C2 / cfg->num_heads; t->hd3 = t->C3 / cfg->num_heads;
   t->hdp2 = round_up(t->hd2, kch); t->hdp3 = round_up(t->hd3, kch);
   t->Cg = t->hid1 / cfg->group;
-  t->side_on = side_stream_default(false);
+  t->side_on = side_stream_default(true);      // round 4: the direct weight-gradient launches beside the data-gradient chain: 14.26 -> 14.15 ms per 800-image step (same box)
   *out = t;
   return 0;
 }

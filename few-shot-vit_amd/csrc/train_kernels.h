@@ -55,6 +55,8 @@ int launch_pool_bn_bwd_reduce(const void* dout, const unsigned char* arg, const 
                               const float* isd, float* partial3, float* partiald, int B, int OH, int OW, int C, int dtype, hipStream_t s);
 int launch_pool_bn_bwd_apply(const void* dout, const unsigned char* arg, const void* z3, const void* zd, const float* mean3, const float* is3, const float* meand,
                              const float* isd, const float* coef3, const float* coefd, void* dz3, void* dzd, int B, int OH, int OW, int C, int dtype, hipStream_t s);
+// 1x1 conv weights with a pre-norm BatchNorm's scale / shift folded in: wf [N][Kw] (storage type), bf [N] fp32 (fold_prenorm_kernel)
+int launch_fold_prenorm(const float* W, const float* sa, const float* sb, void* wf, float* bf, int N, int C, int Kw, int dtype, hipStream_t s);
 int launch_bn_fwd_finalize_nblk(const float* partial, int nblk, int M, int C, float eps, float momentum, const float* gamma, const float* beta, float* rmean, float* rvar,
                                 float* mean, float* invstd, float* sa, float* sb, hipStream_t s);
 int launch_bn_bwd_finalize_nblk(const float* partial, int nblk, int M, int C, const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* ca, float* cb,

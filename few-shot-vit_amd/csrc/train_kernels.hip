@@ -1343,6 +1343,24 @@ __global__ __launch_bounds__(64) void vit_cls_ln_bwd_kernel(const float* __restr
   }
 }
 
+// A 1x1 conv behind a pre-norm BatchNorm with the batch statistics folded in (what the eval engine's packer does with the running statistics):
+// wf[n][c] = W[n][c] * sa[c] rounded ONCE to the storage type ([N][Kw] rows, zero padded), bf[n] = sum_c W[n][c] * sb[c].  One wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void fold_prenorm_kernel(const float* __restrict__ W, const float* __restrict__ sa, const float* __restrict__ sb,
+                                                           T* __restrict__ wf, float* __restrict__ bf, int N, int C, int Kw) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int c = lane; c < Kw; c += 64) {
+    float v = 0.f;
+    if (c < C) { const float w = W[(size_t)n * C + c]; v = w * sa[c]; acc += w * sb[c]; }
+    wf[(size_t)n * Kw + c] = from_f32<T>(v);
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) bf[n] = acc;
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == 0) { CALL_F32; } else { CALL_BF16; } } while (0)
 
@@ -1487,6 +1505,11 @@ int launch_bn_reduce(const void* a, const void* z, const float* mean, const floa
   else if (C % 8 == 0) FSVIT_BNR(bf16, 8);
   else FSVIT_BNR(bf16, 4);
 #undef FSVIT_BNR
+  return (int)hipGetLastError();
+}
+int launch_fold_prenorm(const float* W, const float* sa, const float* sb, void* wf, float* bf, int N, int C, int Kw, int dtype, hipStream_t s) {
+  DISPATCH_T(dtype, hipLaunchKernelGGL(fold_prenorm_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, s, W, sa, sb, (float*)wf, bf, N, C, Kw),
+             hipLaunchKernelGGL(fold_prenorm_kernel<bf16>, dim3((N + 3) / 4), dim3(256), 0, s, W, sa, sb, (bf16*)wf, bf, N, C, Kw));
   return (int)hipGetLastError();
 }
 int launch_bn_fwd_finalize_nblk(const float* partial, int nblk, int M, int C, float eps, float momentum, const float* gamma, const float* beta, float* rmean, float* rvar,
