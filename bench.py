@@ -517,7 +517,46 @@ def extra_legs(args, dev):
     free()
     legs['end_to_end'] = end_to_end_leg(args, dev)
     free()
+    legs['distill'] = distill_leg(dev)
+    free()
     return legs
+
+
+def distill_leg(dev, batch=512, steps=8, warm=3, n_classes=64):
+    """BASELINE configs[3] at its own size (sun_meta_training/offline.py:263-309): one SUN meta-training step = `token-label` student over
+    Visformer-S in train mode (drop_path 0.1) on a batch of 512 images, global CE + 0.5 x SoftTargetCrossEntropy of its 25 x 65 token logits
+    against soft labels generated from the FROZEN teacher's token logits (eval engine), backward, AdamW.  Images resident in HBM."""
+    from fewshot_vit_amd import models, offline, synthetic
+    from fewshot_vit_amd.models.classifier import FsvitAdamW, SoftTargetCrossEntropy
+    margs = dict(encoder='visformer_micro_80', encoder_args=dict(drop_path_rate=0.1, return_map=True, numerics='bf16'), classifier='linear-classifier',
+                 classifier_args=dict(n_classes=n_classes))
+    student, teacher = models.make('token-label', **margs).to(dev), models.make('token-label', **margs).to(dev)
+    for mdl in (student, teacher):
+        enc_shapes = {k: tuple(v.shape) for k, v in mdl.encoder.state_dict().items()}
+        esd = synthetic.synthetic_checkpoint_sd({'encoder.' + k: s for k, s in enc_shapes.items()}, calib='visformer_micro_80')
+        mdl.encoder.load_state_dict({k[len('encoder.'):]: v for k, v in esd.items()})
+    student.train()
+    teacher.eval()
+    opt = FsvitAdamW(student.parameters(), betas=(0.9, 0.999), eps=1e-8, lr=5e-4 * batch / 512, weight_decay=0.05)
+    crit = SoftTargetCrossEntropy()
+    g = torch.Generator(device=dev).manual_seed(4242)
+    x = torch.randn(batch, 3, 80, 80, device=dev, generator=g)
+    label = torch.randint(0, n_classes, (batch,), device=dev, generator=g)
+    for _ in range(warm):
+        offline.distill_step(student, teacher, opt, crit, x, x, label)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, acc = offline.distill_step(student, teacher, opt, crit, x, x, label)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    flop = 4.0 * MODELS['visformer_micro_80'][0] * batch              # student forward + data gradient + weight gradient, teacher forward
+    tf = flop / (ms * 1e-3) / 1e12
+    return {'value': batch / (ms * 1e-3), 'unit': 'images/s', 'ms_per_step': ms, 'steps': steps, 'warmup': warm, 'dtype': 'bf16', 'images_per_step': batch,
+            'whole_path_tflops': tf, 'whole_path_mfma_frac': tf / MFMA_PEAK_TFLOPS['bf16'], 'final_loss': float(loss),
+            'workload': 'BASELINE configs[3]: one offline.py distillation step at batch 512 - token-label student (Visformer-S, train mode, drop_path 0.1) + frozen '
+                        'teacher (eval engine), generate_softlabel(k=3, bp=10), CE + 0.5 x SoftTargetCrossEntropy on 25 x 65 token logits, backward, AdamW',
+            'note': 'FLOPs = 4 x encoder forward (student forward + data gradient + weight gradient, teacher forward), 4.16 TFLOP per step'}
 
 
 def end_to_end_leg(args, dev, n_images=12000, n_classes=20):

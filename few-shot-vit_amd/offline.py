@@ -58,6 +58,28 @@ def few_shot_eval(model, dataset, sampler, n_way, n_shot, n_query, ep_per_batch,
     return la.item(), aa.item()
 
 
+def distill_step(model, teacher, optimizer, criterion_tl, data, weak_data, label, tl_soft_k=3, bp=10, world=1):
+    """One SUN meta-training step (offline.py:283-303): student forward (token logits with the extra background class, global logits), global
+    cross-entropy, frozen teacher forward on the weak view -> generate_softlabel, 0.5 x SoftTargetCrossEntropy on the student's token logits,
+    backward, (gradient all-reduce), AdamW.  Returns (loss, acc) as device tensors / float - the caller decides when to synchronise."""
+    logits_token, logits, _ = model(data)                                            # :283
+    cls_loss = F.cross_entropy(logits, label)
+    acc = (logits.argmax(dim=1) == label).float().mean()                             # (utils.compute_acc without its host synchronisation)
+    with torch.no_grad():                                                            # :296-298
+        logits_token_t, _, _ = teacher(weak_data, True)
+        soft_label = generate_softlabel(logits_token_t, k=tl_soft_k, bp=bp)
+    c = logits_token_t.shape[1]
+    logits_flatten = logits_token.permute(0, 2, 3, 1).reshape(-1, c + 1)            # :293
+    token_loss = criterion_tl(logits_flatten, soft_label)
+    loss = cls_loss + 0.5 * token_loss                                               # :300
+    optimizer.zero_grad()
+    loss.backward()
+    if world > 1:
+        parallel.allreduce_mean_grads(list(model.parameters()))
+    optimizer.step()
+    return loss.detach(), acc
+
+
 def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, save_root='./save'):
     device = device or torch.device('cuda', 0)
     svname = name or 'classifier_{}_{}'.format(config['train_dataset'], config['model_args']['encoder'])
@@ -124,22 +146,9 @@ def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, sa
         for bi in range(n_batches):
             idx = perm[bi * batch_size:(bi + 1) * batch_size][rank * n_local:(rank + 1) * n_local]
             data, weak_data, label = _gather(train_dataset, idx, device)
-            logits_token, logits, _ = model(data)                                            # :283
-            cls_loss = F.cross_entropy(logits, label)
-            acc = utils.compute_acc(logits, label)
-            with torch.no_grad():                                                            # :296-298
-                logits_token_t, _, _ = teacher(weak_data, True)
-                soft_label = generate_softlabel(logits_token_t, k=tl_soft_k, bp=bp)
-            c = logits_token_t.shape[1]
-            logits_flatten = logits_token.permute(0, 2, 3, 1).reshape(-1, c + 1)            # :293
-            token_loss = criterion_tl(logits_flatten, soft_label)
-            loss = cls_loss + 0.5 * token_loss                                               # :300
-            optimizer.zero_grad()
-            loss.backward()
-            parallel.allreduce_mean_grads(list(model.parameters()))
-            optimizer.step()
+            loss, acc = distill_step(model, teacher, optimizer, criterion_tl, data, weak_data, label, tl_soft_k, bp, world)
             aves['tl'].add(float(loss))
-            aves['ta'].add(acc)
+            aves['ta'].add(float(acc))
 
         model.eval()
         np.random.seed(0)

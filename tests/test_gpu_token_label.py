@@ -329,3 +329,47 @@ def test_nn_classifier_forward_backward_vs_torch():
             assert abs(float(m.temp.grad) - float(tr.grad)) <= 1e-4 * max(1.0, abs(float(tr.grad)))
     with pytest.raises(NotImplementedError):
         models.make('nn-classifier', in_dim=8, n_classes=2, metric='sqr')
+
+
+def test_distill_step_at_batch_512_is_the_mean_of_four_128_image_steps():
+    """BASELINE configs[3] at its own size (sun_meta_training/offline.py:263-309 runs batch 512): with frozen BatchNorm and no DropPath every image is
+    independent, so the gradient of the 512-image distillation loss (global CE + 0.5 x SoftTargetCrossEntropy on 512 x 25 x 65 token logits against the
+    frozen teacher's soft labels) equals the mean of the four 128-image gradients to fp32 summation order.  Exact-fp32 mode; through the C-ABI trainer,
+    fsvit_token_softlabel, fsvit_soft_target_ce and the HIP Linear heads at the shapes the reference trains at."""
+    from fewshot_vit_amd import models, synthetic, utils
+    from fewshot_vit_amd.models.classifier import SoftTargetCrossEntropy, generate_softlabel
+    margs = dict(encoder='visformer_micro_80', encoder_args=dict(drop_path_rate=0.0, return_map=True, numerics='parity'), classifier='linear-classifier',
+                 classifier_args=dict(n_classes=64))
+    student, teacher = models.make('token-label', **margs).cuda(), models.make('token-label', **margs).cuda()
+    for mdl in (student, teacher):
+        enc_shapes = {k: tuple(v.shape) for k, v in mdl.encoder.state_dict().items()}
+        esd = synthetic.synthetic_checkpoint_sd({'encoder.' + k: s for k, s in enc_shapes.items()}, calib='visformer_micro_80')
+        mdl.encoder.load_state_dict({k[len('encoder.'):]: v for k, v in esd.items()})
+    student.train()
+    utils.freeze_bn(student)
+    teacher.eval()
+    crit = SoftTargetCrossEntropy()
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(512, 3, 80, 80, generator=g).cuda()
+    label = torch.randint(0, 64, (512,), generator=g).cuda()
+
+    def grads(xb, lb):
+        for p in student.parameters():
+            p.grad = None
+        logits_token, logits, _ = student(xb)
+        with torch.no_grad():
+            lt_t, _, _ = teacher(xb, True)
+            soft = generate_softlabel(lt_t, k=3, bp=10)
+        loss = torch.nn.functional.cross_entropy(logits, lb) + 0.5 * crit(logits_token.permute(0, 2, 3, 1).reshape(-1, 65), soft)
+        loss.backward()
+        return float(loss), {k: p.grad.detach().clone() for k, p in student.named_parameters() if p.grad is not None}
+
+    loss_full, full = grads(x, label)
+    parts = [grads(x[i:i + 128], label[i:i + 128]) for i in range(0, 512, 128)]
+    assert np.isfinite(loss_full) and loss_full == pytest.approx(np.mean([p[0] for p in parts]), rel=1e-5)
+    worst = 0.0
+    for k, v in full.items():
+        mean = sum(p[1][k] for p in parts) / 4.0
+        worst = max(worst, float((v - mean).norm() / (v.norm() + 1e-20)))
+    print(f'[distill 512 = mean of 4 x 128] loss {loss_full:.5f}, worst gradient rel difference {worst:.3e} over {len(full)} tensors')
+    assert len(full) > 140 and worst <= 2e-5

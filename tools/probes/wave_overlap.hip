@@ -5,8 +5,10 @@
 // Prints shader cycles per iteration per wave; sum model = A * 16 + B * c_valu per wave and iteration (x W on the SIMD),
 // overlap model = max over the two pipes.
 //   class 0: v_fma_f32   1: v_pk_fma_f32   2: v_exp_f32   3: v_cndmask / v_cmp pair   4: v_cvt_pk_bf16_f32
+//   round 4 (a GELU on packed fp16 pairs?): 5: v_pk_fma_f16   6: v_pk_mul_f16   7: v_exp_f16   8: v_cvt_pkrtz_f16_f32   9: v_fma_f16
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -18,6 +20,11 @@ template <int CLS> __device__ __forceinline__ void valu(f32x2& v, float c) {
   if (CLS == 2) asm volatile("v_exp_f32 %0, %0" : "+v"(v[0]));
   if (CLS == 3) asm volatile("v_max_f32 %0, %0, %1" : "+v"(v[0]) : "v"(c));
   if (CLS == 4) { unsigned o; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(o) : "v"(v[0]), "v"(v[1])); v[0] = __builtin_bit_cast(float, o); }
+  if (CLS == 5) asm volatile("v_pk_fma_f16 %0, %0, %1, %0" : "+v"(v[0]) : "v"(c));
+  if (CLS == 6) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(v[0]) : "v"(c));
+  if (CLS == 7) asm volatile("v_exp_f16 %0, %0" : "+v"(v[0]));
+  if (CLS == 8) { unsigned o; asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(o) : "v"(v[0]), "v"(v[1])); v[0] = __builtin_bit_cast(float, o); }
+  if (CLS == 9) asm volatile("v_fma_f16 %0, %0, %1, %0" : "+v"(v[0]) : "v"(c));
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -83,10 +90,18 @@ int main() {
   run<3, 4, 64, 0, 1>("max m32 B64", 1, out, clk); run<3, 4, 64, 0, 1>("max m32 B64", 2, out, clk);
   run<3, 8, 64, 0, 0>("max m16 B64", 1, out, clk); run<3, 8, 64, 0, 0>("max m16 B64", 2, out, clk);
   run<2, 4, 32, 0, 1>("exp m32", 2, out, clk); run<1, 4, 32, 0, 1>("pk_fma m32", 2, out, clk);
+  if (getenv("WO_ALL")) {
   SET(0, "fma")
   SET(1, "pk_fma")
   SET(2, "exp")
   SET(3, "max")
   SET(4, "cvt_pk")
+  }
+  SET(5, "pk_fma_f16")
+  SET(6, "pk_mul_f16")
+  SET(7, "exp_f16")
+  SET(8, "cvt_pkrtz")
+  SET(9, "fma_f16")
+  run<5, 4, 32, 0, 1>("pk_fma_f16 m32", 1, out, clk); run<5, 4, 32, 0, 1>("pk_fma_f16 m32", 2, out, clk);
   return 0;
 }
