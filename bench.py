@@ -69,7 +69,7 @@ def parse(argv=None):
     ap.add_argument('--no-legs', action='store_true', help="skip the other configurations' legs (train / deit / deit_train / end_to_end)")
     ap.add_argument('--cpu-episodes', type=int, default=12)
     ap.add_argument('--layers', action='store_true', help='print the per-layer timing table to stderr')
-    ap.add_argument('--mode', default='eval', choices=['eval', 'train'],
+    ap.add_argument('--mode', default='eval', choices=['eval', 'train', 'distill'],
                     help="eval = BASELINE configs[1] (the headline metric); train = configs[2], one SUN-M meta-tuning step "
                          "(train_meta_mini_visformer_5shot.yaml geometry: 8 episodes x 10-way (5 shot + 5 query) = 800 images)")
     ap.add_argument('--train-episodes', type=int, default=8, help='train mode: episodes per GPU per step (ep_per_batch)')
@@ -839,6 +839,9 @@ def main(argv=None):
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
     if args.mode == 'train':
         train_main(args, rank, world, dev)
+    elif args.mode == 'distill':            # BASELINE configs[3] on one GPU: the `legs.distill` entry alone (for profiling)
+        if rank == 0:
+            print(json.dumps(dict(distill_leg(dev, steps=args.steps, warm=args.warmup), metric='distill_images_per_sec_batch512_visformer_s', n_gpus=1)), flush=True)
     else:
         eval_main(args, rank, world, dev)
     if world > 1:
