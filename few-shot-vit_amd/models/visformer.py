@@ -171,9 +171,9 @@ class Visformer(nn.Module):
             keep = [1.0 - r for b, r in enumerate(rates) if r > 0 for _ in range(1 if b < depth[0] else 2)]
             self._keep_dev = torch.tensor(keep, dtype=torch.float32).to(device).unsqueeze(1)
             self._keep_key = key
-        draws = [torch.rand(n_img, device=device) for _ in range(n)]     # one generator call per DropPath call, as the reference makes them
-        # floor(keep_prob + rand) for all calls in one pass (same fp32 values as per-call arithmetic, a third of the launches)
-        return torch.stack(draws).add_(self._keep_dev).floor_()
+        # floor(keep_prob + rand(B)) of every call from ONE generator launch: the draws are i.i.d. uniforms either way, and the device generator's stream
+        # is not the reference's (a CUDA Philox stream cannot be reproduced here); one launch + two in-place passes instead of 16 + 3 (70 us per step)
+        return torch.rand(n, n_img, device=device).add_(self._keep_dev).floor_()
 
     def forward(self, x, droppath_masks=None):
         """[B,3,img,img] fp32 -> [B,out_dim] pooled features (visformer.py:424-462).
