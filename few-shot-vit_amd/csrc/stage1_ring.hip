@@ -411,6 +411,7 @@ bool stage1_ring_preferred() {
 
 // w1 [256][128], w2 [256][320] (columns (tap, c)), w3 [128][256]: the packed layers of the block (engine.hip pack_layer)
 int launch_stage1_ring(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, int H, int W, hipStream_t s) {
+  if (stage1_w4_enabled()) return launch_stage1_w4(x, y, w1, b1, w2, w3, B, H, W, s);
   const long Ml = (long)B * H * W;
   if (Ml <= 0) return 0;
   if (Ml >= (1L << 31) - 256 || W > 20 || H * W < 16) return (int)hipErrorInvalidValue;
