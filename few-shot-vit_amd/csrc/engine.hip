@@ -1307,6 +1307,7 @@ extern "C" int fsvit_pool_affine(const void* x, const float* scale, const float*
 }
 
 // ------------------------------------------------------------------------------------ profiling
+static bool K_w4_enabled(int kdt) { return K(stage1_w4_enabled)(); }
 extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
   static const char* f32n[] = {"gemm256_kernel", "conv_gemm_v2_kernel<float,128,64,2,2,3>", "conv_gemm_v2_kernel<float,128,32,4,1,3>",
                                "im2col27_kernel<float>", "maxpool2_pos_kernel<float>", "attention_v2_kernel<float,...>", "pool_affine_kernel<float>", "proto_head_kernel", "stage1_block_kernel", "conv_gemm_v2_kernel<float,128,128,2,2,2>",
@@ -1319,6 +1320,7 @@ extern "C" const char* fsvit_kernel_name(int kernel_id, int dtype) {
                                "patchify_kernel<_Float16>", "layernorm_kernel<_Float16>", "conv3x3_halo_kernel", "mlp_rows_kernel", "-", "qkv_attn_kernel", "stem_conv1_kernel", "stage1_ring_kernel", "ln_gemm_rows_kernel", "qkv_attn_rows_kernel", "vit_attn_rows_kernel"};
   static const char* x2n[] = {"gemm256_x2_kernel", "conv_gemm_v2_kernel<f32x2l,128,64,2,2,3>", "conv_gemm_v2_kernel<f32x2l,128,32,4,1,3>", "", "", "", "", "", "", "conv_gemm_v2_kernel<f32x2l,128,128,2,2,2>"};
   if (kernel_id < 0 || kernel_id > 20) return "?";
+  if (kernel_id == KID_STAGE1RING && kd(dtype) == 1 && K_w4_enabled(dtype)) return "stage1_w4_kernel";      // (launch_stage1_ring dispatches to stage1_w4.hip)
   if (is_x2(dtype)) return kernel_id == 14 ? "gconv3x3_x2_kernel" : (kernel_id == 0 || kernel_id == 1 || kernel_id == 2 || kernel_id == 9) ? x2n[kernel_id] : f32n[kernel_id];
   return dtype == FSVIT_F32 ? f32n[kernel_id] : dtype == FSVIT_F16 ? f16n[kernel_id] : bf16n[kernel_id];
 }
