@@ -150,9 +150,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvGemmPara
   // -> source byte offset relative to pixel (image b, row r0 - 1, column 0); padding slots and the left / right border read zeros
   auto issue_w = [&](int wk, int stage) {
     const unsigned d = lds0 + OFF_W + stage * STAGE;
-#ifndef H_NO_WDMA          // timing diagnostics only
     hdma2s(offB[0], offB[1], Wb + (size_t)wk * 128, d + (2 * wave) * 1024, d + (2 * wave + 1) * 1024);
-#endif
   };
   // one piece of the halo tile whose pixel (row r0 - 1, column 0, first channel of the half) is at `base` into buffer nb; base == nullptr:
   // nothing to fetch (zero page) - the piece is still issued so that the counted waits below see the same number of operations in
@@ -164,9 +162,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvGemmPara
     const bool ok = (base != nullptr) & (s < HR * HP) & (hc >= 1) & (hc <= TW) & !(top & (hr == 0)) & !(bot & (hr == HR - 1));
     const unsigned long a = (unsigned long)base + (unsigned long)(unsigned)(((hr * p.W + hc - 1) * CIN + wave * 8) * 2);
     const unsigned long z = (unsigned long)g_zero_page_halo;
-#ifndef H_NO_HDMA          // timing diagnostics only
     hdma1(reinterpret_cast<const void*>(ok ? a : z), lds0 + nb * HBUF + wave * PLANE + j * 1024);
-#endif
   };
   auto halo_base = [&](int tile, int h) {
     const int bb = tile / tiles_per_img, rr = (tile - bb * tiles_per_img) * TR;
@@ -200,12 +196,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvGemmPara
   hbar();
   int st_cur = 0, st_pre = 2, q_pre = 2 % NKT;                  // ring state: stage being consumed, stage / step-in-tile being prefetched
   int buf = 0;                                                  // halo buffer of the current phase
-#ifdef H_CLK      // timing diagnostics (tools/build_variant.sh): where a workgroup's cycles go, printed by wave 0 of workgroups 0 and 100
-  long long ck0 = __builtin_readcyclecounter(), ckl = ck0, ckA = 0, ckW = 0, ckB = 0, ckE = 0, ckP = 0, ckT = 0, ckV = 0;
-#define H_STAMP(acc_) { const long long c_ = __builtin_readcyclecounter(); acc_ += c_ - ckl; ckl = c_; }
-#else
 #define H_STAMP(acc_)
-#endif
 
   auto advance = [&]() {
     st_cur = st_cur == NST - 1 ? 0 : st_cur + 1;
@@ -462,11 +453,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvGemmPara
     if (!has_next) break;
     tix = tnext;
   }
-#ifdef H_CLK
-  if (t == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
-    printf("[halo<%d,%d> wg %d] tiles %d total %lld | phase-start reads %lld  region A %lld  waitcnt %lld  barrier %lld  region B %lld  tail %lld  epilogue %lld\n", CIN, (int)FUSE_TAIL,
-           (int)blockIdx.x, my_tiles, __builtin_readcyclecounter() - ck0, ckP, ckA, ckV, ckW, ckB, ckT, ckE);
-#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no DMA (dummy pieces) may be in flight into the LDS of a finished workgroup
   if constexpr (STATS) {
     // workgroup partial: the 16 pixel lanes of a channel quad (shuffles), then the 4 waves that share the 64-channel half, in fixed order

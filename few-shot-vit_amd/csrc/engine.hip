@@ -123,7 +123,6 @@ struct Layer {
 };
 struct Block1 {
   Layer c1, c2, c3;
-  void* img = nullptr;                    // fused stage-1 block: the three layers as per-group LDS images (stage1_fused.hip)
 };
 struct BlockA {
   Layer qkv, proj, fc1, fc2;
@@ -489,14 +488,6 @@ int build(fsvit_visformer* h, const SD& sd) {
         wr.cst[o] += corr3[o];
       }
     }
-    if (K(stage1_fused_supported)(kd(kdt), h->C1, h->hid1, cf.group, h->H1)) {
-      void* img = nullptr;
-      HIP_TRY(hipMalloc(&img, K(stage1_image_bytes)()));
-      h->allocs.push_back(img);
-      RC_TRY(K(launch_stage1_pack)(h->s1[i].c1.w, h->s1[i].c2.w, h->s1[i].c3.w, img, nullptr));
-      HIP_TRY(hipDeviceSynchronize());
-      h->s1[i].img = img;
-    }
   }
   // ---- per stage s = 2, 3: PatchEmbed (visformer.py:266-288: conv k2 s2 + bias -> BN ; pos_embed added in the epilogue), then its
   // attention + MLP blocks (Attention :166-194, Block :259-263)
@@ -775,21 +766,15 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
   // stage 1: x += conv3(GELU(conv2_g(GELU(conv1(BN(x))))))
   const int Cg = h->hid1 / h->cfg.group;
   static const bool no_fuse = [] { const char* e = getenv("FSVIT_NO_FUSE"); return e && e[0] == '1'; }();
-  // one LDS-resident kernel per block: the ring kernel (any map up to 20 wide), or under FSVIT_STAGE1_RING=0 the half-image kernel (20 x 20 tokens)
-  const bool half1 = K(stage1_fused_supported)(dt, h->C1, h->hid1, h->cfg.group, h->H1) && h->s1.size() && h->s1[0].img;
+  // one LDS-resident kernel per block (stage1_w4.hip / stage1_ring.hip, any map up to 20 wide); FSVIT_STAGE1_RING=0 keeps the three-launch route
   const bool ring_ok = K(stage1_ring_supported)(dt, h->C1, h->hid1, h->cfg.group, h->H1) && h->s1.size() && h->s1[0].c2.Kw == 320;
-  const bool ring1 = !no_fuse && ring_ok && (!half1 || K(stage1_ring_preferred)());
-  const bool fuse1 = !no_fuse && (half1 || ring1);
+  const bool fuse1 = !no_fuse && ring_ok && K(stage1_ring_preferred)();
   for (size_t i = 0; i < h->s1.size(); ++i) {
     const Block1& b = h->s1[i];
     if (fuse1) {   // one LDS-resident kernel per block, ping-pong between x1 and x1b
       const double fl = 2.0 * Bc * h->H1 * h->H1 * ((double)h->hid1 * h->C1 + (double)h->hid1 * 9 * Cg + (double)h->C1 * h->hid1);
-      if (ring1)
-        RC_TRY(timed(h, st, "stage1.block", KID_STAGE1RING, fl,
-                     [&]() { return K(launch_stage1_ring)(x1, x1b, b.c1.w, b.c1.bias, b.c2.w, b.c3.w, Bc, h->H1, h->H1, st); }));
-      else
-        RC_TRY(timed(h, st, "stage1.block", KID_STAGE1, fl,
-                     [&]() { return K(launch_stage1_block)(x1, x1b, b.img, b.c1.bias, Bc, st); }));
+      RC_TRY(timed(h, st, "stage1.block", KID_STAGE1RING, fl,
+                   [&]() { return K(launch_stage1_ring)(x1, x1b, b.c1.w, b.c1.bias, b.c2.w, b.c3.w, Bc, h->H1, h->H1, st); }));
       std::swap(x1, x1b);
     } else {
       RC_TRY(run_gemm(h, st, "stage1.mlp.conv1", b.c1, conv_params(b.c1, x1, ha, Bc, h->H1, h->H1, h->C1, h->C1, 1, 1, 1, 0, h->hid1, ACT_GELU, nullptr, 0, nullptr), h->hid1, h->C1));
@@ -1023,15 +1008,8 @@ extern "C" int fsvit_conv_stem_tail(const void* x, const void* w, const float* b
 
 extern "C" int fsvit_stage1_block(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, void* stream) {
   const int kdt = FSVIT_BF16;
-  if (!x || !y || !w1 || !b1 || !w2 || !w3 || x == y) return fail(FSVIT_ERR_ARG, "bad argument");
-  hipStream_t st = (hipStream_t)stream;
-  void* img = nullptr;
-  HIP_TRY(hipMalloc(&img, K(stage1_image_bytes)()));
-  int rc = K(launch_stage1_pack)(w1, w2, w3, img, st);      // (always the half-image kernel of stage1_fused.hip; the ring kernel is fsvit_stage1_block_hw)
-  if (rc == 0) rc = K(launch_stage1_block)(x, y, img, b1, B, st);
-  (void)hipStreamSynchronize(st);
-  (void)hipFree(img);
-  if (rc != 0) return hipfail((hipError_t)rc, "fsvit_stage1_block");
+  if (!x || !y || !w1 || !b1 || !w2 || !w3 || x == y || B <= 0) return fail(FSVIT_ERR_ARG, "bad argument");
+  RC_TRY(K(launch_stage1_ring16)(x, y, w1, b1, w2, w3, B, 20, 20, (hipStream_t)stream));
   return 0;
 }
 

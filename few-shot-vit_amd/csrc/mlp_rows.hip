@@ -204,26 +204,8 @@ __device__ __forceinline__ void mfma32_a_zero(f32x16& c) {
 }
 
 // cache policy of the rows GEMM's streaming accesses (tools/build_variant.sh sweeps): 0 default, 1 nt, 2 sc0 sc1 nt, 3 sc1
-#ifndef LGR_ST_POL
-#define LGR_ST_POL 0
-#endif
-#ifndef LGR_LD_POL
-#define LGR_LD_POL 0
-#endif
-#if LGR_ST_POL == 1
-#define LGR_ST_MOD " nt"
-#elif LGR_ST_POL == 2
-#define LGR_ST_MOD " sc0 sc1 nt"
-#elif LGR_ST_POL == 3
-#define LGR_ST_MOD " sc1"
-#else
 #define LGR_ST_MOD ""
-#endif
-#if LGR_LD_POL == 1
-#define LGR_LD_MOD " nt"
-#else
 #define LGR_LD_MOD ""
-#endif
 __device__ __forceinline__ void mr_gstore16(void* p, u32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off" LGR_ST_MOD :: "v"(p), "v"(v) : "memory");
 }
@@ -335,9 +317,6 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
   const unsigned lds0 = (unsigned)(size_t)(lptrm_t)smem;
   const unsigned voff = (unsigned)(wave * WSH + lane * 16);            // this lane's 16 bytes inside a slot image
   if ((int)blockIdx.x >= n_tiles) return;
-#ifdef MR_PAD     // code-placement screen (tools/screen_mlp_rows.sh): shifts every later instruction by 4 * MR_PAD bytes
-  asm volatile(".rept %0\n\ts_nop 0\n\t.endr" :: "n"(MR_PAD));
-#endif
 
   // bias table of conv1 (already in accumulator order) -> LDS
   for (int i = t; i < HID; i += MR_NW * 64) b1tab[i] = b1img[i];
@@ -363,9 +342,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
   bool first = true;
   auto ring_wait = [&]() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory");     // all but the newest slot image of this wave have landed: the image read after the NEXT barrier
-#if !(defined(MR_DIAG) && (MR_DIAG & 2))
     mr_bar();
-#endif
   };
   auto ring_sync = [&]() {
     ring_wait();
@@ -381,9 +358,6 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
   };
   auto next_slot = [&]() { slot = slot == MR_NST - 1 ? 0 : slot + 1; };
 
-#ifdef MR_CLK
-  const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_w0 = wall_clock64();
-#endif
   u32x4 idf[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};      // LN: identity fragments of the two k-steps of a channel tile
   if constexpr (LN) {
     const int ch = 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
@@ -547,9 +521,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
     // `half` was already flipped by begin_group) or 8 (C = 512) single pieces, 8 / 4 MFMAs apart
     auto refill = [&](int m) {
       constexpr int EVERY = SL / (PW / (PPC == 1 ? 2 : 1));
-#if !(defined(MR_DIAG) && (MR_DIAG & 4))
       if (m % EVERY == 1) issue1((PPC == 1 && !half ? 4 : 0) + m / EVERY);
-#endif
     };
     // conv1's bias = initial value of a chain, read from LDS straight into the accumulator registers a few slots ahead of the chain
     auto bias_init = [&](int rb, int j) {
@@ -573,16 +545,10 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         gx[q][h] = hacc[q >> 3][2 * (q & 7) + h];
-#if defined(MR_DIAG) && (MR_DIAG & 1)
-        gu[q][h] = 0.f; continue;
-#endif
         asm("v_mul_f32_e64 %0, %1, %1 clamp" : "=v"(gu[q][h]) : "v"(gx[q][h]));
       }
     };
     auto gA2 = [&](int q) {
-#if defined(MR_DIAG) && (MR_DIAG & 1)
-      return;
-#endif
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float pp = fmaf(1.0153755e-3f * 32768.0f, gu[q][h], -1.0678257e-1f * 512.0f);
@@ -591,23 +557,14 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
       }
     };
     auto gE = [&](int q) {
-#if defined(MR_DIAG) && (MR_DIAG & 1)
-      ge[q][0] = ge[q][1] = 1.0f; return;
-#endif
 #pragma unroll
       for (int h = 0; h < 2; ++h) ge[q][h] = __builtin_amdgcn_exp2f(gu[q][h]);
     };
     auto gBa = [&](int q) {
-#if defined(MR_DIAG) && (MR_DIAG & 1)
-      return;
-#endif
 #pragma unroll
       for (int h = 0; h < 2; ++h) ge[q][h] = 1.0f + ge[q][h];
     };
     auto gBr = [&](int q) {
-#if defined(MR_DIAG) && (MR_DIAG & 1)
-      return;
-#endif
 #pragma unroll
       for (int h = 0; h < 2; ++h) ge[q][h] = __builtin_amdgcn_rcpf(ge[q][h]);
     };
@@ -653,9 +610,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
         for (int m = 0; m < SL; ++m) {
           const int f = m / RB, rb = m % RB;
           mfma32_a(fr[f % FD], hp_prev[rb][f / NCT], yacc[rb][f % NCT]);
-#if !(defined(MR_DIAG) && (MR_DIAG & 8))
           if (rb == RB - 1 && f + FD < NKS) fr[f % FD] = *reinterpret_cast<const u32x4*>(sp + foff2(f + FD));
-#endif
           refill(m);
           // wait states MFMA (last of GEMM1) -> VALU read of hacc, spent behind the MFMA just issued; the accumulators are threaded
           // through so that no GELU instruction can be scheduled above
@@ -684,9 +639,7 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
         for (int i = 0; i < SL; ++i) {
           const int rb = RB == 2 ? i / NKS : 0, s = RB == 2 ? i % NKS : i;
           mfma32_v(fr[i % FD], xr[rb][s], hacc[rb]);
-#if !(defined(MR_DIAG) && (MR_DIAG & 8))
           if (i + FD < SL) fr[i % FD] = *reinterpret_cast<const u32x4*>(sp + foff1(i + FD));
-#endif
           refill(i);
           if (GE) gelu_slot(SL + i, hp_cur);
           if (RB == 2 && i == NKS - 2) bias_init(1, jn);        // after the last GELU read of row block 1's accumulator (slot 45)
@@ -742,13 +695,6 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
       }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may be in flight into the LDS of a finished workgroup
-#ifdef MR_CLK
-  if (t == 0 && (blockIdx.x % 37 == 0 || blockIdx.x == 255)) {
-    const unsigned long long dc = __builtin_readcyclecounter() - clk_c0, w1 = wall_clock64();
-    printf("[mlp_rows C=%d wg %3d] start %llu end %llu (x10ns)  %.1f us  %.0f MHz\n", C, (int)blockIdx.x, clk_w0 % 10000000ull, w1 % 10000000ull,
-           (w1 - clk_w0) / 100.0, dc / ((w1 - clk_w0) / 100.0));
-  }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -776,9 +722,6 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
 #ifndef LGR_OCC
 #define LGR_OCC 2
 #endif
-#ifndef LGR_SPREAD      // 1: ring refill and output stores issued one instruction at a time between the MFMAs
-#define LGR_SPREAD 1
-#endif
 // GATHER (C = 4 Ci): the 2 x 2 / stride-2 patch-embedding conv (visformer.py:266-288, eval BatchNorm folded) - an output token's row is the
 // concatenation of its four input pixels (k = (ky, kx, c): each 16-byte register load stays inside one pixel), and pos_embed [OH*OW][N]
 // fp32 is added before the rounding: its 16 values per lane and chunk are loaded at the top of the chunk through asm (invisible to hipcc's
@@ -799,9 +742,6 @@ __global__ __launch_bounds__(256, LGR_OCC) void ln_gemm_rows_kernel(const bf16* 
   const unsigned voff = (unsigned)(wave * WSH + lane * 16);
   const int nch = N / 32, n_img = nch * SPC;
   if ((int)blockIdx.x >= n_tiles) return;
-#ifdef MR_PAD     // code-placement screen (tools/screen_mlp_rows.sh)
-  asm volatile(".rept %0\n\ts_nop 0\n\t.endr" :: "n"(MR_PAD));
-#endif
   for (int i = t; i < N; i += MR_NW * 64) btab[i] = bias ? bias[i] : 0.0f;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
@@ -861,20 +801,14 @@ __global__ __launch_bounds__(256, LGR_OCC) void ln_gemm_rows_kernel(const bf16* 
       }
 #pragma unroll
       for (int h = 0; h < SPC; ++h) {
-#if !(defined(LGR_DIAG) && (LGR_DIAG & 2))
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LAG) : "memory");
         mr_bar();
-#endif
-#if LGR_SPREAD
         // A 1 KB VMEM instruction holds the wave's issue stage for ~64 cycles (mlp_rows): the refill of the slot freed by this barrier goes out one
         // piece at a time, 4 MFMAs apart, and the previous chunk's two stores in the gaps of the chunk's first slot.
         const unsigned char* const dsrc = wimg + (size_t)issue_img * SLOT;
         const unsigned ddst = lds0 + issue_slot * SLOT + wave * WSH;
         issue_img = issue_img == n_img - 1 ? 0 : issue_img + 1;
         issue_slot = issue_slot == NST - 1 ? 0 : issue_slot + 1;
-#elif !(defined(LGR_DIAG) && (LGR_DIAG & 8))
-        issue();
-#endif
         unsigned a = slot * SLOT + lane * 16;
         asm volatile("" : "+v"(a));
         const unsigned char* sp = smem + a;
@@ -886,17 +820,13 @@ __global__ __launch_bounds__(256, LGR_OCC) void ln_gemm_rows_kernel(const bf16* 
 #pragma unroll
         for (int i = 0; i < SLF; ++i) {
           mfma32_v(fr[i % FD], xr[h * SLF + i], hacc);
-#if !(defined(LGR_DIAG) && (LGR_DIAG & 32))      // diagnostic: the MFMAs without their fragment reads (wrong results)
           if (i + FD < SLF) fr[i % FD] = *reinterpret_cast<const u32x4*>(sp + (i + FD) * 1024);
-#endif
-#if LGR_SPREAD
           constexpr int EVERY = SLF / PW;
           if (i % EVERY == 1 && i / EVERY < PW) mr_dma1(voff + (i / EVERY) * 1024, dsrc, ddst + (i / EVERY) * 1024);
           if (h == 0 && j > 0 && mok) {
             if (i == 3) mr_gstore16(yrow + (j - 1) * 32, po0);
             if (i == EVERY + 3) mr_gstore16(yrow + (j - 1) * 32 + 8, po1);
           }
-#endif
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -917,7 +847,6 @@ __global__ __launch_bounds__(256, LGR_OCC) void ln_gemm_rows_kernel(const bf16* 
         o0[e] = mr_pk2(hacc[2 * e], hacc[2 * e + 1]);
         o1[e] = mr_pk2(hacc[8 + 2 * e], hacc[8 + 2 * e + 1]);
       }
-#if LGR_SPREAD
       po0 = o0;
       po1 = o1;
     }
@@ -925,18 +854,6 @@ __global__ __launch_bounds__(256, LGR_OCC) void ln_gemm_rows_kernel(const bf16* 
       mr_gstore16(yrow + (nch - 1) * 32, po0);
       mr_gstore16(yrow + (nch - 1) * 32 + 8, po1);
     }
-#else
-#if defined(LGR_DIAG) && (LGR_DIAG & 1)
-      if (o0[0] == 0x12345678u)
-#else
-      if (mok)
-#endif
-      {
-        mr_gstore16(yrow + j * 32, o0);
-        mr_gstore16(yrow + j * 32 + 8, o1);
-      }
-    }
-#endif
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no DMA may be in flight into the LDS of a finished workgroup
 }
@@ -970,9 +887,6 @@ __global__ __launch_bounds__(256, 2) void qkv_attn_rows_kernel(const bf16* __res
   const unsigned voff = (unsigned)(wave * WSH + lane * 16);
   const int HD = HDC * 32, N = 3 * heads * HD, n_img = (N / 32) * SPC;
   if ((int)blockIdx.x >= n_tiles) return;
-#ifdef MR_PAD     // code-placement screen (tools/screen_mlp_rows.sh)
-  asm volatile(".rept %0\n\ts_nop 0\n\t.endr" :: "n"(MR_PAD));
-#endif
   for (int i = t; i < N; i += MR_NW * 64) btab[i] = bias ? bias[i] : 0.0f;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
@@ -1199,12 +1113,8 @@ __global__ __launch_bounds__(512, 1) void vit_attn_rows_kernel(const bf16* __res
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < SLF; ++i) {
-#if !(defined(VAR_DIAG) && (VAR_DIAG & 2))
         if constexpr (SW) mfma32_v(xr[i], fr[i % FD], acc);
         else mfma32_v(fr[i % FD], xr[i], acc);
-#else
-        if (i < 2) { if constexpr (SW) mfma32_v(xr[i], fr[i % FD], acc); else mfma32_v(fr[i % FD], xr[i], acc); }
-#endif
         if (i + FD < SLF) fr[i % FD] = *reinterpret_cast<const u32x4*>(sp + (i + FD) * 1024);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1343,7 +1253,6 @@ __global__ __launch_bounds__(512, 1) void vit_attn_rows_kernel(const bf16* __res
           mfma32_v(vf[c][1], pp[1], oacc[c]);
         }
       };
-#if !(defined(VAR_DIAG) && (VAR_DIAG & 1))                       // (timing diagnostics: -DVAR_DIAG=1 drops the attention phase, 2 the GEMM MFMAs - wrong results)
       {                                                            // two fragment sets: block kb + 1 is read from LDS under block kb's work
         u32x4 kfa[HDC][2], vfa[HDC][2], kfb[HDC][2], vfb[HDC][2];
         kv_load(0, kfa, vfa);
@@ -1355,7 +1264,6 @@ __global__ __launch_bounds__(512, 1) void vit_attn_rows_kernel(const bf16* __res
           if (kb + 1 < NB) kv_step(kb + 1, kfb, vfb);
         }
       }
-#endif
       asm volatile("s_nop 15\n\ts_nop 3" : "+v"(oacc[0]), "+v"(oacc[HDC - 1]));
       const float inv = __builtin_amdgcn_rcpf(lrun);
 #pragma unroll

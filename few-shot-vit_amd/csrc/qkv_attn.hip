@@ -190,11 +190,7 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
             const u32x4 wf = *reinterpret_cast<const u32x4*>(sp + (ks * NCT + c) * 1024);
 #pragma unroll
             for (int tt = 0; tt < TT; ++tt)
-#if defined(QA_DIAG) && (QA_DIAG & 4)
-              acc[c][tt][0] += __builtin_bit_cast(float, wf[tt]);
-#else
               acc[c][tt] = p < 2 ? mma_chunk<bf16>(wf, xr[tt][ks], acc[c][tt]) : mma_chunk<bf16>(xr[tt][ks], wf, acc[c][tt]);
-#endif
           }
           if (ks % 3 == 0 && ks / 3 < PPW) issue1(ks / 3);
         }
@@ -227,7 +223,6 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
       // ---- attention of head h for the wave's two query tiles (attention_v2_kernel's body on the LDS images).  Both tiles run in one
       // straight-line block - padding tiles compute on finite bias-valued rows and are simply not stored - so that the scheduler can
       // put one tile's softmax under the other tile's MFMAs.
-#if !(defined(QA_DIAG) && (QA_DIAG & 2))
       {
         f32x4 sc[TT][NKT];
 #pragma unroll
@@ -265,11 +260,7 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
           for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#if defined(QA_DIAG) && (QA_DIAG & 1)       // timing diagnostics only (tools/build_variant.sh)
-              const float e = sc[tt][kt][r];
-#else
               const float e = __builtin_amdgcn_exp2f(fmaf(sc[tt][kt][r], sscale, -mxs));   // -inf for masked keys -> 0
-#endif
               sc[tt][kt][r] = e;
               sum += e;
             }
@@ -312,13 +303,6 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
           }
         }
       }
-#else
-      pend_h = h;
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-        for (int dt = 0; dt < NCT; ++dt) pend[tt][dt] = u32x2{qf[tt][0][dt], qf[tt][1][0]};
-#endif
     }
     flush_ctx();                                            // the last head's rows
   }

@@ -1,9 +1,9 @@
 // Fused Visformer stage-1 block, second design ("ring"):   y = x + conv3( GELU( conv2_g8_3x3( GELU( conv1( BN(x) ) ) ) ) )
 // (test_phase/models/visformer.py:259-263 Block.forward with attn_disabled, Mlp :152-163; eval BatchNorm folded into conv1 by the packer).
 //
-// stage1_fused.hip owns a half image per workgroup and walks the 8 channel groups with all 16 waves in phase: per group interval the LDS
-// reads (2.9 k cycles), the MFMAs (1.8 k) and the GELUs (~2 k) queue up behind two barriers, every MFMA is fed by 1 .. 1.5 ds_read_b128 because
-// the weights come from LDS, and the MFMA pipe is busy 32 % of the time (profiles/r02_stage1_pmc.txt).  This kernel turns the decomposition
+// The first design (a half image per workgroup, all 16 waves walking the 8 channel groups in phase; retired in round 4, git history) queued the LDS
+// reads (2.9 k cycles), the MFMAs (1.8 k) and the GELUs (~2 k) of a group interval behind two barriers, fed every MFMA with 1 .. 1.5 ds_read_b128 because
+// the weights came from LDS, and kept the MFMA pipe busy 32 % of the time (profiles/r02_stage1_pmc.txt).  This kernel turns the decomposition
 // round - the same move that took the grouped conv of the training step from 213 to 91 us (wgrad3x3.hip gconv3x3_kernel):
 //   * WAVE g IS CHANNEL GROUP g for conv1 and conv2, and a (32 output channels x 32 pixels) block for conv3; all of its weights live in registers
 //     for the whole launch: 8 fragments of W1 (32 hidden channels x 128), 18 of W2 (9 taps x 32 x 32), 16 of W3 (32 output channels x 256) = 168
@@ -16,7 +16,7 @@
 //     over all 256 hidden channels): [32 planes][64 pixels], one barrier.  The output tile goes through LDS for 16-byte coalesced stores;
 //   * per chunk and wave: 32 + 72 + 32 = 136 MFMAs (the algorithmic minimum) fed by 16 + 36 + 16 fragment reads, 64 GELUs per lane (packed pairs), 4 barriers; the next chunk's x
 //     batch (2 x 16 B per thread) is in flight under the MFMAs.
-// Numerics: as stage1_fused - h1 and h2 are rounded to the 16-bit storage type where they are stored, everything else fp32; a pixel's value does
+// Numerics: h1 and h2 are rounded to the 16-bit storage type where they are stored, everything else fp32; a pixel's value does
 // not depend on its position in a chunk (batching never changes a result).
 #include <stdlib.h>
 
@@ -27,11 +27,7 @@
 #define S1R_UNROLL 4
 #endif
 
-#ifdef S1R_NO_BAR        // timing diagnostics only (races)
-#define S1R_SYNC() do { } while (0)
-#else
 #define S1R_SYNC() __syncthreads()
-#endif
 
 namespace FSVIT_NS {
 
@@ -64,9 +60,6 @@ __device__ __forceinline__ u32x4 s1r_pack8(f32x4 a, f32x4 b) {
   return __builtin_bit_cast(u32x4, o);
 }
 __device__ __forceinline__ f32x4 s1r_gelu4(f32x4 v) {
-#ifdef S1R_NO_GELU      // timing diagnostics only (wrong results)
-  return v;
-#endif
   const f32x2 a = gelu_sig2(f32x2{v[0], v[1]}), b = gelu_sig2(f32x2{v[2], v[3]});
   return f32x4{a[0], a[1], b[0], b[1]};
 }
@@ -278,11 +271,7 @@ __device__ __forceinline__ void stage1_ring_body(const bf16* __restrict__ x, bf1
 #pragma unroll
       for (int tp = 0; tp < 9; ++tp) {
         const int dy = tp / 3 - 1, dx = tp % 3 - 1;
-#ifdef S1R_NO_MASK     // timing diagnostics only (wrong results at the image borders)
-        const bool ok = true;
-#else
         const bool ok = (unsigned)(oy + dy) < (unsigned)H && (unsigned)(ox + dx) < (unsigned)W;
-#endif
         const u32x4 hf = *reinterpret_cast<const u32x4*>(ok ? h1plane + ((m + dy * W + dx) & (RING - 1)) * 16 : smem + ZERO);
         acc[0] = mma_chunk<bf16>(wf2[tp][0], hf, acc[0]);
         acc[1] = mma_chunk<bf16>(wf2[tp][1], hf, acc[1]);
@@ -402,8 +391,8 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_block_train_kernel(const b
 bool stage1_ring_supported(int dtype, int C1, int hid, int group, int H1) {
   return dtype == 1 && C1 == s1r::C1 && hid == s1r::HID && group == s1r::G && H1 >= 4 && H1 <= 20;
 }
-// The engines use this kernel for every supported map; FSVIT_STAGE1_RING=0 keeps stage1_fused.hip's half-image kernel where it applies (20 x 20
-// tokens: 9.4 vs 8.8 ms per 128-episode step - both are bound by the 512 GELUs per token)
+// The engines run the block as one launch for every supported map (stage1_w4.hip by default, this kernel under FSVIT_STAGE1_W4=0 and for the
+// training modes); FSVIT_STAGE1_RING=0 keeps the three-launch route (conv1 / grouped conv2 / conv3 through the GEMM kernels)
 bool stage1_ring_preferred() {
   static const bool off = [] { const char* e = getenv("FSVIT_STAGE1_RING"); return e && e[0] == '0'; }();
   return !off;
@@ -412,6 +401,10 @@ bool stage1_ring_preferred() {
 // w1 [256][128], w2 [256][320] (columns (tap, c)), w3 [128][256]: the packed layers of the block (engine.hip pack_layer)
 int launch_stage1_ring(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, int H, int W, hipStream_t s) {
   if (stage1_w4_enabled()) return launch_stage1_w4(x, y, w1, b1, w2, w3, B, H, W, s);
+  return launch_stage1_ring16(x, y, w1, b1, w2, w3, B, H, W, s);
+}
+// this file's kernel whatever FSVIT_STAGE1_W4 says (fsvit_stage1_block: the cross-check of the two kernels in one process)
+int launch_stage1_ring16(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, int H, int W, hipStream_t s) {
   const long Ml = (long)B * H * W;
   if (Ml <= 0) return 0;
   if (Ml >= (1L << 31) - 256 || W > 20 || H * W < 16) return (int)hipErrorInvalidValue;

@@ -305,9 +305,6 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
   // the micro-stages of job J due at relative slot r; pair k starts at k * NUM / 4 (NUM = 7: 1.75 slots per pair, 8: 2); dst(tile, octet) = LDS address
   auto g_slot = [&](auto jt, auto numt, auto rt, const f32x16w& a0, const f32x16w& a1, auto dst) {
     constexpr int J = decltype(jt)::value, NUM = decltype(numt)::value, r = decltype(rt)::value;
-#ifdef W4_NO_GELU
-    return;
-#endif
     w4_for<16>([&](auto kc) {
       constexpr int k = decltype(kc)::value, st = k * NUM / 4;
       if constexpr (r == st) g_a1(J, k, k < 8 ? a0 : a1);
@@ -381,16 +378,8 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
   if (q0 + 1 < q1) gload(q0, -HALO + 2 * CH);
   __syncthreads();
 
-#ifdef W4_CLK
-  long long ck[6] = {0, 0, 0, 0, 0, 0}, ckt;
-#define W4_STAMP(i) do { const long long n_ = __builtin_readcyclecounter(); ck[i] += n_ - ckt; ckt = n_; } while (0)
-#else
 #define W4_STAMP(i) do { } while (0)
-#endif
   auto body_pipe = [&](int q) {
-#ifdef W4_CLK
-    ckt = __builtin_readcyclecounter();
-#endif
     const long Pn = (long)q * CH - HALO + CH;               // linear index of the first of the 64 pixels chunk q adds (h1 ring slots)
     const int sn0 = (int)((Pn + p) & (RING - 1)) * 16, sn1 = (int)((Pn + 32 + p) & (RING - 1)) * 16;
     const int xn0 = xslot16(CH - HALO + p), xn1 = xslot16(CH - HALO + 32 + p);      // ... and their x ring slots
@@ -564,11 +553,6 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
       conv2_mfma(q, 1);
     }
   }
-#ifdef W4_CLK
-  if ((blockIdx.x == 0 || blockIdx.x == 100) && lane == 0)
-    printf("[w4 wg %d wave %d] bodies %d | S1 %lld  barC %lld  S2 %lld  S3 %lld  barD %lld  S4 %lld  (cycles per body)\n", (int)blockIdx.x, w, q1 - q0 - 3,
-           ck[0] / (q1 - q0 - 3), ck[1] / (q1 - q0 - 3), ck[2] / (q1 - q0 - 3), ck[3] / (q1 - q0 - 3), ck[4] / (q1 - q0 - 3), ck[5] / (q1 - q0 - 3));
-#endif
 }
 
 // The engines' stage-1 kernel since round 4 (2.05 vs 2.22 ms per 12 800-image launch); FSVIT_STAGE1_W4=0 keeps stage1_ring's eight-wave kernel

@@ -177,13 +177,14 @@ int fsvit_qkv_attention(const void* x_dev, const void* wqkv_dev, int kw, const f
 int fsvit_vit_ln_qkv_attention(const void* x_dev, const void* wqkv_dev, int kw, const float* bias_dev, void* ctx_dev, int B, int S, int C,
                                int heads, int hdp, float eps, float scale, void* stream);
 /* One fused Visformer stage-1 block (visformer.py:259-263 with attn_disabled + spatial_conv Mlp :152-163), bf16,
- * Visformer-S geometry only (20x20 tokens, 128 channels, 256 hidden, 8 groups): y = x + conv3(GELU(conv2_g(GELU(conv1(x)+b1)))).
- * x, y NHWC [B,20,20,128] bf16 (distinct buffers); w1 [256][128], w2 [8][32][320], w3 [128][256] packed K-major bf16. */
+ * 20x20 tokens, 128 channels, 256 hidden, 8 groups: y = x + conv3(GELU(conv2_g(GELU(conv1(x)+b1)))).
+ * x, y NHWC [B,20,20,128] bf16 (distinct buffers); w1 [256][128], w2 [8][32][320], w3 [128][256] packed K-major bf16.
+ * Always the 16-wave ring kernel (stage1_ring.hip), whatever FSVIT_STAGE1_W4 says: the in-process cross-check of fsvit_stage1_block_hw. */
 int fsvit_stage1_block(const void* x_dev, void* y_dev, const void* w1_dev, const float* b1_dev, const void* w2_dev,
                        const void* w3_dev, int B, void* stream);
-/* The same block for any square token map of 4 .. 20 a side (stage1_ring.hip: wave = channel group, weights in registers, x and the first hidden map in
- * pixel rings - no half-image geometry): x, y NHWC [B,H,W,128], dtype FSVIT_BF16 / FSVIT_F16; weights as above.  This is the kernel the engines run
- * (FSVIT_STAGE1_RING=0 keeps the half-image kernel of fsvit_stage1_block for 20 x 20 maps). */
+/* The same block for any square token map of 4 .. 20 a side: x, y NHWC [B,H,W,128], dtype FSVIT_BF16 / FSVIT_F16; weights as above.  This is the launch the
+ * engines run: stage1_w4.hip (one wave per SIMD, weights in registers / AGPRs, x and the first hidden map in pixel rings), or stage1_ring.hip (wave = channel
+ * group) under FSVIT_STAGE1_W4=0; FSVIT_STAGE1_RING=0 makes the engines take the three-launch GEMM route instead. */
 int fsvit_stage1_block_hw(const void* x_dev, void* y_dev, const void* w1_dev, const float* b1_dev, const void* w2_dev, const void* w3_dev, int B, int H, int W,
                           int dtype, void* stream);
 /* Fused Mlp of a Visformer attention block (visformer.py:146-150 with spatial_conv=False, + the residual of :262):

@@ -317,7 +317,7 @@ def test_full_size_step_equals_small_launches(full_sd):
 
 
 def test_image_size_64_runs_the_ring_stage1_block():
-    """A 64 x 64 model (stage-1 map 16 x 16: the half-image kernel of stage1_fused.hip does not apply, the engine takes stage1_ring.hip; stage 2 has
+    """A 64 x 64 model (stage-1 map 16 x 16: chunks of 64 pixels straddle images in the stage-1 block kernel; stage 2 has
     64 tokens, stage 3 sixteen): parity features vs the oracle, bf16 features vs parity, launch-size invariance."""
     from fewshot_vit_amd import synthetic
     from fewshot_vit_amd.engine import VisformerEngine

@@ -1,5 +1,5 @@
-"""Times the fused stage-1 block operators: fsvit_stage1_block_hw (stage1_ring.hip, the engines' kernel) or, with FSVIT_STAGE1_RING=0,
-fsvit_stage1_block (stage1_fused.hip, the half-image kernel; the op packs its weight image and synchronises per call).
+"""Times the fused stage-1 block operators: fsvit_stage1_block_hw (the engines' launch: stage1_w4.hip, or stage1_ring.hip under FSVIT_STAGE1_W4=0) or,
+with FSVIT_STAGE1_RING=0, fsvit_stage1_block (always the 16-wave kernel of stage1_ring.hip).
 python tools/bench_stage1.py [images [variant.so]]"""
 import math
 import sys
