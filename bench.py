@@ -406,9 +406,8 @@ def train_leg(model_name, numerics, E, steps, warmup, rank, world, dev):
     label = fs.make_nk_label(way, query, E).to(dev)
     reducer = parallel.GradBucket(model) if world > 1 else None
 
-    def step():
-        logits = model(x_shot, x_query).view(-1, way)
-        loss = torch.nn.functional.cross_entropy(logits, label)
+    def step():       # train_meta.train_step without its end-of-step .item() (loss and accuracy stay on the device)
+        loss, _acc, _ = model.forward_loss(x_shot, x_query, label)        # head + F.cross_entropy + compute_acc in one launch (fsvit_proto_head_ce)
         opt.zero_grad()
         loss.backward()
         if reducer is not None:

@@ -103,6 +103,8 @@ SIGNATURES = {
     'fsvit_vit_train_backward': (_i, [_vp, C.POINTER(Param), _i, _fp, _vp]),
     'fsvit_proto_head_backward': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _fp, _fp, _vp]),
     'fsvit_proto_head_backward_sqr': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _fp, _fp, _vp]),
+    'fsvit_proto_head_ce': (_i, [_fp, _fp, _vp, _i, _i, _i, _i, _i, _f, _fp, _i, _fp, _fp, _fp, _fp, _fp, _vp, _vp]),
+    'fsvit_proto_head_ce_backward': (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _f, _fp, _i, _fp, _fp, _fp, _vp, _vp]),
     'fsvit_proto_head_backward_devtemp': (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _i, _fp, _fp, _fp, _vp]),
     'fsvit_visformer_trainer_set_freeze_bn': (_i, [_vp, _i]),
     'fsvit_sgd_step_multi': (_i, [_vp, _i, _sz, _f, _f, _f, _i, _vp]),

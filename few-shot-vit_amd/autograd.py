@@ -101,6 +101,27 @@ class ProtoHeadFn(torch.autograd.Function):
         return ds, dq, dt.reshape(temp.shape), None
 
 
+class ProtoHeadCEFn(torch.autograd.Function):
+    """Head + mean cross entropy + accuracy of the meta-tuning step (train_meta.py:167-169) as ONE launch each way: returns (loss, acc, logits); only
+    the loss carries a gradient.  The forward already forms dlogits; the backward multiplies with the upstream gradient inside the head's kernel."""
+
+    @staticmethod
+    def forward(ctx, feat_shot, feat_query, temp, label, method='cos'):
+        feat_shot, feat_query = feat_shot.contiguous().float(), feat_query.contiguous().float()
+        logits, dlogits, stats = ops.proto_head_ce(feat_shot, feat_query, temp if temp.is_cuda else float(temp), label, method)
+        ctx.save_for_backward(feat_shot, feat_query, temp, dlogits)
+        ctx.method = method
+        loss, acc = stats[0], stats[1]
+        ctx.mark_non_differentiable(acc, logits)
+        return loss, acc, logits
+
+    @staticmethod
+    def backward(ctx, dloss, _dacc, _dlogits):
+        feat_shot, feat_query, temp, dlogits = ctx.saved_tensors
+        ds, dq, dt = ops.proto_head_ce_backward(feat_shot, feat_query, dlogits, dloss.contiguous().float(), temp if temp.is_cuda else float(temp), ctx.method)
+        return ds, dq, dt.reshape(temp.shape), None, None
+
+
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b on the HIP linear kernels (classifier.py:27-34); x [..., K] fp32."""
 

@@ -42,7 +42,9 @@ template <int NT>
 __global__ __launch_bounds__(NT) void proto_head_kernel(const float* __restrict__ feat_shot, const float* __restrict__ feat_query,
                                                          int way, int shot, int Q, int D, float temp, int method,
                                                          float* __restrict__ logits, float* __restrict__ acc, float* __restrict__ loss,
-                                                         const float* __restrict__ temp_dev) {
+                                                         const float* __restrict__ temp_dev, const long long* __restrict__ labels = nullptr,
+                                                         float* __restrict__ dlogits = nullptr, float* __restrict__ mean_out = nullptr,
+                                                         unsigned* __restrict__ ticket = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (temp_dev) temp = *temp_dev;                             // the learnable temperature read where it lives (no host round trip per step)
   float* proto = reinterpret_cast<float*>(smem);              // [way][D]
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(NT) void proto_head_kernel(const float* __restrict_
     int arg = 0;
     float* lrow = logits + ((size_t)e * Q + q) * way;
     float lab_logit = 0.f;
-    const int label = per > 0 ? q / per : 0;
+    const int label = labels ? (int)labels[(size_t)e * Q + q] : (per > 0 ? q / per : 0);
     for (int c = 0; c < way; ++c) {
       float s = 0.f;
       if (method != 1) {
@@ -103,6 +105,11 @@ __global__ __launch_bounds__(NT) void proto_head_kernel(const float* __restrict_
       for (int c = 0; c < way; ++c) se += expf(lrow[c] - mx);
       qstat[q * 2 + 0] = (arg == label) ? 1.0f : 0.0f;
       qstat[q * 2 + 1] = mx + logf(se) - lab_logit;
+      if (dlogits) {      // d(mean cross entropy over all E * Q rows) / dlogits = (softmax - onehot) / (E * Q)   (F.cross_entropy, train_meta.py:168)
+        const float inv_rows = 1.0f / ((float)gridDim.x * (float)Q), inv_se = 1.0f / se;
+        float* drow = dlogits + ((size_t)e * Q + q) * way;
+        for (int c = 0; c < way; ++c) drow[c] = (expf(lrow[c] - mx) * inv_se - (c == label ? 1.0f : 0.0f)) * inv_rows;
+      }
     }
   }
   __syncthreads();
@@ -111,11 +118,29 @@ __global__ __launch_bounds__(NT) void proto_head_kernel(const float* __restrict_
     for (int q = 0; q < Q; ++q) { a += qstat[q * 2]; l += qstat[q * 2 + 1]; }
     if (acc) acc[e] = a / (float)Q;
     if (loss) loss[e] = l / (float)Q;
+    if (mean_out && ticket && acc && loss) {      // batch means by the LAST workgroup to finish, summed in episode order (deterministic); the ticket is left at 0
+      __threadfence();
+      if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+        __threadfence();
+        float sl = 0.f, sa = 0.f;
+        for (unsigned i = 0; i < gridDim.x; ++i) { sl += __builtin_nontemporal_load(loss + i); sa += __builtin_nontemporal_load(acc + i); }
+        mean_out[0] = sl / (float)gridDim.x;
+        mean_out[1] = sa / (float)gridDim.x;
+        *ticket = 0u;
+      }
+    }
   }
 }
 
 int launch_proto_head(const float* feat_shot, const float* feat_query, int E, int way, int shot, int Q, int D,
                       float temp, int method, float* logits, float* acc, float* loss, hipStream_t s, const float* temp_dev) {
+  return launch_proto_head_ce(feat_shot, feat_query, nullptr, E, way, shot, Q, D, temp, method, logits, acc, loss, nullptr, nullptr, nullptr, s, temp_dev);
+}
+
+// head + cross entropy of the meta-tuning step (train_meta.py:167-169) in one launch: logits, per-episode loss / accuracy, dlogits of the mean CE, and the
+// two batch means (mean_out[0] = loss, [1] = accuracy) behind a device ticket (a zeroed 4-byte word the kernel leaves zeroed)
+int launch_proto_head_ce(const float* feat_shot, const float* feat_query, const long long* labels, int E, int way, int shot, int Q, int D, float temp, int method,
+                         float* logits, float* acc, float* loss, float* dlogits, float* mean_out, unsigned* ticket, hipStream_t s, const float* temp_dev) {
   if (E <= 0) return 0;
   const size_t lds = ((size_t)way * D + (size_t)Q * 2) * sizeof(float);
   if (lds > 160 * 1024 || way < 1 || shot < 1 || Q < 1) return (int)hipErrorInvalidValue;
@@ -123,7 +148,7 @@ int launch_proto_head(const float* feat_shot, const float* feat_query, int E, in
   hipError_t e = hipFuncSetAttribute((const void*)proto_head_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(proto_head_kernel<1024>, dim3(E), dim3(1024), lds, s, feat_shot, feat_query, way, shot, Q, D, temp, method,
-                     logits, acc, loss, temp_dev);
+                     logits, acc, loss, temp_dev, labels, dlogits, mean_out, ticket);
   return (int)hipGetLastError();
 }
 
@@ -131,12 +156,27 @@ int launch_proto_head(const float* feat_shot, const float* feat_query, int E, in
 // One workgroup per episode.  x^ = x / max(|x|, 1e-12):  dx = (dx^ - x^ <x^, dx^>) / |x|.
 // (16 waves per episode: the step has only ep_per_batch workgroups, each a chain of wave reductions - with 4 waves the kernel took 275 us)
 constexpr int HB_NT = 1024;
+// dtemp[gridDim.x] = sum over the episodes' dtemp[e], by the last workgroup to arrive, in episode order (ticket: zeroed word, left zeroed)
+__device__ __forceinline__ void head_dtemp_sum(float* dtemp, unsigned* ticket) {
+  if (!ticket) return;
+  __threadfence();
+  if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+    __threadfence();
+    float s = 0.f;
+    for (unsigned i = 0; i < gridDim.x; ++i) s += __builtin_nontemporal_load(dtemp + i);
+    dtemp[gridDim.x] = s;
+    *ticket = 0u;
+  }
+}
 __global__ __launch_bounds__(HB_NT) void proto_head_bwd_kernel(const float* __restrict__ feat_shot, const float* __restrict__ feat_query,
                                                              const float* __restrict__ dlogits, int way, int shot, int Q, int D, float temp,
                                                              float* __restrict__ dfeat_shot, float* __restrict__ dfeat_query, float* __restrict__ dtemp,
-                                                             const float* __restrict__ temp_dev) {
+                                                             const float* __restrict__ temp_dev, const float* __restrict__ up = nullptr,
+                                                             unsigned* __restrict__ ticket = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (temp_dev) temp = *temp_dev;
+  const float upv = up ? *up : 1.0f;                        // the upstream gradient of a scalar loss (the backward is linear in dlogits)
+  temp *= upv;
   float* proto = reinterpret_cast<float*>(smem);            // [way][D] normalised prototypes
   float* dproto = proto + (size_t)way * D;                    // [way][D] gradient w.r.t. the normalised prototypes
   float* pinv = dproto + (size_t)way * D;                     // [way] 1 / |p_c|
@@ -188,7 +228,8 @@ __global__ __launch_bounds__(HB_NT) void proto_head_bwd_kernel(const float* __re
   if (t == 0 && dtemp) {
     float s = 0.f;
     for (int w = 0; w < HB_NT / 64; ++w) s += red[w];
-    dtemp[e] = s;
+    dtemp[e] = s * upv;
+    head_dtemp_sum(dtemp, ticket);
   }
   // prototypes: dp^_c[d] = temp * sum_q dl[q][c] q^[d]
   for (int i = t; i < way * D; i += HB_NT) {
@@ -214,9 +255,12 @@ __global__ __launch_bounds__(HB_NT) void proto_head_bwd_kernel(const float* __re
 __global__ __launch_bounds__(256) void proto_head_sqr_bwd_kernel(const float* __restrict__ feat_shot, const float* __restrict__ feat_query,
                                                                  const float* __restrict__ dlogits, int way, int shot, int Q, int D, float temp,
                                                                  float* __restrict__ dfeat_shot, float* __restrict__ dfeat_query, float* __restrict__ dtemp,
-                                                                 const float* __restrict__ temp_dev) {
+                                                                 const float* __restrict__ temp_dev, const float* __restrict__ up = nullptr,
+                                                                 unsigned* __restrict__ ticket = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   if (temp_dev) temp = *temp_dev;
+  const float upv = up ? *up : 1.0f;
+  temp *= upv;
   float* proto = reinterpret_cast<float*>(smem);            // [way][D]
   float* red = proto + (size_t)way * D;                       // [4]
   const int e = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -246,7 +290,10 @@ __global__ __launch_bounds__(256) void proto_head_sqr_bwd_kernel(const float* __
   }
   if (lane == 0) red[wave] = dt_acc;
   __syncthreads();
-  if (t == 0 && dtemp) dtemp[e] = red[0] + red[1] + red[2] + red[3];
+  if (t == 0 && dtemp) {
+    dtemp[e] = (red[0] + red[1] + red[2] + red[3]) * upv;
+    head_dtemp_sum(dtemp, ticket);
+  }
   for (int i = t; i < way * D; i += 256) {
     const int c = i / D, d = i - c * D;
     float g = 0.f;
@@ -257,24 +304,24 @@ __global__ __launch_bounds__(256) void proto_head_sqr_bwd_kernel(const float* __
 }
 
 int launch_proto_head_sqr_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
-                              float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s, const float* temp_dev) {
+                              float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s, const float* temp_dev, const float* up, unsigned* ticket) {
   if (E <= 0) return 0;
   const size_t lds = ((size_t)way * D + 4) * sizeof(float);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute((const void*)proto_head_sqr_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(proto_head_sqr_bwd_kernel, dim3(E), dim3(256), lds, s, feat_shot, feat_query, dlogits, way, shot, Q, D, temp, dfeat_shot, dfeat_query, dtemp, temp_dev);
+  hipLaunchKernelGGL(proto_head_sqr_bwd_kernel, dim3(E), dim3(256), lds, s, feat_shot, feat_query, dlogits, way, shot, Q, D, temp, dfeat_shot, dfeat_query, dtemp, temp_dev, up, ticket);
   return (int)hipGetLastError();
 }
 
 int launch_proto_head_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
-                          float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s, const float* temp_dev) {
+                          float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s, const float* temp_dev, const float* up, unsigned* ticket) {
   if (E <= 0) return 0;
   const size_t lds = ((size_t)2 * way * D + way + Q + HB_NT / 64) * sizeof(float);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   hipError_t e = hipFuncSetAttribute((const void*)proto_head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(proto_head_bwd_kernel, dim3(E), dim3(HB_NT), lds, s, feat_shot, feat_query, dlogits, way, shot, Q, D, temp, dfeat_shot, dfeat_query, dtemp, temp_dev);
+  hipLaunchKernelGGL(proto_head_bwd_kernel, dim3(E), dim3(HB_NT), lds, s, feat_shot, feat_query, dlogits, way, shot, Q, D, temp, dfeat_shot, dfeat_query, dtemp, temp_dev, up, ticket);
   return (int)hipGetLastError();
 }
 

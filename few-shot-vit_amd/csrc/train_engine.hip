@@ -1336,6 +1336,30 @@ extern "C" int fsvit_proto_head_backward_devtemp(const float* feat_shot, const f
   return rc ? fsvit_set_error(rc, "proto_head_bwd") : 0;
 }
 
+extern "C" int fsvit_proto_head_ce(const float* feat_shot, const float* feat_query, const long long* labels, int E, int way, int shot, int Q, int D, float temp,
+                                   const float* temp_dev, int method, float* logits, float* dlogits, float* acc_per_episode, float* loss_per_episode,
+                                   float* loss_acc_mean, unsigned* ticket, void* stream) {
+  if (!feat_shot || !feat_query || !logits || !acc_per_episode || !loss_per_episode) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
+  if (method != FSVIT_HEAD_COS && method != FSVIT_HEAD_SQR && method != FSVIT_HEAD_DOT) return fsvit_set_error(FSVIT_ERR_ARG, "unknown head method %d", method);
+  if ((loss_acc_mean != nullptr) != (ticket != nullptr)) return fsvit_set_error(FSVIT_ERR_ARG, "fsvit_proto_head_ce: loss_acc_mean needs the ticket word (and the reverse)");
+  int rc = launch_proto_head_ce(feat_shot, feat_query, labels, E, way, shot, Q, D, temp_dev ? 0.f : temp, method, logits, acc_per_episode, loss_per_episode, dlogits,
+                                loss_acc_mean, ticket, (hipStream_t)stream, temp_dev);
+  return rc ? fsvit_set_error(rc, "proto_head_ce") : 0;
+}
+
+extern "C" int fsvit_proto_head_ce_backward(const float* feat_shot, const float* feat_query, const float* dlogits, const float* dloss_dev, int E, int way, int shot,
+                                            int Q, int D, float temp, const float* temp_dev, int method, float* dfeat_shot, float* dfeat_query, float* dtemp,
+                                            unsigned* ticket, void* stream) {
+  if (!feat_shot || !feat_query || !dlogits || !dfeat_shot || !dfeat_query) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
+  if (method != FSVIT_HEAD_COS && method != FSVIT_HEAD_SQR) return fsvit_set_error(FSVIT_ERR_ARG, "head backward: method 'cos' or 'sqr'");
+  if (ticket && !dtemp) return fsvit_set_error(FSVIT_ERR_ARG, "fsvit_proto_head_ce_backward: the ticket sums dtemp[0 .. E) into dtemp[E]");
+  int rc = method == FSVIT_HEAD_COS ? launch_proto_head_bwd(feat_shot, feat_query, dlogits, E, way, shot, Q, D, temp_dev ? 0.f : temp, dfeat_shot, dfeat_query, dtemp,
+                                                            (hipStream_t)stream, temp_dev, dloss_dev, ticket)
+                                    : launch_proto_head_sqr_bwd(feat_shot, feat_query, dlogits, E, way, shot, Q, D, temp_dev ? 0.f : temp, dfeat_shot, dfeat_query,
+                                                                dtemp, (hipStream_t)stream, temp_dev, dloss_dev, ticket);
+  return rc ? fsvit_set_error(rc, "proto_head_ce_backward") : 0;
+}
+
 extern "C" int fsvit_attention_backward(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, int hd, int hdp, float scale, int dtype,
                                         void* stream) {
   if (!qkv || !dctx || !dqkv) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");

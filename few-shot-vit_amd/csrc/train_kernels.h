@@ -78,11 +78,14 @@ int launch_sgd_multi(const void* items_dev, int n_items, size_t max_numel, float
 int launch_sgd(float* p, const float* g, float* buf, size_t n, float lr, float momentum, float wd, int first, hipStream_t s);
 // attention backward (attention_bwd.hip): qkv [B*S][3*heads*hdp], dctx [B*S][heads*hdp] -> dqkv [B*S][3*heads*hdp]
 int launch_attention_bwd(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, int hd, int hdp, float scale, int dtype, hipStream_t s);
-// prototype head backward (head.hip): dlogits [E,Q,way] -> dfeat_shot [E,way,shot,D], dfeat_query [E,Q,D], dtemp[E] (cos method)
+// prototype head backward (head.hip): dlogits [E,Q,way] -> dfeat_shot [E,way,shot,D], dfeat_query [E,Q,D], dtemp[E] (cos method).
+// up: device scalar every gradient is multiplied with (the upstream gradient of a scalar loss); ticket: zeroed device word -> dtemp[E] = sum_e dtemp[e]
 int launch_proto_head_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
-                          float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s, const float* temp_dev = nullptr);
+                          float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s, const float* temp_dev = nullptr, const float* up = nullptr,
+                          unsigned* ticket = nullptr);
 int launch_proto_head_sqr_bwd(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D, float temp,
-                          float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s, const float* temp_dev = nullptr);
+                          float* dfeat_shot, float* dfeat_query, float* dtemp, hipStream_t s, const float* temp_dev = nullptr, const float* up = nullptr,
+                          unsigned* ticket = nullptr);
 
 // ---- ViT / DeiT training (deit.py): LayerNorm with kept row statistics, token assembly, the final norm on the cls row
 int launch_ln_train_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int M, int D, float eps, int dtype, hipStream_t s);

@@ -791,6 +791,64 @@ class ops:
             _lib.check(lib.fsvit_sgd_step(_ptr(param), _ptr(grad), _ptr(buf), param.numel(), float(lr), float(momentum),
                                           float(weight_decay), int(bool(first_step)), _stream_ptr(param.device)))
 
+    _tickets = {}
+
+    @staticmethod
+    def _ticket(dev):
+        """Two zeroed device words per device (forward / backward of the fused CE head; the kernels leave them at zero)."""
+        key = (dev.type, dev.index)
+        if key not in ops._tickets:
+            ops._tickets[key] = torch.zeros(2, dtype=torch.int32, device=dev)
+        return ops._tickets[key]
+
+    @staticmethod
+    def proto_head_ce(feat_shot, feat_query, temp, label=None, method='cos'):
+        """Head + F.cross_entropy + compute_acc of the meta-tuning step in one launch (fsvit_proto_head_ce): -> logits [E,Q,way], dlogits [E,Q,way]
+        (of the mean CE), stats [2 + 2 E] = {loss, acc, acc per episode .., loss per episode ..}.  label: int64 [E*Q] on the device (None: make_nk_label)."""
+        _require_cuda(feat_shot, feat_query)
+        lib = _lib.load()
+        E, way, shot, D = feat_shot.shape
+        Q = feat_query.shape[1]
+        dev = feat_shot.device
+        logits = torch.empty(E, Q, way, dtype=torch.float32, device=dev)
+        dlogits = torch.empty(E, Q, way, dtype=torch.float32, device=dev)
+        stats = torch.empty(2 + 2 * E, dtype=torch.float32, device=dev)
+        m = {'cos': _lib.HEAD_COS, 'sqr': _lib.HEAD_SQR, 'dot': _lib.HEAD_DOT}[method]
+        if label is not None:
+            if label.dtype != torch.int64 or not label.is_cuda or label.numel() != E * Q:
+                raise ValueError('label: int64 [E*Q] on the device')
+            label = label.contiguous()
+        dev_temp = isinstance(temp, torch.Tensor) and temp.is_cuda
+        tk = ops._ticket(dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.fsvit_proto_head_ce(_ptr(feat_shot), _ptr(feat_query), _ptr(label) if label is not None else None, E, way, shot, Q, D,
+                                               0.0 if dev_temp else float(temp), _ptr(temp.detach()) if dev_temp else None, m, _ptr(logits), _ptr(dlogits),
+                                               _ptr(stats[2:2 + E]), _ptr(stats[2 + E:]), _ptr(stats), tk.data_ptr(), _stream_ptr(dev)))
+        return logits, dlogits, stats
+
+    @staticmethod
+    def proto_head_ce_backward(feat_shot, feat_query, dlogits, dloss, temp, method='cos'):
+        """-> dfeat_shot, dfeat_query, dtemp (0-d tensor): fsvit_proto_head_ce_backward with the upstream gradient `dloss` read on the device."""
+        if method not in ('cos', 'sqr'):
+            raise ValueError(method)
+        _require_cuda(feat_shot, feat_query, dlogits)
+        lib = _lib.load()
+        E, way, shot, D = feat_shot.shape
+        Q = feat_query.shape[1]
+        dev = feat_shot.device
+        ds, dq = torch.empty_like(feat_shot), torch.empty_like(feat_query)
+        dt = torch.empty(E + 1, dtype=torch.float32, device=dev)
+        dev_temp = isinstance(temp, torch.Tensor) and temp.is_cuda
+        if dloss is not None and not (dloss.is_cuda and dloss.dtype == torch.float32 and dloss.numel() == 1):
+            raise ValueError('dloss: one fp32 value on the device')
+        tk = ops._ticket(dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.fsvit_proto_head_ce_backward(_ptr(feat_shot), _ptr(feat_query), _ptr(dlogits), _ptr(dloss) if dloss is not None else None, E, way,
+                                                        shot, Q, D, 0.0 if dev_temp else float(temp), _ptr(temp.detach()) if dev_temp else None,
+                                                        _lib.HEAD_COS if method == 'cos' else _lib.HEAD_SQR, _ptr(ds), _ptr(dq), _ptr(dt),
+                                                        tk.data_ptr() + 4, _stream_ptr(dev)))
+        return ds, dq, dt[E]
+
     @staticmethod
     def proto_head(feat_shot, feat_query, temp, method='cos'):
         """feat_shot [E,way,shot,D], feat_query [E,Q,D] fp32 -> logits [E,Q,way], acc [E], loss [E]."""

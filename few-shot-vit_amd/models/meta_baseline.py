@@ -31,7 +31,7 @@ class MetaBaseline(nn.Module):
             return self._forward_train(x_shot, x_query)
         return self._forward_eval(x_shot, x_query)
 
-    def _forward_train(self, x_shot, x_query):
+    def _forward_train(self, x_shot, x_query, label=None):
         """The meta-tuning step's forward (train_meta.py:167): one encoder pass over shot + query images of all
         episodes (so BatchNorm sees the whole batch, meta_baseline.py:31), then the differentiable head ('cos' or 'sqr')."""
         if not hasattr(self.encoder, 'trainer'):
@@ -47,7 +47,21 @@ class MetaBaseline(nn.Module):
         f_shot = x_tot[:n_shot].view(E, way, shot, -1)
         f_query = x_tot[n_shot:].view(E, Q, -1)
         temp = self.temp if isinstance(self.temp, torch.Tensor) else torch.tensor(float(self.temp))      # (a host scalar: passed by value)
+        if label is not None:
+            from ..autograd import ProtoHeadCEFn
+            return ProtoHeadCEFn.apply(f_shot, f_query, temp, label, self.method)
         return ProtoHeadFn.apply(f_shot, f_query, temp, self.method)
+
+    def forward_loss(self, x_shot, x_query, label):
+        """Training only: (loss, acc, logits) of train_meta.py:167-169 - `logits = model(x_shot, x_query).view(-1, n_way)`, `F.cross_entropy(logits, label)`,
+        `utils.compute_acc(logits, label)` - with head, loss and accuracy in one launch (fsvit_proto_head_ce).  loss / acc are 0-d device tensors."""
+        if not self.training:
+            raise RuntimeError('forward_loss is the training-step entry; eval mode returns logits from forward()')
+        if x_shot.dim() != 6 or x_query.dim() != 5:
+            raise ValueError('expected x_shot [E,way,shot,C,H,W] and x_query [E,Q,C,H,W]')
+        if self.method not in ('cos', 'sqr'):
+            raise ValueError(self.method)
+        return self._forward_train(x_shot, x_query, label)
 
     def _forward_eval(self, x_shot, x_query):
         engine = self.encoder.engine()

@@ -58,12 +58,18 @@ def build_model(config):
     return model
 
 
+_FUSED_CE = os.environ.get('FSVIT_FUSED_CE', '1') != '0'       # 0: logits -> F.cross_entropy / compute_acc through ATen (the reference's three lines)
+
+
 def train_step(model, optimizer, x_shot, x_query, label, n_way, world=1, bucket=None):
     """train_meta.py:161-174: forward, CE, zero_grad, backward, (gradient all-reduce), step.  Returns (loss, acc).
     `bucket`: the model's parallel.GradBucket (world > 1): the gradients already sit in its flat buffer, the exchange is one in-place all-reduce."""
-    logits = model(x_shot, x_query).view(-1, n_way)
-    loss = F.cross_entropy(logits, label)
-    acc = utils.compute_acc(logits, label)
+    if _FUSED_CE and hasattr(model, 'forward_loss') and label.is_cuda:
+        loss, acc, _ = model.forward_loss(x_shot, x_query, label)       # head + F.cross_entropy + compute_acc in one launch (fsvit_proto_head_ce)
+    else:
+        logits = model(x_shot, x_query).view(-1, n_way)
+        loss = F.cross_entropy(logits, label)
+        acc = utils.compute_acc(logits, label, reduction='none').mean()
     optimizer.zero_grad()
     loss.backward()
     if world > 1:
@@ -72,7 +78,7 @@ def train_step(model, optimizer, x_shot, x_query, label, n_way, world=1, bucket=
         else:
             parallel.allreduce_mean_grads(model.parameters())
     optimizer.step()
-    return loss.item(), acc
+    return loss.item(), acc.item()          # the step's only host synchronisation: after the optimizer launches, not between forward and backward
 
 
 def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, save_root='./save', warmup=False):

@@ -323,6 +323,20 @@ int fsvit_proto_head_backward_sqr(const float* feat_shot_dev, const float* feat_
 int fsvit_proto_head_backward_devtemp(const float* feat_shot_dev, const float* feat_query_dev, const float* dlogits_dev, int E, int way,
                                       int shot, int Q, int D, const float* temp_dev, int method, float* dfeat_shot_dev,
                                       float* dfeat_query_dev, float* dtemp_per_episode_dev, void* stream);
+/* Head + loss of the meta-tuning step in one launch (train_meta.py:167-169: `logits = model(x_shot, x_query).view(-1, n_way); loss = F.cross_entropy(logits,
+ * label); acc = utils.compute_acc(logits, label)`): logits [E,Q,way], per-episode accuracy / mean cross entropy [E], dlogits [E,Q,way] = d(mean CE over all
+ * E * Q rows) / dlogits (may be NULL), and loss_acc_mean_dev[2] = {F.cross_entropy value, compute_acc value} (may be NULL).  labels_dev: int64 [E*Q] class
+ * indices, or NULL for fs.make_nk_label's (few_shot.py:13-16: q / (Q / way)).  temp_dev (may be NULL): the temperature read from device memory instead of
+ * `temp`.  ticket_dev: a zero-initialised 4-byte device word (required with loss_acc_mean_dev): the last workgroup to finish sums the episodes in index order
+ * and leaves the word at zero - no second launch, no atomics on floating-point data, results bit-reproducible. */
+int fsvit_proto_head_ce(const float* feat_shot_dev, const float* feat_query_dev, const long long* labels_dev, int E, int way, int shot, int Q, int D, float temp,
+                        const float* temp_dev, int method, float* logits_dev, float* dlogits_dev, float* acc_per_episode_dev, float* loss_per_episode_dev,
+                        float* loss_acc_mean_dev, unsigned* ticket_dev, void* stream);
+/* Its backward (methods FSVIT_HEAD_COS / FSVIT_HEAD_SQR): dlogits of fsvit_proto_head_ce times the upstream gradient *dloss_dev (NULL = 1) -> dfeat_shot,
+ * dfeat_query, dtemp_dev [E] per episode (may be NULL) and, with ticket_dev, dtemp_dev[E] = their sum (dtemp_dev then holds E + 1 floats). */
+int fsvit_proto_head_ce_backward(const float* feat_shot_dev, const float* feat_query_dev, const float* dlogits_dev, const float* dloss_dev, int E, int way,
+                                 int shot, int Q, int D, float temp, const float* temp_dev, int method, float* dfeat_shot_dev, float* dfeat_query_dev,
+                                 float* dtemp_dev, unsigned* ticket_dev, void* stream);
 /* The same update for a table of tensors in one launch.  items_dev: DEVICE array of n_items records {float* param; const float* grad;
  * float* momentum_buf; size_t numel} (4 x 8 bytes each); max_numel = the largest numel.  All tensors share lr / momentum / weight_decay /
  * first_step (one param_group of torch.optim.SGD, meta_tuning_sun_m/utils/__init__.py:128-139). */

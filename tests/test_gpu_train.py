@@ -273,6 +273,87 @@ def test_proto_head_sqr_backward_vs_torch():
     assert abs(float(dt) - float(t.grad)) <= 1e-4 * abs(float(t.grad)) + 1e-6
 
 
+@pytest.mark.parametrize('method', ['cos', 'sqr'])
+@pytest.mark.parametrize('labels', ['nk', 'shuffled'])
+def test_fused_head_cross_entropy_vs_torch(method, labels):
+    """fsvit_proto_head_ce / _backward (train_meta.py:167-169 in one launch each way): loss = F.cross_entropy(logits, label), acc = compute_acc, the
+    gradients of 3 x loss w.r.t. both feature tensors and the temperature vs torch autograd; temperature on the device; bit-reproducible; tickets left at 0."""
+    from fewshot_vit_amd.autograd import ProtoHeadCEFn
+    from fewshot_vit_amd.engine import ops
+    from fewshot_vit_amd.utils import few_shot as fs
+    from fewshot_vit_amd import utils
+    E, way, shot, Q, D = 4, 10, 5, 50, 512
+    g = torch.Generator().manual_seed(29)
+    sc = 1.0 if method == 'cos' else 0.1
+    fs_ = torch.randn(E, way, shot, D, generator=g) * sc
+    fq = torch.randn(E, Q, D, generator=g) * sc
+    fq[:, :, :64] += fs_.mean(2).repeat_interleave(Q // way, dim=1)[:, :, :64] * 3            # queries lean towards their class: accuracy well off chance
+    label = fs.make_nk_label(way, Q // way, E)
+    if labels == 'shuffled':
+        label = label[torch.randperm(label.numel(), generator=g)]
+    a, b = fs_.clone().requires_grad_(True), fq.clone().requires_grad_(True)
+    t = torch.tensor(10.0 if method == 'cos' else 2.0, requires_grad=True)
+    if method == 'cos':
+        proto = torch.nn.functional.normalize(a.mean(dim=-2), dim=-1)
+        logits = torch.bmm(torch.nn.functional.normalize(b, dim=-1), proto.transpose(1, 2)) * t
+    else:
+        logits = -(b.unsqueeze(2) - a.mean(dim=-2).unsqueeze(1)).pow(2).sum(dim=-1) * t
+    loss = torch.nn.functional.cross_entropy(logits.view(-1, way), label)
+    (3.0 * loss).backward()
+    acc = utils.compute_acc(logits.view(-1, way), label)
+
+    def run():
+        a2, b2 = fs_.cuda().requires_grad_(True), fq.cuda().requires_grad_(True)
+        t2 = t.detach().cuda().requires_grad_(True)
+        l2, acc2, lg2 = ProtoHeadCEFn.apply(a2, b2, t2, label.cuda() if labels == 'shuffled' else None, method)
+        (3.0 * l2).backward()
+        torch.cuda.synchronize()
+        return l2.detach().cpu(), acc2.cpu(), lg2.cpu(), a2.grad.cpu(), b2.grad.cpu(), t2.grad.cpu()
+    l2, acc2, lg2, da, db, dt = run()
+    assert not acc2.requires_grad and not lg2.requires_grad
+    assert float((lg2 - logits.detach()).abs().max()) <= 1e-4
+    assert abs(float(l2) - float(loss)) <= 2e-6 * max(1.0, abs(float(loss))), (float(l2), float(loss))
+    assert abs(float(acc2) - acc) <= 1e-6, (float(acc2), acc)
+    assert labels == 'shuffled' or 0.15 < acc < 1.0            # (shuffled labels: chance level - the label tensor is what is being tested)
+    assert float((da - a.grad).abs().max()) <= 1e-5 * float(a.grad.abs().max()) + 1e-8
+    assert float((db - b.grad).abs().max()) <= 1e-5 * float(b.grad.abs().max()) + 1e-8
+    assert abs(float(dt) - float(t.grad)) <= 1e-4 * abs(float(t.grad)) + 1e-7
+    again = run()
+    for x, y in zip((l2, acc2, lg2, da, db, dt), again):
+        assert torch.equal(x, y)
+    assert int(ops._ticket(torch.device('cuda', torch.cuda.current_device())).abs().sum()) == 0
+
+
+def test_train_step_fused_head_equals_the_three_reference_lines():
+    """train_meta.train_step through model.forward_loss (fused head + CE + accuracy) vs logits -> F.cross_entropy / compute_acc through ATen: same loss,
+    accuracy and parameters after one parity-mode step."""
+    import copy
+    from fewshot_vit_amd import models, synthetic, train_meta, utils
+    from fewshot_vit_amd.utils import few_shot as fs
+    m0 = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={'drop_path_rate': 0.0, 'numerics': 'parity'})
+    shapes = {k: tuple(v.shape) for k, v in m0.state_dict().items()}
+    m0.load_state_dict(synthetic.synthetic_checkpoint_sd(shapes))
+    E, way, shot, query = 2, 5, 1, 3
+    x = synthetic.synthetic_episodes(3, E, way, shot, query).cuda()
+    x_shot, x_query = fs.split_shot_query(x, way, shot, query, E)
+    label = fs.make_nk_label(way, query, E).cuda()
+    outs = []
+    for fused in (True, False):
+        m = copy.deepcopy(m0).cuda().train()
+        opt, _ = utils.make_optimizer(m.parameters(), 'sgd', lr=0.01, weight_decay=5e-4)
+        train_meta._FUSED_CE = fused
+        try:
+            loss, acc = train_meta.train_step(m, opt, x_shot, x_query, label, way)
+        finally:
+            train_meta._FUSED_CE = True
+        outs.append((loss, acc, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}))
+    (l0, a0, s0), (l1, a1, s1) = outs
+    assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l1)) and abs(a0 - a1) <= 1e-6
+    for k in s0:
+        if s0[k].dtype.is_floating_point:
+            assert float((s0[k] - s1[k]).abs().max()) <= 2e-6 * max(1e-3, float(s1[k].abs().max())), k
+
+
 def test_sgd_step_matches_torch_optim():
     """torch.optim.SGD(momentum=0.9, weight_decay) semantics of utils.make_optimizer (utils/__init__.py:128-132)."""
     from fewshot_vit_amd.engine import ops

@@ -15,6 +15,8 @@ def short(name):
             pass
     name = re.sub(r'\[clone[^\]]*\]', '', name)
     name = re.sub(r'^void ', '', name)
+    if name.startswith('at::native::'):       # ATen kernels: keep the functor names (what the launch was for)
+        return re.sub(r'\(anonymous namespace\)::|at::native::|std::array<char\*,\d+ul> ?', '', name).replace(', ', ',')[:110]
     m = re.match(r'(?:fsvit::)?(?:\(anonymous namespace\)::)?([A-Za-z0-9_:]+(?:<[^(]*>)?)', name)
     return (m.group(1) if m else name).replace(', ', ',')[:110]
 
