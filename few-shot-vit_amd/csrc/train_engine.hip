@@ -108,10 +108,18 @@ struct fsvit_visformer_trainer {
   // Side stream of the backward pass: the direct weight-gradient kernels (wgrad3x3 / wgrad1x1) have no consumer before the end of the pass, so they
   // run on a second HIP stream next to the data-gradient / BatchNorm chain (launch tails and HBM-bound elementwise passes overlap with them).
   // `pend` = the byte ranges pending side launches still READ; a main-stream launch that writes into one of them first waits for the side stream.
-  hipStream_t side = nullptr;
+  // Two side streams (FSVIT_SIDE_STREAMS = 1 .. 4): side launch i goes to stream i % n (each stream in order), so that the weight gradients of two
+  // layers overlap each other as well - with that, half as many row splits per launch (wgrad1x1_splits: 128 workgroups instead of 256) fill the
+  // chip, and the split slabs written by the kernels and read by the finalize pass halve (2.2 GB each way per step): 13.69 -> 13.47 ms per
+  // 800-image step on one box (1 x 256: 13.69, 2 x 256: 13.80, 2 x 128: 13.47, 3 x 128: 13.59, 3 x 96: 13.53, 4 x 128: 14.10, 4 x 64: 14.01).
+  static constexpr int MAX_SIDE = 4;
+  hipStream_t sides[MAX_SIDE] = {nullptr, nullptr, nullptr, nullptr};
+  int n_side = 1;
+  hipStream_t side = nullptr;             // the stream of the side launch being issued (side_begin)
   hipEvent_t ev_a = nullptr;
-  std::vector<hipEvent_t> ev_done;        // one per side launch of a pass (recorded behind it; the side stream runs in order)
+  std::vector<hipEvent_t> ev_done;        // one per side launch of a pass (recorded behind it; a side stream runs in order)
   int side_seq = 0;                       // side launches of this pass so far
+  int side_waited[MAX_SIDE] = {-1, -1, -1, -1};       // per side stream: the youngest launch the main stream has already waited for
   // default: on (ViT / DeiT trainer: 19.2 -> 17.6 ms per 200-image DeiT-S step; Visformer trainer: nothing in round 3 - 16.55 vs 16.67 ms -, 14.26 -> 14.15 ms
   // once round 4 had taken HBM-bound passes out of the main stream); FSVIT_WGRAD_SIDE_STREAM=0 / 1 forces it
   bool side_on = false;
@@ -120,7 +128,7 @@ struct fsvit_visformer_trainer {
   ~fsvit_visformer_trainer() {
     if (ev_a) (void)hipEventDestroy(ev_a);
     for (hipEvent_t e : ev_done) (void)hipEventDestroy(e);
-    if (side) (void)hipStreamDestroy(side);
+    for (hipStream_t q : sides) if (q) (void)hipStreamDestroy(q);
   }
 };
 
@@ -264,10 +272,13 @@ int conv_bwd_data(TR* t, const ConvSpec& c, const void* dz, int B, int OH, int O
 
 // ---------------------------------------------------------------- side stream of the backward pass
 int side_begin(TR* t) {                       // the side stream may start once everything queued on the main stream so far is done
-  if (!t->side) {
-    T_TRY((int)hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+  if (!t->sides[0]) {
+    static const int n = [] { const char* e = getenv("FSVIT_SIDE_STREAMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > TR::MAX_SIDE ? TR::MAX_SIDE : v); }();
+    t->n_side = n;
+    for (int i = 0; i < n; ++i) T_TRY((int)hipStreamCreateWithFlags(&t->sides[i], hipStreamNonBlocking));
     T_TRY((int)hipEventCreateWithFlags(&t->ev_a, hipEventDisableTiming));
   }
+  t->side = t->sides[t->side_seq % t->n_side];
   T_TRY((int)hipEventRecord(t->ev_a, t->st));
   T_TRY((int)hipStreamWaitEvent(t->side, t->ev_a, 0));
   return 0;
@@ -287,7 +298,13 @@ int side_end(TR* t, const void* p0, size_t b0, const void* p1, size_t b1) {
 }
 // the main stream waits for the side launches up to `seq` (the side stream is in order) and forgets their ranges
 int side_wait(TR* t, int seq) {
-  T_TRY((int)hipStreamWaitEvent(t->st, t->ev_done[seq], 0));
+  for (int q = 0; q < t->n_side; ++q) {        // per side stream: its youngest launch <= seq (the stream runs in order), unless already waited for
+    const int i = seq - ((seq - q) % t->n_side + t->n_side) % t->n_side;
+    if (i >= 0 && i > t->side_waited[q]) {
+      T_TRY((int)hipStreamWaitEvent(t->st, t->ev_done[i], 0));
+      t->side_waited[q] = i;
+    }
+  }
   size_t k = 0;
   for (size_t i = 0; i < t->pend.size(); ++i)
     if (t->pend[i].seq > seq) t->pend[k++] = t->pend[i];
@@ -1197,6 +1214,7 @@ extern "C" int fsvit_vit_train_backward(fsvit_vit_trainer* t, const fsvit_param*
   t->save.off = t->save_after_forward;            // the pass's weight-gradient slabs are appended to the saved activations
   t->fin.clear();
   t->side_seq = 0; t->pend.clear();
+  for (int& v : t->side_waited) v = -1;
   return vit_backward_impl(t, dfeat_dev);
 }
 
@@ -1309,6 +1327,7 @@ extern "C" int fsvit_visformer_train_backward(fsvit_visformer_trainer* t, const 
   t->save.off = t->save_after_forward;            // the pass's weight-gradient slabs are appended to the saved activations
   t->fin.clear();
   t->side_seq = 0; t->pend.clear();
+  for (int& v : t->side_waited) v = -1;
   return train_backward_impl(t, dfeat_dev);
 }
 

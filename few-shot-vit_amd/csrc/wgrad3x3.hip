@@ -613,8 +613,8 @@ int wgrad1x1_splits(int N, int C, int M) {
   wgrad1x1_tile(N, C, &NT, &CT);
   const int n_chunks = (M + wg3::CH - 1) / wg3::CH;
   const int tiles = ((N + NT - 1) / NT) * ((C + CT - 1) / CT);
-  static const int target = [] { const char* e = getenv("FSVIT_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
-  int s = (target + tiles - 1) / tiles;        // ~one workgroup per CU: the partial slabs (N x C x 4 B per split) are written and summed once each
+  static const int target = [] { const char* e = getenv("FSVIT_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+  int s = (target + tiles - 1) / tiles;        // 128 workgroups per launch (two launches run side by side, train_engine.hip): the partial slabs (N x C x 4 B per split) are written and summed once each
   if (s > n_chunks) s = n_chunks;
   if (s < 1) s = 1;
   const int cpw = (n_chunks + s - 1) / s;
