@@ -1050,13 +1050,14 @@ extern "C" int fsvit_gconv3x3(const void* x, const void* w_packed, int Kw, void*
 extern "C" int fsvit_conv1x1_wgrad(const void* x, const void* dz, float* dw, int M, int N, int C, int dtype, void* stream) {
   const int kdt = dtype;
   if (!x || !dz || !dw || M <= 0) return fail(FSVIT_ERR_ARG, "bad argument");
-  if (dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "fsvit_conv1x1_wgrad: 16-bit storage only (bf16 / f16)");
-  if (!K(wgrad1x1_supported)(1, N, C)) return fail(FSVIT_ERR_ARG, "fsvit_conv1x1_wgrad: N and C must be multiples of 8");
+  if (dtype != FSVIT_BF16 && dtype != FSVIT_F16 && !is_x2(dtype))
+    return fail(FSVIT_ERR_ARG, "fsvit_conv1x1_wgrad: bf16 / f16 rows, or fp32 rows with two-limb arithmetic (FSVIT_BF16X2 / FSVIT_F16X2)");
+  if (!K(wgrad1x1_supported)(kg(dtype), N, C)) return fail(FSVIT_ERR_ARG, "fsvit_conv1x1_wgrad: N and C must be multiples of 8");
   hipStream_t st = (hipStream_t)stream;
-  const int splits = K(wgrad1x1_splits)(N, C, M), Kc_pad = (C + 3) / 4 * 4;
+  const int splits = K(wgrad1x1_splits)(N, C, M, kg(dtype)), Kc_pad = (C + 3) / 4 * 4;
   void* ysp = nullptr;
   HIP_TRY(hipMalloc(&ysp, (size_t)((N + 3) / 4 * 4) * splits * Kc_pad * 4));
-  int rc = K(launch_wgrad1x1)(x, C, C, dz, N, N, (float*)ysp, M, Kc_pad, st);
+  int rc = K(launch_wgrad1x1)(x, C, C, dz, N, N, (float*)ysp, M, Kc_pad, st, kg(dtype));
   if (rc == 0) rc = fsvit::launch_wgrad_finalize((const float*)ysp, dw, N, C, 1, 1, 0, splits, Kc_pad, 1, 1, 1, 1, st);
   (void)hipStreamSynchronize(st);
   (void)hipFree(ysp);

@@ -350,14 +350,15 @@ int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W
     if (!t->save.dry) t->fin.push_back(FinJob{scratch, w->grad, 3, 0, c.Ig, 3, 3, c.groups == 8 ? 1 : 0, d[1], d[0], 1, 1, 1, 1});
     return 0;
   }
-  if ((c.via_patches || (c.KH == 1 && c.KW == 1 && c.stride == 1 && c.groups == 1)) && wgrad1x1_supported(t->dtype, rows, Cin_tot)) {
+  const int wdt = t->gdt == 2 ? 2 : t->dtype;          // the direct weight-gradient kernels: 16-bit rows, or fp32 rows with two-limb arithmetic
+  if ((c.via_patches || (c.KH == 1 && c.KW == 1 && c.stride == 1 && c.groups == 1)) && wgrad1x1_supported(wdt, rows, Cin_tot)) {
     // direct kernel on the row-major operands (x [M][Cin_tot] - or the 32-wide patch rows - and dz [M][rows]); the finalize pass is the round-1 one
-    const int splits = wgrad1x1_splits(rows, Cin_tot, M);
+    const int splits = wgrad1x1_splits(rows, Cin_tot, M, wdt);
     float* ysp = (float*)t->save.take((size_t)round_up(rows, 4) * splits * Kc_pad * 4);
     if (!ysp) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (wgrad1x1)");
     const bool on_side = t->side_on && !t->save.dry;
     if (on_side) T_TRY(side_begin(t));
-    T_RUN(launch_wgrad1x1(x, Cin_tot, Cin_tot, dz, rows, rows, ysp, M, Kc_pad, on_side ? t->side : t->st));
+    T_RUN(launch_wgrad1x1(x, Cin_tot, Cin_tot, dz, rows, rows, ysp, M, Kc_pad, on_side ? t->side : t->st, wdt));
     if (on_side) T_TRY(side_end(t, x, (size_t)M * Cin_tot * t->es, dz, (size_t)M * rows * t->es));
     const int KHf = c.via_patches ? 3 : c.KH, KWf = c.via_patches ? 3 : c.KW;
     const bool fast = KHf == 1 && KWf == 1 && c.hd_rows == c.hdp_rows && c.hd_cols == c.hdp_cols && (c.Ig & 3) == 0 && (Kc_pad & 3) == 0;

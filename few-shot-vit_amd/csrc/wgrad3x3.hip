@@ -601,16 +601,149 @@ __global__ __launch_bounds__(512) void wgrad1x1_kernel(const bf16* __restrict__ 
     }
 }
 
+// ---- the same for the two-limb trainers (`bf16x2` / `f16x2`: fp32 storage).  x and dz are fp32 rows; the limb split happens on the way into LDS:
+// row m of a chunk becomes TWO 16-bit rows, 2 m = lo(m, :) and 2 m + 1 = hi(m, :) (x2_split: hi = the leading bits, lo = the rounded remainder), so the
+// transposing read hands every lane 32-bit words (lo, hi) of ONE value - the k-slot order of conv_gemm_v2's two-limb arithmetic - and a 16-value k step is
+// two MFMAs: (a, b) sums lo lo + hi hi, (a, b with its halves swapped) the cross terms.  No transposed / limb-packed copies of dz and x in HBM
+// (round 3 route: transpose_cols + im2col_t + a limb GEMM, 12 ms of the 57 ms step in transposes alone).
+template <int NT, int CT>
+__global__ __launch_bounds__(512) void wgrad1x1_x2_kernel(const float* __restrict__ x, int xld, int C, const float* __restrict__ dz, int zld, int N,
+                                                          float* __restrict__ y, int M, int n_chunks, int chunks_per_wg, int splits, int Kc_pad) {
+  using namespace wg3;
+  constexpr int WN = NT / 4, WC = CT / 2;
+  constexpr int TN = WN / 16, TC = WC / 16;
+  constexpr int SUB = 2 * CH * 32 + 32;                            // a 16-column subtile of 2 CH limb rows (+ 32: see wgrad1x1_kernel)
+  constexpr int ZT_BYTES = (NT / 16) * SUB;
+  constexpr int NPZ = (CH * NT / 8) / 512, NPX = (CH * CT / 8) / 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const ZT = smem;
+  unsigned char* const XT = smem + ZT_BYTES;
+  const int t = threadIdx.x, lane = t & 63, i = lane & 15, lq = lane >> 4;
+  const int j = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wn = j & 3, wc = j >> 2;
+  const int n0 = blockIdx.y * NT, c0 = blockIdx.z * CT;
+  const int q0 = blockIdx.x * chunks_per_wg;
+  int q1 = q0 + chunks_per_wg; q1 = q1 < n_chunks ? q1 : n_chunks;
+
+  u32x4 pz[NPZ][2], px[NPX][2];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto gload = [&](int q) {
+    const long m0 = (long)q * CH;
+#pragma unroll
+    for (int u0 = 0; u0 < NPZ; ++u0) {
+      const int u = t + 512 * u0, r = u / (NT / 8), c8 = u % (NT / 8);
+      const long m = m0 + r;
+      const bool ok = m < M && n0 + c8 * 8 < N;
+      const float* src = dz + (size_t)(ok ? m : 0) * zld + (ok ? n0 + c8 * 8 : 0);
+      pz[u0][0] = ok ? *reinterpret_cast<const u32x4*>(src) : zero4;
+      pz[u0][1] = ok ? *reinterpret_cast<const u32x4*>(src + 4) : zero4;
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < NPX; ++u0) {
+      const int u = t + 512 * u0, r = u / (CT / 8), c8 = u % (CT / 8);
+      const long m = m0 + r;
+      const bool ok = m < M && c0 + c8 * 8 < C;
+      const float* src = x + (size_t)(ok ? m : 0) * xld + (ok ? c0 + c8 * 8 : 0);
+      px[u0][0] = ok ? *reinterpret_cast<const u32x4*>(src) : zero4;
+      px[u0][1] = ok ? *reinterpret_cast<const u32x4*>(src + 4) : zero4;
+    }
+  };
+  // 8 fp32 values -> their 8 lo limbs and 8 hi limbs, packed in column order
+  auto limbs8 = [&](const u32x4 a, const u32x4 b, u32x4& lo, u32x4& hi) {
+    u32x4 sa, sb, r_;
+    x2_split(a, sa, r_);
+    x2_split(b, sb, r_);
+    lo = u32x4{__builtin_amdgcn_perm(sa[1], sa[0], 0x05040100u), __builtin_amdgcn_perm(sa[3], sa[2], 0x05040100u),
+               __builtin_amdgcn_perm(sb[1], sb[0], 0x05040100u), __builtin_amdgcn_perm(sb[3], sb[2], 0x05040100u)};
+    hi = u32x4{__builtin_amdgcn_perm(sa[1], sa[0], 0x07060302u), __builtin_amdgcn_perm(sa[3], sa[2], 0x07060302u),
+               __builtin_amdgcn_perm(sb[1], sb[0], 0x07060302u), __builtin_amdgcn_perm(sb[3], sb[2], 0x07060302u)};
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int u0 = 0; u0 < NPZ; ++u0) {
+      const int u = t + 512 * u0, r = u / (NT / 8), c8 = u % (NT / 8);
+      u32x4 lo, hi;
+      limbs8(pz[u0][0], pz[u0][1], lo, hi);
+      unsigned char* d = ZT + (c8 >> 1) * SUB + (2 * r) * 32 + (c8 & 1) * 16;
+      *reinterpret_cast<u32x4*>(d) = lo;
+      *reinterpret_cast<u32x4*>(d + 32) = hi;
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < NPX; ++u0) {
+      const int u = t + 512 * u0, r = u / (CT / 8), c8 = u % (CT / 8);
+      u32x4 lo, hi;
+      limbs8(px[u0][0], px[u0][1], lo, hi);
+      unsigned char* d = XT + (c8 >> 1) * SUB + (2 * r) * 32 + (c8 & 1) * 16;
+      *reinterpret_cast<u32x4*>(d) = lo;
+      *reinterpret_cast<u32x4*>(d + 32) = hi;
+    }
+  };
+  f32x4 acc[TN][TC];
+#pragma unroll
+  for (int a = 0; a < TN * TC; ++a) acc[a / TC][a % TC] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const unsigned lane_off = (lq * 4 + (i >> 2)) * 32 + (i & 3) * 8;
+  const unsigned zt_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ZT + (wn * TN) * SUB + lane_off;
+  const unsigned xt_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)XT + (wc * TC) * SUB + lane_off;
+  auto tr = [&](unsigned addr) -> u32x2 {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(size_t)addr));
+  };
+
+  if (q0 < q1) gload(q0);
+  for (int q = q0; q < q1; ++q) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (q + 1 < q1) gload(q + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {                               // 32 limb rows = 16 fp32 rows per step
+      u32x4 af[TN];
+#pragma unroll
+      for (int k4 = 0; k4 < TN; ++k4) {
+        const u32x2 a1 = tr(zt_lane + k4 * SUB + ks * 1024), a2 = tr(zt_lane + k4 * SUB + ks * 1024 + 512);
+        af[k4] = u32x4{a1[0], a1[1], a2[0], a2[1]};
+      }
+#pragma unroll
+      for (int ct = 0; ct < TC; ++ct) {
+        const u32x2 b1 = tr(xt_lane + ct * SUB + ks * 1024), b2 = tr(xt_lane + ct * SUB + ks * 1024 + 512);
+        const u32x4 bf = {b1[0], b1[1], b2[0], b2[1]};
+        u32x4 br;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) br[e] = __builtin_amdgcn_alignbit(bf[e], bf[e], 16);
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          acc[nt][ct] = mma_chunk<bf16>(af[nt], br, acc[nt][ct]);      // the cross terms first, hi hi + lo lo last (as conv_gemm_v2)
+          acc[nt][ct] = mma_chunk<bf16>(af[nt], bf, acc[nt][ct]);
+        }
+      }
+    }
+  }
+  const size_t ldy = (size_t)splits * Kc_pad;
+#pragma unroll
+  for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = n0 + wn * WN + nt * 16 + lq * 4 + e;
+      if (n < N) {
+#pragma unroll
+        for (int ct = 0; ct < TC; ++ct) {
+          const int c = c0 + wc * WC + ct * 16 + i;
+          if (c < C) y[(size_t)n * ldy + (size_t)blockIdx.x * Kc_pad + c] = acc[nt][ct][e];
+        }
+      }
+    }
+}
+
 bool wgrad1x1_supported(int dtype, int N, int C) {
   static const bool off = [] { const char* e = getenv("FSVIT_WGRAD1X1"); return e && e[0] == '0'; }();
-  return !off && dtype == 1 && (N % 8) == 0 && (C % 8) == 0;
+  return !off && (dtype == 1 || dtype == 2) && (N % 8) == 0 && (C % 8) == 0;      // dtype 2: the two-limb kernel on fp32 rows
 }
 // block shape per layer: 256 along a dimension that has >= 256 columns, else 128 (wave blocks 64 / 32 rows x 128 / 64 columns)
-static void wgrad1x1_tile(int N, int C, int* NT, int* CT) { *NT = N >= 256 ? 256 : 128; *CT = C >= 256 ? 256 : 128; }
+// (two-limb kernel, dtype 2: 256 x 128 at most - the fp32 staging registers of a 256 x 256 block spill)
+static void wgrad1x1_tile(int N, int C, int* NT, int* CT, int dtype) { *NT = N >= 256 ? 256 : 128; *CT = (C >= 256 && !(dtype == 2 && *NT == 256)) ? 256 : 128; }
 // number of row splits (= partial slabs of Y) the launch will use
-int wgrad1x1_splits(int N, int C, int M) {
+int wgrad1x1_splits(int N, int C, int M, int dtype) {
   int NT, CT;
-  wgrad1x1_tile(N, C, &NT, &CT);
+  wgrad1x1_tile(N, C, &NT, &CT, dtype);
   const int n_chunks = (M + wg3::CH - 1) / wg3::CH;
   const int tiles = ((N + NT - 1) / NT) * ((C + CT - 1) / CT);
   static const int target = [] { const char* e = getenv("FSVIT_WGRAD_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
@@ -620,17 +753,27 @@ int wgrad1x1_splits(int N, int C, int M) {
   const int cpw = (n_chunks + s - 1) / s;
   return (n_chunks + cpw - 1) / cpw;
 }
-int launch_wgrad1x1(const void* x, int xld, int C, const void* dz, int zld, int N, float* y, int M, int Kc_pad, hipStream_t s) {
+int launch_wgrad1x1(const void* x, int xld, int C, const void* dz, int zld, int N, float* y, int M, int Kc_pad, hipStream_t s, int dtype) {
   int NT, CT;
-  wgrad1x1_tile(N, C, &NT, &CT);
+  wgrad1x1_tile(N, C, &NT, &CT, dtype);
   const int n_chunks = (M + wg3::CH - 1) / wg3::CH;
-  const int splits = wgrad1x1_splits(N, C, M);
+  const int splits = wgrad1x1_splits(N, C, M, dtype);
   const int cpw = (n_chunks + splits - 1) / splits;
   const dim3 grid(splits, (N + NT - 1) / NT, (C + CT - 1) / CT);
 #define WG1_LAUNCH(A, B) do { const int lds = ((A) / 16 + (B) / 16) * (wg3::CH * 32 + 32);                                                                  \
     hipError_t e = hipFuncSetAttribute((const void*)wgrad1x1_kernel<A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                            \
     if (e != hipSuccess) return (int)e;                                                                                                                  \
     hipLaunchKernelGGL((wgrad1x1_kernel<A, B>), grid, dim3(512), lds, s, (const bf16*)x, xld, C, (const bf16*)dz, zld, N, y, M, n_chunks, cpw, splits, Kc_pad); } while (0)
+#define WG1X_LAUNCH(A, B) do { const int lds = ((A) / 16 + (B) / 16) * (2 * wg3::CH * 32 + 32);                                                             \
+    hipError_t e = hipFuncSetAttribute((const void*)wgrad1x1_x2_kernel<A, B>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                         \
+    if (e != hipSuccess) return (int)e;                                                                                                                  \
+    hipLaunchKernelGGL((wgrad1x1_x2_kernel<A, B>), grid, dim3(512), lds, s, (const float*)x, xld, C, (const float*)dz, zld, N, y, M, n_chunks, cpw, splits, Kc_pad); } while (0)
+  if (dtype == 2) {
+    if (NT == 256) WG1X_LAUNCH(256, 128);
+    else if (CT == 256) WG1X_LAUNCH(128, 256);
+    else WG1X_LAUNCH(128, 128);
+    return (int)hipGetLastError();
+  }
   if (NT == 256 && CT == 256) WG1_LAUNCH(256, 256);
   else if (NT == 256) WG1_LAUNCH(256, 128);
   else if (CT == 256) WG1_LAUNCH(128, 256);

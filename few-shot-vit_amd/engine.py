@@ -732,16 +732,16 @@ class ops:
         return ds, dq, dt.sum()
 
     @staticmethod
-    def conv1x1_wgrad(x, dz):
-        """x [M,C], dz [M,N] (bf16 / fp16) -> dW [N,C] fp32 (fsvit_conv1x1_wgrad)."""
+    def conv1x1_wgrad(x, dz, limbs='bf16'):
+        """x [M,C], dz [M,N] (bf16 / fp16, or fp32 = two-limb arithmetic with `limbs` 'bf16' / 'f16') -> dW [N,C] fp32 (fsvit_conv1x1_wgrad)."""
         _require_cuda(x, dz)
         lib = _lib.load()
-        assert x.dtype == dz.dtype and x.dtype in (torch.bfloat16, torch.float16) and x.shape[0] == dz.shape[0]
+        assert x.dtype == dz.dtype and x.dtype in (torch.bfloat16, torch.float16, torch.float32) and x.shape[0] == dz.shape[0]
         x, dz = x.contiguous(), dz.contiguous()
         dw = torch.empty(dz.shape[1], x.shape[1], dtype=torch.float32, device=x.device)
+        dt = {torch.bfloat16: _lib.BF16, torch.float16: _lib.F16, torch.float32: _lib.BF16X2 if limbs == 'bf16' else _lib.F16X2}[x.dtype]
         with torch.cuda.device(x.device):
-            _lib.check(lib.fsvit_conv1x1_wgrad(_ptr(x), _ptr(dz), _ptr(dw), x.shape[0], dz.shape[1], x.shape[1],
-                                               _lib.BF16 if x.dtype == torch.bfloat16 else _lib.F16, _stream_ptr(x.device)))
+            _lib.check(lib.fsvit_conv1x1_wgrad(_ptr(x), _ptr(dz), _ptr(dw), x.shape[0], dz.shape[1], x.shape[1], dt, _stream_ptr(x.device)))
         return dw
 
     @staticmethod

@@ -372,7 +372,8 @@ int fsvit_conv3x3_wgrad(const void* x_dev, const void* dz_dev, float* dw_dev, in
 int fsvit_gconv3x3(const void* x_dev, const void* w_packed_dev, int Kw, void* y_dev, int B, int H, int W, int dtype, void* stream);
 
 /* Weight gradient of a 1x1 convolution / Linear from the row-major activations: dw[N][C] (fp32, overwritten) = sum_m dz[m][n] * x[m][c].
- * x [M][C], dz [M][N], dtype FSVIT_BF16 / FSVIT_F16, N and C multiples of 8.  (conv1 / conv3 of the Mlps, qkv, proj in train_meta.py:228-232.) */
+ * x [M][C], dz [M][N], dtype FSVIT_BF16 / FSVIT_F16 (16-bit rows) or FSVIT_BF16X2 / FSVIT_F16X2 (fp32 rows, split into two 16-bit limbs on the way into
+ * LDS: the two-limb trainers' kernel); N and C multiples of 8.  (conv1 / conv3 of the Mlps, qkv, proj in train_meta.py:228-232.) */
 int fsvit_conv1x1_wgrad(const void* x_dev, const void* dz_dev, float* dw_dev, int M, int N, int C, int dtype, void* stream);
 
 int fsvit_attention_backward(const void* qkv_dev, const void* dctx_dev, void* dqkv_dev, int B, int S, int heads, int hd, int hdp,

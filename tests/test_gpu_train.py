@@ -548,6 +548,26 @@ def test_conv1x1_wgrad_direct_vs_torch(shape, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(8000, 1024, 256), (2000, 864, 256), (2000, 512, 576), (5000, 128, 32), (777, 256, 128), (64, 1728, 512), (130, 8, 8)])
+@pytest.mark.parametrize('limbs', ['bf16', 'f16'])
+def test_conv1x1_wgrad_two_limb_vs_fp64(shape, limbs):
+    """fsvit_conv1x1_wgrad on fp32 rows (FSVIT_BF16X2 / FSVIT_F16X2: the limb split at LDS staging, two MFMAs per 16 values) vs dz^T @ x in fp64 on
+    the UNROUNDED fp32 operands: the two-limb product carries 16 (bf16 limbs) / 22 (f16 limbs) significand bits."""
+    from fewshot_vit_amd.engine import ops
+    M, N, C = shape
+    g = torch.Generator().manual_seed(M + N + C + 1)
+    x = torch.randn(M, C, generator=g)
+    dz = torch.randn(M, N, generator=g) * 0.1
+    ref = dz.double().t() @ x.double()
+    got = ops.conv1x1_wgrad(x.cuda(), dz.cuda(), limbs).cpu().double()
+    err = (got - ref).abs().max().item()
+    scale = (dz.double().abs().t() @ x.double().abs()).max().item()            # sum of |products|: what a relative operand error multiplies
+    print(f'conv1x1_wgrad two-limb {shape} {limbs}: max err {err:.3e} (sum |products| {scale:.1f})')
+    assert err <= (3e-5 if limbs == 'bf16' else 2e-6) * scale
+    assert torch.equal(got, ops.conv1x1_wgrad(x.cuda(), dz.cuda(), limbs).cpu().double())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(3, 20, 20), (1, 12, 16), (7, 20, 20), (2, 5, 7)])
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_gconv3x3_vs_torch(shape, dtype):
