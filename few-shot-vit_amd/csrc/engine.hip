@@ -1026,12 +1026,13 @@ extern "C" int fsvit_stage1_block_hw(const void* x, void* y, const void* w1, con
 extern "C" int fsvit_conv3x3_wgrad(const void* x, const void* dz, float* dw, int B, int H, int W, int O, int Ig, int groups, int dtype, void* stream) {
   const int kdt = dtype;
   if (!x || !dz || !dw) return fail(FSVIT_ERR_ARG, "null argument");
-  if (dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "fsvit_conv3x3_wgrad: 16-bit storage only (bf16 / f16)");
-  if (!K(wgrad3x3_supported)(1, O, Ig, groups, W)) return fail(FSVIT_ERR_ARG, "fsvit_conv3x3_wgrad: built for 8 groups of 32 -> 32 channels (W <= 20) and dense 64 / 128 -> 128 (W <= 40)");
+  if (dtype != FSVIT_BF16 && dtype != FSVIT_F16 && !is_x2(dtype))
+    return fail(FSVIT_ERR_ARG, "fsvit_conv3x3_wgrad: bf16 / f16 activations, or fp32 activations with two-limb arithmetic (FSVIT_BF16X2 / FSVIT_F16X2)");
+  if (!K(wgrad3x3_supported)(kg(dtype), O, Ig, groups, W)) return fail(FSVIT_ERR_ARG, "fsvit_conv3x3_wgrad: built for 8 groups of 32 -> 32 channels (W <= 20) and dense 64 / 128 -> 128 (W <= 40)");
   hipStream_t st = (hipStream_t)stream;
   void* scratch = nullptr;
-  HIP_TRY(hipMalloc(&scratch, K(wgrad3x3_scratch_bytes)(O, Ig, groups, B * H * W)));
-  int rc = K(launch_wgrad3x3)(x, groups * Ig, dz, O, dw, (float*)scratch, B, H, W, O, Ig, groups, st, nullptr);
+  HIP_TRY(hipMalloc(&scratch, K(wgrad3x3_scratch_bytes)(O, Ig, groups, B * H * W, kg(dtype))));
+  int rc = K(launch_wgrad3x3)(x, groups * Ig, dz, O, dw, (float*)scratch, B, H, W, O, Ig, groups, st, nullptr, kg(dtype));
   (void)hipStreamSynchronize(st);
   (void)hipFree(scratch);
   if (rc != 0) return hipfail((hipError_t)rc, "fsvit_conv3x3_wgrad");

@@ -338,19 +338,19 @@ int conv_bwd_weight(TR* t, const ConvSpec& c, const void* x, int B, int H, int W
   const int rows = c.groups * c.rows_fwd();                                     // all output channels (padded)
   const int Cin_tot = c.via_patches ? 32 : c.groups * (c.kpad_cols() / (c.KH * c.KW));
   const int Kc_pad = c.via_patches ? 32 : round_up(c.KH * c.KW * Cin_tot, 4);
-  if (!c.via_patches && c.KH == 3 && c.KW == 3 && c.stride == 1 && c.pad == 1 && wgrad3x3_supported(t->dtype, c.O, c.Ig, c.groups, W)) {
+  const int wdt = t->gdt == 2 ? 2 : t->dtype;          // the direct weight-gradient kernels: 16-bit rows, or fp32 rows with two-limb arithmetic
+  if (!c.via_patches && c.KH == 3 && c.KW == 3 && c.stride == 1 && c.pad == 1 && wgrad3x3_supported(wdt, c.O, c.Ig, c.groups, W)) {
     // direct kernel: no transposed copies of dz / im2col(x) (wgrad3x3.hip)
-    float* scratch = (float*)t->save.take(wgrad3x3_scratch_bytes(c.O, c.Ig, c.groups, M));
+    float* scratch = (float*)t->save.take(wgrad3x3_scratch_bytes(c.O, c.Ig, c.groups, M, wdt));
     if (!scratch) return fsvit_set_error(FSVIT_ERR_WORKSPACE, "training workspace too small (wgrad3x3)");
     int d[2] = {0, 0};
     const bool on_side = t->side_on && !t->save.dry;
     if (on_side) T_TRY(side_begin(t));
-    T_RUN(launch_wgrad3x3(x, Cin_tot, dz, rows, w->grad, scratch, B, H, W, c.O, c.Ig, c.groups, on_side ? t->side : t->st, d));
+    T_RUN(launch_wgrad3x3(x, Cin_tot, dz, rows, w->grad, scratch, B, H, W, c.O, c.Ig, c.groups, on_side ? t->side : t->st, d, wdt));
     if (on_side) T_TRY(side_end(t, x, (size_t)M * Cin_tot * t->es, dz, (size_t)M * rows * t->es));
     if (!t->save.dry) t->fin.push_back(FinJob{scratch, w->grad, 3, 0, c.Ig, 3, 3, c.groups == 8 ? 1 : 0, d[1], d[0], 1, 1, 1, 1});
     return 0;
   }
-  const int wdt = t->gdt == 2 ? 2 : t->dtype;          // the direct weight-gradient kernels: 16-bit rows, or fp32 rows with two-limb arithmetic
   if ((c.via_patches || (c.KH == 1 && c.KW == 1 && c.stride == 1 && c.groups == 1)) && wgrad1x1_supported(wdt, rows, Cin_tot)) {
     // direct kernel on the row-major operands (x [M][Cin_tot] - or the 32-wide patch rows - and dz [M][rows]); the finalize pass is the round-1 one
     const int splits = wgrad1x1_splits(rows, Cin_tot, M, wdt);

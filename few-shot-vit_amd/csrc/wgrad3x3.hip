@@ -175,6 +175,178 @@ __global__ __launch_bounds__(512) void wgrad3x3_kernel(const bf16* __restrict__ 
         for (int e = 0; e < 4; ++e) out[(tp * 32 + nt * 16 + lq * 4 + e) * 32 + ct * 16 + i] = acc[tp][nt][ct][e];
 }
 
+// ---- the same kernel for the two-limb trainers (fp32 activations, `bf16x2` / `f16x2`): a row of dz / a pixel of x becomes two 16-bit LDS rows
+// (2 r = its lo limbs, 2 r + 1 = its hi limbs; see wgrad1x1_x2_kernel), a tap shifts by 2 rows per pixel, and a 16-row K step is two MFMAs per
+// accumulator tile.  CHX = rows per stage: 64 for the dense layers, 32 for the grouped one (its 256-column window would not fit twice).
+template <int NC, int CC, int MAXW, int CHX>
+__global__ __launch_bounds__(512) void wgrad3x3_x2_kernel(const float* __restrict__ x, int xld, const float* __restrict__ dz, int zld, float* __restrict__ part,
+                                                          int M, int H, int W, int n_chunks, int chunks_per_wg) {
+  using namespace wg3;
+  constexpr int WINP = CHX + 2 * (MAXW + 1) + 3;
+  constexpr int ZSUB = 2 * CHX * 32, XSUB = 2 * WINP * 32;     // subtile pitches (limb rows)
+  constexpr int ZT_BYTES = (NC / 16) * ZSUB;
+  constexpr int XW_BYTES = (CC / 16) * XSUB;
+  constexpr int NPZ = (CHX * NC / 8) / 512;
+  constexpr int NPX = (WINP * (CC / 8) + 511) / 512;
+  static_assert(NPZ + NPX <= 32, "validity bits");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const ZT = smem;
+  unsigned char* const XW = smem + ZT_BYTES;
+  unsigned char* const ZERO = smem + ZT_BYTES + XW_BYTES;      // a zero row (32 B) here and another one subtile pitch further
+
+  const int t = threadIdx.x, lane = t & 63, i = lane & 15, lq = lane >> 4;
+  const int j = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nb = NC == 256 ? j : (j & 3), cb = NC == 256 ? j : (j >> 2);
+  const int xc0 = NC == 256 ? 0 : blockIdx.y * CC;
+  const int halo = W + 1, winp = CHX + 2 * halo;
+  const int q0 = blockIdx.x * chunks_per_wg;
+  int q1 = q0 + chunks_per_wg; q1 = q1 < n_chunks ? q1 : n_chunks;
+
+  if (t < 8) { reinterpret_cast<unsigned*>(ZERO)[t] = 0u; reinterpret_cast<unsigned*>(ZERO + XSUB)[t] = 0u; }
+
+  u32x4 pz[NPZ][2], px[NPX][2];
+  unsigned okm = 0;
+  auto gload = [&](int q) {
+    const long m0 = (long)q * CHX;
+    okm = 0;
+#pragma unroll
+    for (int u0 = 0; u0 < NPZ; ++u0) {
+      const int u = t + 512 * u0, r = u / (NC / 8), c8 = u % (NC / 8);
+      const long m = m0 + r;
+      const float* src = dz + (size_t)(m < M ? m : M - 1) * zld + c8 * 8;
+      pz[u0][0] = *reinterpret_cast<const u32x4*>(src);
+      pz[u0][1] = *reinterpret_cast<const u32x4*>(src + 4);
+      okm |= m < M ? 1u << u0 : 0u;
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < NPX; ++u0) {
+      const int u = t + 512 * u0, p = u / (CC / 8), c8 = u % (CC / 8);
+      const long m = m0 - halo + p;
+      const bool ok = p < winp && m >= 0 && m < M;
+      const float* src = x + (size_t)(ok ? m : 0) * xld + xc0 + c8 * 8;
+      px[u0][0] = *reinterpret_cast<const u32x4*>(src);
+      px[u0][1] = *reinterpret_cast<const u32x4*>(src + 4);
+      okm |= ok ? 1u << (NPZ + u0) : 0u;
+    }
+  };
+  auto limbs8 = [&](const u32x4 a, const u32x4 b, u32x4& lo, u32x4& hi) {
+    u32x4 sa, sb, r_;
+    x2_split(a, sa, r_);
+    x2_split(b, sb, r_);
+    lo = u32x4{__builtin_amdgcn_perm(sa[1], sa[0], 0x05040100u), __builtin_amdgcn_perm(sa[3], sa[2], 0x05040100u),
+               __builtin_amdgcn_perm(sb[1], sb[0], 0x05040100u), __builtin_amdgcn_perm(sb[3], sb[2], 0x05040100u)};
+    hi = u32x4{__builtin_amdgcn_perm(sa[1], sa[0], 0x07060302u), __builtin_amdgcn_perm(sa[3], sa[2], 0x07060302u),
+               __builtin_amdgcn_perm(sb[1], sb[0], 0x07060302u), __builtin_amdgcn_perm(sb[3], sb[2], 0x07060302u)};
+  };
+  auto lstore = [&]() {
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int u0 = 0; u0 < NPZ; ++u0) {
+      const int u = t + 512 * u0, r = u / (NC / 8), c8 = u % (NC / 8);
+      u32x4 lo, hi;
+      limbs8(pz[u0][0], pz[u0][1], lo, hi);
+      const bool ok = (okm >> u0) & 1u;
+      unsigned char* d = ZT + (c8 >> 1) * ZSUB + (2 * r) * 32 + (c8 & 1) * 16;
+      *reinterpret_cast<u32x4*>(d) = ok ? lo : z4;
+      *reinterpret_cast<u32x4*>(d + 32) = ok ? hi : z4;
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < NPX; ++u0) {
+      const int u = t + 512 * u0, p = u / (CC / 8), c8 = u % (CC / 8);
+      if (p < WINP) {
+        u32x4 lo, hi;
+        limbs8(px[u0][0], px[u0][1], lo, hi);
+        const bool ok = (okm >> (NPZ + u0)) & 1u;
+        unsigned char* d = XW + (c8 >> 1) * XSUB + (2 * p) * 32 + (c8 & 1) * 16;
+        *reinterpret_cast<u32x4*>(d) = ok ? lo : z4;
+        *reinterpret_cast<u32x4*>(d + 32) = ok ? hi : z4;
+      }
+    }
+  };
+
+  f32x4 acc[9][2][2];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[tp][a >> 1][a & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned zt_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ZT + (nb * 2) * ZSUB + (lq * 4 + (i >> 2)) * 32 + (i & 3) * 8;
+  const unsigned xw_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)XW + (cb * 2) * XSUB + (i & 3) * 8;
+  const unsigned zero_lane = (unsigned)(size_t)(__attribute__((address_space(3))) void*)ZERO + (i & 3) * 8;
+  auto tr = [&](unsigned addr) -> u32x2 {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(size_t)addr));
+  };
+  const int HW = H * W;
+
+  if (q0 < q1) gload(q0);
+  for (int q = q0; q < q1; ++q) {
+    __syncthreads();
+    lstore();
+    __syncthreads();
+    if (q + 1 < q1) gload(q + 1);
+    const long m0 = (long)q * CHX;
+#pragma unroll 1
+    for (int ks = 0; ks < CHX / 16; ++ks) {                      // 32 limb rows = 16 rows of dz per step (not unrolled: the tap addresses of all steps at once spill)
+      u32x4 af[2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const u32x2 r1 = tr(zt_lane + nt * ZSUB + ks * 1024), r2 = tr(zt_lane + nt * ZSUB + ks * 1024 + 512);
+        af[nt] = u32x4{r1[0], r1[1], r2[0], r2[1]};
+      }
+      // this lane SUPPLIES the addresses of limb rows ks*32 + h*16 + lq*4 + (i >> 2), h = 0, 1: row rr = that >> 1 of the chunk, limb = its low bit
+      int oy[2], ox[2];
+      unsigned rowa[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int lr = ks * 32 + h * 16 + lq * 4 + (i >> 2), rr = lr >> 1;
+        const int m = (int)m0 + rr;
+        const int rem = m % HW;
+        oy[h] = rem / W; ox[h] = rem - oy[h] * W;
+        if (m >= M) oy[h] = -4;
+        rowa[h] = xw_lane + (lr + 2 * halo) * 32;
+      }
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int dy = tp / 3 - 1, dx = tp % 3 - 1;
+        const int shift = (dy * W + dx) * 64;
+        unsigned ad[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool ok = (unsigned)(oy[h] + dy) < (unsigned)H && (unsigned)(ox[h] + dx) < (unsigned)W;
+          ad[h] = ok ? rowa[h] + shift : zero_lane;
+        }
+        u32x4 bf[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const u32x2 r1 = tr(ad[0] + ct * XSUB), r2 = tr(ad[1] + ct * XSUB);
+          bf[ct] = u32x4{r1[0], r1[1], r2[0], r2[1]};
+        }
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          u32x4 br;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) br[e] = __builtin_amdgcn_alignbit(bf[ct][e], bf[ct][e], 16);
+          acc[tp][0][ct] = mma_chunk<bf16>(af[0], br, acc[tp][0][ct]);
+          acc[tp][1][ct] = mma_chunk<bf16>(af[1], br, acc[tp][1][ct]);
+          acc[tp][0][ct] = mma_chunk<bf16>(af[0], bf[ct], acc[tp][0][ct]);
+          acc[tp][1][ct] = mma_chunk<bf16>(af[1], bf[ct], acc[tp][1][ct]);
+        }
+      }
+    }
+  }
+
+  const int job = (NC == 256 ? 0 : blockIdx.y * NW) + j, njobs = (NC == 256 ? 1 : gridDim.y) * NW;
+  float* out = part + ((size_t)blockIdx.x * njobs + job) * JOB;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[(tp * 32 + nt * 16 + lq * 4 + e) * 32 + ct * 16 + i] = acc[tp][nt][ct][e];
+}
+
 // dW[o][ig][ky][kx] (PyTorch layout, overwrite) = sum over splits, in split order.  One thread per partial element in PARTIAL order (c fastest: the
 // reads of a wave are contiguous 128-byte rows, split after split); the 4-byte scatter into the weight layout is 74 k .. 147 k stores per layer.
 // grouped: o = 32 job + n, ig = c;  dense: job = (ig / 64) * 8 + (ig % 64 / 32) * 4 + o / 32
@@ -207,12 +379,14 @@ __global__ __launch_bounds__(256) void wgrad3x3_finalize_kernel(const float* __r
 // channels and 64 / 128 input channels.
 bool wgrad3x3_supported(int dtype, int O, int Ig, int groups, int W) {
   static const bool off = [] { const char* e = getenv("FSVIT_WGRAD3X3"); return e && e[0] == '0'; }();
-  if (off || dtype != 1) return false;
+  if (off || (dtype != 1 && dtype != 2)) return false;         // dtype 2: fp32 rows, two-limb arithmetic (wgrad3x3_x2_kernel)
   if (groups == 8) return O == 256 && Ig == 32 && W <= 20;
   return groups == 1 && O == 128 && (Ig == 64 || Ig == 128) && W <= 40;
 }
-static int wgrad3x3_plan(int O, int Ig, int groups, int M, int* splits, int* cpw, int* njobs) {
-  const int n_chunks = (M + wg3::CH - 1) / wg3::CH;
+static int wgrad3x3_rows(int groups, int dtype) { return dtype == 2 && groups == 8 ? 32 : wg3::CH; }      // rows per stage
+static int wgrad3x3_plan(int O, int Ig, int groups, int M, int* splits, int* cpw, int* njobs, int dtype) {
+  const int ch = wgrad3x3_rows(groups, dtype);
+  const int n_chunks = (M + ch - 1) / ch;
   const int gy = groups == 8 ? 1 : Ig / 64;
   int s = 256 / gy;                     // one workgroup per CU: fewer partials to write and sum
   if (s > n_chunks) s = n_chunks;
@@ -221,19 +395,31 @@ static int wgrad3x3_plan(int O, int Ig, int groups, int M, int* splits, int* cpw
   *njobs = gy * wg3::NW;
   return n_chunks;
 }
-size_t wgrad3x3_scratch_bytes(int O, int Ig, int groups, int M) {
+size_t wgrad3x3_scratch_bytes(int O, int Ig, int groups, int M, int dtype) {
   int splits, cpw, njobs;
-  wgrad3x3_plan(O, Ig, groups, M, &splits, &cpw, &njobs);
+  wgrad3x3_plan(O, Ig, groups, M, &splits, &cpw, &njobs, dtype);
   return (size_t)splits * njobs * wg3::JOB * sizeof(float);
 }
 // defer != nullptr: the split slabs are left in `scratch` for a later batched finalize (train_kernels.hip wgrad_finalize_multi, kind 3) and
 // defer[0..1] = {njobs, splits}
 int launch_wgrad3x3(const void* x, int xld, const void* dz, int zld, float* dw, float* scratch, int B, int H, int W, int O, int Ig, int groups, hipStream_t s,
-                    int* defer) {
+                    int* defer, int dtype) {
   const int M = B * H * W;
   int splits, cpw, njobs;
-  const int n_chunks = wgrad3x3_plan(O, Ig, groups, M, &splits, &cpw, &njobs);
-  if (groups == 8) {
+  const int n_chunks = wgrad3x3_plan(O, Ig, groups, M, &splits, &cpw, &njobs, dtype);
+  if (dtype == 2 && groups == 8) {
+    constexpr int CHX = 32, WINP = CHX + 2 * 21 + 3, lds = (256 / 16) * 2 * CHX * 32 + (256 / 16) * 2 * WINP * 32 + 2 * WINP * 32 + 32;
+    auto kern = wgrad3x3_x2_kernel<256, 256, 20, CHX>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(splits), dim3(512), lds, s, (const float*)x, xld, (const float*)dz, zld, scratch, M, H, W, n_chunks, cpw);
+  } else if (dtype == 2) {
+    constexpr int CHX = 64, WINP = CHX + 2 * 41 + 3, lds = (128 / 16) * 2 * CHX * 32 + (64 / 16) * 2 * WINP * 32 + 2 * WINP * 32 + 32;
+    auto kern = wgrad3x3_x2_kernel<128, 64, 40, CHX>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(splits, Ig / 64), dim3(512), lds, s, (const float*)x, xld, (const float*)dz, zld, scratch, M, H, W, n_chunks, cpw);
+  } else if (groups == 8) {
     constexpr int WINP = wg3::CH + 2 * 21 + 3, lds = (256 / 16) * wg3::CH * 32 + (256 / 16) * WINP * 32 + WINP * 32 + 32;
     {    // per launch: the attribute is per DEVICE (a process-wide "done" flag skipped it on a second GPU), and the call is cheap
       hipError_t e = hipFuncSetAttribute((const void*)wgrad3x3_kernel<256, 256, 20>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

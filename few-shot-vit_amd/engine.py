@@ -745,18 +745,19 @@ class ops:
         return dw
 
     @staticmethod
-    def conv3x3_wgrad(x_nhwc, dz, O, Ig, groups):
-        """x [B,H,W,groups*Ig], dz [B,H,W,O] (bf16 / fp16) -> dW [O,Ig,3,3] fp32 of a 3x3 / stride 1 / pad 1 convolution (fsvit_conv3x3_wgrad)."""
+    def conv3x3_wgrad(x_nhwc, dz, O, Ig, groups, limbs='bf16'):
+        """x [B,H,W,groups*Ig], dz [B,H,W,O] (bf16 / fp16, or fp32 = two-limb arithmetic with `limbs` 'bf16' / 'f16') -> dW [O,Ig,3,3] fp32 of a
+        3x3 / stride 1 / pad 1 convolution (fsvit_conv3x3_wgrad)."""
         _require_cuda(x_nhwc, dz)
         lib = _lib.load()
-        assert x_nhwc.dtype == dz.dtype and x_nhwc.dtype in (torch.bfloat16, torch.float16)
+        assert x_nhwc.dtype == dz.dtype and x_nhwc.dtype in (torch.bfloat16, torch.float16, torch.float32)
         B, H, W, C = x_nhwc.shape
         assert C == groups * Ig and dz.shape == (B, H, W, O)
         x_nhwc, dz = x_nhwc.contiguous(), dz.contiguous()
         dw = torch.empty(O, Ig, 3, 3, dtype=torch.float32, device=x_nhwc.device)
         with torch.cuda.device(x_nhwc.device):
-            _lib.check(lib.fsvit_conv3x3_wgrad(_ptr(x_nhwc), _ptr(dz), _ptr(dw), B, H, W, O, Ig, groups,
-                                               _lib.BF16 if x_nhwc.dtype == torch.bfloat16 else _lib.F16, _stream_ptr(x_nhwc.device)))
+            dt = {torch.bfloat16: _lib.BF16, torch.float16: _lib.F16, torch.float32: _lib.BF16X2 if limbs == 'bf16' else _lib.F16X2}[x_nhwc.dtype]
+            _lib.check(lib.fsvit_conv3x3_wgrad(_ptr(x_nhwc), _ptr(dz), _ptr(dw), B, H, W, O, Ig, groups, dt, _stream_ptr(x_nhwc.device)))
         return dw
 
     @staticmethod

@@ -361,7 +361,8 @@ int fsvit_image_transform_gather(const uint8_t* images_dev, int H, int W, const 
 
 /* Operator level of the training path: attention backward (qkv, dctx -> dqkv; hd real / hdp padded head dim). */
 /* Weight gradient of a 3x3 / stride 1 / pad 1 convolution straight from the NHWC activations (no im2col, no transposed copies):
- * dw[O][Ig][3][3] (fp32, overwritten) = sum_m dz[m][o] * x[pix(m) + tap][i].  x [B,H,W,groups*Ig], dz [B*H*W][O], dtype FSVIT_BF16 / FSVIT_F16.
+ * dw[O][Ig][3][3] (fp32, overwritten) = sum_m dz[m][o] * x[pix(m) + tap][i].  x [B,H,W,groups*Ig], dz [B*H*W][O], dtype FSVIT_BF16 / FSVIT_F16, or
+ * FSVIT_BF16X2 / FSVIT_F16X2 = fp32 activations split into two 16-bit limbs on the way into LDS (the two-limb trainers' kernel).
  * Replaces what autograd computes for stem.conv2 / conv3 and stage1.*.mlp.conv2 in train_meta.py:228-232 (visformer.py:152-163, :209-237).
  * Built shapes: groups = 8 with 32 -> 32 channels per group (W <= 20); dense O = 128, Ig = 64 / 128 (W <= 40). */
 int fsvit_conv3x3_wgrad(const void* x_dev, const void* dz_dev, float* dw_dev, int B, int H, int W, int O, int Ig, int groups, int dtype, void* stream);

@@ -531,6 +531,31 @@ def test_conv3x3_wgrad_direct_vs_torch(shape, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(3, 20, 20, 256, 32, 8), (2, 40, 40, 128, 64, 1), (2, 40, 40, 128, 128, 1), (5, 20, 20, 256, 32, 8), (1, 12, 16, 128, 64, 1), (2, 7, 9, 256, 32, 8)])
+@pytest.mark.parametrize('limbs', ['bf16', 'f16'])
+def test_conv3x3_wgrad_two_limb_vs_fp64(shape, limbs):
+    """fsvit_conv3x3_wgrad on fp32 activations (FSVIT_BF16X2 / FSVIT_F16X2: limb rows at LDS staging, a tap = two rows per pixel) vs torch's conv2d
+    weight gradient in fp64 on the unrounded operands; border taps included."""
+    from fewshot_vit_amd.engine import ops
+    B, H, W, O, Ig, groups = shape
+    g = torch.Generator().manual_seed(19 + B + O + Ig + H)
+    x = torch.randn(B, groups * Ig, H, W, generator=g)
+    dz = torch.randn(B, O, H, W, generator=g) * 0.1
+    wref = torch.zeros(O, Ig, 3, 3, requires_grad=True, dtype=torch.float64)
+    F.conv2d(x.double(), wref, padding=1, groups=groups).backward(dz.double())
+    wabs = torch.zeros(O, Ig, 3, 3, requires_grad=True, dtype=torch.float64)
+    F.conv2d(x.double().abs(), wabs, padding=1, groups=groups).backward(dz.double().abs())
+    scale = wabs.grad.max().item()                                                        # sum of |products|
+    args = (x.permute(0, 2, 3, 1).contiguous().cuda(), dz.permute(0, 2, 3, 1).contiguous().cuda(), O, Ig, groups, limbs)
+    got = ops.conv3x3_wgrad(*args).cpu().double()
+    err = (got - wref.grad).abs().max().item()
+    print(f'conv3x3_wgrad two-limb {shape} {limbs}: max err {err:.3e} (sum |products| {scale:.1f})')
+    assert err <= (3e-5 if limbs == 'bf16' else 2e-6) * scale
+    assert (got[:, :, 0, 0] - wref.grad[:, :, 0, 0]).abs().max().item() <= (3e-5 if limbs == 'bf16' else 2e-6) * scale
+    assert torch.equal(got, ops.conv3x3_wgrad(*args).cpu().double())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('shape', [(8000, 1024, 256), (2000, 864, 256), (2000, 512, 576), (5000, 128, 32), (777, 256, 128), (64, 1728, 512), (130, 8, 8)])
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 def test_conv1x1_wgrad_direct_vs_torch(shape, dtype):
