@@ -115,8 +115,8 @@ __global__ __launch_bounds__(512) void wgrad3x3_kernel(const bf16* __restrict__ 
     __syncthreads();
     if (q + 1 < q1) gload(q + 1);
     const long m0 = (long)q * CH;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll 1
+    for (int ks = 0; ks < 2; ++ks) {      // (not unrolled: with both steps' tap addresses live the grouped variant spilled 20 registers)
       // dz^T fragments: rows (= K slots) ks*32 + h*16 + lq*4 + 0..3, column 16 nt + i
       u32x4 af[2];
 #pragma unroll
