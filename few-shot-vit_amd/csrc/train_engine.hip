@@ -317,6 +317,15 @@ int side_sync(TR* t) {                        // ... for every side launch so fa
   t->pend.clear();
   return 0;
 }
+// error exit of a backward pass: nothing may still be running on a side stream when the caller sees the error (it may free or reuse the workspace the
+// pending weight-gradient launches read)
+template <typename T_>
+int side_drain(T_* t, int rc) {
+  if (rc != 0)
+    for (hipStream_t q : t->sides)
+      if (q) (void)hipStreamSynchronize(q);
+  return rc;
+}
 // call before a main-stream launch that WRITES [p, p + bytes): waits for the youngest pending side launch that still reads any of it
 int side_guard(TR* t, const void* p, size_t bytes) {
   const unsigned char *lo = (const unsigned char*)p, *hi = lo + bytes;
@@ -1216,7 +1225,7 @@ extern "C" int fsvit_vit_train_backward(fsvit_vit_trainer* t, const fsvit_param*
   t->fin.clear();
   t->side_seq = 0; t->pend.clear();
   for (int& v : t->side_waited) v = -1;
-  return vit_backward_impl(t, dfeat_dev);
+  return side_drain(t, vit_backward_impl(t, dfeat_dev));
 }
 
 // ================================================================ C ABI
@@ -1329,7 +1338,7 @@ extern "C" int fsvit_visformer_train_backward(fsvit_visformer_trainer* t, const 
   t->fin.clear();
   t->side_seq = 0; t->pend.clear();
   for (int& v : t->side_waited) v = -1;
-  return train_backward_impl(t, dfeat_dev);
+  return side_drain(t, train_backward_impl(t, dfeat_dev));
 }
 
 extern "C" int fsvit_proto_head_backward(const float* feat_shot, const float* feat_query, const float* dlogits, int E, int way, int shot, int Q, int D,

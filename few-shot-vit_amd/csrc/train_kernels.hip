@@ -1418,14 +1418,18 @@ int launch_wgrad_finalize_multi(const FinJob* jobs, int n, hipStream_t s) {
   return 0;
 }
 int launch_droppath_scales(const float* masks, float* scales, int ncalls, int n_img, const float* keep, hipStream_t s) {
-  if (ncalls <= 0) return 0;
-  if (ncalls > DropKeep::MAX) return (int)hipErrorInvalidValue;
-  DropKeep k;
-  for (int i = 0; i < ncalls; ++i) k.inv[i] = 1.0f / keep[i];
-  unsigned gx = (unsigned)((n_img + 255) / 256);
-  if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(droppath_scales_kernel, dim3(gx, (unsigned)ncalls), dim3(256), 0, s, masks, scales, n_img, k);
-  return (int)hipGetLastError();
+  // the keep table travels as a kernel argument, DropKeep::MAX calls per launch: deeper encoders (> 64 DropPath calls a step) take further launches
+  for (int c0 = 0; c0 < ncalls; c0 += DropKeep::MAX) {
+    const int n = ncalls - c0 < DropKeep::MAX ? ncalls - c0 : DropKeep::MAX;
+    DropKeep k;
+    for (int i = 0; i < n; ++i) k.inv[i] = 1.0f / keep[c0 + i];
+    unsigned gx = (unsigned)((n_img + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(droppath_scales_kernel, dim3(gx, (unsigned)n), dim3(256), 0, s, masks + (size_t)c0 * n_img, scales + (size_t)c0 * n_img, n_img, k);
+    const int rc = (int)hipGetLastError();
+    if (rc) return rc;
+  }
+  return 0;
 }
 int launch_wgrad_finalize(const float* y, float* dw, int Ng, int Ig, int KH, int KW, int g, int splits, int Kc_pad, int hd_rows, int hdp_rows, int hd_cols,
                           int hdp_cols, hipStream_t s) {

@@ -167,6 +167,12 @@ def test_vit_train_step_vs_oracle_autograd_small(numerics, drop, tl, tg):
     _vit_train_check(dict(img_size=36, patch_size=6, embed_dim=128, depth=4, num_heads=4), 6, numerics, drop, tl, tg)
 
 
+def test_vit_train_step_more_than_64_droppath_calls():
+    """A 34-block ViT has 66 DropPath calls with a non-zero rate per step: the keep table of the mask -> scale launch holds 64 per launch
+    (train_kernels.h DropKeep), so the step takes two launches; every gradient still matches torch.autograd of the oracle."""
+    _vit_train_check(dict(img_size=24, patch_size=6, embed_dim=64, depth=34, num_heads=2), 4, 'parity', 0.3, 5e-5, 5e-5)
+
+
 def test_vit_train_step_197_tokens_parity():
     """The 84 x 84 / patch 6 factories' shape (197 tokens, head dim 56 padded to 64... in bf16; 56 in fp32) in the exact-fp32 mode: the tiled fp32
     attention backward (K / V resident, query blocks) lifts the old ~110-token limit of `parity` training."""
