@@ -123,6 +123,7 @@ struct Layer {
 };
 struct Block1 {
   Layer c1, c2, c3;
+  void* c3s = nullptr;      // 8 x the packed conv3 weights (stage1_w4.hip: the residual and the output then need no scaling)
 };
 struct BlockA {
   Layer qkv, proj, fc1, fc2;
@@ -479,6 +480,13 @@ int build(fsvit_visformer* h, const SD& sd) {
                       &wr, &rm, nullptr, true));
     RC_TRY(pack_layer(h, &h->s1[i].c2, w2, h->hid1, Cg, 3, 3, cf.group, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0));
     RC_TRY(pack_layer(h, &h->s1[i].c3, w3, h->C1, h->hid1, 1, 1, 1, nullptr, nullptr, nob, false, nullptr, 0, nullptr, 0, &wr, &mh2, nullptr, false, &corr3));
+    if (kd(kdt) == 1 && h->s1[i].c3.Kw == h->hid1) {
+      const size_t n3 = (size_t)h->C1 * h->s1[i].c3.Kw;
+      HIP_TRY(hipMalloc(&h->s1[i].c3s, n3 * 2));
+      h->allocs.push_back(h->s1[i].c3s);
+      RC_TRY(K(launch_stage1_w4_prescale)(h->s1[i].c3.w, h->s1[i].c3s, (int)n3, nullptr));
+      HIP_TRY(hipDeviceSynchronize());
+    }
     if (wr.on) {
       x_mean.assign(h->C1, 0.0);                  // E[x] behind this block = running mean + conv3 E[h2]: the next PatchEmbed's operand mean
       for (int o = 0; o < h->C1; ++o) {
@@ -774,7 +782,7 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
     if (fuse1) {   // one LDS-resident kernel per block, ping-pong between x1 and x1b
       const double fl = 2.0 * Bc * h->H1 * h->H1 * ((double)h->hid1 * h->C1 + (double)h->hid1 * 9 * Cg + (double)h->C1 * h->hid1);
       RC_TRY(timed(h, st, "stage1.block", KID_STAGE1RING, fl,
-                   [&]() { return K(launch_stage1_ring)(x1, x1b, b.c1.w, b.c1.bias, b.c2.w, b.c3.w, Bc, h->H1, h->H1, st); }));
+                   [&]() { return K(launch_stage1_ring)(x1, x1b, b.c1.w, b.c1.bias, b.c2.w, b.c3.w, Bc, h->H1, h->H1, st, b.c3s); }));
       std::swap(x1, x1b);
     } else {
       RC_TRY(run_gemm(h, st, "stage1.mlp.conv1", b.c1, conv_params(b.c1, x1, ha, Bc, h->H1, h->H1, h->C1, h->C1, 1, 1, 1, 0, h->hid1, ACT_GELU, nullptr, 0, nullptr), h->hid1, h->C1));
@@ -1019,7 +1027,7 @@ extern "C" int fsvit_stage1_block_hw(const void* x, void* y, const void* w1, con
   if (!x || !y || !w1 || !b1 || !w2 || !w3 || x == y || B <= 0) return fail(FSVIT_ERR_ARG, "bad argument");
   if (dtype != FSVIT_BF16 && dtype != FSVIT_F16) return fail(FSVIT_ERR_ARG, "fsvit_stage1_block_hw: 16-bit storage only (bf16 / f16)");
   if (H != W || !K(stage1_ring_supported)(1, 128, 256, 8, W)) return fail(FSVIT_ERR_ARG, "fsvit_stage1_block_hw: square maps of 4 .. 20 tokens a side");
-  RC_TRY(K(launch_stage1_ring)(x, y, w1, b1, w2, w3, B, H, W, (hipStream_t)stream));
+  RC_TRY(K(launch_stage1_ring)(x, y, w1, b1, w2, w3, B, H, W, (hipStream_t)stream, nullptr));
   return 0;
 }
 

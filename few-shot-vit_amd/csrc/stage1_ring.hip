@@ -399,8 +399,8 @@ bool stage1_ring_preferred() {
 }
 
 // w1 [256][128], w2 [256][320] (columns (tap, c)), w3 [128][256]: the packed layers of the block (engine.hip pack_layer)
-int launch_stage1_ring(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, int H, int W, hipStream_t s) {
-  if (stage1_w4_enabled()) return launch_stage1_w4(x, y, w1, b1, w2, w3, B, H, W, s);
+int launch_stage1_ring(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, int H, int W, hipStream_t s, const void* w3s) {
+  if (stage1_w4_enabled()) return launch_stage1_w4(x, y, w1, b1, w2, w3, B, H, W, s, w3s);      // w3s: 8 x w3 or null (stage1_w4.hip)
   return launch_stage1_ring16(x, y, w1, b1, w2, w3, B, H, W, s);
 }
 // this file's kernel whatever FSVIT_STAGE1_W4 says (fsvit_stage1_block: the cross-check of the two kernels in one process)

@@ -85,7 +85,9 @@ __device__ __forceinline__ unsigned w4_pk2(float a, float b) {
 }
 
 // PIPE = false: the same data flow with every GELU pass run en bloc behind its MFMA phase (bring-up / reference for the slotted schedule)
-template <bool PIPE>
+// SC: `w3` is the caller's PRE-SCALED copy 8 x W3 (exact; launch_stage1_w4_prescale) - conv3 then accumulates x + W3 h2 itself, and neither the residual
+// (x / 8 in) nor the output (8 x acc out) is touched by VALU: -64 VALU per chunk and wave
+template <bool PIPE, bool SC>
 __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, const bf16* __restrict__ w1,
                                                            const float* __restrict__ b1, const bf16* __restrict__ w2, const bf16* __restrict__ w3, int M,
                                                            int H, int W, int n_chunks, int chunks_per_wg) {
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
       for (int o = 0; o < 2; ++o) {
         const bf16x8 r = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xres + o * XP + xslot16(-CH + 32 * bt + p)));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc3[bt][8 * o + e] = (float)r[e] * 0.125f;
+        for (int e = 0; e < 8; ++e) acc3[bt][8 * o + e] = SC ? (float)r[e] : (float)r[e] * 0.125f;
       }
   };
   auto conv3_mfma = [&]() {
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
       for (int o = 0; o < 2; ++o) {
         u32x4 v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = w4_pk2(8.0f * acc3[bt][8 * o + 2 * j], 8.0f * acc3[bt][8 * o + 2 * j + 1]);
+        for (int j = 0; j < 4; ++j) v[j] = SC ? w4_pk2(acc3[bt][8 * o + 2 * j], acc3[bt][8 * o + 2 * j + 1]) : w4_pk2(8.0f * acc3[bt][8 * o + 2 * j], 8.0f * acc3[bt][8 * o + 2 * j + 1]);
         if (m < M) *reinterpret_cast<u32x4*>(yl + (size_t)m * C1 + 8 * o) = v;
       }
     }
@@ -325,20 +327,32 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
   typedef std::integral_constant<int, 7> N7;
   typedef std::integral_constant<int, 8> N8;
 
-  // pixel coordinates of the lane's two conv2 pixels (m = 64 q + 32 bt + p), advanced by one chunk per body
+  // pixel coordinates of the lane's two conv2 pixels (m = 64 q + 32 bt + p), advanced by one chunk per body.  Tap validity as LANE MASKS in SGPRs: three row
+  // masks (dy = -1, 0, +1) and three column masks per pixel tile, formed once per body (6 compares); a tap then costs one scalar AND and one v_cndmask
+  // on the mask instead of two adds, two compares and a select
   const int divW = (65536 + W - 1) / W;
-  int remq[2], toy[2], tox[2], tms[2];
+  int remq[2], tms[2];
+  unsigned long long rmk[2][3], cmk[2][3];
+  int zero_off = ZERO;
+  asm volatile("" : "+v"(zero_off));                        // (v_cndmask reads the mask over the constant bus: the zero region's offset has to be a VGPR)
   auto tap_setup = [&](int q, int bt) {                       // remq[bt] = m % HW is current
     const int m = q * CH + 32 * bt + p;
-    toy[bt] = m < M ? (remq[bt] * divW) >> 16 : -4;
-    tox[bt] = remq[bt] - ((remq[bt] * divW) >> 16) * W;
+    const int oy = m < M ? (remq[bt] * divW) >> 16 : -4;
+    const int ox = remq[bt] - ((remq[bt] * divW) >> 16) * W;
     tms[bt] = (m & (RING - 1)) * 16;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      rmk[bt][d] = __builtin_amdgcn_ballot_w64((unsigned)(oy + d - 1) < (unsigned)H);
+      cmk[bt][d] = __builtin_amdgcn_ballot_w64((unsigned)(ox + d - 1) < (unsigned)W);
+    }
   };
   auto tap_addr = [&](int bt, int tp) {                       // LDS offset of the tap's fragment (plane 8 w + kh), or the zero region
     const int dy = tp / 3 - 1, dx = tp % 3 - 1;
-    const bool ok = ((unsigned)(toy[bt] + dy) < (unsigned)H) & ((unsigned)(tox[bt] + dx) < (unsigned)W);      // (bitwise: no short-circuit branch per tap)
+    const unsigned long long mk = rmk[bt][tp / 3] & cmk[bt][tp % 3];
     const int in = h1r_off + ((tms[bt] + (dy * W + dx) * 16) & (PITCH - 1));
-    return ok ? in : ZERO;
+    int r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(zero_off), "v"(in), "s"(mk));
+    return r;
   };
   auto rem_advance = [&](int bt) {
     remq[bt] += CH;
@@ -422,7 +436,7 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
           constexpr int i = m - 32, bt2 = i >> 1, o = i & 1;
           const bf16x8 r = __builtin_bit_cast(bf16x8, rr[i]);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc3[bt2][8 * o + e] = (float)r[e] * 0.125f;
+          for (int e = 0; e < 8; ++e) acc3[bt2][8 * o + e] = SC ? (float)r[e] : (float)r[e] * 0.125f;
         }
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -470,7 +484,7 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
           const long mm = (long)(q - 1) * CH + 32 * bt + p;
           u32x4 v;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = w4_pk2(8.0f * acc3[bt][8 * o + 2 * j], 8.0f * acc3[bt][8 * o + 2 * j + 1]);
+          for (int j = 0; j < 4; ++j) v[j] = SC ? w4_pk2(acc3[bt][8 * o + 2 * j], acc3[bt][8 * o + 2 * j + 1]) : w4_pk2(8.0f * acc3[bt][8 * o + 2 * j], 8.0f * acc3[bt][8 * o + 2 * j + 1]);
           if (mm < M) *reinterpret_cast<u32x4*>(yl + (size_t)mm * C1 + 8 * o) = v;
         }
         if constexpr (m == 28) tap_setup(q, 1);
@@ -561,7 +575,17 @@ bool stage1_w4_enabled() {
   return !off;
 }
 
-int launch_stage1_w4(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, int H, int W, hipStream_t s) {
+__global__ __launch_bounds__(256) void stage1_w4_prescale_kernel(const bf16* __restrict__ w, bf16* __restrict__ ws, int n) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) ws[i] = (bf16)((float)w[i] * 8.0f);      // exact: a power of two
+}
+// ws := 8 x w (the conv3 weights the engines hand to launch_stage1_w4 as `w3s`); n elements of the storage type
+int launch_stage1_w4_prescale(const void* w, void* ws, int n, hipStream_t s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(stage1_w4_prescale_kernel, dim3((n + 255) / 256 < 256 ? (n + 255) / 256 : 256), dim3(256), 0, s, (const bf16*)w, (bf16*)ws, n);
+  return (int)hipGetLastError();
+}
+
+int launch_stage1_w4(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, int H, int W, hipStream_t s, const void* w3s) {
   const long Ml = (long)B * H * W;
   if (Ml <= 0) return 0;
   if (Ml >= (1L << 31) - 256 || W > 20 || H * W < 16) return (int)hipErrorInvalidValue;
@@ -570,10 +594,12 @@ int launch_stage1_w4(const void* x, void* y, const void* w1, const float* b1, co
   const int cpw = (n_chunks + wgs - 1) / wgs;
   wgs = (n_chunks + cpw - 1) / cpw;
   static const bool pipe_off = [] { const char* e = getenv("FSVIT_STAGE1_W4_PIPE"); return e && e[0] == '0'; }();
-  auto kern = pipe_off ? stage1_w4_kernel<false> : stage1_w4_kernel<true>;
+  static const bool sc_off = [] { const char* e = getenv("FSVIT_STAGE1_W4_PRESCALE"); return e && e[0] == '0'; }();
+  const bool sc = w3s && !pipe_off && !sc_off;
+  auto kern = pipe_off ? stage1_w4_kernel<false, false> : (sc ? stage1_w4_kernel<true, true> : stage1_w4_kernel<true, false>);
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, s1w::LDS_BYTES);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), s1w::LDS_BYTES, s, (const bf16*)x, (bf16*)y, (const bf16*)w1, b1, (const bf16*)w2, (const bf16*)w3, M, H, W, n_chunks, cpw);
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), s1w::LDS_BYTES, s, (const bf16*)x, (bf16*)y, (const bf16*)w1, b1, (const bf16*)w2, (const bf16*)(sc ? w3s : w3), M, H, W, n_chunks, cpw);
   return (int)hipGetLastError();
 }
 
