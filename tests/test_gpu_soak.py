@@ -100,3 +100,24 @@ def test_vit_ln_qkv_attention_rows_is_deterministic_at_bench_size():
     w = (rn(3 * heads * hd, C) / math.sqrt(C)).to(bf)
     bias = rn(3 * heads * hd) * 0.3
     assert _repeat(lambda: ops.vit_ln_qkv_attention(x, w, bias, B, S, heads, hd, hd ** -0.5), 30) == 0
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_stage1_w4_block_is_deterministic_at_bench_size(dtype):
+    """stage1_w4.hip orders its LDS hand-offs (h1 / h2 / x rings, 192-slot residual window) with two hand-written barriers per 64-pixel chunk and
+    counted waits: 6400 images (40 000 chunks, 157 per workgroup) repeated 30 times must be bit-identical, and agree with the 16-wave ring kernel."""
+    from fewshot_vit_amd.engine import ops
+    from test_gpu_ops import pack_w
+    g = torch.Generator().manual_seed(77)
+    B = 6400
+    x = torch.randn(B, 20, 20, 128, generator=g).to('cuda', dtype)
+    w1 = torch.randn(256, 128, 1, 1, generator=g) / math.sqrt(128)
+    w2 = torch.randn(256, 32, 3, 3, generator=g) / math.sqrt(288)
+    w3 = torch.randn(128, 256, 1, 1, generator=g) / math.sqrt(256)
+    b1 = (torch.randn(256, generator=g) * 0.2).cuda()
+    args = (pack_w(w1, 1, dtype)[0].cuda(), b1, pack_w(w2, 8, dtype).cuda(), pack_w(w3, 1, dtype)[0].cuda())
+    assert _repeat(lambda: ops.stage1_block_hw(x, *args), 30) == 0
+    if dtype == torch.bfloat16:
+        y, y0 = ops.stage1_block_hw(x, *args).float(), ops.stage1_block(x, *args).float()
+        d = (y - y0).abs()
+        assert d.max().item() <= 3e-2 * max(1.0, float(y0.abs().max())) and d.mean().item() <= 1e-3
