@@ -1084,6 +1084,10 @@ __global__ __launch_bounds__(512, 1) void vit_attn_rows_kernel(const bf16* __res
 
   const int tok = wave * 32 + r;
   const bool ok = tok < S;
+  // a wave beyond the image's row blocks (wave 7 at 197 tokens) keeps every barrier and its share of the weight ring's DMA but skips the arithmetic (the
+  // chip runs power-limited, 2.15 GHz at 1.3 kW; measured 51.0 -> 50.7 ms per DeiT-S step, i.e. within the noise: its SIMD partner and the other
+  // SIMDs still set the pace)
+  const bool active = wave < NB;
   u32x4 xr[NKS];
   auto load_rows = [&](int img) {                                    // this wave's 32 token rows of image `img` (clamped), in flight
     const size_t row = (size_t)img * S + (ok ? tok : S - 1);
@@ -1107,6 +1111,7 @@ __global__ __launch_bounds__(512, 1) void vit_attn_rows_kernel(const bf16* __res
       asm volatile("" : "+v"(a));
       const unsigned char* sp = smem + a;
       slot = slot == NST - 1 ? 0 : slot + 1;
+      if (active) {
       u32x4 fr[FD];
 #pragma unroll
       for (int i = 0; i < FD; ++i) fr[i] = *reinterpret_cast<const u32x4*>(sp + i * 1024);
@@ -1119,6 +1124,7 @@ __global__ __launch_bounds__(512, 1) void vit_attn_rows_kernel(const bf16* __res
         __builtin_amdgcn_sched_barrier(0);
       }
       asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc));          // wait states MFMA -> VALU read of the accumulator
+      }
     };
     auto bias_rows = [&](f32x16& acc, int src) {                 // D[channel][token]: lane (token, kh) holds channels 16 kh + i
       const float* bp = btab + src * 32 + kh * 16;
@@ -1253,7 +1259,7 @@ __global__ __launch_bounds__(512, 1) void vit_attn_rows_kernel(const bf16* __res
           mfma32_v(vf[c][1], pp[1], oacc[c]);
         }
       };
-      {                                                            // two fragment sets: block kb + 1 is read from LDS under block kb's work
+      if (active) {                                                // two fragment sets: block kb + 1 is read from LDS under block kb's work
         u32x4 kfa[HDC][2], vfa[HDC][2], kfb[HDC][2], vfb[HDC][2];
         kv_load(0, kfa, vfa);
 #pragma unroll 1
