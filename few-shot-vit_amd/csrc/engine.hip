@@ -298,8 +298,10 @@ int pack_layer(EngineBase* h, Layer* L, const float* W, int O, int Ig, int KH, i
   const int N = (rowmap ? Npad : O) / groups;
   const int K = colmap ? Kpad : KH * KW * Ig;
   const int Kw = round_up(K, bke);
-  const bool fix = wr && wr->on && in_mean;
-  const bool cst = wr && wr->on && use_cst && !wr->cst.empty();
+  // (an operand-mean / stream-constant vector that does not cover this layer's input channels - e.g. one handed on across a stage without blocks - is
+  // not applied: no correction instead of another tensor's statistics)
+  const bool fix = wr && wr->on && in_mean && in_mean->size() >= (size_t)groups * Ig;
+  const bool cst = wr && wr->on && use_cst && wr->cst.size() >= (size_t)groups * Ig;
   if (corr_out) corr_out->assign(O, 0.0);
   std::vector<float> pk((size_t)groups * N * Kw, 0.0f);
   std::vector<float> pb((size_t)groups * N, 0.0f);
@@ -378,8 +380,12 @@ int build(fsvit_visformer* h, const SD& sd) {
 
   std::vector<double> nob;
   WRound wr;                                    // weight-rounding bias correction: the 16-bit modes only (the two-limb modes carry 16+ bits)
-  wr.on = kdt == FSVIT_BF16 || kdt == FSVIT_F16;
+  // FSVIT_WROUND=0 (read once per build): the plain 16-bit images without the correction - the ablation switch of the one eval route whose effect
+  // rests on statistical assumptions (data that matches the running statistics); tests/test_gpu_unfused_paths.py
+  const char* wr_env = getenv("FSVIT_WROUND");
+  wr.on = (kdt == FSVIT_BF16 || kdt == FSVIT_F16) && !(wr_env && wr_env[0] == '0');
   wr.f16 = kdt == FSVIT_F16;
+  if (wr.on) wr.cst.assign(h->C1, 0.0);
   auto vec = [&](const std::string& name, int C, bool absolute) {      // a [C] state-dict entry as doubles (checked by bn_affine before)
     const float* p = sd.get(name, {C});
     std::vector<double> v(C, 0.0);
@@ -442,7 +448,9 @@ int build(fsvit_visformer* h, const SD& sd) {
     RC_TRY(pack_pos(h, p3, h->C3, h->H3 * h->H3, &h->pos3));
   }
   // ---- stage 1 (Block with attn_disabled, spatial_conv; visformer.py:241-263, Mlp :127-163)
-  std::vector<double> x_mean;                   // WRound: estimated mean of the residual stream where the next PatchEmbed reads it
+  // WRound: estimated mean of the residual stream where the next PatchEmbed reads it.  Seeded with zeros (a stage without blocks hands on "no
+  // estimate" of the right size: ADVICE r04 - depth (0, 1, 1) indexed an empty vector) and re-seeded behind every PatchEmbed.
+  std::vector<double> x_mean(h->C1, 0.0);
   h->s1.resize(cf.depth[0]);
   for (int i = 0; i < cf.depth[0]; ++i) {
     const std::string p = "stage1." + std::to_string(i) + ".";
@@ -511,7 +519,19 @@ int build(fsvit_visformer* h, const SD& sd) {
     for (int o = 0; o < Co; ++o) bias[o] = bn.s[o] * (double)b[o] + bn.t[o];
     // WRound: the operand is the residual stream leaving the previous stage (estimated mean x_mean); its deferred constant ends here
     RC_TRY(pack_layer(h, s == 2 ? &h->pe2 : &h->pe3, w, Co, Ci, 2, 2, 1, &bn.s, nullptr, bias, true, nullptr, 0, nullptr, 0, &wr, &x_mean, nullptr, true));
-    if (wr.on) wr.cst.assign(Co, 0.0);
+    if (wr.on) {
+      wr.cst.assign(Co, 0.0);
+      // the stream behind this PatchEmbed: E = BatchNorm beta + mean_hw(pos_embed) until a block of the stage refines it
+      const std::vector<double> be = vec(p + "norm.bn.bias", Co, false);
+      const int HW = (s == 2 ? h->H2 : h->H3) * (s == 2 ? h->H2 : h->H3);
+      const float* pos = sd.get("pos_embed" + std::to_string(s), {1, Co, s == 2 ? h->H2 : h->H3, s == 2 ? h->H2 : h->H3});
+      x_mean.assign(Co, 0.0);
+      for (int o = 0; o < Co; ++o) {
+        double a = 0.0;
+        for (int q = 0; pos && q < HW; ++q) a += (double)pos[(size_t)o * HW + q];
+        x_mean[o] = be[o] + a / HW;
+      }
+    }
     const Layer& pe = s == 2 ? h->pe2 : h->pe3;
     if (K(patch_embed_rows_supported)(kd(kdt), Ci, s == 2 ? h->H1 : h->H2, Co) && pe.Kw == 4 * Ci) {
       void* img = nullptr;

@@ -38,6 +38,28 @@ template <> __device__ __forceinline__ void store4<limbw>(limbw* p, f32x4 v) {
 //  mode 2 (k2s2 dgrad): row r = (ky*KW + kx) * Ig + i, k = n (no flip): dY[m] . W[:, i, ky, kx] for the non-overlapping patch conv
 // Head-dim padding (qkv rows / proj columns, visformer.py:172-177): logical index j < real maps to
 // (j / hd) * hdp + j % hd in the padded dimension (hd == hdp: identity).
+// modes 3 / 4: fragment images of the row-wise training Mlp (mlp_train.hip).  The logical matrix A[R = rows_pad][K = Kw] has element (row, k) =
+// w[row * O + k * Ig] (O / Ig carry the two strides, so a transposed view is a stride swap); the image is the sequence of 1 KiB MFMA A-operand
+// fragments (lane (r, kh): 8 consecutive k of one row) in the order the kernel consumes them:
+//   mode 3 (first GEMM: rows = hidden units, k = channels):   fragment (chunk j, step s): row 32 j + hperm(r), k = 32 (s >> 1) + 16 kh + 8 (s & 1) + q
+//   mode 4 (second GEMM: rows = output channels, k = hidden): fragment (chunk j, tile ct, half s2): row 32 ct + hperm(r), k = 32 j + 16 kh + 8 s2 + q
+// hperm(rho) = 16 ((rho >> 2) & 1) + 4 (rho >> 3) + (rho & 3): the 32 x 32 result's lane then holds 16 consecutive units of its token.
+__device__ __forceinline__ float frag_image_elem(const float* __restrict__ w, int mode, size_t idx, int R, int K, int rs, int ks) {
+  const int q = (int)(idx & 7), lane = (int)((idx >> 3) & 63), r = lane & 31, kh = lane >> 5;
+  const int f = (int)(idx >> 9);
+  const int hp = 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3);
+  int row, k;
+  if (mode == 3) {
+    const int nks = K / 16, j = f / nks, s = f % nks;
+    row = 32 * j + hp;
+    k = 32 * (s >> 1) + 16 * kh + 8 * (s & 1) + q;
+  } else {
+    const int npc = R / 16, j = f / npc, rem = f % npc, ct = rem >> 1, s2 = rem & 1;
+    row = 32 * ct + hp;
+    k = 32 * j + 16 * kh + 8 * s2 + q;
+  }
+  return w[(size_t)row * rs + (size_t)k * ks];
+}
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int O, int Ig, int KH, int KW,
                                                           int groups, int mode, int rows_pad, int Kw, int hd_rows, int hdp_rows,
@@ -49,6 +71,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     const size_t t2 = idx / Kw;
     const int r = (int)(t2 % rows_pad), g = (int)(t2 / rows_pad);
     float v = 0.0f;
+    if (mode >= 3) { out[idx] = from_f32<T>(frag_image_elem(w, mode, idx, rows_pad, Kw, O, Ig)); continue; }
     if (mode == 2) {
       if (r < KH * KW * Ig && k < Ng) {
         const int tap = r / Ig, ch = r % Ig;
@@ -88,6 +111,7 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackJobs j
     const size_t t2 = idx / j.Kw;
     const int r = (int)(t2 % j.rows_pad), g = (int)(t2 / j.rows_pad);
     float v = 0.0f;
+    if (j.mode >= 3) { out[idx] = from_f32<T>(frag_image_elem(j.w, j.mode, idx, j.rows_pad, j.Kw, j.O, j.Ig)); continue; }
     if (j.mode == 2) {
       if (r < j.KH * j.KW * j.Ig && k < Ng) {
         const int tap = r / j.Ig, ch = r % j.Ig;

@@ -5,6 +5,7 @@ entry points used by the parity tests.  Every call goes through libfsvit.so — 
 """
 import ctypes as C
 import os
+import sys
 from typing import Dict, Optional
 
 import numpy as np
@@ -49,6 +50,32 @@ def default_numerics() -> str:
     return os.environ.get('FSVIT_NUMERICS', 'bf16')
 
 
+# What a drop-in user gets from each mode, measured against the reference's CPU path (DESIGN.md 2; tests/test_gpu_visformer.py gates every line
+# against the reference goldens, bench.py `modes` / `agreement` re-measure the agreement on 2048 episodes): max |dlogit| on the golden 5-shot
+# episode, arg-max agreement with `parity` on the bench episodes, throughput relative to bf16.
+NUMERICS_NOTE = {
+    'bf16': 'bf16 storage + MFMA: logits within ~5e-2 of the reference (golden 5-shot 4.2e-2), 98.9 % arg-max agreement; the throughput mode - NOT the '
+            '1e-3-grade mode: FSVIT_NUMERICS=f16 (same rate, 8 x tighter), bf16x2 (1e-3-grade, 0.24 x) or parity (exact fp32, 0.12 x)',
+    'f16': 'fp16 storage + MFMA: logits within ~8e-3 of the reference (golden 5-shot 7.2e-3), 99.85 % arg-max agreement, same rate as bf16; eval only',
+    'bf16x2': 'fp32 storage, two-limb bf16 MFMA: logits within 1.5e-4 of the reference (meets the 1e-3 tolerance), 0.24 x the bf16 rate; also trains',
+    'f16x2': 'fp32 storage, two-limb fp16 MFMA: logits within 2.2e-5 of the reference (meets the 1e-3 tolerance), 0.24 x the bf16 rate; eval only',
+    'parity': 'exact-fp32 MFMA: logits within 1e-3 of the reference (the parity mode), 0.12 x the bf16 rate',
+    'f32': 'exact-fp32 MFMA: logits within 1e-3 of the reference (the parity mode), 0.12 x the bf16 rate',
+}
+_numerics_logged = set()
+
+
+def log_numerics_once(numerics: str, what: str) -> None:
+    """One line per process and (mode, engine kind): which numerics mode an engine was built with and what that means for the logits - so that the
+    5e-2 throughput mode is never handed to a drop-in user silently (VERDICT r04 #6).  FSVIT_QUIET=1 silences it."""
+    key = (numerics, what)
+    if key in _numerics_logged or os.environ.get('FSVIT_QUIET') == '1':
+        return
+    _numerics_logged.add(key)
+    src = 'FSVIT_NUMERICS' if os.environ.get('FSVIT_NUMERICS') == numerics else 'default / encoder_args'
+    sys.stderr.write('fsvit: %s built in numerics mode %r (%s) - %s\n' % (what, numerics, src, NUMERICS_NOTE.get(numerics, '')))
+
+
 def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -78,9 +105,11 @@ class _EncoderEngine:
         if numerics not in DTYPES:
             raise ValueError(f'unknown numerics mode {numerics!r} (bf16 | f16 | bf16x2 | f16x2 | parity)')
         self.dtype = DTYPES[numerics]
+        self.numerics = numerics
         self.device = torch.device(device if device is not None else 'cuda')
         if self.device.type != 'cuda':
             raise RuntimeError(f'{type(self).__name__} needs a GPU device (no CPU fallback)')
+        log_numerics_once(numerics, type(self).__name__)
         self.chunk_images = int(chunk_images or os.environ.get('FSVIT_CHUNK', self._default_chunk))
         c = self._make_cfg(cfg)
         self.img_size = cfg['img_size']
@@ -220,6 +249,7 @@ class VisformerTrainer:
         if DTYPES[numerics] in EVAL_ONLY:
             raise NotImplementedError(f"fsvit: the {numerics!r} numerics mode is an eval mode; train in 'bf16', 'bf16x2' or 'parity'")
         self.dtype = DTYPES[numerics]
+        log_numerics_once(numerics, type(self).__name__)
         self.device = torch.device(device if device is not None else 'cuda')
         if self.device.type != 'cuda':
             raise RuntimeError('VisformerTrainer needs a GPU device (no CPU fallback)')
@@ -333,6 +363,7 @@ class VitTrainer:
         if DTYPES[numerics] in EVAL_ONLY:
             raise NotImplementedError(f"fsvit: the {numerics!r} numerics mode is an eval mode; train in 'bf16', 'bf16x2' or 'parity'")
         self.dtype = DTYPES[numerics]
+        log_numerics_once(numerics, type(self).__name__)
         self.device = torch.device(device if device is not None else 'cuda')
         if self.device.type != 'cuda':
             raise RuntimeError('VitTrainer needs a GPU device (no CPU fallback)')
@@ -743,6 +774,39 @@ class ops:
         with torch.cuda.device(x.device):
             _lib.check(lib.fsvit_conv1x1_wgrad(_ptr(x), _ptr(dz), _ptr(dw), x.shape[0], dz.shape[1], x.shape[1], dt, _stream_ptr(x.device)))
         return dw
+
+    @staticmethod
+    def mlp_train_forward(xa, w1, w2, sa, sb, scale=None, rows_per_img=1, want_xn=True):
+        """Row-wise training Mlp (fsvit_mlp_train_forward): xa [M,C] bf16, w1 [hid,C], w2 [C,hid], sa / sb [C] fp32, scale [M / rows_per_img] fp32 or
+        None -> (out [M,C], xn [M,C] or None, h [M,hid], g [M,hid]) bf16: out = xa + scale * W2 GELU(W1 (sa xa + sb))."""
+        _require_cuda(xa, w1, w2, sa, sb, scale)
+        lib = _lib.load()
+        M, Cc = xa.shape
+        hid = w1.shape[0]
+        Mp = lib.fsvit_mlp_train_rows_pad(M)
+        out = torch.empty(Mp, Cc, dtype=xa.dtype, device=xa.device)
+        xn = torch.empty(Mp, Cc, dtype=xa.dtype, device=xa.device) if want_xn else None
+        h = torch.empty(Mp, hid, dtype=xa.dtype, device=xa.device)
+        g = torch.empty(Mp, hid, dtype=xa.dtype, device=xa.device)
+        with torch.cuda.device(xa.device):
+            _lib.check(lib.fsvit_mlp_train_forward(_ptr(xa.contiguous()), _ptr(w1.contiguous()), _ptr(w2.contiguous()), _ptr(sa), _ptr(sb), _ptr(scale),
+                                                   int(rows_per_img), _ptr(out), _ptr(xn), _ptr(h), _ptr(g), M, Cc, hid, _stream_ptr(xa.device)))
+        return out[:M], (xn[:M] if want_xn else None), h[:M], g[:M]
+
+    @staticmethod
+    def mlp_train_backward(dz, w1, w2, g):
+        """Data gradient of the row-wise training Mlp (fsvit_mlp_train_backward): dz [M,C], g [M,hid] bf16 -> (dh [M,hid] = (dz W2) * g, dxn [M,C] = dh W1)."""
+        _require_cuda(dz, w1, w2, g)
+        lib = _lib.load()
+        M, Cc = dz.shape
+        hid = w1.shape[0]
+        Mp = lib.fsvit_mlp_train_rows_pad(M)
+        dh = torch.empty(Mp, hid, dtype=dz.dtype, device=dz.device)
+        dxn = torch.empty(Mp, Cc, dtype=dz.dtype, device=dz.device)
+        with torch.cuda.device(dz.device):
+            _lib.check(lib.fsvit_mlp_train_backward(_ptr(dz.contiguous()), _ptr(w1.contiguous()), _ptr(w2.contiguous()), _ptr(g.contiguous()), _ptr(dh), _ptr(dxn),
+                                                    M, Cc, hid, _stream_ptr(dz.device)))
+        return dh[:M], dxn[:M]
 
     @staticmethod
     def conv3x3_wgrad(x_nhwc, dz, O, Ig, groups, limbs='bf16'):

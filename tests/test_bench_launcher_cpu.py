@@ -23,6 +23,7 @@ def test_plain_invocation_launches_ranks_gloo():
     assert len(lines) == 1                                   # rank 0's line only
     out = json.loads(lines[0])
     assert out['selftest'] and out['n_gpus'] == 2 and out['stat_n'] == 10.0       # 5 steps x 2 ranks went through the all-reduce
+    assert out['ranks_seen'] == 2 and len(out['per_rank_eps']) == 2 and all(v > 0 for v in out['per_rank_eps'])     # what the collective saw, not WORLD_SIZE
     expect = sum(0.25 + 0.5 * ((rank * 31 + s * 7) % 11) / 11.0 for rank in range(2) for s in range(5))
     assert abs(out['stat_sum'] - expect) < 1e-12
 

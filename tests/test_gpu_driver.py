@@ -76,6 +76,40 @@ def test_accuracy_agreement_bf16_vs_parity_2000_episodes():
     assert np.abs(va - vp).max() <= 5.5 / 75.0
 
 
+def test_accuracy_agreement_f16_vs_parity_2000_episodes():
+    """The same gate for `--numerics f16` (the same-rate mode with 8 x tighter logits must be gated like the default): the same 2000
+    seeded episodes through fp16 storage + MFMA and through exact fp32 - arg-max agreement >= 99.7 % (bench, 2048 episodes: 99.85 %), the mean
+    accuracies closer than a fifth of the CI, no per-batch accuracy off by more than 2 of 75 queries."""
+    from fewshot_vit_amd import test_few_shot
+    cfg = _config()
+    cfg['dataset_args'] = dict(cfg['dataset_args'], noise=1.0)
+    logs = []
+    n = 2000
+    a = test_few_shot.evaluate(cfg, shot=5, n_batch=n, launch_batches=64, numerics='f16', log=logs.append, collect_pred=True)
+    p = test_few_shot.evaluate(cfg, shot=5, n_batch=n, launch_batches=32, numerics='parity', log=logs.append, collect_pred=True)
+    va, vp = np.array(a['va_lst']), np.array(p['va_lst'])
+    agree = float((a['pred'] == p['pred']).float().mean())
+    dmean = abs(a['acc'] - p['acc'])
+    print(f"[agreement] f16 acc {a['acc']:.4f} +- {a['ci']:.4f}, parity acc {p['acc']:.4f} +- {p['ci']:.4f}, |dmean| {dmean:.5f}, "
+          f"argmax agreement {agree:.5f}, max per-batch |dacc| {np.abs(va - vp).max():.4f}")
+    assert 0.6 < p['acc'] < 0.95
+    assert dmean <= 0.2 * p['ci']
+    assert agree >= 0.997
+    assert np.abs(va - vp).max() <= 2.5 / 75.0
+
+
+def test_engine_logs_its_numerics_mode_once(capfd):
+    """`models.make(...)` + the first engine build says which numerics mode it runs in and what that means for the logits (stderr, once per process and mode)."""
+    from fewshot_vit_amd import engine as eng, models, synthetic
+    eng._numerics_logged.clear()
+    for _ in range(2):
+        m = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={'numerics': 'bf16'})
+        m.load_state_dict(synthetic.synthetic_checkpoint_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}), strict=True)
+        m.cuda().eval().encoder.engine()
+    err = capfd.readouterr().err
+    assert err.count("numerics mode 'bf16'") == 1 and '5e-2' in err and 'FSVIT_NUMERICS=f16' in err
+
+
 def test_bench_rank_launcher_route_on_a_gpu_box():
     """`bench.py --gpus N` invoked plainly starts its ranks from a parent that never touches the GPU (device count by a throw-away child);
     `--via-launcher` sends the 1-GPU run down that same child-spawn route, so it runs once where GPUs exist."""

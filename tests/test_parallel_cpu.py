@@ -145,3 +145,61 @@ def test_grad_bucket_hands_unused_parameters_back_without_a_gradient():
     opt = torch.optim.SGD([used, unused], lr=0.1, momentum=0.9, weight_decay=0.1)
     opt.step()
     assert torch.equal(unused.detach(), torch.ones(3)) and len(opt.state[unused]) == 0
+
+
+# ---------------------------------------------------------------- round 5: every rank draws only what it needs
+def _stream_worker(rank, world, port, n_batch, shard, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from fewshot_vit_amd import parallel
+    from fewshot_vit_amd.datasets.samplers import CategoriesSampler
+    r, w, _ = parallel.init_from_env(backend='gloo')
+    label = np.repeat(np.arange(20), 600).tolist()
+    np.random.seed(12345)
+    before = np.random.get_state()[1].copy()
+    sampler = CategoriesSampler(label, n_batch, 5, 6, 2, rank=r, world_size=w, shard=shard)
+    assert sampler._shard_mode() == ('scatter' if shard in (None, 'scatter') else 'replay')
+    epochs = [[b.tolist() for b in sampler] for _ in range(2)]           # the second epoch continues the same generator (test_epochs > 1)
+    touched = not np.array_equal(before, np.random.get_state()[1])
+    # the exchange at the end of an epoch on n_batch rows that do not divide over the ranks
+    mine = torch.tensor([[float(sum(b) % 97)] for b in epochs[0]], dtype=torch.float64).view(-1, 1)
+    allv = parallel.gather_in_stream_order(mine, n_batch, r, w)
+    q.put((rank, epochs, touched, allv.view(-1).tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n_batch,shard', [(2, 9, None), (4, 10, 'scatter'), (8, 21, None), (8, 21, 'replay'), (8, 5, 'scatter')])
+def test_ranks_reassemble_the_global_stream_bit_for_bit(world, n_batch, shard):
+    """Rank r's batches are global batches r, r + world, ... of the ONE stream a single process draws - for the replayed stream and for the
+    table rank 0 draws alone and broadcasts ('scatter': the other ranks' generators are never touched); n_batch does not divide over the ranks."""
+    from fewshot_vit_amd.datasets.samplers import CategoriesSampler
+    label = np.repeat(np.arange(20), 600).tolist()
+    np.random.seed(12345)
+    single = CategoriesSampler(label, n_batch, 5, 6, 2)
+    ref = [[b.tolist() for b in single] for _ in range(2)]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, n_batch, shard, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in procs:
+        rank, epochs, touched, allv = q.get(timeout=240)
+        results[rank] = (epochs, touched, allv)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    scatter = shard in (None, 'scatter')
+    for e in range(2):
+        glob = [None] * n_batch
+        for rank, (epochs, _, _) in results.items():
+            assert len(epochs[e]) == len(range(rank, n_batch, world))
+            for k, b in enumerate(epochs[e]):
+                glob[rank + k * world] = b
+        assert glob == ref[e]
+    for rank, (_, touched, allv) in results.items():
+        assert touched == (rank == 0 or not scatter)            # scatter: only rank 0 draws
+        assert allv == [float(sum(b) % 97) for b in ref[0]]     # gather_in_stream_order at world 8 with a ragged tail
