@@ -794,7 +794,7 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
   // stage 1: x += conv3(GELU(conv2_g(GELU(conv1(BN(x))))))
   const int Cg = h->hid1 / h->cfg.group;
   static const bool no_fuse = [] { const char* e = getenv("FSVIT_NO_FUSE"); return e && e[0] == '1'; }();
-  // one LDS-resident kernel per block (stage1_w4.hip / stage1_ring.hip, any map up to 20 wide); FSVIT_STAGE1_RING=0 keeps the three-launch route
+  // one LDS-resident kernel per block (stage1_w4.hip / stage1_ring.hip, any map up to 20 wide); other geometries / numerics modes and FSVIT_NO_FUSE=1 take the three-launch route
   const bool ring_ok = K(stage1_ring_supported)(dt, h->C1, h->hid1, h->cfg.group, h->H1) && h->s1.size() && h->s1[0].c2.Kw == 320;
   const bool fuse1 = !no_fuse && ring_ok && K(stage1_ring_preferred)();
   for (size_t i = 0; i < h->s1.size(); ++i) {

@@ -392,11 +392,9 @@ bool stage1_ring_supported(int dtype, int C1, int hid, int group, int H1) {
   return dtype == 1 && C1 == s1r::C1 && hid == s1r::HID && group == s1r::G && H1 >= 4 && H1 <= 20;
 }
 // The engines run the block as one launch for every supported map (stage1_w4.hip by default, this kernel under FSVIT_STAGE1_W4=0 and for the
-// training modes); FSVIT_STAGE1_RING=0 keeps the three-launch route (conv1 / grouped conv2 / conv3 through the GEMM kernels)
-bool stage1_ring_preferred() {
-  static const bool off = [] { const char* e = getenv("FSVIT_STAGE1_RING"); return e && e[0] == '0'; }();
-  return !off;
-}
+// training modes).  The three-launch route (conv1 / grouped conv2 / conv3 through the GEMM kernels) serves the geometries and numerics modes this
+// kernel does not, and FSVIT_NO_FUSE=1 (the all-general eval path); its own switch FSVIT_STAGE1_RING=0 was retired in round 5.
+bool stage1_ring_preferred() { return true; }
 
 // w1 [256][128], w2 [256][320] (columns (tap, c)), w3 [128][256]: the packed layers of the block (engine.hip pack_layer)
 int launch_stage1_ring(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, int H, int W, hipStream_t s, const void* w3s) {

@@ -593,10 +593,10 @@ int launch_stage1_w4(const void* x, void* y, const void* w1, const float* b1, co
   int wgs = n_chunks < 256 ? n_chunks : 256;              // one 4-wave workgroup per CU (156 KB of LDS)
   const int cpw = (n_chunks + wgs - 1) / wgs;
   wgs = (n_chunks + cpw - 1) / cpw;
-  static const bool pipe_off = [] { const char* e = getenv("FSVIT_STAGE1_W4_PIPE"); return e && e[0] == '0'; }();
-  static const bool sc_off = [] { const char* e = getenv("FSVIT_STAGE1_W4_PRESCALE"); return e && e[0] == '0'; }();
-  const bool sc = w3s && !pipe_off && !sc_off;
-  auto kern = pipe_off ? stage1_w4_kernel<false, false> : (sc ? stage1_w4_kernel<true, true> : stage1_w4_kernel<true, false>);
+  // (the unpipelined variant <false, false> and the FSVIT_STAGE1_W4_PIPE / _PRESCALE switches of round 4 are out of the shipped dispatch:
+  // tools/probes/variants/stage1_switches.r05.patch re-adds them for timing)
+  const bool sc = w3s != nullptr;
+  auto kern = sc ? stage1_w4_kernel<true, true> : stage1_w4_kernel<true, false>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, s1w::LDS_BYTES);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), s1w::LDS_BYTES, s, (const bf16*)x, (bf16*)y, (const bf16*)w1, b1, (const bf16*)w2, (const bf16*)(sc ? w3s : w3), M, H, W, n_chunks, cpw);

@@ -184,7 +184,7 @@ int fsvit_stage1_block(const void* x_dev, void* y_dev, const void* w1_dev, const
                        const void* w3_dev, int B, void* stream);
 /* The same block for any square token map of 4 .. 20 a side: x, y NHWC [B,H,W,128], dtype FSVIT_BF16 / FSVIT_F16; weights as above.  This is the launch the
  * engines run: stage1_w4.hip (one wave per SIMD, weights in registers / AGPRs, x and the first hidden map in pixel rings), or stage1_ring.hip (wave = channel
- * group) under FSVIT_STAGE1_W4=0; FSVIT_STAGE1_RING=0 makes the engines take the three-launch GEMM route instead. */
+ * group) under FSVIT_STAGE1_W4=0 (FSVIT_NO_FUSE=1 makes the engines take the three-launch GEMM route instead). */
 int fsvit_stage1_block_hw(const void* x_dev, void* y_dev, const void* w1_dev, const float* b1_dev, const void* w2_dev, const void* w3_dev, int B, int H, int W,
                           int dtype, void* stream);
 /* Fused Mlp of a Visformer attention block (visformer.py:146-150 with spatial_conv=False, + the residual of :262):

@@ -60,7 +60,7 @@ def test_deit_unfused_attention_switch(tmp_path):
 # (FSVIT_GEMM_TILE, FSVIT_GEMM256_X2, FSVIT_GEMM256_MIN_AI, FSVIT_ATTN_BWD_VALU) were removed; the ones below select a general kernel instead
 # of a fused one and must give the same features within the bf16 mode's own noise.
 EVAL_SWITCHES = [{'FSVIT_HALO': '0'}, {'FSVIT_STEM_CONV1': '0'}, {'FSVIT_NO_FUSE': '1'}, {'FSVIT_GEMM256': '0'}, {'FSVIT_QKV_ATTN': '0'},
-                 {'FSVIT_STAGE1_RING': '0', 'FSVIT_STAGE1_W4': '0'}, {'FSVIT_STAGE1_W4': '0'}, {'FSVIT_STAGE1_W4_PIPE': '0'}, {'FSVIT_STAGE1_W4_PRESCALE': '0'}, {'FSVIT_MLP_ROWS': '0'}, {'FSVIT_MLP_ROWS': '3'}]
+                 {'FSVIT_STAGE1_W4': '0'}, {'FSVIT_MLP_ROWS': '0'}, {'FSVIT_MLP_ROWS': '3'}]
 
 
 def test_every_eval_dispatch_switch_agrees_with_the_default_path(tmp_path):

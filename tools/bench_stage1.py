@@ -1,5 +1,5 @@
 """Times the fused stage-1 block operators: fsvit_stage1_block_hw (the engines' launch: stage1_w4.hip, or stage1_ring.hip under FSVIT_STAGE1_W4=0) or,
-with FSVIT_STAGE1_RING=0, fsvit_stage1_block (always the 16-wave kernel of stage1_ring.hip).
+with BENCH_STAGE1_RING=0, fsvit_stage1_block (always the 16-wave kernel of stage1_ring.hip).
 python tools/bench_stage1.py [images [variant.so]]"""
 import math
 import sys
@@ -26,7 +26,7 @@ import os
 if len(sys.argv) > 2:                    # a variant library (tools/build_variant.sh)
     _lib.LIB_PATH = os.path.abspath(sys.argv[2])
 lib = _lib.load()
-RING = os.environ.get('FSVIT_STAGE1_RING', '1') != '0'
+RING = os.environ.get('BENCH_STAGE1_RING', '1') != '0'
 
 
 def call():
