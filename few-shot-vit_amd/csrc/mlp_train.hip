@@ -140,16 +140,89 @@ struct MlpPairArgs {
   int M, n_tiles, rows_per_img;
 };
 
+// one 1 KiB LDS-DMA piece (64 lanes x 16 B): a VMEM instruction of this size holds the wave's issue stage for ~60 cycles, so inside the GEMM loops the
+// refill goes out one piece at a time, two MFMAs apart (mlp_rows.hip)
+__device__ __forceinline__ void mt_dma1(unsigned voff, const void* sbase, unsigned lds) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds)
+      : "memory");
+}
+
+// GELU + derivative of a PAIR of pre-activations (gelu_sig2_d, fsvit_common.h) cut into four micro-steps of 4 .. 7 VALU instructions: one wave per SIMD
+// hides about five single-issue instructions behind a 32 x 32 x 16 MFMA (MI355X_MICROARCH.md), so the 8 pairs of a chunk go out one micro-step per
+// MFMA gap instead of as a 1100-cycle block between the two GEMMs (first version) or four 270-cycle blocks behind four MFMAs (second: the matrix pipe
+// idles through all but 32 cycles of each).
+struct MtGelu { f32x2 x, u, p, s, q; };
+template <int K> __device__ __forceinline__ void mt_gelu_step(MtGelu& g, f32x2& h, f32x2& d) {
+  if constexpr (K == 0) {
+    g.u = g.x * g.x;
+    g.u[0] = fminf(g.u[0], 64.0f);
+    g.u[1] = fminf(g.u[1], 64.0f);
+    g.p = g.u * f32x2{1.0153755e-3f, 1.0153755e-3f} + f32x2{-1.0678257e-1f, -1.0678257e-1f};
+  } else if constexpr (K == 1) {
+    g.p = g.p * g.u + f32x2{-2.3011138f, -2.3011138f};
+    const f32x2 z = g.x * g.p;
+    g.s[0] = __builtin_amdgcn_exp2f(z[0]);
+    g.s[1] = __builtin_amdgcn_exp2f(z[1]);
+  } else if constexpr (K == 2) {
+    const f32x2 e = g.s + f32x2{1.0f, 1.0f};
+    g.s[0] = __builtin_amdgcn_rcpf(e[0]);
+    g.s[1] = __builtin_amdgcn_rcpf(e[1]);
+    g.q = g.u * f32x2{5.0f * 1.0153755e-3f, 5.0f * 1.0153755e-3f} + f32x2{3.0f * -1.0678257e-1f, 3.0f * -1.0678257e-1f};
+  } else {
+    g.q = (g.q * g.u + f32x2{-2.3011138f, -2.3011138f}) * f32x2{-0.69314718055994530942f, -0.69314718055994530942f};
+    d = g.s * ((g.x * (f32x2{1.0f, 1.0f} - g.s)) * g.q + f32x2{1.0f, 1.0f});
+    h = g.x * g.s;
+  }
+}
+
+// Phase structure (round 5, third version).  Per tile:   P0 | Q(0) R(0) | Q(1) R(1) | ... | Q(N-1) R(N-1),   one barrier in front of each phase:
+//   P0   : GEMM1(0)                                                  reads A(0)
+//   Q(j) : GEMM1(j+1) on two alternating accumulators (a filler between two MFMAs of ONE dependent chain costs ~43 cycles, between independent ones
+//          ~6), with mid(j) - MODE 0: the 32 GELU micro-steps of chunk j, MODE 1: the multiply by g' - , the by-product stores and the B pieces
+//          in its MFMA gaps                                           reads A(j+1)
+//   R(j) : GEMM2(j), all channel tiles against the first half of the lane's hidden units, then all against the second (consecutive MFMAs never share an
+//          accumulator), the A pieces in its gaps                     reads B(j)
+// Fragments are read D MFMAs ahead of their use (rolling, D x 32 cycles of cover for the LDS latency).
+// Weight streams (periodic - N parts per tile each -, so they run across the tiles of the persistent workgroup), NBUF buffers per stream (4 at C = 256,
+// 2 at C = 512: 128 KB).  A part is re-issued in the phase right behind the one that read its buffer: Q(j) issues B(j - 1 + NBUF) behind R(j-1), R(j)
+// issues A(j + 1 + NBUF) behind Q(j) - and Q(0) also A(NBUF) behind P0 (first thing, in one burst), so P0 and R(N-1) issue nothing.  VMEM operations per
+// phase, in program order:   Q: [Q(0): PW A pieces] PW B pieces, then NS stores + NL g' pieces      R: PW A pieces
+// and the counted waits sit right in front of the barrier whose far side reads the part ("nothing orders a ds_read behind a pending LDS-DMA except the
+// issuing wave's covering vmcnt, plus a barrier for other waves' reads", MI355X_MICROARCH.md):
+//   end of Q(j): B for R(j)     vmcnt(NS + NL + (NBUF-1) (q + r))       end of R(j): A for Q(j+1)   vmcnt((NBUF-1) (q + r))         q = PW + NS + NL, r = PW
+// (tools/probes/mlp_train_schedule_sim.py replays the queue: every read sees its part landed, no buffer is re-issued before its read, and a count larger
+// by one fails).  Q(0)'s extra pieces only make a wait stricter; R(N-1)'s missing ones sit in front of the full drain (the x loads' vmcnt(0)) at the
+// next tile start.
+// MODE 1's multipliers g' never pass through registers on their way in: each wave LDS-DMAs its own 32 rows x 32 units of g'(j+2) into one of two 2 KiB
+// slots right behind the multiply that read g'(j) from it (an asynchronous VGPR load carried around the loop back edge can be copied by the register
+// allocator before it lands - the second version's wrong rows at more than one tile per workgroup), and reads it back lane for lane after its own
+// counted vmcnt (its own data: no barrier needed).
 template <int C, int HID, int MODE>
 __global__ __launch_bounds__(256, 1) void mlp_pair_kernel(const MlpPairArgs a) {
   constexpr int NKS = C / 16, NCT = C / 32, NCH = HID / 32;
   constexpr int PART = NKS * 1024;                 // one chunk of one image: NKS fragments
   constexpr int PW = NKS / MT_NW;                  // LDS-DMA pieces per wave and part
-  constexpr int NL = MODE == 1 ? 2 : 0;            // g' loads per chunk
+  constexpr int NBUF = C == 256 ? 4 : 2;           // buffers per stream
+  constexpr int D = C == 256 ? 6 : 4;              // fragments read ahead
+  constexpr int NL = MODE == 1 ? 2 : 0;            // g' pieces per chunk
   constexpr int NS = MODE == 1 ? 2 : 4;            // by-product stores per chunk
-  static_assert(NCH % 2 == 0 && (PW == 4 || PW == 8), "shapes");
+  constexpr int QOPS = PW + NS + NL, ROPS = PW;
+  constexpr int WAIT_Q = NS + NL + (NBUF - 1) * (QOPS + ROPS);
+  constexpr int WAIT_R = (NBUF - 1) * (QOPS + ROPS);
+  constexpr int WAIT_G = 2 * ROPS + QOPS + PW;     // MODE 1, in front of g'(j)'s read in Q(j): behind its pieces (the last operations of Q(j-2)) came R(j-2), Q(j-1), R(j-1) and Q(j)'s B pieces
+  constexpr int DSTEP = 2;                         // MFMA slots between two DMA pieces
+  constexpr int GOFF = 2 * NBUF * PART;            // MODE 0: tables; MODE 1: the g' slots [2][4 waves][2 KiB]
+  static_assert(NCH % 2 == 0 && (PW == 4 || PW == 8) && WAIT_Q < 64 && WAIT_R < 64 && WAIT_G < 64 && DSTEP * PW <= NKS / 2, "shapes");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* const b1tab = reinterpret_cast<float*>(smem + 4 * PART);
+  float* const b1tab = reinterpret_cast<float*>(smem + GOFF);
   float* const satab = b1tab + HID;
   float* const sbtab = satab + C;
 
@@ -166,18 +239,22 @@ __global__ __launch_bounds__(256, 1) void mlp_pair_kernel(const MlpPairArgs a) {
       for (int i = t; i < C; i += 256) { satab[i] = a.sa[i]; sbtab[i] = a.sb[i]; }
   }
 
-  int nextA = 0, nextB = 0;       // next chunk (mod NCH) to issue; the buffer is its parity
-  auto issueA = [&]() {
-    mt_dma<PW>(voff, a.imgA + (size_t)nextA * PART, lds0 + (nextA & 1) * PART + wave * PW * 1024);
-    nextA = nextA == NCH - 1 ? 0 : nextA + 1;
-  };
-  auto issueB = [&]() {
-    mt_dma<PW>(voff, a.imgB + (size_t)nextB * PART, lds0 + (2 + (nextB & 1)) * PART + wave * PW * 1024);
-    nextB = nextB == NCH - 1 ? 0 : nextB + 1;
-  };
-  issueA();
-  issueB();
-  issueA();
+  // stream state (wave-uniform): content index and buffer of the next part to issue / to read
+  int aIssC = 0, aIssB = 0, bIssC = 0, bIssB = 0, aRdB = 0, bRdB = 0;
+  auto a_src = [&]() { return a.imgA + (size_t)aIssC * PART; };
+  auto a_dst = [&]() { return lds0 + aIssB * PART + wave * PW * 1024; };
+  auto a_adv = [&]() { aIssC = aIssC == NCH - 1 ? 0 : aIssC + 1; aIssB = aIssB == NBUF - 1 ? 0 : aIssB + 1; };
+  auto b_src = [&]() { return a.imgB + (size_t)bIssC * PART; };
+  auto b_dst = [&]() { return lds0 + (NBUF + bIssB) * PART + wave * PW * 1024; };
+  auto b_adv = [&]() { bIssC = bIssC == NCH - 1 ? 0 : bIssC + 1; bIssB = bIssB == NBUF - 1 ? 0 : bIssB + 1; };
+  auto issueA_all = [&]() { mt_dma<PW>(voff, a_src(), a_dst()); a_adv(); };
+  auto issueB_all = [&]() { mt_dma<PW>(voff, b_src(), b_dst()); b_adv(); };
+  auto issueA_piece = [&](int pc) { mt_dma1(voff + pc * 1024, a_src(), a_dst() + pc * 1024); if (pc == PW - 1) a_adv(); };
+  auto issueB_piece = [&](int pc) { mt_dma1(voff + pc * 1024, b_src(), b_dst() + pc * 1024); if (pc == PW - 1) b_adv(); };
+#pragma unroll
+  for (int i = 0; i < NBUF; ++i) issueA_all();
+#pragma unroll
+  for (int i = 0; i < NBUF - 1; ++i) issueB_all();
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   mt_bar();
 
@@ -185,132 +262,162 @@ __global__ __launch_bounds__(256, 1) void mlp_pair_kernel(const MlpPairArgs a) {
     const int m = tile * MT_BM + wave * 32 + r;
     const int mrow = m < a.M ? m : a.M - 1;
     const bf16* xrow = a.X + (size_t)mrow * C + 16 * kh;
-    bf16* const hrow = a.H + (size_t)m * HID + 16 * kh;                     // (padded rows exist)
-    const bf16* const glrow = a.G + (size_t)mrow * HID + 16 * kh;           // MODE 1: read
-    bf16* const gsrow = a.G + (size_t)m * HID + 16 * kh;                    // MODE 0: written
+    bf16* hrow = a.H + (size_t)m * HID + 16 * kh;                     // (padded rows exist)
+    bf16* gsrow = a.G + (size_t)m * HID + 16 * kh;                    // MODE 0: written
+    // MODE 1: this lane's g' run of chunk j, half h = a.G + goff + (32 j + 8 h) elements; slot sl of this wave at smem + GOFF + (sl * 4 + wave) * 2048
+    const unsigned goff = (unsigned)(((size_t)mrow * HID + 16 * kh) * 2);
+    auto issueG = [&](const int j, const int sl) {
+      const unsigned dst = lds0 + GOFF + (sl * MT_NW + wave) * 2048;
+      mt_dma1(goff, a.G + 32 * j, dst);
+      mt_dma1(goff, a.G + 32 * j + 8, dst + 1024);
+    };
     u32x4 xr[NKS];
     [&]<int... S>(std::integer_sequence<int, S...>) { ((xr[S] = mt_gload16<(32 * (S >> 1) + 8 * (S & 1)) * 2>(xrow)), ...); }(std::make_integer_sequence<int, NKS>{});
-    u32x4 gl[2];                  // MODE 1: g' of the next chunk (one buffer: reloaded right behind the multiply that consumed it)
-    if constexpr (MODE == 1) {
-      gl[0] = mt_gload16<0>(glrow);
-      gl[1] = mt_gload16<16>(glrow);
-    }
+    if constexpr (MODE == 1) { issueG(0, 0); issueG(1, 1); }
     // one drain per tile: everything older (DMAs, the previous tile's stores) has long landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int s = 0; s < NKS; s += 4) asm volatile("" : "+v"(xr[s]), "+v"(xr[s + 1]), "+v"(xr[s + 2]), "+v"(xr[s + 3]) :: "memory");
-    if constexpr (MODE == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(gl[0]), "+v"(gl[1]) :: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int s = 0; s < NKS; s += 4) asm volatile("" : "+v"(xr[s]), "+v"(xr[s + 1]), "+v"(xr[s + 2]), "+v"(xr[s + 3]) :: "memory");
+    mt_bar();                     // (parts issued by every wave: wait, barrier, P0's barrier, read)
 
     f32x16 yacc[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) mt_zero_a(yacc[ct]);
 
+    f32x16 hacc[2];
+    u32x4 hp[2];
+    // GEMM1 of one chunk into `acc` (+ `acc2`, summed at the end) from the A buffer being read; `slot(s)` runs behind MFMA s
+    auto gemm1 = [&](f32x16& acc, auto&& slot) {
+      const unsigned char* const fa = smem + aRdB * PART + lane * 16;
+      u32x4 fr[D];
+      f32x16 acc2;
+#pragma unroll
+      for (int q = 0; q < D; ++q) fr[q] = *reinterpret_cast<const u32x4*>(fa + q * 1024);
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+        if (s == 0) mt_mfma_v_z(fr[0], xr[0], acc);
+        else if (s == 1) mt_mfma_v_z(fr[1 % D], xr[1], acc2);
+        else if (s & 1) mt_mfma_v(fr[s % D], xr[s], acc2);
+        else mt_mfma_v(fr[s % D], xr[s], acc);
+        if (s + D < NKS) fr[s % D] = *reinterpret_cast<const u32x4*>(fa + (s + D) * 1024);
+        slot(s);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc), "+v"(acc2));      // wait states MFMA -> VALU read
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
+      aRdB = aRdB == NBUF - 1 ? 0 : aRdB + 1;
+    };
+    // ---- mid (j) in the gaps of Q (j)
+    MtGelu gs[8];
+    f32x2 gh[8], gd[8];
+    // MODE 0: micro-step tt (0 .. 31) of chunk j: pair tt / 4 (hidden units 2 (tt / 4), + 1 of the lane's 16), step tt % 4; a half is packed and stored behind its last step
+    auto gelu_ms = [&](const f32x16& hc, const int j, auto ttc) {
+      constexpr int tt = decltype(ttc)::value, pr = tt >> 2, k = tt & 3;
+      if constexpr (k == 0) {
+        const f32x2 bq = *reinterpret_cast<const f32x2*>(b1tab + 32 * j + 16 * kh + 2 * pr);
+        gs[pr].x = f32x2{hc[2 * pr] + bq[0], hc[2 * pr + 1] + bq[1]};
+      }
+      mt_gelu_step<k>(gs[pr], gh[pr], gd[pr]);
+      if constexpr (tt == 15 || tt == 31) {
+        constexpr int hf = tt == 31, p0 = 4 * hf;
+        const float hv[8] = {gh[p0][0], gh[p0][1], gh[p0 + 1][0], gh[p0 + 1][1], gh[p0 + 2][0], gh[p0 + 2][1], gh[p0 + 3][0], gh[p0 + 3][1]};
+        const float dv[8] = {gd[p0][0], gd[p0][1], gd[p0 + 1][0], gd[p0 + 1][1], gd[p0 + 2][0], gd[p0 + 2][1], gd[p0 + 3][0], gd[p0 + 3][1]};
+        hp[hf] = mt_pack8(hv);
+        mt_gstore16<16 * hf>(hrow + 32 * j, hp[hf]);
+        mt_gstore16<16 * hf>(gsrow + 32 * j, mt_pack8(dv));
+      }
+    };
+    // MODE 1: half hf of chunk j: dh = hacc * g' (g' from this wave's LDS slot), packed and stored; behind the second half the slot is refilled with g'(j+2)
+    auto mul_half = [&](const f32x16& hc, const int j, auto hfc) {
+      constexpr int hf = decltype(hfc)::value;
+      const unsigned char* const gsl = smem + GOFF + ((j & 1) * MT_NW + wave) * 2048 + lane * 16;
+      if constexpr (hf == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT_G) : "memory");
+      const bf16x8 g8 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(gsl + hf * 1024));
+      float hv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) hv[i] = hc[8 * hf + i] * (float)g8[i];
+      hp[hf] = mt_pack8(hv);
+      mt_gstore16<16 * hf>(hrow + 32 * j, hp[hf]);
+      if constexpr (hf == 1) {
+        asm volatile("" :: "v"(hp[0]), "v"(hp[1]) : "memory");         // (both halves of the slot have been read: the multiplies above consumed them)
+        issueG(j + 2 < NCH ? j + 2 : j + 2 - NCH, j & 1);              // (the last two refills are dummies: counts stay uniform)
+      }
+    };
+    // what runs behind MFMA slot s of Q(j)'s GEMM1 (for the last chunk: on its own): the B pieces in the first half (DSTEP slots apart; every store /
+    // g' piece of the phase is issued behind the last of them - the order the wait counts assume), the steps of mid (j) spread over all slots
+    auto q_slot = [&](const f32x16& hc, const int j, auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s % DSTEP == 0 && s / DSTEP < PW) issueB_piece(s / DSTEP);
+      if constexpr (MODE == 0) {
+        constexpr int MS = 32 / NKS;          // micro-steps per slot: 2 at C = 256, 1 at C = 512
+        gelu_ms(hc, j, std::integral_constant<int, MS * s>{});
+        if constexpr (MS == 2) gelu_ms(hc, j, std::integral_constant<int, MS * s + 1>{});
+      } else {
+        if constexpr (s == NKS / 2) mul_half(hc, j, std::integral_constant<int, 0>{});
+        if constexpr (s == 3 * NKS / 4) mul_half(hc, j, std::integral_constant<int, 1>{});
+      }
+    };
+    auto q_slots_alone = [&](const f32x16& hc, const int j) {
+      [&]<int... S>(std::integer_sequence<int, S...>) { ((q_slot(hc, j, std::integral_constant<int, S>{}), __builtin_amdgcn_sched_barrier(0)), ...); }(std::make_integer_sequence<int, NKS>{});
+    };
+
+    // ---------------- P0: GEMM1 (0)   (everything in flight was drained at the tile start; nothing is issued here)
+    mt_bar();
+    gemm1(hacc[0], [&](int) {});
+
     auto chunk = [&](const int j, auto parity) {
       constexpr int P = decltype(parity)::value;
-      const unsigned char* const fa = smem + P * PART + lane * 16;
-      const unsigned char* const fb = smem + (2 + P) * PART + lane * 16;
-      // ---------------- phase 1: GEMM1 (j)
+      // ---------------- Q (j): GEMM1 (j+1) -> hacc[1 - P]  ||  mid (j) on hacc[P]
       mt_bar();
-      issueB();
-      f32x16 hacc;
-      {     // fragments are read one group of 4 ahead of the MFMAs that consume them (left alone, hipcc hoists all NKS reads: 128 VGPRs at C = 512, spills)
-        constexpr int FG = C == 512 ? 2 : 4;       // (C = 512 has 128 x + 256 y registers: 16 fragment registers instead of 32)
-        u32x4 fr[2][FG];
+      if (j == 0) issueA_all();                          // the buffer P0 read
+      if (j + 1 < NCH) {
+        const unsigned char* const fa = smem + aRdB * PART + lane * 16;
+        f32x16& acc = hacc[1 - P];
+        u32x4 fr[D];
+        f32x16 acc2;
 #pragma unroll
-        for (int q = 0; q < FG; ++q) fr[0][q] = *reinterpret_cast<const u32x4*>(fa + q * 1024);
+        for (int q = 0; q < D; ++q) fr[q] = *reinterpret_cast<const u32x4*>(fa + q * 1024);
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+          (([&] {
+             if constexpr (S == 0) mt_mfma_v_z(fr[0], xr[0], acc);
+             else if constexpr (S == 1) mt_mfma_v_z(fr[1 % D], xr[1], acc2);
+             else if constexpr (S & 1) mt_mfma_v(fr[S % D], xr[S], acc2);
+             else mt_mfma_v(fr[S % D], xr[S], acc);
+             if constexpr (S + D < NKS) fr[S % D] = *reinterpret_cast<const u32x4*>(fa + (S + D) * 1024);
+             q_slot(hacc[P], j, std::integral_constant<int, S>{});
+             __builtin_amdgcn_sched_barrier(0);
+           }()),
+           ...);
+        }(std::make_integer_sequence<int, NKS>{});
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc), "+v"(acc2));      // wait states MFMA -> VALU read
 #pragma unroll
-        for (int g = 0; g < NKS / FG; ++g) {
-          if (g + 1 < NKS / FG) {
+        for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
+        aRdB = aRdB == NBUF - 1 ? 0 : aRdB + 1;
+      } else {
+        q_slots_alone(hacc[P], j);
+      }
+      mt_settle_b(hp[0], hp[1]);
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT_Q) : "memory");
+      // ---------------- R (j): GEMM2 (j)
+      mt_bar();
+      {
+        const unsigned char* const fb = smem + (NBUF + bRdB) * PART + lane * 16;
+        // iteration order (half s2 outer, channel tile ct inner); the image holds fragment (ct, s2) at index 2 ct + s2
+        auto fidx = [](int it) { return 2 * (it % NCT) + it / NCT; };
+        u32x4 fr[D];
 #pragma unroll
-            for (int q = 0; q < FG; ++q) fr[(g + 1) & 1][q] = *reinterpret_cast<const u32x4*>(fa + (FG * (g + 1) + q) * 1024);
-          }
+        for (int q = 0; q < D; ++q) fr[q] = *reinterpret_cast<const u32x4*>(fb + fidx(q) * 1024);
 #pragma unroll
-          for (int q = 0; q < FG; ++q) {
-            if (g == 0 && q == 0) mt_mfma_v_z(fr[0][0], xr[0], hacc);
-            else mt_mfma_v(fr[g & 1][q], xr[FG * g + q], hacc);
-          }
+        for (int it = 0; it < NKS; ++it) {
+          mt_mfma_a(fr[it % D], hp[it / NCT], yacc[it % NCT]);
+          if (it + D < NKS) fr[it % D] = *reinterpret_cast<const u32x4*>(fb + fidx(it + D) * 1024);
+          if (j + 1 < NCH && it % DSTEP == 0 && it / DSTEP < PW) issueA_piece(it / DSTEP);
           __builtin_amdgcn_sched_barrier(0);
         }
-        mt_settle_v(hacc);
+        bRdB = bRdB == NBUF - 1 ? 0 : bRdB + 1;
       }
-      // A (j+1) has landed (issued a phase ago; behind it in the queue: B (j+1)) - and with it this chunk's g' (older)
-      if constexpr (MODE == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(gl[0]), "+v"(gl[1]) : "n"(PW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory");
-      // ---------------- phase 2: mid (j), GEMM2 (j)
-      mt_bar();
-      u32x4 hp[2];
-      if constexpr (MODE == 0) {
-        // (one half of the lane's 16 hidden units at a time, each stored as soon as it is packed: the C = 512 variant has 256 - 128 (x) VGPRs for everything)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          float hv[8], dv[8];
-#pragma unroll
-          for (int i = 0; i < 8; i += 4) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(b1tab + 32 * j + 16 * kh + 8 * hf + i);
-            f32x2 d0, d1;
-            const f32x2 h0 = gelu_sig2_d(f32x2{hacc[8 * hf + i] + b[0], hacc[8 * hf + i + 1] + b[1]}, d0);
-            const f32x2 h1 = gelu_sig2_d(f32x2{hacc[8 * hf + i + 2] + b[2], hacc[8 * hf + i + 3] + b[3]}, d1);
-            hv[i] = h0[0]; hv[i + 1] = h0[1]; hv[i + 2] = h1[0]; hv[i + 3] = h1[1];
-            dv[i] = d0[0]; dv[i + 1] = d0[1]; dv[i + 2] = d1[0]; dv[i + 3] = d1[1];
-          }
-          hp[hf] = mt_pack8(hv);
-          if (hf == 0) { mt_gstore16<0>(hrow + 32 * j, hp[0]); mt_gstore16<0>(gsrow + 32 * j, mt_pack8(dv)); }
-          else { mt_gstore16<16>(hrow + 32 * j, hp[1]); mt_gstore16<16>(gsrow + 32 * j, mt_pack8(dv)); }
-        }
-      } else {
-        float hv[16];
-        const bf16x8 g0 = __builtin_bit_cast(bf16x8, gl[0]), g1 = __builtin_bit_cast(bf16x8, gl[1]);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { hv[i] = hacc[i] * (float)g0[i]; hv[8 + i] = hacc[8 + i] * (float)g1[i]; }
-        hp[0] = mt_pack8(hv);
-        hp[1] = mt_pack8(hv + 8);
-        mt_gstore16<0>(hrow + 32 * j, hp[0]);
-        mt_gstore16<16>(hrow + 32 * j, hp[1]);
-        asm volatile("" :: "v"(hp[0]), "v"(hp[1]) : "memory");         // (the multiply above has consumed gl)
-        const int jn = j + 1 < NCH ? j + 1 : 0;       // (the last chunk's prefetch is a dummy: counts stay uniform)
-        gl[0] = mt_gload16<0>(glrow + 32 * jn);
-        gl[1] = mt_gload16<16>(glrow + 32 * jn);
-      }
-      issueA();
-      mt_settle_b(hp[0], hp[1]);
-      {
-        if constexpr (C == 512) {
-          u32x4 fr[2][2];
-#pragma unroll
-          for (int q = 0; q < 2; ++q) fr[0][q] = *reinterpret_cast<const u32x4*>(fb + q * 1024);
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) {
-            if (ct + 1 < NCT) {
-#pragma unroll
-              for (int q = 0; q < 2; ++q) fr[(ct + 1) & 1][q] = *reinterpret_cast<const u32x4*>(fb + (2 * (ct + 1) + q) * 1024);
-            }
-            mt_mfma_a(fr[ct & 1][0], hp[0], yacc[ct]);
-            mt_mfma_a(fr[ct & 1][1], hp[1], yacc[ct]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        } else {
-          u32x4 fr[2][4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) fr[0][q] = *reinterpret_cast<const u32x4*>(fb + q * 1024);
-#pragma unroll
-          for (int g = 0; g < NCT / 2; ++g) {
-            if (g + 1 < NCT / 2) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) fr[(g + 1) & 1][q] = *reinterpret_cast<const u32x4*>(fb + (4 * (g + 1) + q) * 1024);
-            }
-            // two independent accumulators alternate
-            mt_mfma_a(fr[g & 1][0], hp[0], yacc[2 * g]);
-            mt_mfma_a(fr[g & 1][2], hp[0], yacc[2 * g + 1]);
-            mt_mfma_a(fr[g & 1][1], hp[1], yacc[2 * g]);
-            mt_mfma_a(fr[g & 1][3], hp[1], yacc[2 * g + 1]);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-      }
-      // B (j+1) has landed (behind it: this chunk's stores, the g' prefetch, A (j+2))
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NS + NL + PW) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAIT_R) : "memory");
     };
     for (int j = 0; j < NCH; j += 2) {
       chunk(j, std::integral_constant<int, 0>{});
@@ -400,6 +507,14 @@ __global__ __launch_bounds__(256) void mlp_fold_pack_kernel(const float* __restr
 }
 
 bool mlp_train_supported(int dtype, int C, int hid) { return dtype == 1 && ((C == 256 && hid == 1024) || (C == 512 && hid == 2048)); }
+// Which shapes the trainer routes through this kernel.  Measured at 800 images (profiles/r05_mlp_train_*): stage 2 (C = 256, 80 000 rows, 625 tiles) 205 us
+// forward / 155 us data gradient against 190 / 147 us for the launches it replaces - a draw that removes 164 MB of re-reads and 3 launches per block;
+// stage 3 (C = 512, 20 000 rows = 157 tiles on 256 CUs, 4 MB of weight images against the 4 MB L2 of an XCD) 180 / 135 us against 145 / 100 us - a
+// loss, so stage 3 keeps its two gemm256 launches unless FSVIT_MLP_TRAIN_FUSED=2 asks for the kernel at both stages.
+bool mlp_train_preferred(int C, int hid) {
+  static const int mode = [] { const char* e = getenv("FSVIT_MLP_TRAIN_FUSED"); return e ? atoi(e) : 1; }();
+  return mode == 2 || (mode == 1 && C == 256 && hid == 1024);
+}
 int mlp_train_rows_pad(int M) { return (M + MT_BM - 1) / MT_BM * MT_BM; }
 size_t mlp_train_image_bytes(int C, int hid) { return (size_t)C * hid * 2; }
 
@@ -412,7 +527,7 @@ int launch_mlp_fold_pack(const float* W1, const float* sa, const float* sb, void
 
 template <int C, int HID, int MODE>
 static int mlp_pair_launch(const MlpPairArgs& a, hipStream_t s) {
-  constexpr size_t lds = (size_t)4 * (C / 16) * 1024 + (size_t)(HID + 2 * C) * 4;
+  constexpr size_t lds = (size_t)2 * (C == 256 ? 4 : 2) * (C / 16) * 1024 + (MODE == 0 ? (size_t)(HID + 2 * C) * 4 : (size_t)2 * MT_NW * 2048);
   static_assert(lds <= 160 * 1024, "LDS");
   static bool once = false;
   if (!once) {

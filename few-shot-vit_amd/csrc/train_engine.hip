@@ -675,9 +675,9 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
       const std::string p = "stage" + std::to_string(sg) + "." + std::to_string(i) + ".";
       b.x = xcur;
       // Round 5: the Mlp branch as ONE row-wise launch behind norm2's statistics (mlp_train.hip MODE 0: BatchNorm folded into fc1, GELU + derivative, fc2,
-      // DropPath-scaled residual; xn2 / h / g' as by-products) - its outputs are padded to whole 128-row tiles.  FSVIT_MLP_TRAIN_FUSED=0: two gemm256 launches.
-      static const bool mlp_off = [] { const char* e = getenv("FSVIT_MLP_TRAIN_FUSED"); return e && e[0] == '0'; }();
-      const bool mlp_fused = !mlp_off && t->gdt == 1 && mlp_train_supported(t->gdt, C, hid);
+      // DropPath-scaled residual; xn2 / h / g' as by-products) - its outputs are padded to whole 128-row tiles.  Stage 2 only by default (mlp_train_preferred);
+      // FSVIT_MLP_TRAIN_FUSED=0: two gemm256 launches everywhere, =2: the kernel at both stages.
+      const bool mlp_fused = t->gdt == 1 && mlp_train_supported(t->gdt, C, hid) && mlp_train_preferred(C, hid);
       const size_t Mp = mlp_fused ? (size_t)mlp_train_rows_pad((int)M) : M;
       NEED(b.xn1 = take_act(t, M * C)); NEED(b.qkv = take_act(t, M * 3 * heads * hdp)); NEED(b.ctx = take_act(t, M * heads * hdp));
       NEED(b.xa = take_act(t, M * C)); NEED(b.xn2 = take_act(t, Mp * C)); NEED(b.z1 = take_act(t, Mp * hid)); NEED(b.h = take_act(t, Mp * hid));
@@ -763,8 +763,7 @@ int train_backward_impl(TR* t, const float* dfeat) {
       void* dz2 = take_tmp(t, M * C); NEED(dz2);
       if (i == (int)blocks.size() - 1) { T_TRY(side_guard(t, dz2, M * C * t->es)); T_RUN(launch_add_scaled(nullptr, dx, b.s2, dz2, M * C, (size_t)Ho * Ho * C, dt, st)); }
       T_TRY(conv_bwd_weight(t, cs.fc2, b.h, B, Ho, Ho, dz2));
-      static const bool mlp_off = [] { const char* e = getenv("FSVIT_MLP_TRAIN_FUSED"); return e && e[0] == '0'; }();
-      const bool mlp_fused = !mlp_off && t->gdt == 1 && mlp_train_supported(t->gdt, C, hid);
+      const bool mlp_fused = t->gdt == 1 && mlp_train_supported(t->gdt, C, hid) && mlp_train_preferred(C, hid);
       const size_t Mp = mlp_fused ? (size_t)mlp_train_rows_pad((int)M) : M;
       void* dh = take_tmp(t, Mp * hid); NEED(dh);
       void* dxn2 = nullptr;

@@ -103,6 +103,7 @@ int launch_vit_cls_ln_bwd(const float* dfeat, const void* tokens, const float* m
 // rows / k of the A operand; the forward's first image comes from launch_mlp_fold_pack (norm2's batch statistics folded into W1).
 // Every output has room for mlp_train_rows_pad(M) rows.
 bool mlp_train_supported(int dtype, int C, int hid);
+bool mlp_train_preferred(int C, int hid);      // FSVIT_MLP_TRAIN_FUSED: 0 never, 1 (default) stage 2 only, 2 both stages
 int mlp_train_rows_pad(int M);
 size_t mlp_train_image_bytes(int C, int hid);
 int launch_mlp_fold_pack(const float* W1, const float* sa, const float* sb, void* imgA, float* b1f, int C, int hid, hipStream_t s);

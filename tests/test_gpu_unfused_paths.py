@@ -99,7 +99,7 @@ def test_every_training_dispatch_switch_agrees_with_the_default_path(tmp_path):
         return torch.load(out)
     base = run({}, 'base')
     for i, env in enumerate([{'FSVIT_WGRAD3X3': '0'}, {'FSVIT_WGRAD1X1': '0'}, {'FSVIT_GCONV3X3': '0'}, {'FSVIT_WGRAD_SIDE_STREAM': '0'}, {'FSVIT_BN_ROWS': '0'}, {'FSVIT_STAGE1_TRAIN_FUSED': '0'},
-                             {'FSVIT_STAGE1_BLOCK_FUSED': '0'}, {'FSVIT_BN_PRODUCER_STATS': '0'}, {'FSVIT_MLP_TRAIN_FUSED': '0'},
+                             {'FSVIT_STAGE1_BLOCK_FUSED': '0'}, {'FSVIT_BN_PRODUCER_STATS': '0'}, {'FSVIT_MLP_TRAIN_FUSED': '0'}, {'FSVIT_MLP_TRAIN_FUSED': '2'},
                              {'FSVIT_STAGE1_TRAIN_FUSED': '0', 'FSVIT_GCONV3X3': '0'}]):      # (the grouped-conv kernel only runs on the three-launch route)
         other = run(env, f'tr{i}')
         # (the bias of a PatchEmbed conv and of its BatchNorm have a structurally ZERO gradient - every consumer of the residual stream starts with a
