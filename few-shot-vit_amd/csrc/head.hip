@@ -104,7 +104,9 @@ __global__ __launch_bounds__(NT) void proto_head_kernel(const float* __restrict_
       float se = 0.f;
       for (int c = 0; c < way; ++c) se += expf(lrow[c] - mx);
       qstat[q * 2 + 0] = (arg == label) ? 1.0f : 0.0f;
-      qstat[q * 2 + 1] = mx + logf(se) - lab_logit;
+      // a label outside [0, way) - including F.cross_entropy's ignore_index = -100, which this head does not implement - poisons the episode's loss
+      // (and with it the batch mean) instead of silently scoring the query against no class (the ATen path this replaces raises)
+      qstat[q * 2 + 1] = (label >= 0 && label < way) ? mx + logf(se) - lab_logit : __builtin_nanf("");
       if (dlogits) {      // d(mean cross entropy over all E * Q rows) / dlogits = (softmax - onehot) / (E * Q)   (F.cross_entropy, train_meta.py:168)
         const float inv_rows = 1.0f / ((float)gridDim.x * (float)Q), inv_se = 1.0f / se;
         float* drow = dlogits + ((size_t)e * Q + q) * way;

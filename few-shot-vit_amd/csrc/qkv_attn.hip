@@ -204,11 +204,14 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
           } else if (tokbase + 16 * tt >= TOKK) {
             // token tile beyond the 112 key rows kept (never valid for S <= 112): no K / V^T entry
           } else if (p == 1) {      // k positions: chunk 0 = (tile 0 rows 4 lq.. | tile 1 rows 4 lq..) per lq, chunk 1 = (tile 2 rows | zeros)
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-              const u32x2 o = {qa_pk2(acc[c][tt][0], acc[c][tt][1]), qa_pk2(acc[c][tt][2], acc[c][tt][3])};
-              *reinterpret_cast<u32x2*>(Ks + tok * KS + (c == 2 ? 64 : 8 * c) + 16 * lq) = o;
-            }
+            // Round 5: the 16-byte column of a row is XORed with bit 2 of the row (KSW): the 8-byte stores of the first version put the 16 rows of a
+            // store group on 4 bank positions (row stride 40 dwords = 8 mod 32: 4-way, 21.8 % of the kernel's LDS cycles were conflicts,
+            // profiles/r04_mfma_pmc.txt); rows m and m + 4 now sit one column apart, the two tiles of chunk 0 go out as ONE 16-byte store
+            // (conflict-free in its 8-lane groups), and the b128 reads of the score product stay conflict-free (bank sets checked in tools/lds_conflicts.py)
+            const int ksw = 16 * (lq ^ ((m >> 2) & 1));
+            *reinterpret_cast<u32x4*>(Ks + tok * KS + ksw) = u32x4{qa_pk2(acc[0][tt][0], acc[0][tt][1]), qa_pk2(acc[0][tt][2], acc[0][tt][3]),
+                                                                   qa_pk2(acc[1][tt][0], acc[1][tt][1]), qa_pk2(acc[1][tt][2], acc[1][tt][3])};
+            *reinterpret_cast<u32x2*>(Ks + tok * KS + 64 + ksw) = u32x2{qa_pk2(acc[2][tt][0], acc[2][tt][1]), qa_pk2(acc[2][tt][2], acc[2][tt][3])};
           } else {                  // rows = tokens tokbase + 16 tt + 4 lq + e of channel 16 c + m
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(qa::NW * 64) void qkv_attn_kernel(const bf16* __res
         f32x4 sc[TT][NKT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
-          const unsigned char* ka = Ks + (kt * 16 + m) * KS + lq * 16;
+          const unsigned char* ka = Ks + (kt * 16 + m) * KS + 16 * (lq ^ ((m >> 2) & 1));        // (the store's column swizzle)
           const u32x4 k0 = *reinterpret_cast<const u32x4*>(ka), k1 = *reinterpret_cast<const u32x4*>(ka + 64);
 #pragma unroll
           for (int tt = 0; tt < TT; ++tt) {

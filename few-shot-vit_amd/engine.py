@@ -860,8 +860,10 @@ class ops:
 
     @staticmethod
     def _ticket(dev):
-        """Two zeroed device words per device (forward / backward of the fused CE head; the kernels leave them at zero)."""
-        key = (dev.type, dev.index)
+        """Two zeroed device words per (device, STREAM): forward / backward of the fused CE head count their workgroups on them and leave them at
+        zero.  Launches on one stream are ordered; two models stepping on different streams each get their own pair (one pair per device
+        let concurrent launches race on the counter)."""
+        key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream)
         if key not in ops._tickets:
             ops._tickets[key] = torch.zeros(2, dtype=torch.int32, device=dev)
         return ops._tickets[key]
@@ -877,7 +879,7 @@ class ops:
         dev = feat_shot.device
         logits = torch.empty(E, Q, way, dtype=torch.float32, device=dev)
         dlogits = torch.empty(E, Q, way, dtype=torch.float32, device=dev)
-        stats = torch.empty(2 + 2 * E, dtype=torch.float32, device=dev)
+        stats = torch.full((2 + 2 * E,), float('nan'), dtype=torch.float32, device=dev)      # (a skipped final reduction must not read as a loss)
         m = {'cos': _lib.HEAD_COS, 'sqr': _lib.HEAD_SQR, 'dot': _lib.HEAD_DOT}[method]
         if label is not None:
             if label.dtype != torch.int64 or not label.is_cuda or label.numel() != E * Q:

@@ -324,6 +324,32 @@ def test_fused_head_cross_entropy_vs_torch(method, labels):
     assert int(ops._ticket(torch.device('cuda', torch.cuda.current_device())).abs().sum()) == 0
 
 
+def test_fused_head_flags_labels_outside_the_way_range_and_keeps_a_ticket_per_stream():
+    """a label outside [0, way) - F.cross_entropy's ignore_index included - makes the fused head's loss NaN (the ATen path raises; a silent
+    `logsumexp - 0` would train on garbage); two streams get two ticket pairs."""
+    from fewshot_vit_amd.engine import ops
+    E, way, shot, Q, D = 2, 5, 1, 10, 64
+    g = torch.Generator().manual_seed(3)
+    fs_, fq = torch.randn(E, way, shot, D, generator=g).cuda(), torch.randn(E, Q, D, generator=g).cuda()
+    good = torch.arange(way).repeat_interleave(Q // way).repeat(E).cuda()
+    _, _, st = ops.proto_head_ce(fs_, fq, 10.0, good)
+    assert torch.isfinite(st).all()
+    for bad_value in (-100, way):
+        bad = good.clone()
+        bad[Q + 3] = bad_value                                   # one query of the second episode
+        _, _, st = ops.proto_head_ce(fs_, fq, 10.0, bad)
+        torch.cuda.synchronize()
+        assert torch.isnan(st[0]) and torch.isnan(st[2 + E + 1]) and torch.isfinite(st[2 + E + 0])      # batch loss, episode 1's loss; episode 0 untouched
+    dev = torch.device('cuda', torch.cuda.current_device())
+    t0 = ops._ticket(dev)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        t1 = ops._ticket(dev)
+        _, _, st = ops.proto_head_ce(fs_, fq, 10.0, good)
+        torch.cuda.current_stream().synchronize()
+        assert torch.isfinite(st).all()
+    assert t0.data_ptr() != t1.data_ptr() and int(t0.abs().sum()) == 0 and int(t1.abs().sum()) == 0
+
+
 def test_train_step_fused_head_equals_the_three_reference_lines():
     """train_meta.train_step through model.forward_loss (fused head + CE + accuracy) vs logits -> F.cross_entropy / compute_acc through ATen: same loss,
     accuracy and parameters after one parity-mode step."""

@@ -157,6 +157,49 @@ def test_weight_rounding_correction_switch_and_stale_statistics(tmp_path, mode):
         assert d_on <= 1.5 * d_off, (d_on, d_off)
 
 
+STATS_CHILD = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from fewshot_vit_amd import models, synthetic
+from fewshot_vit_amd.utils import few_shot as fs
+E, out = int(sys.argv[1]), sys.argv[2]
+m = models.make('meta-baseline', encoder='visformer_micro_80', encoder_args={'numerics': 'bf16', 'drop_path_rate': 0.0})
+m.load_state_dict(synthetic.synthetic_checkpoint_sd({k: tuple(v.shape) for k, v in m.state_dict().items()}), strict=True)
+m = m.cuda().train()
+x = synthetic.synthetic_episodes(5, E, 5, 1, 3)
+xs, xq = fs.split_shot_query(x, 5, 1, 3, E)
+with torch.no_grad():
+    m(xs.cuda(), xq.cuda())
+torch.cuda.synchronize()
+torch.save({k: v.float().cpu() for k, v in m.state_dict().items() if k.startswith('encoder.stem') and 'running' in k}, out)
+''' % ROOT
+
+
+@pytest.mark.parametrize('episodes', [1, 7, 40])
+def test_producer_statistics_are_per_channel_exact(tmp_path, episodes):
+    """ADVICE r04: the BatchNorm statistics the stem's GEMM / halo kernels sum in their epilogues (conv_gemm_v2<...,STATS>, conv3x3_halo<...,STATS>: one partial
+    row per persistent workgroup, valid only while (grid / 8) %% tiles_n == 0) against the reduce pass over the stored map (FSVIT_BN_PRODUCER_STATS=0), channel
+    by channel, at three launch geometries (20 / 140 / 800 images).  The two routes sum the same channel's values - fp32 accumulators vs their bf16-rounded
+    stores - so the running means agree to 1e-4 of a standard deviation and the variances to 2e-4 (measured: 6e-6 / 9e-6); a partial row credited to the wrong channel
+    would be off by the spread of the channel means (~ a standard deviation)."""
+    def run(env, tag):
+        out = str(tmp_path / f'{tag}.pt')
+        r = subprocess.run([sys.executable, '-c', STATS_CHILD, str(episodes), out], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env), cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return torch.load(out)
+    a, b = run({}, 'producer'), run({'FSVIT_BN_PRODUCER_STATS': '0'}, 'reduce')
+    assert set(a) == set(b) and len(a) == 8
+    worst_m = worst_v = 0.0
+    for k in a:
+        if k.endswith('running_mean'):
+            sd = b[k.replace('running_mean', 'running_var')].sqrt()
+            worst_m = max(worst_m, float(((a[k] - b[k]).abs() / sd).max()))
+        else:
+            worst_v = max(worst_v, float(((a[k] - b[k]).abs() / b[k]).max()))
+    print(f'{episodes} episodes: worst |d running_mean| / std = {worst_m:.2e}, worst relative d running_var = {worst_v:.2e}')
+    assert worst_m <= 1e-4 and worst_v <= 2e-4          # measured 2 .. 6e-6 / 2 .. 9e-6
+
+
 def test_fp32_attention_backward_fallback_switch():
     """FSVIT_ATTN_BWD_F32_MFMA=0 keeps the FMA-loop attention backward for the Visformer head shapes (the kernel the fp32 MFMA one replaced in
     round 3): the same operator tests must pass through it."""

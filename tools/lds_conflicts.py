@@ -34,3 +34,36 @@ if __name__ == '__main__':
         # writer: thread t -> chunk c = t&7, row = t>>3 (8 rows per wave-instruction)
         wr = cycles_w128(lambda l: (l >> 3) * 128 + (((l & 7) ^ swz(l >> 3)) * 16))
         print('write swz', name, 'cycles', wr)
+
+
+def cycles_w64(addr_of_lane):
+    # ds_write_b64: 16 contiguous lanes per group, bank = (a/4) % 32, 2 dwords per lane
+    tot = 0
+    for g0 in range(0, 64, 16):
+        banks = {}
+        for l in range(g0, g0 + 16):
+            a = addr_of_lane(l) // 4
+            for d in (0, 1):
+                banks.setdefault((a + d) % 32, set()).add(a + d)
+        tot += max(len(s) for s in banks.values())
+    return tot   # 4 = conflict-free
+
+
+def qkv_attn_k_image(swizzle):
+    """Round 5: the K image of qkv_attn.hip (row stride KS = 160 B, lane = (m = lane & 15, lq = lane >> 4)): score-product reads (b128, row m, column lq) and
+    the stores of a head's k part, with and without the column swizzle col ^ ((m >> 2) & 1)."""
+    KS = 160
+    sw = (lambda m: (m >> 2) & 1) if swizzle else (lambda m: 0)
+    col = lambda l: (l >> 4) ^ sw(l & 15)
+    rd = [cycles_b128(lambda l: (l & 15) * KS + 16 * col(l) + off) for off in (0, 64)]
+    if swizzle:
+        wr = (cycles_w128(lambda l: (l & 15) * KS + 16 * col(l)), cycles_w64(lambda l: (l & 15) * KS + 64 + 16 * col(l)))
+    else:
+        wr = tuple(cycles_w64(lambda l: (l & 15) * KS + off + 16 * (l >> 4)) for off in (0, 8, 64))
+    return rd, wr
+
+
+if __name__ == '__main__':
+    for swz in (False, True):
+        rd, wr = qkv_attn_k_image(swz)
+        print('qkv_attn K image, swizzle', swz, ': b128 reads', rd, '(4 = conflict-free); stores', wr, '(b64: 4, b128: 8 = conflict-free)')
