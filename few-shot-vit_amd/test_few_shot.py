@@ -101,9 +101,10 @@ def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch
             losses.append(loss.view(G, ep_per_batch).mean(dim=1))
             pending.clear()
 
-        # the first launches are small so that the GPU starts while the host is still drawing the stream (a full first launch leaves it idle
-        # for launch_batches x ~100 us of sampling); from then on the sampler runs under the previous launch
-        ramp = [n for n in (8, 16, 32, 64) if n < launch_batches]
+        # the first launch is small so that the GPU starts while the host is still drawing the stream; from then on the sampler runs under the
+        # previous launch.  (Round 5: with the native sampler a full launch of 128 episodes is 6 ms of host time, so one 32-episode step replaces the
+        # 8 / 16 / 32 / 64 ramp of the 100-us-per-episode numpy sampler - small launches run the persistent kernels at half their efficiency.)
+        ramp = [n for n in (32,) if n < launch_batches]
         for idx in sampler:
             pending.append(idx)
             last_label = dataset.label[int(idx[-1])]
