@@ -78,6 +78,7 @@ SIGNATURES = {
     'fsvit_row_normalize': (_i, [_fp, _fp, _fp, _i, _i, _vp]),
     'fsvit_row_normalize_backward': (_i, [_fp, _fp, _fp, _fp, _i, _i, _vp]),
     'fsvit_adamw_step': (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _f, _i, _vp]),
+    'fsvit_adamw_step_multi': (_i, [_vp, _i, _sz, _f, _f, _f, _f, _f, _i, _vp]),
     'fsvit_proj_mlp_rows': (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _fp, _vp, _i, _fp, _i, _i, _i, _vp]),
     'fsvit_ln_linear_rows': (_i, [_vp, _vp, _vp, _i, _fp, _i, _i, _i, _f, _vp]),
     'fsvit_patch_embed2x2': (_i, [_vp, _vp, _vp, _i, _fp, _fp, _i, _i, _i, _i, _vp]),

@@ -1227,6 +1227,14 @@ extern "C" int fsvit_adamw_step(float* p, const float* g, float* m, float* v, si
   return 0;
 }
 
+extern "C" int fsvit_adamw_step_multi(const void* items_dev, int n_items, size_t max_numel, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                      int step, void* stream) {
+  const int kdt = FSVIT_BF16;
+  if (!items_dev || n_items < 0 || step < 1) return fail(FSVIT_ERR_ARG, "fsvit_adamw_step_multi: bad argument");
+  RC_TRY(K(launch_adamw_multi)(items_dev, n_items, max_numel, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int fsvit_qkv_attention(const void* x, const void* wqkv, int kw, const float* bias, void* ctx, int B, int S, int C, int heads, int hdp,
                                    float scale, void* stream) {
   const int kdt = FSVIT_BF16;

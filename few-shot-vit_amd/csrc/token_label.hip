@@ -234,6 +234,24 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   p[i] = pi - (lr / bc1) * (mi / denom);
 }
 
+// the same update for a table of tensors in ONE launch (blockIdx.y = tensor; rows of 5 x 8 bytes: p, g, m, v, n): the distillation phase steps 89
+// parameter tensors, i.e. 89 launches of ~4 us and as many host calls per step (profiles/r05_distill_kernel_stats.csv)
+struct AdamwItem { float* p; const float* g; float* m; float* v; size_t n; };
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwItem* __restrict__ items, float lr, float beta1, float beta2, float eps, float wd, float bc1,
+                                                          float rsqrt_bc2) {
+  const AdamwItem it = items[blockIdx.y];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < it.n; i += (size_t)gridDim.x * 256) {
+    const float gi = it.g[i];
+    const float pi = it.p[i] * (1.0f - lr * wd);
+    const float mi = beta1 * it.m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * it.v[i] + (1.0f - beta2) * gi * gi;
+    it.m[i] = mi;
+    it.v[i] = vi;
+    const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+    it.p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
 // token map plumbing: storage dtype <-> fp32
 template <typename T>
 __global__ void tokens_to_f32_kernel(const T* __restrict__ in, const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out, size_t n, int C) {
@@ -306,6 +324,16 @@ int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float l
   if (n == 0) return 0;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, wd, (float)bc1,
+                     (float)(1.0 / sqrt(bc2)));
+  return (int)hipGetLastError();
+}
+
+int launch_adamw_multi(const void* items_dev, int n_items, size_t max_numel, float lr, float beta1, float beta2, float eps, float wd, int step, hipStream_t s) {
+  if (n_items <= 0 || max_numel == 0) return 0;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  size_t gx = (max_numel + 1023) / 1024;
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)gx, (unsigned)n_items), dim3(256), 0, s, (const AdamwItem*)items_dev, lr, beta1, beta2, eps, wd, (float)bc1,
                      (float)(1.0 / sqrt(bc2)));
   return (int)hipGetLastError();
 }

@@ -597,6 +597,30 @@ class ops:
             _lib.check(_lib.load().fsvit_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
                                                     float(weight_decay), int(step), _stream_ptr(p.device)))
 
+    _adamw_tables = {}
+
+    @staticmethod
+    def adamw_step_multi(params, grads, ms, vs, lr, beta1, beta2, eps, weight_decay, step):
+        """One launch for a list of fp32 tensors at the same update number (fsvit_adamw_step_multi); the pointer table is cached per device and re-uploaded
+        only when a pointer changed (as ops.sgd_step_multi)."""
+        if not params:
+            return
+        _require_cuda(*params)
+        lib = _lib.load()
+        bump_weight_generation(params)
+        dev = params[0].device
+        rows = tuple((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()) for p, g, m, v in zip(params, grads, ms, vs))
+        key = (dev, len(rows))
+        cached = ops._adamw_tables.get(key)
+        if cached is None or cached[0] != rows:
+            table = torch.tensor(rows, dtype=torch.int64).pin_memory()
+            with torch.cuda.device(dev):
+                cached = (rows, table.to(dev, non_blocking=True), table)
+            ops._adamw_tables[key] = cached
+        with torch.cuda.device(dev):
+            _lib.check(lib.fsvit_adamw_step_multi(_ptr(cached[1]), len(rows), max(r[4] for r in rows), float(lr), float(beta1), float(beta2), float(eps),
+                                                  float(weight_decay), int(step), _stream_ptr(dev)))
+
     @staticmethod
     def proj_mlp_rows(x, ctx, wp, w1, b1, w2, b2=None):
         """x [M][C], ctx [M][KC] bf16, wp [C][KpW]: x1 = x + ctx wp^T; y = x1 + W2 GELU(W1 x1 + b1) + b2  ((C, KC) = (256, 288) | (512, 576))."""

@@ -125,6 +125,7 @@ class FsvitAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         for group in self.param_groups:
             b1, b2 = group['betas']
+            batches = {}                     # update number -> tensors at that number (one launch each: all parameters of a run share it)
             for p in group['params']:
                 if p.grad is None:
                     continue
@@ -135,5 +136,12 @@ class FsvitAdamW(torch.optim.Optimizer):
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st['step'] += 1
                 data = p.data if p.data.dim() > 0 else p.data.view(1)
-                ops.adamw_step(data, p.grad.contiguous().view(-1), st['exp_avg'].view(-1), st['exp_avg_sq'].view(-1), group['lr'], b1, b2,
-                               group['eps'], group['weight_decay'], st['step'])
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if data.is_contiguous() and data.dtype == torch.float32:
+                    b = batches.setdefault(st['step'], ([], [], [], []))
+                    b[0].append(data); b[1].append(g); b[2].append(st['exp_avg']); b[3].append(st['exp_avg_sq'])
+                else:
+                    ops.adamw_step(data, g.view(-1), st['exp_avg'].view(-1), st['exp_avg_sq'].view(-1), group['lr'], b1, b2,
+                                   group['eps'], group['weight_decay'], st['step'])
+            for step_no, (ps, gs, ms, vs) in batches.items():
+                ops.adamw_step_multi(ps, gs, ms, vs, group['lr'], b1, b2, group['eps'], group['weight_decay'], step_no)

@@ -244,6 +244,10 @@ int fsvit_row_normalize_backward(const float* y_dev, const float* inv_norm_dev, 
 /* AdamW (decoupled weight decay), update number `step` >= 1: p, exp_avg m, exp_avg_sq v updated in place. */
 int fsvit_adamw_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, size_t n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, void* stream);
+/* The same update for a table of tensors in ONE launch (offline.py:233 `optimizer.step()` over every parameter of the student): items_dev = n_items rows of
+ * five 8-byte words {p, g, m, v, numel} in device memory; every tensor at update number `step`; max_numel = the largest numel (sizes the grid). */
+int fsvit_adamw_step_multi(const void* items_dev, int n_items, size_t max_numel, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                           void* stream);
 
 int fsvit_im2col27(const float* x_nchw_dev, void* out_dev, int B, int H, int W, int dtype, void* stream);
 /* im2col27 + stem conv1 + bn1 (folded) + LeakyReLU(0.1) in one pass (visformer.py:209-210,218), bf16, 80x80 images, 64 channels:
