@@ -15,13 +15,13 @@
 // B operands and one 32-byte run of the h / g' / dh row.  The same permutation on Wb's rows gives a lane 16 consecutive output channels per 32-channel
 // tile - the layout of the x registers, so the residual comes from the registers that fed GEMM1.
 // Weight images (fragment sequences in consumption order, written by pack_weight_multi_kernel modes 3 / 4 and mlp_fold_pack_kernel) stream through
-// LDS by LDS-DMA, double buffered per part: every chunk is two phases (GEMM1 | GEMM2) with one barrier each; a part is issued one phase after its
-// buffer's last read, its counted vmcnt wait sits before the NEXT barrier and its first read after the one behind that (cdna_hip_programming.md:
-// "read a staged buffer one phase after the wait that retires it").  Every VMEM instruction inside the chunk loop is issued from inline asm, so the
-// counts below are exact:   phase 1 (j): DMA B(j+1) [PW]                                          | wait A(j+1): vmcnt(PW)
-//                           phase 2 (j): stores mid(j) [NS], loads g'(j+1) [NL], DMA A(j+2) [PW]   | wait B(j+1): vmcnt(NS + NL + PW)
-// The chunk stream is periodic, so the prefetch runs across the tiles of the persistent workgroup.  Rows beyond M are computed on a clamped row and
-// STORED (counts stay uniform): every output has room for n_tiles * 128 rows (mlp_train_rows_pad).
+// LDS by LDS-DMA on counted vmcnt waits; every VMEM instruction inside the chunk loop is issued from inline asm, so the counts are exact - the phase
+// structure, the issue schedule and the counts are described at the kernel.  The chunk stream is periodic, so the prefetch runs across the tiles of the
+// persistent workgroup.  Rows beyond M are computed on a clamped row and STORED (counts stay uniform): every output has room for n_tiles * 128 rows
+// (mlp_train_rows_pad).
+// Where it stands (DESIGN.md 4b "Round 5", profiles/r05_mlp_train_*): correct, 1.1 GB and 6 launches less per 800-image step at stage 2, and a draw in
+// time against the launches it replaces - one wave per SIMD issues its 12 VMEM instructions, ~200 VALU and 32 MFMAs per chunk in order (~4000 cycles
+// against 1024 of MFMA time, none of it waiting); stage 3 keeps its gemm256 launches (mlp_train_preferred).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -104,10 +104,7 @@ __device__ __forceinline__ u32x4 mt_pack8(const float* v) {
   const bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
   return __builtin_bit_cast(u32x4, o);
 }
-__device__ __forceinline__ f32x16 mt_mfma(u32x4 a, u32x4 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-// The output accumulators (32 rows x C channels: 256 registers at C = 512) are pinned to AGPRs by issuing their MFMAs from inline asm: left to hipcc's
+// Every MFMA is issued from inline asm.  The output accumulators (32 rows x C channels: 256 registers at C = 512) are pinned to AGPRs that way: left to hipcc's
 // allocator the C = 512 data-gradient kernel spilled its 128 x registers and reloaded them inside the chunk loop (158 spills).  What the compiler
 // no longer does for these instructions is done by hand, as in mlp_rows.hip: wait states VALU-written operand -> MFMA (mt_settle_b) and
 // MFMA -> accumulator read (mt_settle_acc); dependent MFMAs on one accumulator issue back to back (same opcode, same vDst).
