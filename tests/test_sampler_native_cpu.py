@@ -56,13 +56,14 @@ def test_stream_equals_reference_known_answers(native):
 def test_native_is_faster_than_numpy():
     import time
     label = np.repeat(np.arange(20), 600).tolist()
-    t = {}
-    for native in (False, True):
-        np.random.seed(1)
-        t0 = time.perf_counter()
-        n = sum(1 for _ in CategoriesSampler(label, 300, 5, 20, 1, native=native))
-        t[native] = time.perf_counter() - t0
-        assert n == 300
+    t = {False: float('inf'), True: float('inf')}
+    for _ in range(3):                       # best of three: a timing comparison on a shared CI host
+        for native in (False, True):
+            np.random.seed(1)
+            t0 = time.perf_counter()
+            n = sum(1 for _ in CategoriesSampler(label, 300, 5, 20, 1, native=native))
+            t[native] = min(t[native], time.perf_counter() - t0)
+            assert n == 300
     print('sampler: numpy %.1f us / episode, native %.1f us / episode' % (1e6 * t[False] / 300, 1e6 * t[True] / 300))
     assert t[True] < t[False]
 
