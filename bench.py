@@ -39,6 +39,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+# dmabuf IPC is the only inter-process GPU memory sharing this driver supports: RCCL between the ranks of one node needs it, and it must be in the
+# environment before the first HIP call of the process (the launcher path sets it for its children; under an external torchrun this line does)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

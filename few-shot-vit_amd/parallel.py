@@ -19,6 +19,7 @@ def init_from_env(backend=None):
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL between processes on this driver); effective if no HIP call was made yet
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
