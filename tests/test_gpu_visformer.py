@@ -338,3 +338,32 @@ def test_image_size_64_runs_the_ring_stage1_block():
     assert e_par <= 1e-3
     assert e_bf <= 0.05 * max(1.0, ref.abs().max().item())
     assert torch.equal(bf, one)
+
+
+@pytest.mark.parametrize('depth', [(0, 1, 1), (1, 0, 1), (1, 1, 0)])
+def test_stage_without_blocks_builds_and_matches_parity_in_the_16_bit_modes(depth):
+    """the weight-rounding correction handed the next PatchEmbed an operand-mean vector of the wrong size (or none) when a stage
+    has no blocks - a heap out-of-bounds read in engine.hip's pack_layer.  The vector is now seeded / re-seeded per stage: a Visformer with an empty
+    stage builds in bf16 and f16 and its features stay within the modes' tolerance of the exact-fp32 engine."""
+    from fewshot_vit_amd import synthetic
+    from fewshot_vit_amd.models.visformer import Visformer
+    x = torch.randn(4, 3, 80, 80, generator=torch.Generator().manual_seed(11))
+    feats = {}
+    for numerics in ('parity', 'bf16', 'f16'):
+        m = Visformer(img_size=80, init_channels=64, embed_dim=256, depth=list(depth), num_heads=6, mlp_ratio=4., group=8, numerics=numerics)
+        sd = synthetic.procedural_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+        for k in sd:                       # benign running statistics (the shipped calibration is for depth (4, 2, 3))
+            if k.endswith('running_var'):
+                sd[k] = torch.ones_like(sd[k])
+            if k.endswith('running_mean'):
+                sd[k] = torch.zeros_like(sd[k])
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            feats[numerics] = m(x.cuda()).float().cpu()
+        assert torch.isfinite(feats[numerics]).all(), (depth, numerics)
+    scale = max(1.0, float(feats['parity'].abs().max()))
+    for numerics, tol in (('bf16', 0.05), ('f16', 0.01)):
+        d = float((feats[numerics] - feats['parity']).abs().max()) / scale
+        print(f'depth {depth} {numerics}: max rel |d feature| vs parity = {d:.3e}')
+        assert d <= tol, (depth, numerics, d)
