@@ -332,7 +332,8 @@ int fsvit_proto_head_backward_devtemp(const float* feat_shot_dev, const float* f
  * E * Q rows) / dlogits (may be NULL), and loss_acc_mean_dev[2] = {F.cross_entropy value, compute_acc value} (may be NULL).  labels_dev: int64 [E*Q] class
  * indices, or NULL for fs.make_nk_label's (few_shot.py:13-16: q / (Q / way)).  temp_dev (may be NULL): the temperature read from device memory instead of
  * `temp`.  ticket_dev: a zero-initialised 4-byte device word (required with loss_acc_mean_dev): the last workgroup to finish sums the episodes in index order
- * and leaves the word at zero - no second launch, no atomics on floating-point data, results bit-reproducible. */
+ * and leaves the word at zero - no second launch, no atomics on floating-point data, results bit-reproducible.
+ * A label outside [0, way) - including F.cross_entropy's ignore_index, which this head does not implement - makes the episode's loss (and the batch mean) NaN. */
 int fsvit_proto_head_ce(const float* feat_shot_dev, const float* feat_query_dev, const long long* labels_dev, int E, int way, int shot, int Q, int D, float temp,
                         const float* temp_dev, int method, float* logits_dev, float* dlogits_dev, float* acc_per_episode_dev, float* loss_per_episode_dev,
                         float* loss_acc_mean_dev, unsigned* ticket_dev, void* stream);

@@ -98,18 +98,24 @@ def test_every_training_dispatch_switch_agrees_with_the_default_path(tmp_path):
         assert r.returncode == 0, r.stderr[-2000:]
         return torch.load(out)
     base = run({}, 'base')
-    for i, env in enumerate([{'FSVIT_WGRAD3X3': '0'}, {'FSVIT_WGRAD1X1': '0'}, {'FSVIT_GCONV3X3': '0'}, {'FSVIT_WGRAD_SIDE_STREAM': '0'}, {'FSVIT_BN_ROWS': '0'}, {'FSVIT_STAGE1_TRAIN_FUSED': '0'},
-                             {'FSVIT_STAGE1_BLOCK_FUSED': '0'}, {'FSVIT_BN_PRODUCER_STATS': '0'}, {'FSVIT_MLP_TRAIN_FUSED': '0'}, {'FSVIT_MLP_TRAIN_FUSED': '2'},
-                             {'FSVIT_STAGE1_TRAIN_FUSED': '0', 'FSVIT_GCONV3X3': '0'}]):      # (the grouped-conv kernel only runs on the three-launch route)
+    # (switch, gate): routes that sum in the same order are gated at fp32-rounding level (measured 0 ... 6e-7); routes that ROUND at different points
+    # - a BatchNorm folded into conv1 / fc1's weights, BatchNorm statistics of the fp32 accumulators instead of the stored 16-bit map - move bf16
+    # gradients by 3 ... 6e-2 of their norm (measured next to each) and get 1.5 x that (one 0.1 gate for every route hid the difference)
+    routes = [({'FSVIT_WGRAD3X3': '0'}, 5e-6), ({'FSVIT_WGRAD1X1': '0'}, 5e-6), ({'FSVIT_GCONV3X3': '0'}, 1e-6), ({'FSVIT_WGRAD_SIDE_STREAM': '0'}, 1e-6),
+              ({'FSVIT_BN_ROWS': '0'}, 1e-6),
+              ({'FSVIT_STAGE1_TRAIN_FUSED': '0'}, 0.06),              # 3.8e-2
+              ({'FSVIT_STAGE1_BLOCK_FUSED': '0'}, 0.06),              # 3.8e-2
+              ({'FSVIT_BN_PRODUCER_STATS': '0'}, 0.09),               # 6.0e-2
+              ({'FSVIT_MLP_TRAIN_FUSED': '0'}, 0.05), ({'FSVIT_MLP_TRAIN_FUSED': '2'}, 0.05),       # 2.8e-2 / 3.1e-2, 2.7e-2
+              ({'FSVIT_STAGE1_TRAIN_FUSED': '0', 'FSVIT_GCONV3X3': '0'}, 0.06)]      # (the grouped-conv kernel only runs on the three-launch route)
+    for i, (env, gate) in enumerate(routes):
         other = run(env, f'tr{i}')
         # (the bias of a PatchEmbed conv and of its BatchNorm have a structurally ZERO gradient - every consumer of the residual stream starts with a
         # BatchNorm that removes a per-channel constant - what the kernels return there is rounding noise, different on every route)
         dead = ('patch_embed2.proj.bias', 'patch_embed3.proj.bias', 'patch_embed2.norm.bn.bias', 'patch_embed3.norm.bn.bias')
         worst = max(float((other[k] - v).norm() / (v.norm() + 1e-12)) for k, v in base.items() if float(v.norm()) > 1e-5 and not k.endswith(dead))
-        print(f'{env}: worst gradient rel difference to the default path = {worst:.3e}')
-        # routes that round at different points (BatchNorm statistics of the fp32 accumulators instead of the stored 16-bit map, a BatchNorm folded into
-        # conv1's weights) move the stem's bias gradients by up to 6e-2 in bf16; the bit-compatible routes stay below 1e-6
-        assert worst <= 0.1, env
+        print(f'{env}: worst gradient rel difference to the default path = {worst:.3e} (gate {gate:.1e})')
+        assert worst <= gate, env
 
 
 WROUND_CHILD = r'''
