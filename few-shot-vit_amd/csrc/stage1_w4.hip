@@ -38,13 +38,26 @@ namespace FSVIT_NS {
 namespace s1w {
 constexpr int C1 = 128, HID = 256, CH = 64, RING = 128, XRING = 192, HALO = 21, KW2 = 320;
 constexpr int XP = XRING * 16;                   // x ring plane pitch: 192 pixel slots (the residual of chunk q-1 is still there in S1(q))
-constexpr int PITCH = RING * 16;                 // h1 ring plane pitch
+constexpr int RINGB = RING * 16;                 // bytes of one h1 ring plane's 128 pixel slots (the ring wraps at this)
+constexpr int PITCH = RINGB + 16;                // h1 ring plane pitch: the ring + ONE ZERO SLOT (slot 128) - an out-of-image conv2 tap reads it under every
+                                                 // immediate plane offset of its fragment (round 6; a separate 12 KB zero region until round 5)
 constexpr int XR = 0;                            // x ring: 16 planes
 constexpr int H1R = XR + (C1 / 8) * XP;          // h1 ring: 32 planes
 constexpr int H2P = CH * 16;
 constexpr int H2 = H1R + (HID / 8) * PITCH;      // h2 of one chunk: 32 planes x 64 pixels
-constexpr int ZERO = H2 + (HID / 8) * H2P;       // zeros under every immediate plane offset of a conv2 fragment read (6 planes + 16 B)
-constexpr int LDS_BYTES = ZERO + 6 * PITCH + 16; // 159 760
+// GELU table (bf16 build only, round 6): entry i in [-TN, TN) at TABC + 2 i = bf16(gelu_erf(z) / 8) of the bf16 code z / 8 with magnitude code
+// TLO + a, a = i (z >= 0) or -1 - i (z < 0): |z| in [2^-10, 32), 15 binades x 128 codes per sign
+#ifdef FSVIT_HALF_F16
+constexpr bool TABLE = false;
+constexpr int TNB = 0;
+#else
+constexpr bool TABLE = true;
+constexpr int TNB = 15;
+#endif
+constexpr int TN = TNB * 128, TLO = (127 - 13) << 7;
+constexpr int TAB = H2 + (HID / 8) * H2P;
+constexpr int TABC = TAB + 2 * TN;
+constexpr int LDS_BYTES = TAB + 4 * TN;          // 155 648 (bf16) / 147 968 (f16)
 }  // namespace s1w
 
 typedef float f32x16w __attribute__((ext_vector_type(16)));
@@ -98,7 +111,16 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
   const int q0 = blockIdx.x * chunks_per_wg;
   int q1 = q0 + chunks_per_wg; q1 = q1 < n_chunks ? q1 : n_chunks;
   if (q0 >= q1) return;
-  for (int i = t; i < (6 * PITCH + 16) / 4; i += 256) reinterpret_cast<unsigned*>(smem + ZERO)[i] = 0u;
+  if (t < 4 * (HID / 8)) reinterpret_cast<unsigned*>(smem + H1R + (t >> 2) * PITCH + RINGB)[t & 3] = 0u;      // the zero slot of every h1 plane
+  if constexpr (TABLE) {
+    // the GELU table, exact-erf form (closer to the reference's nn.GELU than gelu_sig; the pre-activation is rounded to bf16 first - DESIGN.md 4)
+    for (int e = t; e < 2 * TN; e += 256) {
+      const int i = e - TN, a = i >= 0 ? i : -1 - i;
+      const float z8 = __builtin_bit_cast(float, (unsigned)(TLO + a) << 16);
+      const float z = i >= 0 ? 8.0f * z8 : -8.0f * z8;
+      reinterpret_cast<bf16*>(smem + TAB)[e] = (bf16)(gelu_erf(z) * 0.125f);
+    }
+  }
 
   // ---- this wave's weights.  MFMA row R = lane & 31 carries channel cR of its 32-channel tile; the lane's k half = kh
   const int cR = 16 * ((p >> 2) & 1) + 4 * (p >> 3) + (p & 3);
@@ -219,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
     for (int tp = 0; tp < 9; ++tp) {
       const int dy = tp / 3 - 1, dx = tp % 3 - 1;
       const bool ok = (unsigned)(oy + dy) < (unsigned)H && (unsigned)(ox + dx) < (unsigned)W;
-      const unsigned char* base = smem + (ok ? h1r_off + ((m + dy * W + dx) & (RING - 1)) * 16 : ZERO);
+      const unsigned char* base = smem + h1r_off + (ok ? ((m + dy * W + dx) & (RING - 1)) * 16 : RINGB);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -320,10 +342,74 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
       }
     });
   };
+  // ---- round 6: the same passes as TABLE LOOK-UPS (bf16 build).  stage1_w4 was VALU-issue-bound on its 512 GELUs per token (17 VALU per pair, 4 of them
+  // quarter-rate) while the LDS pipe idled (r05: VALU busy 62 %, LDS 8 %).  The hidden maps are stored as bf16 anyway, so the GELU is a function of the
+  // bf16-ROUNDED pre-activation: 9 VALU + 2 ds_read_u16 per pair (tools/probes/gelu_lds.hip: -18 % cycles per 32-MFMA segment at this kernel's ratio),
+  //   T1 code pair = cvt_pk_bf16(z0 / 8, z1 / 8)  | T2 magnitudes (& 0x7fff7fff), re-based to 2^-13 with a saturating packed u16 subtraction
+  //   T3 clamp at the last entry; sign mask code >>a 15 | T4 sign as the one's complement i = a ^ mask; byte addresses tabc + 2 i (v_mad_i32_i16, op_sel for the
+  //   upper half) | T5 the two gathers | T6 (two slots later) v_lshl_or_b32 joins the halves; octet store as before
+  // (d16 loads cannot merge the halves: with SRAM ECC on they zero the other half of the register - measured, gelu_lds.out.txt.)
+#ifndef W4_TJOBS
+#define W4_TJOBS 0xf                                // jobs (GELU passes) that run as table look-ups: bit 0 GELU2 / bt1, 1 GELU1 / bt0, 2 GELU1 / bt1, 3 GELU2 / bt0
+#endif
+#ifndef W4_PF
+#define W4_PF 3                                     // fragment read-ahead of S2 / S3 / S4 in slots (<= 4: the prologue's fragments are one tap's)
+#endif
+#ifndef W4_TLAT
+#define W4_TLAT 4                                   // slots between a pair's gathers and their use
+#endif
+  typedef __attribute__((address_space(3))) const unsigned short lds_u16;
+  typedef lds_u16* lds_u16_t;
+  unsigned tc[4][16], ta[4][16], tm[4][16];
+  unsigned ad0[4][16], ad1[4][16];
+  const unsigned tabc = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + TABC);      // LDS address of entry 0
+  unsigned tl[4][16], th[4][16];
+  auto t_slot = [&](auto jt, auto numt, auto rt, const f32x16w& a0, const f32x16w& a1, auto dst) {
+    constexpr int J = decltype(jt)::value, NUM = decltype(numt)::value, r = decltype(rt)::value;
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    typedef short ss2 __attribute__((ext_vector_type(2)));
+    constexpr unsigned klo = (unsigned)TLO * 0x10001u, kmax = (unsigned)(TN > 0 ? TN - 1 : 0) * 0x10001u;
+    w4_for<16>([&](auto kc) {
+      constexpr int k = decltype(kc)::value, st = k * NUM / 4;
+      // (stage boundaries keep a packed 16-bit result and its reader in different slots: gfx950 needs a wait state between such a pair, hipcc
+      // fills it with an s_nop 0)
+      if constexpr (r == st) {
+        const f32x16w& a = k < 8 ? a0 : a1;
+        tc[J][k] = w4_pk2(a[2 * (k & 7)], a[2 * (k & 7) + 1]);
+        asm("" : "+v"(tc[J][k]));                            // (opaque: otherwise the sign shift below converts the two floats again)
+      }
+      if constexpr (r == st + 1)
+        ta[J][k] = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, tc[J][k] & 0x7fff7fffu), __builtin_bit_cast(us2, klo)));
+      if constexpr (r == st + 2) {
+        tm[J][k] = __builtin_bit_cast(unsigned, __builtin_bit_cast(ss2, tc[J][k]) >> 15);
+        ta[J][k] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2, ta[J][k]), __builtin_bit_cast(us2, kmax)));
+      }
+      if constexpr (r == st + 3) {
+        ta[J][k] ^= tm[J][k];
+        asm("v_mad_i32_i16 %0, %1, 2, %2" : "=v"(ad0[J][k]) : "v"(ta[J][k]), "s"(tabc));
+        asm("v_mad_i32_i16 %0, %1, 2, %2 op_sel:[1,0,0,0]" : "=v"(ad1[J][k]) : "v"(ta[J][k]), "s"(tabc));
+      }
+      if constexpr (r == st + 4) {                           // (LDS pointers formed from the integer address: `smem + offset` costs a v_add of the base per load)
+        tl[J][k] = *(lds_u16_t)(size_t)ad0[J][k];
+        th[J][k] = *(lds_u16_t)(size_t)ad1[J][k];
+      }
+      if constexpr (r == st + 4 + W4_TLAT) {
+        gp[J][k] = tl[J][k] | (th[J][k] << 16);
+        if constexpr ((k & 3) == 3) *reinterpret_cast<u32x4*>(dst(k >> 3, (k >> 2) & 1)) = u32x4{gp[J][k - 3], gp[J][k - 2], gp[J][k - 1], gp[J][k]};
+      }
+    });
+  };
+  // one GELU pass slot: the table form (bf16) or the VALU form (fp16: a 10-bit mantissa would need an 8 x larger table).  NT / NV = pair spacing of
+  // the two forms in quarter slots (the table form finishes 6 slots after a pair's start, the VALU form 5)
+  auto gelu_slot = [&](auto jt, auto nt, auto nv, auto rt, const f32x16w& a0, const f32x16w& a1, auto dst) {
+    if constexpr (TABLE && ((W4_TJOBS >> decltype(jt)::value) & 1)) t_slot(jt, nt, rt, a0, a1, dst);
+    else g_slot(jt, nv, rt, a0, a1, dst);
+  };
   typedef std::integral_constant<int, 0> J0;
   typedef std::integral_constant<int, 1> J1;
   typedef std::integral_constant<int, 2> J2;
   typedef std::integral_constant<int, 3> J3;
+  typedef std::integral_constant<int, 6> N6;
   typedef std::integral_constant<int, 7> N7;
   typedef std::integral_constant<int, 8> N8;
 
@@ -333,8 +419,12 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
   const int divW = (65536 + W - 1) / W;
   int remq[2], tms[2];
   unsigned long long rmk[2][3], cmk[2][3];
-  int zero_off = ZERO;
-  asm volatile("" : "+v"(zero_off));                        // (v_cndmask reads the mask over the constant bus: the zero region's offset has to be a VGPR)
+  // tap addresses are LDS ADDRESSES (the base of `smem` folded into the per-lane constants): a read through `smem + offset` costs a v_add of the base
+  // per fragment base, 18 per chunk
+  typedef __attribute__((address_space(3))) const u32x4 lds_frag;
+  typedef lds_frag* lds_frag_t;
+  const int h1r_lds = h1r_off + (int)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int zero_off = h1r_lds + RINGB;                     // the zero slot of the lane's plane (a VGPR: v_cndmask reads the mask over the constant bus)
   auto tap_setup = [&](int q, int bt) {                       // remq[bt] = m % HW is current
     const int m = q * CH + 32 * bt + p;
     const int oy = m < M ? (remq[bt] * divW) >> 16 : -4;
@@ -346,10 +436,10 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
       cmk[bt][d] = __builtin_amdgcn_ballot_w64((unsigned)(ox + d - 1) < (unsigned)W);
     }
   };
-  auto tap_addr = [&](int bt, int tp) {                       // LDS offset of the tap's fragment (plane 8 w + kh), or the zero region
+  auto tap_addr = [&](int bt, int tp) {                       // LDS address of the tap's fragment (plane 8 w + kh), or of the plane's zero slot
     const int dy = tp / 3 - 1, dx = tp % 3 - 1;
     const unsigned long long mk = rmk[bt][tp / 3] & cmk[bt][tp % 3];
-    const int in = h1r_off + ((tms[bt] + (dy * W + dx) * 16) & (PITCH - 1));
+    const int in = h1r_lds + ((tms[bt] + (dy * W + dx) * 16) & (RINGB - 1));
     int r;
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(zero_off), "v"(in), "s"(mk));
     return r;
@@ -365,15 +455,15 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
   auto gelu1 = [&](long P0, int bt) {
     const int slot = (int)((P0 + 32 * bt + p) & (RING - 1)) * 16;
     auto dst = [&](int at, int o) { return h1w + (4 * at + o) * PITCH + slot; };
-    w4_for<36>([&](auto rc) {
-      g_slot(J1{}, N8{}, rc, acc1[0][bt], acc1[1][bt], dst);
+    w4_for<36 + W4_TLAT>([&](auto rc) {
+      gelu_slot(J1{}, N8{}, N8{}, rc, acc1[0][bt], acc1[1][bt], dst);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
   auto gelu2 = [&](int bt) {
     auto dst = [&](int gi, int o) { return h2w + (4 * gi + o) * H2P + 32 * bt * 16; };
-    w4_for<36>([&](auto rc) {
-      g_slot(J3{}, N8{}, rc, acc2[0][bt], acc2[1][bt], dst);
+    w4_for<36 + W4_TLAT>([&](auto rc) {
+      gelu_slot(J3{}, N8{}, N8{}, rc, acc2[0][bt], acc2[1][bt], dst);
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -423,7 +513,7 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
           asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc2[0][1]), "+v"(acc2[1][1]));      // last MFMA of the body before -> first GELU read (behind this slot's MFMA)
           xf[2] = *reinterpret_cast<const u32x4*>(xb + 4 * XP + xn0);
         }
-        if constexpr (m >= 1 && m <= 32) g_slot(J0{}, N7{}, W4_IC(m - 1), acc2[0][1], acc2[1][1], h2dst1);
+        if constexpr (m >= 1 && m <= 35) gelu_slot(J0{}, N7{}, N7{}, W4_IC(m - 1), acc2[0][1], acc2[1][1], h2dst1);      // (table: last octet stored at m = 33)
         // residual of chunk q-1 (x ring, still intact: its slots are re-staged behind barrier C of the NEXT body) -> conv3's accumulators, one octet per
         // visit at the END of the segment (GELU2(q-1) has read acc2[.][1] for the last time at slot 27: acc3 can take those registers): read at
         // slots 28 .. 31, converted at 32 .. 35
@@ -447,38 +537,38 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
     lstore(2 * CH - HALO);                                  // x pixels of chunk q+1 (loaded in S4 of the body before)
     // ---------------- S2: conv3(q-1), slots 0..31 | GELU1(q)/bt0 (job 1)
     {
-      u32x4 hf[4];
+      u32x4 hf[W4_PF + 1];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) hf[i] = *reinterpret_cast<const u32x4*>(h2b + 2 * i * H2P);
+      for (int i = 0; i < W4_PF; ++i) hf[i] = *reinterpret_cast<const u32x4*>(h2b + 2 * i * H2P);
       __builtin_amdgcn_sched_barrier(0);
       w4_for<32>([&](auto mc) {
         constexpr int m = decltype(mc)::value, bt = m >> 4, ks = m & 15;
-        if constexpr (ks < W3A) w4_mfma(wf3[ks], hf[m & 3], acc3[bt]);
-        else w4_mfma_vw(wv[ks - W3A], hf[m & 3], acc3[bt]);
-        if constexpr (m + 3 < 32) hf[(m + 3) & 3] = *reinterpret_cast<const u32x4*>(h2b + 2 * ((m + 3) & 15) * H2P + ((m + 3) >> 4) * 32 * 16);
-        g_slot(J1{}, N7{}, mc, acc1[0][0], acc1[1][0], h1dst0);
+        if constexpr (ks < W3A) w4_mfma(wf3[ks], hf[m % (W4_PF + 1)], acc3[bt]);
+        else w4_mfma_vw(wv[ks - W3A], hf[m % (W4_PF + 1)], acc3[bt]);
+        if constexpr (m + W4_PF < 32) hf[(m + W4_PF) % (W4_PF + 1)] = *reinterpret_cast<const u32x4*>(h2b + 2 * ((m + W4_PF) & 15) * H2P + ((m + W4_PF) >> 4) * 32 * 16);
+        gelu_slot(J1{}, N6{}, N7{}, mc, acc1[0][0], acc1[1][0], h1dst0);      // (table: a pair every 1.5 slots, last octet stored at m = 28)
         __builtin_amdgcn_sched_barrier(0);
       });
     }
     W4_STAMP(2);
     // ---------------- S3: conv2(q)/bt0, slots 0..35 | GELU1(q)/bt1 (job 2) | y(q-1) from the accumulators | tap coordinates of bt1
     {
-      u32x4 hf[4];
+      u32x4 hf[W4_PF + 1];
       int ta = tap_addr(0, 0), tb = tap_addr(0, 1);          // current / next tap's base
 #pragma unroll
-      for (int i = 0; i < 3; ++i) hf[i] = *reinterpret_cast<const u32x4*>(smem + ta + (4 * (i & 1) + 2 * ((i >> 1) & 1)) * PITCH);
+      for (int i = 0; i < W4_PF; ++i) hf[i] = *(lds_frag_t)(size_t)(unsigned)(ta + (4 * (i & 1) + 2 * ((i >> 1) & 1)) * PITCH);
       __builtin_amdgcn_sched_barrier(0);
       w4_for<36>([&](auto mc) {
         constexpr int m = decltype(mc)::value, tp = m >> 2, ks = (m >> 1) & 1, gi = m & 1;
-        if constexpr (m < 2) w4_mfma_z(wf2[gi][0][0], hf[m & 3], acc2[gi][0]);
-        else w4_mfma(wf2[gi][tp][ks], hf[m & 3], acc2[gi][0]);
-        if constexpr (m + 3 < 36) {                        // the read three slots ahead: fragment m3 = (tap m3 >> 2, ks, gi); a tap's base is formed one tap early
-          constexpr int m3 = m + 3;
+        if constexpr (m < 2) w4_mfma_z(wf2[gi][0][0], hf[m % (W4_PF + 1)], acc2[gi][0]);
+        else w4_mfma(wf2[gi][tp][ks], hf[m % (W4_PF + 1)], acc2[gi][0]);
+        if constexpr (m + W4_PF < 36) {                    // the read W4_PF slots ahead: fragment m3 = (tap m3 >> 2, ks, gi); a tap's base is formed one tap early
+          constexpr int m3 = m + W4_PF;
           if constexpr ((m3 & 3) == 0) ta = tb;
-          hf[m3 & 3] = *reinterpret_cast<const u32x4*>(smem + ta + (4 * (m3 & 1) + 2 * ((m3 >> 1) & 1)) * PITCH);
+          hf[m3 % (W4_PF + 1)] = *(lds_frag_t)(size_t)(unsigned)(ta + (4 * (m3 & 1) + 2 * ((m3 >> 1) & 1)) * PITCH);
           if constexpr ((m3 & 3) == 2 && (m3 >> 2) + 1 < 9 && (m3 >> 2) >= 1) tb = tap_addr(0, (m3 >> 2) + 1);
         }
-        g_slot(J2{}, N8{}, mc, acc1[0][1], acc1[1][1], h1dst1);
+        gelu_slot(J2{}, N7{}, N8{}, mc, acc1[0][1], acc1[1][1], h1dst1);
         if constexpr (m == 4 || m == 10 || m == 16 || m == 22) {     // y of chunk q-1: one 16-byte octet per visit (acc3 was complete 4+ slots ago)
           constexpr int i = (m - 4) / 6, bt = i >> 1, o = i & 1;
           const long mm = (long)(q - 1) * CH + 32 * bt + p;
@@ -496,29 +586,29 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
     W4_STAMP(4);
     // ---------------- S4: conv2(q)/bt1, slots 0..35 | GELU2(q)/bt0 (job 3) | loads of chunk q+2 | tap coordinates of q+1 / bt0
     {
-      u32x4 hf[4];
+      u32x4 hf[W4_PF + 1];
       int ta = tap_addr(1, 0), tb = tap_addr(1, 1);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) hf[i] = *reinterpret_cast<const u32x4*>(smem + ta + (4 * (i & 1) + 2 * ((i >> 1) & 1)) * PITCH);
+      for (int i = 0; i < W4_PF; ++i) hf[i] = *(lds_frag_t)(size_t)(unsigned)(ta + (4 * (i & 1) + 2 * ((i >> 1) & 1)) * PITCH);
       __builtin_amdgcn_sched_barrier(0);
       w4_for<36>([&](auto mc) {
         constexpr int m = decltype(mc)::value, tp = m >> 2, ks = (m >> 1) & 1, gi = m & 1;
-        if constexpr (m < 2) w4_mfma_z(wf2[gi][0][0], hf[m & 3], acc2[gi][1]);
-        else w4_mfma(wf2[gi][tp][ks], hf[m & 3], acc2[gi][1]);
+        if constexpr (m < 2) w4_mfma_z(wf2[gi][0][0], hf[m % (W4_PF + 1)], acc2[gi][1]);
+        else w4_mfma(wf2[gi][tp][ks], hf[m % (W4_PF + 1)], acc2[gi][1]);
         if constexpr (m == 0) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc2[0][0]), "+v"(acc2[1][0]));      // S3's last MFMA -> first GELU read
-        if constexpr (m + 3 < 36) {
-          constexpr int m3 = m + 3;
+        if constexpr (m + W4_PF < 36) {
+          constexpr int m3 = m + W4_PF;
           if constexpr ((m3 & 3) == 0) ta = tb;
-          hf[m3 & 3] = *reinterpret_cast<const u32x4*>(smem + ta + (4 * (m3 & 1) + 2 * ((m3 >> 1) & 1)) * PITCH);
+          hf[m3 % (W4_PF + 1)] = *(lds_frag_t)(size_t)(unsigned)(ta + (4 * (m3 & 1) + 2 * ((m3 >> 1) & 1)) * PITCH);
           if constexpr ((m3 & 3) == 2 && (m3 >> 2) + 1 < 9 && (m3 >> 2) >= 1) tb = tap_addr(1, (m3 >> 2) + 1);
         }
-        if constexpr (m >= 1) g_slot(J3{}, N8{}, W4_IC(m - 1), acc2[0][0], acc2[1][0], h2dst0);
+        if constexpr (m >= 1) gelu_slot(J3{}, N7{}, N8{}, W4_IC(m - 1), acc2[0][0], acc2[1][0], h2dst0);
         if constexpr (m == 20) gload(q, 3 * CH - HALO);    // pixels of chunk q+2: staged behind barrier C of the next body (one S1 = ~1.8 k cycles away)
         if constexpr (m == 30) { rem_advance(0); rem_advance(1); }
         if constexpr (m == 32) tap_setup(q + 1, 0);
         __builtin_amdgcn_sched_barrier(0);
       });
-      g_slot(J3{}, N8{}, W4_IC(35), acc2[0][0], acc2[1][0], h2dst0);
+      if constexpr (!(TABLE && ((W4_TJOBS >> 3) & 1))) g_slot(J3{}, N8{}, W4_IC(35), acc2[0][0], acc2[1][0], h2dst0);
     }
     W4_STAMP(5);
   };

@@ -10,7 +10,8 @@ bf16 / bf16 hi+lo / fp32) on the logits can be measured on the CPU before a kern
     1x1 conv -> column scale + bias[n] = sum_c W[n][c] t[c]), then the weights are rounded to bf16 (csrc/engine.hip
     `build`, restating test_phase/models/visformer.py:118-124,202-239,259-263);
   * every conv / GEMM multiplies bf16 operands and accumulates in fp32; bias, activation, residual adds, softmax, pooling
-    are fp32; GELU is the engine's `gelu_sig` (csrc/fsvit_common.h), max |d| 2.6e-5 against erf;
+    are fp32; GELU is the engine's `gelu_sig` (csrc/fsvit_common.h), max |d| 2.6e-5 against erf - except in the stage-1 block of the bf16
+    mode, whose GELUs are a table look-up of the exact erf form on the bf16-rounded pre-activation (`gelu_s1`, round 6);
   * activations that a kernel STORES are rounded to bf16 where the engine stores them: im2col patches, stem c1 / c2,
     the two hidden maps of a stage-1 block, q / k / v, the un-normalised softmax numerators P, ctx, the Mlp hidden map,
     and the block input x1 = x + proj(ctx) as the Mlp's GEMM operand;
@@ -46,6 +47,21 @@ def gelu_sig(x: torch.Tensor) -> torch.Tensor:
     p = 1.0153755e-3 * u - 1.0678257e-1
     p = p * u - 2.3011138
     return x / (1.0 + torch.exp2(x * p))
+
+
+S1_GELU_TABLE = True     # round 6: the bf16 stage-1 kernel (csrc/stage1_w4.hip) evaluates its GELUs as a table look-up on the bf16-ROUNDED pre-activation
+
+
+def gelu_s1(x: torch.Tensor) -> torch.Tensor:
+    """The GELU of the stage-1 block as the engine computes it.  bf16 storage (csrc/stage1_w4.hip, TABLE): the pre-activation is rounded to bf16,
+    its magnitude clamped to the table's range [2^-10, 32) and the exact erf form (visformer.py:152-163's nn.GELU) looked up; fp16 storage (and
+    the image sizes that run stage1_ring.hip) keep gelu_sig on the fp32 pre-activation."""
+    if not S1_GELU_TABLE or STORAGE != torch.bfloat16 or 'act_s1' in SKIP:
+        return gelu_sig(x)
+    xb = x.to(torch.bfloat16).to(torch.float32)
+    a = xb.abs().clamp(min=2.0 ** -10, max=32.0 * (1.0 - 2.0 ** -8))
+    xb = torch.where(torch.signbit(xb), -a, a)
+    return F.gelu(xb.double()).float()
 
 
 class _Stream:
@@ -222,8 +238,8 @@ def visformer_forward_emul(sd: Dict[str, torch.Tensor], x: torch.Tensor, cfg: Vi
         p = f'stage1.{i}.'
         wa, ba = _fold_pre(sd[p + 'mlp.conv1.weight'], sd, p + 'norm2.bn', eps)
         ba = ba + _corr(means, p + 'mlp.conv1', xop, wa, 'w_s1') + wa[:, :, 0, 0] @ cst
-        h1 = bf(gelu_sig(F.conv2d(xop, _w(wa, 'w_s1')) + _b(ba)), 'act_s1')
-        h2 = bf(gelu_sig(F.conv2d(h1, bf(sd[p + 'mlp.conv2.weight'], 'w_s1'), padding=1, groups=cfg.group)), 'act_s1')
+        h1 = bf(gelu_s1(F.conv2d(xop, _w(wa, 'w_s1')) + _b(ba)), 'act_s1')
+        h2 = bf(gelu_s1(F.conv2d(h1, bf(sd[p + 'mlp.conv2.weight'], 'w_s1'), padding=1, groups=cfg.group)), 'act_s1')
         cst = cst + _corr(means, p + 'mlp.conv3', h2, sd[p + 'mlp.conv3.weight'], 'w_s1')
         y = xfull + F.conv2d(h2, bf(sd[p + 'mlp.conv3.weight'], 'w_s1'))
         xop, xfull = st.store(y)

@@ -40,3 +40,22 @@ def test_gelu_sig_matches_erf_gelu():
     from oracle import visformer_emul as ve
     x = torch.linspace(-12, 12, 20001)
     assert (ve.gelu_sig(x) - torch.nn.functional.gelu(x)).abs().max().item() <= 3e-5
+
+
+def test_stage1_table_gelu_model_is_the_exact_gelu_of_the_bf16_rounded_input():
+    """oracle.visformer_emul.gelu_s1 (the model of stage1_w4.hip's table look-up): exact erf GELU of the bf16-rounded pre-activation, magnitude
+    clamped to the table's range [2^-10, 32) - within one bf16 rounding of the input from the reference's nn.GELU."""
+    from oracle import visformer_emul as ve
+    x = torch.cat([torch.linspace(-40, 40, 40001), torch.tensor([0.0, 1e-5, -1e-5, 2.0 ** -10, -2.0 ** -11])])
+    g = ve.gelu_s1(x)
+    xb = x.to(torch.bfloat16).float()
+    inside = (xb.abs() >= 2.0 ** -10) & (xb.abs() < 31.5)
+    assert torch.equal(g[inside], torch.nn.functional.gelu(xb[inside].double()).float())
+    # |d gelu / dx| <= 1.13: the look-up moves the result by at most that times the input's rounding (2^-9 relative) - and the values below the
+    # table's first code share its entry (|gelu| <= 2^-11 there)
+    assert ((g - torch.nn.functional.gelu(x))[x.abs() < 31.5].abs() <= 1.13 * x[x.abs() < 31.5].abs() * 2.0 ** -8 + 2.0 ** -10).all()
+    try:
+        ve.STORAGE = torch.float16
+        assert torch.equal(ve.gelu_s1(x), ve.gelu_sig(x))            # fp16 storage keeps the VALU form
+    finally:
+        ve.STORAGE = torch.bfloat16

@@ -403,8 +403,10 @@ def test_stage1_ring_block_matches_unfused_math(B, HW, dtype):
     b1 = torch.randn(256, generator=g) * 0.2
     w2 = q(torch.randn(256, 32, 3, 3, generator=g) / math.sqrt(288), dtype)
     w3 = q(torch.randn(128, 256, 1, 1, generator=g) / math.sqrt(256), dtype)
-    h1 = q(F.gelu(F.conv2d(x, w1, b1)), dtype)
-    h2 = q(F.gelu(F.conv2d(h1, w2, padding=1, groups=8)), dtype)
+    # the bf16 build of stage1_w4.hip looks its GELUs up in a table indexed by the bf16-ROUNDED pre-activation (round 6): one more rounding point
+    pre = (lambda z: q(z, dtype)) if dtype == torch.bfloat16 else (lambda z: z)
+    h1 = q(F.gelu(pre(F.conv2d(x, w1, b1))), dtype)
+    h2 = q(F.gelu(pre(F.conv2d(h1, w2, padding=1, groups=8))), dtype)
     ref = x + F.conv2d(h2, w3)
     xd = x.permute(0, 2, 3, 1).contiguous().to('cuda', dtype)
     args = (pack_w(w1, 1, dtype)[0].cuda(), b1.cuda(), pack_w(w2, 8, dtype).cuda(), pack_w(w3, 1, dtype)[0].cuda())
@@ -421,7 +423,7 @@ def test_stage1_ring_block_matches_unfused_math(B, HW, dtype):
     if HW == 20 and dtype == torch.bfloat16:                                                 # the 16-wave ring kernel computes the same block
         y0 = ops.stage1_block(xd, *args).float().cpu().permute(0, 3, 1, 2)
         assert (y0 - got).abs().max().item() <= 3e-2 * max(1.0, float(ref.abs().max()))
-        assert (y0 - got).abs().mean().item() <= 1e-3
+        assert (y0 - got).abs().mean().item() <= 2e-3      # (measured 1.4e-3: the ring kernel keeps gelu_sig on the fp32 pre-activation; 8e-6 before the table)
 
 
 @pytest.mark.parametrize('C', [256, 512])
