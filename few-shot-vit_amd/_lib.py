@@ -117,9 +117,6 @@ SIGNATURES = {
                                           C.POINTER(C.c_float), C.POINTER(C.c_float), _fp, _vp]),
     'fsvit_attention_backward': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     'fsvit_sampler_draw': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    'fsvit_mlp_train_rows_pad': (_i, [_i]),
-    'fsvit_mlp_train_forward': (_i, [_vp, _fp, _fp, _fp, _fp, _fp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    'fsvit_mlp_train_backward': (_i, [_vp, _fp, _fp, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 
 _lib = None

@@ -674,14 +674,9 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
       const auto& cs = (sg == 2 ? sp.s2 : sp.s3)[i];
       const std::string p = "stage" + std::to_string(sg) + "." + std::to_string(i) + ".";
       b.x = xcur;
-      // Round 5: the Mlp branch as ONE row-wise launch behind norm2's statistics (mlp_train.hip MODE 0: BatchNorm folded into fc1, GELU + derivative, fc2,
-      // DropPath-scaled residual; xn2 / h / g' as by-products) - its outputs are padded to whole 128-row tiles.  Stage 2 only by default (mlp_train_preferred);
-      // FSVIT_MLP_TRAIN_FUSED=0: two gemm256 launches everywhere, =2: the kernel at both stages.
-      const bool mlp_fused = t->gdt == 1 && mlp_train_supported(t->gdt, C, hid) && mlp_train_preferred(C, hid);
-      const size_t Mp = mlp_fused ? (size_t)mlp_train_rows_pad((int)M) : M;
       NEED(b.xn1 = take_act(t, M * C)); NEED(b.qkv = take_act(t, M * 3 * heads * hdp)); NEED(b.ctx = take_act(t, M * heads * hdp));
-      NEED(b.xa = take_act(t, M * C)); NEED(b.xn2 = take_act(t, Mp * C)); NEED(b.z1 = take_act(t, Mp * hid)); NEED(b.h = take_act(t, Mp * hid));
-      NEED(b.out = take_act(t, Mp * C));
+      NEED(b.xa = take_act(t, M * C)); NEED(b.xn2 = take_act(t, M * C)); NEED(b.z1 = take_act(t, M * hid)); NEED(b.h = take_act(t, M * hid));
+      NEED(b.out = take_act(t, M * C));
       const size_t mark = t->tmp.off;
       void* zp = take_tmp(t, M * C); NEED(zp);
       T_TRY(bn_fwd(t, p + "norm1.bn", b.x, (int)M, C, ACT_NONE, nullptr, b.xn1, &b.bn1, &pend));
@@ -691,22 +686,6 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
       b.s1 = dp_scale(t, dp_call, blk, nblk);
       if (t->dp_rate * blk > 0.f) ++dp_call;
       pend = PendingAdd{b.x, zp, b.s1, b.xa, M * C, (size_t)Ho * Ho * C};                       // b.xa = b.x + s1 * zp inside norm2's reduce pass
-      if (mlp_fused) {
-        T_TRY(bn_fwd(t, p + "norm2.bn", b.xa, (int)M, C, ACT_NONE, nullptr, nullptr, &b.bn2, &pend));      // statistics only (and the queued add)
-        const fsvit_param *w1 = getp(t, cs.fc1.wname), *w2 = getp(t, cs.fc2.wname);
-        if (!w1 || !w2) return FSVIT_ERR_KEY;
-        void* imgA = t->tmp.take(mlp_train_image_bytes(C, hid)); NEED(imgA);
-        float* b1f = (float*)t->tmp.take((size_t)hid * 4); NEED(b1f);
-        T_RUN(launch_mlp_fold_pack(w1->data, b.bn2.sa, b.bn2.sb, imgA, b1f, C, hid, st));
-        void* imgB = nullptr;       // W2 [C][hid] as the second GEMM's A operand: rows = output channels, k = hidden units
-        T_TRY(packed_weight(t, PackJob{w2->data, nullptr, hid, 1, 1, 1, 1, 4, C, hid, 1, 1, 1, 1}, mlp_train_image_bytes(C, hid), &imgB));
-        b.s2 = dp_scale(t, dp_call, blk, nblk);
-        if (t->dp_rate * blk > 0.f) ++dp_call;
-        T_RUN(launch_mlp_train_fwd(b.xa, imgA, b1f, imgB, b.bn2.sa, b.bn2.sb, b.s2, Ho * Ho, b.out, b.xn2, b.h, b.z1, (int)M, C, hid, st));
-        t->tmp.off = mark;
-        xcur = b.out;
-        continue;
-      }
       T_TRY(bn_fwd(t, p + "norm2.bn", b.xa, (int)M, C, ACT_NONE, nullptr, b.xn2, &b.bn2, &pend));
       T_TRY(conv_fwd(t, cs.fc1, b.xn2, B, Ho, Ho, b.h, nullptr, b.z1));                        // b.z1 = GELU'(fc1(xn2))
       T_TRY(conv_fwd(t, cs.fc2, b.h, B, Ho, Ho, zp, nullptr));
@@ -763,29 +742,13 @@ int train_backward_impl(TR* t, const float* dfeat) {
       void* dz2 = take_tmp(t, M * C); NEED(dz2);
       if (i == (int)blocks.size() - 1) { T_TRY(side_guard(t, dz2, M * C * t->es)); T_RUN(launch_add_scaled(nullptr, dx, b.s2, dz2, M * C, (size_t)Ho * Ho * C, dt, st)); }
       T_TRY(conv_bwd_weight(t, cs.fc2, b.h, B, Ho, Ho, dz2));
-      const bool mlp_fused = t->gdt == 1 && mlp_train_supported(t->gdt, C, hid) && mlp_train_preferred(C, hid);
-      const size_t Mp = mlp_fused ? (size_t)mlp_train_rows_pad((int)M) : M;
-      void* dh = take_tmp(t, Mp * hid); NEED(dh);
-      void* dxn2 = nullptr;
-      if (mlp_fused) {
-        // dz2 -> dh = (dz2 W2) * g' -> dxn2 = dh W1 in one row-wise launch (mlp_train.hip MODE 1); dh is written once, for the two weight gradients
-        const fsvit_param *w1 = getp(t, cs.fc1.wname), *w2 = getp(t, cs.fc2.wname);
-        if (!w1 || !w2) return FSVIT_ERR_KEY;
-        void *imgA = nullptr, *imgB = nullptr;
-        // first GEMM: rows = hidden units u, k = channels c, element W2[c][u]; second: rows = channels c, k = hidden units u, element W1[u][c]
-        T_TRY(packed_weight(t, PackJob{w2->data, nullptr, 1, hid, 1, 1, 1, 3, hid, C, 1, 1, 1, 1}, mlp_train_image_bytes(C, hid), &imgA));
-        T_TRY(packed_weight(t, PackJob{w1->data, nullptr, 1, C, 1, 1, 1, 4, C, hid, 1, 1, 1, 1}, mlp_train_image_bytes(C, hid), &imgB));
-        dxn2 = take_tmp(t, Mp * C); NEED(dxn2);
-        T_TRY(side_guard(t, dh, Mp * hid * t->es));
-        T_TRY(side_guard(t, dxn2, Mp * C * t->es));
-        T_RUN(launch_mlp_train_bwd(dz2, imgA, imgB, b.z1, dh, dxn2, (int)M, C, hid, st));
-        T_TRY(conv_bwd_weight(t, cs.fc1, b.xn2, B, Ho, Ho, dh));
-      } else {
-        T_TRY(conv_bwd_data(t, cs.fc2, dz2, B, Ho, Ho, dh, b.z1));                             // dh := dz1 (x GELU' in the epilogue)
-        T_TRY(conv_bwd_weight(t, cs.fc1, b.xn2, B, Ho, Ho, dh));
-        dxn2 = take_tmp(t, M * C); NEED(dxn2);
-        T_TRY(conv_bwd_data(t, cs.fc1, dh, B, Ho, Ho, dxn2));
-      }
+      // (round 5's row-wise Mlp kernel - forward and data gradient in one launch each - was a draw against these gemm256 launches for two rounds and is
+      // retired: tools/probes/variants/mlp_train/)
+      void* dh = take_tmp(t, M * hid); NEED(dh);
+      T_TRY(conv_bwd_data(t, cs.fc2, dz2, B, Ho, Ho, dh, b.z1));                               // dh := dz1 (x GELU' in the epilogue)
+      T_TRY(conv_bwd_weight(t, cs.fc1, b.xn2, B, Ho, Ho, dh));
+      void* dxn2 = take_tmp(t, M * C); NEED(dxn2);
+      T_TRY(conv_bwd_data(t, cs.fc1, dh, B, Ho, Ho, dxn2));
       // dx := d(xa) total = dx + norm2 backward;  attention branch:  xa = x + s1 * proj(attn(qkv(bn1(x)))):  dz2 := dzp = s1 * dx
       T_TRY(bn_bwd(t, p + "norm2.bn", b.bn2, dxn2, dx, dx, b.s1, dz2, (size_t)Ho * Ho));
       T_TRY(conv_bwd_weight(t, cs.proj, b.ctx, B, Ho, Ho, dz2));
@@ -1433,38 +1396,6 @@ extern "C" int fsvit_attention_backward(const void* qkv, const void* dctx, void*
   if (!qkv || !dctx || !dqkv) return fsvit_set_error(FSVIT_ERR_ARG, "null argument");
   int rc = launch_attention_bwd(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, dtype, (hipStream_t)stream);
   return rc ? fsvit_set_error(rc, "attention_bwd") : 0;
-}
-
-// Operator forms of the row-wise training Mlp (tests; the trainer packs through its batched weight pack).  Outputs have fsvit_mlp_train_rows_pad(M) rows.
-extern "C" int fsvit_mlp_train_rows_pad(int M) { return mlp_train_rows_pad(M); }
-extern "C" int fsvit_mlp_train_forward(const void* xa, const float* w1, const float* w2, const float* sa, const float* sb, const float* scale, int rows_per_img,
-                                       void* out, void* xn, void* h, void* g, int M, int C, int hid, void* stream) {
-  if (!xa || !w1 || !w2 || !sa || !sb || !out || !h || !g || M <= 0) return fsvit_set_error(FSVIT_ERR_ARG, "fsvit_mlp_train_forward: null argument");
-  if (!mlp_train_supported(1, C, hid)) return fsvit_set_error(FSVIT_ERR_ARG, "fsvit_mlp_train_forward: (C, hidden) must be (256, 1024) or (512, 2048)");
-  hipStream_t st = (hipStream_t)stream;
-  const size_t ib = mlp_train_image_bytes(C, hid);
-  unsigned char* ws = nullptr;
-  T_TRY((int)hipMalloc((void**)&ws, 2 * ib + (size_t)hid * 4));
-  int rc = launch_mlp_fold_pack(w1, sa, sb, ws, (float*)(ws + 2 * ib), C, hid, st);
-  if (rc == 0) rc = launch_pack_weight(w2, ws + ib, hid, 1, 1, 1, 1, 4, C, hid, 1, 1, 1, 1, 1, st);
-  if (rc == 0) rc = launch_mlp_train_fwd(xa, ws, (const float*)(ws + 2 * ib), ws + ib, sa, sb, scale, rows_per_img, out, xn, h, g, M, C, hid, st);
-  (void)hipStreamSynchronize(st);
-  (void)hipFree(ws);
-  return rc == 0 ? 0 : fsvit_set_error(rc, "fsvit_mlp_train_forward: %s", hipGetErrorString((hipError_t)rc));
-}
-extern "C" int fsvit_mlp_train_backward(const void* dz, const float* w1, const float* w2, const void* g, void* dh, void* dxn, int M, int C, int hid, void* stream) {
-  if (!dz || !w1 || !w2 || !g || !dh || !dxn || M <= 0) return fsvit_set_error(FSVIT_ERR_ARG, "fsvit_mlp_train_backward: null argument");
-  if (!mlp_train_supported(1, C, hid)) return fsvit_set_error(FSVIT_ERR_ARG, "fsvit_mlp_train_backward: (C, hidden) must be (256, 1024) or (512, 2048)");
-  hipStream_t st = (hipStream_t)stream;
-  const size_t ib = mlp_train_image_bytes(C, hid);
-  unsigned char* ws = nullptr;
-  T_TRY((int)hipMalloc((void**)&ws, 2 * ib));
-  int rc = launch_pack_weight(w2, ws, 1, hid, 1, 1, 1, 3, hid, C, 1, 1, 1, 1, 1, st);
-  if (rc == 0) rc = launch_pack_weight(w1, ws + ib, 1, C, 1, 1, 1, 4, C, hid, 1, 1, 1, 1, 1, st);
-  if (rc == 0) rc = launch_mlp_train_bwd(dz, ws, ws + ib, g, dh, dxn, M, C, hid, st);
-  (void)hipStreamSynchronize(st);
-  (void)hipFree(ws);
-  return rc == 0 ? 0 : fsvit_set_error(rc, "fsvit_mlp_train_backward: %s", hipGetErrorString((hipError_t)rc));
 }
 
 extern "C" int fsvit_visformer_trainer_set_freeze_bn(fsvit_visformer_trainer* t, int on) {

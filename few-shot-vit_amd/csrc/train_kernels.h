@@ -98,16 +98,4 @@ int launch_vit_cls_ln_fwd(const void* tokens, const float* gamma, const float* b
                           hipStream_t s);
 int launch_vit_cls_ln_bwd(const float* dfeat, const void* tokens, const float* mean, const float* rstd, const float* gamma, void* dtok, float* partial, float* dgamma,
                           float* dbeta, int B, int S, int D, int dtype, hipStream_t s);
-// ---- row-wise Mlp of the stage-2 / 3 blocks in the meta-tuning step (mlp_train.hip; 16-bit storage, (C, hid) = (256, 1024) / (512, 2048)).
-// Weight images: pack modes 3 / 4 of launch_pack_weight(_multi) with (O, Ig) = the (row, k) strides of the fp32 source, rows_pad / Kw = the logical
-// rows / k of the A operand; the forward's first image comes from launch_mlp_fold_pack (norm2's batch statistics folded into W1).
-// Every output has room for mlp_train_rows_pad(M) rows.
-bool mlp_train_supported(int dtype, int C, int hid);
-bool mlp_train_preferred(int C, int hid);      // FSVIT_MLP_TRAIN_FUSED: 0 never, 1 (default) stage 2 only, 2 both stages
-int mlp_train_rows_pad(int M);
-size_t mlp_train_image_bytes(int C, int hid);
-int launch_mlp_fold_pack(const float* W1, const float* sa, const float* sb, void* imgA, float* b1f, int C, int hid, hipStream_t s);
-int launch_mlp_train_fwd(const void* xa, const void* imgA, const float* b1f, const void* imgB, const float* sa, const float* sb, const float* scale, int rows_per_img,
-                         void* out, void* xn, void* h, void* g, int M, int C, int hid, hipStream_t s);
-int launch_mlp_train_bwd(const void* dz, const void* imgA, const void* imgB, const void* g, void* dh, void* dxn, int M, int C, int hid, hipStream_t s);
 }  // namespace fsvit

@@ -111,6 +111,7 @@ class _EncoderEngine:
             raise RuntimeError(f'{type(self).__name__} needs a GPU device (no CPU fallback)')
         log_numerics_once(numerics, type(self).__name__)
         self.chunk_images = int(chunk_images or os.environ.get('FSVIT_CHUNK', self._default_chunk))
+        self._chunk_given = bool(chunk_images or os.environ.get('FSVIT_CHUNK'))
         c = self._make_cfg(cfg)
         self.img_size = cfg['img_size']
         keep, arr = [], (_lib.Tensor * len(state_dict))()
@@ -148,8 +149,17 @@ class _EncoderEngine:
 
     def workspace(self, n_img: int) -> torch.Tensor:
         chunk = max(1, min(n_img, self.chunk_images))
-        need = getattr(self.lib, self._fn['workspace_bytes'])(self.h, chunk)
+        ws_bytes = getattr(self.lib, self._fn['workspace_bytes'])
+        need = ws_bytes(self.h, chunk)
         if self._ws is None or self._ws.numel() < need:
+            if not self._chunk_given:
+                # the default chunk (the benched 12 800 images) shrinks on a device that cannot spare half of its free memory for the workspace
+                free = torch.cuda.mem_get_info(self.device)[0] + (self._ws.numel() if self._ws is not None else 0)
+                while need > 0.5 * free and chunk > 100:
+                    chunk //= 2
+                    need = ws_bytes(self.h, chunk)
+                    self.chunk_images = chunk                # (the C side takes the largest chunk that fits the workspace it is handed)
+            self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
@@ -224,7 +234,7 @@ class VisformerEngine(_EncoderEngine):
     state_dict: encoder-relative reference keys."""
     _fn = dict(create='fsvit_visformer_create', destroy='fsvit_visformer_destroy', out_dim='fsvit_visformer_out_dim',
                workspace_bytes='fsvit_visformer_workspace_bytes', forward='fsvit_visformer_forward')
-    _default_chunk = 3200
+    _default_chunk = 12800      # the benched launch size (round 6: was 3200 - a drop-in user ran the persistent kernels at a quarter of their launch size)
 
     def _make_cfg(self, cfg):
         c = _lib.VisformerCfg()
@@ -798,39 +808,6 @@ class ops:
         with torch.cuda.device(x.device):
             _lib.check(lib.fsvit_conv1x1_wgrad(_ptr(x), _ptr(dz), _ptr(dw), x.shape[0], dz.shape[1], x.shape[1], dt, _stream_ptr(x.device)))
         return dw
-
-    @staticmethod
-    def mlp_train_forward(xa, w1, w2, sa, sb, scale=None, rows_per_img=1, want_xn=True):
-        """Row-wise training Mlp (fsvit_mlp_train_forward): xa [M,C] bf16, w1 [hid,C], w2 [C,hid], sa / sb [C] fp32, scale [M / rows_per_img] fp32 or
-        None -> (out [M,C], xn [M,C] or None, h [M,hid], g [M,hid]) bf16: out = xa + scale * W2 GELU(W1 (sa xa + sb))."""
-        _require_cuda(xa, w1, w2, sa, sb, scale)
-        lib = _lib.load()
-        M, Cc = xa.shape
-        hid = w1.shape[0]
-        Mp = lib.fsvit_mlp_train_rows_pad(M)
-        out = torch.empty(Mp, Cc, dtype=xa.dtype, device=xa.device)
-        xn = torch.empty(Mp, Cc, dtype=xa.dtype, device=xa.device) if want_xn else None
-        h = torch.empty(Mp, hid, dtype=xa.dtype, device=xa.device)
-        g = torch.empty(Mp, hid, dtype=xa.dtype, device=xa.device)
-        with torch.cuda.device(xa.device):
-            _lib.check(lib.fsvit_mlp_train_forward(_ptr(xa.contiguous()), _ptr(w1.contiguous()), _ptr(w2.contiguous()), _ptr(sa), _ptr(sb), _ptr(scale),
-                                                   int(rows_per_img), _ptr(out), _ptr(xn), _ptr(h), _ptr(g), M, Cc, hid, _stream_ptr(xa.device)))
-        return out[:M], (xn[:M] if want_xn else None), h[:M], g[:M]
-
-    @staticmethod
-    def mlp_train_backward(dz, w1, w2, g):
-        """Data gradient of the row-wise training Mlp (fsvit_mlp_train_backward): dz [M,C], g [M,hid] bf16 -> (dh [M,hid] = (dz W2) * g, dxn [M,C] = dh W1)."""
-        _require_cuda(dz, w1, w2, g)
-        lib = _lib.load()
-        M, Cc = dz.shape
-        hid = w1.shape[0]
-        Mp = lib.fsvit_mlp_train_rows_pad(M)
-        dh = torch.empty(Mp, hid, dtype=dz.dtype, device=dz.device)
-        dxn = torch.empty(Mp, Cc, dtype=dz.dtype, device=dz.device)
-        with torch.cuda.device(dz.device):
-            _lib.check(lib.fsvit_mlp_train_backward(_ptr(dz.contiguous()), _ptr(w1.contiguous()), _ptr(w2.contiguous()), _ptr(g.contiguous()), _ptr(dh), _ptr(dxn),
-                                                    M, Cc, hid, _stream_ptr(dz.device)))
-        return dh[:M], dxn[:M]
 
     @staticmethod
     def conv3x3_wgrad(x_nhwc, dz, O, Ig, groups, limbs='bf16'):

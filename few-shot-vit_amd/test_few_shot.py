@@ -52,10 +52,25 @@ def build_model(config, numerics=None):
     return model
 
 
-def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch_batches=16, numerics=None,
+def default_launch_batches(engine, images_per_batch, img_size, device):
+    """Reference batches (`ep_per_batch` episodes each) per engine launch when the caller does not say: one encoder chunk's worth of images (12 800
+    for the Visformer: the size the persistent kernels are tuned and benched at), bounded so that the launch's fp32 input and its
+    uint8 -> fp32 transform output stay within a quarter of the free device memory."""
+    n_img = engine.chunk_images
+    free = torch.cuda.mem_get_info(device)[0]
+    n_img = min(n_img, max(images_per_batch, int(0.25 * free) // (3 * img_size * img_size * 4)))
+    return max(1, n_img // images_per_batch)
+
+
+def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch_batches=None, numerics=None,
              rank=0, world=1, device=None, log=print, collect_pred=False):
+    """launch_batches: reference batches per engine launch; None (the default, also the CLI's) = `default_launch_batches` - the benched
+    configuration (128 five-shot episodes of 100 images)."""
+    import time
+    t_call = time.perf_counter()
     fix_random_seeds(12345)
     dataset = datasets.make(config['dataset'], **config['dataset_args'])
+    t_dataset = time.perf_counter()
     n_way, n_query = 5, 15
     sampler = CategoriesSampler(dataset.label, n_batch, n_way, shot + n_query, ep_per_batch=ep_per_batch,
                                 rank=rank, world_size=world)
@@ -63,12 +78,14 @@ def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch
     model = build_model(config, numerics).to(device).eval()
     if rank == 0:
         log('num params: {}'.format(utils.compute_n_params(model)))
+    t_model = time.perf_counter()
     engine = model.encoder.engine()
     temp = float(model.temp.detach()) if isinstance(model.temp, torch.Tensor) else float(model.temp)
+    if launch_batches is None:
+        launch_batches = default_launch_batches(engine, ep_per_batch * n_way * (shot + n_query), engine.img_size, device)
 
     np.random.seed(12345)                                  # fixes the episode stream (test_few_shot.py:76)
     out = None
-    import time
     torch.cuda.synchronize(device)
     t_loop = time.perf_counter()
     # the reference keeps ONE pair of averagers and ONE va_lst across epochs (test_few_shot.py:73-74 sit outside the epoch loop), so the
@@ -126,6 +143,8 @@ def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch
             out['pred'] = torch.cat(preds) if preds else torch.zeros(0, n_way * n_query, dtype=torch.uint8)
         # sampler -> gather + transform -> encoder + head -> statistics exchange, everything after model / dataset construction (the gather above synchronised)
         out['loop_seconds'] = time.perf_counter() - t_loop
+        out['launch_batches'] = launch_batches
+        out['phase_seconds'] = {'dataset': t_dataset - t_call, 'model': t_model - t_dataset, 'engine': t_loop - t_model, 'loop': out['loop_seconds']}
         if rank == 0:
             log('test epoch {}: acc={:.2f} +- {:.2f} (%), loss={:.4f} (@{})'.format(
                 epoch, out['acc'] * 100, out['ci'] * 100, out['loss'], last_label))
@@ -140,7 +159,7 @@ def main():
     parser.add_argument('--gpu', default=None, help='kept for CLI compatibility; use torchrun for multi-GPU')
     parser.add_argument('--episodes', type=int, default=2000, help='number of batches (reference: 2000)')
     parser.add_argument('--ep-per-batch', type=int, default=1)
-    parser.add_argument('--launch-batches', type=int, default=16)
+    parser.add_argument('--launch-batches', type=int, default=None, help='reference batches per engine launch (default: one encoder chunk, 12 800 images = 128 five-shot episodes)')
     parser.add_argument('--numerics', default=None, choices=[None, 'bf16', 'f16', 'bf16x2', 'f16x2', 'parity'],
                         help="default: FSVIT_NUMERICS or 'bf16' (throughput mode: logits within ~5e-2 of the reference's, 98.9 %% arg-max agreement). "
                              "'f16' runs at the SAME rate with 8 x tighter logits (~8e-3, 99.85 %%) when the checkpoint's weights fit the fp16 range; "

@@ -385,19 +385,6 @@ int fsvit_conv1x1_wgrad(const void* x_dev, const void* dz_dev, float* dw_dev, in
 int fsvit_attention_backward(const void* qkv_dev, const void* dctx_dev, void* dqkv_dev, int B, int S, int heads, int hd, int hdp,
                              float scale, int dtype, void* stream);
 
-/* Mlp branch of a Visformer attention block inside the meta-tuning step (test_phase/models/visformer.py:146-150 `conv1 -> GELU -> conv3` with
- * spatial_conv=False, :262 `x + drop_path(mlp(norm2(x)))` in train mode; its autograd in meta_tuning_sun_m/train_meta.py:168) as ONE row-wise launch each
- * way, bf16 rows, (C, hidden) = (256, 1024) or (512, 2048):
- *   forward:  out = xa + scale[row / rows_per_img] * W2 GELU(W1 (sa xa + sb));  by-products h = GELU(z1), g = GELU'(z1) [M][hidden], xn = sa xa + sb.
- *             sa / sb fp32 [C] = norm2's batch-statistics scale / shift (folded into W1 on the device), scale fp32 per image or NULL, xn may be NULL;
- *   backward: dh = (dz W2) * g,  dxn = dh W1   (the data gradient; the two weight gradients are fsvit_conv1x1_wgrad on (h, dz) and (xn, dh)).
- * w1 [hidden][C], w2 [C][hidden] fp32 (PyTorch layout).  Every OUTPUT must have room for fsvit_mlp_train_rows_pad(M) rows (whole 128-row tiles). */
-int fsvit_mlp_train_rows_pad(int M);
-int fsvit_mlp_train_forward(const void* xa_dev, const float* w1_dev, const float* w2_dev, const float* sa_dev, const float* sb_dev, const float* scale_dev,
-                            int rows_per_img, void* out_dev, void* xn_dev, void* h_dev, void* g_dev, int M, int C, int hid, void* stream);
-int fsvit_mlp_train_backward(const void* dz_dev, const float* w1_dev, const float* w2_dev, const void* g_dev, void* dh_dev, void* dxn_dev, int M, int C,
-                             int hid, void* stream);
-
 /* ---------------------------------------------------------------- episode sampler (host only, no GPU)
  * The draws of `CategoriesSampler.__iter__` (test_phase/datasets/samplers.py:19-35) replayed natively on the legacy numpy generator state: per episode
  * `np.random.choice(n_cat, n_cls, replace=False)`, then per chosen class `np.random.choice(catlocs[c], n_per, replace=False)`.  mt_key [624] / mt_pos =

@@ -113,3 +113,37 @@ def test_sampler_rank_sharding_partitions_the_reference_stream():
             for j, b in enumerate(mine):
                 got[r + j * world] = b
         assert [got[i] for i in range(10)] == full
+
+
+def _register_tiny():
+    """The registry name the reference-written checkpoints carry (tests/golden/make_golden.py checkpoint_golden registers the same factory on the
+    reference side): tiny Visformer, one block per stage."""
+    from fewshot_vit_amd.models import register
+    from fewshot_vit_amd.models.visformer import Visformer
+    register('tiny_visformer')(lambda **kw: Visformer(img_size=80, init_channels=8, embed_dim=64, depth=[1, 1, 1], num_heads=6, mlp_ratio=4., group=8, **kw))
+
+
+def test_reference_written_checkpoints_rebuild_through_models_load(golden_dir):
+    """The checkpoints in tests/golden/ref_ckpt_*.pth were written by the REFERENCE (torch.save of the dict of meta_tuning_sun_m/train_meta.py:241-257 from
+    a live reference model, `model: meta-baseline` and `model: classifier`).  `models.load` (models.py:21-26) must rebuild both with strict key / shape
+    agreement, keep every tensor bit for bit, and the `load_encoder:` route of test_few_shot.py:61-63 must take `.encoder` of the classifier one."""
+    import os
+    from fewshot_vit_amd import models
+    _register_tiny()
+    for name, kind in (('ref_ckpt_meta_baseline.pth', 'meta-baseline'), ('ref_ckpt_classifier.pth', 'classifier')):
+        ck = torch.load(os.path.join(golden_dir, name), map_location='cpu', weights_only=False)
+        assert {'file', 'config', 'model', 'model_args', 'model_sd', 'training'} <= set(ck) and ck['model'] == kind
+        assert {'epoch', 'optimizer', 'optimizer_args', 'optimizer_sd'} <= set(ck['training'])
+        m = models.load(ck)
+        sd = m.state_dict()
+        assert set(sd) == set(ck['model_sd'])
+        for k, v in ck['model_sd'].items():
+            assert torch.equal(sd[k].cpu(), v), k
+        assert m.encoder.out_dim == 128
+        if kind == 'meta-baseline':
+            assert float(m.temp) == 7.5
+        else:
+            assert tuple(sd['classifier.linear.weight'].shape) == (7, 128)
+            fresh = models.make('meta-baseline', encoder=None)
+            fresh.encoder = m.encoder
+            assert float(fresh.temp) == 10.0 and fresh.encoder.out_dim == 128

@@ -175,3 +175,36 @@ def test_rccl_communicator_runs_the_exchanges_of_the_multi_gpu_paths():
         env.pop(k, None)
     r = subprocess.run([sys.executable, '-c', RCCL_CHILD], capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
     assert r.returncode == 0 and 'rccl-ok' in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize('numerics,tol', [('parity', 1e-3), ('bf16x2', 1e-3), ('f16', 2e-2), ('bf16', 0.12)])
+def test_reference_written_checkpoints_drop_in(golden_dir, monkeypatch, numerics, tol):
+    """tests/golden/ref_ckpt_*.pth are the REFERENCE's own torch.save output (train_meta.py:241-257 schema, tiny Visformer; tests/golden/make_golden.py
+    checkpoint_golden) and ref_ckpt_expected.npz the logits the reference computes from them.  `models.load` of the `meta-baseline` checkpoint, of the
+    `classifier` one (test_phase/models/classifier.py:11-24), and the `load_encoder:` route of test_few_shot.py:55-63 must reproduce them: within 1e-3
+    in the 1e-3-grade modes (the encoder_args in the file are the reference's - empty - so the mode comes from FSVIT_NUMERICS as for a drop-in user)."""
+    from fewshot_vit_amd import models, synthetic
+    from fewshot_vit_amd.utils import few_shot as fs
+    from test_boundary_cpu import _register_tiny
+    _register_tiny()
+    monkeypatch.setenv('FSVIT_NUMERICS', numerics)
+    z = np.load(os.path.join(golden_dir, 'ref_ckpt_expected.npz'))
+    x = synthetic.synthetic_episodes(51, 1, 5, 1, 3)
+    xs, xq = fs.split_shot_query(x, 5, 1, 3, 1)
+    m = models.load(torch.load(os.path.join(golden_dir, 'ref_ckpt_meta_baseline.pth'), map_location='cpu', weights_only=False)).cuda().eval()
+    with torch.no_grad():
+        got = m(xs.cuda(), xq.cuda()).cpu().numpy()
+    d_mb = np.abs(got - z['meta_baseline.logits']).max()
+    cls = models.load(torch.load(os.path.join(golden_dir, 'ref_ckpt_classifier.pth'), map_location='cpu', weights_only=False)).cuda().eval()
+    fresh = models.make('meta-baseline', encoder=None)
+    fresh.encoder = cls.encoder
+    fresh = fresh.cuda().eval()
+    with torch.no_grad():
+        got_le = fresh(xs.cuda(), xq.cuda()).cpu().numpy()
+        got_cls = cls(x[:6].cuda()).float().cpu().numpy()
+    d_le = np.abs(got_le - z['load_encoder.logits']).max()
+    d_cls = np.abs(got_cls - z['classifier.logits']).max()
+    print(f'[{numerics}] reference checkpoints: max|dlogit| meta-baseline {d_mb:.3e}, load_encoder {d_le:.3e}, classifier {d_cls:.3e}')
+    assert d_mb <= tol and d_le <= tol and d_cls <= tol
+    if numerics in ('parity', 'bf16x2'):
+        assert (got.argmax(-1) == z['meta_baseline.logits'].argmax(-1)).all()

@@ -70,7 +70,7 @@ __device__ __forceinline__ void lgkm_wait(int n) {            // n is a compile-
   }
 }
 
-template <int MODE, int NP, int REPL>
+template <int MODE, int NP, int REPL, int NACC = 4>
 __global__ __launch_bounds__(256, 1) void probe(const float* __restrict__ xin, const unsigned short* __restrict__ tab_g, unsigned* __restrict__ out,
                                                 long long* __restrict__ clk, int iters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void probe(const float* __restrict__ xin, c
       constexpr int r = decltype(rc)::value;
       if constexpr (r < 32) {
         lgkm_wait(S.n_at_wait_frag[r] - S.frag_seq[r] - 1);
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[r & 3]) : "a"(wf), "v"(fr[r & 3]));
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[r % NACC]) : "a"(wf), "v"(fr[r & 3]));
         if constexpr (r + 3 < 32) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[(r + 3) & 3]) : "v"(fragb), "n"(((r + 3) & 15) * 1024));
       }
       if constexpr (MODE != 2) cfor<NP>([&](auto kc) {
@@ -203,14 +203,14 @@ static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; _
 static unsigned short f2bf(float f) { unsigned u; __builtin_memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); }
 static double gelu(double x) { return 0.5 * x * (1.0 + erf(x * 0.70710678118654752440)); }
 
-template <int MODE, int NP, int REPL> void run(const char* name, int dist, const float* xin, const unsigned short* tab, unsigned* out, long long* clk, const std::vector<float>& hx) {
+template <int MODE, int NP, int REPL, int NACC = 4> void run(const char* name, int dist, const float* xin, const unsigned short* tab, unsigned* out, long long* clk, const std::vector<float>& hx) {
   const int iters = 2000;
-  hipFuncSetAttribute((const void*)probe<MODE, NP, REPL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-  probe<MODE, NP, REPL><<<256, 256, LDS>>>(xin, tab, out, clk, iters);
+  hipFuncSetAttribute((const void*)probe<MODE, NP, REPL, NACC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  probe<MODE, NP, REPL, NACC><<<256, 256, LDS>>>(xin, tab, out, clk, iters);
   hipDeviceSynchronize();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  probe<MODE, NP, REPL><<<256, 256, LDS>>>(xin, tab, out, clk, iters);
+  probe<MODE, NP, REPL, NACC><<<256, 256, LDS>>>(xin, tab, out, clk, iters);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   long long h; hipMemcpy(&h, clk, 8, hipMemcpyDeviceToHost);
@@ -258,6 +258,10 @@ int main() {
     hipMemcpy(xin, hx.data(), nx * 4, hipMemcpyHostToDevice);
     if (dist == 0) {
       run<2, 16, 1>("no GELU (floor)", dist, xin, tab, out, clk, hx);
+      run<2, 16, 1, 2>("floor, 2 accumulators", dist, xin, tab, out, clk, hx);      // (round 6: is a chain of MFMAs on ONE accumulator paced by its latency?)
+      run<2, 16, 1, 1>("floor, 1 accumulator", dist, xin, tab, out, clk, hx);
+      run<1, 16, 1, 2>("LDS table, 2 acc", dist, xin, tab, out, clk, hx);
+      run<1, 16, 1, 1>("LDS table, 1 acc", dist, xin, tab, out, clk, hx);
       run<3, 16, 1>("table VALU, no gather", dist, xin, tab, out, clk, hx);
       run<3, 64, 1>("table VALU, no gather", dist, xin, tab, out, clk, hx);
     }
