@@ -667,7 +667,7 @@ def _newest_profile(kind, what):
 
 
 # which template instantiation of a kernel runs for which layer of the eval step (the PMC summaries are keyed by instantiation)
-_INSTANCE_HINT = {'stage2': '<256,', 'stage3': '<512,', 'stem.conv2': '<64,', 'stem.conv3': '<128,', 'patch_embed2': '<512,', 'patch_embed3': '<'}
+_INSTANCE_HINT = {'stage2': '<256,', 'stage3': '<512,', 'stem.conv2': '<64,', 'stem.conv3': '<128,', 'patch_embed2': '<512,'}
 
 
 def _pmc_pick(table, kernel, layer):
@@ -710,11 +710,16 @@ def _committed_pmc(kind=''):
     return tabs[0], tabs[1], {'files': sorted(fresh), 'match_current_csrc': bool(fresh) and not stale}
 
 
-def _steps_of(meta_source, default=4):
-    """steps + warm-up of the profiled command (`--steps N --warmup W` in the summary's _meta.source)."""
+def _steps_of(meta):
+    """steps + warm-up of the profiled command: `_meta.steps_profiled` when the summary carries it (tools/pmc_traffic.py writes it since round 6), else
+    `--steps N --warmup W` parsed from _meta.source; None when neither is there (a silent default of 4 made a wrong byte count look
+    authoritative)."""
     import re
-    m1, m2 = re.search(r'--steps (\d+)', meta_source or ''), re.search(r'--warmup (\d+)', meta_source or '')
-    return (int(m1.group(1)) + int(m2.group(1))) if m1 and m2 else default
+    if isinstance(meta.get('steps_profiled'), int) and meta['steps_profiled'] > 0:
+        return meta['steps_profiled']
+    src = meta.get('source') or ''
+    m1, m2 = re.search(r'--steps (\d+)', src), re.search(r'--warmup (\d+)', src)
+    return (int(m1.group(1)) + int(m2.group(1))) if m1 and m2 else None
 
 
 def leg_roofline(kind, ms_per_step, mfma_frac):
@@ -723,7 +728,10 @@ def leg_roofline(kind, ms_per_step, mfma_frac):
     traffic, _, src = _committed_pmc(kind)
     if not traffic:
         return {'bound': 'hbm', 'bytes_per_step': None, 'achieved_TBps': None, 'frac_of_8TBps': None, 'mfma_frac': mfma_frac, 'pmc_files': '', 'pmc_match_current_csrc': False}
-    steps = _steps_of(traffic.get('_meta', {}).get('source'))
+    steps = _steps_of(traffic.get('_meta', {}))
+    if not steps:
+        return {'bound': 'hbm', 'bytes_per_step': None, 'achieved_TBps': None, 'frac_of_8TBps': None, 'mfma_frac': mfma_frac, 'pmc_files': ','.join(src['files']),
+                'pmc_match_current_csrc': src['match_current_csrc'], 'note': 'the committed traffic summary does not say how many steps it profiled'}
     total = sum(v.get('launches', 1) * v.get('hbm_bytes_per_launch', 0.0) for k, v in traffic.items() if k != '_meta')
     launches = sum(v.get('launches', 1) for k, v in traffic.items() if k != '_meta')
     bps = total / steps

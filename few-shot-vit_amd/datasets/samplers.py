@@ -16,14 +16,18 @@ class CategoriesSampler:
       `shard='replay'`: every rank draws the SAME global stream and keeps its batches.  `shard='scatter'`: rank 0 alone draws the
       stream - the whole index table of an epoch, n_batch x ep_per_batch x n_cls x n_per int64 (1.6 MB at the reference's 2000 x 100) -
       and ONE `torch.distributed.broadcast` hands it to the others, which do not touch their generators; the host work of a rank no
-      longer grows with the number of ranks it does not serve.  `shard=None`: 'scatter' when torch.distributed is initialised with
-      this world size, else 'replay'.
+      longer grows with the number of ranks it does not serve.  'scatter' puts a blocking broadcast inside `__iter__`: EVERY rank must iterate
+      the sampler the same number of times (a rank-0-only validation loop would hang), and the other ranks' generators do not advance - so it
+      is opt-in (`test_few_shot.evaluate` / `train_meta` ask for it, their ranks run in lockstep); `shard=None` = 'replay'.
     * `native`: the draws run in libfsvit's `fsvit_sampler_draw` on the generator state taken from `np.random.get_state()` and handed
       back with `set_state()` - the same MT19937 outputs through the same rejection sampling and Fisher-Yates order as numpy's
       `choice(replace=False)`, bit-identical indices AND generator state afterwards, ~7 x less host time per episode
-      (tests/test_sampler_native_cpu.py).  `native=None`: native when the library loads and the generator is MT19937."""
+      (tests/test_sampler_native_cpu.py).  `native=None`: native when the library loads and the generator is MT19937, numpy when the native
+      draw reports an error.  The native path draws AHEAD in slabs (64, 256, 1024 batches): the generator is where the reference's lazy per-batch
+      draws would leave it only at slab boundaries and at the end of the epoch - a caller that breaks out early, or uses np.random between
+      batches, passes `native_slab=1` (one batch per native call) or `native=False`."""
 
-    def __init__(self, label, n_batch, n_cls, n_per, ep_per_batch=1, rank=0, world_size=1, shard=None, native=None):
+    def __init__(self, label, n_batch, n_cls, n_per, ep_per_batch=1, rank=0, world_size=1, shard=None, native=None, native_slab=None):
         self.n_batch = n_batch
         self.n_cls = n_cls
         self.n_per = n_per
@@ -31,7 +35,7 @@ class CategoriesSampler:
         self.rank, self.world_size = rank, world_size
         if shard not in (None, 'replay', 'scatter'):
             raise ValueError(shard)
-        self.shard, self.native = shard, native
+        self.shard, self.native, self.native_slab = shard, native, native_slab
         label = np.array(label)
         self.catlocs = [np.argwhere(label == c).reshape(-1) for c in range(max(label) + 1)]
         self._items = np.ascontiguousarray(np.concatenate(self.catlocs).astype(np.int64))
@@ -86,16 +90,22 @@ class CategoriesSampler:
         lib = self._native_lib()
         if lib is not None:
             # in slabs, so that the first batches are out while a long epoch is still being drawn (the consumer launches GPU work in between)
-            done, slab = 0, 64
+            done, slab = 0, self.native_slab or 64
             while done < self.n_batch:
                 n = min(slab, self.n_batch - done)
-                tab = self._draw_native(lib, n)
+                try:
+                    tab = self._draw_native(lib, n)
+                except Exception:
+                    if self.native:
+                        raise
+                    tab = None                               # (e.g. a class shorter than n_per: numpy raises only when that class is drawn)
                 if tab is None:
                     break
                 for b in tab:
                     yield b
                 done += n
-                slab = min(4 * slab, 1024)
+                if not self.native_slab:
+                    slab = min(4 * slab, 1024)
             if done == self.n_batch:
                 return
             remaining = self.n_batch - done
@@ -106,10 +116,7 @@ class CategoriesSampler:
     def _shard_mode(self):
         if self.world_size == 1:
             return 'replay'
-        if self.shard is not None:
-            return self.shard
-        import torch.distributed as dist
-        return 'scatter' if dist.is_available() and dist.is_initialized() and dist.get_world_size() == self.world_size else 'replay'
+        return self.shard or 'replay'
 
     def __iter__(self):
         if self._shard_mode() == 'scatter':

@@ -12,6 +12,12 @@ import torch
 import torch.distributed as dist
 
 
+def sampler_shard(world):
+    """CategoriesSampler(shard=...) for a loop that EVERY rank runs in lockstep: 'scatter' (rank 0 draws, one broadcast per epoch) when
+    torch.distributed is up with this world size, else None (= 'replay': every rank draws the whole stream)."""
+    return 'scatter' if world > 1 and dist.is_available() and dist.is_initialized() and dist.get_world_size() == world else None
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from torchrun's environment; returns (rank, world, local_rank)."""
     world = int(os.environ.get('WORLD_SIZE', 1))

@@ -73,7 +73,7 @@ def evaluate(config, shot=1, test_epochs=1, n_batch=2000, ep_per_batch=1, launch
     t_dataset = time.perf_counter()
     n_way, n_query = 5, 15
     sampler = CategoriesSampler(dataset.label, n_batch, n_way, shot + n_query, ep_per_batch=ep_per_batch,
-                                rank=rank, world_size=world)
+                                rank=rank, world_size=world, shard=parallel.sampler_shard(world))
     device = device or torch.device('cuda', torch.cuda.current_device())
     model = build_model(config, numerics).to(device).eval()
     if rank == 0:

@@ -55,7 +55,7 @@ def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, sa
         ef_epoch = config.get('eval_fs_epoch') or 5
         for n_shot in n_shots:
             fs_samplers.append(CategoriesSampler(fs_dataset.label, config.get('fs_batches', 200), 5, n_shot + 15, ep_per_batch=4, rank=rank,
-                                                 world_size=world))
+                                                 world_size=world, shard=parallel.sampler_shard(world)))
     if rank == 0:
         log('train dataset: {} (x{}), {}'.format(tuple(train_dataset[0][0].shape), len(train_dataset), train_dataset.n_classes))
 

@@ -114,7 +114,7 @@ def main(config, name=None, tag=None, rank=0, world=1, device=None, log=None, sa
         if config.get(key):
             ds = datasets.make(config[key], **config[key + '_args'])
             evals.append((nm, ds, CategoriesSampler(ds.label, config.get('eval_batches', 500 if warmup else 200), n_way, n_shot + n_query, ep_per_batch=4,
-                                                    rank=rank, world_size=world)))
+                                                    rank=rank, world_size=world, shard=parallel.sampler_shard(world))))
     if rank == 0:
         log('train dataset: {} (x{}), {}'.format(tuple(train_dataset[0][0].shape), len(train_dataset), train_dataset.n_classes))
 

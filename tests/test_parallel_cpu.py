@@ -158,8 +158,12 @@ def _stream_worker(rank, world, port, n_batch, shard, q):
     label = np.repeat(np.arange(20), 600).tolist()
     np.random.seed(12345)
     before = np.random.get_state()[1].copy()
+    # shard=None is 'replay' ('scatter' hangs a loop that not every rank runs); the drivers ask for what parallel.sampler_shard says
+    if shard == 'driver':
+        shard = parallel.sampler_shard(w)
+        assert shard == 'scatter'
     sampler = CategoriesSampler(label, n_batch, 5, 6, 2, rank=r, world_size=w, shard=shard)
-    assert sampler._shard_mode() == ('scatter' if shard in (None, 'scatter') else 'replay')
+    assert sampler._shard_mode() == ('scatter' if shard == 'scatter' else 'replay')
     epochs = [[b.tolist() for b in sampler] for _ in range(2)]           # the second epoch continues the same generator (test_epochs > 1)
     touched = not np.array_equal(before, np.random.get_state()[1])
     # the exchange at the end of an epoch on n_batch rows that do not divide over the ranks
@@ -170,7 +174,7 @@ def _stream_worker(rank, world, port, n_batch, shard, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,n_batch,shard', [(2, 9, None), (4, 10, 'scatter'), (8, 21, None), (8, 21, 'replay'), (8, 5, 'scatter')])
+@pytest.mark.parametrize('world,n_batch,shard', [(2, 9, None), (2, 9, 'driver'), (4, 10, 'scatter'), (8, 21, 'driver'), (8, 21, 'replay'), (8, 5, 'scatter')])
 def test_ranks_reassemble_the_global_stream_bit_for_bit(world, n_batch, shard):
     """Rank r's batches are global batches r, r + world, ... of the ONE stream a single process draws - for the replayed stream and for the
     table rank 0 draws alone and broadcasts ('scatter': the other ranks' generators are never touched); n_batch does not divide over the ranks."""
@@ -192,7 +196,7 @@ def test_ranks_reassemble_the_global_stream_bit_for_bit(world, n_batch, shard):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    scatter = shard in (None, 'scatter')
+    scatter = shard in ('driver', 'scatter')
     for e in range(2):
         glob = [None] * n_batch
         for rank, (epochs, _, _) in results.items():

@@ -85,3 +85,33 @@ def test_native_rejects_short_class():
     lab = [0] * 30 + [1] * 3
     with pytest.raises(Exception):
         list(CategoriesSampler(lab, 1, 2, 5, native=True))
+
+
+def test_native_slab_one_keeps_the_generator_where_the_lazy_draws_leave_it_and_errors_fall_back():
+    """the native path reads ahead in slabs - the generator matches the reference's lazy per-batch draws only at slab boundaries.
+    `native_slab=1` restores the exact interleaving (an early break, np.random between batches); under native=None a native error (here: a
+    class shorter than n_per that is never drawn... numpy would only raise when it IS drawn) falls back to the numpy path instead of failing up front."""
+    from fewshot_vit_amd.datasets.samplers import CategoriesSampler
+    label = np.repeat(np.arange(20), 600).tolist()
+    np.random.seed(7)
+    ref = CategoriesSampler(label, 9, 5, 6, 2, native=False)
+    it = iter(ref)
+    want = [next(it).tolist() for _ in range(3)]
+    want_state = np.random.get_state()[1].copy()                 # after exactly three lazy batches
+    np.random.seed(7)
+    it = iter(CategoriesSampler(label, 9, 5, 6, 2, native=True, native_slab=1))
+    got = [next(it).tolist() for _ in range(3)]
+    assert got == want and np.array_equal(np.random.get_state()[1], want_state)
+    # a label set whose class 19 has 3 items < n_per = 6: the native draw refuses the table; native=None must still run (numpy raises only if class 19 is drawn)
+    short = np.repeat(np.arange(19), 600).tolist() + [19] * 3
+    np.random.seed(11)
+    try:
+        a = [b.tolist() for b in CategoriesSampler(short, 2, 5, 6, 1, native=False)]
+    except ValueError:
+        a = None
+    np.random.seed(11)
+    try:
+        b = [x.tolist() for x in CategoriesSampler(short, 2, 5, 6, 1, native=None)]
+    except ValueError:
+        b = None
+    assert a == b
