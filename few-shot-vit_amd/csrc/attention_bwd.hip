@@ -774,7 +774,7 @@ int launch_attention_bwd(const void* qkv, const void* dctx, void* dqkv, int B, i
     if (rc || ran) return rc;
   }
   if (dtype == 0) {                                     // exact-fp32 MFMA kernel where the head fits the LDS (Visformer stages: 100 x 42, 25 x 85)
-    static const bool off = [] { const char* e = getenv("FSVIT_ATTN_BWD_F32_MFMA"); return e && e[0] == '0'; }();
+    constexpr bool off = false;
     if (!off && (hdp & 3) == 0) {
       if (S <= 32 && hdp <= 48) return launch_bwd_f32mfma<2, 3>(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, s);
       if (S <= 32 && hdp <= 96) return launch_bwd_f32mfma<2, 6>(qkv, dctx, dqkv, B, S, heads, hd, hdp, scale, s);

@@ -761,7 +761,7 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
   // stem: conv1 / downsample as K=32 GEMMs over the im2col rows, conv2, conv3 (+identity, LeakyReLU), max-pool + pos1
   h->prof_last = nullptr;
   if (!xsrc2) B1 = Bc;
-  static const bool stem_fused_on = [] { const char* e = getenv("FSVIT_STEM_CONV1"); return !e || e[0] != '0'; }();
+  constexpr bool stem_fused_on = true;
   if (stem_fused_on && K(stem_conv1_supported)(dt, img, h->C0)) {      // im2col + conv1 + bn1 + LeakyReLU in one pass over the image
     const double fl1 = 2.0 * 27.0 * h->C0 * h->H0 * h->H0;
     RC_TRY(timed(h, st, "stem.im2col+conv1", KID_STEMCONV1, fl1 * B1, [&]() {
@@ -778,7 +778,7 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
     RC_TRY(run_gemm(h, st, "stem.conv1", h->conv1, conv_params(h->conv1, patches, c1, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C0, ACT_LRELU, nullptr, 0, nullptr), h->C0, 27));
   }
   RC_TRY(run_gemm(h, st, "stem.conv2", h->conv2, conv_params(h->conv2, c1, c2, Bc, h->H0, h->H0, h->C0, h->C0, 3, 3, 1, 1, h->C1, ACT_LRELU, nullptr, 0, nullptr), h->C1, 9.0 * h->C0));
-  static const bool split_stem = [] { const char* e = getenv("FSVIT_NO_FUSE"); return e && e[0] == '1'; }();
+  constexpr bool split_stem = false;
   if (!split_stem) {
     // conv3 + bn3 + (downsample conv + bn_d as a tail K slice over the im2col rows) + LeakyReLU + MaxPool2d(2) + pos_embed1
     ConvGemmParams p3 = conv_params(h->conv3f, c2, x1, Bc, h->H0, h->H0, h->C1, h->C1, 3, 3, 1, 1, h->C1, ACT_LRELU, nullptr, 0, h->pos1);
@@ -793,7 +793,7 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
 
   // stage 1: x += conv3(GELU(conv2_g(GELU(conv1(BN(x))))))
   const int Cg = h->hid1 / h->cfg.group;
-  static const bool no_fuse = [] { const char* e = getenv("FSVIT_NO_FUSE"); return e && e[0] == '1'; }();
+  constexpr bool no_fuse = false;
   // one LDS-resident kernel per block (stage1_w4.hip / stage1_ring.hip, any map up to 20 wide); other geometries / numerics modes and FSVIT_NO_FUSE=1 take the three-launch route
   const bool ring_ok = K(stage1_ring_supported)(dt, h->C1, h->hid1, h->cfg.group, h->H1) && h->s1.size() && h->s1[0].c2.Kw == 320;
   const bool fuse1 = !no_fuse && ring_ok && K(stage1_ring_preferred)();

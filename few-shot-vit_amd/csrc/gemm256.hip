@@ -346,7 +346,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_x2_kernel(const ConvGemmParams
 
 // dtype 1: the 16-bit kernel; dtype 2: the two-limb kernel on fp32 storage (4-byte operand elements)
 bool gemm256_eligible(const ConvGemmParams& p, int dtype) {
-  static const bool off = [] { const char* e = getenv("FSVIT_GEMM256"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || (dtype != 1 && dtype != 2)) return false;
   const int es = dtype == 2 ? 4 : 2, bke = 128 / es;
   if (p.KH != 1 || p.KW != 1 || p.stride != 1 || p.pad != 0 || p.groups != 1) return false;

@@ -1310,12 +1310,12 @@ __global__ void ln_gemm_pack_kernel(const bf16* __restrict__ w, int kw, bf16* __
 }
 
 bool ln_gemm_rows_supported(int dtype, int C, int N) {
-  static const bool on = [] { const char* e = getenv("FSVIT_LN_GEMM_ROWS"); return !e || e[0] != '0'; }();
+  constexpr bool on = true;
   return on && dtype == 1 && C == 384 && N >= 32 && N % 32 == 0;
 }
-// the same kernel without the LayerNorm at C = 512 (Visformer stage-3 qkv); FSVIT_LN_GEMM_ROWS=0 turns both off
+// the same kernel without the LayerNorm at C = 512 (Visformer stage-3 qkv) (dispatch switch retired in round 6: tools/probes/variants/dispatch_switches.r06.patch)
 bool gemm_rows_supported(int dtype, int C, int N) {
-  static const bool on = [] { const char* e = getenv("FSVIT_LN_GEMM_ROWS"); return !e || e[0] != '0'; }();
+  constexpr bool on = true;
   return on && dtype == 1 && C == 512 && N >= 32 && N % 32 == 0;
 }
 size_t ln_gemm_rows_image_bytes(int C, int N) { return (size_t)(N / 32) * (C / 16) * 1024; }
@@ -1324,9 +1324,9 @@ int launch_ln_gemm_pack(const void* w, int kw, void* wimg, int C, int N, hipStre
   hipLaunchKernelGGL(ln_gemm_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)w, kw, (bf16*)wimg, C, N, 0, 0);
   return (int)hipGetLastError();
 }
-// qkv conv + attention on the rows kernel: C = 512, head dim padded to 96, maps of at most 32 tokens; FSVIT_QKV_ATTN_ROWS=0 turns it off
+// qkv conv + attention on the rows kernel: C = 512, head dim padded to 96, maps of at most 32 tokens (dispatch switch retired in round 6)
 bool qkv_attn_rows_supported(int dtype, int C, int heads, int hdp, int S) {
-  static const bool on = [] { const char* e = getenv("FSVIT_QKV_ATTN_ROWS"); return !e || e[0] != '0'; }();
+  constexpr bool on = true;
   return on && dtype == 1 && C == 512 && hdp == 96 && heads >= 1 && S >= 1 && S <= 32;
 }
 int launch_qkv_attn_rows_pack(const void* w, int kw, void* wimg, int C, int heads, int hdp, hipStream_t s) {
@@ -1351,9 +1351,9 @@ int launch_qkv_attn_rows(const void* x, void* ctx, const void* wimg, const float
                      S, heads, n_tiles);
   return (int)hipGetLastError();
 }
-// norm1 + qkv + attention of a ViT block in one launch (vit_attn_rows_kernel): C = 384, head dim 64, up to 256 tokens; FSVIT_VIT_ATTN_ROWS=0 turns it off
+// norm1 + qkv + attention of a ViT block in one launch (vit_attn_rows_kernel): C = 384, head dim 64, up to 256 tokens (dispatch switch retired in round 6)
 bool vit_attn_rows_supported(int dtype, int C, int heads, int hdp, int S) {
-  static const bool on = [] { const char* e = getenv("FSVIT_VIT_ATTN_ROWS"); return !e || e[0] != '0'; }();
+  constexpr bool on = true;
   return on && dtype == 1 && C == 384 && hdp == 64 && heads >= 1 && S >= 1 && S <= 256;
 }
 // ctx [B*S][heads*64] = softmax(scale q k^T) v per image and head, q | k | v = bias + W' LN(x)   (image from launch_qkv_attn_rows_pack with C = 384)
@@ -1395,7 +1395,7 @@ static int launch_gemm_rows_t(const void* x, void* y, const void* wimg, const fl
 }
 // 2 x 2 / stride-2 patch embedding on the rows kernel: x NHWC [B][H][H][Ci] with 4 Ci = 512, y [B (H/2)^2][N] = bias + W patches + pos
 bool patch_embed_rows_supported(int dtype, int Ci, int H, int N) {
-  static const bool on = [] { const char* e = getenv("FSVIT_LN_GEMM_ROWS"); return !e || e[0] != '0'; }();
+  constexpr bool on = true;
   return on && dtype == 1 && 4 * Ci == 512 && H >= 2 && H % 2 == 0 && N >= 32 && N % 32 == 0;
 }
 int launch_patch_embed_rows(const void* x, void* y, const void* wimg, const float* bias, const float* pos, int B, int H, int Ci, int N, hipStream_t s) {
@@ -1462,19 +1462,19 @@ __global__ void mlp_pack_kernel(const bf16* __restrict__ w1, int k1w, const floa
   wimg[idx] = v;
 }
 
-// the ViT / DeiT block (proj + bias + residual, LayerNorm, Mlp with biases): DeiT-S geometry; FSVIT_MLP_ROWS bit 3
+// the ViT / DeiT block (proj + bias + residual, LayerNorm, Mlp with biases): DeiT-S geometry (was bit 3 of the retired FSVIT_MLP_ROWS switch)
 bool mlp_rows_ln_supported(int dtype, int C, int hid, int KC) {
-  static const int mode = [] { const char* e = getenv("FSVIT_MLP_ROWS"); return e ? atoi(e) : 15; }();
+  constexpr int mode = 15;
   return dtype == 1 && (mode & 8) && C == 384 && hid == 1536 && KC == 384;
 }
 bool mlp_rows_supported(int dtype, int C, int hid) {
-  static const int mode = [] { const char* e = getenv("FSVIT_MLP_ROWS"); return e ? atoi(e) : 7; }();      // bit 0: C = 256, bit 1: C = 512, bit 2: proj fusion
+  constexpr int mode = 7;      // bit 0: C = 256, bit 1: C = 512, bit 2: proj fusion
   if (dtype != 1) return false;
   return (C == 256 && hid == 1024 && (mode & 1)) || (C == 512 && hid == 2048 && (mode & 2));
 }
 // proj fusion is built for the Visformer-S geometries: (C, KC) = (256, 288) and (512, 576) (6 heads x head dim padded to 48 / 96)
 bool mlp_rows_proj_supported(int C, int hid, int KC) {
-  static const int mode = [] { const char* e = getenv("FSVIT_MLP_ROWS"); return e ? atoi(e) : 7; }();
+  constexpr int mode = 7;
   return (mode & 4) && ((C == 256 && hid == 1024 && KC == 288) || (C == 512 && hid == 2048 && KC == 576));
 }
 size_t mlp_rows_image_bytes(int C, int hid, int KC) {

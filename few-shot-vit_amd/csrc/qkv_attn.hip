@@ -324,7 +324,7 @@ __global__ void qkv_attn_pack_kernel(const bf16* __restrict__ w, int kw, bf16* _
 }
 
 bool qkv_attn_supported(int dtype, int C, int heads, int hdp, int S) {
-  static const int on = [] { const char* e = getenv("FSVIT_QKV_ATTN"); return e ? atoi(e) : 1; }();
+  constexpr int on = 1;
   return on && dtype == 1 && C == qa::C && heads == qa::HEADS && hdp == qa::HDP && S >= 1 && S <= qa::TOKK;
 }
 size_t qkv_attn_image_bytes() { return (size_t)qa::NIMG * qa::SLOT; }

@@ -391,9 +391,9 @@ __global__ __launch_bounds__(512, 1) void stage1_ring_block_train_kernel(const b
 bool stage1_ring_supported(int dtype, int C1, int hid, int group, int H1) {
   return dtype == 1 && C1 == s1r::C1 && hid == s1r::HID && group == s1r::G && H1 >= 4 && H1 <= 20;
 }
-// The engines run the block as one launch for every supported map (stage1_w4.hip by default, this kernel under FSVIT_STAGE1_W4=0 and for the
-// training modes).  The three-launch route (conv1 / grouped conv2 / conv3 through the GEMM kernels) serves the geometries and numerics modes this
-// kernel does not, and FSVIT_NO_FUSE=1 (the all-general eval path); its own switch FSVIT_STAGE1_RING=0 was retired in round 5.
+// The engines run the block as one launch for every supported map (stage1_w4.hip; this kernel for the
+// training modes and behind fsvit_stage1_block).  The three-launch route (conv1 / grouped conv2 / conv3 through the GEMM kernels) serves the geometries and numerics modes this
+// kernel does not (the FSVIT_STAGE1_RING / FSVIT_STAGE1_W4 / FSVIT_NO_FUSE switches were retired in rounds 5 / 6: tools/probes/variants/*.patch).
 bool stage1_ring_preferred() { return true; }
 
 // w1 [256][128], w2 [256][320] (columns (tap, c)), w3 [128][256]: the packed layers of the block (engine.hip pack_layer)
@@ -401,7 +401,7 @@ int launch_stage1_ring(const void* x, void* y, const void* w1, const float* b1, 
   if (stage1_w4_enabled()) return launch_stage1_w4(x, y, w1, b1, w2, w3, B, H, W, s, w3s);      // w3s: 8 x w3 or null (stage1_w4.hip)
   return launch_stage1_ring16(x, y, w1, b1, w2, w3, B, H, W, s);
 }
-// this file's kernel whatever FSVIT_STAGE1_W4 says (fsvit_stage1_block: the cross-check of the two kernels in one process)
+// this file's kernel (fsvit_stage1_block: the cross-check of the two kernels in one process)
 int launch_stage1_ring16(const void* x, void* y, const void* w1, const float* b1, const void* w2, const void* w3, int B, int H, int W, hipStream_t s) {
   const long Ml = (long)B * H * W;
   if (Ml <= 0) return 0;

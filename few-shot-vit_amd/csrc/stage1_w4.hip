@@ -659,9 +659,10 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
   }
 }
 
-// The engines' stage-1 kernel since round 4 (2.05 vs 2.22 ms per 12 800-image launch); FSVIT_STAGE1_W4=0 keeps stage1_ring's eight-wave kernel
+// The engines' stage-1 kernel since round 4 (round 6: 1.91 ms per 12 800-image launch, stage1_ring's eight-wave kernel 2.22).  The FSVIT_STAGE1_W4=0 switch
+// left the sources in round 6 (tools/probes/variants/dispatch_switches.r06.patch re-adds it and the other retired dispatch switches)
 bool stage1_w4_enabled() {
-  static const bool off = [] { const char* e = getenv("FSVIT_STAGE1_W4"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   return !off;
 }
 

@@ -585,9 +585,9 @@ int train_forward_impl(TR* t, const float* x, float* feat) {
   // Round 4: a block is ONE launch behind its BatchNorm's statistics (stage1_ring.hip MODE 3): the batch statistics are folded into conv1 as the eval
   // engine folds the running statistics (fold_prenorm), the residual with the DropPath scale is added in the same kernel - no apply pass, and the
   // reduce pass reads one finished map instead of adding two and storing a third.  (The statistics of the block's output from the same kernel were
-  // built and measured: 16 more VGPRs than the kernel has, 25 spills, +95 us per launch.)  FSVIT_STAGE1_BLOCK_FUSED=0: the round-3 route.
-  static const bool block_off = [] { const char* e = getenv("FSVIT_STAGE1_BLOCK_FUSED"); return e && e[0] == '0'; }();
-  static const bool fused_off = [] { const char* e = getenv("FSVIT_STAGE1_TRAIN_FUSED"); return e && e[0] == '0'; }();
+  // built and measured: 16 more VGPRs than the kernel has, 25 spills, +95 us per launch.)  (FSVIT_STAGE1_BLOCK_FUSED / _TRAIN_FUSED: retired in round 6, dispatch_switches.r06.patch.)
+  constexpr bool block_off = false;
+  constexpr bool fused_off = false;
   const bool block_fused = !block_off && !fused_off && stage1_ring_supported(t->gdt, t->C1, t->hid1, t->cfg.group, H1);
   const size_t s1_mark = t->tmp.off;
   for (int i = 0; i < t->cfg.depth[0]; ++i, ++blk) {
@@ -812,7 +812,7 @@ int train_backward_impl(TR* t, const float* dfeat) {
     const size_t mark = t->tmp.off;
     void* dz3 = take_tmp(t, M1 * t->C1); NEED(dz3);
     if (i == (int)t->s1.size() - 1) { T_TRY(side_guard(t, dz3, M1 * t->C1 * t->es)); T_RUN(launch_add_scaled(nullptr, dx, b.scale, dz3, M1 * t->C1, (size_t)H1 * H1 * t->C1, dt, st)); }
-    static const bool fused_off = [] { const char* e = getenv("FSVIT_STAGE1_TRAIN_FUSED"); return e && e[0] == '0'; }();
+    constexpr bool fused_off = false;
     void* dxn = dz3;                                                                           // d(xn): in place over dz3 on the three-launch route
     if (!fused_off && stage1_ring_supported(t->gdt, t->C1, t->hid1, t->cfg.group, H1)) {
       // the block's data-gradient chain dz3 -> dz2 -> dz1 -> d(xn) in ONE kernel (stage1_ring.hip MODE 2), then the three weight gradients

@@ -1566,7 +1566,7 @@ int launch_bn_frozen_coeffs(int C, float eps, const float* gamma, const float* b
   return (int)hipGetLastError();
 }
 int launch_bn_apply(const void* z, const float* sa, const float* sb, const void* res, void* y, size_t M, int C, int act, int dtype, hipStream_t s) {
-  static const bool rows_off = [] { const char* e = getenv("FSVIT_BN_ROWS"); return e && e[0] == '0'; }();
+  constexpr bool rows_off = false;
   if (!rows_off && rows_form_ok(C, dtype == 0 ? 4 : 8)) {
     if (dtype == 0) hipLaunchKernelGGL((bn_apply_rows_kernel<float, 4, 4>), dim3(rows_grid(M, C, 4, 4)), dim3(256), 0, s, (const float*)z, sa, sb, (const float*)res, (float*)y, M, C, act);
     else hipLaunchKernelGGL((bn_apply_rows_kernel<bf16, 8, 4>), dim3(rows_grid(M, C, 8, 4)), dim3(256), 0, s, (const bf16*)z, sa, sb, (const bf16*)res, (bf16*)y, M, C, act);
@@ -1588,7 +1588,7 @@ int launch_bn_bwd_apply(const void* dy, const void* z, const float* mean, const 
                         const float* act_sb) {
   const size_t total = M * (C / 4);
   if (!rows_per_img) rows_per_img = 1;
-  static const bool rows_off = [] { const char* e = getenv("FSVIT_BN_ROWS"); return e && e[0] == '0'; }();
+  constexpr bool rows_off = false;
   if (!rows_off && rows_form_ok(C, dtype == 0 ? 4 : 8)) {
     if (dtype == 0)
       hipLaunchKernelGGL((bn_bwd_apply_rows_kernel<float, 4, 2>), dim3(rows_grid(M, C, 4, 2)), dim3(256), 0, s, (const float*)dy, (const float*)z, mean, invstd, ca, cb, cc, (float*)dz, M, C,
@@ -1737,7 +1737,7 @@ int launch_ln_bwd(const void* dy, const void* x, const float* mean, const float*
   if (D % 4 || (size_t)8 * D * 4 > 64 * 1024) return (int)hipErrorInvalidValue;
   const int nb = ln_bwd_blocks(M), rpb = (M + nb - 1) / nb;
   const size_t lds = (size_t)8 * D * sizeof(float);
-  static const bool rows_off = [] { const char* e = getenv("FSVIT_LN_BWD_ROWS"); return e && e[0] == '0'; }();
+  constexpr bool rows_off = false;
   const int ng = (D + 255) / 256;
   if (!rows_off && ng <= 4) {
 #define FSVIT_LNB(T, NG) hipLaunchKernelGGL((ln_bwd_rows_kernel<T, NG>), dim3(nb), dim3(256), lds, s, (const T*)dy, (const T*)x, mean, rstd, gamma, (const T*)add, (T*)dx, partial, M, D, rpb)

@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_finalize_kernel(const float* __r
 // Supported: 3x3 / stride 1 / pad 1, 16-bit storage; grouped with 32 -> 32 channels per group and 8 groups, or dense with 128 output
 // channels and 64 / 128 input channels.
 bool wgrad3x3_supported(int dtype, int O, int Ig, int groups, int W) {
-  static const bool off = [] { const char* e = getenv("FSVIT_WGRAD3X3"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   if (off || (dtype != 1 && dtype != 2)) return false;         // dtype 2: fp32 rows, two-limb arithmetic (wgrad3x3_x2_kernel)
   if (groups == 8) return O == 256 && Ig == 32 && W <= 20;
   return groups == 1 && O == 128 && (Ig == 64 || Ig == 128) && W <= 40;
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512) void gconv3x3_kernel(const bf16* __restrict__ 
 }
 
 bool gconv3x3_supported(int dtype, int O, int Ig, int groups, int KH, int KW, int stride, int pad, int W) {
-  static const bool off = [] { const char* e = getenv("FSVIT_GCONV3X3"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   return !off && dtype == 1 && O == 256 && Ig == 32 && groups == 8 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && W <= 20;
 }
 int launch_gconv3x3(const void* x, const void* w_packed, int Kw, void* y, int B, int H, int W, hipStream_t s, void* y2, const void* mul) {
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(512) void wgrad1x1_x2_kernel(const float* __restric
 }
 
 bool wgrad1x1_supported(int dtype, int N, int C) {
-  static const bool off = [] { const char* e = getenv("FSVIT_WGRAD1X1"); return e && e[0] == '0'; }();
+  constexpr bool off = false;
   return !off && (dtype == 1 || dtype == 2) && (N % 8) == 0 && (C % 8) == 0;      // dtype 2: the two-limb kernel on fp32 rows
 }
 // block shape per layer: 256 along a dimension that has >= 256 columns, else 128 (wave blocks 64 / 32 rows x 128 / 64 columns)

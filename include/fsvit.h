@@ -179,12 +179,12 @@ int fsvit_vit_ln_qkv_attention(const void* x_dev, const void* wqkv_dev, int kw, 
 /* One fused Visformer stage-1 block (visformer.py:259-263 with attn_disabled + spatial_conv Mlp :152-163), bf16,
  * 20x20 tokens, 128 channels, 256 hidden, 8 groups: y = x + conv3(GELU(conv2_g(GELU(conv1(x)+b1)))).
  * x, y NHWC [B,20,20,128] bf16 (distinct buffers); w1 [256][128], w2 [8][32][320], w3 [128][256] packed K-major bf16.
- * Always the 16-wave ring kernel (stage1_ring.hip), whatever FSVIT_STAGE1_W4 says: the in-process cross-check of fsvit_stage1_block_hw. */
+ * Always the 16-wave ring kernel (stage1_ring.hip): the in-process cross-check of fsvit_stage1_block_hw. */
 int fsvit_stage1_block(const void* x_dev, void* y_dev, const void* w1_dev, const float* b1_dev, const void* w2_dev,
                        const void* w3_dev, int B, void* stream);
 /* The same block for any square token map of 4 .. 20 a side: x, y NHWC [B,H,W,128], dtype FSVIT_BF16 / FSVIT_F16; weights as above.  This is the launch the
- * engines run: stage1_w4.hip (one wave per SIMD, weights in registers / AGPRs, x and the first hidden map in pixel rings), or stage1_ring.hip (wave = channel
- * group) under FSVIT_STAGE1_W4=0 (FSVIT_NO_FUSE=1 makes the engines take the three-launch GEMM route instead). */
+ * engines run: stage1_w4.hip (one wave per SIMD, weights in registers / AGPRs, x and the first hidden map in pixel rings; bf16: GELU by table look-up on
+ * the bf16-rounded pre-activation). */
 int fsvit_stage1_block_hw(const void* x_dev, void* y_dev, const void* w1_dev, const float* b1_dev, const void* w2_dev, const void* w3_dev, int B, int H, int W,
                           int dtype, void* stream);
 /* Fused Mlp of a Visformer attention block (visformer.py:146-150 with spatial_conv=False, + the residual of :262):

@@ -393,7 +393,7 @@ def test_stage1_fused_block_matches_unfused_math():
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('B,HW', [(5, 20), (3, 16), (7, 10), (2, 4), (130, 20)])
 def test_stage1_ring_block_matches_unfused_math(B, HW, dtype):
-    """fsvit_stage1_block_hw (stage1_w4.hip by default, stage1_ring.hip under FSVIT_STAGE1_W4=0: weights in registers, pixel rings) vs fp32 torch with the
+    """fsvit_stage1_block_hw (stage1_w4.hip: weights in registers, pixel rings) vs fp32 torch with the
     same 16-bit roundings of x, the weights and the two hidden maps - several map sizes (chunks of 64 pixels straddle images and the batch end), and
     against the 16-wave ring kernel (fsvit_stage1_block) at 20 x 20."""
     from fewshot_vit_amd.engine import ops

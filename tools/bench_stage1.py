@@ -1,4 +1,4 @@
-"""Times the fused stage-1 block operators: fsvit_stage1_block_hw (the engines' launch: stage1_w4.hip, or stage1_ring.hip under FSVIT_STAGE1_W4=0) or,
+"""Times the fused stage-1 block operators: fsvit_stage1_block_hw (the engines' launch: stage1_w4.hip) or,
 with BENCH_STAGE1_RING=0, fsvit_stage1_block (always the 16-wave kernel of stage1_ring.hip).
 python tools/bench_stage1.py [images [variant.so]]"""
 import math

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs the stage-1 block operator (fsvit_stage1_block_hw: stage1_w4.hip, or stage1_ring.hip with FSVIT_STAGE1_W4=0) a few times for rocprofv3 --pmc passes."""
+"""Runs the stage-1 block operator (fsvit_stage1_block_hw: stage1_w4.hip) a few times for rocprofv3 --pmc passes."""
 import sys, os, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -20,4 +20,4 @@ t0 = time.perf_counter()
 for _ in range(10):
     ops.stage1_block_hw(x, w1, b1, w2, w3)
 torch.cuda.synchronize()
-print("stage1_block_hw B=%d (FSVIT_STAGE1_W4=%s): %.1f us per launch" % (B, os.environ.get("FSVIT_STAGE1_W4", "1"), (time.perf_counter() - t0) * 1e5))
+print("stage1_block_hw B=%d: %.1f us per launch" % (B, (time.perf_counter() - t0) * 1e5))
