@@ -157,6 +157,52 @@ __device__ __forceinline__ f32x2 gelu_sig2_d(f32x2 x, f32x2& d) {
   return x * s;
 }
 
+// GELU as an LDS table look-up on the bf16-ROUNDED pre-activation (round 6; the bf16 build of stage1_w4.hip and mlp_rows.hip, whose GELU micro-stages
+// competed with the MFMAs for the wave's issue slots: 9 VALU + 2 ds_read_u16 per pair of values instead of 17 VALU, 4 of them transcendental -
+// tools/probes/gelu_lds.hip).  The kernels carry their pre-activations at 1 / 8 scale (z / 8; W1 / 8 and 8 W2 are exact in bf16), so the table maps
+// the bf16 code of z / 8 to bf16(gelu_erf(z) / 8): entry i in [-TN, TN) at byte 2 i from the table's centre, magnitude code TLO + a with a = i
+// (z >= 0) or -1 - i (z < 0) - the sign folded in as the one's complement, one contiguous table.  |z| in [2^-10, 32): 15 binades x 128 codes per sign,
+// 7680 bytes; smaller magnitudes share the first entry (|gelu| <= 2^-11 there), larger ones the last (z = 31.9).  The fp16 build keeps the VALU
+// form: a 10-bit mantissa would need an 8 x larger table.
+namespace gelu_tab {
+#ifdef FSVIT_HALF_F16
+constexpr bool ON = false;
+constexpr int NB = 0;
+#else
+constexpr bool ON = true;
+constexpr int NB = 15;
+#endif
+constexpr int TN = NB * 128, TLO = (127 - 13) << 7, BYTES = 4 * TN;
+// every thread of the workgroup (t of nthreads) fills its share of the table at `tab`; the caller orders the stores before the first look-up
+__device__ __forceinline__ void fill(unsigned char* tab, int t, int nthreads) {
+  for (int e = t; e < 2 * TN; e += nthreads) {
+    const int i = e - TN, a = i >= 0 ? i : -1 - i;
+    const float z8 = __builtin_bit_cast(float, (unsigned)(TLO + a) << 16);
+    const float z = i >= 0 ? 8.0f * z8 : -8.0f * z8;
+    reinterpret_cast<bf16*>(tab)[e] = (bf16)(gelu_erf(z) * 0.125f);
+  }
+}
+// packed bf16 code pair of (z0 / 8, z1 / 8) -> packed signed table indices (steps T2 .. T4 of the kernels' micro-stages, here in one piece)
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+typedef short ss2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned rebase(unsigned codes) {       // magnitudes re-based to 2^-13 (saturating at 0)
+  constexpr unsigned klo = (unsigned)TLO * 0x10001u;
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2_t, codes & 0x7fff7fffu), __builtin_bit_cast(us2_t, klo)));
+}
+__device__ __forceinline__ unsigned clamp_top(unsigned a) {        // ... and clamped at the last entry
+  constexpr unsigned kmax = (unsigned)(TN > 0 ? TN - 1 : 0) * 0x10001u;
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2_t, a), __builtin_bit_cast(us2_t, kmax)));
+}
+__device__ __forceinline__ unsigned sign_mask(unsigned codes) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(ss2_t, codes) >> 15); }
+// LDS byte addresses of the two entries: centre + 2 i (v_mad_i32_i16, op_sel picks the upper half)
+__device__ __forceinline__ void addresses(unsigned idx, unsigned centre, unsigned& a0, unsigned& a1) {
+  asm("v_mad_i32_i16 %0, %1, 2, %2" : "=v"(a0) : "v"(idx), "s"(centre));
+  asm("v_mad_i32_i16 %0, %1, 2, %2 op_sel:[1,0,0,0]" : "=v"(a1) : "v"(idx), "s"(centre));
+}
+typedef __attribute__((address_space(3))) const unsigned short lds_u16;
+__device__ __forceinline__ unsigned gather(unsigned addr) { return *(lds_u16*)(size_t)addr; }      // (d16 loads zero the other half under SRAM ECC: two registers, one v_lshl_or)
+}  // namespace gelu_tab
+
 // FAST selects gelu_sig (bf16 storage); the fp32 parity path keeps the exact erff form.
 template <bool FAST>
 __device__ __forceinline__ float apply_act(float v, int act) {

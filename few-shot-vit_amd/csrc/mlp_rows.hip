@@ -310,6 +310,8 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
   float* const b1tab = reinterpret_cast<float*>(smem + MR_NST * MR_SLOT);
   float* const bptab = b1tab + HID;                      // LN: proj bias, fc2 bias (channel order)
   float* const b2tab = bptab + C;
+  // GELU table of the bf16 build (fsvit_common.h gelu_tab, round 6) behind the bias tables; TABC = LDS address of its centre (wave-uniform)
+  unsigned char* const gtab = smem + MR_NST * MR_SLOT + HID * 4 + (LN ? 2 * C * 4 : 0);
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -322,6 +324,8 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
   for (int i = t; i < HID; i += MR_NW * 64) b1tab[i] = b1img[i];
   if constexpr (LN)
     for (int i = t; i < C; i += MR_NW * 64) { bptab[i] = bproj[i]; b2tab[i] = b2[i]; }
+  if constexpr (gelu_tab::ON) gelu_tab::fill(gtab, t, MR_NW * 64);
+  const unsigned tabc = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptrm_t)gtab + 2u * gelu_tab::TN);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // table written before the first ring barrier publishes it
 
   // ring: slot image n (the weight image is a sequence of NCH * PPC slot images, repeated for every tile) is issued right after
@@ -581,15 +585,36 @@ __global__ __launch_bounds__(256, 1) void mlp_rows_kernel(const bf16* __restrict
     auto st = [](int q) { return q * CAD2 / 2; };
     auto st_a1 = [&](int q) { const int lim = (RB == 2 ? 45 : SL - 4) - (NP - 1 - q); return (RB == 1 || q >= 8) && st(q) > lim ? lim : st(q); };
     constexpr int G_LAST = (NP - 1) * CAD2 / 2 + O_C;     // slot of the last micro-stage
+    // Round 6 (bf16 build): the same passes as TABLE LOOK-UPS on the bf16-rounded pre-activation (fsvit_common.h gelu_tab; stage1_w4.hip's t_slot):
+    //   T1 (where A1 reads the accumulator) code pair | +1 magnitudes re-based | +2 top clamp, sign mask | +3 index | +4 addresses, gathers | +6 / +7 join
+    // 9 VALU + 2 ds_read_u16 per pair instead of 17 VALU incl. 4 transcendentals; a packed 16-bit result and its reader never share a slot.
+    unsigned tc[NP], ta[NP], tm[NP], tl[NP], th[NP];
     auto gelu_slot = [&](int m, u32x4 (&hp)[RB][2]) {
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
-        if (m == st_a1(q)) gA1(q);
-        if (m == st(q) + O_A2) gA2(q);
-        if (m == st(q) + O_E) gE(q);
-        if (m == st(q) + O_BA) gBa(q);
-        if (m == st(q) + O_BR) gBr(q);
-        if (m == st(q) + O_C) gC(q, hp);
+        if constexpr (gelu_tab::ON) {
+          if (m == st_a1(q)) {
+            tc[q] = mr_pk2(hacc[q >> 3][2 * (q & 7)], hacc[q >> 3][2 * (q & 7) + 1]);
+            asm("" : "+v"(tc[q]));                           // (opaque: otherwise the sign shift converts the two floats again)
+          }
+          if (m == st(q) + 1) ta[q] = gelu_tab::rebase(tc[q]);
+          if (m == st(q) + 2) { tm[q] = gelu_tab::sign_mask(tc[q]); ta[q] = gelu_tab::clamp_top(ta[q]); }
+          if (m == st(q) + 3) ta[q] ^= tm[q];
+          if (m == st(q) + 4) {
+            unsigned a0, a1;
+            gelu_tab::addresses(ta[q], tabc, a0, a1);
+            tl[q] = gelu_tab::gather(a0);
+            th[q] = gelu_tab::gather(a1);
+          }
+          if (m == st(q) + O_C) hp[q >> 3][(q >> 2) & 1][q & 3] = tl[q] | (th[q] << 16);
+        } else {
+          if (m == st_a1(q)) gA1(q);
+          if (m == st(q) + O_A2) gA2(q);
+          if (m == st(q) + O_E) gE(q);
+          if (m == st(q) + O_BA) gBa(q);
+          if (m == st(q) + O_BR) gBr(q);
+          if (m == st(q) + O_C) gC(q, hp);
+        }
       }
     };
     static_assert(G_LAST < 2 * SL, "the GELU fits in one body");
@@ -1495,7 +1520,7 @@ template <int C, int HID, int RB, int KC, bool LN = false>
 static int launch_mlp_rows_t(const void* x, void* y, const void* wimg, const float* b1img, const float* b2, const void* ctx, const float* bproj, float eps,
                              int M, hipStream_t s) {
   auto kern = mlp_rows_kernel<C, HID, RB, KC, LN>;
-  const int lds = MR_NST * mr_slot_frags(C) * 1024 + HID * 4 + (LN ? 2 * C * 4 : 0);
+  const int lds = MR_NST * mr_slot_frags(C) * 1024 + HID * 4 + (LN ? 2 * C * 4 : 0) + gelu_tab::BYTES;
   {    // per launch: the attribute is per DEVICE (a process-wide "done" flag skipped it on a second GPU), and the call is cheap
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;

@@ -45,19 +45,11 @@ constexpr int XR = 0;                            // x ring: 16 planes
 constexpr int H1R = XR + (C1 / 8) * XP;          // h1 ring: 32 planes
 constexpr int H2P = CH * 16;
 constexpr int H2 = H1R + (HID / 8) * PITCH;      // h2 of one chunk: 32 planes x 64 pixels
-// GELU table (bf16 build only, round 6): entry i in [-TN, TN) at TABC + 2 i = bf16(gelu_erf(z) / 8) of the bf16 code z / 8 with magnitude code
-// TLO + a, a = i (z >= 0) or -1 - i (z < 0): |z| in [2^-10, 32), 15 binades x 128 codes per sign
-#ifdef FSVIT_HALF_F16
-constexpr bool TABLE = false;
-constexpr int TNB = 0;
-#else
-constexpr bool TABLE = true;
-constexpr int TNB = 15;
-#endif
-constexpr int TN = TNB * 128, TLO = (127 - 13) << 7;
+// GELU table (bf16 build only, round 6; fsvit_common.h gelu_tab): 7680 bytes behind h2
+constexpr bool TABLE = gelu_tab::ON;
 constexpr int TAB = H2 + (HID / 8) * H2P;
-constexpr int TABC = TAB + 2 * TN;
-constexpr int LDS_BYTES = TAB + 4 * TN;          // 155 648 (bf16) / 147 968 (f16)
+constexpr int TABC = TAB + 2 * gelu_tab::TN;       // the table's centre: entry i at TABC + 2 i
+constexpr int LDS_BYTES = TAB + gelu_tab::BYTES;   // 155 648 (bf16) / 147 968 (f16)
 }  // namespace s1w
 
 typedef float f32x16w __attribute__((ext_vector_type(16)));
@@ -112,15 +104,7 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
   int q1 = q0 + chunks_per_wg; q1 = q1 < n_chunks ? q1 : n_chunks;
   if (q0 >= q1) return;
   if (t < 4 * (HID / 8)) reinterpret_cast<unsigned*>(smem + H1R + (t >> 2) * PITCH + RINGB)[t & 3] = 0u;      // the zero slot of every h1 plane
-  if constexpr (TABLE) {
-    // the GELU table, exact-erf form (closer to the reference's nn.GELU than gelu_sig; the pre-activation is rounded to bf16 first - DESIGN.md 4)
-    for (int e = t; e < 2 * TN; e += 256) {
-      const int i = e - TN, a = i >= 0 ? i : -1 - i;
-      const float z8 = __builtin_bit_cast(float, (unsigned)(TLO + a) << 16);
-      const float z = i >= 0 ? 8.0f * z8 : -8.0f * z8;
-      reinterpret_cast<bf16*>(smem + TAB)[e] = (bf16)(gelu_erf(z) * 0.125f);
-    }
-  }
+  if constexpr (TABLE) gelu_tab::fill(smem + TAB, t, 256);      // exact-erf form (closer to the reference's nn.GELU than gelu_sig)
 
   // ---- this wave's weights.  MFMA row R = lane & 31 carries channel cR of its 32-channel tile; the lane's k half = kh
   const int cR = 16 * ((p >> 2) & 1) + 4 * (p >> 3) + (p & 3);
@@ -358,17 +342,12 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
 #ifndef W4_TLAT
 #define W4_TLAT 4                                   // slots between a pair's gathers and their use
 #endif
-  typedef __attribute__((address_space(3))) const unsigned short lds_u16;
-  typedef lds_u16* lds_u16_t;
   unsigned tc[4][16], ta[4][16], tm[4][16];
   unsigned ad0[4][16], ad1[4][16];
   const unsigned tabc = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + TABC);      // LDS address of entry 0
   unsigned tl[4][16], th[4][16];
   auto t_slot = [&](auto jt, auto numt, auto rt, const f32x16w& a0, const f32x16w& a1, auto dst) {
     constexpr int J = decltype(jt)::value, NUM = decltype(numt)::value, r = decltype(rt)::value;
-    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-    typedef short ss2 __attribute__((ext_vector_type(2)));
-    constexpr unsigned klo = (unsigned)TLO * 0x10001u, kmax = (unsigned)(TN > 0 ? TN - 1 : 0) * 0x10001u;
     w4_for<16>([&](auto kc) {
       constexpr int k = decltype(kc)::value, st = k * NUM / 4;
       // (stage boundaries keep a packed 16-bit result and its reader in different slots: gfx950 needs a wait state between such a pair, hipcc
@@ -378,20 +357,15 @@ __global__ __launch_bounds__(256, 1) void stage1_w4_kernel(const bf16* __restric
         tc[J][k] = w4_pk2(a[2 * (k & 7)], a[2 * (k & 7) + 1]);
         asm("" : "+v"(tc[J][k]));                            // (opaque: otherwise the sign shift below converts the two floats again)
       }
-      if constexpr (r == st + 1)
-        ta[J][k] = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, tc[J][k] & 0x7fff7fffu), __builtin_bit_cast(us2, klo)));
+      if constexpr (r == st + 1) ta[J][k] = gelu_tab::rebase(tc[J][k]);
       if constexpr (r == st + 2) {
-        tm[J][k] = __builtin_bit_cast(unsigned, __builtin_bit_cast(ss2, tc[J][k]) >> 15);
-        ta[J][k] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2, ta[J][k]), __builtin_bit_cast(us2, kmax)));
+        tm[J][k] = gelu_tab::sign_mask(tc[J][k]);
+        ta[J][k] = gelu_tab::clamp_top(ta[J][k]);
       }
-      if constexpr (r == st + 3) {
-        ta[J][k] ^= tm[J][k];
-        asm("v_mad_i32_i16 %0, %1, 2, %2" : "=v"(ad0[J][k]) : "v"(ta[J][k]), "s"(tabc));
-        asm("v_mad_i32_i16 %0, %1, 2, %2 op_sel:[1,0,0,0]" : "=v"(ad1[J][k]) : "v"(ta[J][k]), "s"(tabc));
-      }
-      if constexpr (r == st + 4) {                           // (LDS pointers formed from the integer address: `smem + offset` costs a v_add of the base per load)
-        tl[J][k] = *(lds_u16_t)(size_t)ad0[J][k];
-        th[J][k] = *(lds_u16_t)(size_t)ad1[J][k];
+      if constexpr (r == st + 3) gelu_tab::addresses(ta[J][k] ^ tm[J][k], tabc, ad0[J][k], ad1[J][k]);
+      if constexpr (r == st + 4) {
+        tl[J][k] = gelu_tab::gather(ad0[J][k]);
+        th[J][k] = gelu_tab::gather(ad1[J][k]);
       }
       if constexpr (r == st + 4 + W4_TLAT) {
         gp[J][k] = tl[J][k] | (th[J][k] << 16);

@@ -49,14 +49,14 @@ def gelu_sig(x: torch.Tensor) -> torch.Tensor:
     return x / (1.0 + torch.exp2(x * p))
 
 
-S1_GELU_TABLE = True     # round 6: the bf16 stage-1 kernel (csrc/stage1_w4.hip) evaluates its GELUs as a table look-up on the bf16-ROUNDED pre-activation
+S1_GELU_TABLE = True     # round 6: the bf16 kernels with GELU micro-stages (csrc/stage1_w4.hip, csrc/mlp_rows.hip) evaluate them as a table look-up on the bf16-ROUNDED pre-activation
 
 
-def gelu_s1(x: torch.Tensor) -> torch.Tensor:
-    """The GELU of the stage-1 block as the engine computes it.  bf16 storage (csrc/stage1_w4.hip, TABLE): the pre-activation is rounded to bf16,
-    its magnitude clamped to the table's range [2^-10, 32) and the exact erf form (visformer.py:152-163's nn.GELU) looked up; fp16 storage (and
-    the image sizes that run stage1_ring.hip) keep gelu_sig on the fp32 pre-activation."""
-    if not S1_GELU_TABLE or STORAGE != torch.bfloat16 or 'act_s1' in SKIP:
+def gelu_s1(x: torch.Tensor, site: str = 'act_s1') -> torch.Tensor:
+    """The GELU of the stage-1 block and of the stage-2 / 3 Mlps as the engine computes it.  bf16 storage (csrc/fsvit_common.h gelu_tab: stage1_w4.hip,
+    mlp_rows.hip): the pre-activation is rounded to bf16, its magnitude clamped to the table's range [2^-10, 32) and the exact erf form
+    (visformer.py:146-163's nn.GELU) looked up; fp16 storage (and the geometries that run the general kernels) keep gelu_sig on the fp32 pre-activation."""
+    if not S1_GELU_TABLE or STORAGE != torch.bfloat16 or site in SKIP:
         return gelu_sig(x)
     xb = x.to(torch.bfloat16).to(torch.float32)
     a = xb.abs().clamp(min=2.0 ** -10, max=32.0 * (1.0 - 2.0 ** -8))
@@ -274,7 +274,7 @@ def visformer_forward_emul(sd: Dict[str, torch.Tensor], x: torch.Tensor, cfg: Vi
             x1op, x1full = st.store(x1)
             wf, bfc = _fold_pre(sd[p + 'mlp.conv1.weight'], sd, p + 'norm2.bn', eps)
             bfc = bfc + _corr(means, p + 'mlp.conv1', x1op, wf, 'w_mlp') + wf[:, :, 0, 0] @ cst
-            hid = bf(gelu_sig(F.conv2d(x1op, _w(wf, 'w_mlp')) + _b(bfc)), 'act_mlp')
+            hid = bf(gelu_s1(F.conv2d(x1op, _w(wf, 'w_mlp')) + _b(bfc), 'act_mlp'), 'act_mlp')
             cst = cst + _corr(means, p + 'mlp.conv3', hid, sd[p + 'mlp.conv3.weight'], 'w_mlp')
             y = x1full + F.conv2d(hid, bf(sd[p + 'mlp.conv3.weight'], 'w_mlp'))
             xop, xfull = st.store(y)

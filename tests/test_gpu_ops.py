@@ -440,7 +440,7 @@ def test_mlp_rows_fused_matches_unfused_math(M, C):
     b1 = torch.randn(HID, generator=g) * 0.3
     w2 = q(torch.randn(C, HID, generator=g) / math.sqrt(HID), bf)
     b2 = torch.randn(C, generator=g) * 0.3
-    hdn = q(F.gelu(x @ w1.t() + b1), bf)
+    hdn = q(F.gelu(q(x @ w1.t() + b1, bf)), bf)        # (round 6: mlp_rows looks its GELU up by the bf16-rounded pre-activation - one more rounding point)
     xd, w1d, w2d = x.to('cuda', bf), w1.to('cuda', bf), w2.to('cuda', bf)
     for use_b2 in (False, True):
         ref = x + hdn @ w2.t() + (b2 if use_b2 else 0.0)
@@ -476,7 +476,7 @@ def test_proj_mlp_rows_fused_matches_unfused_math(M, C, KC):
     b1 = torch.randn(HID, generator=g) * 0.3
     w2 = q(torch.randn(C, HID, generator=g) / math.sqrt(HID), bf)
     x1 = q(x + ctx @ wp.t(), bf)
-    ref = x1 + q(F.gelu(x1 @ w1.t() + b1), bf) @ w2.t()
+    ref = x1 + q(F.gelu(q(x1 @ w1.t() + b1, bf)), bf) @ w2.t()
     args = [t.to('cuda', bf) for t in (x, ctx, wp, w1)] + [b1.cuda(), w2.to('cuda', bf)]
     y0 = ops.proj_mlp_rows(*args)
     torch.cuda.synchronize()
@@ -507,7 +507,7 @@ def test_vit_block_tail_matches_unfused_math(M):
     b2 = torch.randn(C, generator=g) * 0.3
     x1 = q(x + ctx @ wp.t() + bp, bf)
     xn = q(F.layer_norm(x1, (C,), eps=eps), bf)
-    ref = x1 + q(F.gelu(xn @ w1.t() + b1), bf) @ w2.t() + b2
+    ref = x1 + q(F.gelu(q(xn @ w1.t() + b1, bf)), bf) @ w2.t() + b2
     args = [x.to('cuda', bf), ctx.to('cuda', bf), wp.to('cuda', bf), bp.cuda(), w1.to('cuda', bf), b1.cuda(), w2.to('cuda', bf), b2.cuda()]
     y0 = ops.vit_block_tail(*args, eps=eps)
     torch.cuda.synchronize()

@@ -19,3 +19,12 @@ bias = torch.randn(3 * heads * hdp, device='cuda') * 0.3
 for _ in range(8):
     ops.qkv_attention(x, w, bias, B, S, heads, hdp, hd ** -0.5)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    ops.qkv_attention(x, w, bias, B, S, heads, hdp, hd ** -0.5)
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 100.0
+flop = B * (2.0 * S * C * 3 * heads * hd + 4.0 * S * S * hd * heads)
+print('qkv_attn %d images: %.1f us per launch, %.1f algorithmic TFLOP/s%s' % (B, us, flop / us / 1e6, (' (' + os.path.basename(sys.argv[2]) + ')') if len(sys.argv) > 2 else ''))
