@@ -152,6 +152,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvGemmPara
     const unsigned d = lds0 + OFF_W + stage * STAGE;
     hdma2s(offB[0], offB[1], Wb + (size_t)wk * 128, d + (2 * wave) * 1024, d + (2 * wave + 1) * 1024);
   };
+  // source of (halo row hr, halo column hc) of this wave's chunk plane = base + hr * x_rs + (hc - 1) * x_ps bytes: NHWC (pixel = CIN * 2 bytes, the wave's
+  // chunk 16 bytes into the half) or row-chunk-planar (conv_gemm.h x_planar: a row of one chunk = W * 16 contiguous bytes)
+  const int x_rs = p.x_planar ? (CIN / 8) * p.W * 16 : p.W * CIN * 2, x_ps = p.x_planar ? 16 : CIN * 2;
   // one piece of the halo tile whose pixel (row r0 - 1, column 0, first channel of the half) is at `base` into buffer nb; base == nullptr:
   // nothing to fetch (zero page) - the piece is still issued so that the counted waits below see the same number of operations in
   // flight on every path.  top / bot: the tile touches the upper / lower image border (halo row 0 / 9 is zero padding).
@@ -160,13 +163,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvGemmPara
     // branch-free (bitwise & / one select): an exec-masked branch here is a scheduling boundary that keeps the whole address computation
     // in front of the MFMA block instead of between its MFMAs
     const bool ok = (base != nullptr) & (s < HR * HP) & (hc >= 1) & (hc <= TW) & !(top & (hr == 0)) & !(bot & (hr == HR - 1));
-    const unsigned long a = (unsigned long)base + (unsigned long)(unsigned)(((hr * p.W + hc - 1) * CIN + wave * 8) * 2);
+    const unsigned long a = (unsigned long)base + (unsigned long)(unsigned)(hr * x_rs + (hc - 1) * x_ps);
     const unsigned long z = (unsigned long)g_zero_page_halo;
     hdma1(reinterpret_cast<const void*>(ok ? a : z), lds0 + nb * HBUF + wave * PLANE + j * 1024);
   };
   auto halo_base = [&](int tile, int h) {
     const int bb = tile / tiles_per_img, rr = (tile - bb * tiles_per_img) * TR;
-    return Xb + ((long)(bb * p.H + rr - 1) * p.W) * (CIN * 2) + h * 128;
+    return Xb + (long)(bb * p.H + rr - 1) * x_rs + (p.x_planar ? (h * 8 + wave) * p.W * 16 : h * 128 + wave * 16);
   };
 
   f32x4 acc[MT][NT];
@@ -406,7 +409,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvGemmPara
             }
             if (!FUSE_TAIL || (lrow_e & 3) == 0) {
               const bf16x8 o = {(bf16)v[0][0], (bf16)v[0][1], (bf16)v[0][2], (bf16)v[0][3], (bf16)v[1][0], (bf16)v[1][1], (bf16)v[1][2], (bf16)v[1][3]};
-              *reinterpret_cast<bf16x8*>(Y + orow * p.y_cstride + n) = o;
+              if (!FUSE_TAIL && p.y_planar) *reinterpret_cast<bf16x8*>(Y + (((size_t)(b * p.H + r0 + prow_i) * (p.y_cstride >> 3) + (n >> 3)) * p.W + pcol_i) * 8) = o;
+              else *reinterpret_cast<bf16x8*>(Y + orow * p.y_cstride + n) = o;
             }
           }
         }
@@ -490,6 +494,7 @@ bool conv3x3_halo_eligible(const ConvGemmParams& p, int dtype) {
   if (p.res || p.y2 || p.act == ACT_MUL || p.y_rpi || p.out_f32 || p.w_rstride || p.w_gstride) return false;
   if (p.Cin != p.x_cstride || p.K != 9 * p.Cin) return false;
   if (p.stats && (p.pool2 || p.act != ACT_NONE)) return false;
+  if (p.y_planar && (p.pool2 || p.stats)) return false;      // the planar output exists for the plain epilogue only (conv2 -> conv3 inside the eval stem)
   if (p.pool2) return p.Cin == 128 && p.x2 && p.K2 == 32 && p.x2_cstride >= 32 && p.pos && p.Kw == p.K + 64;
   return (p.Cin == 64 || p.Cin == 128) && !p.x2 && !p.pos && p.Kw == p.K;
 }

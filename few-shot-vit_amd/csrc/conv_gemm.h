@@ -67,6 +67,12 @@ struct ConvGemmParams {
   // rows is conv_stats_rows(p, dtype) (0: this layer's kernel does not produce them); bn_fwd_finalize sums them - the separate reduce pass
   // over the stored map is gone.  conv3x3_halo only so far.
   float* stats;
+  // Round 6, conv3x3_halo only (the eval engine's stem): x_planar / y_planar != 0 -> that operand is ROW-CHUNK-PLANAR instead of NHWC: element (b, row, col, c)
+  // at ((b * H + row) * (C / 8) + c / 8) * W * 8 + col * 8 + c % 8 - a 16-byte chunk of 8 channels is contiguous along a ROW.  The halo tile's LDS image is
+  // chunk-planar, and an LDS-DMA piece writes 64 consecutive slots of ONE chunk plane: from NHWC that is 64 lanes on 64 different 128-byte lines (16 bytes
+  // of each: 20 % of the kernel's time went into the halo fetch, tools/probes/variants/conv3x3_halo.diag.patch -DH_NO_HDMA); from this layout the lanes of
+  // a piece read row segments of 640 contiguous bytes.  Same size as NHWC; only stem_conv1 / conv3x3_halo produce and consume it.
+  int x_planar = 0, y_planar = 0;
 };
 
 }  // namespace fsvit_types

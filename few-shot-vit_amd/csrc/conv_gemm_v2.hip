@@ -552,6 +552,7 @@ int conv_stats_rows(const ConvGemmParams& p, int dtype) {
 
 int launch_conv_gemm(const ConvGemmParams& p, int dtype, hipStream_t stream) {
   if (conv3x3_halo_eligible(p, dtype)) return launch_conv3x3_halo(p, stream);
+  if (p.x_planar || p.y_planar) return (int)hipErrorInvalidValue;      // only conv3x3_halo reads / writes the row-chunk-planar layout
   if (gconv3x3_x2_eligible(p, dtype)) return launch_gconv3x3_x2(p, stream);
   if (gemm256_eligible(p, dtype)) return run_gemm256(p, dtype, stream);
   // A plain 1x1 layer whose activation matrix is past gemm256's 32-bit DMA offsets (a 12 800-image ViT chunk: 2.5 M rows x 1536 columns)

@@ -736,6 +736,12 @@ int timed(EngineBase* h, hipStream_t st, const char* layer, int kernel, double f
   return 0;
 }
 
+// images per slice of the dedicated stem (forward_chunk); FSVIT_STEM_SLICE overrides (tuning knob)
+static int stem_slice_images() {
+  static const int n = [] { const char* e = getenv("FSVIT_STEM_SLICE"); const int v = e ? atoi(e) : 3200; return v > 0 ? v : 3200; }();
+  return n;
+}
+
 int run_gemm(EngineBase* h, hipStream_t st, const char* layer, const Layer& L, const ConvGemmParams& p, double n_true, double k_true) {
   const int kdt = h->dtype;
   const double flops = 2.0 * (double)p.M * n_true * k_true * (double)p.groups;     // algorithmic: unpadded N and K
@@ -762,32 +768,64 @@ int forward_chunk(fsvit_visformer* h, const float* x, int Bc, float* feat, unsig
   h->prof_last = nullptr;
   if (!xsrc2) B1 = Bc;
   constexpr bool stem_fused_on = true;
-  if (stem_fused_on && K(stem_conv1_supported)(dt, img, h->C0)) {      // im2col + conv1 + bn1 + LeakyReLU in one pass over the image
+  // Round 6: when the whole stem runs on its dedicated kernels (stem_conv1 -> conv3x3_halo -> conv3x3_halo + tail) the two intermediate maps c1 / c2 are
+  // stored row-chunk-planar (conv_gemm.h x_planar): the halo fetch of the consumer then reads row segments instead of 16 bytes of every 128-byte line
+  ConvGemmParams p2 = conv_params(h->conv2, c1, c2, Bc, h->H0, h->H0, h->C0, h->C0, 3, 3, 1, 1, h->C1, ACT_LRELU, nullptr, 0, nullptr);
+  ConvGemmParams p3 = conv_params(h->conv3f, c2, x1, Bc, h->H0, h->H0, h->C1, h->C1, 3, 3, 1, 1, h->C1, ACT_LRELU, nullptr, 0, h->pos1);
+  p3.x2 = patches; p3.x2_cstride = 32; p3.K2 = 32; p3.pool2 = 1;
+  const bool planar = stem_fused_on && K(stem_conv1_supported)(dt, img, h->C0) && K(conv_gemm_route)(p2, kg(kdt)) == 0 && K(conv_gemm_route)(p3, kg(kdt)) == 0;
+  p2.x_planar = p2.y_planar = p3.x_planar = planar ? 1 : 0;
+  if (planar) {
+    // The dedicated stem runs in SLICES of the chunk (stem_conv1 -> conv2 -> conv3 + tail per slice of STEM_SLICE images): the two halo convs take
+    // ~10 % less per image at 1600 ... 3200-image launches than at 12 800 (measured per launch size, profiles/r06_*; their halo fetch is bound by HBM
+    // latency, and a slice's maps are produced and consumed within a few ms), while every later kernel wants the whole chunk.
+    const int S = stem_slice_images();
+    const size_t s_pat = (size_t)h->H0 * h->H0 * 32 * es, s_c1 = (size_t)h->H0 * h->H0 * h->C0 * es, s_c2 = (size_t)h->H0 * h->H0 * h->C1 * es,
+                 s_x1 = (size_t)h->H1 * h->H1 * h->C1 * es, s_img = (size_t)3 * img * img * sizeof(float);
     const double fl1 = 2.0 * 27.0 * h->C0 * h->H0 * h->H0;
-    RC_TRY(timed(h, st, "stem.im2col+conv1", KID_STEMCONV1, fl1 * B1, [&]() {
-      return K(launch_stem_conv1)(x, patches, c1, h->conv1.w, h->conv1.Kw, h->conv1.bias, B1, st); }));
-    if (Bc > B1)
-      RC_TRY(timed(h, st, "stem.im2col+conv1", KID_STEMCONV1, fl1 * (Bc - B1), [&]() {
-        return K(launch_stem_conv1)(xsrc2, (unsigned char*)patches + (size_t)B1 * h->H0 * h->H0 * 32 * es, (unsigned char*)c1 + (size_t)B1 * h->H0 * h->H0 * h->C0 * es,
-                                 h->conv1.w, h->conv1.Kw, h->conv1.bias, Bc - B1, st); }));
+    for (int g0 = 0; g0 < Bc; g0 += S) {
+      const int g1 = g0 + S < Bc ? g0 + S : Bc;
+      for (int part = 0; part < 2; ++part) {               // images [g0, g1) of cat([shot, query]): [0, B1) from x, [B1, Bc) from xsrc2
+        const int a = part == 0 ? g0 : (g0 > B1 ? g0 : B1), b = part == 0 ? (g1 < B1 ? g1 : B1) : g1;
+        if (a >= b) continue;
+        const float* src = part == 0 ? x + (size_t)a * 3 * img * img : xsrc2 + (size_t)(a - B1) * 3 * img * img;
+        (void)s_img;
+        RC_TRY(timed(h, st, "stem.im2col+conv1", KID_STEMCONV1, fl1 * (b - a), [&]() {
+          return K(launch_stem_conv1)(src, (unsigned char*)patches + a * s_pat, (unsigned char*)c1 + a * s_c1, h->conv1.w, h->conv1.Kw, h->conv1.bias, b - a, st, 1); }));
+      }
+      ConvGemmParams q2 = p2, q3 = p3;
+      q2.x = (const unsigned char*)c1 + g0 * s_c1; q2.y = (unsigned char*)c2 + g0 * s_c2; q2.B = g1 - g0; q2.M = (g1 - g0) * q2.OH * q2.OW;
+      q3.x = (const unsigned char*)c2 + g0 * s_c2; q3.x2 = (const unsigned char*)patches + g0 * s_pat; q3.y = (unsigned char*)x1 + g0 * s_x1;
+      q3.B = g1 - g0; q3.M = (g1 - g0) * q3.OH * q3.OW;
+      RC_TRY(run_gemm(h, st, "stem.conv2", h->conv2, q2, h->C1, 9.0 * h->C0));
+      RC_TRY(run_gemm(h, st, "stem.conv3+down+pool", h->conv3f, q3, h->C1, 9.0 * h->C1 + 27.0));
+    }
   } else {
-    RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() { return K(launch_im2col27)(x, patches, B1, img, img, h->H0, h->H0, dt, st); }));
-    if (Bc > B1)
-      RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() {
-        return K(launch_im2col27)(xsrc2, (unsigned char*)patches + (size_t)B1 * h->H0 * h->H0 * 32 * es, Bc - B1, img, img, h->H0, h->H0, dt, st); }));
-    RC_TRY(run_gemm(h, st, "stem.conv1", h->conv1, conv_params(h->conv1, patches, c1, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C0, ACT_LRELU, nullptr, 0, nullptr), h->C0, 27));
-  }
-  RC_TRY(run_gemm(h, st, "stem.conv2", h->conv2, conv_params(h->conv2, c1, c2, Bc, h->H0, h->H0, h->C0, h->C0, 3, 3, 1, 1, h->C1, ACT_LRELU, nullptr, 0, nullptr), h->C1, 9.0 * h->C0));
-  constexpr bool split_stem = false;
-  if (!split_stem) {
-    // conv3 + bn3 + (downsample conv + bn_d as a tail K slice over the im2col rows) + LeakyReLU + MaxPool2d(2) + pos_embed1
-    ConvGemmParams p3 = conv_params(h->conv3f, c2, x1, Bc, h->H0, h->H0, h->C1, h->C1, 3, 3, 1, 1, h->C1, ACT_LRELU, nullptr, 0, h->pos1);
-    p3.x2 = patches; p3.x2_cstride = 32; p3.K2 = 32; p3.pool2 = 1;
-    RC_TRY(run_gemm(h, st, "stem.conv3+down+pool", h->conv3f, p3, h->C1, 9.0 * h->C1 + 27.0));
-  } else {
-    RC_TRY(run_gemm(h, st, "stem.downsample", h->down, conv_params(h->down, patches, ident, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C1, ACT_NONE, nullptr, 0, nullptr), h->C1, 27));
-    RC_TRY(run_gemm(h, st, "stem.conv3", h->conv3, conv_params(h->conv3, c2, c3, Bc, h->H0, h->H0, h->C1, h->C1, 3, 3, 1, 1, h->C1, ACT_LRELU, ident, 1, nullptr), h->C1, 9.0 * h->C1));
-    RC_TRY(timed(h, st, "stem.maxpool", KID_MAXPOOL, 0.0, [&]() { return K(launch_maxpool2_pos)(c3, h->pos1, x1, Bc, h->H1, h->H1, h->C1, dt, st); }));
+  if (stem_fused_on && K(stem_conv1_supported)(dt, img, h->C0)) {      // im2col + conv1 + bn1 + LeakyReLU in one pass over the image
+      const double fl1 = 2.0 * 27.0 * h->C0 * h->H0 * h->H0;
+      RC_TRY(timed(h, st, "stem.im2col+conv1", KID_STEMCONV1, fl1 * B1, [&]() {
+        return K(launch_stem_conv1)(x, patches, c1, h->conv1.w, h->conv1.Kw, h->conv1.bias, B1, st, planar); }));
+      if (Bc > B1)
+        RC_TRY(timed(h, st, "stem.im2col+conv1", KID_STEMCONV1, fl1 * (Bc - B1), [&]() {
+          return K(launch_stem_conv1)(xsrc2, (unsigned char*)patches + (size_t)B1 * h->H0 * h->H0 * 32 * es, (unsigned char*)c1 + (size_t)B1 * h->H0 * h->H0 * h->C0 * es,
+                                   h->conv1.w, h->conv1.Kw, h->conv1.bias, Bc - B1, st, planar); }));
+    } else {
+      RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() { return K(launch_im2col27)(x, patches, B1, img, img, h->H0, h->H0, dt, st); }));
+      if (Bc > B1)
+        RC_TRY(timed(h, st, "stem.im2col", KID_IM2COL, 0.0, [&]() {
+          return K(launch_im2col27)(xsrc2, (unsigned char*)patches + (size_t)B1 * h->H0 * h->H0 * 32 * es, Bc - B1, img, img, h->H0, h->H0, dt, st); }));
+      RC_TRY(run_gemm(h, st, "stem.conv1", h->conv1, conv_params(h->conv1, patches, c1, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C0, ACT_LRELU, nullptr, 0, nullptr), h->C0, 27));
+    }
+    RC_TRY(run_gemm(h, st, "stem.conv2", h->conv2, p2, h->C1, 9.0 * h->C0));
+    constexpr bool split_stem = false;
+    if (!split_stem) {
+      // conv3 + bn3 + (downsample conv + bn_d as a tail K slice over the im2col rows) + LeakyReLU + MaxPool2d(2) + pos_embed1
+      RC_TRY(run_gemm(h, st, "stem.conv3+down+pool", h->conv3f, p3, h->C1, 9.0 * h->C1 + 27.0));
+    } else {
+      RC_TRY(run_gemm(h, st, "stem.downsample", h->down, conv_params(h->down, patches, ident, Bc, h->H0, h->H0, 32, 32, 1, 1, 1, 0, h->C1, ACT_NONE, nullptr, 0, nullptr), h->C1, 27));
+      RC_TRY(run_gemm(h, st, "stem.conv3", h->conv3, conv_params(h->conv3, c2, c3, Bc, h->H0, h->H0, h->C1, h->C1, 3, 3, 1, 1, h->C1, ACT_LRELU, ident, 1, nullptr), h->C1, 9.0 * h->C1));
+      RC_TRY(timed(h, st, "stem.maxpool", KID_MAXPOOL, 0.0, [&]() { return K(launch_maxpool2_pos)(c3, h->pos1, x1, Bc, h->H1, h->H1, h->C1, dt, st); }));
+    }
   }
   RC_TRY(tap(h, "stem", x1, (size_t)Bc * h->H1 * h->H1 * h->C1 * es, first, st));
 
@@ -1301,7 +1339,7 @@ extern "C" int fsvit_stem_conv1(const float* x, const void* w, int kw, const flo
   const int kdt = FSVIT_BF16;
   if (!x || !w || !patches || !c1 || kw < 32) return fail(FSVIT_ERR_ARG, "bad argument");
   if (H != W || !K(stem_conv1_supported)(1, H, 64)) return fail(FSVIT_ERR_ARG, "fsvit_stem_conv1: only 80x80 images, 64 output channels (bf16) are built");
-  RC_TRY(K(launch_stem_conv1)(x, patches, c1, w, kw, bias, B, (hipStream_t)stream));
+  RC_TRY(K(launch_stem_conv1)(x, patches, c1, w, kw, bias, B, (hipStream_t)stream, 0));
   return 0;
 }
 

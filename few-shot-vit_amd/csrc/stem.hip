@@ -77,8 +77,9 @@ constexpr int PLANE = IR * ICP;                             // elements per chan
 constexpr int NW = 4;
 }  // namespace stem1
 
+// c1_planar: c1 is stored row-chunk-planar ([b][row][8 chunks][40 columns][8 channels], conv_gemm.h x_planar) for conv3x3_halo's halo fetch
 __global__ __launch_bounds__(stem1::NW * 64) void stem_conv1_kernel(const float* __restrict__ x, bf16* __restrict__ patches, bf16* __restrict__ c1,
-                                                                    const bf16* __restrict__ w, const int kw, const float* __restrict__ bias) {
+                                                                    const bf16* __restrict__ w, const int kw, const float* __restrict__ bias, const int c1_planar) {
   using namespace stem1;
   __shared__ __attribute__((aligned(16))) bf16 tile[3 * PLANE];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -136,16 +137,17 @@ __global__ __launch_bounds__(stem1::NW * 64) void stem_conv1_kernel(const float*
         o[q] = (bf16)fmaxf(a0[q], 0.1f * a0[q]);
         o[4 + q] = (bf16)fmaxf(a1[q], 0.1f * a1[q]);
       }
-      *reinterpret_cast<bf16x8*>(c1 + (prow0 + pix) * 64 + 32 * p + 8 * lq) = o;
+      if (c1_planar) *reinterpret_cast<bf16x8*>(c1 + ((((size_t)b * OH + oy0 + oy) * 8 + 4 * p + lq) * OH + ox) * 8) = o;      // 16 lanes = 256 contiguous bytes
+      else *reinterpret_cast<bf16x8*>(c1 + (prow0 + pix) * 64 + 32 * p + 8 * lq) = o;
     }
   }
 }
 
 bool stem_conv1_supported(int dtype, int img, int C0) { return dtype == 1 && img == stem1::IMG && C0 == 64; }
 
-int launch_stem_conv1(const float* x, void* patches, void* c1, const void* w, int kw, const float* bias, int B, hipStream_t s) {
+int launch_stem_conv1(const float* x, void* patches, void* c1, const void* w, int kw, const float* bias, int B, hipStream_t s, int c1_planar) {
   if (B <= 0) return 0;
-  hipLaunchKernelGGL(stem_conv1_kernel, dim3(B * (stem1::OH / stem1::ROWS)), dim3(stem1::NW * 64), 0, s, x, (bf16*)patches, (bf16*)c1, (const bf16*)w, kw, bias);
+  hipLaunchKernelGGL(stem_conv1_kernel, dim3(B * (stem1::OH / stem1::ROWS)), dim3(stem1::NW * 64), 0, s, x, (bf16*)patches, (bf16*)c1, (const bf16*)w, kw, bias, c1_planar);
   return (int)hipGetLastError();
 }
 
