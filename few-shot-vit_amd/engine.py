@@ -44,7 +44,7 @@ def weights_fingerprint(module) -> tuple:
 
 
 def default_numerics() -> str:
-    """'bf16' (throughput mode) unless FSVIT_NUMERICS selects another one: 'f16' (fp16 storage + MFMA: same kernels and rate, 8 x smaller
+    """'bf16' (throughput mode) unless FSVIT_NUMERICS selects another one: 'f16' (fp16 storage + MFMA: same kernels, 0.93 x the rate, 7 x smaller
     logit deviation than bf16, eval only), 'bf16x2' / 'f16x2' (fp32 storage, every GEMM on the 16-bit MFMA with two-limb operands: meets the
     1e-3 logit tolerance at several times the fp32-MFMA rate; 'bf16x2' also trains, 'f16x2' is eval only) or 'parity' / 'f32' (exact-fp32 MFMA)."""
     return os.environ.get('FSVIT_NUMERICS', 'bf16')
@@ -54,9 +54,9 @@ def default_numerics() -> str:
 # against the reference goldens, bench.py `modes` / `agreement` re-measure the agreement on 2048 episodes): max |dlogit| on the golden 5-shot
 # episode, arg-max agreement with `parity` on the bench episodes, throughput relative to bf16.
 NUMERICS_NOTE = {
-    'bf16': 'bf16 storage + MFMA: logits within ~5e-2 of the reference (golden 5-shot 4.2e-2), 98.9 % arg-max agreement; the throughput mode - NOT the '
-            '1e-3-grade mode: FSVIT_NUMERICS=f16 (same rate, 8 x tighter), bf16x2 (1e-3-grade, 0.24 x) or parity (exact fp32, 0.12 x)',
-    'f16': 'fp16 storage + MFMA: logits within ~8e-3 of the reference (golden 5-shot 7.2e-3), 99.85 % arg-max agreement, same rate as bf16; eval only',
+    'bf16': 'bf16 storage + MFMA: logits within ~5e-2 of the reference (golden 5-shot 4.9e-2, 1-shot 5.0e-2), 98.8 % arg-max agreement; the throughput mode - NOT the '
+            '1e-3-grade mode: FSVIT_NUMERICS=f16 (0.93 x the rate, 7 x tighter), bf16x2 (1e-3-grade, 0.23 x) or parity (exact fp32, 0.11 x)',
+    'f16': 'fp16 storage + MFMA: logits within ~8e-3 of the reference (golden 5-shot 7.2e-3), 99.85 % arg-max agreement, 0.93 x the bf16 rate (its GELUs stay on the VALU); eval only',
     'bf16x2': 'fp32 storage, two-limb bf16 MFMA: logits within 1.5e-4 of the reference (meets the 1e-3 tolerance), 0.24 x the bf16 rate; also trains',
     'f16x2': 'fp32 storage, two-limb fp16 MFMA: logits within 2.2e-5 of the reference (meets the 1e-3 tolerance), 0.24 x the bf16 rate; eval only',
     'parity': 'exact-fp32 MFMA: logits within 1e-3 of the reference (the parity mode), 0.12 x the bf16 rate',

@@ -161,8 +161,8 @@ def main():
     parser.add_argument('--ep-per-batch', type=int, default=1)
     parser.add_argument('--launch-batches', type=int, default=None, help='reference batches per engine launch (default: one encoder chunk, 12 800 images = 128 five-shot episodes)')
     parser.add_argument('--numerics', default=None, choices=[None, 'bf16', 'f16', 'bf16x2', 'f16x2', 'parity'],
-                        help="default: FSVIT_NUMERICS or 'bf16' (throughput mode: logits within ~5e-2 of the reference's, 98.9 %% arg-max agreement). "
-                             "'f16' runs at the SAME rate with 8 x tighter logits (~8e-3, 99.85 %%) when the checkpoint's weights fit the fp16 range; "
+                        help="default: FSVIT_NUMERICS or 'bf16' (throughput mode: logits within ~5e-2 of the reference's, 98.8 %% arg-max agreement). "
+                             "'f16' runs at 0.93 x the rate with 7 x tighter logits (~8e-3, 99.85 %%) when the checkpoint's weights fit the fp16 range; "
                              "'bf16x2' / 'f16x2' meet the reference's logits within 1e-3 at 0.24 x the rate; 'parity' = exact fp32 (0.12 x)")
     args = parser.parse_args()
     config = yaml.load(open(args.config, 'r'), Loader=yaml.FullLoader)

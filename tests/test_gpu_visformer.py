@@ -14,14 +14,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 LOGIT_TOL_PARITY = 1e-3        # BASELINE.json north_star
-# bf16 throughput mode against the fp32 reference golden: 1.5 x the measured 4.2e-2 (5-shot) / 5.7e-2 (1-shot) of round 4.  Rounds 1-3 measured
+# bf16 throughput mode against the fp32 reference golden: 1.5 x the measured 4.9e-2 (5-shot) / 5.0e-2 (1-shot) of round 6 (table GELU on the bf16-rounded
+# pre-activation in stage1_w4 / mlp_rows; round 4: 4.2e-2 / 5.7e-2 with gelu_sig on the fp32 one).  Rounds 1-3 measured
 # 9.0e-2 .. 1.07e-1: the bf16 rounding of the (BN-folded) WEIGHTS - a fixed perturbation of the model that does not average out over tokens
 # (ablation on the rounding-point emulator: DESIGN.md 2, tools/emul_ablation.py).  Its MEAN effect is now folded into the fp32 biases at pack
 # time from the checkpoint's own BatchNorm statistics (engine.hip `WRound`); what is left is the per-image part and the activation rounding.
-LOGIT_TOL_BF16 = 0.086
+LOGIT_TOL_BF16 = 0.076
 # ... and against the oracle that rounds where the kernels round (oracle/visformer_emul.py): only accumulation order and the
 # softmax / GELU instruction sequences differ - one-ulp flips of stored bf16 activations (2^-8 relative) that then propagate.
-# 1.5 x the measured 3.1e-2 / 3.5e-2 (logits, mean 7e-3) and 1.2e-2 (taps, relative to the tap's max).
+# 1.5 x the measured 3.1e-2 / 3.5e-2 (logits, mean 7e-3; round 6: 3.5e-2 / 4.0e-2, mean 9e-3 - the same gate holds) and 1.2e-2 (taps, relative to the tap's max).
 LOGIT_TOL_BF16_EMUL = 5.3e-2
 TAP_TOL_BF16_EMUL = 1.8e-2
 
