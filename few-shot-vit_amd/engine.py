@@ -436,7 +436,7 @@ class VitEngine(_EncoderEngine):
     """cfg: dict(img_size, patch_size, embed_dim, depth, num_heads[, mlp_ratio, ln_eps]) (deit.py:142-144)."""
     _fn = dict(create='fsvit_vit_create', destroy='fsvit_vit_destroy', out_dim='fsvit_vit_out_dim',
                workspace_bytes='fsvit_vit_workspace_bytes', forward='fsvit_vit_forward')
-    _default_chunk = 400
+    _default_chunk = 12800      # the benched launch size (round 6: was 400); shrinks to half of the free device memory in workspace()
 
     def _make_cfg(self, cfg):
         c = _lib.VitCfg()
