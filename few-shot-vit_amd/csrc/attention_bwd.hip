@@ -546,7 +546,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_mfma_kernel(const bf16*
                                                                      bf16* __restrict__ dqkv, int S, int heads, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int HDP = NDT * 16, SKP = NKT * 16;
-  constexpr int RS = HDP * 2 + 16;             // row-major row stride (bytes): odd multiple of 16 -> conflict-free b128 reads
+  constexpr int RS = HDP * 2 + 32;             // row-major row stride (bytes): 32 mod 64 - the conflict-free pitch for b128 reads whose 16-lane groups mix rows of two lq (round 6: 244 -> 233 us at the stage-2 shape; an odd multiple of 16 - 144 before - reads 2-way)
   constexpr int NKC = HDP / 32;                // 32-element MFMA chunks along the head dim
   constexpr int CPR = HDP / 8;                 // 16-byte chunks per row
   unsigned char* const Qr = smem;
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(NW * 64) void attention_bwd_mfma_kernel(const bf16*
 template <int NKT, int NDT, int NW>
 static int launch_bwd_mfma(const void* qkv, const void* dctx, void* dqkv, int B, int S, int heads, float scale, hipStream_t s, bool* ran) {
   constexpr int HDP = NDT * 16, SKP = NKT * 16;
-  const size_t lds = (size_t)4 * SKP * (HDP * 2 + 16) + (size_t)3 * SKP * sizeof(float);
+  const size_t lds = (size_t)4 * SKP * (HDP * 2 + 32) + (size_t)3 * SKP * sizeof(float);
   *ran = false;
   if (lds > 160 * 1024) return 0;
   auto kern = attention_bwd_mfma_kernel<NKT, NDT, NW>;

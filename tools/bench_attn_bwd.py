@@ -1,7 +1,11 @@
-"""Times fsvit_attention_backward at the Visformer head shapes of an 800-image training step:  python tools/bench_attn_bwd.py [f32|bf16]"""
+"""Times fsvit_attention_backward at the Visformer head shapes of an 800-image training step:  python tools/bench_attn_bwd.py [f32|bf16] [variant .so]"""
 import sys
 import torch
+import os
 sys.path.insert(0, '.')
+from fewshot_vit_amd import _lib            # noqa: E402
+if len(sys.argv) > 2:                       # a variant library
+    _lib.LIB_PATH = os.path.abspath(sys.argv[2])
 from fewshot_vit_amd.engine import ops      # noqa: E402
 
 dt = torch.float32 if (len(sys.argv) < 2 or sys.argv[1] == 'f32') else torch.bfloat16
