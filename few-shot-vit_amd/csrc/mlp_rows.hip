@@ -1033,6 +1033,7 @@ __global__ __launch_bounds__(256, 2) void qkv_attn_rows_kernel(const bf16* __res
         const float bv = btab[((2 * heads + h) * HDC + c) * 32 + perm];       // D[token][channel]: lane = channel, every accumulator a token
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = bv;
+        asm volatile("s_nop 1" : "+v"(acc));                        // VALU-written accumulator -> MFMA SrcC (tools/check_mfma_hazard.py)
         chunk(yes_t{}, acc);
         u32x4 vp[2];
         pack2(acc, vp);
@@ -1198,6 +1199,7 @@ __global__ __launch_bounds__(512, 1) void vit_attn_rows_kernel(const bf16* __res
         const float bv = btab[((2 * heads + h) * HDC + c) * 32 + perm];       // D[token][channel]: lane = channel, every accumulator a token
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = bv;
+        asm volatile("s_nop 1" : "+v"(acc));                        // VALU-written accumulator -> MFMA SrcC (tools/check_mfma_hazard.py)
         chunk(yes_t{}, acc);
         u32x4 vp[2];
         pack2(acc, vp);
