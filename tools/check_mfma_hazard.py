@@ -5,6 +5,8 @@
     8 for the 4-pass 16x16x32 one (what hipcc itself pads behind a builtin MFMA); an intervening MFMA counts as its passes, s_nop N as N + 1,
     anything else as 1.
    python3 tools/check_mfma_hazard.py build/X.o kernel_name_pattern
+(c) a VALU write to the data registers of a global / buffer store of more than 8 bytes in the very next issue slot (hipcc keeps one instruction between
+    them in its own code; an inline-asm store is not padded, cdna_asm_programming.md 4.1 rows 8 / 9).
 Also prints, per kernel: instructions issued between consecutive MFMAs (histogram) - a single wave per SIMD issues one instruction per 4 cycles."""
 import os
 import re
@@ -67,6 +69,27 @@ for name, ins in body.items():
                     if regs(dst) & reads and states < 2:
                         bad += 1
                         print('HAZARD %s: "%s" -> "%s" with %d wait states' % (name[:40], p, s, states))
+                states += 1
+            if states >= 2:
+                break
+    for i, s in enumerate(ins):                      # (c)
+        w0 = s.split()[0]
+        if not (w0.endswith('store_dwordx4') or w0.endswith('store_dwordx3')) or w0.startswith('ds_') or w0.startswith('scratch_'):
+            continue
+        ops = [o.strip() for o in s.split(None, 1)[1].split(',')]
+        data = regs(ops[1].split(' ')[0]) if w0.startswith('global_') else regs(ops[0].split(' ')[0])
+        states = 0
+        for j in range(i + 1, min(i + 2, len(ins))):
+            q = ins[j]
+            w = q.split()[0]
+            if w.startswith('s_nop'):
+                states += int(q.split()[1]) + 1
+            else:
+                if w.startswith('v_') and not w.startswith('v_cmp') and len(q.split(None, 1)) > 1:
+                    dst = regs([o.strip() for o in q.split(None, 1)[1].split(',')][0])
+                    if dst & data and states < 1:
+                        bad += 1
+                        print('HAZARD(c) %s: "%s" then "%s" after %d wait states' % (name[:40], s, q, states))
                 states += 1
             if states >= 2:
                 break
